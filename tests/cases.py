@@ -1,0 +1,54 @@
+"""Shared case tables for the parity tests (oracle vs goldens, HIP vs oracle)."""
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# (expected file, bam, contig fixture, freq kwargs) -- the reference's own freq tests,
+# reference test/test.sh:116-232 (Test 3,4,5,5a,5b,5c,6,7,8,9,12,16).  `exact` marks configs that
+# cannot tie on (contig,pos), where the raw bytes must match; the rest compare after the same
+# whole-line sort the reference's tests apply (test/test.sh:119-121).
+GOLDEN_CASES = [
+    ("test3.tsv", "example-hifi.bam", "chr22", dict(), True),
+    ("test4.bedmethyl", "example-hifi.bam", "chr22", dict(K=1), True),
+    ("test5.tsv", "example-ont.bam", "chr22", dict(), True),
+    ("test5a.tsv", "example-ont.bam", "chr22", dict(insertions=True), False),
+    ("test5b.tsv", "example-ont.bam", "chr22", dict(c="m[*]"), False),
+    ("test5c.tsv", "hap.bam", "chr1", dict(haplotypes=True), False),
+    ("test6.bedmethyl", "example-ont.bam", "chr22", dict(), True),
+    ("test7.tsv", "example-ont.bam", "chr22", dict(m="0.8"), True),
+    ("test8.tsv", "example-ont.bam", "chr22", dict(c="m,h", m="0.8,0.8"), False),
+    ("test9.tsv", "example-ont.bam", "chr22", dict(c="h"), True),
+    ("test12.tsv", "example-ont.bam", "chr22", dict(c="m,h", m="0.8,0.5"), False),
+    ("test16.tsv", "eb.bam", "chr1", dict(c="e,b", m="0.5"), False),
+]
+
+# known-answer reads, SURVEY.md section 8(c) KAT / KAT2
+KAT_REF = "AACGTTCGACCGGTACGATCGTTAACGCGA"
+KAT_SEQ = "CGTTCGACCGGTACGATCGT"
+
+
+def kat_records():
+    from oracle import pybam
+    return [
+        pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+hm,0,0,0,0,0,0;", [10, 250, 0, 5, 10, 250, 0, 5, 10, 250, 0, 5]),
+        pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+m.,1;", [255]),
+        pybam.make_record(0, 2, 16, KAT_SEQ, "20M", "C+m?,0,0;", [255, 0]),
+        pybam.make_record(0, 2, 0, "CGTTCCGGACGTACGATCGT", "5M2I3M2D10M", "C+m?,0,0,0,0,0,0;", [255] * 6, hp=1),
+    ]
+
+
+def kat2_records():
+    from oracle import pybam
+    s2 = "CGTTCCGGACCGGTACGATC"
+    return [
+        pybam.make_record(0, 2, 0, s2, "5M2I13M", "C+m.,0;", [255]),
+        pybam.make_record(0, 2, 16, s2, "5M2I13M", "C+m.,0;", [255]),
+        pybam.make_record(0, 2, 16, s2, "5M2I13M", "C+m?,0,0,0,0,0,0;", [255] * 6),
+    ]
+
+
+KAT_M = [(2, "+", 3, 2), (6, "+", 3, 2), (10, "+", 2, 0), (15, "+", 3, 2), (16, "-", 1, 0), (19, "+", 3, 1),
+         (20, "-", 1, 1)]
+KAT2_INS = [(2, "+", 1, 1, 0), (3, "-", 2, 1, 0), (6, "+", 1, 0, 0), (6, "+", 1, 0, 1), (6, "-", 1, 1, 2),
+            (7, "-", 2, 1, 0), (9, "+", 1, 0, 0), (10, "+", 1, 0, 0), (11, "-", 2, 1, 0), (12, "-", 2, 1, 0),
+            (15, "+", 1, 0, 0), (16, "-", 2, 2, 0), (19, "+", 1, 0, 0)]
