@@ -1,0 +1,190 @@
+/*
+ * minimod_hip.h -- C ABI of the MI355X (gfx950) `freq` hot path.
+ *
+ * The reference (warp9seq/minimod v0.5.0) has no plugin or FFI layer; the seam this library sits behind is
+ * the three internal calls freq_main() makes per batch plus the reference set-up (all paths under
+ * /root/reference):
+ *
+ *   load_ref + load_ref_contexts + init_core   src/ref.c:46-89,177-229, src/minimod.c:51-137   -> mm_freq_create
+ *   process_db -> work_db -> freq_view_single  src/minimod.c:344-350, src/thread.c:145-158,
+ *                                              src/mod.c:948-1370 (get_aln :776-881, update_freq_map :883-929)
+ *                                                                                             -> mm_freq_submit*
+ *   merge_db -> merge_freq_maps                src/minimod.c:373-386, src/mod.c:743-774        -> (none: counters
+ *                                              are global on the device; mm_freq_wait reports per-read errors)
+ *   output_core -> print_freq_output           src/minimod.c:388-394, src/mod.c:644-728        -> mm_freq_finalize
+ *   destroy_ref / free_core                    src/ref.c:241-259, src/minimod.c:140-161        -> mm_freq_destroy
+ *
+ * Everything is plain C: pointers, sizes, POD structs.  No torch / HIP types appear in signatures (a HIP
+ * stream is passed as void*).  Errors: the reference prints and exit(1)s from inside the hot path
+ * (src/error.h:98-152); here every entry point returns a code and the caller (minimod_amd/csrc/host) prints
+ * the reference's message and exits, so the behaviour at the CLI is the same.
+ */
+#ifndef MINIMOD_HIP_H
+#define MINIMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+#define MM_MAX_MODS 13    /* requested -c entries (2 context bits each + 5 base bits in one 32-bit ref word) */
+#define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
+#define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
+#define MM_MAX_HP_PLANES 8
+
+/* One read of a batch: what load_db keeps of a bam1_t (src/minimod.c:235-333) flattened to offsets into four
+ * pools.  64 bytes.  seq_off/mm_off are 16-byte aligned, cigar_off (in uint32 units) 4-aligned, and every pool
+ * carries >= 64 zero bytes of slack at its end. */
+typedef struct mm_read {
+    uint64_t cigar_off;  /* index into cigar pool (uint32 units)   bam_get_cigar */
+    uint64_t seq_off;    /* byte offset into seq pool (4-bit packed, high nibble first)  bam_get_seq */
+    uint64_t mm_off;     /* byte offset into mm pool (MM:Z text, not NUL-counted)  get_mm_tag_ptr */
+    uint64_t ml_off;     /* byte offset into ml pool (ML:B:C bytes)  get_ml_tag */
+    int32_t tid;         /* core.tid */
+    int32_t pos;         /* core.pos */
+    uint32_t l_qseq;     /* core.l_qseq */
+    uint32_t n_cigar;    /* core.n_cigar */
+    uint32_t mm_len;     /* strlen(MM) */
+    uint32_t ml_len;     /* ML array length (0 when absent / not B:C) */
+    uint16_t flag;       /* core.flag (0x10 = reverse strand) */
+    uint8_t hp;          /* get_hp_tag: (uint8) HP value, 0 when absent */
+    uint8_t rsvd;
+    uint32_t rsvd2;
+} mm_read_t;
+
+/* A -K/-B sized batch (db_t, src/minimod.h:125-156).  Pointers are host pointers for mm_freq_submit and device
+ * pointers for mm_freq_submit_device. */
+typedef struct mm_batch {
+    const mm_read_t *reads;
+    const uint32_t *cigar;
+    const uint8_t *seq;
+    const uint8_t *mm;
+    const uint8_t *ml;
+    const int32_t *order;    /* optional: processing order of the reads (e.g. longest first); NULL = as stored */
+    int32_t n_reads;
+    int32_t rsvd;
+    uint64_t n_cigar_words;  /* pool sizes incl. slack (elements / bytes) */
+    uint64_t n_seq_bytes;
+    uint64_t n_mm_bytes;
+    uint64_t n_ml_bytes;
+    uint32_t max_n_cigar;    /* largest n_cigar / l_qseq in the batch (sizes the spill scratch) */
+    uint32_t max_l_qseq;
+} mm_batch_t;
+
+/* One requested modification (modcodem_t, src/minimod.h:60-64 + the key of modcodes_map).  klass is the
+ * threshold rule of src/mod.c:1180-1191 tabulated by the host in double precision for all 256 ML values:
+ * 0 ambiguous (skipped), 1 called unmodified, 3 called modified. */
+typedef struct mm_mod {
+    char code[MM_CODE_LEN];
+    char context[MM_CODE_LEN];
+    uint8_t klass[256];
+} mm_mod_t;
+
+typedef struct mm_freq_opts {
+    int32_t abi_version;
+    int32_t n_mods;
+    int32_t insertions;      /* opt.insertions */
+    int32_t haplotypes;      /* opt.haplotypes */
+    int32_t device;          /* HIP device ordinal */
+    int32_t n_hp_planes;     /* dense planes for HP 0..n-1 (others go to the sparse side list); 0 = default */
+    int64_t side_capacity;   /* sparse side-list records (16 B each); 0 = default */
+    int32_t n_wild_planes;   /* with -c '*': dense planes for the first n interned codes; 0 = default */
+    int32_t rsvd;
+    mm_mod_t mods[MM_MAX_MODS];
+} mm_freq_opts_t;
+
+/* One BAM-header contig (bam_hdr_t target_name/target_len) with its FASTA sequence (ref_t.forward before
+ * normalisation; NULL when the FASTA lacks the contig -- a read on it then fails like src/mod.c:793). */
+typedef struct mm_contig {
+    const char *name;
+    int64_t length;        /* BAM header target_len */
+    const uint8_t *seq;    /* host pointer, raw FASTA letters, or NULL */
+    int64_t seq_length;    /* FASTA length; must equal `length` (src/mod.c:861) */
+} mm_contig_t;
+
+/* Optional: restrict the dense counter planes to one reference interval per contig (multi-GPU sharding,
+ * SURVEY.md section 8e).  Updates outside [begin, end + halo) of every listed contig go to the side list. */
+typedef struct mm_interval {
+    int32_t tid;
+    int32_t rsvd;
+    int64_t begin, end;    /* owned interval [begin, end) */
+    int64_t halo;          /* extra positions kept past `end` */
+} mm_interval_t;
+
+/* One output row = one key of the reference's freq map (src/mod.c:428-439) with its value. */
+typedef struct mm_row {
+    int32_t tid;
+    int32_t pos;
+    uint8_t strand;        /* 0 '+', 1 '-' */
+    uint8_t rsvd;
+    uint16_t ins_offset;
+    int16_t code;          /* index for mm_freq_code_name */
+    int16_t hp;            /* -1 = '*' (all haplotypes / haplotypes off) */
+    uint32_t n_called;
+    uint32_t n_mod;
+} mm_row_t;
+
+/* per-read status codes (0 = ok); the reference's message for each is in INTEGRATION.md */
+enum {
+    MM_OK = 0, MM_E_HARDCLIP = 1, MM_E_CIGAROP = 2, MM_E_MMBASE = 3, MM_E_MMSTRAND = 4, MM_E_MMCODE = 5,
+    MM_E_MMEMPTY = 6, MM_E_MMMIXED = 7, MM_E_SKIPLEN = 8, MM_E_SKIPVAL = 9, MM_E_READPOS = 10,
+    MM_E_MLIDX = 11, MM_E_NOCONTIG = 12, MM_E_REFPOS = 13, MM_E_QOVER = 14,
+    /* library-level */
+    MM_E_SIDEFULL = 32, MM_E_ARG = 33, MM_E_HIP = 34, MM_E_NOMEM = 35, MM_E_TOOMANY = 36, MM_E_NOCODE = 37
+};
+
+typedef struct mm_freq mm_freq_t;
+
+/* set-up: upload the reference, build per-base context words (kernel K0), allocate counter planes.
+ * Returns NULL on failure with a message in err. */
+mm_freq_t *mm_freq_create(const mm_freq_opts_t *opts, int32_t n_contigs, const mm_contig_t *contigs,
+                          int32_t n_intervals, const mm_interval_t *intervals, char *err, size_t err_len);
+
+/* Process one batch from HOST memory: H2D on an internal stream, then the per-read kernel (K1).  Asynchronous;
+ * the batch memory must stay valid until mm_freq_wait(ticket) returns.  Returns a ticket >= 0 or -MM_E_*. */
+int32_t mm_freq_submit(mm_freq_t *h, const mm_batch_t *host_batch);
+
+/* Process one batch already RESIDENT in device memory (all mm_batch_t pointers are device pointers) on the given
+ * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*. */
+int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *hip_stream);
+
+/* Wait for a ticket.  Returns 0, or the first failing read's MM_E_* code with its batch index in *bad_read. */
+int32_t mm_freq_wait(mm_freq_t *h, int32_t ticket, int32_t *bad_read);
+
+/* Intern a code string seen in reads (only meaningful with -c '*'): returns its code index. */
+int32_t mm_freq_intern_code(mm_freq_t *h, const char *code);
+int32_t mm_freq_n_codes(const mm_freq_t *h);
+const char *mm_freq_code_name(const mm_freq_t *h, int32_t code);
+
+/* Finalize: compact non-zero counters (kernel K2), fold in the side list, order rows by (contig name in strcmp
+ * order, pos) like cmp_key_fast (src/mod.c:59-87) with ties in (strand, code, ins_offset, haplotype, '*' last)
+ * order.  *rows is owned by the handle and valid until the next finalize/destroy.  Returns the row count or
+ * -MM_E_*.  Counters are left intact (more batches may follow). */
+int64_t mm_freq_finalize(mm_freq_t *h, const mm_row_t **rows);
+
+/* Multi-GPU halo exchange: device pointer and element count (uint64 each) of the
+ * counter slab covering [begin, begin+len) of an interval, plane-major: for plane, for strand: len words.
+ * mm_freq_slab_export packs it into `dst` (device), mm_freq_slab_add adds a packed slab into the planes. */
+int64_t mm_freq_slab_words(const mm_freq_t *h, int64_t len);
+int32_t mm_freq_slab_export(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *dst_dev, void *hip_stream);
+int32_t mm_freq_slab_add(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *src_dev, void *hip_stream);
+int32_t mm_freq_slab_clear(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *hip_stream);
+
+/* Measurement hooks (bench.py): device time of the last K1 launch of a ticket in milliseconds (HIP events on
+ * the launch stream), and the number of K1 launches so far. */
+float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
+int64_t mm_freq_device_bytes(const mm_freq_t *h);
+
+void mm_freq_reset_counters(mm_freq_t *h);
+void mm_freq_destroy(mm_freq_t *h);
+
+const char *mm_strerror(int32_t code);
+int32_t mm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINIMOD_HIP_H */

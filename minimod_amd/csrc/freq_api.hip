@@ -1,0 +1,677 @@
+// freq_api.hip -- the C ABI of include/minimod_hip.h on top of the gfx950 kernels in freq_kernels.hip.h.
+//
+// Host-side life cycle (reference seams in parentheses, paths under /root/reference):
+//   mm_freq_create   upload reference, K0, allocate counter planes   (load_ref/load_ref_contexts src/ref.c:46-229,
+//                                                                     init_core src/minimod.c:51-137)
+//   mm_freq_submit*  one -K/-B batch -> K1                            (process_db src/minimod.c:344-350)
+//   mm_freq_wait     per-read errors                                  (the ERROR()+exit paths of src/mod.c)
+//   mm_freq_finalize K2 + side list + ordering                        (print_freq_output src/mod.c:644-728)
+// There is no CPU fallback: every entry point needs a HIP device and fails with MM_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "freq_kernels.hip.h"
+#include "minimod_hip.h"
+
+using namespace mmhip;
+
+namespace {
+
+constexpr int kSlots = 4;
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    bool busy = false, timed = false;
+    // staging for host batches
+    void* d_reads = nullptr; size_t cap_reads = 0;
+    void* d_cigar = nullptr; size_t cap_cigar = 0;
+    void* d_seq = nullptr;   size_t cap_seq = 0;
+    void* d_mm = nullptr;    size_t cap_mm = 0;
+    void* d_ml = nullptr;    size_t cap_ml = 0;
+    void* d_order = nullptr; size_t cap_order = 0;
+    int32_t* d_status = nullptr; size_t cap_status = 0;
+    uint32_t* d_spill = nullptr; size_t cap_spill = 0;
+    unsigned int* d_ctl = nullptr;   // [0] queue, [1] err_summary
+    unsigned int* h_ctl = nullptr;   // pinned copy
+    int32_t n_reads = 0;
+};
+
+}  // namespace
+
+struct mm_freq {
+    mm_freq_opts_t opts;
+    int device = 0;
+    int n_cu = 0, blocks_per_cu = 1;
+    bool wide = false;  // 32-bit reference words (n_mods > 5)
+    int n_contigs = 0;
+    std::vector<std::string> names;
+    std::vector<int64_t> ctg_len, ref_base, seg_begin, seg_len, cnt_base;
+    std::vector<int> ctg_rank;  // rank of contig names in strcmp order
+    int64_t ref_total = 0, plane_len = 0;
+    int n_code_planes = 0, n_hp = 1, wildcard = -1;
+    void* d_refw = nullptr;
+    int64_t *d_ref_base = nullptr, *d_ctg_len = nullptr, *d_seg_begin = nullptr, *d_seg_len = nullptr, *d_cnt_base = nullptr;
+    unsigned long long* d_counters = nullptr;
+    int64_t n_counter_words = 0;
+    DevMod* d_mods = nullptr;
+    DevCode* d_codes = nullptr;
+    std::vector<DevCode> codes;
+    bool codes_dirty = false;
+    SideRec* d_side = nullptr;
+    unsigned long long* d_side_count = nullptr;
+    int64_t side_cap = 0;
+    Slot slots[kSlots];
+    int next_slot = 0;
+    hipStream_t stream = nullptr;  // set-up / finalize stream
+    std::vector<mm_row_t> rows;
+    int64_t device_bytes = 0;
+    // finalize scratch
+    uint32_t* d_tile_counts = nullptr; unsigned long long* d_tile_offsets = nullptr; size_t cap_tiles = 0;
+    DenseRow* d_rows = nullptr; size_t cap_rows = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            std::fprintf(stderr, "[minimod_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                                          \
+            return -MM_E_HIP;                                                                          \
+        }                                                                                              \
+    } while (0)
+
+int dev_alloc(mm_freq* h, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return -MM_E_NOMEM;
+    h->device_bytes += (int64_t)bytes;
+    return 0;
+}
+
+int grow(mm_freq* h, void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return 0;
+    size_t ncap = std::max(need + need / 4, (size_t)4096);
+    if (*p) { (void)hipFree(*p); h->device_bytes -= (int64_t)*cap; }
+    *p = nullptr; *cap = 0;
+    int r = dev_alloc(h, p, ncap);
+    if (r) return r;
+    *cap = ncap;
+    return 0;
+}
+
+int complement(int c) {
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'U': return 'A'; case 'N': return 'N'; default: return 0;
+    }
+}
+
+int upload_codes(mm_freq* h, hipStream_t s) {
+    if (!h->codes_dirty) return 0;
+    HIPCHK(hipMemcpyAsync(h->d_codes, h->codes.data(), sizeof(DevCode) * h->codes.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->codes_dirty = false;
+    return 0;
+}
+
+DevParams base_params(mm_freq* h) {
+    DevParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.refw = h->d_refw;
+    p.ref_base = h->d_ref_base; p.ctg_len = h->d_ctg_len;
+    p.seg_begin = h->d_seg_begin; p.seg_len = h->d_seg_len; p.cnt_base = h->d_cnt_base;
+    p.n_contigs = h->n_contigs;
+    p.counters = h->d_counters; p.plane_len = h->plane_len; p.n_hp = h->n_hp;
+    p.n_mods = h->opts.n_mods; p.n_codes = (int)h->codes.size();
+    p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
+    p.mods = h->d_mods; p.codes = h->d_codes;
+    p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
+    return p;
+}
+
+int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
+    DevParams p = base_params(h);
+    p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
+    p.n_reads = b->n_reads;
+    int blocks = std::min((b->n_reads + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->blocks_per_cu);
+    if (blocks < 1) blocks = 1;
+    uint32_t spill_cig = b->max_n_cigar > (uint32_t)kCigCap ? b->max_n_cigar - kCigCap : 0;
+    uint32_t max_blk = (b->max_l_qseq + 31u) / 32u;
+    uint32_t spill_blk = max_blk > (uint32_t)kDirCap ? max_blk - kDirCap : 0;
+    size_t per_wave = 2u * (size_t)spill_cig + spill_blk;
+    size_t need = per_wave * (size_t)blocks * kWavesPerBlock * sizeof(uint32_t);
+    int r = grow(h, (void**)&s.d_spill, &s.cap_spill, need);
+    if (r) return r;
+    r = grow(h, (void**)&s.d_status, &s.cap_status, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1));
+    if (r) return r;
+    p.spill = s.d_spill; p.spill_cig = spill_cig; p.spill_blk = spill_blk;
+    p.status = s.d_status;
+    p.queue = s.d_ctl; p.err_summary = s.d_ctl + 1;
+    s.h_ctl[0] = 0u; s.h_ctl[1] = 0xFFFFFFFFu;
+    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 2 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(s.d_status, 0, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1), st));
+    HIPCHK(hipEventRecord(s.ev_start, st));
+    if (b->n_reads > 0) {
+        if (h->wide) hipLaunchKernelGGL(k_freq_reads<uint32_t>, dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_freq_reads<uint16_t>, dim3(blocks), dim3(256), 0, st, p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(s.ev_stop, st));
+    HIPCHK(hipMemcpyAsync(s.h_ctl + 2, s.d_ctl, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s.ev_done, st));
+    s.busy = true; s.timed = true; s.n_reads = b->n_reads;
+    return 0;
+}
+
+int acquire_slot(mm_freq* h) {
+    int i = h->next_slot;
+    h->next_slot = (h->next_slot + 1) % kSlots;
+    Slot& s = h->slots[i];
+    if (s.busy) (void)hipEventSynchronize(s.ev_done);
+    return i;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mm_abi_version(void) { return MM_ABI_VERSION; }
+
+const char* mm_strerror(int32_t code) {
+    switch (code < 0 ? -code : code) {
+        case MM_OK: return "ok";
+        case MM_E_HARDCLIP: return "hard clipping found (not supported)";
+        case MM_E_CIGAROP: return "unhandled CIGAR operation";
+        case MM_E_MMBASE: return "invalid base in MM tag";
+        case MM_E_MMSTRAND: return "invalid strand in MM tag";
+        case MM_E_MMCODE: return "invalid base modification code in MM tag";
+        case MM_E_MMEMPTY: return "empty modification codes in MM tag";
+        case MM_E_MMMIXED: return "modification codes both numeric and alphabetic";
+        case MM_E_SKIPLEN: return "skip count longer than 9 characters";
+        case MM_E_SKIPVAL: return "invalid skip count";
+        case MM_E_READPOS: return "read position exceeds sequence length";
+        case MM_E_MLIDX: return "mod prob index mismatch (ML shorter than MM)";
+        case MM_E_NOCONTIG: return "contig not found in reference provided";
+        case MM_E_REFPOS: return "reference position outside contig";
+        case MM_E_QOVER: return "CIGAR longer than the sequence";
+        case MM_E_SIDEFULL: return "sparse side list full";
+        case MM_E_ARG: return "invalid argument";
+        case MM_E_HIP: return "HIP runtime error";
+        case MM_E_NOMEM: return "out of device memory";
+        case MM_E_TOOMANY: return "too many modification codes";
+        case MM_E_NOCODE: return "modification code not interned";
+        default: return "unknown error";
+    }
+}
+
+void mm_freq_destroy(mm_freq_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : h->slots) {
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.ev_start) (void)hipEventDestroy(s.ev_start);
+        if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl};
+        for (void* p : ps) if (p) (void)hipFree(p);
+        if (s.h_ctl) (void)hipHostFree(s.h_ctl);
+    }
+    void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
+                  h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_tile_counts, h->d_tile_offsets, h->d_rows};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const mm_contig_t* contigs,
+                          int32_t n_intervals, const mm_interval_t* intervals, char* err, size_t err_len) {
+    auto fail = [&](mm_freq* h, const char* msg) -> mm_freq_t* {
+        if (err && err_len) std::snprintf(err, err_len, "%s", msg);
+        if (h) mm_freq_destroy(h);
+        return nullptr;
+    };
+    if (!opts || opts->abi_version != MM_ABI_VERSION) return fail(nullptr, "ABI version mismatch");
+    if (opts->n_mods < 1 || opts->n_mods > MM_MAX_MODS) return fail(nullptr, "n_mods out of range (1..13)");
+    if (n_contigs < 0 || (n_contigs > 0 && !contigs)) return fail(nullptr, "bad contig table");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device (the HIP path has no CPU fallback)");
+    if (opts->device < 0 || opts->device >= ndev) return fail(nullptr, "bad device ordinal");
+    mm_freq* h = new mm_freq();
+    h->opts = *opts;
+    h->device = opts->device;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return fail(h, "hipGetDeviceProperties failed");
+    h->n_cu = prop.multiProcessorCount;
+    h->wide = opts->n_mods > 5;
+    {
+        int nb = 0;
+        hipError_t e = h->wide
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint32_t>, 256, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t>, 256, 0);
+        h->blocks_per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
+    for (auto& s : h->slots) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
+        if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
+        if (dev_alloc(h, (void**)&s.d_ctl, 4 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        if (hipHostMalloc((void**)&s.h_ctl, 4 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+    }
+    // ---- mods / codes
+    std::vector<DevMod> mods(opts->n_mods);
+    h->wildcard = -1;
+    for (int i = 0; i < opts->n_mods; i++) {
+        const mm_mod_t& m = opts->mods[i];
+        DevMod& d = mods[i];
+        std::memset(&d, 0, sizeof(d));
+        std::memcpy(d.klass, m.klass, 256);
+        size_t cl = strnlen(m.context, MM_CODE_LEN);
+        if (cl >= MM_CODE_LEN) return fail(h, "context too long");
+        d.ctx_is_star = std::strcmp(m.context, "*") == 0;
+        d.ctx_len = (int)cl;
+        for (size_t j = 0; j < cl; j++) {
+            d.ctx_fwd[j] = m.context[j];
+            d.ctx_rev[j] = (char)complement((unsigned char)m.context[cl - 1 - j]);  // ref.c:183-193
+        }
+        if (strnlen(m.code, MM_CODE_LEN) >= MM_CODE_LEN) return fail(h, "code too long");
+        if (std::strcmp(m.code, "*") == 0) h->wildcard = i;
+    }
+    if (h->wildcard >= 0) {
+        h->n_code_planes = opts->n_wild_planes > 0 ? opts->n_wild_planes : 4;
+    } else {
+        h->n_code_planes = opts->n_mods;
+        for (int i = 0; i < opts->n_mods; i++) {
+            DevCode c;
+            std::memset(&c, 0, sizeof(c));
+            std::snprintf(c.str, MM_CODE_LEN, "%s", opts->mods[i].code);
+            c.len = (int16_t)std::strlen(c.str); c.req = (int16_t)i; c.plane = (int16_t)i;
+            h->codes.push_back(c);
+        }
+    }
+    h->n_hp = opts->haplotypes ? (opts->n_hp_planes > 0 ? std::min(opts->n_hp_planes, MM_MAX_HP_PLANES) : 4) : 1;
+    h->side_cap = opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20);
+    if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
+    if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
+    if (dev_alloc(h, (void**)&h->d_side, sizeof(SideRec) * (size_t)h->side_cap)) return fail(h, "side list alloc failed");
+    if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
+    (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
+    (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
+    h->codes_dirty = !h->codes.empty();
+    // ---- contigs: reference words for every contig that has a sequence; counter segments
+    h->n_contigs = n_contigs;
+    h->names.resize(n_contigs);
+    h->ctg_len.assign(n_contigs, 0); h->ref_base.assign(n_contigs, -1);
+    h->seg_begin.assign(n_contigs, 0); h->seg_len.assign(n_contigs, 0); h->cnt_base.assign(n_contigs, 0);
+    int64_t ref_total = 0;
+    for (int t = 0; t < n_contigs; t++) {
+        h->names[t] = contigs[t].name ? contigs[t].name : "";
+        h->ctg_len[t] = contigs[t].length;
+        if (contigs[t].seq) {
+            if (contigs[t].seq_length != contigs[t].length) {   // mod.c:861 ref_len == target_len
+                char msg[256];
+                std::snprintf(msg, sizeof msg, "ref_len:%lld target_len:%lld for contig %s", (long long)contigs[t].seq_length,
+                              (long long)contigs[t].length, h->names[t].c_str());
+                return fail(h, msg);
+            }
+            h->ref_base[t] = ref_total;
+            ref_total += (contigs[t].length + 63) / 64 * 64;
+        }
+    }
+    h->ref_total = ref_total;
+    int64_t plane_len = 0;
+    if (n_intervals > 0) {
+        for (int i = 0; i < n_intervals; i++) {
+            const mm_interval_t& iv = intervals[i];
+            if (iv.tid < 0 || iv.tid >= n_contigs || h->ref_base[iv.tid] < 0) return fail(h, "interval on unknown contig");
+            int64_t b = std::max<int64_t>(0, iv.begin);
+            int64_t e = std::min<int64_t>(h->ctg_len[iv.tid], iv.end + iv.halo);
+            if (e <= b || h->seg_len[iv.tid] != 0) return fail(h, "bad or duplicate interval");
+            h->seg_begin[iv.tid] = b; h->seg_len[iv.tid] = e - b; h->cnt_base[iv.tid] = plane_len;
+            plane_len += (e - b + 63) / 64 * 64;
+        }
+    } else {
+        for (int t = 0; t < n_contigs; t++) {
+            if (h->ref_base[t] < 0) continue;
+            h->seg_begin[t] = 0; h->seg_len[t] = h->ctg_len[t]; h->cnt_base[t] = plane_len;
+            plane_len += (h->ctg_len[t] + 63) / 64 * 64;
+        }
+    }
+    h->plane_len = plane_len;
+    // contig order of the output: strcmp on names (cmp_key_fast, mod.c:59-76)
+    {
+        std::vector<int> idx(n_contigs);
+        for (int t = 0; t < n_contigs; t++) idx[t] = t;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::strcmp(h->names[a].c_str(), h->names[b].c_str()) < 0; });
+        h->ctg_rank.assign(n_contigs, 0);
+        for (int r = 0; r < n_contigs; r++) h->ctg_rank[idx[r]] = r;
+    }
+    size_t wbytes = h->wide ? 4 : 2;
+    if (dev_alloc(h, &h->d_refw, (size_t)std::max<int64_t>(ref_total, 64) * wbytes)) return fail(h, "reference alloc failed");
+    size_t tb = sizeof(int64_t) * (size_t)std::max(n_contigs, 1);
+    if (dev_alloc(h, (void**)&h->d_ref_base, tb) || dev_alloc(h, (void**)&h->d_ctg_len, tb) || dev_alloc(h, (void**)&h->d_seg_begin, tb) ||
+        dev_alloc(h, (void**)&h->d_seg_len, tb) || dev_alloc(h, (void**)&h->d_cnt_base, tb)) return fail(h, "alloc failed");
+    if (n_contigs > 0) {
+        (void)hipMemcpy(h->d_ref_base, h->ref_base.data(), tb, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_ctg_len, h->ctg_len.data(), tb, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_seg_begin, h->seg_begin.data(), tb, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_seg_len, h->seg_len.data(), tb, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_cnt_base, h->cnt_base.data(), tb, hipMemcpyHostToDevice);
+    }
+    // K0 per contig through a staging buffer
+    {
+        int64_t maxlen = 0;
+        for (int t = 0; t < n_contigs; t++) if (h->ref_base[t] >= 0) maxlen = std::max(maxlen, h->ctg_len[t]);
+        uint8_t* d_raw = nullptr;
+        if (maxlen > 0) {
+            if (hipMalloc((void**)&d_raw, (size_t)maxlen) != hipSuccess) return fail(h, "staging alloc failed");
+            for (int t = 0; t < n_contigs; t++) {
+                if (h->ref_base[t] < 0 || h->ctg_len[t] == 0) continue;
+                int64_t len = h->ctg_len[t];
+                if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "reference upload failed"); }
+                int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
+                if (h->wide) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                                (uint32_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                else hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                        (uint16_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "context kernel failed"); }
+            }
+            (void)hipFree(d_raw);
+        }
+    }
+    // counters
+    h->n_counter_words = (int64_t)h->n_code_planes * h->n_hp * 2 * plane_len;
+    if (dev_alloc(h, (void**)&h->d_counters, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)))
+        return fail(h, "counter plane alloc failed");
+    if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)) != hipSuccess)
+        return fail(h, "counter memset failed");
+    if (hipDeviceSynchronize() != hipSuccess) return fail(h, "device sync failed");
+    return h;
+}
+
+int32_t mm_freq_intern_code(mm_freq_t* h, const char* code) {
+    if (!h || !code) return -MM_E_ARG;
+    size_t L = std::strlen(code);
+    if (L == 0 || L >= MM_CODE_LEN) return -MM_E_ARG;
+    for (size_t i = 0; i < h->codes.size(); i++)
+        if (std::strcmp(h->codes[i].str, code) == 0) return (int32_t)i;
+    if (h->wildcard < 0) return -MM_E_ARG;
+    if (h->codes.size() >= MM_MAX_CODES) return -MM_E_TOOMANY;
+    DevCode c;
+    std::memset(&c, 0, sizeof(c));
+    std::snprintf(c.str, MM_CODE_LEN, "%s", code);
+    c.len = (int16_t)L; c.req = (int16_t)h->wildcard;
+    c.plane = (int16_t)((int)h->codes.size() < h->n_code_planes ? (int)h->codes.size() : -1);
+    h->codes.push_back(c);
+    h->codes_dirty = true;
+    return (int32_t)h->codes.size() - 1;
+}
+int32_t mm_freq_n_codes(const mm_freq_t* h) { return h ? (int32_t)h->codes.size() : 0; }
+const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
+    if (!h || code < 0 || code >= (int32_t)h->codes.size()) return "";
+    return h->codes[code].str;
+}
+
+int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
+    if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24)) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int si = acquire_slot(h);
+    Slot& s = h->slots[si];
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s.stream;
+    // all slots of the handle share the code table; make sure it is current (sync only when it changed)
+    int r = upload_codes(h, st);
+    if (r) return r;
+    r = launch_k1(h, s, b, st);
+    return r ? r : si;
+}
+
+int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
+    if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24)) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int si = acquire_slot(h);
+    Slot& s = h->slots[si];
+    hipStream_t st = s.stream;
+    int r = upload_codes(h, st);
+    if (r) return r;
+    size_t nr = sizeof(mm_read_t) * (size_t)hb->n_reads;
+    if ((r = grow(h, &s.d_reads, &s.cap_reads, nr)) || (r = grow(h, &s.d_cigar, &s.cap_cigar, 4 * hb->n_cigar_words)) ||
+        (r = grow(h, &s.d_seq, &s.cap_seq, hb->n_seq_bytes)) || (r = grow(h, &s.d_mm, &s.cap_mm, hb->n_mm_bytes)) ||
+        (r = grow(h, &s.d_ml, &s.cap_ml, hb->n_ml_bytes)))
+        return r;
+    mm_batch_t db = *hb;
+    if (hb->n_reads) HIPCHK(hipMemcpyAsync(s.d_reads, hb->reads, nr, hipMemcpyHostToDevice, st));
+    if (hb->n_cigar_words) HIPCHK(hipMemcpyAsync(s.d_cigar, hb->cigar, 4 * hb->n_cigar_words, hipMemcpyHostToDevice, st));
+    if (hb->n_seq_bytes) HIPCHK(hipMemcpyAsync(s.d_seq, hb->seq, hb->n_seq_bytes, hipMemcpyHostToDevice, st));
+    if (hb->n_mm_bytes) HIPCHK(hipMemcpyAsync(s.d_mm, hb->mm, hb->n_mm_bytes, hipMemcpyHostToDevice, st));
+    if (hb->n_ml_bytes) HIPCHK(hipMemcpyAsync(s.d_ml, hb->ml, hb->n_ml_bytes, hipMemcpyHostToDevice, st));
+    db.reads = (const mm_read_t*)s.d_reads; db.cigar = (const uint32_t*)s.d_cigar; db.seq = (const uint8_t*)s.d_seq;
+    db.mm = (const uint8_t*)s.d_mm; db.ml = (const uint8_t*)s.d_ml; db.order = nullptr;
+    if (hb->order && hb->n_reads) {
+        if ((r = grow(h, &s.d_order, &s.cap_order, sizeof(int32_t) * (size_t)hb->n_reads))) return r;
+        HIPCHK(hipMemcpyAsync(s.d_order, hb->order, sizeof(int32_t) * (size_t)hb->n_reads, hipMemcpyHostToDevice, st));
+        db.order = (const int32_t*)s.d_order;
+    }
+    r = launch_k1(h, s, &db, st);
+    return r ? r : si;
+}
+
+int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
+    if (!h || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
+    Slot& s = h->slots[ticket];
+    if (!s.busy) return MM_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
+    if (hipEventSynchronize(s.ev_done) != hipSuccess) return MM_E_HIP;
+    s.busy = false;
+    unsigned int sum = s.h_ctl[3];
+    if (sum != 0xFFFFFFFFu) {
+        if (bad_read) *bad_read = (int32_t)(sum >> 8);
+        return (int32_t)(sum & 0xFFu);
+    }
+    return MM_OK;
+}
+
+float mm_freq_last_kernel_ms(mm_freq_t* h, int32_t ticket) {
+    if (!h || ticket < 0 || ticket >= kSlots || !h->slots[ticket].timed) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, h->slots[ticket].ev_start, h->slots[ticket].ev_stop) != hipSuccess) return -1.f;
+    return ms;
+}
+
+int64_t mm_freq_device_bytes(const mm_freq_t* h) { return h ? h->device_bytes : 0; }
+
+void mm_freq_reset_counters(mm_freq_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1));
+    (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
+    (void)hipDeviceSynchronize();
+}
+
+int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
+    if (!h) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<mm_row_t>& rows = h->rows;
+    rows.clear();
+    // ---- K2 over all planes at once: the flat counter array is [run][plane_len] with run = (plane*n_hp+hp)*2+strand
+    int64_t n = h->n_counter_words;
+    if (n > 0) {
+        size_t tiles = (size_t)((n + kTile - 1) / kTile);
+        if (tiles > h->cap_tiles) {
+            if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
+            if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
+            h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
+            if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * tiles) ||
+                dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * tiles)) return -MM_E_NOMEM;
+            h->cap_tiles = tiles;
+        }
+        hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, n, h->d_tile_counts);
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> tc(tiles);
+        HIPCHK(hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> to(tiles);
+        unsigned long long total = 0;
+        for (size_t i = 0; i < tiles; i++) { to[i] = total; total += tc[i]; }
+        if (total > 0) {
+            if (total > h->cap_rows) {
+                if (h->d_rows) (void)hipFree(h->d_rows);
+                h->d_rows = nullptr; h->cap_rows = 0;
+                size_t cap = (size_t)(total + total / 8 + 1024);
+                if (dev_alloc(h, (void**)&h->d_rows, sizeof(DenseRow) * cap)) return -MM_E_NOMEM;
+                h->cap_rows = cap;
+            }
+            HIPCHK(hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * tiles, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, n, h->d_tile_offsets, h->d_rows);
+            HIPCHK(hipGetLastError());
+            std::vector<DenseRow> dr((size_t)total);
+            HIPCHK(hipMemcpyAsync(dr.data(), h->d_rows, sizeof(DenseRow) * (size_t)total, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            // decode flat index -> (plane, hp, strand, tid, pos)
+            std::vector<int> seg_tids;
+            for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) seg_tids.push_back(t);
+            std::sort(seg_tids.begin(), seg_tids.end(), [&](int a, int b) { return h->cnt_base[a] < h->cnt_base[b]; });
+            rows.reserve((size_t)total);
+            size_t cursor = 0;
+            int64_t last_run = -1;
+            for (const DenseRow& d : dr) {
+                int64_t run = d.index / h->plane_len, off = d.index - run * h->plane_len;
+                if (run != last_run) { cursor = 0; last_run = run; }
+                while (cursor + 1 < seg_tids.size() && h->cnt_base[seg_tids[cursor + 1]] <= off) cursor++;
+                int t = seg_tids[cursor];
+                int64_t rel = off - h->cnt_base[t];
+                if (rel >= h->seg_len[t]) continue;  // padding, never written
+                int strand = (int)(run & 1);
+                int64_t ph = run >> 1;
+                int plane = (int)(ph / h->n_hp), hp = (int)(ph % h->n_hp);
+                mm_row_t r;
+                std::memset(&r, 0, sizeof(r));
+                r.tid = t; r.pos = (int32_t)(h->seg_begin[t] + rel); r.strand = (uint8_t)strand; r.ins_offset = 0;
+                r.code = (int16_t)plane;   // dense plane i belongs to code i (both orders are interning order)
+                r.hp = (int16_t)(h->opts.haplotypes ? hp : -1);
+                r.n_called = d.n_called; r.n_mod = d.n_mod;
+                rows.push_back(r);
+            }
+        }
+    }
+    // ---- side list
+    unsigned long long ns = 0;
+    HIPCHK(hipMemcpy(&ns, h->d_side_count, sizeof(ns), hipMemcpyDeviceToHost));
+    if (ns > (unsigned long long)h->side_cap) return -MM_E_SIDEFULL;
+    if (ns) {
+        std::vector<SideRec> sr((size_t)ns);
+        HIPCHK(hipMemcpy(sr.data(), h->d_side, sizeof(SideRec) * (size_t)ns, hipMemcpyDeviceToHost));
+        rows.reserve(rows.size() + (size_t)ns);
+        for (const SideRec& s : sr) {
+            mm_row_t r;
+            std::memset(&r, 0, sizeof(r));
+            r.tid = s.tid; r.pos = s.pos; r.strand = s.strand; r.ins_offset = s.ins_off; r.code = s.code;
+            r.hp = (int16_t)(h->opts.haplotypes ? s.hp : -1);
+            r.n_called = 1; r.n_mod = s.is_mod;
+            rows.push_back(r);
+        }
+    }
+    // ---- order + merge equal keys (+ '*' aggregates with haplotypes, update_freq_map mod.c:906-928)
+    auto hpkey = [](int hp) { return hp < 0 ? 100000 : hp; };
+    auto less = [&](const mm_row_t& a, const mm_row_t& b) {
+        if (a.tid != b.tid) {
+            int ra = h->ctg_rank[a.tid], rb = h->ctg_rank[b.tid];
+            return ra < rb;
+        }
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.strand != b.strand) return a.strand < b.strand;
+        if (a.code != b.code) return a.code < b.code;
+        if (a.ins_offset != b.ins_offset) return a.ins_offset < b.ins_offset;
+        return hpkey(a.hp) < hpkey(b.hp);
+    };
+    std::sort(rows.begin(), rows.end(), less);
+    auto same_site = [](const mm_row_t& a, const mm_row_t& b) {
+        return a.tid == b.tid && a.pos == b.pos && a.strand == b.strand && a.code == b.code && a.ins_offset == b.ins_offset;
+    };
+    std::vector<mm_row_t> merged;
+    merged.reserve(rows.size() + (h->opts.haplotypes ? rows.size() : 0));
+    size_t i = 0;
+    while (i < rows.size()) {
+        size_t j = i;
+        mm_row_t agg = rows[i];
+        agg.hp = -1; agg.n_called = 0; agg.n_mod = 0;
+        while (j < rows.size() && same_site(rows[i], rows[j])) {
+            mm_row_t cur = rows[j];
+            size_t k = j + 1;
+            while (k < rows.size() && same_site(rows[i], rows[k]) && rows[k].hp == cur.hp) {
+                cur.n_called += rows[k].n_called; cur.n_mod += rows[k].n_mod; k++;
+            }
+            agg.n_called += cur.n_called; agg.n_mod += cur.n_mod;
+            merged.push_back(cur);
+            j = k;
+        }
+        if (h->opts.haplotypes) merged.push_back(agg);
+        i = j;
+    }
+    rows.swap(merged);
+    if (out_rows) *out_rows = rows.data();
+    return (int64_t)rows.size();
+}
+
+// ---------------------------------------------------------------------------------- halo slabs
+int64_t mm_freq_slab_words(const mm_freq_t* h, int64_t len) {
+    return h ? (int64_t)h->n_code_planes * h->n_hp * 2 * len : 0;
+}
+static int slab_range(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, int64_t* off) {
+    if (!h || tid < 0 || tid >= h->n_contigs || len < 0) return -MM_E_ARG;
+    int64_t rel = begin - h->seg_begin[tid];
+    if (rel < 0 || rel + len > h->seg_len[tid]) return -MM_E_ARG;
+    *off = h->cnt_base[tid] + rel;
+    return 0;
+}
+int32_t mm_freq_slab_export(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* dst, void* st) {
+    int64_t off;
+    int r = slab_range(h, tid, begin, len, &off);
+    if (r || len == 0) return r;
+    HIPCHK(hipSetDevice(h->device));
+    int runs = h->n_code_planes * h->n_hp * 2;
+    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_slab_export, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off,
+                       len, runs, (unsigned long long*)dst);
+    HIPCHK(hipGetLastError());
+    if (!st) HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t mm_freq_slab_add(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src, void* st) {
+    int64_t off;
+    int r = slab_range(h, tid, begin, len, &off);
+    if (r || len == 0) return r;
+    HIPCHK(hipSetDevice(h->device));
+    int runs = h->n_code_planes * h->n_hp * 2;
+    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_slab_add, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len,
+                       runs, (const unsigned long long*)src);
+    HIPCHK(hipGetLastError());
+    if (!st) HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t mm_freq_slab_clear(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* st) {
+    int64_t off;
+    int r = slab_range(h, tid, begin, len, &off);
+    if (r || len == 0) return r;
+    HIPCHK(hipSetDevice(h->device));
+    int runs = h->n_code_planes * h->n_hp * 2;
+    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_slab_clear, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len, runs);
+    HIPCHK(hipGetLastError());
+    if (!st) HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,732 @@
+// freq_kernels.hip.h -- hand-written gfx950 kernels of the `freq` hot path (device code only).
+//
+//   K0  k_build_refwords   load_ref normalisation + load_ref_contexts      reference src/ref.c:73-78,92-229
+//   K1  k_freq_reads       get_aln + freq_view_single + update_freq_map    reference src/mod.c:776-1370
+//   K2  k_count_nonzero / k_emit_rows   collect step of print_freq_output  reference src/mod.c:644-664
+//   slab kernels           halo exchange helpers (no reference counterpart)
+//
+// Design (MI355X first, not a translation): one 64-lane wavefront owns one read.  Nothing of size O(l_qseq)
+// is ever materialised: the CIGAR becomes two exclusive prefix arrays (query / reference offsets per op) in
+// LDS, the packed sequence becomes a per-32-base rank directory for the one base class an MM group needs,
+// and MM text is parsed 64 characters per step with ballots; skip counts are compacted in LDS so that the
+// expensive per-call work (rank -> read position -> reference position -> context test -> ML threshold ->
+// counter) runs with all 64 lanes busy.  Counters are one 64-bit word per (plane, strand, position) holding
+// {n_called (low 32), n_mod (high 32)}, updated with ONE global_atomic_add_x2 per call.  This is integer
+// select/scan/scatter work: no MFMA, HBM- and latency-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minimod_hip.h"
+
+namespace mmhip {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kCigCap = 1024;  // CIGAR ops whose prefix sums live in LDS (the rest spill to a global scratch)
+constexpr int kDirCap = 1024;  // 32-base blocks whose rank directory lives in LDS (32 kb of read)
+constexpr int kTokCap = 128;
+
+struct DevCode {
+    char str[MM_CODE_LEN];
+    int16_t len;
+    int16_t req;    // index of the requested mod whose context/threshold applies
+    int16_t plane;  // dense counter plane, or -1 (side list only)
+    int16_t rsvd;
+};
+
+struct DevMod {
+    uint8_t klass[256];
+    int32_t ctx_is_star;
+    int32_t ctx_len;
+    char ctx_fwd[MM_CODE_LEN];
+    char ctx_rev[MM_CODE_LEN];
+};
+
+struct SideRec {  // one counter update that does not fit the dense planes (16 bytes)
+    int32_t tid;
+    int32_t pos;
+    uint16_t ins_off;
+    uint8_t strand;
+    uint8_t is_mod;
+    int16_t code;
+    int16_t hp;
+};
+
+struct DevParams {
+    // batch
+    const mm_read_t* reads;
+    const uint32_t* cigar;
+    const uint8_t* seq;
+    const uint8_t* mm;
+    const uint8_t* ml;
+    const int32_t* order;  // optional processing order
+    int32_t n_reads;
+    // reference
+    const void* refw;            // uint16 or uint32 per base: bits 0-4 base code, bit 5+2i fwd ctx, 6+2i rev ctx
+    const int64_t* ref_base;     // per tid: offset into refw, -1 = contig absent
+    const int64_t* ctg_len;      // per tid
+    const int64_t* seg_begin;    // per tid: first position with dense counters
+    const int64_t* seg_len;      // per tid: number of positions with dense counters (0 = none)
+    const int64_t* cnt_base;     // per tid: offset of the segment inside a plane
+    int32_t n_contigs;
+    // counters
+    unsigned long long* counters;  // [(plane * n_hp + hp) * 2 + strand][plane_len]
+    int64_t plane_len;
+    int32_t n_hp;                  // dense haplotype planes (1 when haplotypes are off)
+    // options
+    int32_t n_mods, n_codes, insertions, haplotypes, wildcard;
+    const DevMod* mods;
+    const DevCode* codes;
+    // outputs
+    int32_t* status;               // per read
+    unsigned int* err_summary;     // min over failing reads of (read index << 8 | code), 0xFFFFFFFF = none
+    SideRec* side;
+    unsigned long long* side_count;
+    unsigned long long side_cap;
+    // scheduling / scratch
+    unsigned int* queue;
+    uint32_t* spill;               // per wave slot: [max_cig] q, [max_cig] r, [max_blk] dir
+    uint32_t spill_cig, spill_blk;
+};
+
+// ---------------------------------------------------------------------------------- wave primitives
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---------------------------------------------------------------------------------- nibble helpers
+// bit 4n+3 of the result is set iff nibble n of x equals nib
+__device__ __forceinline__ uint32_t nib_eq(uint32_t x, uint32_t nib) {
+    uint32_t y = x ^ (nib * 0x11111111u);
+    uint32_t t = (y & 0x77777777u) + 0x77777777u;
+    return ~(t | y) & 0x88888888u;
+}
+// match bits (bit 4n+3) of the bases of class cls in one word; mod.c:97 base_idx_lookup on seq_nt16_str:
+// A(1)->0 C(2)->1 G(4)->2 T(8)->3 N(15)->4, every other code -> 0.
+__device__ __forceinline__ uint32_t class_bits(uint32_t x, int cls) {
+    if (cls == 1) return nib_eq(x, 2);
+    if (cls == 2) return nib_eq(x, 4);
+    if (cls == 3) return nib_eq(x, 8);
+    if (cls == 4) return nib_eq(x, 15);
+    return 0x88888888u & ~(nib_eq(x, 2) | nib_eq(x, 4) | nib_eq(x, 8) | nib_eq(x, 15));
+}
+// BAM packs base 2j in the HIGH nibble of byte j: swap nibbles inside each byte so nibble n == base n
+__device__ __forceinline__ uint32_t base_order(uint32_t w) { return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu); }
+// mask with bit 4n+3 set for the first `valid` (0..8) bases of a word
+__device__ __forceinline__ uint32_t valid_bits(int valid) {
+    return valid >= 8 ? 0x88888888u : (valid <= 0 ? 0u : (0x88888888u & ((1u << (4 * valid)) - 1u)));
+}
+__device__ __forceinline__ int base_class_of_char(int c) {
+    switch (c) {
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        case 'N': case 'n': return 4;
+        default: return 0;
+    }
+}
+__device__ __forceinline__ int complement_char(int c) {  // mod.c:98 base_complement_lookup
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'U': return 'A'; case 'N': return 'N'; case 'a': return 't'; case 'c': return 'g';
+        case 'g': return 'c'; case 't': return 'a'; case 'u': return 'a'; case 'n': return 'n';
+        default: return 0;
+    }
+}
+__device__ __forceinline__ bool valid_base_char(int c) {  // mod.c:95 valid_bases
+    switch (c) {
+        case 'A': case 'C': case 'G': case 'T': case 'U': case 'N':
+        case 'a': case 'c': case 'g': case 't': case 'u': case 'n': return true;
+        default: return false;
+    }
+}
+
+// ---------------------------------------------------------------------------------- K0
+// Per-base reference word.  bits 0-4: index of the (upper-cased, U->T) letter in "=ACMGRSVTWYHKDBN" or 16;
+// bit 5+2i: position lies inside a forward-context match of mod i; bit 6+2i: inside a reverse-context match.
+__device__ __forceinline__ int norm_ref_char(int c) {
+    if (c >= 'a' && c <= 'z') c -= 32;
+    return c == 'U' ? 'T' : c;
+}
+__device__ __forceinline__ int nt16_code(int c) {
+    switch (c) {
+        case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4;
+        case 'R': return 5; case 'S': return 6; case 'V': return 7; case 'T': return 8; case 'W': return 9;
+        case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14;
+        case 'N': return 15; default: return 16;
+    }
+}
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_build_refwords(const uint8_t* __restrict__ raw, int64_t len,
+                                                        RefWord* __restrict__ out, const DevMod* __restrict__ mods,
+                                                        int n_mods) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < len; p += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t w = (uint32_t)nt16_code(norm_ref_char(raw[p]));
+        for (int i = 0; i < n_mods; i++) {
+            const DevMod& m = mods[i];
+            if (m.ctx_is_star) { w |= 3u << (5 + 2 * i); continue; }
+            int L = m.ctx_len;
+            if (L <= 0) continue;
+            bool f = false, r = false;
+            for (int64_t s = p - L + 1; s <= p; s++) {
+                if (s < 0 || s + L > len) continue;
+                bool mf = true, mr = true;
+                for (int j = 0; j < L; j++) {
+                    int c = norm_ref_char(raw[s + j]);
+                    mf = mf && (c == m.ctx_fwd[j]);
+                    mr = mr && (c == m.ctx_rev[j]);
+                }
+                f = f || mf; r = r || mr;
+            }
+            w |= (f ? 1u : 0u) << (5 + 2 * i);
+            w |= (r ? 1u : 0u) << (6 + 2 * i);
+        }
+        out[p] = (RefWord)w;
+    }
+}
+
+// ---------------------------------------------------------------------------------- K1
+struct WaveLds {
+    uint32_t cig_q[kCigCap];  // query offset at the start of op i
+    uint32_t cig_r[kCigCap];  // reference offset at the start of op i | op << 28
+    uint32_t dir[kDirCap];    // # bases of the current class before 32-base block b
+    uint32_t tok[kTokCap];    // compacted skip counts
+    uint32_t gap[64];         // exclusive prefix of skip counts (implicit-call expansion)
+    uint32_t gstart[64];      // first rank of each gap
+    uint8_t mm[96];           // 64 MM characters + look-ahead
+    char hdr[16];             // code characters of the current MM group
+    int16_t g_code[16];       // per code letter: device code index or -1
+};
+
+struct ReadCtx {
+    // wave-uniform
+    const uint8_t* seq;
+    const uint8_t* ml;
+    const void* refw;
+    uint32_t* spill_q; uint32_t* spill_r; uint32_t* spill_d;
+    int64_t ref_base, seg_begin, seg_len, cnt_base;
+    uint32_t L, ncig, nblk, q_total, ml_len;
+    int32_t tid, pos, rev, hp, hpi;
+    // current MM group
+    int32_t cls, direct, mb_is_N, n_codes_grp;
+    uint32_t nb, ml_start;
+};
+
+template <typename RefWord>
+struct K1 {
+    const DevParams& p;
+    WaveLds& S;
+    ReadCtx c;
+    int err;
+
+    __device__ K1(const DevParams& p_, WaveLds& s_) : p(p_), S(s_), err(0) {}
+
+    __device__ __forceinline__ uint32_t cq(uint32_t i) const { return i < (uint32_t)kCigCap ? S.cig_q[i] : c.spill_q[i - kCigCap]; }
+    __device__ __forceinline__ uint32_t cr(uint32_t i) const { return i < (uint32_t)kCigCap ? S.cig_r[i] : c.spill_r[i - kCigCap]; }
+    __device__ __forceinline__ uint32_t dr(uint32_t b) const { return b < (uint32_t)kDirCap ? S.dir[b] : c.spill_d[b - kDirCap]; }
+
+    // ---- a4 get_aln (mod.c:776-881) as prefix sums: no aln[] array
+    __device__ void scan_cigar(const uint32_t* cg, int64_t ctg_len) {
+        const int lane = lane_id();
+        uint32_t carry_q = 0, carry_r = 0;
+        for (uint32_t i0 = 0; i0 < c.ncig; i0 += 64) {
+            uint32_t i = i0 + lane;
+            bool act = i < c.ncig;
+            uint32_t w = act ? cg[i] : 0u;
+            uint32_t op = w & 15u, len = w >> 4;
+            // ops MIDNSHP=X = 0..8 ; query-consuming {M,I,S,=,X}, reference-consuming {M,D,N,=,X}
+            uint32_t qinc = (act && ((0x193u >> op) & 1u)) ? len : 0u;
+            uint32_t rinc = (act && ((0x18Du >> op) & 1u)) ? len : 0u;
+            if (act && op == 5u) err = MM_E_HARDCLIP;                     // mod.c:841-844
+            else if (act && (op == 6u || op > 8u)) err = MM_E_CIGAROP;    // mod.c:845-848
+            uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
+            uint32_t qtot = __shfl(qs, 63, 64), rtot = __shfl(rs, 63, 64);
+            qs = carry_q + qs - qinc;
+            rs = carry_r + rs - rinc;
+            bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
+            if (aligned) {
+                if ((uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;                        // mod.c:853
+                int64_t r0 = (int64_t)c.pos + rs;
+                if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;          // mod.c:860
+            }
+            if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;  // mod.c:865
+            if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
+            if (act) {
+                uint32_t rv = (rs & 0x0FFFFFFFu) | (op << 28);
+                if (i < (uint32_t)kCigCap) { S.cig_q[i] = qs; S.cig_r[i] = rv; }
+                else { c.spill_q[i - kCigCap] = qs; c.spill_r[i - kCigCap] = rv; }
+            }
+            carry_q += qtot; carry_r += rtot;
+        }
+        c.q_total = carry_q;
+        wave_sync();
+    }
+
+    // ---- a5 base directory (mod.c:972-981) as a rank directory over 32-base blocks
+    __device__ void build_dir(int cls) {
+        const int lane = lane_id();
+        const uint4* sq = reinterpret_cast<const uint4*>(c.seq);
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < c.nblk; b0 += 64) {
+            uint32_t b = b0 + lane;
+            uint32_t cnt = 0;
+            if (b < c.nblk) {
+                uint4 v = sq[b];
+                int valid = (int)min(32u, c.L - b * 32u);
+                if (cls == 0) {
+                    uint32_t o = 0;
+                    o += __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15));
+                    o += __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15));
+                    o += __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15));
+                    o += __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
+                    cnt = (uint32_t)valid - o;  // zero padding nibbles never match 2/4/8/15
+                } else {
+                    cnt = __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) +
+                          __popc(class_bits(v.w, cls));
+                }
+            }
+            uint32_t incl = wave_incl_scan(cnt);
+            uint32_t tot = __shfl(incl, 63, 64);
+            if (b < c.nblk) {
+                uint32_t ex = carry + incl - cnt;
+                if (b < (uint32_t)kDirCap) S.dir[b] = ex; else c.spill_d[b - kDirCap] = ex;
+            }
+            carry += tot;
+        }
+        c.nb = carry;
+        c.cls = cls;
+        wave_sync();
+    }
+
+    // rank (0-based, BAM orientation) of a base of the current class -> (BAM index q, nt16 code)
+    __device__ __forceinline__ uint32_t select_base(uint32_t rr, uint32_t& code) const {
+        uint32_t lo = 0;
+        uint32_t step = 1;
+        while (step < c.nblk) step <<= 1;
+        for (step >>= 1; step; step >>= 1) {
+            uint32_t cand = lo + step;
+            if (cand < c.nblk && dr(cand) <= rr) lo = cand;
+        }
+        uint32_t k = rr - dr(lo);
+        uint4 v = reinterpret_cast<const uint4*>(c.seq)[lo];
+        int valid = (int)min(32u, c.L - lo * 32u);
+        uint32_t w0 = base_order(v.x), w1 = base_order(v.y), w2 = base_order(v.z), w3 = base_order(v.w);
+        uint32_t m0 = class_bits(w0, c.cls) & valid_bits(valid);
+        uint32_t m1 = class_bits(w1, c.cls) & valid_bits(valid - 8);
+        uint32_t m2 = class_bits(w2, c.cls) & valid_bits(valid - 16);
+        uint32_t m3 = class_bits(w3, c.cls) & valid_bits(valid - 24);
+        uint32_t c0 = __popc(m0), c1 = __popc(m1), c2 = __popc(m2);
+        uint32_t word = 0, mk = m0, wv = w0;
+        if (k >= c0) { k -= c0; word = 1; mk = m1; wv = w1;
+            if (k >= c1) { k -= c1; word = 2; mk = m2; wv = w2;
+                if (k >= c2) { k -= c2; word = 3; mk = m3; wv = w3; } } }
+        uint32_t n = 0, cn = __popc(mk & 0xFFFFu);
+        if (k >= cn) { k -= cn; n += 4; mk >>= 16; }
+        cn = __popc(mk & 0xFFu);
+        if (k >= cn) { k -= cn; n += 2; mk >>= 8; }
+        cn = __popc(mk & 0xFu);
+        if (k >= cn) { n += 1; }
+        code = (wv >> (4 * n)) & 15u;
+        return lo * 32u + word * 8u + n;
+    }
+
+    // BAM index q -> CIGAR op containing it (largest i with cq(i) <= q); only valid for q < q_total
+    __device__ __forceinline__ uint32_t find_op(uint32_t q) const {
+        uint32_t lo = 0, step = 1;
+        while (step < c.ncig) step <<= 1;
+        for (step >>= 1; step; step >>= 1) {
+            uint32_t cand = lo + step;
+            if (cand < c.ncig && cq(cand) <= q) lo = cand;
+        }
+        return lo;
+    }
+
+    __device__ __forceinline__ void side_append(int32_t pos, uint32_t ins_off, int is_mod, int code) {
+        uint64_t m = __ballot(1);
+        int leader = __ffsll((unsigned long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane_id() == leader) base = atomicAdd(p.side_count, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, 64);
+        unsigned long long idx = base + __popcll(m & lanemask_lt());
+        if (idx < p.side_cap) {
+            SideRec r;
+            r.tid = c.tid; r.pos = pos; r.ins_off = (uint16_t)ins_off; r.strand = (uint8_t)c.rev;
+            r.is_mod = (uint8_t)is_mod; r.code = (int16_t)code; r.hp = (int16_t)c.hp;
+            p.side[idx] = r;
+        } else {
+            err = MM_E_SIDEFULL;
+        }
+    }
+
+    // ---- a7/a8/a9: one candidate call: rank -> read position -> reference position -> filters -> counter
+    //      (mod.c:1097-1199 explicit, :1203-1367 implicit, update_freq_map :883-929)
+    __device__ void process_call(uint32_t rank, uint32_t k, bool is_explicit) {
+        uint32_t q, code;
+        if (c.direct) {  // canonical base N: every base counts (mod.c:1102-1107)
+            if (rank >= c.L) { err = MM_E_READPOS; return; }
+            q = c.rev ? c.L - 1 - rank : rank;
+            uint8_t b = c.seq[q >> 1];
+            code = (q & 1u) ? (b & 15u) : (b >> 4);
+        } else {
+            if (rank >= c.nb) { err = MM_E_READPOS; return; }  // the reference reads out of bounds here
+            q = select_base(c.rev ? c.nb - 1 - rank : rank, code);
+        }
+        // (a') of SURVEY.md: proj(q) for aligned bases; with --insertions the anchor insL() left of the insertion
+        int64_t ref_pos = -1, ins_anchor = -1;
+        uint32_t ins_off = 0;
+        if (q < c.q_total) {
+            uint32_t i = find_op(q);
+            uint32_t rv = cr(i), op = rv >> 28, qs = cq(i);
+            if ((0x181u >> op) & 1u) {
+                ref_pos = (int64_t)c.pos + (rv & 0x0FFFFFFFu) + (q - qs);
+            } else if (op == 1u && p.insertions) {
+                ins_off = (q - qs + 1u) & 0xFFFFu;  // ins_offset, truncated like make_key's uint16 (mod.c:428)
+                ins_anchor = (int64_t)c.pos + (rv & 0x0FFFFFFFu) - 1;
+            }
+        }
+        if (ref_pos < 0 && p.insertions) {
+            if (is_explicit || !c.rev) {
+                ref_pos = ins_anchor;                                    // mod.c:1124
+            } else {
+                // quirk (mod.c:1234,1314): the implicit path indexes ins[] with the BAM-orientation position,
+                // i.e. for reverse reads it takes the insertion anchor of the MIRRORED base L-1-q.
+                uint32_t q2 = c.L - 1u - q;
+                if (q2 < c.q_total) {
+                    uint32_t i2 = find_op(q2);
+                    uint32_t rv2 = cr(i2);
+                    if ((rv2 >> 28) == 1u) ref_pos = (int64_t)c.pos + (rv2 & 0x0FFFFFFFu) - 1;
+                }
+            }
+        }
+        if (ref_pos < 0) return;
+        const RefWord* rw = reinterpret_cast<const RefWord*>(c.refw);
+        uint32_t w = (uint32_t)rw[c.ref_base + ref_pos];
+        uint32_t refcode = w & 31u;
+        for (int m = 0; m < c.n_codes_grp; m++) {
+            int ci = S.g_code[m];
+            if (ci < 0) continue;
+            const DevCode& dc = p.codes[ci];
+            int req = dc.req;
+            if (!p.insertions) {
+                bool in_ctx = (w >> (5 + 2 * req + c.rev)) & 1u;
+                bool matches = p.mods[req].ctx_is_star || c.mb_is_N || refcode == code;
+                if (!(in_ctx && matches)) continue;
+            }
+            int is_mod = 0;
+            if (is_explicit) {
+                uint64_t ml_idx = (uint64_t)c.ml_start + (uint64_t)k * c.n_codes_grp + m;
+                if (ml_idx >= c.ml_len) { err = MM_E_MLIDX; return; }  // mod.c:1174
+                uint32_t kl = p.mods[req].klass[c.ml[ml_idx]];
+                if (kl == 0) continue;
+                is_mod = kl == 3;
+            }
+            int64_t off = ref_pos - c.seg_begin;
+            if (ins_off == 0 && dc.plane >= 0 && c.hpi >= 0 && off >= 0 && off < c.seg_len) {
+                unsigned long long* dst = p.counters +
+                    ((int64_t)(dc.plane * p.n_hp + c.hpi) * 2 + c.rev) * p.plane_len + c.cnt_base + off;
+                atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+            } else {
+                side_append((int32_t)ref_pos, ins_off, is_mod, ci);
+            }
+        }
+    }
+
+    // compacted skip counts -> calls; cnt <= 64 tokens of the current group
+    __device__ void flush_tokens(uint32_t cnt, uint32_t& rank_carry, uint32_t& k_carry, bool dot) {
+        const int lane = lane_id();
+        bool act = (uint32_t)lane < cnt;
+        uint32_t s = act ? S.tok[lane] : 0u;
+        uint32_t incl = wave_incl_scan(act ? s + 1u : 0u);
+        uint32_t tot = __shfl(incl, 63, 64);
+        uint32_t rank = rank_carry + incl - 1u;
+        if (act) process_call(rank, k_carry + lane, true);
+        if (dot) {
+            uint32_t gi = wave_incl_scan(s);
+            uint32_t T = __shfl(gi, 63, 64);
+            S.gap[lane] = gi - s;
+            S.gstart[lane] = rank - s;
+            wave_sync();
+            for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+                uint32_t t = t0 + lane;
+                if (t < T) {
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1) {
+                        uint32_t cand = lo + step;
+                        if (cand < 64u && S.gap[cand] <= t) lo = cand;
+                    }
+                    process_call(S.gstart[lo] + (t - S.gap[lo]), 0, false);
+                }
+            }
+            wave_sync();
+        }
+        rank_carry += tot;
+        k_carry += cnt;
+    }
+
+    __device__ int finish(int ridx) {
+        uint64_t eb = __ballot(err != 0);
+        if (eb) {
+            int e = __shfl(err, __ffsll((unsigned long long)eb) - 1, 64);
+            if (lane_id() == 0) { p.status[ridx] = e; atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e); }
+            return e;
+        }
+        return 0;
+    }
+
+    // ---- freq_view_single (mod.c:948-1370) for one read
+    __device__ void run(int ridx, int wave_slot) {
+        const int lane = lane_id();
+        const mm_read_t& rd = p.reads[ridx];
+        err = 0;
+        c.tid = uni(rd.tid); c.pos = uni(rd.pos);
+        c.L = uniu(rd.l_qseq); c.ncig = uniu(rd.n_cigar);
+        c.rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        c.ml_len = uniu(rd.ml_len);
+        const uint32_t mlen = uniu(rd.mm_len);
+        c.seq = p.seq + rd.seq_off;
+        c.ml = p.ml + rd.ml_off;
+        const uint8_t* mm = p.mm + rd.mm_off;
+        c.nblk = (c.L + 31u) >> 5;
+        c.hp = p.haplotypes ? (int)rd.hp : -1;
+        c.hpi = p.haplotypes ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
+        c.refw = p.refw;
+        uint32_t* sp = p.spill + (size_t)wave_slot * (2u * p.spill_cig + p.spill_blk);
+        c.spill_q = sp; c.spill_r = sp + p.spill_cig; c.spill_d = sp + 2u * p.spill_cig;
+        if (c.tid < 0 || c.tid >= p.n_contigs || p.ref_base[c.tid] < 0) {  // mod.c:793
+            if (lane == 0) { p.status[ridx] = MM_E_NOCONTIG; atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)MM_E_NOCONTIG); }
+            return;
+        }
+        c.ref_base = p.ref_base[c.tid];
+        c.seg_begin = p.seg_begin[c.tid]; c.seg_len = p.seg_len[c.tid]; c.cnt_base = p.cnt_base[c.tid];
+        scan_cigar(p.cigar + rd.cigar_off, p.ctg_len[c.tid]);
+        if (finish(ridx)) return;
+        c.cls = -1; c.nb = 0; c.ml_start = 0;
+
+        uint32_t mpos = 0;
+        while (mpos < mlen) {
+            // ---------------- a6 group header (mod.c:1003-1062)
+            uint32_t ci = mpos + lane;
+            int ch = ci < mlen ? (int)mm[ci] : 0;
+            int c0 = __shfl(ch, 0, 64), c1 = __shfl(ch, 1, 64);
+            if (!valid_base_char(c0)) { err = MM_E_MMBASE; break; }
+            int modbase = c0 == 'U' ? 'T' : c0;
+            int hl = 1;
+            if (mpos + 1 < mlen) {
+                if (c1 != '+' && c1 != '-') { err = MM_E_MMSTRAND; break; }
+                hl = 2;
+            }
+            bool stop = lane >= hl && (ci >= mlen || ch == ',' || ch == ';' || ch == '?' || ch == '.');
+            uint64_t sb = __ballot(stop);
+            int e = sb ? __ffsll((unsigned long long)sb) - 1 : 64;
+            int ncode = e - hl;
+            bool iscode = lane >= hl && lane < e;
+            bool dig = ch >= '0' && ch <= '9';
+            bool alp = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z');
+            if (__ballot(iscode && !dig && !alp)) { err = MM_E_MMCODE; break; }   // mod.c:1029-1032
+            if (e == 64 || ncode >= MM_CODE_LEN) { err = MM_E_MMCODE; break; }
+            bool has_nums = __ballot(iscode && dig) != 0, has_alpha = __ballot(iscode && alp) != 0;
+            int n = has_nums ? 1 : ncode;
+            if (n <= 0) { err = MM_E_MMEMPTY; break; }                              // mod.c:1053
+            if (has_nums && has_alpha) { err = MM_E_MMMIXED; break; }               // mod.c:1054
+            int flag = '.';
+            uint32_t cpos = mpos + e;
+            if (cpos < mlen) {
+                int ce = __shfl(ch, e, 64);
+                if (ce == '?' || ce == '.') { flag = ce; cpos++; }
+            }
+            // required-code lookup per code letter (mod.c:1146-1160): the C string starting at letter m
+            if (iscode) S.hdr[lane - hl] = (char)ch;
+            if (lane < 16) S.g_code[lane] = -1;
+            wave_sync();
+            {
+                int pairs = n * p.n_codes;
+                for (int p0 = 0; p0 < pairs; p0 += 64) {
+                    int pi = p0 + lane;
+                    if (pi < pairs) {
+                        int m = pi / p.n_codes, t = pi - m * p.n_codes;
+                        int slen = has_nums ? ncode : ncode - m;
+                        const DevCode& dc = p.codes[t];
+                        bool eq = dc.len == slen;
+                        for (int j = 0; eq && j < slen; j++) eq = dc.str[j] == S.hdr[m + j];
+                        if (eq) S.g_code[m] = (int16_t)t;
+                    }
+                }
+            }
+            wave_sync();
+            if (p.wildcard && lane < n && S.g_code[lane] < 0) err = MM_E_NOCODE;  // the host interns before submit
+            if (__ballot(err != 0)) break;
+            c.n_codes_grp = n;
+            int mb = c.rev ? complement_char(modbase) : modbase;
+            c.mb_is_N = mb == 'N';
+            c.direct = modbase == 'N';
+            int cls = base_class_of_char(mb);
+            bool dot = flag == '.';
+            if ((!c.direct || dot) && cls != c.cls) build_dir(cls);
+
+            // ---------------- a6 skip counts (mod.c:1064-1089), 64 characters per step
+            uint32_t k_carry = 0, rank_carry = 0, ntok = 0;
+            bool prev_delim = true, done = false;
+            while (!done) {
+                uint32_t cj = cpos + lane;
+                int x = cj < mlen ? (int)mm[cj] : ';';   // the end of the string closes the group
+                S.mm[lane] = (uint8_t)x;
+                if (lane < 16) { uint32_t ck = cpos + 64 + lane; S.mm[64 + lane] = ck < mlen ? mm[ck] : (uint8_t)';'; }
+                wave_sync();
+                uint64_t semi = __ballot(x == ';');
+                int endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
+                bool in = lane < endl;
+                int pv = __shfl_up(x, 1, 64);
+                bool pdel = lane == 0 ? prev_delim : (pv == ',');
+                bool tstart = in && x != ',' && pdel;
+                uint32_t v = 0;
+                if (tstart) {
+                    int j = 0;
+                    for (; j < 10; j++) {
+                        int d = S.mm[lane + j];
+                        if (d == ',' || d == ';') break;
+                        if (d < '0' || d > '9') { err = MM_E_SKIPVAL; break; }
+                        v = v * 10u + (uint32_t)(d - '0');
+                    }
+                    if (j == 10) err = MM_E_SKIPLEN;                                 // mod.c:1080
+                }
+                uint64_t tb = __ballot(tstart);
+                if (tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = v;
+                ntok += __popcll(tb);
+                wave_sync();
+                if (__ballot(err != 0)) { done = true; break; }
+                if (endl < 64) { done = true; cpos += endl + 1; }
+                else { cpos += 64; prev_delim = __shfl(x, 63, 64) == ','; }
+                while (ntok >= 64 || (done && ntok > 0)) {
+                    uint32_t cnt = ntok < 64u ? ntok : 64u;
+                    flush_tokens(cnt, rank_carry, k_carry, dot);
+                    uint32_t rem = ntok - cnt;
+                    uint32_t y = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
+                    wave_sync();
+                    if ((uint32_t)lane < rem) S.tok[lane] = y;
+                    wave_sync();
+                    ntok = rem;
+                }
+            }
+            if (__ballot(err != 0)) break;
+            if (k_carry > 0) c.ml_start += k_carry * (uint32_t)n;                    // mod.c:1200
+            if (dot) {  // bases after the last listed one (mod.c:1289-1365)
+                for (uint32_t r0 = rank_carry; r0 < c.nb; r0 += 64) {
+                    uint32_t rk = r0 + lane;
+                    if (rk < c.nb) process_call(rk, 0, false);
+                }
+            }
+            if (__ballot(err != 0)) break;
+            mpos = cpos;
+        }
+        finish(ridx);
+    }
+};
+
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_freq_reads(const DevParams p) {
+    __shared__ WaveLds lds[kWavesPerBlock];
+    const int wv = threadIdx.x >> 6;
+    const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
+    K1<RefWord> k(p, lds[wv]);
+    for (;;) {
+        int r = 0;
+        if (lane_id() == 0) r = (int)atomicAdd(p.queue, 1u);
+        r = uni(r);
+        if (r >= p.n_reads) break;
+        int ridx = p.order ? p.order[r] : r;
+        k.run(uni(ridx), wave_slot);
+    }
+}
+
+// ---------------------------------------------------------------------------------- K2
+// Stream compaction of non-zero counters, in position order, per (plane, strand) run.
+constexpr int kTile = 2048;
+__global__ __launch_bounds__(256) void k_count_nonzero(const unsigned long long* __restrict__ cnt, int64_t n,
+                                                       uint32_t* __restrict__ tile_counts) {
+    __shared__ uint32_t part[4];
+    int64_t base = (int64_t)blockIdx.x * kTile;
+    uint32_t c = 0;
+    for (int j = threadIdx.x; j < kTile; j += 256) {
+        int64_t i = base + j;
+        if (i < n && cnt[i] != 0ull) c++;
+    }
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+struct DenseRow { int64_t index; uint32_t n_called, n_mod; };  // index = flat index into the counter array
+__global__ __launch_bounds__(256) void k_emit_rows(const unsigned long long* __restrict__ cnt, int64_t n,
+                                                   const unsigned long long* __restrict__ tile_offsets,
+                                                   DenseRow* __restrict__ rows) {
+    __shared__ uint32_t wsum[4];
+    int64_t base = (int64_t)blockIdx.x * kTile;
+    unsigned long long out = tile_offsets[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < kTile; j0 += 256) {
+        int64_t i = base + j0 + threadIdx.x;
+        unsigned long long v = i < n ? cnt[i] : 0ull;
+        bool nz = v != 0ull;
+        uint64_t b = __ballot(nz);
+        if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wv; w++) before += wsum[w];
+        uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (nz) {
+            DenseRow r;
+            r.index = i; r.n_called = (uint32_t)v; r.n_mod = (uint32_t)(v >> 32);
+            rows[out + before + __popcll(b & ((1ull << lane) - 1ull))] = r;
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------- halo slabs
+__global__ void k_slab_export(const unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len,
+                              int n_runs, unsigned long long* __restrict__ dst) {
+    int64_t total = (int64_t)n_runs * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t run = i / len, j = i - run * len;
+        dst[i] = cnt[run * plane_len + off + j];
+    }
+}
+__global__ void k_slab_add(unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len,
+                           int n_runs, const unsigned long long* __restrict__ src) {
+    int64_t total = (int64_t)n_runs * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t run = i / len, j = i - run * len;
+        unsigned long long v = src[i];
+        if (v) {
+            unsigned long long a = cnt[run * plane_len + off + j];
+            // two independent 32-bit lanes (n_called, n_mod)
+            unsigned long long lo = (a & 0xFFFFFFFFull) + (v & 0xFFFFFFFFull);
+            unsigned long long hi = (a >> 32) + (v >> 32);
+            cnt[run * plane_len + off + j] = (lo & 0xFFFFFFFFull) | (hi << 32);
+        }
+    }
+}
+__global__ void k_slab_clear(unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len, int n_runs) {
+    int64_t total = (int64_t)n_runs * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t run = i / len, j = i - run * len;
+        cnt[run * plane_len + off + j] = 0ull;
+    }
+}
+
+}  // namespace mmhip

@@ -1,0 +1,302 @@
+"""ctypes mirror of include/minimod_hip.h (the drop-in boundary).  Argument meaning and error behaviour follow the
+reference seams cited in that header: create = load_ref + load_ref_contexts + init_core, submit = process_db,
+finalize = output_core."""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import build_hip, lib_path
+
+MM_ABI_VERSION = 1
+MM_MAX_MODS = 13
+MM_CODE_LEN = 16
+
+READ_DTYPE = np.dtype([
+    ("cigar_off", "<u8"), ("seq_off", "<u8"), ("mm_off", "<u8"), ("ml_off", "<u8"),
+    ("tid", "<i4"), ("pos", "<i4"), ("l_qseq", "<u4"), ("n_cigar", "<u4"),
+    ("mm_len", "<u4"), ("ml_len", "<u4"), ("flag", "<u2"), ("hp", "u1"), ("rsvd", "u1"),
+    ("rsvd2", "<u4"),
+])
+ROW_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("strand", "u1"), ("rsvd", "u1"), ("ins_offset", "<u2"),
+                      ("code", "<i2"), ("hp", "<i2"), ("n_called", "<u4"), ("n_mod", "<u4")])
+assert READ_DTYPE.itemsize == 64 and ROW_DTYPE.itemsize == 24
+
+
+class mm_batch_t(ctypes.Structure):
+    _fields_ = [("reads", ctypes.c_void_p), ("cigar", ctypes.c_void_p), ("seq", ctypes.c_void_p),
+                ("mm", ctypes.c_void_p), ("ml", ctypes.c_void_p), ("order", ctypes.c_void_p),
+                ("n_reads", ctypes.c_int32), ("rsvd", ctypes.c_int32),
+                ("n_cigar_words", ctypes.c_uint64), ("n_seq_bytes", ctypes.c_uint64),
+                ("n_mm_bytes", ctypes.c_uint64), ("n_ml_bytes", ctypes.c_uint64),
+                ("max_n_cigar", ctypes.c_uint32), ("max_l_qseq", ctypes.c_uint32)]
+
+
+class mm_mod_t(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_char * MM_CODE_LEN), ("context", ctypes.c_char * MM_CODE_LEN),
+                ("klass", ctypes.c_uint8 * 256)]
+
+
+class mm_freq_opts_t(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("n_mods", ctypes.c_int32), ("insertions", ctypes.c_int32),
+                ("haplotypes", ctypes.c_int32), ("device", ctypes.c_int32), ("n_hp_planes", ctypes.c_int32),
+                ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("rsvd", ctypes.c_int32),
+                ("mods", mm_mod_t * MM_MAX_MODS)]
+
+
+class mm_contig_t(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("length", ctypes.c_int64), ("seq", ctypes.c_void_p),
+                ("seq_length", ctypes.c_int64)]
+
+
+class mm_interval_t(ctypes.Structure):
+    _fields_ = [("tid", ctypes.c_int32), ("rsvd", ctypes.c_int32), ("begin", ctypes.c_int64),
+                ("end", ctypes.c_int64), ("halo", ctypes.c_int64)]
+
+
+EXPORTS = ["mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
+           "mm_freq_wait", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
+           "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
+           "mm_freq_last_kernel_ms", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
+
+_lib = None
+
+
+class MinimodHipError(RuntimeError):
+    def __init__(self, code, msg, read=None):
+        RuntimeError.__init__(self, msg)
+        self.code = code
+        self.read = read
+
+
+def load_library(build=True):
+    """Load the HIP library; fails loudly when it is missing (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build and not os.path.exists(path):
+        build_hip()
+    if not os.path.exists(path):
+        raise MinimodHipError(-1, "HIP extension %s is missing: run __graft_entry__.build()" % path)
+    L = ctypes.CDLL(path)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.mm_abi_version.restype = i32
+    L.mm_strerror.restype = ctypes.c_char_p
+    L.mm_strerror.argtypes = [i32]
+    L.mm_freq_create.restype = vp
+    L.mm_freq_create.argtypes = [ctypes.POINTER(mm_freq_opts_t), i32, ctypes.POINTER(mm_contig_t), i32,
+                                 ctypes.POINTER(mm_interval_t), ctypes.c_char_p, ctypes.c_size_t]
+    L.mm_freq_submit.restype = i32
+    L.mm_freq_submit.argtypes = [vp, ctypes.POINTER(mm_batch_t)]
+    L.mm_freq_submit_device.restype = i32
+    L.mm_freq_submit_device.argtypes = [vp, ctypes.POINTER(mm_batch_t), vp]
+    L.mm_freq_wait.restype = i32
+    L.mm_freq_wait.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.mm_freq_intern_code.restype = i32
+    L.mm_freq_intern_code.argtypes = [vp, ctypes.c_char_p]
+    L.mm_freq_n_codes.restype = i32
+    L.mm_freq_n_codes.argtypes = [vp]
+    L.mm_freq_code_name.restype = ctypes.c_char_p
+    L.mm_freq_code_name.argtypes = [vp, i32]
+    L.mm_freq_finalize.restype = i64
+    L.mm_freq_finalize.argtypes = [vp, ctypes.POINTER(vp)]
+    L.mm_freq_slab_words.restype = i64
+    L.mm_freq_slab_words.argtypes = [vp, i64]
+    for f in ("mm_freq_slab_export", "mm_freq_slab_add"):
+        getattr(L, f).restype = i32
+        getattr(L, f).argtypes = [vp, i32, i64, i64, vp, vp]
+    L.mm_freq_slab_clear.restype = i32
+    L.mm_freq_slab_clear.argtypes = [vp, i32, i64, i64, vp]
+    L.mm_freq_last_kernel_ms.restype = ctypes.c_float
+    L.mm_freq_last_kernel_ms.argtypes = [vp, i32]
+    L.mm_freq_device_bytes.restype = i64
+    L.mm_freq_device_bytes.argtypes = [vp]
+    L.mm_freq_reset_counters.argtypes = [vp]
+    L.mm_freq_destroy.argtypes = [vp]
+    if L.mm_abi_version() != MM_ABI_VERSION:
+        raise MinimodHipError(-1, "ABI version mismatch")
+    _lib = L
+    return L
+
+
+def klass_lut(thresh):
+    """The threshold rule of reference src/mod.c:56,1180-1191 for all 256 ML values, in double precision:
+    0 ambiguous, 1 called unmodified, 3 called modified."""
+    t = float(thresh)
+    out = np.zeros(256, dtype=np.uint8)
+    for x in range(256):
+        p = (x + 0.5) / 256.0
+        if p >= t:
+            out[x] = 3
+        elif p <= 1 - t:
+            out[x] = 1
+    return out
+
+
+def batch_struct(batch, order=None, device=False):
+    """numpy batch (dict with reads/cigar/seq/mm/ml) or dict of device pointers -> mm_batch_t."""
+    b = mm_batch_t()
+    if device:
+        for k in ("reads", "cigar", "seq", "mm", "ml"):
+            setattr(b, k, int(batch[k]))
+        b.order = int(batch.get("order", 0) or 0)
+        for k in ("n_reads", "n_cigar_words", "n_seq_bytes", "n_mm_bytes", "n_ml_bytes", "max_n_cigar", "max_l_qseq"):
+            setattr(b, k, int(batch[k]))
+        return b
+    rd = batch["reads"]
+    b.reads, b.cigar, b.seq = rd.ctypes.data, batch["cigar"].ctypes.data, batch["seq"].ctypes.data
+    b.mm, b.ml = batch["mm"].ctypes.data, batch["ml"].ctypes.data
+    b.order = order.ctypes.data if order is not None else 0
+    b.n_reads = len(rd)
+    b.n_cigar_words, b.n_seq_bytes = len(batch["cigar"]), len(batch["seq"])
+    b.n_mm_bytes, b.n_ml_bytes = len(batch["mm"]), len(batch["ml"])
+    b.max_n_cigar = int(rd["n_cigar"].max()) if len(rd) else 0
+    b.max_l_qseq = int(rd["l_qseq"].max()) if len(rd) else 0
+    return b
+
+
+class FreqEngine(object):
+    """One handle = one `minimod freq` run on one GPU.
+
+    mods: [(code, context, threshold)] as parse_mod_codes/parse_mod_threshes of the reference would produce;
+    contigs: [(name, target_len, raw_sequence_bytes_or_None)] in BAM-header (tid) order."""
+
+    def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
+                 n_hp_planes=0, side_capacity=0, n_wild_planes=0):
+        L = load_library()
+        if not (1 <= len(mods) <= MM_MAX_MODS):
+            raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
+        o = mm_freq_opts_t()
+        o.abi_version, o.n_mods = MM_ABI_VERSION, len(mods)
+        o.insertions, o.haplotypes, o.device = int(insertions), int(haplotypes), int(device)
+        o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
+        for i, (code, ctx, th) in enumerate(mods):
+            o.mods[i].code = code.encode()
+            o.mods[i].context = ctx.encode()
+            lut = klass_lut(th)
+            ctypes.memmove(o.mods[i].klass, lut.ctypes.data, 256)
+        self._keep = []
+        cs = (mm_contig_t * max(len(contigs), 1))()
+        self.names = []
+        for t, (name, length, seq) in enumerate(contigs):
+            self.names.append(name)
+            cs[t].name = name.encode()
+            cs[t].length = int(length)
+            if seq is not None:
+                arr = np.ascontiguousarray(np.frombuffer(seq, dtype=np.uint8) if not isinstance(seq, np.ndarray) else seq)
+                self._keep.append(arr)
+                cs[t].seq = arr.ctypes.data
+                cs[t].seq_length = len(arr)
+        ivs, n_iv = None, 0
+        if intervals:
+            n_iv = len(intervals)
+            ivs = (mm_interval_t * n_iv)()
+            for i, (tid, b, e, halo) in enumerate(intervals):
+                ivs[i].tid, ivs[i].begin, ivs[i].end, ivs[i].halo = int(tid), int(b), int(e), int(halo)
+        err = ctypes.create_string_buffer(512)
+        self.L = L
+        self.h = L.mm_freq_create(ctypes.byref(o), len(contigs), cs, n_iv, ivs, err, 512)
+        if not self.h:
+            raise MinimodHipError(-1, "mm_freq_create: " + err.value.decode(errors="replace"))
+        self._keep = []  # the reference has been uploaded
+        self.insertions, self.haplotypes = insertions, haplotypes
+        self.wildcard = any(c == "*" for c, _, _ in mods)
+
+    # -- batches
+    def intern_codes_from(self, batch):
+        """-c '*' only: scan MM group headers on the host so every code string has an index before the kernel."""
+        mm = batch["mm"]
+        for rd in batch["reads"]:
+            s = bytes(mm[int(rd["mm_off"]):int(rd["mm_off"]) + int(rd["mm_len"])])
+            for g in s.split(b";"):
+                if len(g) < 3:
+                    continue
+                j = 2
+                while j < len(g) and g[j:j + 1] not in (b",", b"?", b"."):
+                    j += 1
+                codes = g[2:j]
+                if not codes:
+                    continue
+                if codes.isdigit():
+                    self.L.mm_freq_intern_code(self.h, codes)
+                else:
+                    for m in range(len(codes)):
+                        self.L.mm_freq_intern_code(self.h, codes[m:])
+
+    def submit(self, batch, order=None):
+        if self.wildcard:
+            self.intern_codes_from(batch)
+        b = batch_struct(batch, order)
+        t = self.L.mm_freq_submit(self.h, ctypes.byref(b))
+        if t < 0:
+            raise MinimodHipError(-t, "mm_freq_submit: " + self.L.mm_strerror(t).decode())
+        return t
+
+    def submit_device(self, dev_batch, stream=None):
+        b = batch_struct(dev_batch, device=True)
+        t = self.L.mm_freq_submit_device(self.h, ctypes.byref(b), stream)
+        if t < 0:
+            raise MinimodHipError(-t, "mm_freq_submit_device: " + self.L.mm_strerror(t).decode())
+        return t
+
+    def wait(self, ticket):
+        bad = ctypes.c_int32(-1)
+        e = self.L.mm_freq_wait(self.h, ticket, ctypes.byref(bad))
+        if e:
+            raise MinimodHipError(e, "read %d: %s" % (bad.value, self.L.mm_strerror(e).decode()), bad.value)
+
+    def process(self, batch, order=None):
+        self.wait(self.submit(batch, order))
+
+    def kernel_ms(self, ticket):
+        return float(self.L.mm_freq_last_kernel_ms(self.h, ticket))
+
+    # -- results
+    def finalize(self):
+        p = ctypes.c_void_p()
+        n = self.L.mm_freq_finalize(self.h, ctypes.byref(p))
+        if n < 0:
+            raise MinimodHipError(-n, "mm_freq_finalize: " + self.L.mm_strerror(int(n)).decode())
+        if n == 0:
+            return np.zeros(0, dtype=ROW_DTYPE)
+        buf = (ctypes.c_char * (n * ROW_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+
+    def code_names(self):
+        return [self.L.mm_freq_code_name(self.h, i).decode() for i in range(self.L.mm_freq_n_codes(self.h))]
+
+    def reset(self):
+        self.L.mm_freq_reset_counters(self.h)
+
+    def device_bytes(self):
+        return int(self.L.mm_freq_device_bytes(self.h))
+
+    def slab_words(self, length):
+        return int(self.L.mm_freq_slab_words(self.h, length))
+
+    def slab_export(self, tid, begin, length, dst_ptr, stream=None):
+        r = self.L.mm_freq_slab_export(self.h, tid, begin, length, dst_ptr, stream)
+        if r:
+            raise MinimodHipError(-r, "slab_export failed")
+
+    def slab_add(self, tid, begin, length, src_ptr, stream=None):
+        r = self.L.mm_freq_slab_add(self.h, tid, begin, length, src_ptr, stream)
+        if r:
+            raise MinimodHipError(-r, "slab_add failed")
+
+    def slab_clear(self, tid, begin, length, stream=None):
+        r = self.L.mm_freq_slab_clear(self.h, tid, begin, length, stream)
+        if r:
+            raise MinimodHipError(-r, "slab_clear failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mm_freq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
