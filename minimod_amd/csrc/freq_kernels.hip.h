@@ -14,6 +14,11 @@
 // {n_called (low 32), n_mod (high 32)}, updated with ONE global_atomic_add_x2 per call.  This is integer
 // select/scan/scatter work: no MFMA, HBM- and latency-bound.
 #pragma once
+#ifdef MM_DEBUG
+#define MMDBG(...) do { unsigned long long _m = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll(_m) - 1) { printf("[exec %llx] ", _m); printf(__VA_ARGS__); } } while (0)
+#else
+#define MMDBG(...) do {} while (0)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -106,6 +111,9 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// value of lane `l` (wave-uniform l) as a wave-uniform scalar
+__device__ __forceinline__ int lane_val(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ uint32_t lane_valu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l)); }
 
 // ---------------------------------------------------------------------------------- nibble helpers
 // bit 4n+3 of the result is set iff nibble n of x equals nib
@@ -253,7 +261,7 @@ struct K1 {
             if (act && op == 5u) err = MM_E_HARDCLIP;                     // mod.c:841-844
             else if (act && (op == 6u || op > 8u)) err = MM_E_CIGAROP;    // mod.c:845-848
             uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
-            uint32_t qtot = __shfl(qs, 63, 64), rtot = __shfl(rs, 63, 64);
+            uint32_t qtot = lane_valu(qs, 63), rtot = lane_valu(rs, 63);
             qs = carry_q + qs - qinc;
             rs = carry_r + rs - rinc;
             bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
@@ -299,7 +307,7 @@ struct K1 {
                 }
             }
             uint32_t incl = wave_incl_scan(cnt);
-            uint32_t tot = __shfl(incl, 63, 64);
+            uint32_t tot = lane_valu(incl, 63);
             if (b < c.nblk) {
                 uint32_t ex = carry + incl - cnt;
                 if (b < (uint32_t)kDirCap) S.dir[b] = ex; else c.spill_d[b - kDirCap] = ex;
@@ -450,12 +458,12 @@ struct K1 {
         bool act = (uint32_t)lane < cnt;
         uint32_t s = act ? S.tok[lane] : 0u;
         uint32_t incl = wave_incl_scan(act ? s + 1u : 0u);
-        uint32_t tot = __shfl(incl, 63, 64);
+        uint32_t tot = lane_valu(incl, 63);
         uint32_t rank = rank_carry + incl - 1u;
         if (act) process_call(rank, k_carry + lane, true);
         if (dot) {
             uint32_t gi = wave_incl_scan(s);
-            uint32_t T = __shfl(gi, 63, 64);
+            uint32_t T = lane_valu(gi, 63);
             S.gap[lane] = gi - s;
             S.gstart[lane] = rank - s;
             wave_sync();
@@ -477,18 +485,17 @@ struct K1 {
         k_carry += cnt;
     }
 
-    __device__ int finish(int ridx) {
+    // wave-uniform error code of the read so far (0 = none); no side effects
+    __device__ __forceinline__ int any_err() const {
         uint64_t eb = __ballot(err != 0);
-        if (eb) {
-            int e = __shfl(err, __ffsll((unsigned long long)eb) - 1, 64);
-            if (lane_id() == 0) { p.status[ridx] = e; atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e); }
-            return e;
-        }
-        return 0;
+        int l = eb ? __ffsll((unsigned long long)eb) - 1 : 0;
+        int e = lane_val(err, l);
+        return eb ? e : 0;
     }
 
     // ---- freq_view_single (mod.c:948-1370) for one read
-    __device__ void run(int ridx, int wave_slot) {
+    // Returns the read's status code (wave-uniform).  Single exit, no early returns: the caller reports errors.
+    __device__ int run(int ridx, int wave_slot) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         err = 0;
@@ -506,27 +513,34 @@ struct K1 {
         c.refw = p.refw;
         uint32_t* sp = p.spill + (size_t)wave_slot * (2u * p.spill_cig + p.spill_blk);
         c.spill_q = sp; c.spill_r = sp + p.spill_cig; c.spill_d = sp + 2u * p.spill_cig;
-        if (c.tid < 0 || c.tid >= p.n_contigs || p.ref_base[c.tid] < 0) {  // mod.c:793
-            if (lane == 0) { p.status[ridx] = MM_E_NOCONTIG; atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)MM_E_NOCONTIG); }
-            return;
-        }
+        int result = 0;
+        bool have_ref = c.tid >= 0 && c.tid < p.n_contigs;
+        if (have_ref) have_ref = p.ref_base[c.tid] >= 0;
+        if (!have_ref) {  // mod.c:793
+            result = MM_E_NOCONTIG;
+        } else {
         c.ref_base = p.ref_base[c.tid];
         c.seg_begin = p.seg_begin[c.tid]; c.seg_len = p.seg_len[c.tid]; c.cnt_base = p.cnt_base[c.tid];
         scan_cigar(p.cigar + rd.cigar_off, p.ctg_len[c.tid]);
-        if (finish(ridx)) return;
+        result = any_err();
         c.cls = -1; c.nb = 0; c.ml_start = 0;
-
+        if (result == 0) {
+        // Control flow below is kept wave-uniform and free of `break`: every exit condition is folded into
+        // `bad` (a ballot over the lanes' err), which the loop headers test.  (A version with divergent-looking
+        // breaks out of the nested loops hung on gfx950 when an error was raised inside the MM loop.)
         uint32_t mpos = 0;
-        while (mpos < mlen) {
+        bool bad = false;
+        while (mpos < mlen && !bad) {
             // ---------------- a6 group header (mod.c:1003-1062)
             uint32_t ci = mpos + lane;
             int ch = ci < mlen ? (int)mm[ci] : 0;
-            int c0 = __shfl(ch, 0, 64), c1 = __shfl(ch, 1, 64);
-            if (!valid_base_char(c0)) { err = MM_E_MMBASE; break; }
+            int c0 = lane_val(ch, 0), c1 = lane_val(ch, 1);
+            int herr = 0;
+            if (!valid_base_char(c0)) herr = MM_E_MMBASE;
             int modbase = c0 == 'U' ? 'T' : c0;
             int hl = 1;
             if (mpos + 1 < mlen) {
-                if (c1 != '+' && c1 != '-') { err = MM_E_MMSTRAND; break; }
+                if (c1 != '+' && c1 != '-') herr = herr ? herr : MM_E_MMSTRAND;
                 hl = 2;
             }
             bool stop = lane >= hl && (ci >= mlen || ch == ',' || ch == ';' || ch == '?' || ch == '.');
@@ -536,103 +550,122 @@ struct K1 {
             bool iscode = lane >= hl && lane < e;
             bool dig = ch >= '0' && ch <= '9';
             bool alp = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z');
-            if (__ballot(iscode && !dig && !alp)) { err = MM_E_MMCODE; break; }   // mod.c:1029-1032
-            if (e == 64 || ncode >= MM_CODE_LEN) { err = MM_E_MMCODE; break; }
             bool has_nums = __ballot(iscode && dig) != 0, has_alpha = __ballot(iscode && alp) != 0;
             int n = has_nums ? 1 : ncode;
-            if (n <= 0) { err = MM_E_MMEMPTY; break; }                              // mod.c:1053
-            if (has_nums && has_alpha) { err = MM_E_MMMIXED; break; }               // mod.c:1054
-            int flag = '.';
-            uint32_t cpos = mpos + e;
-            if (cpos < mlen) {
-                int ce = __shfl(ch, e, 64);
-                if (ce == '?' || ce == '.') { flag = ce; cpos++; }
-            }
-            // required-code lookup per code letter (mod.c:1146-1160): the C string starting at letter m
-            if (iscode) S.hdr[lane - hl] = (char)ch;
-            if (lane < 16) S.g_code[lane] = -1;
-            wave_sync();
-            {
-                int pairs = n * p.n_codes;
-                for (int p0 = 0; p0 < pairs; p0 += 64) {
-                    int pi = p0 + lane;
-                    if (pi < pairs) {
-                        int m = pi / p.n_codes, t = pi - m * p.n_codes;
-                        int slen = has_nums ? ncode : ncode - m;
-                        const DevCode& dc = p.codes[t];
-                        bool eq = dc.len == slen;
-                        for (int j = 0; eq && j < slen; j++) eq = dc.str[j] == S.hdr[m + j];
-                        if (eq) S.g_code[m] = (int16_t)t;
+            if (!herr && __ballot(iscode && !dig && !alp)) herr = MM_E_MMCODE;      // mod.c:1029-1032
+            if (!herr && (e == 64 || ncode >= MM_CODE_LEN)) herr = MM_E_MMCODE;
+            if (!herr && n <= 0) herr = MM_E_MMEMPTY;                                // mod.c:1053
+            if (!herr && has_nums && has_alpha) herr = MM_E_MMMIXED;                 // mod.c:1054
+            herr = uni(herr);
+            if (herr) {
+                err = herr;
+                bad = true;
+            } else {
+                int flag = '.';
+                uint32_t cpos = mpos + e;
+                if (cpos < mlen) {
+                    int ce = lane_val(ch, e);
+                    if (ce == '?' || ce == '.') { flag = ce; cpos++; }
+                }
+                // required-code lookup per code letter (mod.c:1146-1160): the C string starting at letter m
+                if (iscode) S.hdr[lane - hl] = (char)ch;
+                if (lane < 16) S.g_code[lane] = -1;
+                wave_sync();
+                {
+                    int pairs = n * p.n_codes;
+                    for (int p0 = 0; p0 < pairs; p0 += 64) {
+                        int pi = p0 + lane;
+                        if (pi < pairs) {
+                            int m = pi / p.n_codes, t = pi - m * p.n_codes;
+                            int slen = has_nums ? ncode : ncode - m;
+                            const DevCode& dc = p.codes[t];
+                            bool eq = dc.len == slen;
+                            for (int j = 0; j < slen; j++) eq = eq && (dc.str[j & (MM_CODE_LEN - 1)] == S.hdr[(m + j) & 15]);
+                            if (eq) S.g_code[m] = (int16_t)t;
+                        }
                     }
                 }
-            }
-            wave_sync();
-            if (p.wildcard && lane < n && S.g_code[lane] < 0) err = MM_E_NOCODE;  // the host interns before submit
-            if (__ballot(err != 0)) break;
-            c.n_codes_grp = n;
-            int mb = c.rev ? complement_char(modbase) : modbase;
-            c.mb_is_N = mb == 'N';
-            c.direct = modbase == 'N';
-            int cls = base_class_of_char(mb);
-            bool dot = flag == '.';
-            if ((!c.direct || dot) && cls != c.cls) build_dir(cls);
+                wave_sync();
+                if (p.wildcard && lane < n && S.g_code[lane] < 0) err = MM_E_NOCODE;  // the host interns before submit
+                bad = __ballot(err != 0) != 0;
+                c.n_codes_grp = n;
+                int mb = c.rev ? complement_char(modbase) : modbase;
+                c.mb_is_N = mb == 'N';
+                c.direct = modbase == 'N';
+                int cls = base_class_of_char(mb);
+                bool dot = flag == '.';
+                if (!bad && (!c.direct || dot) && cls != c.cls) build_dir(cls);
 
-            // ---------------- a6 skip counts (mod.c:1064-1089), 64 characters per step
-            uint32_t k_carry = 0, rank_carry = 0, ntok = 0;
-            bool prev_delim = true, done = false;
-            while (!done) {
-                uint32_t cj = cpos + lane;
-                int x = cj < mlen ? (int)mm[cj] : ';';   // the end of the string closes the group
-                S.mm[lane] = (uint8_t)x;
-                if (lane < 16) { uint32_t ck = cpos + 64 + lane; S.mm[64 + lane] = ck < mlen ? mm[ck] : (uint8_t)';'; }
-                wave_sync();
-                uint64_t semi = __ballot(x == ';');
-                int endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
-                bool in = lane < endl;
-                int pv = __shfl_up(x, 1, 64);
-                bool pdel = lane == 0 ? prev_delim : (pv == ',');
-                bool tstart = in && x != ',' && pdel;
-                uint32_t v = 0;
-                if (tstart) {
-                    int j = 0;
-                    for (; j < 10; j++) {
-                        int d = S.mm[lane + j];
-                        if (d == ',' || d == ';') break;
-                        if (d < '0' || d > '9') { err = MM_E_SKIPVAL; break; }
-                        v = v * 10u + (uint32_t)(d - '0');
+                // ---------------- a6 skip counts (mod.c:1064-1089), 64 characters per step
+                uint32_t k_carry = 0, rank_carry = 0, ntok = 0;
+                bool prev_delim = true, done = bad;
+                while (!done) {
+                    uint32_t cj = cpos + lane;
+                    int x = cj < mlen ? (int)mm[cj] : ';';   // the end of the string closes the group
+                    S.mm[lane] = (uint8_t)x;
+                    if (lane < 16) { uint32_t ck = cpos + 64 + lane; S.mm[64 + lane] = ck < mlen ? mm[ck] : (uint8_t)';'; }
+                    wave_sync();
+                    uint64_t semi = __ballot(x == ';');
+                    int endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
+                    bool in = lane < endl;
+                    int pv = __shfl_up(x, 1, 64);
+                    bool pdel = lane == 0 ? prev_delim : (pv == ',');
+                    bool tstart = in && x != ',' && pdel;
+                    uint32_t v = 0;
+                    if (tstart) {
+                        // decimal fold over at most 10 look-ahead characters, no early exit (mod.c:1074-1084)
+                        bool open = true;
+                        int len = 0;
+#pragma unroll
+                        for (int j = 0; j < 10; j++) {
+                            int d = S.mm[lane + j];
+                            bool delim = d == ',' || d == ';';
+                            open = open && !delim;
+                            if (open) {
+                                if (d < '0' || d > '9') err = MM_E_SKIPVAL;
+                                v = v * 10u + (uint32_t)(d - '0');
+                                len++;
+                            }
+                        }
+                        if (len == 10) err = MM_E_SKIPLEN;                             // assert(l < 10), mod.c:1080
                     }
-                    if (j == 10) err = MM_E_SKIPLEN;                                 // mod.c:1080
+                    uint64_t tb = __ballot(tstart);
+                    if (tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = v;
+                    ntok += __popcll(tb);
+                    wave_sync();
+                    bad = __ballot(err != 0) != 0;
+                    if (endl < 64) { done = true; cpos += endl + 1; }
+                    else { cpos += 64; prev_delim = lane_val(x, 63) == ','; }
+                    if (bad) { done = true; ntok = 0; }
+                    while (ntok >= 64 || (done && ntok > 0)) {
+                        uint32_t cnt = ntok < 64u ? ntok : 64u;
+                        flush_tokens(cnt, rank_carry, k_carry, dot);
+                        uint32_t rem = ntok - cnt;
+                        uint32_t y = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
+                        wave_sync();
+                        if ((uint32_t)lane < rem) S.tok[lane] = y;
+                        wave_sync();
+                        ntok = rem;
+                        if (__ballot(err != 0)) { bad = true; done = true; ntok = 0; }
+                    }
                 }
-                uint64_t tb = __ballot(tstart);
-                if (tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = v;
-                ntok += __popcll(tb);
-                wave_sync();
-                if (__ballot(err != 0)) { done = true; break; }
-                if (endl < 64) { done = true; cpos += endl + 1; }
-                else { cpos += 64; prev_delim = __shfl(x, 63, 64) == ','; }
-                while (ntok >= 64 || (done && ntok > 0)) {
-                    uint32_t cnt = ntok < 64u ? ntok : 64u;
-                    flush_tokens(cnt, rank_carry, k_carry, dot);
-                    uint32_t rem = ntok - cnt;
-                    uint32_t y = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
-                    wave_sync();
-                    if ((uint32_t)lane < rem) S.tok[lane] = y;
-                    wave_sync();
-                    ntok = rem;
+                if (!bad) {
+                    if (k_carry > 0) c.ml_start += k_carry * (uint32_t)n;                // mod.c:1200
+                    if (dot) {  // bases after the last listed one (mod.c:1289-1365)
+                        for (uint32_t r0 = rank_carry; r0 < c.nb; r0 += 64) {
+                            uint32_t rk = r0 + lane;
+                            if (rk < c.nb) process_call(rk, 0, false);
+                        }
+                    }
+                    bad = __ballot(err != 0) != 0;
+                    mpos = cpos;
                 }
             }
-            if (__ballot(err != 0)) break;
-            if (k_carry > 0) c.ml_start += k_carry * (uint32_t)n;                    // mod.c:1200
-            if (dot) {  // bases after the last listed one (mod.c:1289-1365)
-                for (uint32_t r0 = rank_carry; r0 < c.nb; r0 += 64) {
-                    uint32_t rk = r0 + lane;
-                    if (rk < c.nb) process_call(rk, 0, false);
-                }
-            }
-            if (__ballot(err != 0)) break;
-            mpos = cpos;
         }
-        finish(ridx);
+        result = any_err();
+        }  // cigar ok
+        }  // have_ref
+        return result;
     }
 };
 
@@ -648,7 +681,12 @@ __global__ __launch_bounds__(256) void k_freq_reads(const DevParams p) {
         r = uni(r);
         if (r >= p.n_reads) break;
         int ridx = p.order ? p.order[r] : r;
-        k.run(uni(ridx), wave_slot);
+        ridx = uni(ridx);
+        int e = uni(k.run(ridx, wave_slot));
+        if (e != 0 && lane_id() == 0) {
+            p.status[ridx] = e;
+            atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
+        }
     }
 }
 

@@ -93,7 +93,7 @@ ERR_CASES = [
     (pybam.make_record(0, 2, 0, "CGTT", "4M", "X+m?,0;", [255]), 3),
     (pybam.make_record(0, 2, 0, "CGTT", "4M", "C*m?,0;", [255]), 4),
     (pybam.make_record(0, 2, 0, "CGTT", "4M", "C+m?,0,0;", [255]), 10),       # more calls than C bases
-    (pybam.make_record(0, 2, 0, "CGTTCG", "6M", "C+m?,0,1;", [255]), 11),     # ML shorter than MM
+    (pybam.make_record(0, 2, 0, "CGTTCG", "6M", "C+m?,0,0;", [255]), 11),     # ML shorter than MM
     (pybam.make_record(0, 2, 0, "CGTT", "4M", "C+m?,1234567890;", [255]), 8),
     (pybam.make_record(0, 28, 0, "CGTT", "4M", "C+m?,0;", [255]), 13),        # runs off the contig
 ]
