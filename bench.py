@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py -- `minimod freq` hot path on MI355X: Mbases/s on synthetic ONT-shape reads.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run with one
+rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1], "C2"): 100k ONT-shape reads (~15 kb) on one ~50 Mb reference interval per GPU,
+5mC `-c m[CG] -m 0.8`, -K 4096.  A "step" is one -K 4096 batch through the hot path (kernel K1) with the batch
+already resident in HBM; steps cycle over the 25 resident batches of the rank's shard.  N>1 is WEAK scaling: every rank
+owns its own 50 Mb interval of one long contig with its own 100k reads (reads routed by start position, SURVEY.md
+section 8e); the only exchange is one halo-slab send/recv to the right neighbour (RCCL) inside the timed region.
+
+`roofline.achieved` = algorithmic bytes per K1 launch / mean K1 duration from HIP events recorded by the library on the
+launch stream; algorithmic bytes follow SURVEY.md section 8(d):
+    B_read = 40 + 4*n_cigar + ceil(l_qseq/2) + |MM| + |ML| + 2*n_lookups + 16*n_updates
+with n_lookups / n_updates tallied by the kernel itself in an untimed pass.
+`cpu_baseline` = the oracle (oracle/freq_oracle.c, a bit-exact CPU restatement of the reference's algorithm: the
+reference binary itself needs htslib, which this image lacks) on a bounded sample of the same batches, kind "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INTERVAL = 48 << 20          # 50,331,648 positions per GPU ("one 50 Mb contig")
+HALO = 1 << 18               # counters kept past the right edge of an interval
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="-K")
+    ap.add_argument("--seed", type=int, default=0x5EED)
+    ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = choose for ~15 s of CPU work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
+    ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
+    return ap.parse_args()
+
+
+def shard_plan(rank, world):
+    """Owned interval, halo and contig length for a rank (pure function, covered by the CPU tests)."""
+    contig_len = world * INTERVAL + HALO
+    begin = rank * INTERVAL
+    end = (rank + 1) * INTERVAL if rank < world - 1 else contig_len
+    halo = HALO if rank < world - 1 else 0
+    return {"contig_len": contig_len, "begin": begin, "end": end, "halo": halo,
+            "read_begin": begin, "read_len": INTERVAL}
+
+
+def exchange_halos(rank, world, export_fn, add_fn, make_buf, dist):
+    """Send my halo slab to rank+1, add the slab received from rank-1.  export_fn(buf) fills buf with my halo slab,
+    add_fn(buf) adds a received slab into my planes; make_buf() allocates a slab tensor.  Works with any
+    torch.distributed backend (RCCL on GPUs, gloo in the CPU tests)."""
+    if world == 1:
+        return
+    ops = []
+    send = recv = None
+    if rank < world - 1:
+        send = make_buf()
+        export_fn(send)
+        ops.append(dist.P2POp(dist.isend, send, rank + 1))
+    if rank > 0:
+        recv = make_buf()
+        ops.append(dist.P2POp(dist.irecv, recv, rank - 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if recv is not None:
+        add_fn(recv)
+
+
+def algorithmic_bytes(reads, lookups, updates):
+    """bytes the path must touch, summed over a batch."""
+    n = len(reads)
+    return int(40 * n + 4 * int(reads["n_cigar"].sum()) + int(((reads["l_qseq"].astype(np.int64) + 1) // 2).sum()) +
+               int(reads["mm_len"].sum()) + int(reads["ml_len"].sum()) + 2 * lookups + 16 * updates)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import minimod_amd
+    from minimod_amd import synth
+
+    plan = shard_plan(rank, world)
+    t0 = time.time()
+    # every rank generates the reference of its own interval (+ halo + one read span past it); the rest stays 'N'
+    ref = np.full(plan["contig_len"], ord("N"), dtype=np.uint8)
+    g_end = min(plan["contig_len"], plan["end"] + plan["halo"] + (1 << 20))
+    ref[plan["begin"]:g_end] = synth.reference_slice(args.seed, plan["begin"], g_end - plan["begin"])
+    n_batches = (args.reads + args.batch - 1) // args.batch
+
+    def gen(bi):
+        first = bi * args.batch
+        n = min(args.batch, args.reads - first)
+        return synth.batch(ref, first, n, seed=args.seed + 7919 * rank, contig_len=plan["contig_len"],
+                           n_reads_total=args.reads, region_begin=plan["read_begin"], region_len=plan["read_len"])
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        host_batches = list(ex.map(gen, range(n_batches)))
+    t_gen = time.time() - t0
+
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank,
+                                 intervals=[(0, plan["begin"], plan["end"], plan["halo"])])
+    # ---- make the batches resident in HBM (torch owns the memory: plumbing only)
+    dev_batches = []
+    keep = []
+    for hb in host_batches:
+        d = {}
+        for k in ("reads", "cigar", "seq", "mm", "ml"):
+            t = torch.from_numpy(hb[k].view(np.uint8).reshape(-1)).to(dev)
+            keep.append(t)
+            d[k] = t.data_ptr()
+        if hb["order"] is not None and not args.natural_order:
+            t = torch.from_numpy(hb["order"].view(np.uint8).reshape(-1)).to(dev)
+            keep.append(t)
+            d["order"] = t.data_ptr()
+        d.update(n_reads=len(hb["reads"]), n_cigar_words=len(hb["cigar"]), n_seq_bytes=len(hb["seq"]),
+                 n_mm_bytes=len(hb["mm"]), n_ml_bytes=len(hb["ml"]), max_n_cigar=hb["max_n_cigar"],
+                 max_l_qseq=hb["max_l_qseq"])
+        dev_batches.append(d)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=dev)   # one explicit HIP stream carries every K1 launch
+    stream = tstream.cuda_stream
+    batch_bases = [hb["n_bases"] for hb in host_batches]
+
+    # ---- untimed tally pass: lookups/updates per batch for the algorithmic-bytes figure
+    eng.stats_enable(True)
+    alg_bytes = []
+    for hb, db in zip(host_batches, dev_batches):
+        eng.wait(eng.submit_device(db, stream))
+        st = eng.stats_get()
+        alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], st["dense_updates"] + st["side_updates"]))
+    eng.stats_enable(False)
+    eng.reset()
+
+    def run_steps(n, first_step=0):
+        tickets, bases, kms, abytes = [], 0, [], 0
+        for s in range(n):
+            bi = (first_step + s) % n_batches
+            t = eng.submit_device(dev_batches[bi], stream)
+            tickets.append((t, bi))
+            bases += batch_bases[bi]
+            abytes += alg_bytes[bi]
+            if len(tickets) >= 3:   # the library has 4 slots; keep the host a few launches ahead of the device
+                tk, _ = tickets.pop(0)
+                eng.wait(tk)
+                kms.append(eng.kernel_ms(tk))
+        for tk, _ in tickets:
+            eng.wait(tk)
+            kms.append(eng.kernel_ms(tk))
+        return bases, kms, abytes
+
+    # ---- warm-up, then the timed region: barrier + sync on both sides, max over ranks
+    run_steps(args.warmup)
+    eng.reset()
+    slab_words = eng.slab_words(HALO)
+
+    def make_buf():
+        return torch.empty(slab_words, dtype=torch.int64, device=dev)
+
+    def export_fn(buf):
+        eng.slab_export(0, plan["end"], plan["halo"], buf.data_ptr(), stream)
+        eng.slab_clear(0, plan["end"], plan["halo"], stream)
+
+    def add_fn(buf):
+        eng.slab_add(0, plan["begin"], HALO, buf.data_ptr(), stream)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bases, kms, abytes = run_steps(args.steps, first_step=args.warmup)
+    exchange_halos(rank, world, export_fn, add_fn, make_buf, dist)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([bases], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = int(tb.item())
+    else:
+        total_bases = bases
+
+    result = None
+    if rank == 0:
+        mean_ms = float(np.mean(kms))
+        achieved = (abytes / len(kms)) / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "minimod freq Mbases/sec", "value": total_bases / elapsed / 1e6, "unit": "Mbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "C2: %d ONT-shape reads (~15 kb) per GPU on a %.1f Mb interval, -c m[CG] -m 0.8, -K %d, "
+                                   "batches resident in HBM" % (args.reads, INTERVAL / 1e6, args.batch),
+                       "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(
+                           np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches]))),
+                       "sharding": "interval per GPU + halo slab to the right neighbour" if world > 1 else "single GPU",
+                       "read_order": "natural" if args.natural_order else "longest first"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_freq_reads",
+                         "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms),
+                         "bytes_per_base": abytes / max(bases, 1)},
+            "gen_seconds": t_gen,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, host_batches, plan, ref)
+        if args.verify:
+            result["verify"] = verify(host_batches[:2], plan, ref, local_rank)
+        print(json.dumps(result))
+        sys.stdout.flush()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(args, host_batches, plan, ref):
+    """The oracle (bit-exact CPU restatement) timed on this host's cores over a bounded sample of the same batches."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    n = args.cpu_sample_batches
+    t0 = time.perf_counter()
+    orc.process(host_batches[0], threads=cores)
+    t1 = time.perf_counter() - t0
+    bases = host_batches[0]["n_bases"]
+    total_t = t1
+    if n == 0:
+        n = int(max(1, min(len(host_batches), round(15.0 / max(t1, 1e-3)))))
+    for hb in host_batches[1:n]:
+        t0 = time.perf_counter()
+        orc.process(hb, threads=cores)
+        total_t += time.perf_counter() - t0
+        bases += hb["n_bases"]
+    orc.close()
+    return {"value": bases / total_t / 1e6, "unit": "Mbases/s", "cores": cores, "kind": "port",
+            "sample": "first %d of %d -K %d batches (%d bases), oracle/freq_oracle.c with %d threads, process step only"
+                      % (min(n, len(host_batches)), len(host_batches), args.batch, bases, cores)}
+
+
+def verify(batches, plan, ref, device):
+    import minimod_amd
+    from oracle import oracle as O
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=device)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    for hb in batches:
+        eng.process(hb, hb.get("order"))
+        orc.process(hb, threads=os.cpu_count() or 1)
+    got, want = eng.finalize(), orc.rows()
+    eng.close()
+    ok = (len(got) == len(want) and (got["pos"] == want["pos"]).all() and (got["strand"] == want["strand"]).all() and
+          (got["n_called"] == want["n_called"]).all() and (got["n_mod"] == want["n_mod"]).all())
+    return {"rows": int(len(got)), "bit_exact": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()

@@ -176,6 +176,10 @@ int32_t mm_freq_slab_clear(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len
 /* Measurement hooks (bench.py): device time of the last K1 launch of a ticket in milliseconds (HIP events on
  * the launch stream), and the number of K1 launches so far. */
 float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
+/* Work tallies for the algorithmic-bytes figure: enable!=0 makes K1 count reference-word
+ * lookups, ML bytes read, dense counter updates and side-list updates; get copies and clears the four totals. */
+int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
+int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[4]);
 int64_t mm_freq_device_bytes(const mm_freq_t *h);
 
 void mm_freq_reset_counters(mm_freq_t *h);

@@ -67,6 +67,8 @@ struct mm_freq {
     SideRec* d_side = nullptr;
     unsigned long long* d_side_count = nullptr;
     int64_t side_cap = 0;
+    unsigned long long* d_stats = nullptr;
+    bool stats_on = false;
     Slot slots[kSlots];
     int next_slot = 0;
     hipStream_t stream = nullptr;  // set-up / finalize stream
@@ -135,6 +137,7 @@ DevParams base_params(mm_freq* h) {
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
+    p.stats = h->stats_on ? h->d_stats : nullptr;
     return p;
 }
 
@@ -227,7 +230,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
-                  h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_tile_counts, h->d_tile_offsets, h->d_rows};
+                  h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows};
     for (void* p : ps) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -307,6 +310,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
+    if (dev_alloc(h, (void**)&h->d_stats, 4 * sizeof(unsigned long long))) return fail(h, "alloc failed");
+    (void)hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long));
     h->codes_dirty = !h->codes.empty();
     // ---- contigs: reference words for every contig that has a sequence; counter segments
     h->n_contigs = n_contigs;
@@ -485,6 +490,20 @@ float mm_freq_last_kernel_ms(mm_freq_t* h, int32_t ticket) {
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, h->slots[ticket].ev_start, h->slots[ticket].ev_stop) != hipSuccess) return -1.f;
     return ms;
+}
+
+int32_t mm_freq_stats_enable(mm_freq_t* h, int32_t enable) {
+    if (!h) return -MM_E_ARG;
+    h->stats_on = enable != 0;
+    return 0;
+}
+int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[4]) {
+    if (!h || !out) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long)));
+    return 0;
 }
 
 int64_t mm_freq_device_bytes(const mm_freq_t* h) { return h ? h->device_bytes : 0; }

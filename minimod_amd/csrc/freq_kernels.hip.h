@@ -88,6 +88,7 @@ struct DevParams {
     SideRec* side;
     unsigned long long* side_count;
     unsigned long long side_cap;
+    unsigned long long* stats;     // optional [4]: reference-word lookups, ML bytes read, dense updates, side updates
     // scheduling / scratch
     unsigned int* queue;
     uint32_t* spill;               // per wave slot: [max_cig] q, [max_cig] r, [max_blk] dir
@@ -239,8 +240,9 @@ struct K1 {
     WaveLds& S;
     ReadCtx c;
     int err;
+    uint32_t st_look, st_ml, st_dense, st_side;  // per-lane tallies, flushed once per read when p.stats is set
 
-    __device__ K1(const DevParams& p_, WaveLds& s_) : p(p_), S(s_), err(0) {}
+    __device__ K1(const DevParams& p_, WaveLds& s_) : p(p_), S(s_), err(0), st_look(0), st_ml(0), st_dense(0), st_side(0) {}
 
     __device__ __forceinline__ uint32_t cq(uint32_t i) const { return i < (uint32_t)kCigCap ? S.cig_q[i] : c.spill_q[i - kCigCap]; }
     __device__ __forceinline__ uint32_t cr(uint32_t i) const { return i < (uint32_t)kCigCap ? S.cig_r[i] : c.spill_r[i - kCigCap]; }
@@ -422,6 +424,7 @@ struct K1 {
         if (ref_pos < 0) return;
         const RefWord* rw = reinterpret_cast<const RefWord*>(c.refw);
         uint32_t w = (uint32_t)rw[c.ref_base + ref_pos];
+        st_look++;
         uint32_t refcode = w & 31u;
         for (int m = 0; m < c.n_codes_grp; m++) {
             int ci = S.g_code[m];
@@ -438,6 +441,7 @@ struct K1 {
                 uint64_t ml_idx = (uint64_t)c.ml_start + (uint64_t)k * c.n_codes_grp + m;
                 if (ml_idx >= c.ml_len) { err = MM_E_MLIDX; return; }  // mod.c:1174
                 uint32_t kl = p.mods[req].klass[c.ml[ml_idx]];
+                st_ml++;
                 if (kl == 0) continue;
                 is_mod = kl == 3;
             }
@@ -446,8 +450,10 @@ struct K1 {
                 unsigned long long* dst = p.counters +
                     ((int64_t)(dc.plane * p.n_hp + c.hpi) * 2 + c.rev) * p.plane_len + c.cnt_base + off;
                 atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+                st_dense++;
             } else {
                 side_append((int32_t)ref_pos, ins_off, is_mod, ci);
+                st_side++;
             }
         }
     }
@@ -483,6 +489,17 @@ struct K1 {
         }
         rank_carry += tot;
         k_carry += cnt;
+    }
+
+    __device__ void flush_stats() {
+        uint32_t v[4] = {st_look, st_ml, st_dense, st_side};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t x = wave_incl_scan(v[i]);
+            uint32_t t = lane_valu(x, 63);
+            if (lane_id() == 0 && t) atomicAdd(p.stats + i, (unsigned long long)t);
+        }
+        st_look = st_ml = st_dense = st_side = 0;
     }
 
     // wave-uniform error code of the read so far (0 = none); no side effects
@@ -683,6 +700,7 @@ __global__ __launch_bounds__(256) void k_freq_reads(const DevParams p) {
         int ridx = p.order ? p.order[r] : r;
         ridx = uni(ridx);
         int e = uni(k.run(ridx, wave_slot));
+        if (p.stats) k.flush_stats();
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);

@@ -1,0 +1,336 @@
+/*
+ * synth.c -- synthetic reference + ONT / HiFi shaped reads, generated straight into the flattened batch layout of
+ * include/minimod_hip.h (SURVEY.md section 8d "Synthetic inputs").  Deterministic: every read is a pure function of
+ * (seed, read index), so any batch can be regenerated independently and on any number of threads.
+ *
+ * The reads are what load_db (reference src/minimod.c:235-333) would hand to the hot path: mapped, primary or
+ * supplementary, with MM:Z / ML:B:C in the style of dorado/remora 5mC+5hmC CpG models: "C+h?,...;C+m?,...;" listing
+ * every CpG of the ORIGINAL read (so for reverse-strand reads the skip counts run over the complement strand from
+ * the end of SEQ, reference src/mod.c:1092-1114).
+ */
+#include "synth.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- splitmix64 / xoshiro-free small RNG ---- */
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t rng_next(rng_t *r) {
+    uint64_t z = (r->s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline double rng_u(rng_t *r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint32_t rng_below(rng_t *r, uint32_t n) { return (uint32_t)(((rng_next(r) >> 32) * (uint64_t)n) >> 32); }
+static inline double rng_normal(rng_t *r) {
+    double u1 = rng_u(r), u2 = rng_u(r);
+    if (u1 < 1e-300) u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+/* geometric with mean m (>= 1), support 1.. */
+static inline uint32_t rng_geom(rng_t *r, double m) {
+    if (m <= 1.0) return 1;
+    double u = rng_u(r);
+    if (u < 1e-300) u = 1e-300;
+    double p = 1.0 / m;
+    return 1u + (uint32_t)(log(u) / log(1.0 - p));
+}
+
+/* ---- reference: i.i.d. ACGT with CpG depletion, soft-masked stretches, a few N runs ---- */
+/* Chunks of 1 MiB are pure functions of (seed, chunk index): any MiB-aligned slice can be generated alone. */
+void mm_synth_reference_slice(uint64_t seed, int64_t begin, int64_t len, uint8_t *out_slice) {
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    const int64_t CH = 1 << 20;
+    int64_t c0 = begin / CH;
+    uint8_t *out = out_slice - c0 * CH; /* index by absolute position */
+    len += c0 * CH;
+    int64_t nchunks = (len + CH - 1) / CH;
+    for (int64_t c = c0; c < nchunks; c++) {
+        rng_t r = {seed * 0x9E3779B97F4A7C15ull + (uint64_t)c * 0xD1B54A32D192ED03ull + 12345};
+        int64_t lo = c * CH, hi = lo + CH < len ? lo + CH : len;
+        int prev = 'A'; /* chunks are independent */
+        int64_t i = lo;
+        while (i < hi) {
+            uint64_t x = rng_next(&r);
+            for (int k = 0; k < 12 && i < hi; k++, x >>= 5) {
+                int b = B[x & 3];
+                /* human-like CpG depletion: most G after C are redrawn (CpG ~ 1% of dinucleotides) */
+                if ((prev == 'C') && b == 'G' && ((x >> 2) & 7) != 0) b = B[(x >> 2) & 1 ? 0 : 3];
+                out[i++] = (uint8_t)b;
+                prev = b;
+            }
+        }
+        /* one soft-masked stretch and (rarely) one N run per chunk */
+        rng_t q = {seed ^ (0xA5A5A5A5ull + (uint64_t)c * 77)};
+        int64_t span = hi - lo;
+        if (span > 4096) {
+            int64_t s = lo + rng_below(&q, (uint32_t)(span - 2048)), l = 200 + rng_below(&q, 1800);
+            for (int64_t j = s; j < s + l && j < hi; j++) out[j] = (uint8_t)(out[j] | 0x20);
+            if ((c & 15) == 7) {
+                int64_t s2 = lo + rng_below(&q, (uint32_t)(span - 1024)), l2 = 50 + rng_below(&q, 500);
+                for (int64_t j = s2; j < s2 + l2 && j < hi; j++) out[j] = 'N';
+            }
+        }
+    }
+}
+
+/* ---- growable byte pools ---- */
+typedef struct { uint8_t *p; size_t n, cap; } buf_t;
+static void buf_need(buf_t *b, size_t extra) {
+    if (b->n + extra <= b->cap) return;
+    size_t nc = b->cap ? b->cap * 2 : (1 << 20);
+    while (nc < b->n + extra) nc *= 2;
+    b->p = (uint8_t *)realloc(b->p, nc);
+    b->cap = nc;
+}
+static void buf_pad(buf_t *b, size_t align) {
+    size_t r = (align - (b->n % align)) % align;
+    buf_need(b, r);
+    memset(b->p + b->n, 0, r);
+    b->n += r;
+}
+
+static inline int nt16(int c) {
+    switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; default: return 15; }
+}
+static inline int upper(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+
+static size_t put_uint(uint8_t *dst, uint32_t v) {
+    char tmp[12];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (int i = 0; i < n; i++) dst[i] = (uint8_t)tmp[n - 1 - i];
+    return (size_t)n;
+}
+
+/* One read -> appended to the pools.  Returns the number of MM-listed calls (per code). */
+static uint32_t gen_read(const mm_synth_opts_t *o, const uint8_t *ref, int64_t idx, mm_read_t *rd, buf_t *cig, buf_t *seq,
+                         buf_t *mm, buf_t *ml, uint8_t **scratch, size_t *scratch_cap) {
+    rng_t r = {o->seed * 0x2545F4914F6CDD1Dull + (uint64_t)idx * 0x9E3779B97F4A7C15ull + 99};
+    (void)rng_next(&r);
+    /* length */
+    double L;
+    if (o->shape == MM_SYNTH_HIFI) {
+        L = 15000.0 + 3000.0 * rng_normal(&r);
+        if (L < 1000) L = 1000;
+    } else {
+        L = exp(log(o->median_len > 0 ? o->median_len : 12000.0) + 0.668 * rng_normal(&r));
+        if (L < 200) L = 200;
+        if (L > (o->max_len > 0 ? o->max_len : 200000.0)) L = o->max_len > 0 ? o->max_len : 200000.0;
+    }
+    uint32_t want = (uint32_t)L;
+    /* stratified, hence sorted, start positions */
+    int64_t region = o->region_len > 0 ? o->region_len : o->contig_len;
+    double slot = (double)region / (double)(o->n_reads_total > 0 ? o->n_reads_total : 1);
+    int64_t pos = o->region_begin + (int64_t)(((double)idx + rng_u(&r)) * slot);
+    if (pos >= o->contig_len - 64) pos = o->contig_len - 64;
+    if (pos < 0) pos = 0;
+    int rev = (rng_next(&r) >> 40) & 1;
+    double op_gap = o->shape == MM_SYNTH_HIFI ? 650.0 : 33.0; /* mean M-run length: ~0.057 (ONT) / ~0.003 (HiFi) ops per base */
+    double mism = o->shape == MM_SYNTH_HIFI ? 0.001 : 0.02;
+
+    if (*scratch_cap < (size_t)want + 4096) {
+        *scratch_cap = (size_t)want * 2 + 8192;
+        *scratch = (uint8_t *)realloc(*scratch, *scratch_cap);
+    }
+    uint8_t *s = *scratch; /* read bases as letters, BAM orientation */
+    uint32_t q = 0;
+    size_t cig0 = cig->n;
+    buf_need(cig, ((size_t)want / 8 + 64) * 4 + 64);
+#define PUSH_OP(len, op)                                                    \
+    do {                                                                    \
+        buf_need(cig, 8);                                                   \
+        uint32_t w_ = ((uint32_t)(len) << 4) | (uint32_t)(op);              \
+        memcpy(cig->p + cig->n, &w_, 4);                                    \
+        cig->n += 4;                                                        \
+    } while (0)
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    /* leading soft clip (about 4% of the read mass at each end for 60% of ONT reads) */
+    uint32_t clip5 = 0, clip3 = 0;
+    if (o->shape != MM_SYNTH_HIFI) {
+        if (rng_u(&r) < 0.6) clip5 = (uint32_t)(rng_u(&r) * 0.13 * want);
+        if (rng_u(&r) < 0.6) clip3 = (uint32_t)(rng_u(&r) * 0.13 * want);
+    }
+    if (clip5) {
+        for (uint32_t i = 0; i < clip5; i++) s[q++] = (uint8_t)B[rng_next(&r) >> 62];
+        PUSH_OP(clip5, 4);
+    }
+    int64_t rp = pos;
+    uint32_t body = want - clip5 - clip3;
+    uint32_t made = 0;
+    while (made < body && rp < o->contig_len - 1) {
+        uint32_t m = rng_geom(&r, op_gap);
+        if (m > body - made) m = body - made;
+        if ((int64_t)m > o->contig_len - rp) m = (uint32_t)(o->contig_len - rp);
+        if (m == 0) break;
+        for (uint32_t i = 0; i < m; i++) {
+            int c = upper(ref[rp + i]);
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') c = B[rng_next(&r) >> 62];
+            if (rng_u(&r) < mism) c = B[rng_next(&r) >> 62];
+            s[q++] = (uint8_t)c;
+        }
+        PUSH_OP(m, 0);
+        rp += m; made += m;
+        if (made >= body || rp >= o->contig_len - 1) break;
+        if (rng_u(&r) < 0.4) { /* insertion; C5-style longer insertions carry CpGs */
+            uint32_t l = rng_geom(&r, o->long_insertions ? 6.0 : 1.3);
+            if (l > body - made) l = body - made;
+            for (uint32_t i = 0; i < l; i++) s[q++] = (uint8_t)((o->long_insertions && (i & 1)) ? 'G' : (o->long_insertions ? 'C' : B[rng_next(&r) >> 62]));
+            PUSH_OP(l, 1);
+            made += l;
+        } else {
+            uint32_t l = rng_geom(&r, 1.75);
+            if ((int64_t)l > o->contig_len - 1 - rp) l = (uint32_t)(o->contig_len - 1 - rp);
+            if (l) { PUSH_OP(l, 2); rp += l; }
+        }
+    }
+    /* a CIGAR must not end on I/D before the clip: close with a match if needed */
+    {
+        uint32_t lastw;
+        if (cig->n > cig0) {
+            memcpy(&lastw, cig->p + cig->n - 4, 4);
+            if (((lastw & 15) == 1 || (lastw & 15) == 2) && rp < o->contig_len) {
+                int c = upper(ref[rp]);
+                if (c != 'A' && c != 'C' && c != 'G' && c != 'T') c = 'A';
+                s[q++] = (uint8_t)c;
+                PUSH_OP(1, 0);
+                rp++;
+            }
+        }
+    }
+    if (clip3) {
+        for (uint32_t i = 0; i < clip3; i++) s[q++] = (uint8_t)B[rng_next(&r) >> 62];
+        PUSH_OP(clip3, 4);
+    }
+#undef PUSH_OP
+    uint32_t lq = q;
+    uint32_t ncig = (uint32_t)((cig->n - cig0) / 4);
+    buf_pad(cig, 16);
+
+    /* packed sequence */
+    size_t seq0 = seq->n;
+    buf_need(seq, (size_t)lq / 2 + 32);
+    for (uint32_t i = 0; i + 1 < lq; i += 2) seq->p[seq->n++] = (uint8_t)((nt16(s[i]) << 4) | nt16(s[i + 1]));
+    if (lq & 1) seq->p[seq->n++] = (uint8_t)(nt16(s[lq - 1]) << 4);
+    buf_pad(seq, 16);
+
+    /* MM / ML */
+    size_t mm0 = mm->n, ml0 = ml->n;
+    int n_groups = o->single_code ? 1 : 2;
+    int dot = o->dot_fraction > 0 && rng_u(&r) < o->dot_fraction;
+    /* per-read methylation state so that sites are bimodal */
+    uint32_t ncalls = 0;
+    for (int g = 0; g < n_groups; g++) {
+        int is_m = o->single_code ? 1 : (g == 1);
+        buf_need(mm, 8);
+        mm->p[mm->n++] = 'C'; mm->p[mm->n++] = '+'; mm->p[mm->n++] = (uint8_t)(is_m ? 'm' : 'h');
+        mm->p[mm->n++] = (uint8_t)(dot ? '.' : '?');
+        rng_t rq = {o->seed ^ ((uint64_t)idx * 0xC2B2AE3D27D4EB4Full + (uint64_t)g * 977 + 5)};
+        uint32_t skip = 0, calls = 0;
+        if (!rev) {
+            for (uint32_t i = 0; i < lq; i++) {
+                if (s[i] != 'C') continue;
+                int listed = i + 1 < lq && s[i + 1] == 'G';
+                if (!listed) { skip++; continue; }
+                buf_need(mm, 12); buf_need(ml, 1);
+                mm->p[mm->n++] = ',';
+                mm->n += put_uint(mm->p + mm->n, skip);
+                skip = 0; calls++;
+                double u = rng_u(&rq);
+                uint32_t v = is_m ? (u < 0.70 ? rng_below(&rq, 21) : (u < 0.95 ? 235 + rng_below(&rq, 21) : rng_below(&rq, 256)))
+                                  : (u < 0.93 ? rng_below(&rq, 16) : rng_below(&rq, 256));
+                ml->p[ml->n++] = (uint8_t)v;
+            }
+        } else {
+            for (uint32_t k = lq; k-- > 0;) {
+                if (s[k] != 'G') continue;
+                int listed = k > 0 && s[k - 1] == 'C';
+                if (!listed) { skip++; continue; }
+                buf_need(mm, 12); buf_need(ml, 1);
+                mm->p[mm->n++] = ',';
+                mm->n += put_uint(mm->p + mm->n, skip);
+                skip = 0; calls++;
+                double u = rng_u(&rq);
+                uint32_t v = is_m ? (u < 0.70 ? rng_below(&rq, 21) : (u < 0.95 ? 235 + rng_below(&rq, 21) : rng_below(&rq, 256)))
+                                  : (u < 0.93 ? rng_below(&rq, 16) : rng_below(&rq, 256));
+                ml->p[ml->n++] = (uint8_t)v;
+            }
+        }
+        buf_need(mm, 2);
+        mm->p[mm->n++] = ';';
+        ncalls += calls;
+    }
+    uint32_t mm_len = (uint32_t)(mm->n - mm0), ml_len = (uint32_t)(ml->n - ml0);
+    buf_need(mm, 1);
+    mm->p[mm->n++] = 0;
+    buf_pad(mm, 16);
+    buf_pad(ml, 4);
+
+    memset(rd, 0, sizeof(*rd));
+    rd->cigar_off = cig0 / 4; rd->seq_off = seq0; rd->mm_off = mm0; rd->ml_off = ml0;
+    rd->tid = o->tid; rd->pos = (int32_t)pos; rd->l_qseq = lq; rd->n_cigar = ncig;
+    rd->mm_len = mm_len; rd->ml_len = ml_len;
+    rd->flag = (uint16_t)((rev ? 0x10 : 0) | ((rng_u(&r) < 0.03) ? 0x800 : 0));
+    rd->hp = 0;
+    if (o->haplotypes) { uint32_t h = rng_below(&r, 3); rd->hp = (uint8_t)h; }
+    return ncalls;
+}
+
+int mm_synth_batch(const mm_synth_opts_t *o, const uint8_t *ref, int64_t first_read, int32_t n_reads, mm_host_batch_t *out) {
+    if (!o || !ref || !out || n_reads < 0) return -1;
+    memset(out, 0, sizeof(*out));
+    buf_t cig = {0}, seq = {0}, mm = {0}, ml = {0};
+    mm_read_t *reads = (mm_read_t *)calloc((size_t)(n_reads > 0 ? n_reads : 1), sizeof(mm_read_t));
+    uint8_t *scratch = NULL;
+    size_t scap = 0;
+    uint64_t bases = 0, calls = 0;
+    uint32_t max_cig = 0, max_l = 0;
+    for (int32_t i = 0; i < n_reads; i++) {
+        calls += gen_read(o, ref, first_read + i, &reads[i], &cig, &seq, &mm, &ml, &scratch, &scap);
+        bases += reads[i].l_qseq;
+        if (reads[i].n_cigar > max_cig) max_cig = reads[i].n_cigar;
+        if (reads[i].l_qseq > max_l) max_l = reads[i].l_qseq;
+    }
+    free(scratch);
+    /* >= 64 bytes of zero slack on every pool */
+    buf_need(&cig, 64); memset(cig.p + cig.n, 0, 64); cig.n += 64;
+    buf_need(&seq, 64); memset(seq.p + seq.n, 0, 64); seq.n += 64;
+    buf_need(&mm, 64); memset(mm.p + mm.n, 0, 64); mm.n += 64;
+    buf_need(&ml, 64); memset(ml.p + ml.n, 0, 64); ml.n += 64;
+    out->b.reads = reads;
+    out->b.cigar = (const uint32_t *)cig.p; out->b.seq = seq.p; out->b.mm = mm.p; out->b.ml = ml.p;
+    out->b.order = NULL;
+    out->b.n_reads = n_reads;
+    out->b.n_cigar_words = cig.n / 4; out->b.n_seq_bytes = seq.n; out->b.n_mm_bytes = mm.n; out->b.n_ml_bytes = ml.n;
+    out->b.max_n_cigar = max_cig; out->b.max_l_qseq = max_l;
+    out->n_bases = bases; out->n_listed_calls = calls;
+    return 0;
+}
+
+void mm_synth_batch_free(mm_host_batch_t *b) {
+    if (!b) return;
+    free((void *)b->b.reads); free((void *)b->b.cigar); free((void *)b->b.seq); free((void *)b->b.mm); free((void *)b->b.ml);
+    free((void *)b->b.order);
+    memset(b, 0, sizeof(*b));
+}
+
+/* longest-first processing order (counting sort on l_qseq/256) */
+int mm_batch_make_order(mm_host_batch_t *hb) {
+    int32_t n = hb->b.n_reads;
+    if (n <= 0) return 0;
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    if (!order) return -1;
+    enum { NB = 4096 };
+    uint32_t *cnt = (uint32_t *)calloc(NB + 1, sizeof(uint32_t));
+    for (int32_t i = 0; i < n; i++) { uint32_t k = hb->b.reads[i].l_qseq >> 8; if (k >= NB) k = NB - 1; cnt[NB - 1 - k + 1]++; }
+    for (int k = 0; k < NB; k++) cnt[k + 1] += cnt[k];
+    for (int32_t i = 0; i < n; i++) { uint32_t k = hb->b.reads[i].l_qseq >> 8; if (k >= NB) k = NB - 1; order[cnt[NB - 1 - k]++] = i; }
+    free(cnt);
+    free((void *)hb->b.order);
+    hb->b.order = order;
+    return 0;
+}
+
+void mm_synth_reference(uint64_t seed, int64_t len, uint8_t *out) { mm_synth_reference_slice(seed, 0, len, out); }

@@ -57,7 +57,7 @@ class mm_interval_t(ctypes.Structure):
 EXPORTS = ["mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
            "mm_freq_wait", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
-           "mm_freq_last_kernel_ms", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
+           "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
 
 _lib = None
 
@@ -110,6 +110,10 @@ def load_library(build=True):
     L.mm_freq_slab_clear.argtypes = [vp, i32, i64, i64, vp]
     L.mm_freq_last_kernel_ms.restype = ctypes.c_float
     L.mm_freq_last_kernel_ms.argtypes = [vp, i32]
+    L.mm_freq_stats_enable.restype = i32
+    L.mm_freq_stats_enable.argtypes = [vp, i32]
+    L.mm_freq_stats_get.restype = i32
+    L.mm_freq_stats_get.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mm_freq_device_bytes.restype = i64
     L.mm_freq_device_bytes.argtypes = [vp]
     L.mm_freq_reset_counters.argtypes = [vp]
@@ -251,6 +255,16 @@ class FreqEngine(object):
 
     def kernel_ms(self, ticket):
         return float(self.L.mm_freq_last_kernel_ms(self.h, ticket))
+
+    def stats_enable(self, on=True):
+        self.L.mm_freq_stats_enable(self.h, int(on))
+
+    def stats_get(self):
+        out = (ctypes.c_uint64 * 4)()
+        r = self.L.mm_freq_stats_get(self.h, out)
+        if r:
+            raise MinimodHipError(-r, "stats_get failed")
+        return {"lookups": int(out[0]), "ml_reads": int(out[1]), "dense_updates": int(out[2]), "side_updates": int(out[3])}
 
     # -- results
     def finalize(self):
