@@ -49,14 +49,15 @@ def parse_args():
     return ap.parse_args()
 
 
-def shard_plan(rank, world):
-    """Owned interval, halo and contig length for a rank (pure function, covered by the CPU tests)."""
-    contig_len = world * INTERVAL + HALO
-    begin = rank * INTERVAL
-    end = (rank + 1) * INTERVAL if rank < world - 1 else contig_len
-    halo = HALO if rank < world - 1 else 0
-    return {"contig_len": contig_len, "begin": begin, "end": end, "halo": halo,
-            "read_begin": begin, "read_len": INTERVAL}
+def shard_plan(rank, world, interval=INTERVAL, halo=HALO):
+    """Owned interval, halo and contig length for a rank (pure function, covered by the CPU tests).  Reads are routed
+    by alignment START to the owner of that position; their calls may run past the owner's right edge by at most one
+    read's reference span, which the halo must cover."""
+    contig_len = world * interval + halo
+    begin = rank * interval
+    end = (rank + 1) * interval if rank < world - 1 else contig_len
+    return {"contig_len": contig_len, "begin": begin, "end": end, "halo": halo if rank < world - 1 else 0,
+            "read_begin": begin, "read_len": interval}
 
 
 def exchange_halos(rank, world, export_fn, add_fn, make_buf, dist):

@@ -1,0 +1,41 @@
+/* bamio.h -- minimal BGZF/BAM reader for the freq path (own code; replaces the htslib calls the reference makes:
+ * sam_open/sam_hdr_read/sam_read1 reference src/minimod.c:73-90,250 and the aux accessors of src/mod.c:123-202).
+ * BGZF blocks are inflated by a small thread pool (the reference gets this from hts_set_threads, minimod.c:76-78). */
+#ifndef MM_BAMIO_H
+#define MM_BAMIO_H
+#include <stdint.h>
+#include <stdio.h>
+
+typedef struct mm_bam_hdr {
+    int32_t n_targets;
+    char **target_name;
+    uint32_t *target_len;
+} mm_bam_hdr_t;
+
+/* a view of one alignment record inside the reader's buffer (valid until the next mm_bam_next) */
+typedef struct mm_bam_rec {
+    int32_t tid, pos;
+    uint16_t flag;
+    uint8_t mapq, l_read_name;
+    uint32_t n_cigar;
+    int32_t l_qseq;
+    const char *qname;
+    const uint32_t *cigar;   /* may be unaligned: copy with memcpy */
+    const uint8_t *seq;      /* (l_qseq+1)/2 bytes */
+    const uint8_t *aux;
+    int32_t l_aux;
+    int32_t l_data;          /* htslib's bam1_t.l_data for this record (used by the -B rule, minimod.c:249,324) */
+} mm_bam_rec_t;
+
+typedef struct mm_bam mm_bam_t;
+
+mm_bam_t *mm_bam_open(const char *path, int n_threads);
+const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b);
+/* 1 = record read, 0 = end of file, <0 = error */
+int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *rec);
+void mm_bam_close(mm_bam_t *b);
+
+/* bam_aux_get: pointer to the TYPE byte of the first tag `tag`, or NULL */
+const uint8_t *mm_aux_get(const uint8_t *aux, int32_t l_aux, const char tag[2]);
+
+#endif

@@ -1,0 +1,83 @@
+/* mmhost.h -- C host side of `minimod freq` on the MI355X library (include/minimod_hip.h).
+ * Mirrors the reference's driver layer: options (src/freq_main.c:46-64,182-296, src/mod.c:204-398), reference load
+ * (src/ref.c:46-89), load_db (src/minimod.c:235-333) and print_freq_output (src/mod.c:628-728). */
+#ifndef MMHOST_H
+#define MMHOST_H
+#include <stdint.h>
+#include <stdio.h>
+
+#include "bamio.h"
+#include "minimod_hip.h"
+#include "synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMH_VERSION "0.1.0-mi355x (minimod v0.5.0 freq semantics)"
+
+/* ---- logging in the reference's format (src/error.h:58-152) ---- */
+extern int mmh_log_level;
+#define MMH_INFO(msg, ...) do { if (mmh_log_level >= 3) fprintf(stderr, "[%s::INFO]\033[1;34m " msg "\033[0m\n", __func__, __VA_ARGS__); } while (0)
+#define MMH_WARNING(msg, ...) do { if (mmh_log_level >= 2) fprintf(stderr, "[%s::WARNING]\033[1;33m " msg "\033[0m At %s:%d\n", __func__, __VA_ARGS__, __FILE__, __LINE__); } while (0)
+#define MMH_ERROR(msg, ...) do { if (mmh_log_level >= 1) fprintf(stderr, "[%s::ERROR]\033[1;31m " msg "\033[0m At %s:%d\n", __func__, __VA_ARGS__, __FILE__, __LINE__); } while (0)
+
+double mmh_realtime(void);
+double mmh_cputime(void);
+long mmh_peakrss(void);
+int64_t mmh_parse_num(const char *str);   /* mm_parse_num, src/misc.c:74-87 */
+
+/* ---- -c / -m ---- */
+typedef struct mmh_mods {
+    int n_mods;
+    char code[MM_MAX_MODS][MM_CODE_LEN];
+    char context[MM_MAX_MODS][MM_CODE_LEN];
+    double thresh[MM_MAX_MODS];
+} mmh_mods_t;
+/* both return 0 or -1 with a message in err (the CLI prints it as the reference would and exits) */
+int mmh_parse_mod_codes(const char *s, mmh_mods_t *out, char *err, size_t errlen);
+int mmh_parse_mod_threshes(const char *s, mmh_mods_t *m, char *err, size_t errlen);
+void mmh_klass_lut(double thresh, uint8_t lut[256]);   /* src/mod.c:56,1180-1191 */
+void mmh_fill_opts(const mmh_mods_t *m, int insertions, int haplotypes, int device, mm_freq_opts_t *o);
+
+/* ---- reference ---- */
+typedef struct mmh_ref {
+    int n;
+    char **name;
+    uint8_t **seq;
+    int64_t *len;
+} mmh_ref_t;
+mmh_ref_t *mmh_load_ref(const char *path);      /* load_ref: names up to the first whitespace, raw letters */
+int mmh_ref_find(const mmh_ref_t *r, const char *name);   /* last duplicate wins like kh_put (src/ref.c:81-82) */
+void mmh_free_ref(mmh_ref_t *r);
+
+/* ---- load_db ---- */
+typedef struct mmh_loader {
+    mm_bam_t *bam;
+    int allow_secondary, skip_supplementary;
+    int32_t K;
+    int64_t B;
+    /* statistics of the last batch / totals (db_t / core_t counters, src/minimod.h:147-150,190-194) */
+    int32_t last_total_reads; int64_t last_total_bytes, last_processed_bytes;
+    uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
+    /* growable pools reused between batches */
+    struct { uint8_t *p; size_t n, cap; } pool[5];
+} mmh_loader_t;
+mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary);
+/* Fills `out` with the next batch (pointers into the loader's pools, valid until the next call with the same pool set).
+ * Returns the number of accepted reads, or -1 on a read error.  *more = 0 when the reference's loop would stop
+ * (src/freq_main.c:410). */
+int32_t mmh_loader_next(mmh_loader_t *ld, int pool_set, mm_batch_t *out, int *more);
+void mmh_loader_close(mmh_loader_t *ld);
+
+/* ---- output ---- */
+void mmh_print_freq_header(FILE *fp, int bedmethyl, int insertions, int haplotypes);
+void mmh_print_freq_rows(FILE *fp, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, mm_freq_t *h, int bedmethyl,
+                         int insertions, int haplotypes);
+
+int mmh_freq_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

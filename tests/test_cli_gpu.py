@@ -1,0 +1,99 @@
+"""End-to-end `minimod freq` (C host + HIP library) against the reference's golden files.  GPU only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.cases import GOLDEN, GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "minimod_amd", "bin", "minimod")
+
+
+def _write_fasta(path, name, seq):
+    with open(path, "wb") as f:
+        f.write(b">" + name.encode() + b" pseudo-reference\n")
+        a = np.frombuffer(seq, dtype=np.uint8) if not isinstance(seq, np.ndarray) else seq
+        n = len(a) // 60 * 60
+        body = np.empty((n // 60, 61), dtype=np.uint8)
+        body[:, :60] = a[:n].reshape(-1, 60)
+        body[:, 60] = 10
+        f.write(body.tobytes())
+        if n < len(a):
+            f.write(a[n:].tobytes() + b"\n")
+
+
+@pytest.fixture(scope="session")
+def fastas(tmp_path_factory, chr22, chr1):
+    import minimod_amd
+    minimod_amd.build_all()
+    d = tmp_path_factory.mktemp("fa")
+    out = {}
+    for key, ctg in (("chr22", chr22), ("chr1", chr1)):
+        (name, seq), = ctg.items()
+        p = str(d / (key + ".fa"))
+        _write_fasta(p, name, seq)
+        out[key] = p
+    return out
+
+
+def _args(kw):
+    a = []
+    if "c" in kw:
+        a += ["-c", kw["c"]]
+    if "m" in kw:
+        a += ["-m", kw["m"]]
+    if "K" in kw:
+        a += ["-K", str(kw["K"])]
+    if kw.get("insertions"):
+        a.append("--insertions")
+    if kw.get("haplotypes"):
+        a.append("--haplotypes")
+    return a
+
+
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
+def test_cli_matches_reference_golden(exp, bam, ctg, kw, exact, fastas, tmp_path):
+    cmd = [BIN, "freq"] + _args(kw) + (["-b"] if exp.endswith("bedmethyl") else []) + [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    got = r.stdout.decode()
+    if exact:
+        assert got == want
+    else:
+        assert sorted(got.splitlines()) == sorted(want.splitlines())
+
+
+def test_cli_output_file_and_batch_invariance(fastas, tmp_path):
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    outs = []
+    for i, extra in enumerate((["-K", "1"], ["-K", "4096", "-B", "100M", "-t", "4"], ["-B", "50K"])):
+        o = str(tmp_path / ("o%d.tsv" % i))
+        r = subprocess.run([BIN, "freq", "-m", "0.8", "-o", o] + extra + [fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and r.stdout == b""
+        outs.append(open(o).read())
+    assert outs[0] == outs[1] == outs[2] == open(os.path.join(GOLDEN, "expected", "test7.tsv")).read()
+
+
+def test_cli_hard_clip_exits_like_reference(fastas, tmp_path):
+    r = subprocess.run([BIN, "freq", fastas["chr22"], os.path.join(GOLDEN, "data", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    # the reference dies on the hard-clipped supplementary alignments of this file unless they are filtered
+    if r.returncode != 0:
+        assert b"Hard clipping" in r.stderr
+    r2 = subprocess.run([BIN, "freq", "--skip-supplementary", fastas["chr22"],
+                         os.path.join(GOLDEN, "data", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam")],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r2.returncode == 0 and len(r2.stdout) > 1000
+
+
+def test_cli_missing_args_and_version():
+    r = subprocess.run([BIN, "freq"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Usage: minimod freq ref.fa reads.bam" in r.stderr
+    r = subprocess.run([BIN, "freq", "-h"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"Usage: minimod freq ref.fa reads.bam" in r.stdout
+    r = subprocess.run([BIN, "--version"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout.startswith(b"minimod ")

@@ -1,0 +1,151 @@
+"""CPU-only tests of the host side: the C ABI library loads and exports what include/minimod_hip.h declares, and the
+C host code (options, FASTA, BGZF/BAM loader) agrees with the oracle's independent Python restatements."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import pybam
+from tests.cases import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from minimod_amd import engine
+    L = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "minimod_hip.h")).read()
+    declared = set(re.findall(r"\b(mm_[a-z_0-9]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(L, name), "library does not export %s" % name
+    assert declared == set(engine.EXPORTS)
+    assert L.mm_abi_version() == engine.MM_ABI_VERSION
+    assert engine.READ_DTYPE.itemsize == 64 == pybam.READ_DTYPE.itemsize
+    assert [n for n in engine.READ_DTYPE.names] == [n for n in pybam.READ_DTYPE.names]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import minimod_amd
+    with pytest.raises(minimod_amd.MinimodHipError):
+        minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrT", 4, b"ACGT")])
+
+
+OPT_CASES = ["m", "m[CG]", "m,h", "m[CG],h[CG]", "h", "*", "m[*]", "*[CG]", "21839[C],m[*]", "17802[*],a,m[C]", "e,b",
+             "a[A]", "m[Ct]", "hm[CG]", "m[cg],h[*],a", "o,n,f,c,g,T,U,A,C,G,N"]
+
+
+@pytest.mark.parametrize("c", OPT_CASES)
+def test_mod_code_parser_matches_oracle(c):
+    from minimod_amd import hostlib
+    want = O.parse_mod_codes(c)
+    got = hostlib.parse_mods(c, None)
+    assert [(a, b) for a, b, _ in got] == want
+    assert all(t == 0.8 for _, _, t in got)
+
+
+def test_mod_code_parser_errors():
+    from minimod_amd import hostlib
+    for bad in ["m[CG", "m1", "m[C*]", "m,m", "m[X]", "m-"]:
+        with pytest.raises(ValueError):
+            O.parse_mod_codes(bad)
+        with pytest.raises(ValueError):
+            hostlib.parse_mods(bad)
+    with pytest.raises(ValueError):
+        hostlib.parse_mods("m,h", "0.8,0.7,0.6")
+    with pytest.raises(ValueError):
+        hostlib.parse_mods("m", "1.5")
+    assert [t for _, _, t in hostlib.parse_mods("m,h", "0.8,0.5")] == [0.8, 0.5]
+    assert [t for _, _, t in hostlib.parse_mods("m,h,a", "0.7")] == [0.7, 0.7, 0.7]
+
+
+def test_threshold_classes_and_numbers():
+    from minimod_amd import engine, hostlib
+    for th in (0.0, 0.2, 0.5, 0.7, 0.8, 0.9, 0.999, 1.0):
+        a, b = hostlib.klass_lut(th), engine.klass_lut(th)
+        assert (a == b).all()
+        for x in range(256):
+            p = (x + 0.5) / 256.0
+            want = 3 if p >= th else (1 if p <= 1 - th else 0)
+            assert a[x] == want
+    assert hostlib.parse_num("100M") == 100000000 and hostlib.parse_num("20K") == 20000 and hostlib.parse_num("1.5G") == 1500000000
+    assert hostlib.parse_num("4096") == 4096
+
+
+def test_fasta_loader(tmp_path):
+    from minimod_amd import hostlib
+    p = tmp_path / "r.fa"
+    p.write_text(">chrA some description\nACGTacgt\nNNnn\n\n>chrB\tx\nUUuu\r\nGG\n>empty\n>chrC\nA")
+    got = hostlib.load_ref(str(p))
+    assert got == [("chrA", b"ACGTacgtNNnn"), ("chrB", b"UUuuGG"), ("empty", b""), ("chrC", b"A")]
+    import gzip
+    pz = tmp_path / "r.fa.gz"
+    with gzip.open(str(pz), "wb") as f:
+        f.write(p.read_bytes())
+    assert hostlib.load_ref(str(pz)) == got
+
+
+def _same_batch(a, b):
+    ra, rb = a["reads"], b["reads"]
+    assert len(ra) == len(rb)
+    for f in ("tid", "pos", "l_qseq", "n_cigar", "mm_len", "ml_len", "flag", "hp"):
+        assert (ra[f] == rb[f]).all(), f
+    for x, y in zip(ra, rb):
+        n = int(x["n_cigar"])
+        assert (a["cigar"][int(x["cigar_off"]):int(x["cigar_off"]) + n] == b["cigar"][int(y["cigar_off"]):int(y["cigar_off"]) + n]).all()
+        n = (int(x["l_qseq"]) + 1) // 2
+        assert (a["seq"][int(x["seq_off"]):int(x["seq_off"]) + n] == b["seq"][int(y["seq_off"]):int(y["seq_off"]) + n]).all()
+        n = int(x["mm_len"])
+        assert (a["mm"][int(x["mm_off"]):int(x["mm_off"]) + n + 1] == b["mm"][int(y["mm_off"]):int(y["mm_off"]) + n + 1]).all()
+        n = int(x["ml_len"])
+        assert (a["ml"][int(x["ml_off"]):int(x["ml_off"]) + n] == b["ml"][int(y["ml_off"]):int(y["ml_off"]) + n]).all()
+        assert int(y["seq_off"]) % 16 == 0 and int(y["mm_off"]) % 16 == 0 and int(y["cigar_off"]) % 4 == 0
+
+
+LOADER_CASES = [("example-ont.bam", dict(K=7)), ("example-hifi.bam", dict(K=1)), ("hap.bam", dict()),
+                ("dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", dict(allow_secondary=True)),
+                ("dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", dict(skip_supplementary=True, K=100)),
+                ("dRNA.bam", dict(B=50000)), ("eb.bam", dict(K=4096))]
+
+
+@pytest.mark.parametrize("bam,kw", LOADER_CASES, ids=["%s-%s" % (b, "-".join(k)) for b, k in LOADER_CASES])
+def test_c_loader_matches_python_reader(bam, kw):
+    """load_db in C (BGZF inflate pool + filters + flattening) == the oracle's pure-Python reader, batch by batch."""
+    from minimod_amd import hostlib
+    path = os.path.join(GOLDEN, "data", bam)
+    got = list(hostlib.load_batches(path, **kw))
+    want = [b for _, b, _ in pybam.load_batches(path, **kw)]
+    assert len(got) == len(want)
+    for a, b in zip(want, got):
+        _same_batch(a, b)
+
+
+def test_synthetic_generator_is_deterministic_and_valid():
+    from minimod_amd import synth
+    ref = synth.reference(7, 3 << 20)
+    assert (synth.reference_slice(7, 1 << 20, 2 << 20) == ref[1 << 20:]).all()
+    b1 = synth.batch(ref, 10, 50, seed=3, n_reads_total=500)
+    b2 = synth.batch(ref, 0, 60, seed=3, n_reads_total=500)
+    for k in ("l_qseq", "pos", "n_cigar", "mm_len", "flag"):
+        assert (b1["reads"][k] == b2["reads"][k][10:]).all()
+    rd = b1["reads"]
+    assert (np.diff(rd["pos"]) >= 0).all()                       # coordinate sorted
+    assert sorted(b1["order"].tolist()) == list(range(50))
+    assert (rd["l_qseq"][b1["order"]][:-1] // 256 >= rd["l_qseq"][b1["order"]][1:] // 256).all()   # longest first
+    # every read is well-formed for the oracle, and MM lists exactly the read's CpGs
+    o = O.Oracle([("m", "CG"), ("h", "CG")], [0.8, 0.8], ["chrS"])
+    o.add_contig("chrS", ref)
+    o.process(b1)
+    assert len(o.rows()) > 100
+    for shape, dot in ((1, 0.5), (0, 1.0)):
+        b = synth.batch(ref, 0, 20, seed=9, n_reads_total=200, shape=shape, dot_fraction=dot, haplotypes=True)
+        o = O.Oracle([("m", "CG")], [0.8], ["chrS"], insertions=True, haplotypes=True)
+        o.add_contig("chrS", ref)
+        o.process(b)
+        assert len(o.rows()) > 100
