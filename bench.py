@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = choose for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
+    ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
     ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
     return ap.parse_args()
 
@@ -103,7 +104,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import minimod_amd
-    from minimod_amd import synth
+    from minimod_amd import engine, synth
 
     plan = shard_plan(rank, world)
     t0 = time.time()
@@ -117,7 +118,7 @@ def main():
         first = bi * args.batch
         n = min(args.batch, args.reads - first)
         return synth.batch(ref, first, n, seed=args.seed + 7919 * rank, contig_len=plan["contig_len"],
-                           n_reads_total=args.reads, region_begin=plan["read_begin"], region_len=plan["read_len"])
+                           n_reads_total=args.reads, region_begin=plan["read_begin"], region_len=plan["read_len"], max_len=args.max_len)
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         host_batches = list(ex.map(gen, range(n_batches)))
@@ -134,10 +135,12 @@ def main():
             t = torch.from_numpy(hb[k].view(np.uint8).reshape(-1)).to(dev)
             keep.append(t)
             d[k] = t.data_ptr()
-        if hb["order"] is not None and not args.natural_order:
-            t = torch.from_numpy(hb["order"].view(np.uint8).reshape(-1)).to(dev)
+        if not args.natural_order:
+            items = engine.plan_batch(hb["reads"])
+            t = torch.from_numpy(items.view(np.uint8).reshape(-1)).to(dev)
             keep.append(t)
             d["order"] = t.data_ptr()
+            d["n_order"] = len(items)
         d.update(n_reads=len(hb["reads"]), n_cigar_words=len(hb["cigar"]), n_seq_bytes=len(hb["seq"]),
                  n_mm_bytes=len(hb["mm"]), n_ml_bytes=len(hb["ml"]), max_n_cigar=hb["max_n_cigar"],
                  max_l_qseq=hb["max_l_qseq"])
@@ -230,7 +233,7 @@ def main():
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(
                            np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches]))),
                        "sharding": "interval per GPU + halo slab to the right neighbour" if world > 1 else "single GPU",
-                       "read_order": "natural" if args.natural_order else "longest first"},
+                       "read_order": "natural, unsplit" if args.natural_order else "mm_freq_plan_batch (long reads split, costliest first)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_freq_reads",
                          "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms),
@@ -282,7 +285,7 @@ def verify(batches, plan, ref, device):
     orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
     orc.add_contig("chrS", ref)
     for hb in batches:
-        eng.process(hb, hb.get("order"))
+        eng.process(hb)
         orc.process(hb, threads=os.cpu_count() or 1)
     got, want = eng.finalize(), orc.rows()
     eng.close()

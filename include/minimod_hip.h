@@ -63,9 +63,10 @@ typedef struct mm_batch {
     const uint8_t *seq;
     const uint8_t *mm;
     const uint8_t *ml;
-    const int32_t *order;    /* optional: processing order of the reads (e.g. longest first); NULL = as stored */
+    const int32_t *order;    /* optional work items from mm_freq_plan_batch (long reads split into parts, costliest
+                              * first); NULL = one item per read in stored order (mm_freq_submit plans by itself) */
     int32_t n_reads;
-    int32_t rsvd;
+    int32_t n_order;         /* entries of order[] (ignored when order is NULL) */
     uint64_t n_cigar_words;  /* pool sizes incl. slack (elements / bytes) */
     uint64_t n_seq_bytes;
     uint64_t n_mm_bytes;
@@ -154,6 +155,11 @@ int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *h
 /* Wait for a ticket.  Returns 0, or the first failing read's MM_E_* code with its batch index in *bad_read. */
 int32_t mm_freq_wait(mm_freq_t *h, int32_t ticket, int32_t *bad_read);
 
+/* Plan a batch: writes work items (read index | part << 24 | (parts-1) << 28) for reads[0..n), long reads split into
+ * up to 16 parts, costliest first.  Returns the number of items (<= cap) or -MM_E_ARG when cap is too small
+ * (cap >= 16*n always suffices).  Pure host function. */
+int32_t mm_freq_plan_batch(const mm_read_t *reads, int32_t n, int32_t *items, int32_t cap);
+
 /* Intern a code string seen in reads (only meaningful with -c '*'): returns its code index. */
 int32_t mm_freq_intern_code(mm_freq_t *h, const char *code);
 int32_t mm_freq_n_codes(const mm_freq_t *h);
@@ -179,7 +185,7 @@ float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
 /* Work tallies for the algorithmic-bytes figure: enable!=0 makes K1 count reference-word
  * lookups, ML bytes read, dense counter updates and side-list updates; get copies and clears the four totals. */
 int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
-int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[4]);
+int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[8]);   /* [4..7]: phase cycle sums in diagnostic builds, else 0 */
 int64_t mm_freq_device_bytes(const mm_freq_t *h);
 
 void mm_freq_reset_counters(mm_freq_t *h);

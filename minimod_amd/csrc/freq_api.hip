@@ -41,6 +41,7 @@ struct Slot {
     unsigned int* d_ctl = nullptr;   // [0] queue, [1] err_summary
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
+    std::vector<int32_t> plan;   // host copy of the work items while the upload is in flight
 };
 
 }  // namespace
@@ -145,7 +146,8 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     DevParams p = base_params(h);
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
     p.n_reads = b->n_reads;
-    int blocks = std::min((b->n_reads + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->blocks_per_cu);
+    p.n_items = b->order ? b->n_order : b->n_reads;
+    int blocks = std::min((p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->blocks_per_cu);
     if (blocks < 1) blocks = 1;
     uint32_t spill_cig = b->max_n_cigar > (uint32_t)kCigCap ? b->max_n_cigar - kCigCap : 0;
     uint32_t max_blk = (b->max_l_qseq + 31u) / 32u;
@@ -279,6 +281,13 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         DevMod& d = mods[i];
         std::memset(&d, 0, sizeof(d));
         std::memcpy(d.klass, m.klass, 256);
+        d.t_hi = 256; d.t_lo = -1;
+        for (int x = 255; x >= 0; x--) if (m.klass[x] == 3) d.t_hi = x; else break;
+        for (int x = 0; x < 256; x++) if (m.klass[x] == 1) d.t_lo = x; else break;
+        for (int x = 0; x < 256; x++) {
+            int want = x >= d.t_hi ? 3 : (x <= d.t_lo ? 1 : 0);
+            if (m.klass[x] != want) return fail(h, "klass table must be monotone (called | ambiguous | modified)");
+        }
         size_t cl = strnlen(m.context, MM_CODE_LEN);
         if (cl >= MM_CODE_LEN) return fail(h, "context too long");
         d.ctx_is_star = std::strcmp(m.context, "*") == 0;
@@ -310,8 +319,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
-    if (dev_alloc(h, (void**)&h->d_stats, 4 * sizeof(unsigned long long))) return fail(h, "alloc failed");
-    (void)hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long));
+    if (dev_alloc(h, (void**)&h->d_stats, 8 * sizeof(unsigned long long))) return fail(h, "alloc failed");
+    (void)hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long));
     h->codes_dirty = !h->codes.empty();
     // ---- contigs: reference words for every contig that has a sequence; counter segments
     h->n_contigs = n_contigs;
@@ -404,6 +413,30 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     return h;
 }
 
+int32_t mm_freq_plan_batch(const mm_read_t* reads, int32_t n, int32_t* items, int32_t cap) {
+    if (n < 0 || (n > 0 && (!reads || !items)) || n >= (1 << 24)) return -MM_E_ARG;
+    static int split = 0;
+    if (!split) {
+        const char* e = std::getenv("MM_SPLIT_BASES");
+        split = e ? std::atoi(e) : 16384;
+        if (split < 1024) split = 1024;
+    }
+    // counting sort on estimated cost (bases per part, 256-base buckets), costliest first
+    enum { NB = 4096 };
+    std::vector<uint32_t> cnt(NB + 1, 0);
+    auto parts_of = [&](uint32_t L) { uint32_t w = (L + (uint32_t)split - 1) / (uint32_t)split; return w < 1 ? 1u : (w > 16 ? 16u : w); };
+    auto bucket = [&](uint32_t L, uint32_t w) { uint32_t k = (L / w) >> 8; if (k >= NB) k = NB - 1; return (uint32_t)(NB - 1 - k); };
+    int64_t total = 0;
+    for (int32_t i = 0; i < n; i++) { uint32_t w = parts_of(reads[i].l_qseq); cnt[bucket(reads[i].l_qseq, w) + 1] += w; total += w; }
+    if (total > cap) return -MM_E_ARG;
+    for (int k = 0; k < NB; k++) cnt[k + 1] += cnt[k];
+    for (int32_t i = 0; i < n; i++) {
+        uint32_t w = parts_of(reads[i].l_qseq), b = bucket(reads[i].l_qseq, w);
+        for (uint32_t j = 0; j < w; j++) items[cnt[b]++] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1) << 28));
+    }
+    return (int32_t)total;
+}
+
 int32_t mm_freq_intern_code(mm_freq_t* h, const char* code) {
     if (!h || !code) return -MM_E_ARG;
     size_t L = std::strlen(code);
@@ -461,10 +494,21 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (hb->n_ml_bytes) HIPCHK(hipMemcpyAsync(s.d_ml, hb->ml, hb->n_ml_bytes, hipMemcpyHostToDevice, st));
     db.reads = (const mm_read_t*)s.d_reads; db.cigar = (const uint32_t*)s.d_cigar; db.seq = (const uint8_t*)s.d_seq;
     db.mm = (const uint8_t*)s.d_mm; db.ml = (const uint8_t*)s.d_ml; db.order = nullptr;
-    if (hb->order && hb->n_reads) {
-        if ((r = grow(h, &s.d_order, &s.cap_order, sizeof(int32_t) * (size_t)hb->n_reads))) return r;
-        HIPCHK(hipMemcpyAsync(s.d_order, hb->order, sizeof(int32_t) * (size_t)hb->n_reads, hipMemcpyHostToDevice, st));
+    if (hb->n_reads) {
+        // work items: the caller's plan, or our own (long reads split into parts, costliest first)
+        const int32_t* items = hb->order;
+        int32_t n_items = hb->n_order;
+        std::vector<int32_t>& plan = s.plan;
+        if (!items) {
+            plan.resize((size_t)hb->n_reads * 16);
+            n_items = mm_freq_plan_batch(hb->reads, hb->n_reads, plan.data(), (int32_t)plan.size());
+            if (n_items < 0) return n_items;
+            items = plan.data();
+        }
+        if ((r = grow(h, &s.d_order, &s.cap_order, sizeof(int32_t) * (size_t)n_items))) return r;
+        HIPCHK(hipMemcpyAsync(s.d_order, items, sizeof(int32_t) * (size_t)n_items, hipMemcpyHostToDevice, st));
         db.order = (const int32_t*)s.d_order;
+        db.n_order = n_items;
     }
     r = launch_k1(h, s, &db, st);
     return r ? r : si;
@@ -497,12 +541,12 @@ int32_t mm_freq_stats_enable(mm_freq_t* h, int32_t enable) {
     h->stats_on = enable != 0;
     return 0;
 }
-int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[4]) {
+int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[8]) {
     if (!h || !out) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(out, h->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long)));
     return 0;
 }
 

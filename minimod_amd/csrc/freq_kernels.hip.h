@@ -14,6 +14,13 @@
 // {n_called (low 32), n_mod (high 32)}, updated with ONE global_atomic_add_x2 per call.  This is integer
 // select/scan/scatter work: no MFMA, HBM- and latency-bound.
 #pragma once
+#ifdef MM_PHASE_TIMING
+#define MMT_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1
+#define MMT_LAP(slot) do { _t1 = __builtin_readcyclecounter(); if (lane_id() == 0 && p.stats) atomicAdd(p.stats + (slot), _t1 - _t0); _t0 = _t1; } while (0)
+#else
+#define MMT_DECL do {} while (0)
+#define MMT_LAP(slot) do {} while (0)
+#endif
 #ifdef MM_DEBUG
 #define MMDBG(...) do { unsigned long long _m = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll(_m) - 1) { printf("[exec %llx] ", _m); printf(__VA_ARGS__); } } while (0)
 #else
@@ -28,8 +35,9 @@ namespace mmhip {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kCigCap = 1024;  // CIGAR ops whose prefix sums live in LDS (the rest spill to a global scratch)
-constexpr int kDirCap = 1024;  // 32-base blocks whose rank directory lives in LDS (32 kb of read)
-constexpr int kTokCap = 128;
+constexpr int kDirCap = 512;   // 32-base blocks whose rank directory lives in LDS (16 kb of read)
+constexpr int kTokCap = 512;   // compacted skip counts: one flush takes 256, one 256-character trip adds <= 128
+constexpr int kCallsPerLane = 4;  // calls a lane carries through the staged call pipeline (memory-level parallelism)
 
 struct DevCode {
     char str[MM_CODE_LEN];
@@ -41,6 +49,7 @@ struct DevCode {
 
 struct DevMod {
     uint8_t klass[256];
+    int32_t t_lo, t_hi;   // klass is monotone in the ML value: <= t_lo -> called, >= t_hi -> called+modified
     int32_t ctx_is_star;
     int32_t ctx_len;
     char ctx_fwd[MM_CODE_LEN];
@@ -64,8 +73,9 @@ struct DevParams {
     const uint8_t* seq;
     const uint8_t* mm;
     const uint8_t* ml;
-    const int32_t* order;  // optional processing order
+    const int32_t* order;  // optional work items: read index | part << 24 | (parts - 1) << 28
     int32_t n_reads;
+    int32_t n_items;       // entries of order[] (== n_reads when order is null)
     // reference
     const void* refw;            // uint16 or uint32 per base: bits 0-4 base code, bit 5+2i fwd ctx, 6+2i rev ctx
     const int64_t* ref_base;     // per tid: offset into refw, -1 = contig absent
@@ -97,13 +107,17 @@ struct DevParams {
 
 // ---------------------------------------------------------------------------------- wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (no LDS traffic): 4 row_shr steps
+// inside each 16-lane row, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane_id() >= d) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
 }
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -215,7 +229,7 @@ struct WaveLds {
     uint32_t tok[kTokCap];    // compacted skip counts
     uint32_t gap[64];         // exclusive prefix of skip counts (implicit-call expansion)
     uint32_t gstart[64];      // first rank of each gap
-    uint8_t mm[96];           // 64 MM characters + look-ahead
+    uint32_t mmw[68];         // 256 MM characters + 16 of look-ahead, written as dwords
     char hdr[16];             // code characters of the current MM group
     int16_t g_code[16];       // per code letter: device code index or -1
 };
@@ -252,87 +266,107 @@ struct K1 {
     __device__ void scan_cigar(const uint32_t* cg, int64_t ctg_len) {
         const int lane = lane_id();
         uint32_t carry_q = 0, carry_r = 0;
-        for (uint32_t i0 = 0; i0 < c.ncig; i0 += 64) {
-            uint32_t i = i0 + lane;
-            bool act = i < c.ncig;
-            uint32_t w = act ? cg[i] : 0u;
-            uint32_t op = w & 15u, len = w >> 4;
-            // ops MIDNSHP=X = 0..8 ; query-consuming {M,I,S,=,X}, reference-consuming {M,D,N,=,X}
-            uint32_t qinc = (act && ((0x193u >> op) & 1u)) ? len : 0u;
-            uint32_t rinc = (act && ((0x18Du >> op) & 1u)) ? len : 0u;
-            if (act && op == 5u) err = MM_E_HARDCLIP;                     // mod.c:841-844
-            else if (act && (op == 6u || op > 8u)) err = MM_E_CIGAROP;    // mod.c:845-848
-            uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
-            uint32_t qtot = lane_valu(qs, 63), rtot = lane_valu(rs, 63);
-            qs = carry_q + qs - qinc;
-            rs = carry_r + rs - rinc;
-            bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
-            if (aligned) {
-                if ((uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;                        // mod.c:853
-                int64_t r0 = (int64_t)c.pos + rs;
-                if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;          // mod.c:860
+        // 256 ops per trip: the four loads are issued before any of them is consumed (memory-level parallelism;
+        // one wave alone otherwise pays a full HBM round trip per 64 ops)
+        for (uint32_t i0 = 0; i0 < c.ncig; i0 += 256) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t i = i0 + 64u * u + lane;
+                wv[u] = i < c.ncig ? cg[i] : 0u;
             }
-            if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;  // mod.c:865
-            if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
-            if (act) {
-                uint32_t rv = (rs & 0x0FFFFFFFu) | (op << 28);
-                if (i < (uint32_t)kCigCap) { S.cig_q[i] = qs; S.cig_r[i] = rv; }
-                else { c.spill_q[i - kCigCap] = qs; c.spill_r[i - kCigCap] = rv; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t i = i0 + 64u * u + lane;
+                bool act = i < c.ncig;
+                uint32_t w = wv[u];
+                uint32_t op = w & 15u, len = w >> 4;
+                // ops MIDNSHP=X = 0..8 ; query-consuming {M,I,S,=,X}, reference-consuming {M,D,N,=,X}
+                uint32_t qinc = (act && ((0x193u >> op) & 1u)) ? len : 0u;
+                uint32_t rinc = (act && ((0x18Du >> op) & 1u)) ? len : 0u;
+                if (act && op == 5u) err = MM_E_HARDCLIP;                     // mod.c:841-844
+                else if (act && (op == 6u || op > 8u)) err = MM_E_CIGAROP;    // mod.c:845-848
+                uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
+                uint32_t qtot = lane_valu(qs, 63), rtot = lane_valu(rs, 63);
+                qs = carry_q + qs - qinc;
+                rs = carry_r + rs - rinc;
+                bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
+                if (aligned) {
+                    if ((uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;                        // mod.c:853
+                    int64_t r0 = (int64_t)c.pos + rs;
+                    if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;          // mod.c:860
+                }
+                if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;  // mod.c:865
+                if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
+                if (act) {
+                    uint32_t rv = (rs & 0x0FFFFFFFu) | (op << 28);
+                    if (i < (uint32_t)kCigCap) { S.cig_q[i] = qs; S.cig_r[i] = rv; }
+                    else { c.spill_q[i - kCigCap] = qs; c.spill_r[i - kCigCap] = rv; }
+                }
+                carry_q += qtot; carry_r += rtot;
             }
-            carry_q += qtot; carry_r += rtot;
         }
         c.q_total = carry_q;
         wave_sync();
     }
 
     // ---- a5 base directory (mod.c:972-981) as a rank directory over 32-base blocks
+    __device__ __forceinline__ uint32_t count_block(uint4 v, int cls, uint32_t b) const {
+        int valid = (int)min(32u, c.L - b * 32u);
+        if (cls == 0) {
+            uint32_t o = 0;
+            o += __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15));
+            o += __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15));
+            o += __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15));
+            o += __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
+            return (uint32_t)valid - o;  // zero padding nibbles never match 2/4/8/15
+        }
+        return __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) +
+               __popc(class_bits(v.w, cls));
+    }
     __device__ void build_dir(int cls) {
         const int lane = lane_id();
         const uint4* sq = reinterpret_cast<const uint4*>(c.seq);
         uint32_t carry = 0;
-        for (uint32_t b0 = 0; b0 < c.nblk; b0 += 64) {
-            uint32_t b = b0 + lane;
-            uint32_t cnt = 0;
-            if (b < c.nblk) {
-                uint4 v = sq[b];
-                int valid = (int)min(32u, c.L - b * 32u);
-                if (cls == 0) {
-                    uint32_t o = 0;
-                    o += __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15));
-                    o += __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15));
-                    o += __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15));
-                    o += __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
-                    cnt = (uint32_t)valid - o;  // zero padding nibbles never match 2/4/8/15
-                } else {
-                    cnt = __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) +
-                          __popc(class_bits(v.w, cls));
+        // 256 blocks (8192 bases) per trip, four 16-byte loads in flight per lane
+        for (uint32_t b0 = 0; b0 < c.nblk; b0 += 256) {
+            uint4 vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t b = b0 + 64u * u + lane;
+                vv[u] = b < c.nblk ? sq[b] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t b = b0 + 64u * u + lane;
+                uint32_t cnt = b < c.nblk ? count_block(vv[u], cls, b) : 0u;
+                uint32_t incl = wave_incl_scan(cnt);
+                uint32_t tot = lane_valu(incl, 63);
+                if (b < c.nblk) {
+                    uint32_t ex = carry + incl - cnt;
+                    if (b < (uint32_t)kDirCap) S.dir[b] = ex; else c.spill_d[b - kDirCap] = ex;
                 }
+                carry += tot;
             }
-            uint32_t incl = wave_incl_scan(cnt);
-            uint32_t tot = lane_valu(incl, 63);
-            if (b < c.nblk) {
-                uint32_t ex = carry + incl - cnt;
-                if (b < (uint32_t)kDirCap) S.dir[b] = ex; else c.spill_d[b - kDirCap] = ex;
-            }
-            carry += tot;
         }
         c.nb = carry;
         c.cls = cls;
         wave_sync();
     }
 
-    // rank (0-based, BAM orientation) of a base of the current class -> (BAM index q, nt16 code)
-    __device__ __forceinline__ uint32_t select_base(uint32_t rr, uint32_t& code) const {
-        uint32_t lo = 0;
-        uint32_t step = 1;
+    // rank (0-based, BAM orientation) of a base of the current class -> its 32-base block (largest b with dir[b] <= rr)
+    __device__ __forceinline__ uint32_t find_block(uint32_t rr) const {
+        uint32_t lo = 0, step = 1;
         while (step < c.nblk) step <<= 1;
         for (step >>= 1; step; step >>= 1) {
             uint32_t cand = lo + step;
             if (cand < c.nblk && dr(cand) <= rr) lo = cand;
         }
-        uint32_t k = rr - dr(lo);
-        uint4 v = reinterpret_cast<const uint4*>(c.seq)[lo];
-        int valid = (int)min(32u, c.L - lo * 32u);
+        return lo;
+    }
+    // k-th base of the current class inside block `blk` (16 bytes v) -> BAM index q, nt16 code
+    __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
+        int valid = (int)min(32u, c.L - blk * 32u);
         uint32_t w0 = base_order(v.x), w1 = base_order(v.y), w2 = base_order(v.z), w3 = base_order(v.w);
         uint32_t m0 = class_bits(w0, c.cls) & valid_bits(valid);
         uint32_t m1 = class_bits(w1, c.cls) & valid_bits(valid - 8);
@@ -350,7 +384,7 @@ struct K1 {
         cn = __popc(mk & 0xFu);
         if (k >= cn) { n += 1; }
         code = (wv >> (4 * n)) & 15u;
-        return lo * 32u + word * 8u + n;
+        return blk * 32u + word * 8u + n;
     }
 
     // BAM index q -> CIGAR op containing it (largest i with cq(i) <= q); only valid for q < q_total
@@ -381,114 +415,218 @@ struct K1 {
         }
     }
 
-    // ---- a7/a8/a9: one candidate call: rank -> read position -> reference position -> filters -> counter
-    //      (mod.c:1097-1199 explicit, :1203-1367 implicit, update_freq_map :883-929)
-    __device__ void process_call(uint32_t rank, uint32_t k, bool is_explicit) {
-        uint32_t q, code;
-        if (c.direct) {  // canonical base N: every base counts (mod.c:1102-1107)
-            if (rank >= c.L) { err = MM_E_READPOS; return; }
-            q = c.rev ? c.L - 1 - rank : rank;
-            uint8_t b = c.seq[q >> 1];
-            code = (q & 1u) ? (b & 15u) : (b >> 4);
-        } else {
-            if (rank >= c.nb) { err = MM_E_READPOS; return; }  // the reference reads out of bounds here
-            q = select_base(c.rev ? c.nb - 1 - rank : rank, code);
-        }
-        // (a') of SURVEY.md: proj(q) for aligned bases; with --insertions the anchor insL() left of the insertion
-        int64_t ref_pos = -1, ins_anchor = -1;
-        uint32_t ins_off = 0;
-        if (q < c.q_total) {
-            uint32_t i = find_op(q);
-            uint32_t rv = cr(i), op = rv >> 28, qs = cq(i);
-            if ((0x181u >> op) & 1u) {
-                ref_pos = (int64_t)c.pos + (rv & 0x0FFFFFFFu) + (q - qs);
-            } else if (op == 1u && p.insertions) {
-                ins_off = (q - qs + 1u) & 0xFFFFu;  // ins_offset, truncated like make_key's uint16 (mod.c:428)
-                ins_anchor = (int64_t)c.pos + (rv & 0x0FFFFFFFu) - 1;
+    // ---- a7/a8/a9: J candidate calls per lane, run as a staged pipeline so that the J dependent chains
+    //      rank -> seq block (global) -> read position -> CIGAR op (LDS) -> reference word (global) -> ML (global) -> atomic
+    //      overlap their memory latency.  (mod.c:1097-1199 explicit, :1203-1367 implicit, update_freq_map :883-929)
+    template <int J>
+    __device__ __forceinline__ void process_calls(const uint32_t (&rank)[J], const uint32_t (&kidx)[J], const bool (&live_in)[J], bool is_explicit) {
+        bool live[J];
+        uint32_t blk[J], kk[J], q[J], code[J], ins_off[J];
+        int64_t ref_pos[J];
+        uint4 sv[J];
+        // stage 1: block of the rank directory (LDS), or the direct position for canonical base N (mod.c:1102-1107)
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            live[u] = live_in[u];
+            blk[u] = 0; kk[u] = 0; q[u] = 0; code[u] = 0; ins_off[u] = 0; ref_pos[u] = -1;
+            if (!live[u]) continue;
+            if (c.direct) {
+                if (rank[u] >= c.L) { err = MM_E_READPOS; live[u] = false; continue; }
+                q[u] = c.rev ? c.L - 1 - rank[u] : rank[u];
+            } else {
+                if (rank[u] >= c.nb) { err = MM_E_READPOS; live[u] = false; continue; }  // the reference reads out of bounds here
+                uint32_t rr = c.rev ? c.nb - 1 - rank[u] : rank[u];
+                blk[u] = find_block(rr);
+                kk[u] = rr - dr(blk[u]);
             }
         }
-        if (ref_pos < 0 && p.insertions) {
-            if (is_explicit || !c.rev) {
-                ref_pos = ins_anchor;                                    // mod.c:1124
-            } else {
-                // quirk (mod.c:1234,1314): the implicit path indexes ins[] with the BAM-orientation position,
-                // i.e. for reverse reads it takes the insertion anchor of the MIRRORED base L-1-q.
-                uint32_t q2 = c.L - 1u - q;
-                if (q2 < c.q_total) {
-                    uint32_t i2 = find_op(q2);
-                    uint32_t rv2 = cr(i2);
-                    if ((rv2 >> 28) == 1u) ref_pos = (int64_t)c.pos + (rv2 & 0x0FFFFFFFu) - 1;
+        // stage 2: the 16 sequence bytes of each block (global; all J loads in flight together)
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            sv[u] = make_uint4(0, 0, 0, 0);
+            if (live[u]) sv[u] = c.direct ? make_uint4(c.seq[q[u] >> 1], 0, 0, 0) : reinterpret_cast<const uint4*>(c.seq)[blk[u]];
+        }
+        // stage 3: read position + base, then projection through the CIGAR prefix arrays (LDS)
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            if (!live[u]) continue;
+            if (c.direct) { uint32_t b = sv[u].x; code[u] = (q[u] & 1u) ? (b & 15u) : (b >> 4); }
+            else q[u] = select_in_block(sv[u], blk[u], kk[u], code[u]);
+            // (a') of SURVEY.md: proj(q) for aligned bases; with --insertions the anchor insL() left of the insertion
+            int64_t rp = -1, anchor = -1;
+            if (q[u] < c.q_total) {
+                uint32_t i = find_op(q[u]);
+                uint32_t rv = cr(i), op = rv >> 28, qs = cq(i);
+                if ((0x181u >> op) & 1u) {
+                    rp = (int64_t)c.pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
+                } else if (op == 1u && p.insertions) {
+                    ins_off[u] = (q[u] - qs + 1u) & 0xFFFFu;  // ins_offset, truncated like make_key's uint16 (mod.c:428)
+                    anchor = (int64_t)c.pos + (rv & 0x0FFFFFFFu) - 1;
                 }
             }
+            if (rp < 0 && p.insertions) {
+                if (is_explicit || !c.rev) {
+                    rp = anchor;                                             // mod.c:1124
+                } else {
+                    // quirk (mod.c:1234,1314): the implicit path indexes ins[] with the BAM-orientation position,
+                    // i.e. for reverse reads it takes the insertion anchor of the MIRRORED base L-1-q.
+                    uint32_t q2 = c.L - 1u - q[u];
+                    if (q2 < c.q_total) {
+                        uint32_t i2 = find_op(q2);
+                        uint32_t rv2 = cr(i2);
+                        if ((rv2 >> 28) == 1u) rp = (int64_t)c.pos + (rv2 & 0x0FFFFFFFu) - 1;
+                    }
+                }
+            }
+            ref_pos[u] = rp;
+            if (rp < 0) live[u] = false;
         }
-        if (ref_pos < 0) return;
+        // stage 4: reference words and the first code's ML byte (global, J + J loads in flight)
+        uint32_t w[J], ml0[J];
         const RefWord* rw = reinterpret_cast<const RefWord*>(c.refw);
-        uint32_t w = (uint32_t)rw[c.ref_base + ref_pos];
-        st_look++;
-        uint32_t refcode = w & 31u;
-        for (int m = 0; m < c.n_codes_grp; m++) {
-            int ci = S.g_code[m];
-            if (ci < 0) continue;
-            const DevCode& dc = p.codes[ci];
-            int req = dc.req;
-            if (!p.insertions) {
-                bool in_ctx = (w >> (5 + 2 * req + c.rev)) & 1u;
-                bool matches = p.mods[req].ctx_is_star || c.mb_is_N || refcode == code;
-                if (!(in_ctx && matches)) continue;
-            }
-            int is_mod = 0;
+        const int ncg = c.n_codes_grp;
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            w[u] = 0; ml0[u] = 0;
+            if (!live[u]) continue;
+            w[u] = (uint32_t)rw[c.ref_base + ref_pos[u]];
+            st_look++;
             if (is_explicit) {
-                uint64_t ml_idx = (uint64_t)c.ml_start + (uint64_t)k * c.n_codes_grp + m;
-                if (ml_idx >= c.ml_len) { err = MM_E_MLIDX; return; }  // mod.c:1174
-                uint32_t kl = p.mods[req].klass[c.ml[ml_idx]];
-                st_ml++;
-                if (kl == 0) continue;
-                is_mod = kl == 3;
+                uint64_t mi = (uint64_t)c.ml_start + (uint64_t)kidx[u] * ncg;
+                if (mi < c.ml_len) ml0[u] = c.ml[mi];
             }
-            int64_t off = ref_pos - c.seg_begin;
-            if (ins_off == 0 && dc.plane >= 0 && c.hpi >= 0 && off >= 0 && off < c.seg_len) {
-                unsigned long long* dst = p.counters +
-                    ((int64_t)(dc.plane * p.n_hp + c.hpi) * 2 + c.rev) * p.plane_len + c.cnt_base + off;
-                atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
-                st_dense++;
-            } else {
-                side_append((int32_t)ref_pos, ins_off, is_mod, ci);
-                st_side++;
+        }
+        // stage 5: per code: context + base test, threshold class, counter update
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            if (!live[u]) continue;
+            uint32_t refcode = w[u] & 31u;
+            for (int m = 0; m < ncg; m++) {
+                int ci = S.g_code[m];
+                if (ci < 0) continue;
+                const DevCode& dc = p.codes[ci];
+                int req = dc.req;
+                const DevMod& dm = p.mods[req];
+                if (!p.insertions) {
+                    bool in_ctx = (w[u] >> (5 + 2 * req + c.rev)) & 1u;
+                    bool matches = dm.ctx_is_star || c.mb_is_N || refcode == code[u];
+                    if (!(in_ctx && matches)) continue;
+                }
+                int is_mod = 0;
+                if (is_explicit) {
+                    uint64_t ml_idx = (uint64_t)c.ml_start + (uint64_t)kidx[u] * ncg + m;
+                    if (ml_idx >= c.ml_len) { err = MM_E_MLIDX; break; }  // mod.c:1174
+                    int mv = m == 0 ? (int)ml0[u] : (int)c.ml[ml_idx];
+                    st_ml++;
+                    if (mv >= dm.t_hi) is_mod = 1;            // mod.c:1184
+                    else if (mv <= dm.t_lo) is_mod = 0;        // mod.c:1187
+                    else continue;                             // ambiguous
+                }
+                int64_t off = ref_pos[u] - c.seg_begin;
+                if (ins_off[u] == 0 && dc.plane >= 0 && c.hpi >= 0 && off >= 0 && off < c.seg_len) {
+                    unsigned long long* dst = p.counters +
+                        ((int64_t)(dc.plane * p.n_hp + c.hpi) * 2 + c.rev) * p.plane_len + c.cnt_base + off;
+                    atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+                    st_dense++;
+                } else {
+                    side_append((int32_t)ref_pos[u], ins_off[u], is_mod, ci);
+                    st_side++;
+                }
             }
         }
     }
 
-    // compacted skip counts -> calls; cnt <= 64 tokens of the current group
+    // four MM characters starting at byte offset `off`; characters at or past the end of the string read as ';'
+    __device__ __forceinline__ uint32_t load_mm_dword(const uint8_t* mm, uint32_t mlen, uint32_t off) const {
+        uint32_t w = 0x3B3B3B3Bu;
+        if (off < mlen) {
+            uint32_t raw;
+            __builtin_memcpy(&raw, mm + off, 4);   // unaligned dword; the pool is padded past the string
+            uint32_t left = mlen - off;            // valid characters in this dword (>= 1)
+            uint32_t keep = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
+            w = (raw & keep) | (0x3B3B3B3Bu & ~keep);
+        }
+        return w;
+    }
+
+    // the rank directory is built lazily, when a group is about to make its first call
+    __device__ __forceinline__ void ensure_dir(int cls, bool dot) {
+        if ((!c.direct || dot) && cls != c.cls) build_dir(cls);
+    }
+
+    // compacted skip counts -> calls; cnt <= 256 tokens of the current group (token t = 64*u + lane)
     __device__ void flush_tokens(uint32_t cnt, uint32_t& rank_carry, uint32_t& k_carry, bool dot) {
         const int lane = lane_id();
-        bool act = (uint32_t)lane < cnt;
-        uint32_t s = act ? S.tok[lane] : 0u;
-        uint32_t incl = wave_incl_scan(act ? s + 1u : 0u);
-        uint32_t tot = lane_valu(incl, 63);
-        uint32_t rank = rank_carry + incl - 1u;
-        if (act) process_call(rank, k_carry + lane, true);
-        if (dot) {
-            uint32_t gi = wave_incl_scan(s);
-            uint32_t T = lane_valu(gi, 63);
-            S.gap[lane] = gi - s;
-            S.gstart[lane] = rank - s;
-            wave_sync();
-            for (uint32_t t0 = 0; t0 < T; t0 += 64) {
-                uint32_t t = t0 + lane;
-                if (t < T) {
-                    uint32_t lo = 0;
+        constexpr int J = kCallsPerLane;
+        uint32_t s[J], rank[J], kidx[J];
+        bool live[J];
+        uint32_t carry = rank_carry;
 #pragma unroll
-                    for (uint32_t step = 32; step; step >>= 1) {
-                        uint32_t cand = lo + step;
-                        if (cand < 64u && S.gap[cand] <= t) lo = cand;
+        for (int u = 0; u < J; u++) {
+            uint32_t t = 64u * u + lane;
+            live[u] = t < cnt;
+            s[u] = live[u] ? S.tok[t] : 0u;
+            uint32_t incl = wave_incl_scan(live[u] ? s[u] + 1u : 0u);
+            rank[u] = carry + incl - 1u;
+            kidx[u] = k_carry + t;
+            carry += lane_valu(incl, 63);
+        }
+        process_calls<J>(rank, kidx, live, true);
+        if (dot) {
+            // implicit calls: every rank inside the gap in front of each listed one (mod.c:1206-1287), expanded
+            // 64 tokens at a time by a load-balanced search over the exclusive prefix of the gap sizes.  The skip
+            // counts are re-read from LDS (they are still in tok[]) so that nothing is indexed dynamically in registers.
+            uint32_t carry2 = rank_carry;
+#pragma unroll 1
+            for (uint32_t t64 = 0; t64 < cnt; t64 += 64u) {
+                uint32_t t = t64 + lane;
+                bool lv = t < cnt;
+                uint32_t su = lv ? S.tok[t] : 0u;
+                uint32_t incl = wave_incl_scan(lv ? su + 1u : 0u);
+                uint32_t ranku = carry2 + incl - 1u;
+                carry2 += lane_valu(incl, 63);
+                uint32_t gi = wave_incl_scan(su);
+                uint32_t T = lane_valu(gi, 63);
+                wave_sync();
+                S.gap[lane] = gi - su;
+                S.gstart[lane] = ranku - su;
+                wave_sync();
+                for (uint32_t t0 = 0; t0 < T; t0 += 64u * J) {
+                    uint32_t r2[J], k2[J];
+                    bool l2[J];
+#pragma unroll
+                    for (int v = 0; v < J; v++) {
+                        uint32_t tt = t0 + 64u * v + lane;
+                        l2[v] = tt < T; r2[v] = 0; k2[v] = 0;
+                        if (l2[v]) {
+                            uint32_t lo = 0;
+#pragma unroll
+                            for (uint32_t step = 32; step; step >>= 1) {
+                                uint32_t cand = lo + step;
+                                if (cand < 64u && S.gap[cand] <= tt) lo = cand;
+                            }
+                            r2[v] = S.gstart[lo] + (tt - S.gap[lo]);
+                        }
                     }
-                    process_call(S.gstart[lo] + (t - S.gap[lo]), 0, false);
+                    process_calls<J>(r2, k2, l2, false);
                 }
             }
-            wave_sync();
         }
-        rank_carry += tot;
+        rank_carry = carry;
         k_carry += cnt;
+    }
+
+    // bases after the last listed one of a '.' group (mod.c:1289-1365)
+    __device__ void implicit_tail(uint32_t first_rank) {
+        const int lane = lane_id();
+        constexpr int J = kCallsPerLane;
+        for (uint32_t r0 = first_rank; r0 < c.nb; r0 += 64u * J) {
+            uint32_t r2[J], k2[J];
+            bool l2[J];
+#pragma unroll
+            for (int v = 0; v < J; v++) { r2[v] = r0 + 64u * v + lane; k2[v] = 0; l2[v] = r2[v] < c.nb; }
+            process_calls<J>(r2, k2, l2, false);
+        }
     }
 
     __device__ void flush_stats() {
@@ -512,7 +650,7 @@ struct K1 {
 
     // ---- freq_view_single (mod.c:948-1370) for one read
     // Returns the read's status code (wave-uniform).  Single exit, no early returns: the caller reports errors.
-    __device__ int run(int ridx, int wave_slot) {
+    __device__ int run(int ridx, int wave_slot, uint32_t part, uint32_t nparts) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         err = 0;
@@ -538,7 +676,9 @@ struct K1 {
         } else {
         c.ref_base = p.ref_base[c.tid];
         c.seg_begin = p.seg_begin[c.tid]; c.seg_len = p.seg_len[c.tid]; c.cnt_base = p.cnt_base[c.tid];
+        MMT_DECL;
         scan_cigar(p.cigar + rd.cigar_off, p.ctg_len[c.tid]);
+        MMT_LAP(4);
         result = any_err();
         c.cls = -1; c.nb = 0; c.ml_start = 0;
         if (result == 0) {
@@ -546,7 +686,9 @@ struct K1 {
         // `bad` (a ballot over the lanes' err), which the loop headers test.  (A version with divergent-looking
         // breaks out of the nested loops hung on gfx950 when an error was raised inside the MM loop.)
         uint32_t mpos = 0;
-        bool bad = false;
+        bool bad = false, finished_part = false;
+        const uint32_t own_lo = (uint32_t)(((uint64_t)mlen * part) / nparts);
+        const uint32_t own_hi = part + 1u >= nparts ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)mlen * (part + 1u)) / nparts);
         while (mpos < mlen && !bad) {
             // ---------------- a6 group header (mod.c:1003-1062)
             uint32_t ci = mpos + lane;
@@ -611,72 +753,106 @@ struct K1 {
                 c.direct = modbase == 'N';
                 int cls = base_class_of_char(mb);
                 bool dot = flag == '.';
-                if (!bad && (!c.direct || dot) && cls != c.cls) build_dir(cls);
+                MMT_LAP(6);
 
-                // ---------------- a6 skip counts (mod.c:1064-1089), 64 characters per step
+                // ---------------- a6 skip counts (mod.c:1064-1089): 256 characters per trip (one dword per lane, the
+                // next trip's dword already in flight), parsed as four 64-character sub-chunks from LDS.
+                // A read split into parts owns the sub-chunks whose first character lies in [own_lo, own_hi): chunks
+                // before it only advance the token / rank carries, the first chunk after it ends the part.
                 uint32_t k_carry = 0, rank_carry = 0, ntok = 0;
-                bool prev_delim = true, done = bad;
+                bool prev_delim = true, done = bad, group_end_owned = false;
+                uint32_t wd_next = 0;
+                bool have_next = false;
                 while (!done) {
-                    uint32_t cj = cpos + lane;
-                    int x = cj < mlen ? (int)mm[cj] : ';';   // the end of the string closes the group
-                    S.mm[lane] = (uint8_t)x;
-                    if (lane < 16) { uint32_t ck = cpos + 64 + lane; S.mm[64 + lane] = ck < mlen ? mm[ck] : (uint8_t)';'; }
+                    uint32_t wd;
+                    if (have_next) wd = wd_next;
+                    else wd = load_mm_dword(mm, mlen, cpos + 4u * lane);
+                    wd_next = load_mm_dword(mm, mlen, cpos + 256u + 4u * lane);   // look-ahead + next trip
                     wave_sync();
-                    uint64_t semi = __ballot(x == ';');
-                    int endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
-                    bool in = lane < endl;
-                    int pv = __shfl_up(x, 1, 64);
-                    bool pdel = lane == 0 ? prev_delim : (pv == ',');
-                    bool tstart = in && x != ',' && pdel;
-                    uint32_t v = 0;
-                    if (tstart) {
-                        // decimal fold over at most 10 look-ahead characters, no early exit (mod.c:1074-1084)
-                        bool open = true;
-                        int len = 0;
-#pragma unroll
-                        for (int j = 0; j < 10; j++) {
-                            int d = S.mm[lane + j];
-                            bool delim = d == ',' || d == ';';
-                            open = open && !delim;
-                            if (open) {
-                                if (d < '0' || d > '9') err = MM_E_SKIPVAL;
-                                v = v * 10u + (uint32_t)(d - '0');
-                                len++;
-                            }
+                    S.mmw[lane] = wd;
+                    if (lane < 4) S.mmw[64 + lane] = wd_next;   // characters 256..271 = the next trip's first four dwords
+                    wave_sync();
+                    const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
+                    bool group_closed = false;
+#pragma unroll 1
+                    for (int sub = 0; sub < 4; sub++) {
+                        if (group_closed || done) continue;
+                        uint32_t cs = cpos + 64u * sub;
+                        if (cs >= own_hi) {          // past this part's share: finish what is pending and stop the read
+                            done = true; finished_part = true;
+                            continue;
                         }
-                        if (len == 10) err = MM_E_SKIPLEN;                             // assert(l < 10), mod.c:1080
+                        bool own = cs >= own_lo;
+                        int x = mb8[64 * sub + lane];
+                        uint64_t semi = __ballot(x == ';');
+                        int endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
+                        bool in = lane < endl;
+                        int pv = __shfl_up(x, 1, 64);
+                        bool pdel = lane == 0 ? prev_delim : (pv == ',');
+                        bool tstart = in && x != ',' && pdel;
+                        uint32_t v = 0;
+                        if (tstart) {
+                            // decimal fold over at most 10 look-ahead characters, no early exit (mod.c:1074-1084)
+                            bool open = true;
+                            int len = 0;
+#pragma unroll
+                            for (int j = 0; j < 10; j++) {
+                                int d = mb8[64 * sub + lane + j];
+                                bool delim = d == ',' || d == ';';
+                                open = open && !delim;
+                                if (open) {
+                                    if (d < '0' || d > '9') err = MM_E_SKIPVAL;
+                                    v = v * 10u + (uint32_t)(d - '0');
+                                    len++;
+                                }
+                            }
+                            if (len == 10) err = MM_E_SKIPLEN;                         // assert(l < 10), mod.c:1080
+                        }
+                        uint64_t tb = __ballot(tstart);
+                        uint32_t nt = (uint32_t)__popcll(tb);
+                        if (own) {
+                            if (tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = v;
+                            ntok += nt;
+                        } else {
+                            uint32_t sm = wave_incl_scan(tstart ? v + 1u : 0u);
+                            rank_carry += lane_valu(sm, 63);
+                            k_carry += nt;
+                        }
+                        if (endl < 64) { group_closed = true; done = true; group_end_owned = own; cpos = cs + (uint32_t)endl + 1u; }
+                        else prev_delim = lane_val(x, 63) == ',';
                     }
-                    uint64_t tb = __ballot(tstart);
-                    if (tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = v;
-                    ntok += __popcll(tb);
                     wave_sync();
+                    if (!group_closed && !done) { cpos += 256u; have_next = true; }
                     bad = __ballot(err != 0) != 0;
-                    if (endl < 64) { done = true; cpos += endl + 1; }
-                    else { cpos += 64; prev_delim = lane_val(x, 63) == ','; }
                     if (bad) { done = true; ntok = 0; }
-                    while (ntok >= 64 || (done && ntok > 0)) {
-                        uint32_t cnt = ntok < 64u ? ntok : 64u;
+                    MMT_LAP(6);
+                    while (ntok >= 256u || (done && ntok > 0)) {
+                        uint32_t cnt = ntok < 256u ? ntok : 256u;
+                        ensure_dir(cls, dot);
+                        MMT_LAP(5);
                         flush_tokens(cnt, rank_carry, k_carry, dot);
-                        uint32_t rem = ntok - cnt;
-                        uint32_t y = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
+                        uint32_t rem = ntok - cnt;   // < 128
+                        uint32_t y0 = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
+                        uint32_t y1 = (uint32_t)lane + 64u < rem ? S.tok[cnt + 64u + lane] : 0u;
                         wave_sync();
-                        if ((uint32_t)lane < rem) S.tok[lane] = y;
+                        if ((uint32_t)lane < rem) S.tok[lane] = y0;
+                        if ((uint32_t)lane + 64u < rem) S.tok[64u + lane] = y1;
                         wave_sync();
                         ntok = rem;
                         if (__ballot(err != 0)) { bad = true; done = true; ntok = 0; }
+                        MMT_LAP(7);
                     }
                 }
-                if (!bad) {
+                if (!bad && !finished_part) {
                     if (k_carry > 0) c.ml_start += k_carry * (uint32_t)n;                // mod.c:1200
-                    if (dot) {  // bases after the last listed one (mod.c:1289-1365)
-                        for (uint32_t r0 = rank_carry; r0 < c.nb; r0 += 64) {
-                            uint32_t rk = r0 + lane;
-                            if (rk < c.nb) process_call(rk, 0, false);
-                        }
+                    if (dot && group_end_owned) {   // bases after the last listed one (mod.c:1289-1365)
+                        ensure_dir(cls, dot);
+                        implicit_tail(rank_carry);
                     }
                     bad = __ballot(err != 0) != 0;
                     mpos = cpos;
                 }
+                if (finished_part) bad = bad || true;   // leaves the group loop; `result` comes from any_err()
             }
         }
         result = any_err();
@@ -687,7 +863,7 @@ struct K1 {
 };
 
 template <typename RefWord>
-__global__ __launch_bounds__(256) void k_freq_reads(const DevParams p) {
+__global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     __shared__ WaveLds lds[kWavesPerBlock];
     const int wv = threadIdx.x >> 6;
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
@@ -696,10 +872,12 @@ __global__ __launch_bounds__(256) void k_freq_reads(const DevParams p) {
         int r = 0;
         if (lane_id() == 0) r = (int)atomicAdd(p.queue, 1u);
         r = uni(r);
-        if (r >= p.n_reads) break;
-        int ridx = p.order ? p.order[r] : r;
-        ridx = uni(ridx);
-        int e = uni(k.run(ridx, wave_slot));
+        if (r >= p.n_items) break;
+        uint32_t item = p.order ? (uint32_t)p.order[r] : (uint32_t)r;
+        item = uniu(item);
+        int ridx = (int)(item & 0xFFFFFFu);
+        uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
+        int e = uni(k.run(ridx, wave_slot, part, nparts));
         if (p.stats) k.flush_stats();
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;

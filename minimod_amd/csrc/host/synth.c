@@ -330,6 +330,7 @@ int mm_batch_make_order(mm_host_batch_t *hb) {
     free(cnt);
     free((void *)hb->b.order);
     hb->b.order = order;
+    hb->b.n_order = n;
     return 0;
 }
 

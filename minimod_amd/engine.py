@@ -26,7 +26,7 @@ assert READ_DTYPE.itemsize == 64 and ROW_DTYPE.itemsize == 24
 class mm_batch_t(ctypes.Structure):
     _fields_ = [("reads", ctypes.c_void_p), ("cigar", ctypes.c_void_p), ("seq", ctypes.c_void_p),
                 ("mm", ctypes.c_void_p), ("ml", ctypes.c_void_p), ("order", ctypes.c_void_p),
-                ("n_reads", ctypes.c_int32), ("rsvd", ctypes.c_int32),
+                ("n_reads", ctypes.c_int32), ("n_order", ctypes.c_int32),
                 ("n_cigar_words", ctypes.c_uint64), ("n_seq_bytes", ctypes.c_uint64),
                 ("n_mm_bytes", ctypes.c_uint64), ("n_ml_bytes", ctypes.c_uint64),
                 ("max_n_cigar", ctypes.c_uint32), ("max_l_qseq", ctypes.c_uint32)]
@@ -54,7 +54,7 @@ class mm_interval_t(ctypes.Structure):
                 ("end", ctypes.c_int64), ("halo", ctypes.c_int64)]
 
 
-EXPORTS = ["mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
+EXPORTS = ["mm_freq_plan_batch", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
            "mm_freq_wait", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
@@ -93,6 +93,8 @@ def load_library(build=True):
     L.mm_freq_submit_device.argtypes = [vp, ctypes.POINTER(mm_batch_t), vp]
     L.mm_freq_wait.restype = i32
     L.mm_freq_wait.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.mm_freq_plan_batch.restype = i32
+    L.mm_freq_plan_batch.argtypes = [vp, i32, vp, i32]
     L.mm_freq_intern_code.restype = i32
     L.mm_freq_intern_code.argtypes = [vp, ctypes.c_char_p]
     L.mm_freq_n_codes.restype = i32
@@ -138,6 +140,17 @@ def klass_lut(thresh):
     return out
 
 
+def plan_batch(reads):
+    """Work items for a batch (long reads split into parts, costliest first) as an int32 array."""
+    L = load_library()
+    reads = np.ascontiguousarray(reads)
+    out = np.empty(max(16 * len(reads), 1), dtype=np.int32)
+    n = L.mm_freq_plan_batch(reads.ctypes.data, len(reads), out.ctypes.data, len(out))
+    if n < 0:
+        raise MinimodHipError(-n, "mm_freq_plan_batch failed")
+    return out[:n].copy()
+
+
 def batch_struct(batch, order=None, device=False):
     """numpy batch (dict with reads/cigar/seq/mm/ml) or dict of device pointers -> mm_batch_t."""
     b = mm_batch_t()
@@ -145,6 +158,7 @@ def batch_struct(batch, order=None, device=False):
         for k in ("reads", "cigar", "seq", "mm", "ml"):
             setattr(b, k, int(batch[k]))
         b.order = int(batch.get("order", 0) or 0)
+        b.n_order = int(batch.get("n_order", 0) or 0)
         for k in ("n_reads", "n_cigar_words", "n_seq_bytes", "n_mm_bytes", "n_ml_bytes", "max_n_cigar", "max_l_qseq"):
             setattr(b, k, int(batch[k]))
         return b
@@ -152,6 +166,7 @@ def batch_struct(batch, order=None, device=False):
     b.reads, b.cigar, b.seq = rd.ctypes.data, batch["cigar"].ctypes.data, batch["seq"].ctypes.data
     b.mm, b.ml = batch["mm"].ctypes.data, batch["ml"].ctypes.data
     b.order = order.ctypes.data if order is not None else 0
+    b.n_order = len(order) if order is not None else 0
     b.n_reads = len(rd)
     b.n_cigar_words, b.n_seq_bytes = len(batch["cigar"]), len(batch["seq"])
     b.n_mm_bytes, b.n_ml_bytes = len(batch["mm"]), len(batch["ml"])
@@ -260,11 +275,12 @@ class FreqEngine(object):
         self.L.mm_freq_stats_enable(self.h, int(on))
 
     def stats_get(self):
-        out = (ctypes.c_uint64 * 4)()
+        out = (ctypes.c_uint64 * 8)()
         r = self.L.mm_freq_stats_get(self.h, out)
         if r:
             raise MinimodHipError(-r, "stats_get failed")
-        return {"lookups": int(out[0]), "ml_reads": int(out[1]), "dense_updates": int(out[2]), "side_updates": int(out[3])}
+        return {"lookups": int(out[0]), "ml_reads": int(out[1]), "dense_updates": int(out[2]), "side_updates": int(out[3]),
+                "phase_cycles": [int(out[i]) for i in range(4, 8)]}
 
     # -- results
     def finalize(self):
