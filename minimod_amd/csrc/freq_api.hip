@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "freq_kernels.hip.h"
+#include "freq_tiles.hip.h"
 #include "minimod_hip.h"
 
 using namespace mmhip;
@@ -38,7 +39,13 @@ struct Slot {
     void* d_order = nullptr; size_t cap_order = 0;
     int32_t* d_status = nullptr; size_t cap_status = 0;
     uint32_t* d_spill = nullptr; size_t cap_spill = 0;
-    unsigned int* d_ctl = nullptr;   // [0] queue, [1] err_summary
+    unsigned int* d_ctl = nullptr;   // [0] read queue, [1] err_summary, [2] tile_count, [3] tile_queue, [4] fb_count, [5] fb_queue
+    uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
+    uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
+    uint32_t* d_gdir = nullptr; size_t cap_gdir = 0;
+    uint32_t* d_gqtot = nullptr; size_t cap_gqtot = 0;
+    TileRec* d_tiles = nullptr; size_t cap_tiles = 0;
+    int32_t* d_fb = nullptr; size_t cap_fb = 0;
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
     std::vector<int32_t> plan;   // host copy of the work items while the upload is in flight
@@ -49,7 +56,8 @@ struct Slot {
 struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
-    int n_cu = 0, blocks_per_cu = 1;
+    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4;
+    bool use_tiles = true;   // MM_FUSED=1 forces the fused one-wave-per-read kernel
     bool wide = false;  // 32-bit reference words (n_mods > 5)
     int n_contigs = 0;
     std::vector<std::string> names;
@@ -147,8 +155,11 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
     p.n_reads = b->n_reads;
     p.n_items = b->order ? b->n_order : b->n_reads;
-    int blocks = std::min((p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->blocks_per_cu);
+    p.n_items_dev = nullptr;
+    const int full_grid = h->n_cu * h->blocks_per_cu;
+    int blocks = std::min((p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, full_grid);
     if (blocks < 1) blocks = 1;
+    if (h->use_tiles) blocks = full_grid;   // the fused kernel then only runs the fallback list, whose length the host does not know
     uint32_t spill_cig = b->max_n_cigar > (uint32_t)kCigCap ? b->max_n_cigar - kCigCap : 0;
     uint32_t max_blk = (b->max_l_qseq + 31u) / 32u;
     uint32_t spill_blk = max_blk > (uint32_t)kDirCap ? max_blk - kDirCap : 0;
@@ -161,17 +172,50 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     p.spill = s.d_spill; p.spill_cig = spill_cig; p.spill_blk = spill_blk;
     p.status = s.d_status;
     p.queue = s.d_ctl; p.err_summary = s.d_ctl + 1;
-    s.h_ctl[0] = 0u; s.h_ctl[1] = 0xFFFFFFFFu;
-    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 2 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    TileParams tp;
+    std::memset(&tp, 0, sizeof(tp));
+    if (h->use_tiles) {
+        size_t tile_cap = (size_t)(b->n_mm_bytes / 4 + b->n_seq_bytes / 1024 + 16 * (size_t)std::max(b->n_reads, 1));
+        if ((r = grow(h, (void**)&s.d_gcq, &s.cap_gcq, 4 * (size_t)b->n_cigar_words)) ||
+            (r = grow(h, (void**)&s.d_gcr, &s.cap_gcr, 4 * (size_t)b->n_cigar_words)) ||
+            (r = grow(h, (void**)&s.d_gdir, &s.cap_gdir, 4 * ((size_t)b->n_seq_bytes / 16 + 16))) ||
+            (r = grow(h, (void**)&s.d_gqtot, &s.cap_gqtot, 4 * (size_t)std::max(b->n_reads, 1))) ||
+            (r = grow(h, (void**)&s.d_tiles, &s.cap_tiles, sizeof(TileRec) * tile_cap)) ||
+            (r = grow(h, (void**)&s.d_fb, &s.cap_fb, 4 * (size_t)std::max(b->n_reads, 1))))
+            return r;
+        tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot;
+        tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap, 0x7FFFFFFFu);
+        tp.tile_count = s.d_ctl + 2; tp.tile_queue = s.d_ctl + 3;
+        tp.fb_list = s.d_fb; tp.fb_count = s.d_ctl + 4;
+    }
+    for (int i = 0; i < 8; i++) s.h_ctl[i] = 0u;
+    s.h_ctl[1] = 0xFFFFFFFFu;
+    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 8 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(s.d_status, 0, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1), st));
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
+        if (h->use_tiles) {
+            tp.d = p;
+            int ga = std::min((p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->scan_blocks_per_cu);
+            int gc = h->n_cu * h->call_blocks_per_cu;
+            if (ga < 1) ga = 1;
+            if (h->wide) {
+                hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
+                hipLaunchKernelGGL(k_call_tiles<uint32_t>, dim3(gc), dim3(256), 0, st, tp);
+            } else {
+                hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
+                hipLaunchKernelGGL(k_call_tiles<uint16_t>, dim3(gc), dim3(256), 0, st, tp);
+            }
+            HIPCHK(hipGetLastError());
+            // reads the tile form does not cover: the fused kernel over the fallback list (usually empty)
+            p.order = s.d_fb; p.n_items = 0; p.n_items_dev = s.d_ctl + 4; p.queue = s.d_ctl + 5;
+        }
         if (h->wide) hipLaunchKernelGGL(k_freq_reads<uint32_t>, dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_freq_reads<uint16_t>, dim3(blocks), dim3(256), 0, st, p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
-    HIPCHK(hipMemcpyAsync(s.h_ctl + 2, s.d_ctl, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s.h_ctl + 8, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s.ev_done, st));
     s.busy = true; s.timed = true; s.n_reads = b->n_reads;
     return 0;
@@ -227,7 +271,8 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
-        void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl};
+        void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl,
+                      s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_tiles, s.d_fb};
         for (void* p : ps) if (p) (void)hipFree(p);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
     }
@@ -265,13 +310,25 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint32_t>, 256, 0)
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t>, 256, 0);
         h->blocks_per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
+        int na = 0, nc = 0;
+        if (h->wide) {
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint32_t>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t>, 256, 0);
+        } else {
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint16_t>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t>, 256, 0);
+        }
+        h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
+        h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
+        const char* ef = std::getenv("MM_FUSED");
+        h->use_tiles = !(ef && std::atoi(ef) != 0);
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
     for (auto& s : h->slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
-        if (dev_alloc(h, (void**)&s.d_ctl, 4 * sizeof(unsigned int))) return fail(h, "alloc failed");
-        if (hipHostMalloc((void**)&s.h_ctl, 4 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        if (dev_alloc(h, (void**)&s.d_ctl, 8 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        if (hipHostMalloc((void**)&s.h_ctl, 16 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
     }
     // ---- mods / codes
     std::vector<DevMod> mods(opts->n_mods);
@@ -521,7 +578,7 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_done) != hipSuccess) return MM_E_HIP;
     s.busy = false;
-    unsigned int sum = s.h_ctl[3];
+    unsigned int sum = s.h_ctl[9];
     if (sum != 0xFFFFFFFFu) {
         if (bad_read) *bad_read = (int32_t)(sum >> 8);
         return (int32_t)(sum & 0xFFu);

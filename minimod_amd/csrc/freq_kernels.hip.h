@@ -37,7 +37,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kCigCap = 1024;  // CIGAR ops whose prefix sums live in LDS (the rest spill to a global scratch)
 constexpr int kDirCap = 512;   // 32-base blocks whose rank directory lives in LDS (16 kb of read)
 constexpr int kTokCap = 512;   // compacted skip counts: one flush takes 256, one 256-character trip adds <= 128
-constexpr int kCallsPerLane = 4;  // calls a lane carries through the staged call pipeline (memory-level parallelism)
+constexpr int kCallsPerLane = 2;  // calls a lane carries through the staged call pipeline (memory-level parallelism)
 
 struct DevCode {
     char str[MM_CODE_LEN];
@@ -76,6 +76,7 @@ struct DevParams {
     const int32_t* order;  // optional work items: read index | part << 24 | (parts - 1) << 28
     int32_t n_reads;
     int32_t n_items;       // entries of order[] (== n_reads when order is null)
+    const unsigned int* n_items_dev;  // when set, the item count is read from device memory (fallback list)
     // reference
     const void* refw;            // uint16 or uint32 per base: bits 0-4 base code, bit 5+2i fwd ctx, 6+2i rev ctx
     const int64_t* ref_base;     // per tid: offset into refw, -1 = contig absent
@@ -826,17 +827,22 @@ struct K1 {
                     bad = __ballot(err != 0) != 0;
                     if (bad) { done = true; ntok = 0; }
                     MMT_LAP(6);
-                    while (ntok >= 256u || (done && ntok > 0)) {
-                        uint32_t cnt = ntok < 256u ? ntok : 256u;
+                    constexpr uint32_t kFlush = 64u * kCallsPerLane;
+                    while (ntok >= kFlush || (done && ntok > 0)) {
+                        uint32_t cnt = ntok < kFlush ? ntok : kFlush;
                         ensure_dir(cls, dot);
                         MMT_LAP(5);
                         flush_tokens(cnt, rank_carry, k_carry, dot);
-                        uint32_t rem = ntok - cnt;   // < 128
+                        uint32_t rem = ntok - cnt;   // < 64*J + 128 - 64*J... at most 255
                         uint32_t y0 = (uint32_t)lane < rem ? S.tok[cnt + lane] : 0u;
                         uint32_t y1 = (uint32_t)lane + 64u < rem ? S.tok[cnt + 64u + lane] : 0u;
+                        uint32_t y2 = (uint32_t)lane + 128u < rem ? S.tok[cnt + 128u + lane] : 0u;
+                        uint32_t y3 = (uint32_t)lane + 192u < rem ? S.tok[cnt + 192u + lane] : 0u;
                         wave_sync();
                         if ((uint32_t)lane < rem) S.tok[lane] = y0;
                         if ((uint32_t)lane + 64u < rem) S.tok[64u + lane] = y1;
+                        if ((uint32_t)lane + 128u < rem) S.tok[128u + lane] = y2;
+                        if ((uint32_t)lane + 192u < rem) S.tok[192u + lane] = y3;
                         wave_sync();
                         ntok = rem;
                         if (__ballot(err != 0)) { bad = true; done = true; ntok = 0; }
@@ -868,11 +874,12 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     const int wv = threadIdx.x >> 6;
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
     K1<RefWord> k(p, lds[wv]);
+    if (p.n_items_dev && *p.n_items_dev == 0u) return;   // empty fallback list: do not even touch the work counter
     for (;;) {
         int r = 0;
         if (lane_id() == 0) r = (int)atomicAdd(p.queue, 1u);
         r = uni(r);
-        if (r >= p.n_items) break;
+        if (r >= (p.n_items_dev ? (int)*p.n_items_dev : p.n_items)) break;
         uint32_t item = p.order ? (uint32_t)p.order[r] : (uint32_t)r;
         item = uniu(item);
         int ridx = (int)(item & 0xFFFFFFu);

@@ -1,0 +1,813 @@
+// freq_tiles.hip.h -- the balanced two-kernel form of the freq hot path (reference src/mod.c:776-1370).
+//
+// The fused kernel of freq_kernels.hip.h gives one wavefront a whole read and keeps the CIGAR prefix arrays and the
+// rank directory in LDS: at -K 4096 that is only 4096 waves, 13 KB of LDS each (3 waves per SIMD), and a launch lasts
+// as long as its longest read.  Here the same work is cut differently:
+//
+//   KA  k_scan_reads   one wave per read, light and streaming: CIGAR prefix arrays and the rank directory go to a
+//                      global scratch (L2-resident, indexed like the pools they come from), and the MM text is scanned
+//                      once to cut every group's skip list into TILES of 256 characters, each stamped with the carries
+//                      it needs (tokens, ranks, ML index before it).  '.' groups also get tail tiles.
+//   KC  k_call_tiles   one wave per tile, any order, 1.3 KB of LDS: parse the tile's tokens, turn ranks into read
+//                      positions (directory search + in-block select), project through the CIGAR arrays, test the
+//                      reference word, threshold the ML byte, one 64-bit atomic per call.
+//
+// Reads the tile form does not cover (more than 4 code letters in a group, groups with different canonical bases) are
+// put on a list and run through the fused kernel afterwards: same results, just slower.
+#pragma once
+#include "freq_kernels.hip.h"
+
+namespace mmhip {
+
+constexpr uint32_t kTileChars = 256;
+constexpr uint32_t kTailRanks = 16384;  // implicit-call ranks per tail tile
+
+struct TileRec {  // 64 bytes
+    uint32_t ridx;
+    uint32_t cpos;        // list tile: offset of its first character in the MM string
+    uint32_t k_carry;     // tokens of the group in front of this tile
+    uint32_t rank_carry;  // sum(skip+1) in front of this tile; tail tile: first rank
+    uint32_t ml_start;    // ML index of the group's first call
+    uint32_t nb;          // bases of the group's class in the read; tail tile: one past the last rank
+    uint32_t flags;       // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 prev_delim, 8-10 cls, 12-14 n_codes
+    uint32_t rsvd0;
+    int16_t g_code[4];
+    uint32_t rsvd[6];
+};
+static_assert(sizeof(TileRec) == 64, "TileRec must be 64 bytes");
+
+struct TileParams {
+    DevParams d;              // batch, reference, counters, options (d.queue = KA's read queue)
+    uint32_t* g_cq;           // [n_cigar_words] query offset at the start of each op (indexed like the cigar pool)
+    uint32_t* g_cr;           // [n_cigar_words] reference offset | op << 28
+    uint32_t* g_dir;          // [n_seq_bytes / 16] rank directory (indexed like the seq pool, one entry per 16 bytes)
+    uint32_t* g_qtot;         // [n_reads] query length of the CIGAR
+    TileRec* tiles;
+    unsigned int* tile_count; // tiles reserved so far
+    unsigned int tile_cap;
+    unsigned int* tile_queue; // KC's work counter
+    int32_t* fb_list;         // reads left to the fused kernel
+    unsigned int* fb_count;
+};
+
+struct ScanLds {
+    uint32_t mmw[68];
+    char hdr[16];
+    int16_t g_code[16];
+};
+struct CallLds {
+    uint32_t mmw[68];
+    uint32_t tok[128];
+    uint32_t gap[64];
+    uint32_t gstart[64];
+};
+
+// position of the first ';' at or after `from` (or mlen): 256 characters per trip, no LDS
+__device__ __forceinline__ uint32_t find_semicolon(const uint8_t* mm, uint32_t mlen, uint32_t from) {
+    const int lane = lane_id();
+    uint32_t pos = from;
+    uint32_t found = mlen;
+    bool hit = false;
+    while (pos < mlen && !hit) {
+        uint32_t off = pos + 4u * lane;
+        uint32_t w = 0;
+        if (off < mlen) {
+            __builtin_memcpy(&w, mm + off, 4);
+            uint32_t left = mlen - off;
+            if (left < 4u) w &= (1u << (8u * left)) - 1u;
+        }
+        uint32_t y = w ^ 0x3B3B3B3Bu;                                  // zero byte where the character is ';'
+        uint32_t z = (y - 0x01010101u) & ~y & 0x80808080u;            // 0x80 in every zero byte (exact for the lowest one)
+        if (off >= mlen) z = 0;
+        uint64_t b = __ballot(z != 0);
+        if (b) {
+            int l = __ffsll((unsigned long long)b) - 1;
+            uint32_t zl = lane_valu(z, l);
+            found = pos + 4u * (uint32_t)l + ((uint32_t)__ffs((int)zl) - 1u) / 8u;
+            hit = true;
+        }
+        pos += 256u;
+    }
+    return found < mlen ? found : mlen;
+}
+
+// four MM characters starting at byte offset `off`; characters at or past the end of the string read as ';'
+__device__ __forceinline__ uint32_t mm_dword(const uint8_t* mm, uint32_t mlen, uint32_t off) {
+    uint32_t w = 0x3B3B3B3Bu;
+    if (off < mlen) {
+        uint32_t raw;
+        __builtin_memcpy(&raw, mm + off, 4);
+        uint32_t left = mlen - off;
+        uint32_t keep = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
+        w = (raw & keep) | (0x3B3B3B3Bu & ~keep);
+    }
+    return w;
+}
+
+// One 64-character sub-chunk of a skip list held in LDS bytes mb8[0..]: token starts, values, where the group ends.
+struct SubParse {
+    bool tstart;
+    uint32_t v;
+    int endl;       // 64 = no ';' here
+    int err;
+    int last_char;
+};
+__device__ __forceinline__ SubParse parse_sub(const uint8_t* mb8, int base, bool prev_delim) {
+    const int lane = lane_id();
+    SubParse r;
+    int x = mb8[base + lane];
+    uint64_t semi = __ballot(x == ';');
+    r.endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
+    bool in = lane < r.endl;
+    int pv = __shfl_up(x, 1, 64);
+    bool pdel = lane == 0 ? prev_delim : (pv == ',');
+    r.tstart = in && x != ',' && pdel;
+    r.v = 0;
+    r.err = 0;
+    if (r.tstart) {
+        bool open = true;
+        int len = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {          // at most 9 digits (mod.c:1074-1081)
+            int d = mb8[base + lane + j];
+            bool delim = d == ',' || d == ';';
+            open = open && !delim;
+            if (open) {
+                if (d < '0' || d > '9') r.err = MM_E_SKIPVAL;
+                r.v = r.v * 10u + (uint32_t)(d - '0');
+                len++;
+            }
+        }
+        if (len == 10) r.err = MM_E_SKIPLEN;
+    }
+    r.last_char = lane_val(x, 63);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ KA
+struct GroupHdr {
+    int herr;
+    int modbase, n, ncode, hl, e, flag;
+    bool has_nums;
+    uint32_t lstart;   // first character of the skip list
+};
+
+template <typename RefWord>
+struct KA {
+    const TileParams& P;
+    const DevParams& p;
+    ScanLds& S;
+    int err;
+    __device__ KA(const TileParams& tp, ScanLds& s) : P(tp), p(tp.d), S(s), err(0) {}
+
+    // group header at mpos (mod.c:1003-1062); also leaves the code characters in S.hdr
+    __device__ GroupHdr parse_header(const uint8_t* mm, uint32_t mlen, uint32_t mpos) {
+        const int lane = lane_id();
+        GroupHdr g;
+        uint32_t ci = mpos + lane;
+        int ch = ci < mlen ? (int)mm[ci] : 0;
+        int c0 = lane_val(ch, 0), c1 = lane_val(ch, 1);
+        int herr = 0;
+        if (!valid_base_char(c0)) herr = MM_E_MMBASE;
+        g.modbase = c0 == 'U' ? 'T' : c0;
+        int hl = 1;
+        if (mpos + 1 < mlen) {
+            if (c1 != '+' && c1 != '-') herr = herr ? herr : MM_E_MMSTRAND;
+            hl = 2;
+        }
+        bool stop = lane >= hl && (ci >= mlen || ch == ',' || ch == ';' || ch == '?' || ch == '.');
+        uint64_t sb = __ballot(stop);
+        int e = sb ? __ffsll((unsigned long long)sb) - 1 : 64;
+        int ncode = e - hl;
+        bool iscode = lane >= hl && lane < e;
+        bool dig = ch >= '0' && ch <= '9';
+        bool alp = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z');
+        g.has_nums = __ballot(iscode && dig) != 0;
+        bool has_alpha = __ballot(iscode && alp) != 0;
+        int n = g.has_nums ? 1 : ncode;
+        if (!herr && __ballot(iscode && !dig && !alp)) herr = MM_E_MMCODE;
+        if (!herr && (e == 64 || ncode >= MM_CODE_LEN)) herr = MM_E_MMCODE;
+        if (!herr && n <= 0) herr = MM_E_MMEMPTY;
+        if (!herr && g.has_nums && has_alpha) herr = MM_E_MMMIXED;
+        g.herr = uni(herr);
+        g.n = n; g.ncode = ncode; g.hl = hl; g.e = e;
+        g.flag = '.';
+        uint32_t cpos = mpos + (uint32_t)e;
+        if (!g.herr && cpos < mlen) {
+            int ce = lane_val(ch, e);
+            if (ce == '?' || ce == '.') { g.flag = ce; cpos++; }
+        }
+        g.lstart = cpos;
+        wave_sync();
+        if (iscode && !g.herr) S.hdr[(lane - hl) & 15] = (char)ch;
+        wave_sync();
+        return g;
+    }
+
+    // required-code lookup per code letter (mod.c:1146-1160) -> S.g_code[m]
+    __device__ void lookup_codes(const GroupHdr& g) {
+        const int lane = lane_id();
+        if (lane < 16) S.g_code[lane] = -1;
+        wave_sync();
+        int pairs = g.n * p.n_codes;
+        for (int p0 = 0; p0 < pairs; p0 += 64) {
+            int pi = p0 + lane;
+            if (pi < pairs) {
+                int m = pi / p.n_codes, t = pi - m * p.n_codes;
+                int slen = g.has_nums ? g.ncode : g.ncode - m;
+                const DevCode& dc = p.codes[t];
+                bool eq = dc.len == slen;
+                for (int j = 0; j < slen; j++) eq = eq && (dc.str[j & (MM_CODE_LEN - 1)] == S.hdr[(m + j) & 15]);
+                if (eq) S.g_code[m] = (int16_t)t;
+            }
+        }
+        wave_sync();
+        if (p.wildcard && lane < g.n && S.g_code[lane] < 0) err = MM_E_NOCODE;
+    }
+
+    __device__ __forceinline__ int any_err() const {
+        uint64_t eb = __ballot(err != 0);
+        int l = eb ? __ffsll((unsigned long long)eb) - 1 : 0;
+        int e = lane_val(err, l);
+        return eb ? e : 0;
+    }
+
+    __device__ void write_tile(uint32_t idx, const TileRec& t) {
+        // lanes 0..15 store one dword each: one 64-byte line
+        const int lane = lane_id();
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&t);
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if (lane == i) v = src[i];
+        if (lane < 16) reinterpret_cast<uint32_t*>(P.tiles + idx)[lane] = v;
+    }
+
+    // returns the read's status (0 = ok / handed to the fused kernel)
+    __device__ int run(int ridx) {
+        const int lane = lane_id();
+        const mm_read_t& rd = p.reads[ridx];
+        err = 0;
+        const int tid = uni(rd.tid), pos = uni(rd.pos);
+        const uint32_t L = uniu(rd.l_qseq), ncig = uniu(rd.n_cigar), mlen = uniu(rd.mm_len);
+        const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        const uint8_t* mm = p.mm + rd.mm_off;
+        const uint64_t cig_off = rd.cigar_off, dir_off = rd.seq_off >> 4;
+        const uint32_t nblk = (L + 31u) >> 5;
+        bool have_ref = tid >= 0 && tid < p.n_contigs;
+        if (have_ref) have_ref = p.ref_base[tid] >= 0;
+        int result = have_ref ? 0 : MM_E_NOCONTIG;   // single exit below: no early returns (see freq_kernels.hip.h)
+
+        // ---------------- pass 1: group headers only -> regular or not, and how many tiles the read needs
+        int first_cls = -1;
+        bool irregular = false;
+        uint32_t need = 0;
+        if (have_ref) {
+            uint32_t mpos = 0;
+            int guard = 0;
+            while (mpos < mlen && !irregular) {
+                GroupHdr g = parse_header(mm, mlen, mpos);
+                if (g.herr || g.n > 4 || ++guard > 4096) { irregular = true; }   // errors are reported by the fused kernel
+                else {
+                    int mb = rev ? complement_char(g.modbase) : g.modbase;
+                    bool direct = g.modbase == 'N', dot = g.flag == '.';
+                    int cls = base_class_of_char(mb);
+                    if (!direct || dot) {
+                        if (first_cls < 0) first_cls = cls;
+                        else if (cls != first_cls) irregular = true;
+                    }
+                    uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                    need += (endp - g.lstart) / kTileChars + 1u;
+                    if (dot) need += L / kTailRanks + 1u;
+                    mpos = endp + 1u;
+                }
+            }
+        }
+        uint32_t tbase = 0, tcur = 0;
+        if (have_ref && !irregular && need > 0) {
+            if (lane == 0) tbase = atomicAdd(P.tile_count, need);
+            tbase = uniu(tbase);
+            if ((uint64_t)tbase + need > P.tile_cap) irregular = true;   // reserved slots are marked invalid below
+        }
+        tcur = tbase;
+        if (have_ref && irregular) {
+            // hand the whole read to the fused kernel
+            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; }
+        }
+        const bool go = have_ref && !irregular;
+
+        // ---------------- CIGAR prefix arrays -> global (mod.c:776-881 as scans)
+        if (go) {
+            const uint32_t* cg = p.cigar + cig_off;
+            const int64_t ctg_len = p.ctg_len[tid];
+            uint32_t carry_q = 0, carry_r = 0;
+            for (uint32_t i0 = 0; i0 < ncig; i0 += 256) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t i = i0 + 64u * u + lane;
+                    wv[u] = i < ncig ? cg[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t i = i0 + 64u * u + lane;
+                    bool act = i < ncig;
+                    uint32_t w = wv[u], op = w & 15u, len = w >> 4;
+                    uint32_t qinc = (act && ((0x193u >> op) & 1u)) ? len : 0u;
+                    uint32_t rinc = (act && ((0x18Du >> op) & 1u)) ? len : 0u;
+                    if (act && op == 5u) err = MM_E_HARDCLIP;
+                    else if (act && (op == 6u || op > 8u)) err = MM_E_CIGAROP;
+                    uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
+                    uint32_t qtot = lane_valu(qs, 63), rtot = lane_valu(rs, 63);
+                    qs = carry_q + qs - qinc;
+                    rs = carry_r + rs - rinc;
+                    bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
+                    if (aligned) {
+                        if ((uint64_t)qs + len > L) err = err ? err : MM_E_QOVER;
+                        int64_t r0 = (int64_t)pos + rs;
+                        if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;
+                    }
+                    if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > L) err = err ? err : MM_E_QOVER;
+                    if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
+                    if (act) { P.g_cq[cig_off + i] = qs; P.g_cr[cig_off + i] = (rs & 0x0FFFFFFFu) | (op << 28); }
+                    carry_q += qtot; carry_r += rtot;
+                }
+            }
+            if (lane == 0) P.g_qtot[ridx] = carry_q;
+        }
+        if (go) result = any_err();
+        // ---------------- rank directory of the read's one class -> global (mod.c:972-981)
+        uint32_t nb = 0;
+        if (go && result == 0 && first_cls >= 0) {
+            const uint4* sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
+            uint32_t carry = 0;
+            for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
+                uint4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t b = b0 + 64u * u + lane;
+                    vv[u] = b < nblk ? sq[b] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t b = b0 + 64u * u + lane;
+                    uint32_t cnt = 0;
+                    if (b < nblk) {
+                        uint4 v = vv[u];
+                        int valid = (int)min(32u, L - b * 32u);
+                        if (first_cls == 0) {
+                            uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
+                                         __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
+                                         __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
+                                         __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
+                            cnt = (uint32_t)valid - o;
+                        } else {
+                            cnt = __popc(class_bits(v.x, first_cls)) + __popc(class_bits(v.y, first_cls)) +
+                                  __popc(class_bits(v.z, first_cls)) + __popc(class_bits(v.w, first_cls));
+                        }
+                    }
+                    uint32_t incl = wave_incl_scan(cnt);
+                    if (b < nblk) P.g_dir[dir_off + b] = carry + incl - cnt;
+                    carry += lane_valu(incl, 63);
+                }
+            }
+            nb = carry;
+        }
+        // ---------------- pass 2: cut every skip list into tiles stamped with their carries
+        if (go && result == 0) {
+            uint32_t mpos = 0, ml_start = 0;
+            bool bad = false;
+            while (mpos < mlen && !bad) {
+                GroupHdr g = parse_header(mm, mlen, mpos);
+                lookup_codes(g);
+                bad = __ballot(err != 0) != 0;
+                int mb = rev ? complement_char(g.modbase) : g.modbase;
+                bool direct = g.modbase == 'N', dot = g.flag == '.';
+                uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) |
+                                  ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
+                int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
+                uint32_t cpos = g.lstart, k_carry = 0, rank_carry = 0;
+                bool prev_delim = true, done = bad;
+                uint32_t wd_next = 0;
+                bool have_next = false;
+                while (!done) {
+                    uint32_t wd = have_next ? wd_next : mm_dword(mm, mlen, cpos + 4u * lane);
+                    wd_next = mm_dword(mm, mlen, cpos + 256u + 4u * lane);
+                    wave_sync();
+                    S.mmw[lane] = wd;
+                    if (lane < 4) S.mmw[64 + lane] = wd_next;
+                    wave_sync();
+                    const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
+                    // the tile record carries the state in front of this trip
+                    TileRec t;
+                    t.ridx = (uint32_t)ridx; t.cpos = cpos; t.k_carry = k_carry; t.rank_carry = rank_carry; t.ml_start = ml_start;
+                    t.nb = nb; t.flags = gflags | (prev_delim ? 32u : 0u); t.rsvd0 = 0;
+                    t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
+                    write_tile(tcur++, t);
+                    bool closed = false;
+#pragma unroll 1
+                    for (int sub = 0; sub < 4; sub++) {
+                        if (closed) continue;
+                        SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
+                        if (sp.err) err = sp.err;
+                        uint64_t tb = __ballot(sp.tstart);
+                        uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
+                        rank_carry += lane_valu(sm, 63);
+                        k_carry += (uint32_t)__popcll(tb);
+                        if (sp.endl < 64) { closed = true; cpos = cpos + 64u * (uint32_t)sub + (uint32_t)sp.endl + 1u; }
+                        else prev_delim = sp.last_char == ',';
+                    }
+                    if (closed) done = true;
+                    else { cpos += 256u; have_next = true; }
+                    bad = __ballot(err != 0) != 0;
+                    if (bad) done = true;
+                }
+                if (!bad) {
+                    if (k_carry > 0) ml_start += k_carry * (uint32_t)g.n;      // mod.c:1200
+                    if (dot) {                                                   // mod.c:1289-1365
+                        for (uint32_t r0 = rank_carry; r0 < nb; r0 += kTailRanks) {
+                            TileRec t;
+                            t.ridx = (uint32_t)ridx; t.cpos = 0; t.k_carry = 0; t.rank_carry = r0; t.ml_start = ml_start;
+                            t.nb = min(nb, r0 + kTailRanks); t.flags = gflags | 2u; t.rsvd0 = 0;
+                            t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
+#pragma unroll
+                            for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
+                            write_tile(tcur++, t);
+                        }
+                    }
+                    mpos = cpos;
+                }
+            }
+            result = any_err();
+        }
+        // reserved slots this read did not fill are marked invalid (flags = 0)
+        if (have_ref && need > 0) {
+            uint32_t hi = tbase + need;
+            if (hi > P.tile_cap) hi = P.tile_cap;
+            for (uint32_t i = tcur + lane; i < hi; i += 64) P.tiles[i].flags = 0u;
+        }
+        return result;
+    }
+};
+
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
+    __shared__ ScanLds lds[kWavesPerBlock];
+    KA<RefWord> k(P, lds[threadIdx.x >> 6]);
+    const DevParams& p = P.d;
+    // static round-robin over the (costliest-first) item list: one shared work counter would serialise ~4k dequeues
+    const int n_waves = (int)gridDim.x * kWavesPerBlock;
+    for (int r = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6); r < p.n_items; r += n_waves) {
+        uint32_t item = p.order ? (uint32_t)p.order[r] : (uint32_t)r;
+        item = uniu(item);
+        if ((item >> 24) & 15u) continue;   // plans made for the fused kernel split long reads into parts: one visit per read here
+        int ridx = (int)(item & 0xFFFFFFu);
+        int e = uni(k.run(ridx));
+        if (e != 0 && lane_id() == 0) {
+            p.status[ridx] = e;
+            atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ KC
+template <typename RefWord>
+struct KC {
+    const TileParams& P;
+    const DevParams& p;
+    CallLds& S;
+    int err;
+    uint32_t st_look, st_ml, st_dense, st_side;
+    // per-tile context (wave-uniform)
+    const uint8_t* seq;
+    const uint8_t* ml;
+    const uint32_t* gq;
+    const uint32_t* gr;
+    const uint32_t* gd;
+    int64_t ref_base, seg_begin, seg_len, cnt_base;
+    uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
+    int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
+    int32_t gc0, gc1, gc2, gc3;
+
+    __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
+
+    __device__ KC(const TileParams& tp, CallLds& s) : P(tp), p(tp.d), S(s), err(0), st_look(0), st_ml(0), st_dense(0), st_side(0) {}
+
+    __device__ __forceinline__ uint32_t find_block(uint32_t rr) const {
+        uint32_t lo = 0, step = 1;
+        while (step < nblk) step <<= 1;
+        for (step >>= 1; step; step >>= 1) {
+            uint32_t cand = lo + step;
+            if (cand < nblk && gd[cand] <= rr) lo = cand;
+        }
+        return lo;
+    }
+    __device__ __forceinline__ uint32_t find_op(uint32_t q) const {
+        uint32_t lo = 0, step = 1;
+        while (step < ncig) step <<= 1;
+        for (step >>= 1; step; step >>= 1) {
+            uint32_t cand = lo + step;
+            if (cand < ncig && gq[cand] <= q) lo = cand;
+        }
+        return lo;
+    }
+    __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
+        int valid = (int)min(32u, L - blk * 32u);
+        uint32_t w0 = base_order(v.x), w1 = base_order(v.y), w2 = base_order(v.z), w3 = base_order(v.w);
+        uint32_t m0 = class_bits(w0, cls) & valid_bits(valid);
+        uint32_t m1 = class_bits(w1, cls) & valid_bits(valid - 8);
+        uint32_t m2 = class_bits(w2, cls) & valid_bits(valid - 16);
+        uint32_t m3 = class_bits(w3, cls) & valid_bits(valid - 24);
+        uint32_t c0 = __popc(m0), c1 = __popc(m1), c2 = __popc(m2);
+        uint32_t word = 0, mk = m0, wv = w0;
+        if (k >= c0) { k -= c0; word = 1; mk = m1; wv = w1;
+            if (k >= c1) { k -= c1; word = 2; mk = m2; wv = w2;
+                if (k >= c2) { k -= c2; word = 3; mk = m3; wv = w3; } } }
+        uint32_t n = 0, cn = __popc(mk & 0xFFFFu);
+        if (k >= cn) { k -= cn; n += 4; mk >>= 16; }
+        cn = __popc(mk & 0xFFu);
+        if (k >= cn) { k -= cn; n += 2; mk >>= 8; }
+        cn = __popc(mk & 0xFu);
+        if (k >= cn) { n += 1; }
+        code = (wv >> (4 * n)) & 15u;
+        return blk * 32u + word * 8u + n;
+    }
+    __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
+        uint64_t m = __ballot(1);
+        int leader = __ffsll((unsigned long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane_id() == leader) base = atomicAdd(p.side_count, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, 64);
+        unsigned long long idx = base + __popcll(m & lanemask_lt());
+        if (idx < p.side_cap) {
+            SideRec r;
+            r.tid = tid; r.pos = spos; r.ins_off = (uint16_t)ins_off; r.strand = (uint8_t)rev;
+            r.is_mod = (uint8_t)is_mod; r.code = (int16_t)code; r.hp = (int16_t)hp;
+            p.side[idx] = r;
+        } else {
+            err = MM_E_SIDEFULL;
+        }
+    }
+
+    // J calls per lane as a staged pipeline (same stages as K1::process_calls, prefix arrays in global memory)
+    template <int J>
+    __device__ __forceinline__ void process_calls(const uint32_t (&rank)[J], const uint32_t (&kidx)[J], const bool (&live_in)[J], bool is_explicit) {
+        bool live[J];
+        uint32_t blk[J], kk[J], q[J], code[J], ins_off[J];
+        int64_t ref_pos[J];
+        uint4 sv[J];
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            live[u] = live_in[u];
+            blk[u] = 0; kk[u] = 0; q[u] = 0; code[u] = 0; ins_off[u] = 0; ref_pos[u] = -1;
+            if (!live[u]) continue;
+            if (direct) {
+                if (rank[u] >= L) { err = MM_E_READPOS; live[u] = false; continue; }
+                q[u] = rev ? L - 1 - rank[u] : rank[u];
+            } else {
+                if (rank[u] >= nb) { err = MM_E_READPOS; live[u] = false; continue; }
+                uint32_t rr = rev ? nb - 1 - rank[u] : rank[u];
+                blk[u] = find_block(rr);
+                kk[u] = rr - gd[blk[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            sv[u] = make_uint4(0, 0, 0, 0);
+            if (live[u]) sv[u] = direct ? make_uint4(seq[q[u] >> 1], 0, 0, 0) : reinterpret_cast<const uint4*>(seq)[blk[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            if (!live[u]) continue;
+            if (direct) { uint32_t b = sv[u].x; code[u] = (q[u] & 1u) ? (b & 15u) : (b >> 4); }
+            else q[u] = select_in_block(sv[u], blk[u], kk[u], code[u]);
+            int64_t rp = -1, anchor = -1;
+            if (q[u] < q_total) {
+                uint32_t i = find_op(q[u]);
+                uint32_t rv = gr[i], op = rv >> 28, qs = gq[i];
+                if ((0x181u >> op) & 1u) {
+                    rp = (int64_t)pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
+                } else if (op == 1u && p.insertions) {
+                    ins_off[u] = (q[u] - qs + 1u) & 0xFFFFu;
+                    anchor = (int64_t)pos + (rv & 0x0FFFFFFFu) - 1;
+                }
+            }
+            if (rp < 0 && p.insertions) {
+                if (is_explicit || !rev) {
+                    rp = anchor;
+                } else {   // mod.c:1234,1314 quirk: the mirrored base's insertion anchor
+                    uint32_t q2 = L - 1u - q[u];
+                    if (q2 < q_total) {
+                        uint32_t i2 = find_op(q2);
+                        uint32_t rv2 = gr[i2];
+                        if ((rv2 >> 28) == 1u) rp = (int64_t)pos + (rv2 & 0x0FFFFFFFu) - 1;
+                    }
+                }
+            }
+            ref_pos[u] = rp;
+            if (rp < 0) live[u] = false;
+        }
+        uint32_t w[J], ml0[J];
+        const RefWord* rw = reinterpret_cast<const RefWord*>(p.refw);
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            w[u] = 0; ml0[u] = 0;
+            if (!live[u]) continue;
+            w[u] = (uint32_t)rw[ref_base + ref_pos[u]];
+            st_look++;
+            if (is_explicit) {
+                uint64_t mi = (uint64_t)ml_start + (uint64_t)kidx[u] * ncg;
+                if (mi < ml_len) ml0[u] = ml[mi];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            if (!live[u]) continue;
+            uint32_t refcode = w[u] & 31u;
+            for (int m = 0; m < ncg; m++) {
+                int ci = gcode_at(m);
+                if (ci < 0) continue;
+                const DevCode& dc = p.codes[ci];
+                int req = dc.req;
+                const DevMod& dm = p.mods[req];
+                if (!p.insertions) {
+                    bool in_ctx = (w[u] >> (5 + 2 * req + rev)) & 1u;
+                    bool matches = dm.ctx_is_star || mb_is_N || refcode == code[u];
+                    if (!(in_ctx && matches)) continue;
+                }
+                int is_mod = 0;
+                if (is_explicit) {
+                    uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx[u] * ncg + m;
+                    if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
+                    int mv = m == 0 ? (int)ml0[u] : (int)ml[ml_idx];
+                    st_ml++;
+                    if (mv >= dm.t_hi) is_mod = 1;
+                    else if (mv <= dm.t_lo) is_mod = 0;
+                    else continue;
+                }
+                int64_t off = ref_pos[u] - seg_begin;
+                if (ins_off[u] == 0 && dc.plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
+                    unsigned long long* dst = p.counters + ((int64_t)(dc.plane * p.n_hp + hpi) * 2 + rev) * p.plane_len + cnt_base + off;
+                    atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+                    st_dense++;
+                } else {
+                    side_append((int32_t)ref_pos[u], ins_off[u], is_mod, ci);
+                    st_side++;
+                }
+            }
+        }
+    }
+
+    struct TileArgs { uint32_t ridx, cpos, k_carry, rank_carry, ml_start, nb, flags; };
+    __device__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23) {
+        const int lane = lane_id();
+        constexpr int J = 2;
+        err = 0;
+        const int ridx = (int)t.ridx;
+        const mm_read_t& rd = p.reads[ridx];
+        tid = uni(rd.tid); pos = uni(rd.pos);
+        L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); ml_len = uniu(rd.ml_len);
+        rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        const uint32_t mlen = uniu(rd.mm_len);
+        seq = p.seq + rd.seq_off; ml = p.ml + rd.ml_off;
+        const uint8_t* mm = p.mm + rd.mm_off;
+        gq = P.g_cq + rd.cigar_off; gr = P.g_cr + rd.cigar_off; gd = P.g_dir + (rd.seq_off >> 4);
+        nblk = (L + 31u) >> 5;
+        q_total = P.g_qtot[ridx];
+        hp = p.haplotypes ? (int)rd.hp : -1;
+        hpi = p.haplotypes ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
+        ref_base = p.ref_base[tid]; seg_begin = p.seg_begin[tid]; seg_len = p.seg_len[tid]; cnt_base = p.cnt_base[tid];
+        const uint32_t fl = t.flags;
+        const bool tail = fl & 2u, dot = fl & 4u;
+        direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
+        nb = t.nb; ml_start = t.ml_start;
+        gc0 = (int16_t)(gc01 & 0xFFFFu); gc1 = (int16_t)(gc01 >> 16); gc2 = (int16_t)(gc23 & 0xFFFFu); gc3 = (int16_t)(gc23 >> 16);
+        if (tail) {
+            for (uint32_t r0 = t.rank_carry; r0 < t.nb; r0 += 64u * J) {
+                uint32_t r2[J], k2[J];
+                bool l2[J];
+#pragma unroll
+                for (int v = 0; v < J; v++) { r2[v] = r0 + 64u * v + lane; k2[v] = 0; l2[v] = r2[v] < t.nb; }
+                process_calls<J>(r2, k2, l2, false);
+            }
+        } else {
+            // the tile's 256 characters (+16 of look-ahead) -> LDS, tokens compacted into tok[]
+            uint32_t wd = mm_dword(mm, mlen, t.cpos + 4u * lane);
+            uint32_t la = lane < 4 ? mm_dword(mm, mlen, t.cpos + 256u + 4u * lane) : 0u;
+            S.mmw[lane] = wd;
+            if (lane < 4) S.mmw[64 + lane] = la;
+            wave_sync();
+            const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
+            bool prev_delim = (fl >> 5) & 1u, closed = false;
+            uint32_t ntok = 0;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; sub++) {
+                if (closed) continue;
+                SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
+                uint64_t tb = __ballot(sp.tstart);
+                if (sp.tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = sp.v;
+                ntok += (uint32_t)__popcll(tb);
+                if (sp.endl < 64) closed = true;
+                else prev_delim = sp.last_char == ',';
+            }
+            wave_sync();
+            // ranks of the (<= 128) tokens: two per lane
+            uint32_t s[J], rank[J], kidx[J];
+            bool live[J];
+            uint32_t carry = t.rank_carry;
+#pragma unroll
+            for (int u = 0; u < J; u++) {
+                uint32_t ti = 64u * u + lane;
+                live[u] = ti < ntok;
+                s[u] = live[u] ? S.tok[ti] : 0u;
+                uint32_t incl = wave_incl_scan(live[u] ? s[u] + 1u : 0u);
+                rank[u] = carry + incl - 1u;
+                kidx[u] = t.k_carry + ti;
+                carry += lane_valu(incl, 63);
+            }
+            process_calls<J>(rank, kidx, live, true);
+            if (dot) {   // implicit calls in the gaps in front of the listed ranks (mod.c:1206-1287)
+                uint32_t carry2 = t.rank_carry;
+#pragma unroll 1
+                for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
+                    uint32_t ti = t64 + lane;
+                    bool lv = ti < ntok;
+                    uint32_t su = lv ? S.tok[ti] : 0u;
+                    uint32_t incl = wave_incl_scan(lv ? su + 1u : 0u);
+                    uint32_t ranku = carry2 + incl - 1u;
+                    carry2 += lane_valu(incl, 63);
+                    uint32_t gi = wave_incl_scan(su);
+                    uint32_t T = lane_valu(gi, 63);
+                    wave_sync();
+                    S.gap[lane] = gi - su;
+                    S.gstart[lane] = ranku - su;
+                    wave_sync();
+                    for (uint32_t t0 = 0; t0 < T; t0 += 64u * J) {
+                        uint32_t r2[J], k2[J];
+                        bool l2[J];
+#pragma unroll
+                        for (int v = 0; v < J; v++) {
+                            uint32_t tt = t0 + 64u * v + lane;
+                            l2[v] = tt < T; r2[v] = 0; k2[v] = 0;
+                            if (l2[v]) {
+                                uint32_t lo = 0;
+#pragma unroll
+                                for (uint32_t step = 32; step; step >>= 1) {
+                                    uint32_t cand = lo + step;
+                                    if (cand < 64u && S.gap[cand] <= tt) lo = cand;
+                                }
+                                r2[v] = S.gstart[lo] + (tt - S.gap[lo]);
+                            }
+                        }
+                        process_calls<J>(r2, k2, l2, false);
+                    }
+                }
+            }
+        }
+        uint64_t eb = __ballot(err != 0);
+        int l = eb ? __ffsll((unsigned long long)eb) - 1 : 0;
+        int e = lane_val(err, l);
+        return eb ? e : 0;
+    }
+
+    __device__ void flush_stats() {
+        uint32_t v[4] = {st_look, st_ml, st_dense, st_side};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t x = wave_incl_scan(v[i]);
+            uint32_t tt = lane_valu(x, 63);
+            if (lane_id() == 0 && tt) atomicAdd(p.stats + i, (unsigned long long)tt);
+        }
+        st_look = st_ml = st_dense = st_side = 0;
+    }
+};
+
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_call_tiles(const TileParams P) {
+    __shared__ CallLds lds[kWavesPerBlock];
+    KC<RefWord> k(P, lds[threadIdx.x >> 6]);
+    const DevParams& p = P.d;
+    // static round-robin over the tiles (they cost about the same): no shared work counter to serialise on
+    unsigned int n_tiles = *P.tile_count;
+    if (n_tiles > P.tile_cap) n_tiles = P.tile_cap;
+    n_tiles = uniu(n_tiles);
+    const unsigned int n_waves = gridDim.x * kWavesPerBlock;
+    for (unsigned int ti = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); ti < n_tiles; ti += n_waves) {
+        // the tile record as wave-uniform scalars
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tiles + ti);
+        typename KC<RefWord>::TileArgs t;
+        t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.k_carry = uniu(src[2]); t.rank_carry = uniu(src[3]);
+        t.ml_start = uniu(src[4]); t.nb = uniu(src[5]); t.flags = uniu(src[6]);
+        uint32_t gc01 = uniu(src[8]), gc23 = uniu(src[9]);
+        if (!(t.flags & 1u)) continue;
+        int e = uni(k.run(t, gc01, gc23));
+        if (p.stats) k.flush_stats();
+        if (e != 0 && lane_id() == 0) {
+            p.status[t.ridx] = e;
+            atomicMin(p.err_summary, ((unsigned int)t.ridx << 8) | (unsigned int)e);
+        }
+    }
+}
+
+}  // namespace mmhip
