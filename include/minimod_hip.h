@@ -185,7 +185,7 @@ float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
 /* Work tallies for the algorithmic-bytes figure: enable!=0 makes K1 count reference-word
  * lookups, ML bytes read, dense counter updates and side-list updates; get copies and clears the four totals. */
 int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
-int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[8]);   /* [4..7]: phase cycle sums in diagnostic builds, else 0 */
+int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[16]);   /* [4..15]: phase time sums in diagnostic builds, else 0 */
 int64_t mm_freq_device_bytes(const mm_freq_t *h);
 
 void mm_freq_reset_counters(mm_freq_t *h);

@@ -39,7 +39,7 @@ struct Slot {
     void* d_order = nullptr; size_t cap_order = 0;
     int32_t* d_status = nullptr; size_t cap_status = 0;
     uint32_t* d_spill = nullptr; size_t cap_spill = 0;
-    unsigned int* d_ctl = nullptr;   // [0] read queue, [1] err_summary, [2] tile_count, [3] tile_queue, [4] fb_count, [5] fb_queue
+    unsigned int* d_ctl = nullptr;   // [0] read queue, [1] err_summary, [4] fb_count, [5] fb_queue, [8..8+64) tile_count per region
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
     uint32_t* d_gdir = nullptr; size_t cap_gdir = 0;
@@ -180,17 +180,17 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             (r = grow(h, (void**)&s.d_gcr, &s.cap_gcr, 4 * (size_t)b->n_cigar_words)) ||
             (r = grow(h, (void**)&s.d_gdir, &s.cap_gdir, 4 * ((size_t)b->n_seq_bytes / 16 + 16))) ||
             (r = grow(h, (void**)&s.d_gqtot, &s.cap_gqtot, 4 * (size_t)std::max(b->n_reads, 1))) ||
-            (r = grow(h, (void**)&s.d_tiles, &s.cap_tiles, sizeof(TileRec) * tile_cap)) ||
+            (r = grow(h, (void**)&s.d_tiles, &s.cap_tiles, sizeof(TileRec) * (tile_cap / kTileRegions + 64) * kTileRegions)) ||
             (r = grow(h, (void**)&s.d_fb, &s.cap_fb, 4 * (size_t)std::max(b->n_reads, 1))))
             return r;
         tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot;
-        tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap, 0x7FFFFFFFu);
-        tp.tile_count = s.d_ctl + 2; tp.tile_queue = s.d_ctl + 3;
+        tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap / kTileRegions + 64, 0x3FFFFFFu);
+        tp.tile_count = s.d_ctl + 8; tp.tile_queue = s.d_ctl + 3;
         tp.fb_list = s.d_fb; tp.fb_count = s.d_ctl + 4;
     }
-    for (int i = 0; i < 8; i++) s.h_ctl[i] = 0u;
+    for (int i = 0; i < 80; i++) s.h_ctl[i] = 0u;
     s.h_ctl[1] = 0xFFFFFFFFu;
-    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 8 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 80 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(s.d_status, 0, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1), st));
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
@@ -215,7 +215,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
-    HIPCHK(hipMemcpyAsync(s.h_ctl + 8, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s.h_ctl + 80, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s.ev_done, st));
     s.busy = true; s.timed = true; s.n_reads = b->n_reads;
     return 0;
@@ -327,8 +327,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     for (auto& s : h->slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
-        if (dev_alloc(h, (void**)&s.d_ctl, 8 * sizeof(unsigned int))) return fail(h, "alloc failed");
-        if (hipHostMalloc((void**)&s.h_ctl, 16 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        if (dev_alloc(h, (void**)&s.d_ctl, 128 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        if (hipHostMalloc((void**)&s.h_ctl, 160 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
     }
     // ---- mods / codes
     std::vector<DevMod> mods(opts->n_mods);
@@ -376,8 +376,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
-    if (dev_alloc(h, (void**)&h->d_stats, 8 * sizeof(unsigned long long))) return fail(h, "alloc failed");
-    (void)hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long));
+    if (dev_alloc(h, (void**)&h->d_stats, 16 * sizeof(unsigned long long))) return fail(h, "alloc failed");
+    (void)hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long));
     h->codes_dirty = !h->codes.empty();
     // ---- contigs: reference words for every contig that has a sequence; counter segments
     h->n_contigs = n_contigs;
@@ -578,7 +578,7 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_done) != hipSuccess) return MM_E_HIP;
     s.busy = false;
-    unsigned int sum = s.h_ctl[9];
+    unsigned int sum = s.h_ctl[81];
     if (sum != 0xFFFFFFFFu) {
         if (bad_read) *bad_read = (int32_t)(sum >> 8);
         return (int32_t)(sum & 0xFFu);
@@ -598,12 +598,12 @@ int32_t mm_freq_stats_enable(mm_freq_t* h, int32_t enable) {
     h->stats_on = enable != 0;
     return 0;
 }
-int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[8]) {
+int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     if (!h || !out) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(out, h->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
     return 0;
 }
 

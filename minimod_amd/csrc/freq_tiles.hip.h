@@ -19,8 +19,17 @@
 
 namespace mmhip {
 
+#ifdef MM_PHASE_TIMING
+#define KAT_DECL unsigned long long _k0 = __builtin_amdgcn_s_memrealtime(), _k1
+#define KAT_LAP(slot) do { _k1 = __builtin_amdgcn_s_memrealtime(); tacc[(slot) - 8] += _k1 - _k0; _k0 = _k1; } while (0)
+#else
+#define KAT_DECL do {} while (0)
+#define KAT_LAP(slot) do {} while (0)
+#endif
+
 constexpr uint32_t kTileChars = 256;
 constexpr uint32_t kTailRanks = 16384;  // implicit-call ranks per tail tile
+constexpr uint32_t kTileRegions = 64;   // independent reservation counters / tile regions
 
 struct TileRec {  // 64 bytes
     uint32_t ridx;
@@ -42,16 +51,16 @@ struct TileParams {
     uint32_t* g_cr;           // [n_cigar_words] reference offset | op << 28
     uint32_t* g_dir;          // [n_seq_bytes / 16] rank directory (indexed like the seq pool, one entry per 16 bytes)
     uint32_t* g_qtot;         // [n_reads] query length of the CIGAR
-    TileRec* tiles;
-    unsigned int* tile_count; // tiles reserved so far
-    unsigned int tile_cap;
+    TileRec* tiles;           // kTileRegions regions of tile_cap records each
+    unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
+    unsigned int tile_cap;    // records per region
     unsigned int* tile_queue; // KC's work counter
     int32_t* fb_list;         // reads left to the fused kernel
     unsigned int* fb_count;
 };
 
 struct ScanLds {
-    uint32_t mmw[68];
+    uint32_t mmw[260];   // 1024 MM characters + 16 of look-ahead
     char hdr[16];
     int16_t g_code[16];
 };
@@ -62,31 +71,43 @@ struct CallLds {
     uint32_t gstart[64];
 };
 
-// position of the first ';' at or after `from` (or mlen): 256 characters per trip, no LDS
+// 0x80 in every byte of w that equals ';' (exact for the lowest such byte, which is all that is used)
+__device__ __forceinline__ uint32_t semi_bytes(uint32_t w) {
+    uint32_t y = w ^ 0x3B3B3B3Bu;
+    return (y - 0x01010101u) & ~y & 0x80808080u;
+}
+// position of the first ';' at or after `from` (or mlen): 1024 characters per trip (four dwords per lane in flight), no LDS
 __device__ __forceinline__ uint32_t find_semicolon(const uint8_t* mm, uint32_t mlen, uint32_t from) {
     const int lane = lane_id();
     uint32_t pos = from;
     uint32_t found = mlen;
     bool hit = false;
     while (pos < mlen && !hit) {
-        uint32_t off = pos + 4u * lane;
-        uint32_t w = 0;
-        if (off < mlen) {
-            __builtin_memcpy(&w, mm + off, 4);
-            uint32_t left = mlen - off;
-            if (left < 4u) w &= (1u << (8u * left)) - 1u;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t off = pos + 16u * lane + 4u * j;
+            w[j] = 0;
+            if (off < mlen) {
+                __builtin_memcpy(&w[j], mm + off, 4);
+                uint32_t left = mlen - off;
+                if (left < 4u) w[j] &= (1u << (8u * left)) - 1u;
+            }
         }
-        uint32_t y = w ^ 0x3B3B3B3Bu;                                  // zero byte where the character is ';'
-        uint32_t z = (y - 0x01010101u) & ~y & 0x80808080u;            // 0x80 in every zero byte (exact for the lowest one)
-        if (off >= mlen) z = 0;
-        uint64_t b = __ballot(z != 0);
+        // first ';' among this lane's 16 characters
+        uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            uint32_t z = semi_bytes(w[j]);
+            if (z) first = 4u * j + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+        }
+        uint64_t b = __ballot(first != 0xFFFFFFFFu);
         if (b) {
             int l = __ffsll((unsigned long long)b) - 1;
-            uint32_t zl = lane_valu(z, l);
-            found = pos + 4u * (uint32_t)l + ((uint32_t)__ffs((int)zl) - 1u) / 8u;
+            found = pos + 16u * (uint32_t)l + lane_valu(first, l);
             hit = true;
         }
-        pos += 256u;
+        pos += 1024u;
     }
     return found < mlen ? found : mlen;
 }
@@ -158,6 +179,7 @@ struct KA {
     const DevParams& p;
     ScanLds& S;
     int err;
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};   // diagnostic builds: time per phase, flushed once per wave
     __device__ KA(const TileParams& tp, ScanLds& s) : P(tp), p(tp.d), S(s), err(0) {}
 
     // group header at mpos (mod.c:1003-1062); also leaves the code characters in S.hdr
@@ -232,18 +254,18 @@ struct KA {
         return eb ? e : 0;
     }
 
-    __device__ void write_tile(uint32_t idx, const TileRec& t) {
+    __device__ void write_tile(TileRec* tiles_base, uint32_t idx, const TileRec& t) {
         // lanes 0..15 store one dword each: one 64-byte line
         const int lane = lane_id();
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&t);
         uint32_t v = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) if (lane == i) v = src[i];
-        if (lane < 16) reinterpret_cast<uint32_t*>(P.tiles + idx)[lane] = v;
+        if (lane < 16) reinterpret_cast<uint32_t*>(tiles_base + idx)[lane] = v;
     }
 
     // returns the read's status (0 = ok / handed to the fused kernel)
-    __device__ int run(int ridx) {
+    __device__ int run(int ridx, uint32_t region) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         err = 0;
@@ -257,6 +279,18 @@ struct KA {
         if (have_ref) have_ref = p.ref_base[tid] >= 0;
         int result = have_ref ? 0 : MM_E_NOCONTIG;   // single exit below: no early returns (see freq_kernels.hip.h)
 
+        // warm L2 with everything this read will stream (CIGAR, packed sequence, MM): one touch per 128-byte line,
+        // all in flight at once, so that the dependent passes below hit L2 instead of paying an HBM round trip each
+        {
+            uint32_t acc = 0;
+            const uint8_t* bases[3] = {reinterpret_cast<const uint8_t*>(p.cigar + cig_off), p.seq + rd.seq_off, mm};
+            const uint32_t sizes[3] = {4u * ncig, (L + 1u) / 2u, mlen};
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                for (uint32_t o = 128u * lane; o < sizes[a]; o += 128u * 64u) acc ^= *reinterpret_cast<const uint32_t*>(bases[a] + o);
+            if (acc == 0x9E3779B9u && L == 0xFFFFFFFFu) P.g_qtot[ridx] = acc;   // never true: keeps the loads alive
+        }
+        KAT_DECL;
         // ---------------- pass 1: group headers only -> regular or not, and how many tiles the read needs
         int first_cls = -1;
         bool irregular = false;
@@ -282,33 +316,36 @@ struct KA {
                 }
             }
         }
+        KAT_LAP(8);
         uint32_t tbase = 0, tcur = 0;
         if (have_ref && !irregular && need > 0) {
-            if (lane == 0) tbase = atomicAdd(P.tile_count, need);
+            if (lane == 0) tbase = atomicAdd(P.tile_count + region, need);
             tbase = uniu(tbase);
             if ((uint64_t)tbase + need > P.tile_cap) irregular = true;   // reserved slots are marked invalid below
         }
         tcur = tbase;
+        TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
         if (have_ref && irregular) {
             // hand the whole read to the fused kernel
             if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; }
         }
         const bool go = have_ref && !irregular;
+        KAT_LAP(9);
 
         // ---------------- CIGAR prefix arrays -> global (mod.c:776-881 as scans)
         if (go) {
             const uint32_t* cg = p.cigar + cig_off;
             const int64_t ctg_len = p.ctg_len[tid];
             uint32_t carry_q = 0, carry_r = 0;
-            for (uint32_t i0 = 0; i0 < ncig; i0 += 256) {
-                uint32_t wv[4];
+            for (uint32_t i0 = 0; i0 < ncig; i0 += 512) {
+                uint32_t wv[8];   // eight loads in flight: a wave alone pays one memory round trip per 512 ops
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     uint32_t i = i0 + 64u * u + lane;
                     wv[u] = i < ncig ? cg[i] : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     uint32_t i = i0 + 64u * u + lane;
                     bool act = i < ncig;
                     uint32_t w = wv[u], op = w & 15u, len = w >> 4;
@@ -335,20 +372,21 @@ struct KA {
             if (lane == 0) P.g_qtot[ridx] = carry_q;
         }
         if (go) result = any_err();
+        KAT_LAP(10);
         // ---------------- rank directory of the read's one class -> global (mod.c:972-981)
         uint32_t nb = 0;
         if (go && result == 0 && first_cls >= 0) {
             const uint4* sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
             uint32_t carry = 0;
-            for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
-                uint4 vv[4];
+            for (uint32_t b0 = 0; b0 < nblk; b0 += 512) {
+                uint4 vv[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     uint32_t b = b0 + 64u * u + lane;
                     vv[u] = b < nblk ? sq[b] : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     uint32_t b = b0 + 64u * u + lane;
                     uint32_t cnt = 0;
                     if (b < nblk) {
@@ -372,6 +410,7 @@ struct KA {
             }
             nb = carry;
         }
+        KAT_LAP(11);
         // ---------------- pass 2: cut every skip list into tiles stamped with their carries
         if (go && result == 0) {
             uint32_t mpos = 0, ml_start = 0;
@@ -387,39 +426,45 @@ struct KA {
                 int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
                 uint32_t cpos = g.lstart, k_carry = 0, rank_carry = 0;
                 bool prev_delim = true, done = bad;
-                uint32_t wd_next = 0;
-                bool have_next = false;
                 while (!done) {
-                    uint32_t wd = have_next ? wd_next : mm_dword(mm, mlen, cpos + 4u * lane);
-                    wd_next = mm_dword(mm, mlen, cpos + 256u + 4u * lane);
+                    // 1024 characters (+16 of look-ahead) per trip: four dwords per lane in flight, four tiles per trip
+                    uint32_t w4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w4[j] = mm_dword(mm, mlen, cpos + 16u * lane + 4u * j);
+                    uint32_t la = lane < 4 ? mm_dword(mm, mlen, cpos + 1024u + 4u * lane) : 0u;
                     wave_sync();
-                    S.mmw[lane] = wd;
-                    if (lane < 4) S.mmw[64 + lane] = wd_next;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) S.mmw[4 * lane + j] = w4[j];
+                    if (lane < 4) S.mmw[256 + lane] = la;
                     wave_sync();
                     const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-                    // the tile record carries the state in front of this trip
-                    TileRec t;
-                    t.ridx = (uint32_t)ridx; t.cpos = cpos; t.k_carry = k_carry; t.rank_carry = rank_carry; t.ml_start = ml_start;
-                    t.nb = nb; t.flags = gflags | (prev_delim ? 32u : 0u); t.rsvd0 = 0;
-                    t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
-#pragma unroll
-                    for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
-                    write_tile(tcur++, t);
                     bool closed = false;
 #pragma unroll 1
-                    for (int sub = 0; sub < 4; sub++) {
+                    for (int ti = 0; ti < 4; ti++) {
                         if (closed) continue;
-                        SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
-                        if (sp.err) err = sp.err;
-                        uint64_t tb = __ballot(sp.tstart);
-                        uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
-                        rank_carry += lane_valu(sm, 63);
-                        k_carry += (uint32_t)__popcll(tb);
-                        if (sp.endl < 64) { closed = true; cpos = cpos + 64u * (uint32_t)sub + (uint32_t)sp.endl + 1u; }
-                        else prev_delim = sp.last_char == ',';
+                        // the tile record carries the state in front of its 256 characters
+                        TileRec t;
+                        t.ridx = (uint32_t)ridx; t.cpos = cpos + 256u * (uint32_t)ti; t.k_carry = k_carry; t.rank_carry = rank_carry;
+                        t.ml_start = ml_start; t.nb = nb; t.flags = gflags | (prev_delim ? 32u : 0u); t.rsvd0 = 0;
+                        t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
+                        write_tile(rtiles, tcur++, t);
+#pragma unroll 1
+                        for (int sub = 0; sub < 4; sub++) {
+                            if (closed) continue;
+                            SubParse sp = parse_sub(mb8, 256 * ti + 64 * sub, prev_delim);
+                            if (sp.err) err = sp.err;
+                            uint64_t tb = __ballot(sp.tstart);
+                            uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
+                            rank_carry += lane_valu(sm, 63);
+                            k_carry += (uint32_t)__popcll(tb);
+                            if (sp.endl < 64) { closed = true; cpos = cpos + 256u * (uint32_t)ti + 64u * (uint32_t)sub + (uint32_t)sp.endl + 1u; }
+                            else prev_delim = sp.last_char == ',';
+                        }
                     }
                     if (closed) done = true;
-                    else { cpos += 256u; have_next = true; }
+                    else cpos += 1024u;
                     bad = __ballot(err != 0) != 0;
                     if (bad) done = true;
                 }
@@ -433,7 +478,7 @@ struct KA {
                             t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
 #pragma unroll
                             for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
-                            write_tile(tcur++, t);
+                            write_tile(rtiles, tcur++, t);
                         }
                     }
                     mpos = cpos;
@@ -441,11 +486,12 @@ struct KA {
             }
             result = any_err();
         }
+        KAT_LAP(12);
         // reserved slots this read did not fill are marked invalid (flags = 0)
         if (have_ref && need > 0) {
             uint32_t hi = tbase + need;
             if (hi > P.tile_cap) hi = P.tile_cap;
-            for (uint32_t i = tcur + lane; i < hi; i += 64) P.tiles[i].flags = 0u;
+            for (uint32_t i = tcur + lane; i < hi; i += 64) rtiles[i].flags = 0u;
         }
         return result;
     }
@@ -463,12 +509,15 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         item = uniu(item);
         if ((item >> 24) & 15u) continue;   // plans made for the fused kernel split long reads into parts: one visit per read here
         int ridx = (int)(item & 0xFFFFFFu);
-        int e = uni(k.run(ridx));
+        int e = uni(k.run(ridx, (uint32_t)r % kTileRegions));
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
         }
     }
+#ifdef MM_PHASE_TIMING
+    if (lane_id() == 0 && p.stats) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, k.tacc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ KC
@@ -788,14 +837,18 @@ __global__ __launch_bounds__(256) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
-    // static round-robin over the tiles (they cost about the same): no shared work counter to serialise on
-    unsigned int n_tiles = *P.tile_count;
+    // static round-robin: wave g serves region g % kTileRegions, striding over that region's tiles with the other
+    // waves of the same residue (tiles cost about the same; no shared work counter to serialise on)
+    const unsigned int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int n_waves = gridDim.x * kWavesPerBlock;
+    const unsigned int region = g % kTileRegions;
+    unsigned int n_tiles = P.tile_count[region];
     if (n_tiles > P.tile_cap) n_tiles = P.tile_cap;
     n_tiles = uniu(n_tiles);
-    const unsigned int n_waves = gridDim.x * kWavesPerBlock;
-    for (unsigned int ti = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); ti < n_tiles; ti += n_waves) {
+    const TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
+    for (unsigned int ti = g / kTileRegions; ti < n_tiles; ti += n_waves / kTileRegions) {
         // the tile record as wave-uniform scalars
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tiles + ti);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
         typename KC<RefWord>::TileArgs t;
         t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.k_carry = uniu(src[2]); t.rank_carry = uniu(src[3]);
         t.ml_start = uniu(src[4]); t.nb = uniu(src[5]); t.flags = uniu(src[6]);

@@ -275,12 +275,12 @@ class FreqEngine(object):
         self.L.mm_freq_stats_enable(self.h, int(on))
 
     def stats_get(self):
-        out = (ctypes.c_uint64 * 8)()
+        out = (ctypes.c_uint64 * 16)()
         r = self.L.mm_freq_stats_get(self.h, out)
         if r:
             raise MinimodHipError(-r, "stats_get failed")
         return {"lookups": int(out[0]), "ml_reads": int(out[1]), "dense_updates": int(out[2]), "side_updates": int(out[3]),
-                "phase_cycles": [int(out[i]) for i in range(4, 8)]}
+                "phase_cycles": [int(out[i]) for i in range(4, 16)]}
 
     # -- results
     def finalize(self):
