@@ -4,12 +4,14 @@
 // rank directory in LDS: at -K 4096 that is only 4096 waves, 13 KB of LDS each (3 waves per SIMD), and a launch lasts
 // as long as its longest read.  Here the same work is cut differently:
 //
-//   KA  k_scan_reads   one wave per read, light and streaming: CIGAR prefix arrays and the rank directory go to a
-//                      global scratch (L2-resident, indexed like the pools they come from), and the MM text is scanned
-//                      once to cut every group's skip list into TILES of 256 characters, each stamped with the carries
-//                      it needs (tokens, ranks, ML index before it).  '.' groups also get tail tiles.
-//   KC  k_call_tiles   one wave per tile, any order, 1.3 KB of LDS: parse the tile's tokens, turn ranks into read
-//                      positions (directory search + in-block select), project through the CIGAR arrays, test the
+//   KA  k_scan_reads   three independent waves per read, light and streaming: (1) CIGAR prefix arrays and (2) the rank
+//                      directory go to a global scratch (L2-resident, indexed like the pools they come from); (3) the
+//                      MM group headers are parsed and every group's skip list is cut into TILES of 256 characters
+//                      (plus tail tiles for '.' groups) -- nothing sequential over the text itself.
+//   KS  k_sum_tiles    one wave per tile: tokens and rank sum of the tile (8 bytes per tile).
+//   KC  k_call_tiles   one wave per tile, any order, 1.3 KB of LDS: prefix over the summaries of the tiles in front of
+//                      it gives the carries (tokens, ranks, ML index); then parse the tile's tokens, turn ranks into
+//                      read positions (directory search + in-block select), project through the CIGAR arrays, test the
 //                      reference word, threshold the ML byte, one 64-bit atomic per call.
 //
 // Reads the tile form does not cover (more than 4 code letters in a group, groups with different canonical bases) are
@@ -31,30 +33,29 @@ constexpr uint32_t kTileChars = 256;
 constexpr uint32_t kTailRanks = 16384;  // implicit-call ranks per tail tile
 constexpr uint32_t kTileRegions = 64;   // independent reservation counters / tile regions
 
-struct TileRec {  // 64 bytes
+struct TileRec {  // 32 bytes
     uint32_t ridx;
-    uint32_t cpos;        // list tile: offset of its first character in the MM string
-    uint32_t k_carry;     // tokens of the group in front of this tile
-    uint32_t rank_carry;  // sum(skip+1) in front of this tile; tail tile: first rank
-    uint32_t ml_start;    // ML index of the group's first call
-    uint32_t nb;          // bases of the group's class in the read; tail tile: one past the last rank
-    uint32_t flags;       // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 prev_delim, 8-10 cls, 12-14 n_codes
-    uint32_t rsvd0;
+    uint32_t cpos;         // list tile: offset of its first character in the MM string; tail tile: its index j in the group's tail
+    uint32_t read_first;   // index (inside the region) of the read's first tile
+    uint32_t group_first;  // index of the group's first tile
+    uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, 8-10 cls, 12-14 n_codes
     int16_t g_code[4];
-    uint32_t rsvd[6];
+    uint32_t rsvd;
 };
-static_assert(sizeof(TileRec) == 64, "TileRec must be 64 bytes");
+static_assert(sizeof(TileRec) == 32, "TileRec must be 32 bytes");
 
 struct TileParams {
-    DevParams d;              // batch, reference, counters, options (d.queue = KA's read queue)
+    DevParams d;              // batch, reference, counters, options
     uint32_t* g_cq;           // [n_cigar_words] query offset at the start of each op (indexed like the cigar pool)
     uint32_t* g_cr;           // [n_cigar_words] reference offset | op << 28
     uint32_t* g_dir;          // [n_seq_bytes / 16] rank directory (indexed like the seq pool, one entry per 16 bytes)
     uint32_t* g_qtot;         // [n_reads] query length of the CIGAR
+    uint32_t* g_nb;           // [n_reads] bases of the read's class
     TileRec* tiles;           // kTileRegions regions of tile_cap records each
+    uint2* g_sum;             // per tile: x = tokens | n_codes << 16, y = sum(skip+1)
     unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
     unsigned int tile_cap;    // records per region
-    unsigned int* tile_queue; // KC's work counter
+    unsigned int* tile_queue; // unused (kept for layout)
     int32_t* fb_list;         // reads left to the fused kernel
     unsigned int* fb_count;
 };
@@ -255,90 +256,32 @@ struct KA {
     }
 
     __device__ void write_tile(TileRec* tiles_base, uint32_t idx, const TileRec& t) {
-        // lanes 0..15 store one dword each: one 64-byte line
+        // lanes 0..7 store one dword each
         const int lane = lane_id();
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&t);
         uint32_t v = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) if (lane == i) v = src[i];
-        if (lane < 16) reinterpret_cast<uint32_t*>(tiles_base + idx)[lane] = v;
+        for (int i = 0; i < 8; i++) if (lane == i) v = src[i];
+        if (lane < 8) reinterpret_cast<uint32_t*>(tiles_base + idx)[lane] = v;
     }
 
-    // returns the read's status (0 = ok / handed to the fused kernel)
-    __device__ int run(int ridx, uint32_t region) {
+    // ---------------- item kind 0: CIGAR prefix arrays -> global (mod.c:776-881 as scans)
+    __device__ int run_cigar(int ridx) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         err = 0;
         const int tid = uni(rd.tid), pos = uni(rd.pos);
-        const uint32_t L = uniu(rd.l_qseq), ncig = uniu(rd.n_cigar), mlen = uniu(rd.mm_len);
-        const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
-        const uint8_t* mm = p.mm + rd.mm_off;
-        const uint64_t cig_off = rd.cigar_off, dir_off = rd.seq_off >> 4;
-        const uint32_t nblk = (L + 31u) >> 5;
+        const uint32_t L = uniu(rd.l_qseq), ncig = uniu(rd.n_cigar);
+        const uint64_t cig_off = rd.cigar_off;
         bool have_ref = tid >= 0 && tid < p.n_contigs;
         if (have_ref) have_ref = p.ref_base[tid] >= 0;
-        int result = have_ref ? 0 : MM_E_NOCONTIG;   // single exit below: no early returns (see freq_kernels.hip.h)
-
-        // warm L2 with everything this read will stream (CIGAR, packed sequence, MM): one touch per 128-byte line,
-        // all in flight at once, so that the dependent passes below hit L2 instead of paying an HBM round trip each
-        {
-            uint32_t acc = 0;
-            const uint8_t* bases[3] = {reinterpret_cast<const uint8_t*>(p.cigar + cig_off), p.seq + rd.seq_off, mm};
-            const uint32_t sizes[3] = {4u * ncig, (L + 1u) / 2u, mlen};
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-                for (uint32_t o = 128u * lane; o < sizes[a]; o += 128u * 64u) acc ^= *reinterpret_cast<const uint32_t*>(bases[a] + o);
-            if (acc == 0x9E3779B9u && L == 0xFFFFFFFFu) P.g_qtot[ridx] = acc;   // never true: keeps the loads alive
-        }
-        KAT_DECL;
-        // ---------------- pass 1: group headers only -> regular or not, and how many tiles the read needs
-        int first_cls = -1;
-        bool irregular = false;
-        uint32_t need = 0;
+        int result = have_ref ? 0 : MM_E_NOCONTIG;
         if (have_ref) {
-            uint32_t mpos = 0;
-            int guard = 0;
-            while (mpos < mlen && !irregular) {
-                GroupHdr g = parse_header(mm, mlen, mpos);
-                if (g.herr || g.n > 4 || ++guard > 4096) { irregular = true; }   // errors are reported by the fused kernel
-                else {
-                    int mb = rev ? complement_char(g.modbase) : g.modbase;
-                    bool direct = g.modbase == 'N', dot = g.flag == '.';
-                    int cls = base_class_of_char(mb);
-                    if (!direct || dot) {
-                        if (first_cls < 0) first_cls = cls;
-                        else if (cls != first_cls) irregular = true;
-                    }
-                    uint32_t endp = find_semicolon(mm, mlen, g.lstart);
-                    need += (endp - g.lstart) / kTileChars + 1u;
-                    if (dot) need += L / kTailRanks + 1u;
-                    mpos = endp + 1u;
-                }
-            }
-        }
-        KAT_LAP(8);
-        uint32_t tbase = 0, tcur = 0;
-        if (have_ref && !irregular && need > 0) {
-            if (lane == 0) tbase = atomicAdd(P.tile_count + region, need);
-            tbase = uniu(tbase);
-            if ((uint64_t)tbase + need > P.tile_cap) irregular = true;   // reserved slots are marked invalid below
-        }
-        tcur = tbase;
-        TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
-        if (have_ref && irregular) {
-            // hand the whole read to the fused kernel
-            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; }
-        }
-        const bool go = have_ref && !irregular;
-        KAT_LAP(9);
-
-        // ---------------- CIGAR prefix arrays -> global (mod.c:776-881 as scans)
-        if (go) {
             const uint32_t* cg = p.cigar + cig_off;
             const int64_t ctg_len = p.ctg_len[tid];
             uint32_t carry_q = 0, carry_r = 0;
             for (uint32_t i0 = 0; i0 < ncig; i0 += 512) {
-                uint32_t wv[8];   // eight loads in flight: a wave alone pays one memory round trip per 512 ops
+                uint32_t wv[8];   // eight loads in flight
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     uint32_t i = i0 + 64u * u + lane;
@@ -370,12 +313,41 @@ struct KA {
                 }
             }
             if (lane == 0) P.g_qtot[ridx] = carry_q;
+            result = any_err();
         }
-        if (go) result = any_err();
-        KAT_LAP(10);
-        // ---------------- rank directory of the read's one class -> global (mod.c:972-981)
+        return result;
+    }
+
+    // the base class the read's groups select from (complement class for reverse reads), -1 if none / unparsable
+    __device__ int first_class(const uint8_t* mm, uint32_t mlen, int rev) {
+        int cls = -1;
+        uint32_t mpos = 0;
+        int guard = 0;
+        bool stop = false;
+        while (mpos < mlen && !stop) {
+            GroupHdr g = parse_header(mm, mlen, mpos);
+            if (g.herr || ++guard > 4096) stop = true;
+            else {
+                int mb = rev ? complement_char(g.modbase) : g.modbase;
+                bool direct = g.modbase == 'N', dot = g.flag == '.';
+                if (!direct || dot) { cls = base_class_of_char(mb); stop = true; }
+                else mpos = find_semicolon(mm, mlen, g.lstart) + 1u;
+            }
+        }
+        return cls;
+    }
+
+    // ---------------- item kind 2: rank directory of the read's one class -> global (mod.c:972-981)
+    __device__ int run_dir(int ridx) {
+        const int lane = lane_id();
+        const mm_read_t& rd = p.reads[ridx];
+        const uint32_t L = uniu(rd.l_qseq), mlen = uniu(rd.mm_len);
+        const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        const uint64_t dir_off = rd.seq_off >> 4;
+        const uint32_t nblk = (L + 31u) >> 5;
+        const int cls = first_class(p.mm + rd.mm_off, mlen, rev);
         uint32_t nb = 0;
-        if (go && result == 0 && first_cls >= 0) {
+        if (cls >= 0) {
             const uint4* sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
             uint32_t carry = 0;
             for (uint32_t b0 = 0; b0 < nblk; b0 += 512) {
@@ -392,15 +364,15 @@ struct KA {
                     if (b < nblk) {
                         uint4 v = vv[u];
                         int valid = (int)min(32u, L - b * 32u);
-                        if (first_cls == 0) {
+                        if (cls == 0) {
                             uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
                                          __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
                                          __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
                                          __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
                             cnt = (uint32_t)valid - o;
                         } else {
-                            cnt = __popc(class_bits(v.x, first_cls)) + __popc(class_bits(v.y, first_cls)) +
-                                  __popc(class_bits(v.z, first_cls)) + __popc(class_bits(v.w, first_cls));
+                            cnt = __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) +
+                                  __popc(class_bits(v.z, cls)) + __popc(class_bits(v.w, cls));
                         }
                     }
                     uint32_t incl = wave_incl_scan(cnt);
@@ -410,10 +382,61 @@ struct KA {
             }
             nb = carry;
         }
-        KAT_LAP(11);
-        // ---------------- pass 2: cut every skip list into tiles stamped with their carries
-        if (go && result == 0) {
-            uint32_t mpos = 0, ml_start = 0;
+        if (lane == 0) P.g_nb[ridx] = nb;
+        return 0;
+    }
+
+    // ---------------- item kind 1: MM group headers -> tiles (or the fallback list)
+    __device__ int run_mm(int ridx, uint32_t region) {
+        const int lane = lane_id();
+        const mm_read_t& rd = p.reads[ridx];
+        err = 0;
+        const int tid = uni(rd.tid);
+        const uint32_t L = uniu(rd.l_qseq), mlen = uniu(rd.mm_len);
+        const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        const uint8_t* mm = p.mm + rd.mm_off;
+        bool have_ref = tid >= 0 && tid < p.n_contigs;
+        if (have_ref) have_ref = p.ref_base[tid] >= 0;
+        int result = 0;   // a missing contig is reported by the CIGAR item
+        // pass 1: regular or not, and how many tiles
+        int first_cls = -1;
+        bool irregular = false;
+        uint32_t need = 0;
+        if (have_ref) {
+            uint32_t mpos = 0;
+            int guard = 0;
+            while (mpos < mlen && !irregular) {
+                GroupHdr g = parse_header(mm, mlen, mpos);
+                if (g.herr || g.n > 4 || ++guard > 4096) { irregular = true; }   // errors are reported by the fused kernel
+                else {
+                    int mb = rev ? complement_char(g.modbase) : g.modbase;
+                    bool direct = g.modbase == 'N', dot = g.flag == '.';
+                    int cls = base_class_of_char(mb);
+                    if (!direct || dot) {
+                        if (first_cls < 0) first_cls = cls;
+                        else if (cls != first_cls) irregular = true;
+                    }
+                    uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                    need += (endp - g.lstart) / kTileChars + 1u;
+                    if (dot) need += L / kTailRanks + 1u;
+                    mpos = endp + 1u;
+                }
+            }
+        }
+        uint32_t tbase = 0;
+        if (have_ref && !irregular && need > 0) {
+            if (lane == 0) tbase = atomicAdd(P.tile_count + region, need);
+            tbase = uniu(tbase);
+            if ((uint64_t)tbase + need > P.tile_cap) irregular = true;   // reserved slots are marked invalid below
+        }
+        uint32_t tcur = tbase;
+        TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
+        if (have_ref && irregular) {
+            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; }
+        }
+        // pass 2: the tile records (no text is parsed here beyond the headers)
+        if (have_ref && !irregular) {
+            uint32_t mpos = 0;
             bool bad = false;
             while (mpos < mlen && !bad) {
                 GroupHdr g = parse_header(mm, mlen, mpos);
@@ -424,69 +447,32 @@ struct KA {
                 uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) |
                                   ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
                 int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
-                uint32_t cpos = g.lstart, k_carry = 0, rank_carry = 0;
-                bool prev_delim = true, done = bad;
-                while (!done) {
-                    // 1024 characters (+16 of look-ahead) per trip: four dwords per lane in flight, four tiles per trip
-                    uint32_t w4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) w4[j] = mm_dword(mm, mlen, cpos + 16u * lane + 4u * j);
-                    uint32_t la = lane < 4 ? mm_dword(mm, mlen, cpos + 1024u + 4u * lane) : 0u;
-                    wave_sync();
-#pragma unroll
-                    for (int j = 0; j < 4; j++) S.mmw[4 * lane + j] = w4[j];
-                    if (lane < 4) S.mmw[256 + lane] = la;
-                    wave_sync();
-                    const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-                    bool closed = false;
-#pragma unroll 1
-                    for (int ti = 0; ti < 4; ti++) {
-                        if (closed) continue;
-                        // the tile record carries the state in front of its 256 characters
-                        TileRec t;
-                        t.ridx = (uint32_t)ridx; t.cpos = cpos + 256u * (uint32_t)ti; t.k_carry = k_carry; t.rank_carry = rank_carry;
-                        t.ml_start = ml_start; t.nb = nb; t.flags = gflags | (prev_delim ? 32u : 0u); t.rsvd0 = 0;
-                        t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
-#pragma unroll
-                        for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
-                        write_tile(rtiles, tcur++, t);
-#pragma unroll 1
-                        for (int sub = 0; sub < 4; sub++) {
-                            if (closed) continue;
-                            SubParse sp = parse_sub(mb8, 256 * ti + 64 * sub, prev_delim);
-                            if (sp.err) err = sp.err;
-                            uint64_t tb = __ballot(sp.tstart);
-                            uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
-                            rank_carry += lane_valu(sm, 63);
-                            k_carry += (uint32_t)__popcll(tb);
-                            if (sp.endl < 64) { closed = true; cpos = cpos + 256u * (uint32_t)ti + 64u * (uint32_t)sub + (uint32_t)sp.endl + 1u; }
-                            else prev_delim = sp.last_char == ',';
-                        }
-                    }
-                    if (closed) done = true;
-                    else cpos += 1024u;
-                    bad = __ballot(err != 0) != 0;
-                    if (bad) done = true;
-                }
+                uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                uint32_t nlist = (endp - g.lstart) / kTileChars + 1u;
+                uint32_t ntail = dot ? L / kTailRanks + 1u : 0u;
+                uint32_t gfirst = tcur;
                 if (!bad) {
-                    if (k_carry > 0) ml_start += k_carry * (uint32_t)g.n;      // mod.c:1200
-                    if (dot) {                                                   // mod.c:1289-1365
-                        for (uint32_t r0 = rank_carry; r0 < nb; r0 += kTailRanks) {
+                    // lanes write the group's records in parallel: record j of the group
+                    for (uint32_t j0 = 0; j0 < nlist + ntail; j0 += 64) {
+                        uint32_t j = j0 + lane;
+                        if (j < nlist + ntail) {
                             TileRec t;
-                            t.ridx = (uint32_t)ridx; t.cpos = 0; t.k_carry = 0; t.rank_carry = r0; t.ml_start = ml_start;
-                            t.nb = min(nb, r0 + kTailRanks); t.flags = gflags | 2u; t.rsvd0 = 0;
+                            bool tail = j >= nlist;
+                            t.ridx = (uint32_t)ridx;
+                            t.cpos = tail ? j - nlist : g.lstart + kTileChars * j;
+                            t.read_first = tbase; t.group_first = gfirst;
+                            t.flags = gflags | (tail ? 2u : 0u) | ((!tail && j == 0) ? 32u : 0u);
                             t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
-#pragma unroll
-                            for (int i = 0; i < 6; i++) t.rsvd[i] = 0;
-                            write_tile(rtiles, tcur++, t);
+                            t.rsvd = 0;
+                            rtiles[gfirst + j] = t;
                         }
                     }
-                    mpos = cpos;
+                    tcur += nlist + ntail;
+                    mpos = endp + 1u;
                 }
             }
             result = any_err();
         }
-        KAT_LAP(12);
         // reserved slots this read did not fill are marked invalid (flags = 0)
         if (have_ref && need > 0) {
             uint32_t hi = tbase + need;
@@ -502,22 +488,86 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
     __shared__ ScanLds lds[kWavesPerBlock];
     KA<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
-    // static round-robin over the (costliest-first) item list: one shared work counter would serialise ~4k dequeues
+    // three items per read (CIGAR scan, MM headers -> tiles, rank directory), the heaviest kind first; static
+    // round-robin over the (costliest-first) item list: a shared work counter would serialise ~12k dequeues
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
-    for (int r = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6); r < p.n_items; r += n_waves) {
-        uint32_t item = p.order ? (uint32_t)p.order[r] : (uint32_t)r;
+    const int n = p.n_items;
+    for (int r = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6); r < 3 * n; r += n_waves) {
+        const int kind = r / n, ri = r - kind * n;
+        uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
         item = uniu(item);
         if ((item >> 24) & 15u) continue;   // plans made for the fused kernel split long reads into parts: one visit per read here
         int ridx = (int)(item & 0xFFFFFFu);
-        int e = uni(k.run(ridx, (uint32_t)r % kTileRegions));
+        int e = 0;
+        if (kind == 0) e = k.run_cigar(ridx);
+        else if (kind == 1) e = k.run_mm(ridx, (uint32_t)ri % kTileRegions);
+        else e = k.run_dir(ridx);
+        e = uni(e);
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
         }
     }
-#ifdef MM_PHASE_TIMING
-    if (lane_id() == 0 && p.stats) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, k.tacc[i]);
-#endif
+}
+
+// first-character state of a list tile: its first character starts a token iff the previous one is a delimiter
+__device__ __forceinline__ bool tile_prev_delim(const uint8_t* mm, uint32_t cpos, uint32_t flags) {
+    return (flags & 32u) ? true : (mm[cpos - 1u] == ',');
+}
+
+// ------------------------------------------------------------------------------------------------ KS
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
+    __shared__ uint32_t lds[kWavesPerBlock][68];
+    const DevParams& p = P.d;
+    const int lane = lane_id();
+    uint32_t* mmw = lds[threadIdx.x >> 6];
+    const unsigned int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int n_waves = gridDim.x * kWavesPerBlock;
+    const unsigned int region = g % kTileRegions;
+    unsigned int n_tiles = P.tile_count[region];
+    if (n_tiles > P.tile_cap) n_tiles = P.tile_cap;
+    n_tiles = uniu(n_tiles);
+    const TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
+    uint2* const rsum = P.g_sum + (size_t)region * P.tile_cap;
+    for (unsigned int ti = g / kTileRegions; ti < n_tiles; ti += n_waves / kTileRegions) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
+        const uint32_t ridx = uniu(src[0]), cpos = uniu(src[1]), flags = uniu(src[4]);
+        uint32_t ntok = 0, rsum_v = 0;
+        int terr = 0;
+        if ((flags & 1u) && !(flags & 2u)) {
+            const mm_read_t& rd = p.reads[ridx];
+            const uint32_t mlen = uniu(rd.mm_len);
+            const uint8_t* mm = p.mm + rd.mm_off;
+            uint32_t wd = mm_dword(mm, mlen, cpos + 4u * lane);
+            uint32_t la = lane < 4 ? mm_dword(mm, mlen, cpos + 256u + 4u * lane) : 0u;
+            bool prev_delim = tile_prev_delim(mm, cpos, flags);
+            wave_sync();
+            mmw[lane] = wd;
+            if (lane < 4) mmw[64 + lane] = la;
+            wave_sync();
+            const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mmw);
+            bool closed = false;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; sub++) {
+                if (closed) continue;
+                SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
+                if (sp.err) terr = sp.err;
+                uint64_t tb = __ballot(sp.tstart);
+                uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
+                rsum_v += lane_valu(sm, 63);
+                ntok += (uint32_t)__popcll(tb);
+                if (sp.endl < 64) closed = true;
+                else prev_delim = sp.last_char == ',';
+            }
+            uint64_t eb = __ballot(terr != 0);
+            if (eb) {
+                int e = lane_val(terr, __ffsll((unsigned long long)eb) - 1);
+                if (lane == 0) { p.status[ridx] = e; atomicMin(p.err_summary, (ridx << 8) | (unsigned int)e); }
+            }
+        }
+        if (lane == 0) rsum[ti] = make_uint2(ntok | (((flags >> 12) & 7u) << 16), rsum_v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ KC
@@ -708,8 +758,8 @@ struct KC {
         }
     }
 
-    struct TileArgs { uint32_t ridx, cpos, k_carry, rank_carry, ml_start, nb, flags; };
-    __device__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23) {
+    struct TileArgs { uint32_t ridx, cpos, read_first, group_first, flags, index; };
+    __device__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23, const uint2* rsum) {
         const int lane = lane_id();
         constexpr int J = 2;
         err = 0;
@@ -724,20 +774,41 @@ struct KC {
         gq = P.g_cq + rd.cigar_off; gr = P.g_cr + rd.cigar_off; gd = P.g_dir + (rd.seq_off >> 4);
         nblk = (L + 31u) >> 5;
         q_total = P.g_qtot[ridx];
+        nb = P.g_nb[ridx];
         hp = p.haplotypes ? (int)rd.hp : -1;
         hpi = p.haplotypes ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
         ref_base = p.ref_base[tid]; seg_begin = p.seg_begin[tid]; seg_len = p.seg_len[tid]; cnt_base = p.cnt_base[tid];
+        // carries = prefix over the summaries of the read's tiles in front of this one:
+        //   ml_start  = sum over earlier groups of tokens * n_codes      (mod.c:1200)
+        //   k_carry   = tokens of this group in front of the tile
+        //   rank_carry= sum(skip+1) of this group in front of the tile
+        uint32_t a_ml = 0, a_k = 0, a_r = 0;
+        for (uint32_t i0 = t.read_first; i0 < t.index; i0 += 64) {
+            uint32_t i = i0 + lane;
+            if (i < t.index) {
+                uint2 sv = rsum[i];
+                uint32_t nt = sv.x & 0xFFFFu, nc = (sv.x >> 16) & 7u;
+                if (i < t.group_first) a_ml += nt * nc;
+                else { a_k += nt; a_r += sv.y; }
+            }
+        }
+        ml_start = lane_valu(wave_incl_scan(a_ml), 63);
+        const uint32_t k_carry0 = lane_valu(wave_incl_scan(a_k), 63);
+        const uint32_t rank_carry0 = lane_valu(wave_incl_scan(a_r), 63);
         const uint32_t fl = t.flags;
         const bool tail = fl & 2u, dot = fl & 4u;
         direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
-        nb = t.nb; ml_start = t.ml_start;
         gc0 = (int16_t)(gc01 & 0xFFFFu); gc1 = (int16_t)(gc01 >> 16); gc2 = (int16_t)(gc23 & 0xFFFFu); gc3 = (int16_t)(gc23 >> 16);
         if (tail) {
-            for (uint32_t r0 = t.rank_carry; r0 < t.nb; r0 += 64u * J) {
+            // bases after the last listed one (mod.c:1289-1365): this tile's slice of [rank_carry0, nb)
+            const uint64_t lo64 = (uint64_t)rank_carry0 + (uint64_t)kTailRanks * t.cpos;
+            const uint32_t tlo = lo64 < nb ? (uint32_t)lo64 : nb;
+            const uint32_t thi = (lo64 + kTailRanks) < nb ? (uint32_t)(lo64 + kTailRanks) : nb;
+            for (uint32_t r0 = tlo; r0 < thi; r0 += 64u * J) {
                 uint32_t r2[J], k2[J];
                 bool l2[J];
 #pragma unroll
-                for (int v = 0; v < J; v++) { r2[v] = r0 + 64u * v + lane; k2[v] = 0; l2[v] = r2[v] < t.nb; }
+                for (int v = 0; v < J; v++) { r2[v] = r0 + 64u * v + lane; k2[v] = 0; l2[v] = r2[v] < thi; }
                 process_calls<J>(r2, k2, l2, false);
             }
         } else {
@@ -748,7 +819,7 @@ struct KC {
             if (lane < 4) S.mmw[64 + lane] = la;
             wave_sync();
             const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-            bool prev_delim = (fl >> 5) & 1u, closed = false;
+            bool prev_delim = tile_prev_delim(mm, t.cpos, fl), closed = false;
             uint32_t ntok = 0;
 #pragma unroll 1
             for (int sub = 0; sub < 4; sub++) {
@@ -764,7 +835,7 @@ struct KC {
             // ranks of the (<= 128) tokens: two per lane
             uint32_t s[J], rank[J], kidx[J];
             bool live[J];
-            uint32_t carry = t.rank_carry;
+            uint32_t carry = rank_carry0;
 #pragma unroll
             for (int u = 0; u < J; u++) {
                 uint32_t ti = 64u * u + lane;
@@ -772,12 +843,12 @@ struct KC {
                 s[u] = live[u] ? S.tok[ti] : 0u;
                 uint32_t incl = wave_incl_scan(live[u] ? s[u] + 1u : 0u);
                 rank[u] = carry + incl - 1u;
-                kidx[u] = t.k_carry + ti;
+                kidx[u] = k_carry0 + ti;
                 carry += lane_valu(incl, 63);
             }
             process_calls<J>(rank, kidx, live, true);
             if (dot) {   // implicit calls in the gaps in front of the listed ranks (mod.c:1206-1287)
-                uint32_t carry2 = t.rank_carry;
+                uint32_t carry2 = rank_carry0;
 #pragma unroll 1
                 for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
                     uint32_t ti = t64 + lane;
@@ -850,11 +921,11 @@ __global__ __launch_bounds__(256) void k_call_tiles(const TileParams P) {
         // the tile record as wave-uniform scalars
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
         typename KC<RefWord>::TileArgs t;
-        t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.k_carry = uniu(src[2]); t.rank_carry = uniu(src[3]);
-        t.ml_start = uniu(src[4]); t.nb = uniu(src[5]); t.flags = uniu(src[6]);
-        uint32_t gc01 = uniu(src[8]), gc23 = uniu(src[9]);
+        t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.read_first = uniu(src[2]); t.group_first = uniu(src[3]);
+        t.flags = uniu(src[4]); t.index = ti;
+        uint32_t gc01 = uniu(src[5]), gc23 = uniu(src[6]);
         if (!(t.flags & 1u)) continue;
-        int e = uni(k.run(t, gc01, gc23));
+        int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
         if (p.stats) k.flush_stats();
         if (e != 0 && lane_id() == 0) {
             p.status[t.ridx] = e;
