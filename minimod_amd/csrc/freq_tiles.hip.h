@@ -65,11 +65,16 @@ struct ScanLds {
     char hdr[16];
     int16_t g_code[16];
 };
+constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
+constexpr uint32_t kSliceC = 640;   // CIGAR ops staged in LDS per tile
 struct CallLds {
     uint32_t mmw[68];
     uint32_t tok[128];
     uint32_t gap[64];
     uint32_t gstart[64];
+    uint32_t ds[kSliceD];    // slice of the rank directory covering the tile's listed ranks
+    uint32_t csq[kSliceC];   // slice of the CIGAR query-offset array covering the tile's read positions
+    uint32_t csr[kSliceC];   //   ... and of the reference-offset | op array
 };
 
 // 0x80 in every byte of w that equals ';' (exact for the lowest such byte, which is all that is used)
@@ -588,27 +593,99 @@ struct KC {
     uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
     int32_t gc0, gc1, gc2, gc3;
+    // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
+    // CIGAR ops [cs_lo, cs_lo+cs_cnt) answer read positions in [cs_q_lo, cs_q_hi)
+    uint32_t ds_lo, ds_cnt, ds_rr_lo, ds_rr_hi, cs_lo, cs_cnt, cs_q_lo, cs_q_hi;
 
     __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
 
     __device__ KC(const TileParams& tp, CallLds& s) : P(tp), p(tp.d), S(s), err(0), st_look(0), st_ml(0), st_dense(0), st_side(0) {}
 
-    __device__ __forceinline__ uint32_t find_block(uint32_t rr) const {
+    // Cooperative 64-ary search, two targets at once (t1 <= t2): largest i in [0,n) with arr[i] <= t.  arr is
+    // non-decreasing with arr[0] <= t1.  Each round is ONE gather per target (64 lanes sample the current window).
+    __device__ __forceinline__ void coop_find2(const uint32_t* arr, uint32_t n, uint32_t t1, uint32_t t2, uint32_t& i1, uint32_t& i2) const {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t lo1 = 0, len1 = n, lo2 = 0, len2 = n;
+        while (len1 > 1u || len2 > 1u) {
+            uint32_t st1 = (len1 + 63u) / 64u, st2 = (len2 + 63u) / 64u;
+            uint32_t a1 = lo1 + lane * st1, a2 = lo2 + lane * st2;
+            bool in1 = lane * st1 < len1, in2 = lane * st2 < len2;
+            uint32_t v1 = in1 ? arr[a1] : 0xFFFFFFFFu, v2 = in2 ? arr[a2] : 0xFFFFFFFFu;
+            uint64_t b1 = __ballot(in1 && v1 <= t1) | 1ull, b2 = __ballot(in2 && v2 <= t2) | 1ull;
+            uint32_t top1 = 63u - (uint32_t)__clzll((unsigned long long)b1), top2 = 63u - (uint32_t)__clzll((unsigned long long)b2);
+            uint32_t nlo1 = lo1 + top1 * st1, nlo2 = lo2 + top2 * st2;
+            len1 = min(st1, lo1 + len1 - nlo1); lo1 = nlo1;
+            len2 = min(st2, lo2 + len2 - nlo2); lo2 = nlo2;
+        }
+        i1 = lo1; i2 = lo2;
+    }
+
+    // stage the directory blocks that cover ranks [rr_a, rr_b] (rr_a <= rr_b < nb) in LDS
+    __device__ void setup_dir_slice(uint32_t rr_a, uint32_t rr_b, uint32_t& b1, uint32_t& b2) {
+        const uint32_t lane = (uint32_t)lane_id();
+        coop_find2(gd, nblk, rr_a, rr_b, b1, b2);
+        uint32_t cnt = b2 - b1 + 1u;
+        ds_cnt = 0;
+        if (cnt <= kSliceD) {
+            for (uint32_t j = lane; j < cnt; j += 64u) S.ds[j] = gd[b1 + j];
+            wave_sync();
+            ds_lo = b1; ds_cnt = cnt;
+            ds_rr_lo = rr_a; ds_rr_hi = rr_b + 1u;   // every rank in [rr_a, rr_b] lies in blocks b1..b2
+        }
+    }
+    // stage the CIGAR ops that cover read positions [q_a, q_b] (q_a <= q_b < q_total) in LDS
+    __device__ void setup_cig_slice(uint32_t q_a, uint32_t q_b) {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t i1, i2;
+        coop_find2(gq, ncig, q_a, q_b, i1, i2);
+        uint32_t cnt = i2 - i1 + 1u;
+        cs_cnt = 0;
+        if (cnt <= kSliceC) {
+            for (uint32_t j = lane; j < cnt; j += 64u) { S.csq[j] = gq[i1 + j]; S.csr[j] = gr[i1 + j]; }
+            wave_sync();
+            cs_lo = i1; cs_cnt = cnt;
+            cs_q_lo = q_a; cs_q_hi = q_b + 1u;
+        }
+    }
+
+    // rank (BAM orientation) -> block and the block's first rank; LDS slice when it covers the rank
+    __device__ __forceinline__ uint32_t find_block(uint32_t rr, uint32_t& base) const {
         uint32_t lo = 0, step = 1;
+        if (ds_cnt && rr >= ds_rr_lo && rr < ds_rr_hi) {
+            while (step < ds_cnt) step <<= 1;
+            for (step >>= 1; step; step >>= 1) {
+                uint32_t cand = lo + step;
+                if (cand < ds_cnt && S.ds[cand] <= rr) lo = cand;
+            }
+            base = S.ds[lo];
+            return ds_lo + lo;
+        }
         while (step < nblk) step <<= 1;
         for (step >>= 1; step; step >>= 1) {
             uint32_t cand = lo + step;
             if (cand < nblk && gd[cand] <= rr) lo = cand;
         }
+        base = gd[lo];
         return lo;
     }
-    __device__ __forceinline__ uint32_t find_op(uint32_t q) const {
+    // read position -> CIGAR op (largest i with cq[i] <= q), its query offset and reference word
+    __device__ __forceinline__ uint32_t find_op(uint32_t q, uint32_t& qs, uint32_t& rv) const {
         uint32_t lo = 0, step = 1;
+        if (cs_cnt && q >= cs_q_lo && q < cs_q_hi) {
+            while (step < cs_cnt) step <<= 1;
+            for (step >>= 1; step; step >>= 1) {
+                uint32_t cand = lo + step;
+                if (cand < cs_cnt && S.csq[cand] <= q) lo = cand;
+            }
+            qs = S.csq[lo]; rv = S.csr[lo];
+            return cs_lo + lo;
+        }
         while (step < ncig) step <<= 1;
         for (step >>= 1; step; step >>= 1) {
             uint32_t cand = lo + step;
             if (cand < ncig && gq[cand] <= q) lo = cand;
         }
+        qs = gq[lo]; rv = gr[lo];
         return lo;
     }
     __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
@@ -650,16 +727,14 @@ struct KC {
     }
 
     // J calls per lane as a staged pipeline (same stages as K1::process_calls, prefix arrays in global memory)
+    // J calls per lane as a staged pipeline: locate (rank -> read position + base) ...
     template <int J>
-    __device__ __forceinline__ void process_calls(const uint32_t (&rank)[J], const uint32_t (&kidx)[J], const bool (&live_in)[J], bool is_explicit) {
-        bool live[J];
-        uint32_t blk[J], kk[J], q[J], code[J], ins_off[J];
-        int64_t ref_pos[J];
+    __device__ __forceinline__ void locate(const uint32_t (&rank)[J], bool (&live)[J], uint32_t (&q)[J], uint32_t (&code)[J]) {
+        uint32_t blk[J], kk[J];
         uint4 sv[J];
 #pragma unroll
         for (int u = 0; u < J; u++) {
-            live[u] = live_in[u];
-            blk[u] = 0; kk[u] = 0; q[u] = 0; code[u] = 0; ins_off[u] = 0; ref_pos[u] = -1;
+            blk[u] = 0; kk[u] = 0; q[u] = 0; code[u] = 0;
             if (!live[u]) continue;
             if (direct) {
                 if (rank[u] >= L) { err = MM_E_READPOS; live[u] = false; continue; }
@@ -667,8 +742,9 @@ struct KC {
             } else {
                 if (rank[u] >= nb) { err = MM_E_READPOS; live[u] = false; continue; }
                 uint32_t rr = rev ? nb - 1 - rank[u] : rank[u];
-                blk[u] = find_block(rr);
-                kk[u] = rr - gd[blk[u]];
+                uint32_t base;
+                blk[u] = find_block(rr, base);
+                kk[u] = rr - base;
             }
         }
 #pragma unroll
@@ -681,10 +757,22 @@ struct KC {
             if (!live[u]) continue;
             if (direct) { uint32_t b = sv[u].x; code[u] = (q[u] & 1u) ? (b & 15u) : (b >> 4); }
             else q[u] = select_in_block(sv[u], blk[u], kk[u], code[u]);
+        }
+    }
+    // ... then finish (read position -> reference position -> filters -> counter)
+    template <int J>
+    __device__ __forceinline__ void finish(const uint32_t (&q)[J], const uint32_t (&code)[J], const uint32_t (&kidx)[J], bool (&live)[J], bool is_explicit) {
+        uint32_t ins_off[J];
+        int64_t ref_pos[J];
+#pragma unroll
+        for (int u = 0; u < J; u++) {
+            ins_off[u] = 0; ref_pos[u] = -1;
+            if (!live[u]) continue;
             int64_t rp = -1, anchor = -1;
             if (q[u] < q_total) {
-                uint32_t i = find_op(q[u]);
-                uint32_t rv = gr[i], op = rv >> 28, qs = gq[i];
+                uint32_t qs, rv;
+                (void)find_op(q[u], qs, rv);
+                uint32_t op = rv >> 28;
                 if ((0x181u >> op) & 1u) {
                     rp = (int64_t)pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
                 } else if (op == 1u && p.insertions) {
@@ -698,8 +786,8 @@ struct KC {
                 } else {   // mod.c:1234,1314 quirk: the mirrored base's insertion anchor
                     uint32_t q2 = L - 1u - q[u];
                     if (q2 < q_total) {
-                        uint32_t i2 = find_op(q2);
-                        uint32_t rv2 = gr[i2];
+                        uint32_t qs2, rv2;
+                        (void)find_op(q2, qs2, rv2);
                         if ((rv2 >> 28) == 1u) rp = (int64_t)pos + (rv2 & 0x0FFFFFFFu) - 1;
                     }
                 }
@@ -758,10 +846,19 @@ struct KC {
         }
     }
 
+    template <int J>
+    __device__ __forceinline__ void process_calls(const uint32_t (&rank)[J], const uint32_t (&kidx)[J], const bool (&live_in)[J], bool is_explicit) {
+        bool live[J];
+        uint32_t q[J], code[J];
+#pragma unroll
+        for (int u = 0; u < J; u++) live[u] = live_in[u];
+        locate<J>(rank, live, q, code);
+        finish<J>(q, code, kidx, live, is_explicit);
+    }
+
     struct TileArgs { uint32_t ridx, cpos, read_first, group_first, flags, index; };
-    __device__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23, const uint2* rsum) {
+    __device__ __forceinline__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23, const uint2* rsum) {
         const int lane = lane_id();
-        constexpr int J = 2;
         err = 0;
         const int ridx = (int)t.ridx;
         const mm_read_t& rd = p.reads[ridx];
@@ -795,6 +892,7 @@ struct KC {
         ml_start = lane_valu(wave_incl_scan(a_ml), 63);
         const uint32_t k_carry0 = lane_valu(wave_incl_scan(a_k), 63);
         const uint32_t rank_carry0 = lane_valu(wave_incl_scan(a_r), 63);
+        ds_cnt = 0; cs_cnt = 0;
         const uint32_t fl = t.flags;
         const bool tail = fl & 2u, dot = fl & 4u;
         direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
@@ -804,22 +902,20 @@ struct KC {
             const uint64_t lo64 = (uint64_t)rank_carry0 + (uint64_t)kTailRanks * t.cpos;
             const uint32_t tlo = lo64 < nb ? (uint32_t)lo64 : nb;
             const uint32_t thi = (lo64 + kTailRanks) < nb ? (uint32_t)(lo64 + kTailRanks) : nb;
-            for (uint32_t r0 = tlo; r0 < thi; r0 += 64u * J) {
-                uint32_t r2[J], k2[J];
-                bool l2[J];
-#pragma unroll
-                for (int v = 0; v < J; v++) { r2[v] = r0 + 64u * v + lane; k2[v] = 0; l2[v] = r2[v] < thi; }
-                process_calls<J>(r2, k2, l2, false);
+            for (uint32_t r0 = tlo; r0 < thi; r0 += 64u) {
+                uint32_t r2[1] = {r0 + lane}, k2[1] = {0};
+                bool l2[1] = {r2[0] < thi};
+                process_calls<1>(r2, k2, l2, false);
             }
         } else {
             // the tile's 256 characters (+16 of look-ahead) -> LDS, tokens compacted into tok[]
             uint32_t wd = mm_dword(mm, mlen, t.cpos + 4u * lane);
             uint32_t la = lane < 4 ? mm_dword(mm, mlen, t.cpos + 256u + 4u * lane) : 0u;
+            bool prev_delim = tile_prev_delim(mm, t.cpos, fl), closed = false;
             S.mmw[lane] = wd;
             if (lane < 4) S.mmw[64 + lane] = la;
             wave_sync();
             const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-            bool prev_delim = tile_prev_delim(mm, t.cpos, fl), closed = false;
             uint32_t ntok = 0;
 #pragma unroll 1
             for (int sub = 0; sub < 4; sub++) {
@@ -832,55 +928,66 @@ struct KC {
                 else prev_delim = sp.last_char == ',';
             }
             wave_sync();
-            // ranks of the (<= 128) tokens: two per lane
-            uint32_t s[J], rank[J], kidx[J];
-            bool live[J];
+            // skip counts -> ranks, in place (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
             uint32_t carry = rank_carry0;
-#pragma unroll
-            for (int u = 0; u < J; u++) {
-                uint32_t ti = 64u * u + lane;
-                live[u] = ti < ntok;
-                s[u] = live[u] ? S.tok[ti] : 0u;
-                uint32_t incl = wave_incl_scan(live[u] ? s[u] + 1u : 0u);
-                rank[u] = carry + incl - 1u;
-                kidx[u] = k_carry0 + ti;
+#pragma unroll 1
+            for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
+                uint32_t ti = t64 + lane;
+                bool lv = ti < ntok;
+                uint32_t su = lv ? S.tok[ti] : 0u;
+                uint32_t incl = wave_incl_scan(lv ? su + 1u : 0u);
+                if (lv) S.tok[ti] = carry + incl - 1u;
                 carry += lane_valu(incl, 63);
             }
-            process_calls<J>(rank, kidx, live, true);
-            if (dot) {   // implicit calls in the gaps in front of the listed ranks (mod.c:1206-1287)
-                uint32_t carry2 = rank_carry0;
+            wave_sync();
+            if (ntok > 0) {
+                // listed ranks rise with the token index: the first and last token bound everything this tile touches;
+                // both slices are staged before the first call ('.' groups also visit the gap in front of the first token)
+                const uint32_t r_first = dot ? rank_carry0 : S.tok[0], r_last = S.tok[ntok - 1u];
+                if (r_last < (direct ? L : nb)) {
+                    uint32_t qa, qb;
+                    if (direct) {
+                        qa = rev ? L - 1u - r_last : r_first; qb = rev ? L - 1u - r_first : r_last;
+                    } else {
+                        uint32_t rr_a = rev ? nb - 1u - r_last : r_first, rr_b = rev ? nb - 1u - r_first : r_last;
+                        uint32_t b1, b2;
+                        setup_dir_slice(rr_a, rr_b, b1, b2);
+                        qa = 32u * b1; qb = min(L - 1u, 32u * b2 + 31u);
+                    }
+                    if (q_total > 0 && qa < q_total) setup_cig_slice(qa, min(qb, q_total - 1u));
+                }
+            }
 #pragma unroll 1
-                for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
-                    uint32_t ti = t64 + lane;
-                    bool lv = ti < ntok;
-                    uint32_t su = lv ? S.tok[ti] : 0u;
-                    uint32_t incl = wave_incl_scan(lv ? su + 1u : 0u);
-                    uint32_t ranku = carry2 + incl - 1u;
-                    carry2 += lane_valu(incl, 63);
+            for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
+                uint32_t ti = t64 + lane;
+                bool lv = ti < ntok;
+                uint32_t rk = lv ? S.tok[ti] : 0u;
+                uint32_t prev = ti == 0 ? rank_carry0 - 1u : (lv ? S.tok[ti - 1u] : 0u);
+                uint32_t r1[1] = {rk}, k1[1] = {k_carry0 + ti};
+                bool l1[1] = {lv};
+                process_calls<1>(r1, k1, l1, true);
+                if (dot) {   // implicit calls in the gap in front of each listed rank (mod.c:1206-1287)
+                    uint32_t su = lv ? rk - prev - 1u : 0u;
                     uint32_t gi = wave_incl_scan(su);
                     uint32_t T = lane_valu(gi, 63);
                     wave_sync();
                     S.gap[lane] = gi - su;
-                    S.gstart[lane] = ranku - su;
+                    S.gstart[lane] = rk - su;
                     wave_sync();
-                    for (uint32_t t0 = 0; t0 < T; t0 += 64u * J) {
-                        uint32_t r2[J], k2[J];
-                        bool l2[J];
+                    for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+                        uint32_t tt = t0 + lane;
+                        bool l2[1] = {tt < T};
+                        uint32_t r2[1] = {0}, k2[1] = {0};
+                        if (l2[0]) {
+                            uint32_t lo = 0;
 #pragma unroll
-                        for (int v = 0; v < J; v++) {
-                            uint32_t tt = t0 + 64u * v + lane;
-                            l2[v] = tt < T; r2[v] = 0; k2[v] = 0;
-                            if (l2[v]) {
-                                uint32_t lo = 0;
-#pragma unroll
-                                for (uint32_t step = 32; step; step >>= 1) {
-                                    uint32_t cand = lo + step;
-                                    if (cand < 64u && S.gap[cand] <= tt) lo = cand;
-                                }
-                                r2[v] = S.gstart[lo] + (tt - S.gap[lo]);
+                            for (uint32_t step = 32; step; step >>= 1) {
+                                uint32_t cand = lo + step;
+                                if (cand < 64u && S.gap[cand] <= tt) lo = cand;
                             }
+                            r2[0] = S.gstart[lo] + (tt - S.gap[lo]);
                         }
-                        process_calls<J>(r2, k2, l2, false);
+                        process_calls<1>(r2, k2, l2, false);
                     }
                 }
             }
@@ -904,7 +1011,7 @@ struct KC {
 };
 
 template <typename RefWord>
-__global__ __launch_bounds__(256) void k_call_tiles(const TileParams P) {
+__global__ __launch_bounds__(256, 4) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
