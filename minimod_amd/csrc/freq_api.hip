@@ -161,7 +161,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     const int full_grid = h->n_cu * h->blocks_per_cu;
     int blocks = std::min((p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, full_grid);
     if (blocks < 1) blocks = 1;
-    if (h->use_tiles) blocks = full_grid;   // the fused kernel then only runs the fallback list, whose length the host does not know
+    if (h->use_tiles) blocks = std::min(full_grid, 128);   // the fused kernel then only runs the (usually empty) fallback list
     uint32_t spill_cig = b->max_n_cigar > (uint32_t)kCigCap ? b->max_n_cigar - kCigCap : 0;
     uint32_t max_blk = (b->max_l_qseq + 31u) / 32u;
     uint32_t spill_blk = max_blk > (uint32_t)kDirCap ? max_blk - kDirCap : 0;
