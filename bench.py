@@ -10,8 +10,9 @@ already resident in HBM; steps cycle over the 25 resident batches of the rank's 
 owns its own 50 Mb interval of one long contig with its own 100k reads (reads routed by start position, SURVEY.md
 section 8e); the only exchange is one halo-slab send/recv to the right neighbour (RCCL) inside the timed region.
 
-`roofline.achieved` = algorithmic bytes per K1 launch / mean K1 duration from HIP events recorded by the library on the
-launch stream; algorithmic bytes follow SURVEY.md section 8(d):
+`roofline.achieved` = algorithmic bytes per batch / mean device time of the batch's hot-path launches (k_scan_reads,
+k_sum_tiles, k_call_tiles, fallback) from HIP events recorded by the library on the launch stream (the sum of the
+four kernels, not just the largest one: the conservative reading); algorithmic bytes follow SURVEY.md section 8(d):
     B_read = 40 + 4*n_cigar + ceil(l_qseq/2) + |MM| + |ML| + 2*n_lookups + 16*n_updates
 with n_lookups / n_updates tallied by the kernel itself in an untimed pass.
 `cpu_baseline` = the oracle (oracle/freq_oracle.c, a bit-exact CPU restatement of the reference's algorithm: the
@@ -235,7 +236,8 @@ def main():
                        "sharding": "interval per GPU + halo slab to the right neighbour" if world > 1 else "single GPU",
                        "read_order": "natural, unsplit" if args.natural_order else "mm_freq_plan_batch (long reads split, costliest first)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_freq_reads",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "freq hot path per batch = k_scan_reads + k_sum_tiles + k_call_tiles (+ k_freq_reads on the fallback list), HIP events around the four launches",
                          "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms),
                          "bytes_per_base": abytes / max(bases, 1)},
             "gen_seconds": t_gen,

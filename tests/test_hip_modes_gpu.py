@@ -1,0 +1,66 @@
+"""Both device forms of the hot path -- the tile pipeline (default) and the fused one-wave-per-read kernel
+(MM_FUSED=1, also the fallback for reads the tiles do not cover) -- against the oracle on synthetic reads that
+exercise what the bundled BAMs do not at scale: long reads (spills past the LDS caps, many tiles), HiFi shape, '.'
+groups (implicit calls, tail tiles), haplotypes, insertions, the side list."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+ref = synth.reference(21, 6 << 20)
+out = {}
+cases = {
+  "ont_long": dict(gen=dict(n=400, max_len=0.0), c=[("m","CG"),("h","CG")], th=[0.8,0.7], kw={}),
+  "hifi_dot": dict(gen=dict(n=200, shape=1, dot_fraction=0.6), c=[("m","CG")], th=[0.8], kw={}),
+  "dot_hp_ins": dict(gen=dict(n=150, dot_fraction=1.0, haplotypes=True, long_insertions=True, max_len=20000.0), c=[("m","C")], th=[0.7],
+                     kw=dict(insertions=True, haplotypes=True)),
+  "star_ctx_single": dict(gen=dict(n=200, single_code=True), c=[("m","*")], th=[0.9], kw={}),
+}
+for name, cs in cases.items():
+    g = dict(cs["gen"]); n = g.pop("n")
+    b = synth.batch(ref, 0, n, seed=77, n_reads_total=n, **g)
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], **cs["kw"])
+    eng.process(b)
+    got = eng.finalize(); eng.close()
+    orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
+    want = orc.rows()
+    key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+    out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max())}
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("fused", [0, 1], ids=["tiles", "fused"])
+def test_synthetic_shapes_match_oracle(fused):
+    env = dict(os.environ, MM_FUSED=str(fused))
+    r = subprocess.run([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single"}
+    for name, v in res.items():
+        assert v["rows"] > 1000, (name, v)
+        assert v["equal"], (name, v)
+    assert res["ont_long"]["max_l"] > 40000
+
+
+def test_device_resident_batches_and_bench_verify():
+    """bench.py's own check: resident batches through mm_freq_submit_device, compared with the oracle."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "6000", "--batch", "2048", "--steps", "6", "--warmup", "1",
+                        "--verify", "--cpu-sample-batches", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["verify"]["bit_exact"] and d["verify"]["rows"] > 1000
+    assert d["unit"] == "Mbases/s" and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"

@@ -149,3 +149,24 @@ def test_synthetic_generator_is_deterministic_and_valid():
         o.add_contig("chrS", ref)
         o.process(b)
         assert len(o.rows()) > 100
+
+
+def test_plan_batch_splits_long_reads_and_orders_by_cost():
+    from minimod_amd import engine, synth
+    ref = synth.reference(3, 2 << 20)
+    b = synth.batch(ref, 0, 300, seed=4, n_reads_total=300)
+    items = engine.plan_batch(b["reads"])
+    rd = b["reads"]
+    ridx, part, nparts = items & 0xFFFFFF, (items >> 24) & 15, ((items >> 28) & 15) + 1
+    # every read appears with all of its parts exactly once
+    seen = {}
+    for r, p_, n_ in zip(ridx.tolist(), part.tolist(), nparts.tolist()):
+        seen.setdefault(r, []).append((p_, n_))
+    assert sorted(seen) == list(range(len(rd)))
+    for r, ps in seen.items():
+        n_ = ps[0][1]
+        assert sorted(p_ for p_, _ in ps) == list(range(n_)) and all(x == n_ for _, x in ps)
+        assert n_ == min(16, max(1, -(-int(rd["l_qseq"][r]) // 16384)))
+    cost = rd["l_qseq"][ridx] // nparts // 256
+    assert (cost[:-1] >= cost[1:]).all()      # costliest first
+    assert len(engine.plan_batch(rd[:0])) == 0
