@@ -383,8 +383,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
-    if (dev_alloc(h, (void**)&h->d_stats, 16 * sizeof(unsigned long long))) return fail(h, "alloc failed");
-    (void)hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long));
+    if (dev_alloc(h, (void**)&h->d_stats, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long))) return fail(h, "alloc failed");
+    (void)hipMemset(h->d_stats, 0, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long));
     h->codes_dirty = !h->codes.empty();
     // ---- contigs: reference words for every contig that has a sequence; counter segments
     h->n_contigs = n_contigs;
@@ -609,8 +609,12 @@ int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     if (!h || !out) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
+    std::vector<unsigned long long> all(16 + 4 * (size_t)kStatSlots);
+    HIPCHK(hipMemcpy(all.data(), h->d_stats, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stats, 0, all.size() * sizeof(unsigned long long)));
+    for (int i = 0; i < 16; i++) out[i] = all[i];
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    for (size_t w = 0; w < kStatSlots; w++) for (int i = 0; i < 4; i++) out[i] += all[16 + 4 * w + i];
     return 0;
 }
 

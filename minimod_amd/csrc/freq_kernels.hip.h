@@ -34,6 +34,7 @@
 namespace mmhip {
 
 constexpr int kWavesPerBlock = 4;
+constexpr uint32_t kStatSlots = 16384;   // per-wave tally rows (power of two)
 constexpr int kCigCap = 1024;  // CIGAR ops whose prefix sums live in LDS (the rest spill to a global scratch)
 constexpr int kDirCap = 512;   // 32-base blocks whose rank directory lives in LDS (16 kb of read)
 constexpr int kTokCap = 512;   // compacted skip counts: one flush takes 256, one 256-character trip adds <= 128
@@ -99,7 +100,8 @@ struct DevParams {
     SideRec* side;
     unsigned long long* side_count;
     unsigned long long side_cap;
-    unsigned long long* stats;     // optional [4]: reference-word lookups, ML bytes read, dense updates, side updates
+    unsigned long long* stats;     // optional: [0..15] diagnostic timers, then kStatSlots rows of {reference-word lookups, ML bytes
+                                   // read, dense updates, side updates}, one row per wave slot (summed by the host)
     // scheduling / scratch
     unsigned int* queue;
     uint32_t* spill;               // per wave slot: [max_cig] q, [max_cig] r, [max_blk] dir
@@ -630,13 +632,13 @@ struct K1 {
         }
     }
 
-    __device__ void flush_stats() {
+    __device__ void flush_stats(uint32_t stat_slot) {
         uint32_t v[4] = {st_look, st_ml, st_dense, st_side};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t x = wave_incl_scan(v[i]);
             uint32_t t = lane_valu(x, 63);
-            if (lane_id() == 0 && t) atomicAdd(p.stats + i, (unsigned long long)t);
+            if (lane_id() == 0 && t) p.stats[16 + 4 * (size_t)stat_slot + i] += (unsigned long long)t;   // this wave owns the row: no atomics
         }
         st_look = st_ml = st_dense = st_side = 0;
     }
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
         int ridx = (int)(item & 0xFFFFFFu);
         uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
         int e = uni(k.run(ridx, wave_slot, part, nparts));
-        if (p.stats) k.flush_stats();
+        if (p.stats) k.flush_stats((uint32_t)wave_slot & (kStatSlots - 1));
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);

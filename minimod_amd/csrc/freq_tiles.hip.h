@@ -998,13 +998,13 @@ struct KC {
         return eb ? e : 0;
     }
 
-    __device__ void flush_stats() {
+    __device__ void flush_stats(uint32_t stat_slot) {
         uint32_t v[4] = {st_look, st_ml, st_dense, st_side};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t x = wave_incl_scan(v[i]);
             uint32_t tt = lane_valu(x, 63);
-            if (lane_id() == 0 && tt) atomicAdd(p.stats + i, (unsigned long long)tt);
+            if (lane_id() == 0 && tt) p.stats[16 + 4 * (size_t)stat_slot + i] += (unsigned long long)tt;   // this wave owns the row: no atomics
         }
         st_look = st_ml = st_dense = st_side = 0;
     }
@@ -1033,12 +1033,12 @@ __global__ __launch_bounds__(256, 4) void k_call_tiles(const TileParams P) {
         uint32_t gc01 = uniu(src[5]), gc23 = uniu(src[6]);
         if (!(t.flags & 1u)) continue;
         int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
-        if (p.stats) k.flush_stats();
         if (e != 0 && lane_id() == 0) {
             p.status[t.ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)t.ridx << 8) | (unsigned int)e);
         }
     }
+    if (p.stats) k.flush_stats(g & (kStatSlots - 1));
 }
 
 }  // namespace mmhip
