@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
     ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
     return ap.parse_args()
 
@@ -99,10 +100,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # testing: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
+    host_staged = world > 1 and args.backend != "nccl"   # gloo moves CPU tensors
 
     import minimod_amd
     from minimod_amd import engine, synth
@@ -184,14 +191,21 @@ def main():
     slab_words = eng.slab_words(HALO)
 
     def make_buf():
-        return torch.empty(slab_words, dtype=torch.int64, device=dev)
+        return torch.empty(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
 
     def export_fn(buf):
-        eng.slab_export(0, plan["end"], plan["halo"], buf.data_ptr(), stream)
+        dbuf = torch.empty(slab_words, dtype=torch.int64, device=dev) if host_staged else buf
+        eng.slab_export(0, plan["end"], plan["halo"], dbuf.data_ptr(), stream)
         eng.slab_clear(0, plan["end"], plan["halo"], stream)
+        tstream.synchronize()          # the slab must be complete before RCCL (another stream) reads it
+        if host_staged:
+            buf.copy_(dbuf.cpu())
 
     def add_fn(buf):
-        eng.slab_add(0, plan["begin"], HALO, buf.data_ptr(), stream)
+        dbuf = buf.to(dev) if host_staged else buf
+        torch.cuda.synchronize()       # the received slab is complete before our stream adds it
+        eng.slab_add(0, plan["begin"], HALO, dbuf.data_ptr(), stream)
+        tstream.synchronize()
 
     if world > 1:
         dist.barrier()
@@ -204,10 +218,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = "cpu" if host_staged else dev
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tb = torch.tensor([bases], dtype=torch.int64, device=dev)
+        tb = torch.tensor([bases], dtype=torch.int64, device=rdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
     else:

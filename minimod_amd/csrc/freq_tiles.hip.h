@@ -1011,7 +1011,7 @@ struct KC {
 };
 
 template <typename RefWord>
-__global__ __launch_bounds__(256, 4) void k_call_tiles(const TileParams P) {
+__global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;

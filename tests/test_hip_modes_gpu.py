@@ -64,3 +64,55 @@ def test_device_resident_batches_and_bench_verify():
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["verify"]["bit_exact"] and d["verify"]["rows"] > 1000
     assert d["unit"] == "Mbases/s" and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
+
+
+SHARD_WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import torch
+torch.zeros(1, device="cuda")   # torch's HIP runtime comes up before the library's (as in bench.py)
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+import bench
+interval, halo = 1 << 20, 1 << 16
+plans = [bench.shard_plan(r, 2, interval, halo) for r in range(2)]
+ref = synth.reference(5, plans[0]["contig_len"])
+batches = [synth.batch(ref, 0, 900, seed=11 + 7919 * r, contig_len=plans[r]["contig_len"], n_reads_total=900,
+                       region_begin=plans[r]["read_begin"], region_len=plans[r]["read_len"], median_len=3000.0, max_len=30000.0)
+           for r in range(2)]
+engs = []
+for r in range(2):
+    e = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plans[r]["contig_len"], ref)],
+                               intervals=[(0, plans[r]["begin"], plans[r]["end"], plans[r]["halo"])])
+    e.process(batches[r])
+    engs.append(e)
+words = engs[0].slab_words(halo)
+buf = torch.zeros(words, dtype=torch.int64, device="cuda")
+engs[0].slab_export(0, plans[0]["end"], halo, buf.data_ptr())
+engs[0].slab_clear(0, plans[0]["end"], halo)
+crossed = int((buf != 0).sum())
+engs[1].slab_add(0, plans[1]["begin"], halo, buf.data_ptr())
+got = []
+for e in engs:
+    rows = e.finalize()
+    got += list(zip(rows["pos"].tolist(), rows["strand"].tolist(), rows["n_called"].tolist(), rows["n_mod"].tolist()))
+    e.close()
+orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+orc.add_contig("chrS", ref)
+for b in batches:
+    orc.process(b)
+w = orc.rows()
+want = sorted(zip(w["pos"].tolist(), w["strand"].tolist(), w["n_called"].tolist(), w["n_mod"].tolist()))
+print(json.dumps({"crossed": crossed, "rows": len(want), "equal": sorted(got) == want}))
+'''
+
+
+def test_interval_sharding_with_halo_slabs_on_device():
+    """Two handles own neighbouring intervals of one contig (as two ranks would); the left one's halo slab is exported,
+    cleared, and added into the right one's planes with the library's slab kernels; the union equals the unsharded
+    oracle bit for bit."""
+    r = subprocess.run([sys.executable, "-c", SHARD_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["crossed"] > 0 and res["rows"] > 1000 and res["equal"], res
