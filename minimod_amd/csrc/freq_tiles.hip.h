@@ -51,6 +51,8 @@ struct TileParams {
     uint32_t* g_dir;          // [n_seq_bytes / 16] rank directory (indexed like the seq pool, one entry per 16 bytes)
     uint32_t* g_qtot;         // [n_reads] query length of the CIGAR
     uint32_t* g_nb;           // [n_reads] bases of the read's class
+    uint32_t* g_qdir;         // coarse: CIGAR op containing read position 256*k  (base (seq_off >> 7) + 2*ridx)
+    uint32_t* g_rdir;         // coarse: directory block containing rank 64*k       (base (seq_off >> 5) + 2*ridx)
     TileRec* tiles;           // kTileRegions regions of tile_cap records each
     uint2* g_sum;             // per tile: x = tokens | n_codes << 16, y = sum(skip+1)
     unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
@@ -271,7 +273,9 @@ struct KA {
     }
 
     // ---------------- item kind 0: CIGAR prefix arrays -> global (mod.c:776-881 as scans)
-    __device__ int run_cigar(int ridx) {
+    // A long read's scan is cut into `nparts` chunks of ops, one wave each: a chunk first SUMS the op lengths in
+    // front of it (cheap: no scans, no stores) to get its carries, then scans only its own ops.
+    __device__ int run_cigar(int ridx, uint32_t part, uint32_t nparts) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         err = 0;
@@ -284,18 +288,40 @@ struct KA {
         if (have_ref) {
             const uint32_t* cg = p.cigar + cig_off;
             const int64_t ctg_len = p.ctg_len[tid];
+            uint32_t* const qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx;
             uint32_t carry_q = 0, carry_r = 0;
-            for (uint32_t i0 = 0; i0 < ncig; i0 += 512) {
+            const uint32_t op_lo = (uint32_t)(((uint64_t)ncig * part) / nparts) & ~63u;   // chunk starts on a 64-op boundary
+            const uint32_t op_hi = part + 1u >= nparts ? ncig : ((uint32_t)(((uint64_t)ncig * (part + 1u)) / nparts) & ~63u);
+            {   // carries of the chunk: sums over ops [0, op_lo)
+                uint32_t sq = 0, sr = 0;
+                for (uint32_t i0 = 0; i0 < op_lo; i0 += 512) {
+                    uint32_t wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        uint32_t i = i0 + 64u * u + lane;
+                        wv[u] = i < op_lo ? cg[i] : 0x6u;   // pad op (consumes nothing)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        uint32_t op = wv[u] & 15u, len = wv[u] >> 4;
+                        sq += ((0x193u >> op) & 1u) ? len : 0u;
+                        sr += ((0x18Du >> op) & 1u) ? len : 0u;
+                    }
+                }
+                carry_q = lane_valu(wave_incl_scan(sq), 63);
+                carry_r = lane_valu(wave_incl_scan(sr), 63);
+            }
+            for (uint32_t i0 = op_lo; i0 < op_hi; i0 += 512) {
                 uint32_t wv[8];   // eight loads in flight
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     uint32_t i = i0 + 64u * u + lane;
-                    wv[u] = i < ncig ? cg[i] : 0u;
+                    wv[u] = i < op_hi ? cg[i] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     uint32_t i = i0 + 64u * u + lane;
-                    bool act = i < ncig;
+                    bool act = i < op_hi;
                     uint32_t w = wv[u], op = w & 15u, len = w >> 4;
                     uint32_t qinc = (act && ((0x193u >> op) & 1u)) ? len : 0u;
                     uint32_t rinc = (act && ((0x18Du >> op) & 1u)) ? len : 0u;
@@ -314,10 +340,24 @@ struct KA {
                     if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > L) err = err ? err : MM_E_QOVER;
                     if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
                     if (act) { P.g_cq[cig_off + i] = qs; P.g_cr[cig_off + i] = (rs & 0x0FFFFFFFu) | (op << 28); }
+                    {   // coarse directory: the op that holds every read position that is a multiple of 256.  Most ops
+                        // cross no multiple or one (written by their own lane); the few long ones (soft clips, long
+                        // matches) are filled by the whole wave so that one lane never loops alone.
+                        uint32_t k_lo = (qs + 255u) >> 8, k_hi = (act && qinc) ? (qs + qinc - 1u) >> 8 : 0u;
+                        bool any = act && qinc && k_lo <= k_hi;
+                        if (any) qdir[k_lo] = i;
+                        uint64_t more = __ballot(any && k_hi > k_lo);
+                        while (more) {
+                            int l = __ffsll((unsigned long long)more) - 1;
+                            uint32_t a = lane_valu(k_lo, l) + 1u, b = lane_valu(k_hi, l), idx = lane_valu(i, l);
+                            for (uint32_t k = a + (uint32_t)lane; k <= b; k += 64u) qdir[k] = idx;
+                            more &= more - 1ull;
+                        }
+                    }
                     carry_q += qtot; carry_r += rtot;
                 }
             }
-            if (lane == 0) P.g_qtot[ridx] = carry_q;
+            if (lane == 0 && part + 1u >= nparts) P.g_qtot[ridx] = carry_q;
             result = any_err();
         }
         return result;
@@ -354,6 +394,7 @@ struct KA {
         uint32_t nb = 0;
         if (cls >= 0) {
             const uint4* sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
+            uint32_t* const rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
             uint32_t carry = 0;
             for (uint32_t b0 = 0; b0 < nblk; b0 += 512) {
                 uint4 vv[8];
@@ -381,7 +422,12 @@ struct KA {
                         }
                     }
                     uint32_t incl = wave_incl_scan(cnt);
-                    if (b < nblk) P.g_dir[dir_off + b] = carry + incl - cnt;
+                    if (b < nblk) {
+                        uint32_t ex = carry + incl - cnt;
+                        P.g_dir[dir_off + b] = ex;
+                        uint32_t k = (ex + 63u) >> 6;          // a 32-base block holds at most one multiple of 64 ranks
+                        if ((k << 6) < ex + cnt) rdir[k] = b;
+                    }
                     carry += lane_valu(incl, 63);
                 }
             }
@@ -501,10 +547,11 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         const int kind = r / n, ri = r - kind * n;
         uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
         item = uniu(item);
-        if ((item >> 24) & 15u) continue;   // plans made for the fused kernel split long reads into parts: one visit per read here
+        const uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
+        if (kind != 0 && part != 0u) continue;   // a long read's parts split its CIGAR scan; the other kinds visit a read once
         int ridx = (int)(item & 0xFFFFFFu);
         int e = 0;
-        if (kind == 0) e = k.run_cigar(ridx);
+        if (kind == 0) e = k.run_cigar(ridx, part, nparts);
         else if (kind == 1) e = k.run_mm(ridx, (uint32_t)ri % kTileRegions);
         else e = k.run_dir(ridx);
         e = uni(e);
@@ -589,6 +636,8 @@ struct KC {
     const uint32_t* gq;
     const uint32_t* gr;
     const uint32_t* gd;
+    const uint32_t* qdir;
+    const uint32_t* rdir;
     int64_t ref_base, seg_begin, seg_len, cnt_base;
     uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
@@ -596,6 +645,7 @@ struct KC {
     // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
     // CIGAR ops [cs_lo, cs_lo+cs_cnt) answer read positions in [cs_q_lo, cs_q_hi)
     uint32_t ds_lo, ds_cnt, ds_rr_lo, ds_rr_hi, cs_lo, cs_cnt, cs_q_lo, cs_q_hi;
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};   // diagnostic builds: time per phase, flushed once per wave
 
     __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
 
@@ -620,28 +670,41 @@ struct KC {
         i1 = lo1; i2 = lo2;
     }
 
-    // stage the directory blocks that cover ranks [rr_a, rr_b] (rr_a <= rr_b < nb) in LDS
+    // stage the directory blocks that cover ranks [rr_a, rr_b] (rr_a <= rr_b < nb) in LDS; the block bounds come from
+    // the coarse directory the prepass left (block of every 64th rank): one load instead of a search
     __device__ void setup_dir_slice(uint32_t rr_a, uint32_t rr_b, uint32_t& b1, uint32_t& b2) {
         const uint32_t lane = (uint32_t)lane_id();
-        coop_find2(gd, nblk, rr_a, rr_b, b1, b2);
+        const uint32_t ka = rr_a >> 6, kb = (rr_b >> 6) + 1u;
+        b1 = rdir[ka];
+        b2 = kb <= ((nb - 1u) >> 6) ? rdir[kb] : nblk - 1u;
         uint32_t cnt = b2 - b1 + 1u;
         ds_cnt = 0;
         if (cnt <= kSliceD) {
-            for (uint32_t j = lane; j < cnt; j += 64u) S.ds[j] = gd[b1 + j];
+            uint32_t v[kSliceD / 64];
+#pragma unroll
+            for (uint32_t j = 0; j < kSliceD / 64; j++) { uint32_t i = lane + 64u * j; v[j] = i < cnt ? gd[b1 + i] : 0u; }
+#pragma unroll
+            for (uint32_t j = 0; j < kSliceD / 64; j++) { uint32_t i = lane + 64u * j; if (i < cnt) S.ds[i] = v[j]; }
             wave_sync();
             ds_lo = b1; ds_cnt = cnt;
             ds_rr_lo = rr_a; ds_rr_hi = rr_b + 1u;   // every rank in [rr_a, rr_b] lies in blocks b1..b2
         }
     }
-    // stage the CIGAR ops that cover read positions [q_a, q_b] (q_a <= q_b < q_total) in LDS
+    // stage the CIGAR ops that cover read positions [q_a, q_b] (q_a <= q_b < q_total) in LDS (bounds: op of every
+    // 256th read position, from the prepass)
     __device__ void setup_cig_slice(uint32_t q_a, uint32_t q_b) {
         const uint32_t lane = (uint32_t)lane_id();
-        uint32_t i1, i2;
-        coop_find2(gq, ncig, q_a, q_b, i1, i2);
+        const uint32_t ka = q_a >> 8, kb = (q_b >> 8) + 1u;
+        uint32_t i1 = qdir[ka];
+        uint32_t i2 = kb <= ((q_total - 1u) >> 8) ? qdir[kb] : ncig - 1u;
         uint32_t cnt = i2 - i1 + 1u;
         cs_cnt = 0;
         if (cnt <= kSliceC) {
-            for (uint32_t j = lane; j < cnt; j += 64u) { S.csq[j] = gq[i1 + j]; S.csr[j] = gr[i1 + j]; }
+            uint32_t vq[kSliceC / 64], vr[kSliceC / 64];
+#pragma unroll
+            for (uint32_t j = 0; j < kSliceC / 64; j++) { uint32_t i = lane + 64u * j; vq[j] = i < cnt ? gq[i1 + i] : 0u; vr[j] = i < cnt ? gr[i1 + i] : 0u; }
+#pragma unroll
+            for (uint32_t j = 0; j < kSliceC / 64; j++) { uint32_t i = lane + 64u * j; if (i < cnt) { S.csq[i] = vq[j]; S.csr[i] = vr[j]; } }
             wave_sync();
             cs_lo = i1; cs_cnt = cnt;
             cs_q_lo = q_a; cs_q_hi = q_b + 1u;
@@ -860,6 +923,7 @@ struct KC {
     __device__ __forceinline__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23, const uint2* rsum) {
         const int lane = lane_id();
         err = 0;
+        KAT_DECL;
         const int ridx = (int)t.ridx;
         const mm_read_t& rd = p.reads[ridx];
         tid = uni(rd.tid); pos = uni(rd.pos);
@@ -869,6 +933,7 @@ struct KC {
         seq = p.seq + rd.seq_off; ml = p.ml + rd.ml_off;
         const uint8_t* mm = p.mm + rd.mm_off;
         gq = P.g_cq + rd.cigar_off; gr = P.g_cr + rd.cigar_off; gd = P.g_dir + (rd.seq_off >> 4);
+        qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx; rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
         nblk = (L + 31u) >> 5;
         q_total = P.g_qtot[ridx];
         nb = P.g_nb[ridx];
@@ -893,6 +958,7 @@ struct KC {
         const uint32_t k_carry0 = lane_valu(wave_incl_scan(a_k), 63);
         const uint32_t rank_carry0 = lane_valu(wave_incl_scan(a_r), 63);
         ds_cnt = 0; cs_cnt = 0;
+        KAT_LAP(8);
         const uint32_t fl = t.flags;
         const bool tail = fl & 2u, dot = fl & 4u;
         direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
@@ -928,6 +994,7 @@ struct KC {
                 else prev_delim = sp.last_char == ',';
             }
             wave_sync();
+            KAT_LAP(9);
             // skip counts -> ranks, in place (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
             uint32_t carry = rank_carry0;
 #pragma unroll 1
@@ -952,11 +1019,13 @@ struct KC {
                         uint32_t rr_a = rev ? nb - 1u - r_last : r_first, rr_b = rev ? nb - 1u - r_first : r_last;
                         uint32_t b1, b2;
                         setup_dir_slice(rr_a, rr_b, b1, b2);
+                        KAT_LAP(10);
                         qa = 32u * b1; qb = min(L - 1u, 32u * b2 + 31u);
                     }
                     if (q_total > 0 && qa < q_total) setup_cig_slice(qa, min(qb, q_total - 1u));
                 }
             }
+            KAT_LAP(11);
 #pragma unroll 1
             for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
                 uint32_t ti = t64 + lane;
@@ -992,6 +1061,7 @@ struct KC {
                 }
             }
         }
+        KAT_LAP(12);
         uint64_t eb = __ballot(err != 0);
         int l = eb ? __ffsll((unsigned long long)eb) - 1 : 0;
         int e = lane_val(err, l);
@@ -1039,6 +1109,9 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
         }
     }
     if (p.stats) k.flush_stats(g & (kStatSlots - 1));
+#ifdef MM_PHASE_TIMING
+    if (lane_id() == 0 && p.stats) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, k.tacc[i]);
+#endif
 }
 
 }  // namespace mmhip
