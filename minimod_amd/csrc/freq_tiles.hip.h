@@ -38,7 +38,7 @@ struct TileRec {  // 32 bytes
     uint32_t cpos;         // list tile: offset of its first character in the MM string; tail tile: its index j in the group's tail
     uint32_t read_first;   // index (inside the region) of the read's first tile
     uint32_t group_first;  // index of the group's first tile
-    uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, 8-10 cls, 12-14 n_codes
+    uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, bit6 no requested code, 8-10 cls, 12-14 n_codes
     int16_t g_code[4];
     uint32_t rsvd;
 };
@@ -495,9 +495,10 @@ struct KA {
                 bad = __ballot(err != 0) != 0;
                 int mb = rev ? complement_char(g.modbase) : g.modbase;
                 bool direct = g.modbase == 'N', dot = g.flag == '.';
-                uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) |
-                                  ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
                 int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
+                const bool unwanted = gc0 < 0 && gc1 < 0 && gc2 < 0 && gc3 < 0;   // none of the group's codes was asked for with -c
+                uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) | (unwanted ? 64u : 0u) |
+                                  ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
                 uint32_t endp = find_semicolon(mm, mlen, g.lstart);
                 uint32_t nlist = (endp - g.lstart) / kTileChars + 1u;
                 uint32_t ntail = dot ? L / kTailRanks + 1u : 0u;
@@ -551,10 +552,16 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         if (kind != 0 && part != 0u) continue;   // a long read's parts split its CIGAR scan; the other kinds visit a read once
         int ridx = (int)(item & 0xFFFFFFu);
         int e = 0;
+#ifdef MM_PHASE_TIMING
+        unsigned long long kt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (kind == 0) e = k.run_cigar(ridx, part, nparts);
         else if (kind == 1) e = k.run_mm(ridx, (uint32_t)ri % kTileRegions);
         else e = k.run_dir(ridx);
         e = uni(e);
+#ifdef MM_PHASE_TIMING
+        if (lane_id() == 0 && p.stats) { unsigned long long dt = __builtin_amdgcn_s_memrealtime() - kt0; atomicMax(p.stats + 4 + kind, dt); atomicAdd(p.stats + 7, 1ull); }
+#endif
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
             atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
@@ -959,6 +966,20 @@ struct KC {
         const uint32_t rank_carry0 = lane_valu(wave_incl_scan(a_r), 63);
         ds_cnt = 0; cs_cnt = 0;
         KAT_LAP(8);
+        if (t.flags & 64u) {
+            // No code of this group was requested: every call would be discarded (mod.c:1157).  The only thing the
+            // reference still does with such a group is assert its read positions (mod.c:1116): the last listed rank
+            // must exist.  (Its tokens still count towards ML indices: that is k_sum_tiles' job.)
+            if (!(t.flags & 2u)) {
+                uint2 own = rsum[t.index];
+                if ((own.x & 0xFFFFu) != 0u) {
+                    uint32_t r_last = rank_carry0 + own.y - 1u;
+                    if (r_last >= (((t.flags >> 3) & 1u) ? L : nb)) err = MM_E_READPOS;
+                }
+            }
+            uint64_t eb0 = __ballot(err != 0);
+            return eb0 ? MM_E_READPOS : 0;
+        }
         const uint32_t fl = t.flags;
         const bool tail = fl & 2u, dot = fl & 4u;
         direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
