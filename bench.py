@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
     ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
+    ap.add_argument("--streams", type=int, default=1, help="1: every launch on one explicit stream; >1: the library's per-slot streams (up to 4 batches overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
     return ap.parse_args()
@@ -168,11 +169,11 @@ def main():
     eng.stats_enable(False)
     eng.reset()
 
-    def run_steps(n, first_step=0):
+    def run_steps(n, first_step=0, use_stream=stream):
         tickets, bases, kms, abytes = [], 0, [], 0
         for s in range(n):
             bi = (first_step + s) % n_batches
-            t = eng.submit_device(dev_batches[bi], stream)
+            t = eng.submit_device(dev_batches[bi], use_stream)
             tickets.append((t, bi))
             bases += batch_bases[bi]
             abytes += alg_bytes[bi]
@@ -211,7 +212,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    bases, kms, abytes = run_steps(args.steps, first_step=args.warmup)
+    bases, kms, abytes = run_steps(args.steps, first_step=args.warmup, use_stream=stream if args.streams <= 1 else None)
     exchange_halos(rank, world, export_fn, add_fn, make_buf, dist)
     torch.cuda.synchronize()
     if world > 1:
@@ -227,6 +228,17 @@ def main():
         total_bases = int(tb.item())
     else:
         total_bases = bases
+
+    # extra, outside the contract's timed region: the same steps with the library's per-slot streams, i.e. up to three
+    # batches in flight as the CLI's load/process overlap gives (kernels of consecutive batches overlap on the device)
+    overlap = None
+    if world == 1 and args.streams <= 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ob, _, _ = run_steps(args.steps, first_step=args.warmup, use_stream=None)
+        torch.cuda.synchronize()
+        overlap = {"value": ob / (time.perf_counter() - t1) / 1e6, "unit": "Mbases/s",
+                   "note": "same steps on the library's per-slot streams (3 batches in flight); not the contract's timed region"}
 
     result = None
     if rank == 0:
@@ -257,6 +269,8 @@ def main():
                          "bytes_per_base": abytes / max(bases, 1)},
             "gen_seconds": t_gen,
         }
+        if overlap:
+            result["overlapped_streams"] = overlap
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, host_batches, plan, ref)
         if args.verify:
