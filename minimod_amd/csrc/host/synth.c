@@ -335,3 +335,132 @@ int mm_batch_make_order(mm_host_batch_t *hb) {
 }
 
 void mm_synth_reference(uint64_t seed, int64_t len, uint8_t *out) { mm_synth_reference_slice(seed, 0, len, out); }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BAM / FASTA writers: any flattened host batch as a real BGZF-compressed BAM (64 KB blocks + EOF marker), so the
+ * same synthetic reads can be fed to the CLI (and to real htslib tools).  Filter fodder is interleaved: every 97th
+ * record is followed by an unmapped copy, every 89th by a secondary copy, every 83rd by a copy without MM/ML --
+ * load_db (reference src/minimod.c:260-284) must drop all three.
+ * ------------------------------------------------------------------------------------------------------------ */
+#include <stdio.h>
+#include <zlib.h>
+
+typedef struct { FILE *fp; uint8_t *buf; size_t n; } bgzf_w;
+static int bgzf_flush_block(bgzf_w *w, const uint8_t *data, size_t len) {
+    uint8_t out[65536 + 1024];
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return -1;
+    zs.next_in = (Bytef *)data; zs.avail_in = (uInt)len;
+    zs.next_out = out + 18; zs.avail_out = sizeof(out) - 18 - 8;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); return -1; }
+    size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    static const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    memcpy(out, hdr, 16);
+    size_t total = 18 + clen + 8;
+    out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
+    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len), isz = (uint32_t)len;
+    memcpy(out + 18 + clen, &crc, 4); memcpy(out + 18 + clen + 4, &isz, 4);
+    return fwrite(out, 1, total, w->fp) == total ? 0 : -1;
+}
+static int bgzf_put(bgzf_w *w, const void *data, size_t len) {
+    const uint8_t *p = (const uint8_t *)data;
+    while (len) {
+        size_t room = 0xFF00 - w->n, k = len < room ? len : room;
+        memcpy(w->buf + w->n, p, k);
+        w->n += k; p += k; len -= k;
+        if (w->n == 0xFF00) { if (bgzf_flush_block(w, w->buf, w->n)) return -1; w->n = 0; }
+    }
+    return 0;
+}
+
+static int put_record(bgzf_w *w, const mm_batch_t *b, int32_t i, int variant, uint64_t serial) {
+    const mm_read_t *rd = &b->reads[i];
+    char qname[40];
+    int lq = snprintf(qname, sizeof qname, "synth_%010llu", (unsigned long long)serial) + 1;
+    uint32_t n_cigar = variant == 1 ? 0 : rd->n_cigar;   /* variant 1 = unmapped */
+    uint16_t flag = rd->flag;
+    if (variant == 1) flag |= 0x4;
+    if (variant == 2) flag |= 0x100;
+    int with_mm = variant != 3;
+    uint32_t l_seq = rd->l_qseq;
+    size_t aux = 0;
+    if (with_mm) aux += 3 + rd->mm_len + 1 + 4 + 4 + rd->ml_len;
+    if (rd->hp) aux += 4;
+    uint32_t block = 32 + (uint32_t)lq + 4 * n_cigar + (l_seq + 1) / 2 + l_seq + (uint32_t)aux;
+    uint8_t fixed[36];
+    int32_t refid = variant == 1 ? -1 : rd->tid, pos = variant == 1 ? -1 : rd->pos, m1 = -1, zero = 0;
+    uint32_t bin_mq_nl = ((uint32_t)4680 << 16) | (60u << 8) | (uint32_t)lq;
+    uint32_t flag_nc = ((uint32_t)flag << 16) | n_cigar;
+    memcpy(fixed, &block, 4); memcpy(fixed + 4, &refid, 4); memcpy(fixed + 8, &pos, 4); memcpy(fixed + 12, &bin_mq_nl, 4);
+    memcpy(fixed + 16, &flag_nc, 4); memcpy(fixed + 20, &l_seq, 4); memcpy(fixed + 24, &m1, 4); memcpy(fixed + 28, &m1, 4);
+    memcpy(fixed + 32, &zero, 4);
+    if (bgzf_put(w, fixed, 36) || bgzf_put(w, qname, (size_t)lq)) return -1;
+    if (n_cigar && bgzf_put(w, b->cigar + rd->cigar_off, 4 * (size_t)n_cigar)) return -1;
+    if (bgzf_put(w, b->seq + rd->seq_off, (l_seq + 1) / 2)) return -1;
+    {
+        uint8_t q[4096];
+        memset(q, 0xFF, sizeof q);
+        for (uint32_t left = l_seq; left;) { uint32_t k = left < sizeof q ? left : (uint32_t)sizeof q; if (bgzf_put(w, q, k)) return -1; left -= k; }
+    }
+    if (with_mm) {
+        uint8_t t[8] = {'M', 'M', 'Z'};
+        if (bgzf_put(w, t, 3) || bgzf_put(w, b->mm + rd->mm_off, rd->mm_len) || bgzf_put(w, "", 1)) return -1;
+        uint8_t t2[8] = {'M', 'L', 'B', 'C'};
+        memcpy(t2 + 4, &rd->ml_len, 4);
+        if (bgzf_put(w, t2, 8) || (rd->ml_len && bgzf_put(w, b->ml + rd->ml_off, rd->ml_len))) return -1;
+    }
+    if (rd->hp) { uint8_t t3[4] = {'H', 'P', 'C', rd->hp}; if (bgzf_put(w, t3, 4)) return -1; }
+    return 0;
+}
+
+typedef struct mm_bam_writer { bgzf_w w; uint64_t serial; } mm_bam_writer_t;
+
+mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens) {
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return NULL;
+    mm_bam_writer_t *bw = (mm_bam_writer_t *)calloc(1, sizeof(*bw));
+    bw->w.fp = fp; bw->w.buf = (uint8_t *)malloc(0x10000);
+    char text[256];
+    int lt = snprintf(text, sizeof text, "@HD\tVN:1.6\tSO:coordinate\n");
+    bgzf_put(&bw->w, "BAM\1", 4);
+    int32_t l_text = lt;
+    bgzf_put(&bw->w, &l_text, 4); bgzf_put(&bw->w, text, (size_t)lt);
+    bgzf_put(&bw->w, &n_contigs, 4);
+    for (int32_t i = 0; i < n_contigs; i++) {
+        int32_t ln = (int32_t)strlen(names[i]) + 1, ll = (int32_t)lens[i];
+        bgzf_put(&bw->w, &ln, 4); bgzf_put(&bw->w, names[i], (size_t)ln); bgzf_put(&bw->w, &ll, 4);
+    }
+    return bw;
+}
+int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_filter_fodder) {
+    for (int32_t i = 0; i < b->n_reads; i++) {
+        if (put_record(&bw->w, b, i, 0, bw->serial)) return -1;
+        if (with_filter_fodder) {
+            if (bw->serial % 97 == 5 && put_record(&bw->w, b, i, 1, bw->serial)) return -1;
+            if (bw->serial % 89 == 7 && put_record(&bw->w, b, i, 2, bw->serial)) return -1;
+            if (bw->serial % 83 == 11 && put_record(&bw->w, b, i, 3, bw->serial)) return -1;
+        }
+        bw->serial++;
+    }
+    return 0;
+}
+int mm_bam_writer_close(mm_bam_writer_t *bw) {
+    int r = 0;
+    if (bw->w.n) r |= bgzf_flush_block(&bw->w, bw->w.buf, bw->w.n);
+    r |= bgzf_flush_block(&bw->w, bw->w.buf, 0);   /* the 28-byte EOF marker: an empty block */
+    r |= fclose(bw->w.fp);
+    free(bw->w.buf); free(bw);
+    return r;
+}
+int mm_write_fasta(const char *path, const char *name, const uint8_t *seq, int64_t len) {
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    fprintf(fp, ">%s synthetic\n", name);
+    for (int64_t i = 0; i < len; i += 80) {
+        int64_t k = len - i < 80 ? len - i : 80;
+        fwrite(seq + i, 1, (size_t)k, fp); fputc('\n', fp);
+    }
+    return fclose(fp);
+}

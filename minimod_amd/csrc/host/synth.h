@@ -42,6 +42,13 @@ int mm_synth_batch(const mm_synth_opts_t *o, const uint8_t *ref, int64_t first_r
 void mm_synth_batch_free(mm_host_batch_t *b);
 int mm_batch_make_order(mm_host_batch_t *b);
 
+/* any flattened host batch as a BGZF-compressed BAM; optional filter fodder (unmapped / secondary / tag-less copies) */
+typedef struct mm_bam_writer mm_bam_writer_t;
+mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens);
+int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_filter_fodder);
+int mm_bam_writer_close(mm_bam_writer_t *bw);
+int mm_write_fasta(const char *path, const char *name, const uint8_t *seq, int64_t len);
+
 #ifdef __cplusplus
 }
 #endif

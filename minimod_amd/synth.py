@@ -36,6 +36,11 @@ def host_lib():
                                      ctypes.POINTER(mm_host_batch_t)]
         L.mm_synth_batch_free.argtypes = [ctypes.POINTER(mm_host_batch_t)]
         L.mm_batch_make_order.argtypes = [ctypes.POINTER(mm_host_batch_t)]
+        L.mm_bam_writer_open.restype = ctypes.c_void_p
+        L.mm_bam_writer_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64)]
+        L.mm_bam_writer_put_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(mm_batch_t), ctypes.c_int]
+        L.mm_bam_writer_close.argtypes = [ctypes.c_void_p]
+        L.mm_write_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]
         _lib = L
     return _lib
 
@@ -92,3 +97,26 @@ def batch(ref, first_read, n_reads, seed=0x5EED, contig_len=None, n_reads_total=
     }
     host_lib().mm_synth_batch_free(ctypes.byref(hb))
     return out
+
+
+def write_bam(path, contigs, batches, filter_fodder=True):
+    """Write numpy batches (dicts as returned by batch()) as one coordinate-sorted BGZF BAM.  contigs: [(name, length)]."""
+    from .engine import batch_struct
+    L = host_lib()
+    names = (ctypes.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
+    lens = (ctypes.c_int64 * len(contigs))(*[int(l) for _, l in contigs])
+    w = L.mm_bam_writer_open(path.encode(), len(contigs), names, lens)
+    if not w:
+        raise IOError("cannot create %s" % path)
+    for b in batches:
+        bs = batch_struct(b)
+        if L.mm_bam_writer_put_batch(w, ctypes.byref(bs), int(filter_fodder)):
+            raise IOError("write failed")
+    if L.mm_bam_writer_close(w):
+        raise IOError("close failed")
+
+
+def write_fasta(path, name, seq):
+    seq = np.ascontiguousarray(seq)
+    if host_lib().mm_write_fasta(path.encode(), name.encode(), seq.ctypes.data, len(seq)):
+        raise IOError("cannot write %s" % path)

@@ -97,3 +97,25 @@ def test_cli_missing_args_and_version():
     assert r.returncode == 0 and b"Usage: minimod freq ref.fa reads.bam" in r.stdout
     r = subprocess.run([BIN, "--version"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout.startswith(b"minimod ")
+
+
+def test_cli_on_synthetic_bam_matches_oracle(tmp_path):
+    """20 Mbases of synthetic ONT-shape reads as a real BGZF BAM + FASTA through the CLI (-K 512, several batches,
+    filter fodder in the file): bedmethyl byte-identical to the oracle's."""
+    from minimod_amd import synth
+    from oracle import oracle as O
+    ref = synth.reference(13, 4 << 20)
+    bs = [synth.batch(ref, i * 350, 350, seed=3, n_reads_total=1400) for i in range(4)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    r = subprocess.run([BIN, "freq", "-b", "-c", "m[CG]", "-m", "0.8", "-K", "512", "-B", "100M", "-t", "4", fa, bam],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    for b in bs:
+        orc.process(b, threads=4)
+    want = O.format_rows(orc.rows(), ["chrS"], orc.code_names(), bedmethyl=True)
+    assert len(want) > 100000 and r.stdout.decode() == want
+    assert b"total processed entries: 1400" in r.stderr
