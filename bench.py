@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
     ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
     ap.add_argument("--streams", type=int, default=1, help="1: every launch on one explicit stream; >1: the library's per-slot streams (up to 4 batches overlap)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra overlapped-streams measurement (use when profiling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
     return ap.parse_args()
@@ -232,7 +233,7 @@ def main():
     # extra, outside the contract's timed region: the same steps with the library's per-slot streams, i.e. up to three
     # batches in flight as the CLI's load/process overlap gives (kernels of consecutive batches overlap on the device)
     overlap = None
-    if world == 1 and args.streams <= 1:
+    if world == 1 and args.streams <= 1 and not args.no_extra:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ob, _, _ = run_steps(args.steps, first_step=args.warmup, use_stream=None)

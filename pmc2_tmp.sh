@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 25 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --no-cpu-baseline --no-extra --steps 25 --warmup 2 > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv,glob,collections,json

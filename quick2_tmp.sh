@@ -1,6 +1,6 @@
 bash quick_tmp.sh
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_q -- python3 bench.py --no-cpu-baseline --steps 25 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_q -- python3 bench.py --no-cpu-baseline --no-extra --steps 25 --warmup 2 > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob
 f=sorted(glob.glob('gpurun_out/prof_q/*/*kernel_trace.csv'))[-1]
