@@ -153,12 +153,14 @@ __device__ __forceinline__ SubParse parse_sub(const uint8_t* mb8, int base, bool
     r.tstart = in && x != ',' && pdel;
     r.v = 0;
     r.err = 0;
-    if (r.tstart) {
-        bool open = true;
+    {
+        // decimal fold over the look-ahead window; the loop ends as soon as every token of the sub-chunk has met its
+        // delimiter (skip counts are mostly one to three digits), at most 10 characters (mod.c:1074-1081)
+        bool open = r.tstart;
         int len = 0;
-#pragma unroll
-        for (int j = 0; j < 10; j++) {          // at most 9 digits (mod.c:1074-1081)
-            int d = mb8[base + lane + j];
+#pragma unroll 1
+        for (int j = 0; j < 10 && __ballot(open); j++) {
+            int d = open ? (int)mb8[base + lane + j] : ',';
             bool delim = d == ',' || d == ';';
             open = open && !delim;
             if (open) {
