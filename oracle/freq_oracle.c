@@ -42,6 +42,13 @@ typedef struct {
     uint32_t n_called, n_mod;
 } orc_row_t;
 
+/* one row of `minimod view` (add_view_entry, mod.c:931-946; print_view_output, mod.c:560-626) */
+typedef struct {
+    int64_t read;     /* running index of the read over all processed batches */
+    int32_t tid, pos, strand, code, ins_off, hp, read_pos;
+    uint32_t prob;    /* ML byte, 0 for implicit calls */
+} orc_view_row_t;
+
 enum {
     ORC_OK = 0, ORC_E_HARDCLIP = 1, ORC_E_CIGAROP = 2, ORC_E_MMBASE = 3, ORC_E_MMSTRAND = 4,
     ORC_E_MMCODE = 5, ORC_E_MMEMPTY = 6, ORC_E_MMMIXED = 7, ORC_E_SKIPLEN = 8, ORC_E_SKIPVAL = 9,
@@ -83,6 +90,9 @@ typedef struct {
     map_t global;
     int err;
     int64_t err_read;
+    int view;                 /* 1: collect view rows instead of counting */
+    orc_view_row_t *vrows;
+    int64_t n_vrows, cap_vrows, reads_seen;
 } orc_t;
 
 /* ------------------------------------------------------------------ counter table */
@@ -302,9 +312,15 @@ typedef struct {
 
 /* one candidate call (explicit or implicit): filters + threshold + count.
  * mod.c:1140-1197 (explicit) and mod.c:1242-1284,1322-1364 (implicit). */
+typedef struct { orc_view_row_t *v; int64_t n, cap; } vbuf_t;
+static void vbuf_push(vbuf_t *b, orc_view_row_t r) {
+    if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 1024; b->v = (orc_view_row_t *)realloc(b->v, sizeof(orc_view_row_t) * b->cap); }
+    b->v[b->n++] = r;
+}
+
 static inline int emit_call(orc_t *o, map_t *m, const orc_read_t *rd, const contig_t *c, const group_codes_t *g,
                             int mb, int read_base, int ref_pos, int ins_off, int hp, int rev,
-                            int explicit_call, int call_idx, int ml_start, const uint8_t *ml) {
+                            int explicit_call, int call_idx, int ml_start, const uint8_t *ml, vbuf_t *vb, int fq_pos) {
     for (int k = 0; k < g->n; k++) {
         int req = g->req[k];
         if (req < 0) continue;
@@ -313,6 +329,19 @@ static inline int emit_call(orc_t *o, map_t *m, const orc_read_t *rd, const cont
         int matches = all_ctx || mb == 'N' || c->fwd[ref_pos] == read_base;
         if (!o->insertions && !(in_ctx && matches)) continue;
         int is_mod = 0;
+        if (o->view) {   /* mod.c:1194-1196, :1281-1283: no threshold, probability 0 for implicit calls */
+            uint32_t prob = 0;
+            if (explicit_call) {
+                int64_t ml_idx = (int64_t)ml_start + (int64_t)call_idx * g->n + k;
+                if (ml_idx >= (int64_t)rd->ml_len) return ORC_E_MLIDX;
+                prob = ml[ml_idx];
+            }
+            orc_view_row_t r;
+            r.read = 0; r.tid = rd->tid; r.pos = ref_pos; r.strand = rev; r.code = g->cid[k]; r.ins_off = ins_off; r.hp = hp;
+            r.read_pos = fq_pos; r.prob = prob;
+            vbuf_push(vb, r);
+            continue;
+        }
         if (explicit_call) {
             int64_t ml_idx = (int64_t)ml_start + (int64_t)call_idx * g->n + k;
             if (ml_idx >= (int64_t)rd->ml_len) return ORC_E_MLIDX;
@@ -329,7 +358,7 @@ static inline int emit_call(orc_t *o, map_t *m, const orc_read_t *rd, const cont
 
 /* freq_view_single (mod.c:948-1370) for one read */
 static int process_read(orc_t *o, map_t *m, const orc_read_t *rd, const uint32_t *cigar_pool,
-                        const uint8_t *seq_pool, const uint8_t *mm_pool, const uint8_t *ml_pool, scratch_t *s) {
+                        const uint8_t *seq_pool, const uint8_t *mm_pool, const uint8_t *ml_pool, scratch_t *s, vbuf_t *vb) {
     const uint32_t *cigar = cigar_pool + rd->cigar_off;
     const uint8_t *seq = seq_pool + rd->seq_off;
     const char *mm = (const char *)(mm_pool + rd->mm_off);
@@ -408,7 +437,7 @@ static int process_read(orc_t *o, map_t *m, const orc_read_t *rd, const uint32_t
             if (o->insertions && ref_pos == -1) ref_pos = s->ins[fq];
             if (ref_pos == -1) continue;
             int ins_off = o->insertions ? s->ins_off[fq] : 0;
-            e = emit_call(o, m, rd, c, &g, mb, read_base, ref_pos, ins_off, hp, rev, 1, cidx, ml_start, ml);
+            e = emit_call(o, m, rd, c, &g, mb, read_base, ref_pos, ins_off, hp, rev, 1, cidx, ml_start, ml, vb, fq);
             if (e) return e;
         }
         if (ns > 0) ml_start += ns * g.n; /* mod.c:1200 */
@@ -433,7 +462,7 @@ static int process_read(orc_t *o, map_t *m, const orc_read_t *rd, const uint32_t
                     if (o->insertions && ref_pos == -1) ref_pos = s->ins[read_pos];
                     if (ref_pos == -1) continue;
                     int ins_off = o->insertions ? s->ins_off[fq] : 0;
-                    e = emit_call(o, m, rd, c, &g, mb, read_base, ref_pos, ins_off, hp, rev, 0, 0, 0, ml);
+                    e = emit_call(o, m, rd, c, &g, mb, read_base, ref_pos, ins_off, hp, rev, 0, 0, 0, ml, vb, fq);
                     if (e) return e;
                 }
                 prev = hi;
@@ -449,16 +478,44 @@ typedef struct {
     orc_t *o; const orc_read_t *reads; int lo, hi;
     const uint32_t *cigar; const uint8_t *seq, *mm, *ml;
     map_t map; int err; int64_t err_read;
+    vbuf_t rows;   /* view mode: this thread's rows, reads in order */
 } job_t;
+
+static int vrow_cmp(const void *a, const void *b) {
+    const orc_view_row_t *x = (const orc_view_row_t *)a, *y = (const orc_view_row_t *)b;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    if (x->strand != y->strand) return x->strand - y->strand;
+    if (x->code != y->code) return x->code - y->code;
+    if ((x->ins_off & 0xFFFF) != (y->ins_off & 0xFFFF)) return (x->ins_off & 0xFFFF) - (y->ins_off & 0xFFFF);
+    if (x->hp != y->hp) return x->hp - y->hp;
+    return x->read < y->read ? -1 : (x->read > y->read);   /* `read` holds the emission order here */
+}
 
 static void *worker(void *arg) {
     job_t *j = (job_t *)arg;
     scratch_t s; memset(&s, 0, sizeof(s));
     map_init(&j->map, 1 << 12);
+    vbuf_t vb = {0};
     for (int i = j->lo; i < j->hi; i++) {
-        int e = process_read(j->o, &j->map, &j->reads[i], j->cigar, j->seq, j->mm, j->ml, &s);
+        vb.n = 0;
+        int e = process_read(j->o, &j->map, &j->reads[i], j->cigar, j->seq, j->mm, j->ml, &s, &vb);
         if (e) { j->err = e; j->err_read = i; break; }
+        if (j->o->view && vb.n) {
+            /* per read: sort by key, keep the first entry of every key (add_view_entry), rows by position */
+            for (int64_t k = 0; k < vb.n; k++) vb.v[k].read = k;
+            qsort(vb.v, (size_t)vb.n, sizeof(orc_view_row_t), vrow_cmp);
+            for (int64_t k = 0; k < vb.n; k++) {
+                if (k > 0) {
+                    const orc_view_row_t *a = &vb.v[k - 1], *b = &vb.v[k];
+                    if (a->pos == b->pos && a->strand == b->strand && a->code == b->code && (a->ins_off & 0xFFFF) == (b->ins_off & 0xFFFF) && a->hp == b->hp) continue;
+                }
+                orc_view_row_t r = vb.v[k];
+                r.read = i;
+                vbuf_push(&j->rows, r);
+            }
+        }
     }
+    free(vb.v);
     scratch_free(&s);
     return NULL;
 }
@@ -479,14 +536,28 @@ int orc_process(void *h, const orc_read_t *reads, int n, const uint32_t *cigar, 
     for (int t = 0; t < n_threads; t++) {
         if (n_threads > 1) pthread_join(th[t], NULL);
         if (jobs[t].err && !err) { err = jobs[t].err; o->err = err; o->err_read = jobs[t].err_read; }
+        if (o->view) {
+            for (int64_t k = 0; k < jobs[t].rows.n; k++) {
+                if (o->n_vrows == o->cap_vrows) { o->cap_vrows = o->cap_vrows ? o->cap_vrows * 2 : 4096; o->vrows = (orc_view_row_t *)realloc(o->vrows, sizeof(orc_view_row_t) * o->cap_vrows); }
+                orc_view_row_t r = jobs[t].rows.v[k];
+                r.read += o->reads_seen;
+                o->vrows[o->n_vrows++] = r;
+            }
+            free(jobs[t].rows.v);
+        }
         map_t *m = &jobs[t].map;
         for (uint64_t i = 0; i < m->cap; i++)
             if (m->s[i].k1) map_add(&o->global, m->s[i].k0, m->s[i].k1, m->s[i].n_called, m->s[i].n_mod);
         free(m->s);
     }
     free(jobs); free(th);
+    o->reads_seen += n;
     return err;
 }
+
+void orc_set_view(void *h, int on) { ((orc_t *)h)->view = on; }
+int64_t orc_n_view_rows(void *h) { return ((orc_t *)h)->n_vrows; }
+void orc_view_rows(void *h, orc_view_row_t *out) { orc_t *o = (orc_t *)h; memcpy(out, o->vrows, sizeof(orc_view_row_t) * (size_t)o->n_vrows); }
 
 int64_t orc_error_read(void *h) { return ((orc_t *)h)->err_read; }
 int64_t orc_n_rows(void *h) { return (int64_t)((orc_t *)h)->global.n; }
@@ -535,7 +606,7 @@ void orc_destroy(void *h) {
         free(c->name); free(c->fwd);
         for (int i = 0; i < o->n_mods; i++) { free(c->ctx[i]); free(c->ctx_rev[i]); }
     }
-    free(o->contigs); free(o->global.s);
+    free(o->contigs); free(o->global.s); free(o->vrows);
     pthread_mutex_destroy(&o->code_mu);
     free(o);
 }

@@ -20,6 +20,9 @@ LIB = os.path.join(BUILD, "libfreq_oracle.so")
 ROW_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("strand", "<i4"), ("code", "<i4"),
                       ("ins_off", "<i4"), ("hp", "<i4"), ("n_called", "<u4"), ("n_mod", "<u4")])
 
+VIEW_DTYPE = np.dtype([("read", "<i8"), ("tid", "<i4"), ("pos", "<i4"), ("strand", "<i4"), ("code", "<i4"),
+                       ("ins_off", "<i4"), ("hp", "<i4"), ("read_pos", "<i4"), ("prob", "<u4")])
+
 ERRORS = {1: "hard clip", 2: "unhandled cigar op", 3: "invalid MM base", 4: "invalid MM strand",
           5: "invalid mod code char", 6: "empty mod codes", 7: "mixed mod codes", 8: "skip count too long",
           9: "bad skip count", 10: "read pos out of range", 11: "ML index overrun", 12: "contig not in reference",
@@ -60,6 +63,10 @@ def lib():
         L.orc_code_name.restype = ctypes.c_char_p
         L.orc_code_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_set_view.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_n_view_rows.restype = ctypes.c_int64
+        L.orc_n_view_rows.argtypes = [ctypes.c_void_p]
+        L.orc_view_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -173,6 +180,16 @@ class Oracle(object):
             lib().orc_rows(self.h, out.ctypes.data)
         return out
 
+    def set_view(self, on=True):
+        lib().orc_set_view(self.h, int(on))
+
+    def view_rows(self):
+        n = lib().orc_n_view_rows(self.h)
+        out = np.zeros(n, dtype=VIEW_DTYPE)
+        if n:
+            lib().orc_view_rows(self.h, out.ctypes.data)
+        return out
+
     def code_names(self):
         return [lib().orc_code_name(self.h, i).decode() for i in range(lib().orc_n_codes(self.h))]
 
@@ -221,6 +238,54 @@ def format_rows(rows, names, code_names, bedmethyl=False, insertions=False, hapl
                 line += "\t*" if r["hp"] < 0 else "\t%d" % int(r["hp"])
             out.append(line + "\n")
     return "".join(out)
+
+
+def format_view(rows, qnames, names, code_names, insertions=False, haplotypes=False, header=True):
+    """print_view_header + print_view_output, src/mod.c:545-626.  qnames: read names by running read index."""
+    out = []
+    if header:
+        h = "ref_contig\tref_pos\tstrand\tread_id\tread_pos\tmod_code\tmod_prob"
+        if insertions:
+            h += "\tins_offset"
+        if haplotypes:
+            h += "\thaplotype"
+        out.append(h + "\n")
+    for r in rows:
+        q = qnames[int(r["read"])]
+        q = q.decode() if isinstance(q, bytes) else q
+        line = "%s\t%d\t%s\t%s\t%d\t%s\t%s" % (names[r["tid"]], int(r["pos"]), "-" if r["strand"] else "+", q,
+                                                int(r["read_pos"]), code_names[r["code"]],
+                                                _f6((int(r["prob"]) + 0.5) / 256.0))
+        if insertions:
+            line += "\t%d" % int(r["ins_off"])
+        if haplotypes:
+            line += "\t%d" % int(r["hp"])
+        out.append(line + "\n")
+    return "".join(out)
+
+
+def view(bam_path, contigs, c="m", insertions=False, haplotypes=False, allow_secondary=False,
+         skip_supplementary=False, threads=1, K=512, B=20 * 1000 * 1000):
+    """End-to-end `minimod view` on the oracle: returns (rows, qnames, names, code_names)."""
+    mods = parse_mod_codes(c)
+    th = parse_mod_threshes(None, len(mods))
+    orc = None
+    qnames = []
+    for bam, batch, _st in pybam.load_batches(bam_path, K=K, B=B, allow_secondary=allow_secondary,
+                                             skip_supplementary=skip_supplementary):
+        if orc is None:
+            orc = Oracle(mods, th, bam.target_name, insertions, haplotypes)
+            orc.set_view(True)
+            for name, seq in contigs.items():
+                if name in bam.target_name:
+                    orc.add_contig(name, seq)
+        if len(batch["reads"]):
+            orc.process(batch, threads)
+            qnames += batch["qnames"]
+    rows = orc.view_rows()
+    names, codes = orc.names, orc.code_names()
+    orc.close()
+    return rows, qnames, names, codes
 
 
 def pseudo_reference(npz_path):

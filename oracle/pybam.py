@@ -206,6 +206,7 @@ def flatten(records):
         "seq": cat(seq_parts, "u1", tail),
         "mm": cat(mm_parts, "u1", tail),
         "ml": cat(ml_parts, "u1", tail),
+        "qnames": [r.qname for r in records],
     }
 
 

@@ -22,6 +22,22 @@ GOLDEN_CASES = [
     ("test16.tsv", "eb.bam", "chr1", dict(c="e,b", m="0.5"), False),
 ]
 
+# the reference's own view tests, reference test/test.sh:66-111,186-247 (Test 1,2,2a,2b,2c_wild,2c,10,11,15,17a).
+# `exact`: one code requested, so a read cannot tie on (contig,pos) and the bytes must match; the others compare as
+# the reference's tests do (after sorting both sides, test/test.sh:69-70).
+VIEW_CASES = [
+    ("test1.tsv", "example-hifi.bam", "chr22", dict(c="m[CG]"), True),
+    ("test2.tsv", "example-ont.bam", "chr22", dict(c="m[CG]"), True),
+    ("test2a.tsv", "example-ont.bam", "chr22", dict(c="m[CG]", insertions=True), True),
+    ("test2b.tsv", "example-ont.bam", "chr22", dict(c="m[*]"), True),
+    ("test2c_wild.tsv", "example-ont.bam", "chr22", dict(c="*"), False),
+    ("test2c.tsv", "hap.bam", "chr1", dict(c="m[CG]", haplotypes=True), True),
+    ("test10.tsv", "example-ont.bam", "chr22", dict(c="m"), True),
+    ("test11.tsv", "example-ont.bam", "chr22", dict(c="m,h"), False),
+    ("test15.tsv", "eb.bam", "chr1", dict(c="e,b"), False),
+    ("test17a.tsv", "dRNA.bam", "chr22", dict(c="17802[*]"), True),
+]
+
 # known-answer reads, SURVEY.md section 8(c) KAT / KAT2
 KAT_REF = "AACGTTCGACCGGTACGATCGTTAACGCGA"
 KAT_SEQ = "CGTTCGACCGGTACGATCGT"

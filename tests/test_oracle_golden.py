@@ -6,7 +6,7 @@ import pytest
 
 from oracle import oracle as O
 from oracle import pybam
-from tests.cases import GOLDEN, GOLDEN_CASES, KAT2_INS, KAT_M, KAT_REF, kat2_records, kat_records
+from tests.cases import GOLDEN, GOLDEN_CASES, VIEW_CASES, KAT2_INS, KAT_M, KAT_REF, KAT_SEQ, kat2_records, kat_records
 
 
 @pytest.mark.parametrize("exp,bam,ctg,kw,exact", GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
@@ -20,6 +20,39 @@ def test_reference_golden(exp, bam, ctg, kw, exact, request):
         assert txt == want
     else:
         assert sorted(txt.splitlines()) == sorted(want.splitlines())
+
+
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", VIEW_CASES, ids=["view-" + c[0] for c in VIEW_CASES])
+def test_reference_view_golden(exp, bam, ctg, kw, exact, request):
+    contigs = request.getfixturevalue(ctg)
+    rows, qnames, names, codes = O.view(os.path.join(GOLDEN, "data", bam), contigs, **kw)
+    txt = O.format_view(rows, qnames, names, codes, insertions=kw.get("insertions", False),
+                        haplotypes=kw.get("haplotypes", False))
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    if exact:
+        assert txt == want
+    else:
+        assert sorted(txt.splitlines()) == sorted(want.splitlines())
+
+
+def test_view_batch_invariance(chr22):
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    a = O.view(bam, chr22, c="m,h", insertions=True, haplotypes=True, K=7)[0]
+    b = O.view(bam, chr22, c="m,h", insertions=True, haplotypes=True, K=4096, threads=3)[0]
+    assert (a == b).all()
+
+
+def test_view_first_entry_wins_and_implicit_prob_zero():
+    """add_view_entry keeps the first entry of a key (mod.c:931-946); '.'-mode implicit calls carry probability 0."""
+    recs = [pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+m.,1;C+m?,1;", [255, 7], qname=b"dup")]
+    mods = O.parse_mod_codes("m")
+    o = O.Oracle(mods, O.parse_mod_threshes(None, 1), ["chrT"])
+    o.set_view(True)
+    o.add_contig("chrT", KAT_REF.encode())
+    o.process(pybam.flatten(recs))
+    got = [(int(r["pos"]), int(r["read_pos"]), int(r["prob"])) for r in o.view_rows()]
+    # C at read 0,4,7,8,13,17 ; CG context at 0,4,8,13,17 ; listed C (rank 1) is read 4 -> prob 255, once
+    assert got == [(2, 0, 0), (6, 4, 255), (10, 8, 0), (15, 13, 0), (19, 17, 0)]
 
 
 def _run(recs, c, **kw):
