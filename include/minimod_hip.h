@@ -14,6 +14,12 @@
  *   output_core -> print_freq_output           src/minimod.c:388-394, src/mod.c:644-728        -> mm_freq_finalize
  *   destroy_ref / free_core                    src/ref.c:241-259, src/minimod.c:140-161        -> mm_freq_destroy
  *
+ * `minimod view` (src/view_main.c) runs the same per-read function with core->opt.subtool == VIEW: a handle created with
+ * opts.view = 1 collects per-read rows instead of counters:
+ *
+ *   add_view_entry                              src/mod.c:931-946 (called at :1195, :1282, :1362)   -> the call kernels
+ *   print_view_output (per batch)               src/mod.c:560-626                                  -> mm_view_fetch
+ *
  * Everything is plain C: pointers, sizes, POD structs.  No torch / HIP types appear in signatures (a HIP
  * stream is passed as void*).  Errors: the reference prints and exit(1)s from inside the hot path
  * (src/error.h:98-152); here every entry point returns a code and the caller (minimod_amd/csrc/host) prints
@@ -29,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 #define MM_MAX_MODS 13    /* requested -c entries (2 context bits each + 5 base bits in one 32-bit ref word) */
 #define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
 #define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
@@ -93,7 +99,7 @@ typedef struct mm_freq_opts {
     int32_t n_hp_planes;     /* dense planes for HP 0..n-1 (others go to the sparse side list); 0 = default */
     int64_t side_capacity;   /* sparse side-list records (16 B each); 0 = default */
     int32_t n_wild_planes;   /* with -c '*': dense planes for the first n interned codes; 0 = default */
-    int32_t rsvd;
+    int32_t view;            /* 1 = `minimod view`: per-read rows (mm_view_fetch) instead of counters (mm_freq_finalize) */
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
 
@@ -128,6 +134,19 @@ typedef struct mm_row {
     uint32_t n_mod;
 } mm_row_t;
 
+/* One row of `minimod view` = one entry of a read's view map (view_t + its key, src/mod.c:931-946) in the order
+ * print_view_output prints it (src/mod.c:560-626): reads in batch order, a read's rows by reference position; rows of
+ * one read on one position -- which the reference leaves in hash order -- by (code, ins_offset).  Strand, contig,
+ * haplotype and read name are per-read values the caller already holds (reads[row.read]).  16 bytes. */
+typedef struct mm_view_row {
+    uint32_t read;         /* index of the read in the batch */
+    int32_t pos;           /* ref_pos */
+    uint32_t read_pos;     /* position in the read as sequenced (view_t.read_pos) */
+    uint16_t ins_offset;   /* 0 unless --insertions */
+    uint8_t code;          /* index for mm_freq_code_name */
+    uint8_t prob;          /* ML byte (view_t.mod_prob); 0 for the implicit calls of a '.' group */
+} mm_view_row_t;
+
 /* per-read status codes (0 = ok); the reference's message for each is in INTEGRATION.md */
 enum {
     MM_OK = 0, MM_E_HARDCLIP = 1, MM_E_CIGAROP = 2, MM_E_MMBASE = 3, MM_E_MMSTRAND = 4, MM_E_MMCODE = 5,
@@ -154,6 +173,14 @@ int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *h
 
 /* Wait for a ticket.  Returns 0, or the first failing read's MM_E_* code with its batch index in *bad_read. */
 int32_t mm_freq_wait(mm_freq_t *h, int32_t ticket, int32_t *bad_read);
+
+/* View mode: wait for a ticket, order the batch's rows on the device and hand them over -- as a host array
+ * (mm_view_fetch) or left in device memory (mm_view_fetch_device).  Returns the row count, or -MM_E_* with the failing
+ * read's batch index in *bad_read.  The rows stay valid until the ticket's slot is used by a later submit (four
+ * submits later).  A batch submitted with mm_freq_submit_device must stay resident until it has been fetched: when a
+ * batch produces more rows than the record buffer was sized for, fetch grows the buffer and runs the batch again. */
+int64_t mm_view_fetch(mm_freq_t *h, int32_t ticket, const mm_view_row_t **rows, int32_t *bad_read);
+int64_t mm_view_fetch_device(mm_freq_t *h, int32_t ticket, const void **dev_rows, int32_t *bad_read);
 
 /* Plan a batch: writes work items (read index | part << 24 | (parts-1) << 28) for reads[0..n), long reads split into
  * up to 16 parts, costliest first.  Returns the number of items (<= cap) or -MM_E_ARG when cap is too small

@@ -18,6 +18,7 @@
 
 #include "freq_kernels.hip.h"
 #include "freq_tiles.hip.h"
+#include "view_kernels.hip.h"
 #include "minimod_hip.h"
 
 using namespace mmhip;
@@ -53,6 +54,25 @@ struct Slot {
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
     std::vector<int32_t> plan;   // host copy of the work items while the upload is in flight
+    // view mode: regional record buffers filled by the call kernels, then the ordering pipeline's buffers
+    unsigned long long* d_vkeys = nullptr; size_t cap_vkeys = 0;
+    unsigned long long* d_vvals = nullptr; size_t cap_vvals = 0;
+    unsigned int* d_vcount = nullptr;      // [kViewRegions * kViewCountStride] + [1] selected rows
+    unsigned int* h_vcount = nullptr;      // pinned copy
+    unsigned int view_cap = 0;             // records per region
+    unsigned long long* d_ka = nullptr; size_t cap_ka = 0;
+    unsigned long long* d_kb = nullptr; size_t cap_kb = 0;
+    unsigned long long* d_va = nullptr; size_t cap_va = 0;
+    unsigned long long* d_vb = nullptr; size_t cap_vb = 0;
+    ViewRow* d_vrows = nullptr; size_t cap_vrows = 0;
+    ViewRow* d_vout = nullptr; size_t cap_vout = 0;
+    uint8_t* d_vkeep = nullptr; size_t cap_vkeep = 0;
+    void* d_vtmp = nullptr; size_t cap_vtmp = 0;
+    ViewRow* h_vrows = nullptr; size_t cap_hrows = 0;   // pinned
+    mm_batch_t last_batch;       // device-side batch of the ticket (view mode may have to run it again)
+    hipStream_t last_stream = nullptr;
+    int64_t view_rows = -1;      // rows of the ticket once ordered (-1 = not yet)
+    bool view_on_host = false;   // ... and copied to h_vrows
 };
 
 }  // namespace
@@ -175,6 +195,20 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     if (r) return r;
     p.spill = s.d_spill; p.spill_cig = spill_cig; p.spill_blk = spill_blk;
     p.status = s.d_status;
+    if (h->opts.view) {
+        // every explicit row consumes one ML byte, so the ML pool bounds them; implicit rows ('.' groups) are not bounded
+        // by anything cheap: mm_view_fetch grows the buffer and runs the batch again when a region overflows
+        size_t want = (size_t)(b->n_ml_bytes / kViewRegions) * 3 / 2 + 4096;
+        if (const char* ev = std::getenv("MM_VIEW_CAP")) want = (size_t)std::max(1, std::atoi(ev));   // tests: force the overflow path
+        if (want > s.view_cap) {
+            if ((r = grow(h, (void**)&s.d_vkeys, &s.cap_vkeys, 8 * want * kViewRegions)) ||
+                (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)))
+                return r;
+            s.view_cap = (unsigned int)std::min<size_t>(std::min(s.cap_vkeys, s.cap_vvals) / (8 * kViewRegions), 0xFFFFFFFFu / kViewRegions);
+        }
+        p.view = 1; p.view_cap = s.view_cap; p.view_keys = s.d_vkeys; p.view_vals = s.d_vvals; p.view_count = s.d_vcount;
+        HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1), st));
+    }
     p.queue = s.d_ctl; p.err_summary = s.d_ctl + 1;
     TileParams tp;
     std::memset(&tp, 0, sizeof(tp));
@@ -211,24 +245,34 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             if (h->wide) {
                 hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
                 hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
-                hipLaunchKernelGGL(k_call_tiles<uint32_t>, dim3(gc), dim3(256), 0, st, tp);
+                if (p.view) hipLaunchKernelGGL((k_call_tiles<uint32_t, true>), dim3(gc), dim3(256), 0, st, tp);
+                else hipLaunchKernelGGL((k_call_tiles<uint32_t, false>), dim3(gc), dim3(256), 0, st, tp);
             } else {
                 hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
                 hipLaunchKernelGGL(k_sum_tiles<uint16_t>, dim3(gs), dim3(256), 0, st, tp);
-                hipLaunchKernelGGL(k_call_tiles<uint16_t>, dim3(gc), dim3(256), 0, st, tp);
+                if (p.view) hipLaunchKernelGGL((k_call_tiles<uint16_t, true>), dim3(gc), dim3(256), 0, st, tp);
+                else hipLaunchKernelGGL((k_call_tiles<uint16_t, false>), dim3(gc), dim3(256), 0, st, tp);
             }
             HIPCHK(hipGetLastError());
             // reads the tile form does not cover: the fused kernel over the fallback list (usually empty)
             p.order = s.d_fb; p.n_items = 0; p.n_items_dev = s.d_ctl + 4; p.queue = s.d_ctl + 5;
         }
-        if (h->wide) hipLaunchKernelGGL(k_freq_reads<uint32_t>, dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_freq_reads<uint16_t>, dim3(blocks), dim3(256), 0, st, p);
+        if (h->wide) {
+            if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, st, p);
+        } else {
+            if (p.view) hipLaunchKernelGGL((k_freq_reads<uint16_t, true>), dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, st, p);
+        }
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
     HIPCHK(hipMemcpyAsync(s.h_ctl + 80, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    if (h->opts.view)
+        HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * kViewRegions * kViewCountStride, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s.ev_done, st));
     s.busy = true; s.timed = true; s.n_reads = b->n_reads;
+    s.last_batch = *b; s.last_stream = st; s.view_rows = -1; s.view_on_host = false;
     return 0;
 }
 
@@ -267,7 +311,7 @@ const char* mm_strerror(int32_t code) {
         case MM_E_ARG: return "invalid argument";
         case MM_E_HIP: return "HIP runtime error";
         case MM_E_NOMEM: return "out of device memory";
-        case MM_E_TOOMANY: return "too many modification codes";
+        case MM_E_TOOMANY: return "too many modification codes (or, in view mode, more than 2048 MM groups in one read)";
         case MM_E_NOCODE: return "modification code not interned";
         default: return "unknown error";
     }
@@ -283,9 +327,12 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl,
-                      s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_tiles, s.d_fb};
+                      s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_tiles, s.d_fb,
+                      s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_kb, s.d_va, s.d_vb, s.d_vrows, s.d_vout, s.d_vkeep, s.d_vtmp};
         for (void* p : ps) if (p) (void)hipFree(p);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
+        if (s.h_vcount) (void)hipHostFree(s.h_vcount);
+        if (s.h_vrows) (void)hipHostFree(s.h_vrows);
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows};
@@ -318,16 +365,16 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     {
         int nb = 0;
         hipError_t e = h->wide
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint32_t>, 256, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t>, 256, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint32_t, false>, 256, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t, false>, 256, 0);
         h->blocks_per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
         int na = 0, nc = 0;
         if (h->wide) {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint32_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false>, 256, 0);
         } else {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint16_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false>, 256, 0);
         }
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
@@ -340,6 +387,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
         if (dev_alloc(h, (void**)&s.d_ctl, 128 * sizeof(unsigned int))) return fail(h, "alloc failed");
         if (hipHostMalloc((void**)&s.h_ctl, 160 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        if (opts->view) {
+            if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1))) return fail(h, "alloc failed");
+            if (hipHostMalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1), hipHostMallocDefault) != hipSuccess)
+                return fail(h, "pinned alloc failed");
+        }
     }
     // ---- mods / codes
     std::vector<DevMod> mods(opts->n_mods);
@@ -380,7 +432,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
     }
     h->n_hp = opts->haplotypes ? (opts->n_hp_planes > 0 ? std::min(opts->n_hp_planes, MM_MAX_HP_PLANES) : 4) : 1;
-    h->side_cap = opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20);
+    h->side_cap = opts->view ? 16 : (opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20));
     if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_side, sizeof(SideRec) * (size_t)h->side_cap)) return fail(h, "side list alloc failed");
@@ -472,7 +524,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
     }
     // counters
-    h->n_counter_words = (int64_t)h->n_code_planes * h->n_hp * 2 * plane_len;
+    h->n_counter_words = opts->view ? 0 : (int64_t)h->n_code_planes * h->n_hp * 2 * plane_len;   // view keeps no counters
     if (dev_alloc(h, (void**)&h->d_counters, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)))
         return fail(h, "counter plane alloc failed");
     if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)) != hipSuccess)
@@ -634,7 +686,7 @@ void mm_freq_reset_counters(mm_freq_t* h) {
 }
 
 int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
-    if (!h) return -MM_E_ARG;
+    if (!h || h->opts.view) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     std::vector<mm_row_t>& rows = h->rows;
@@ -757,6 +809,104 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     rows.swap(merged);
     if (out_rows) *out_rows = rows.data();
     return (int64_t)rows.size();
+}
+
+// ---------------------------------------------------------------------------------- view rows
+// print_view_output (src/mod.c:560-626) up to the fprintf: wait, order the records on the device, hand the rows over.
+static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool to_host) {
+    if (!h || !h->opts.view || ticket < 0 || ticket >= kSlots) return -MM_E_ARG;
+    Slot& s = h->slots[ticket];
+    HIPCHK(hipSetDevice(h->device));
+    if (!s.timed) return -MM_E_ARG;
+    hipStream_t st = s.last_stream;
+    auto copy_out = [&](size_t nsel) -> int {
+        if (!to_host || s.view_on_host || nsel == 0) return 0;
+        if (nsel > s.cap_hrows) {
+            if (s.h_vrows) (void)hipHostFree(s.h_vrows);
+            s.h_vrows = nullptr; s.cap_hrows = 0;
+            size_t cap = nsel + nsel / 4 + 4096;
+            if (hipHostMalloc((void**)&s.h_vrows, sizeof(ViewRow) * cap, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
+            s.cap_hrows = cap;
+        }
+        HIPCHK(hipMemcpyAsync(s.h_vrows, s.d_vout, sizeof(ViewRow) * nsel, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        s.view_on_host = true;
+        return 0;
+    };
+    if (s.view_rows >= 0) {   // already ordered (fetch after fetch_device, or twice)
+        int r = copy_out((size_t)s.view_rows);
+        return r ? r : s.view_rows;
+    }
+    unsigned long long n = 0;
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(hipEventSynchronize(s.ev_done));
+        s.busy = false;
+        unsigned int sum = s.h_ctl[81];
+        if (sum != 0xFFFFFFFFu) {
+            if (bad_read) *bad_read = (int32_t)(sum >> 8);
+            return -(int64_t)(sum & 0xFFu);
+        }
+        unsigned int worst = 0;
+        n = 0;
+        for (uint32_t r = 0; r < kViewRegions; r++) { unsigned int c = s.h_vcount[r * kViewCountStride]; worst = std::max(worst, c); n += c; }
+        if (worst <= s.view_cap) break;
+        if (attempt >= 2) return -MM_E_NOMEM;   // a deterministic re-run cannot overflow twice
+        // a region overflowed: size every region for the fullest one (+25 %) and run the batch again
+        size_t want = (size_t)worst + worst / 4 + 1024;
+        int r;
+        if ((r = grow(h, (void**)&s.d_vkeys, &s.cap_vkeys, 8 * want * kViewRegions)) ||
+            (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)))
+            return r;
+        s.view_cap = (unsigned int)std::min<size_t>(std::min(s.cap_vkeys, s.cap_vvals) / (8 * kViewRegions), 0xFFFFFFFFu / kViewRegions);
+        mm_batch_t again = s.last_batch;
+        if ((r = launch_k1(h, s, &again, st))) return r;
+    }
+    if (n >= (1ull << 32)) return -MM_E_TOOMANY;
+    s.view_rows = 0;
+    if (n == 0) return 0;
+    int r;
+    if ((r = grow(h, (void**)&s.d_ka, &s.cap_ka, 8 * (size_t)n)) || (r = grow(h, (void**)&s.d_kb, &s.cap_kb, 8 * (size_t)n)) ||
+        (r = grow(h, (void**)&s.d_va, &s.cap_va, 8 * (size_t)n)) || (r = grow(h, (void**)&s.d_vb, &s.cap_vb, 8 * (size_t)n)) ||
+        (r = grow(h, (void**)&s.d_vrows, &s.cap_vrows, sizeof(ViewRow) * (size_t)n)) ||
+        (r = grow(h, (void**)&s.d_vout, &s.cap_vout, sizeof(ViewRow) * (size_t)n)) ||
+        (r = grow(h, (void**)&s.d_vkeep, &s.cap_vkeep, (size_t)n)))
+        return r;
+    unsigned int rbits = 1;
+    while ((1u << rbits) <= (unsigned int)std::max(s.n_reads, 1)) rbits++;
+    const unsigned int key_bits = 28 + rbits;
+    size_t tmp_sort = 0, tmp_sel = 0;
+    uint4* rows_in = reinterpret_cast<uint4*>(s.d_vrows);
+    uint4* rows_out = reinterpret_cast<uint4*>(s.d_vout);
+    unsigned int* d_nsel = s.d_vcount + kViewRegions * kViewCountStride;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_sort, s.d_ka, s.d_kb, s.d_va, s.d_vb, (size_t)n, 0u, key_bits, st));
+    HIPCHK(rocprim::select(nullptr, tmp_sel, rows_in, s.d_vkeep, rows_out, d_nsel, (size_t)n, st));
+    if ((r = grow(h, &s.d_vtmp, &s.cap_vtmp, std::max(tmp_sort, tmp_sel)))) return r;
+    const int blocks = (int)std::min<unsigned long long>((n + 255) / 256, (unsigned long long)h->n_cu * 16);
+    hipLaunchKernelGGL(k_view_pack, dim3(blocks), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount, s.view_cap, s.d_ka, s.d_va);
+    HIPCHK(hipGetLastError());
+    HIPCHK(rocprim::radix_sort_pairs(s.d_vtmp, tmp_sort, s.d_ka, s.d_kb, s.d_va, s.d_vb, (size_t)n, 0u, key_bits, st));
+    hipLaunchKernelGGL(k_view_rows, dim3(blocks), dim3(256), 0, st, s.d_kb, s.d_vb, n, key_bits, s.last_batch.reads, s.d_vrows, s.d_vkeep);
+    HIPCHK(hipGetLastError());
+    HIPCHK(rocprim::select(s.d_vtmp, tmp_sel, rows_in, s.d_vkeep, rows_out, d_nsel, (size_t)n, st));
+    HIPCHK(hipMemcpyAsync(s.h_vcount + kViewRegions * kViewCountStride, d_nsel, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t nsel = s.h_vcount[kViewRegions * kViewCountStride];
+    s.view_rows = (int64_t)nsel;
+    if ((r = copy_out(nsel))) return r;
+    return (int64_t)nsel;
+}
+
+static_assert(sizeof(mm_view_row_t) == sizeof(ViewRow), "mm_view_row_t layout");
+
+int64_t mm_view_fetch(mm_freq_t* h, int32_t ticket, const mm_view_row_t** rows, int32_t* bad_read) {
+    int64_t n = view_finish(h, ticket, bad_read, true);
+    if (n >= 0 && rows) *rows = reinterpret_cast<const mm_view_row_t*>(h->slots[ticket].h_vrows);
+    return n;
+}
+int64_t mm_view_fetch_device(mm_freq_t* h, int32_t ticket, const void** dev_rows, int32_t* bad_read) {
+    int64_t n = view_finish(h, ticket, bad_read, false);
+    if (n >= 0 && dev_rows) *dev_rows = h->slots[ticket].d_vout;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------- halo slabs

@@ -106,7 +106,18 @@ struct DevParams {
     unsigned int* queue;
     uint32_t* spill;               // per wave slot: [max_cig] q, [max_cig] r, [max_blk] dir
     uint32_t spill_cig, spill_blk;
+    // `minimod view` (add_view_entry, mod.c:931-946): every call that passes the context test becomes a 16-byte record
+    // instead of a counter update.  Records are appended to kViewRegions independent regions (one append counter each,
+    // 128 bytes apart: a single counter would serialise every wave of the launch on one address).
+    int32_t view;
+    unsigned int view_cap;           // records per region
+    unsigned long long* view_keys;   // [kViewRegions][view_cap]  prob << 56 | read << 28 | (ref_pos - read.pos + 1)
+    unsigned long long* view_vals;   // [kViewRegions][view_cap]  code << 56 | ins_offset << 40 | group << 29 | implicit << 28 | fastq read_pos
+    unsigned int* view_count;        // [kViewRegions * kViewCountStride]; counts past view_cap mean "grow and run again"
 };
+constexpr uint32_t kViewRegions = 64;
+constexpr uint32_t kViewCountStride = 32;
+constexpr uint32_t kViewMaxGroup = 2047;   // group ordinals that fit the record; a read with more MM groups fails loudly
 
 // ---------------------------------------------------------------------------------- wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -127,6 +138,26 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Append one view record per active lane (called under divergence: the ballot is the set of lanes with a record).
+// The value orders the records of one (read, position): by key (code, ins_offset), then in the order the reference
+// would have met them -- MM group, listed calls before implicit ones, rising position in the read as sequenced -- so
+// that the smallest value of a key is the entry add_view_entry keeps.
+__device__ __forceinline__ void view_append(const DevParams& p, uint32_t region, uint32_t ridx, uint32_t rel_pos, uint32_t fq_pos,
+                                            uint32_t ins_off, uint32_t code, uint32_t group, uint32_t implicit, uint32_t prob) {
+    uint64_t m = __ballot(1);
+    int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned int base = 0;
+    if (lane_id() == leader) base = atomicAdd(p.view_count + region * kViewCountStride, (unsigned int)__popcll(m));
+    base = __shfl(base, leader, 64);
+    unsigned int idx = base + (unsigned int)__popcll(m & lanemask_lt());
+    if (idx < p.view_cap) {
+        size_t at = (size_t)region * p.view_cap + idx;
+        p.view_keys[at] = ((unsigned long long)prob << 56) | ((unsigned long long)ridx << 28) | (unsigned long long)rel_pos;
+        p.view_vals[at] = ((unsigned long long)code << 56) | ((unsigned long long)(ins_off & 0xFFFFu) << 40) |
+                          ((unsigned long long)group << 29) | ((unsigned long long)implicit << 28) | (unsigned long long)fq_pos;
+    }
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // value of lane `l` (wave-uniform l) as a wave-uniform scalar
@@ -249,9 +280,10 @@ struct ReadCtx {
     // current MM group
     int32_t cls, direct, mb_is_N, n_codes_grp;
     uint32_t nb, ml_start;
+    uint32_t ridx, gord, vregion;   // view mode: read index, ordinal of the current MM group, append region
 };
 
-template <typename RefWord>
+template <typename RefWord, bool kView>
 struct K1 {
     const DevParams& p;
     WaveLds& S;
@@ -521,9 +553,18 @@ struct K1 {
                     if (ml_idx >= c.ml_len) { err = MM_E_MLIDX; break; }  // mod.c:1174
                     int mv = m == 0 ? (int)ml0[u] : (int)c.ml[ml_idx];
                     st_ml++;
+                    if (kView) {                              // mod.c:1194-1196: no threshold, the ML byte itself
+                        view_append(p, c.vregion, c.ridx, (uint32_t)(ref_pos[u] - c.pos + 1), c.rev ? c.L - 1u - q[u] : q[u], ins_off[u],
+                                    (uint32_t)ci, c.gord, 0u, (uint32_t)mv);
+                        continue;
+                    }
                     if (mv >= dm.t_hi) is_mod = 1;            // mod.c:1184
                     else if (mv <= dm.t_lo) is_mod = 0;        // mod.c:1187
                     else continue;                             // ambiguous
+                } else if (kView) {                           // mod.c:1281-1283, :1361-1363: implicit calls carry 0
+                    view_append(p, c.vregion, c.ridx, (uint32_t)(ref_pos[u] - c.pos + 1), c.rev ? c.L - 1u - q[u] : q[u], ins_off[u],
+                                (uint32_t)ci, c.gord, 1u, 0u);
+                    continue;
                 }
                 int64_t off = ref_pos[u] - c.seg_begin;
                 if (ins_off[u] == 0 && dc.plane >= 0 && c.hpi >= 0 && off >= 0 && off < c.seg_len) {
@@ -684,6 +725,7 @@ struct K1 {
         MMT_LAP(4);
         result = any_err();
         c.cls = -1; c.nb = 0; c.ml_start = 0;
+        c.ridx = (uint32_t)ridx; c.gord = 0xFFFFFFFFu; c.vregion = (uint32_t)wave_slot % kViewRegions;
         if (result == 0) {
         // Control flow below is kept wave-uniform and free of `break`: every exit condition is folded into
         // `bad` (a ballot over the lanes' err), which the loop headers test.  (A version with divergent-looking
@@ -694,6 +736,7 @@ struct K1 {
         const uint32_t own_hi = part + 1u >= nparts ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)mlen * (part + 1u)) / nparts);
         while (mpos < mlen && !bad) {
             // ---------------- a6 group header (mod.c:1003-1062)
+            c.gord++;
             uint32_t ci = mpos + lane;
             int ch = ci < mlen ? (int)mm[ci] : 0;
             int c0 = lane_val(ch, 0), c1 = lane_val(ch, 1);
@@ -718,6 +761,7 @@ struct K1 {
             if (!herr && (e == 64 || ncode >= MM_CODE_LEN)) herr = MM_E_MMCODE;
             if (!herr && n <= 0) herr = MM_E_MMEMPTY;                                // mod.c:1053
             if (!herr && has_nums && has_alpha) herr = MM_E_MMMIXED;                 // mod.c:1054
+            if (!herr && kView && c.gord > kViewMaxGroup) herr = MM_E_TOOMANY;
             herr = uni(herr);
             if (herr) {
                 err = herr;
@@ -870,12 +914,12 @@ struct K1 {
     }
 };
 
-template <typename RefWord>
+template <typename RefWord, bool kView>
 __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     __shared__ WaveLds lds[kWavesPerBlock];
     const int wv = threadIdx.x >> 6;
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
-    K1<RefWord> k(p, lds[wv]);
+    K1<RefWord, kView> k(p, lds[wv]);
     if (p.n_items_dev && *p.n_items_dev == 0u) return;   // empty fallback list: do not even touch the work counter
     for (;;) {
         int r = 0;

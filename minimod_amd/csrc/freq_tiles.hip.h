@@ -40,7 +40,7 @@ struct TileRec {  // 32 bytes
     uint32_t group_first;  // index of the group's first tile
     uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, bit6 no requested code, 8-10 cls, 12-14 n_codes
     int16_t g_code[4];
-    uint32_t rsvd;
+    uint32_t gord;         // ordinal of the MM group in the read (view mode: which of two entries with one key came first)
 };
 static_assert(sizeof(TileRec) == 32, "TileRec must be 32 bytes");
 
@@ -489,11 +489,12 @@ struct KA {
         }
         // pass 2: the tile records (no text is parsed here beyond the headers)
         if (have_ref && !irregular) {
-            uint32_t mpos = 0;
+            uint32_t mpos = 0, gord = 0;
             bool bad = false;
             while (mpos < mlen && !bad) {
                 GroupHdr g = parse_header(mm, mlen, mpos);
                 lookup_codes(g);
+                if (p.view && gord > kViewMaxGroup) err = MM_E_TOOMANY;
                 bad = __ballot(err != 0) != 0;
                 int mb = rev ? complement_char(g.modbase) : g.modbase;
                 bool direct = g.modbase == 'N', dot = g.flag == '.';
@@ -517,12 +518,13 @@ struct KA {
                             t.read_first = tbase; t.group_first = gfirst;
                             t.flags = gflags | (tail ? 2u : 0u) | ((!tail && j == 0) ? 32u : 0u);
                             t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
-                            t.rsvd = 0;
+                            t.gord = gord;
                             rtiles[gfirst + j] = t;
                         }
                     }
                     tcur += nlist + ntail;
                     mpos = endp + 1u;
+                    gord++;
                 }
             }
             result = any_err();
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------ KC
-template <typename RefWord>
+template <typename RefWord, bool kView>
 struct KC {
     const TileParams& P;
     const DevParams& p;
@@ -651,6 +653,7 @@ struct KC {
     uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
     int32_t gc0, gc1, gc2, gc3;
+    uint32_t v_ridx, v_gord, v_region;   // view mode: read index, group ordinal, append region
     // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
     // CIGAR ops [cs_lo, cs_lo+cs_cnt) answer read positions in [cs_q_lo, cs_q_hi)
     uint32_t ds_lo, ds_cnt, ds_rr_lo, ds_rr_hi, cs_lo, cs_cnt, cs_q_lo, cs_q_hi;
@@ -901,9 +904,18 @@ struct KC {
                     if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
                     int mv = m == 0 ? (int)ml0[u] : (int)ml[ml_idx];
                     st_ml++;
+                    if (kView) {   // mod.c:1194-1196: no threshold, the ML byte itself
+                        view_append(p, v_region, v_ridx, (uint32_t)(ref_pos[u] - pos + 1), rev ? L - 1u - q[u] : q[u], ins_off[u],
+                                    (uint32_t)ci, v_gord, 0u, (uint32_t)mv);
+                        continue;
+                    }
                     if (mv >= dm.t_hi) is_mod = 1;
                     else if (mv <= dm.t_lo) is_mod = 0;
                     else continue;
+                } else if (kView) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
+                    view_append(p, v_region, v_ridx, (uint32_t)(ref_pos[u] - pos + 1), rev ? L - 1u - q[u] : q[u], ins_off[u],
+                                (uint32_t)ci, v_gord, 1u, 0u);
+                    continue;
                 }
                 int64_t off = ref_pos[u] - seg_begin;
                 if (ins_off[u] == 0 && dc.plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
@@ -928,12 +940,13 @@ struct KC {
         finish<J>(q, code, kidx, live, is_explicit);
     }
 
-    struct TileArgs { uint32_t ridx, cpos, read_first, group_first, flags, index; };
+    struct TileArgs { uint32_t ridx, cpos, read_first, group_first, flags, index, gord, region; };
     __device__ __forceinline__ int run(const TileArgs t, uint32_t gc01, uint32_t gc23, const uint2* rsum) {
         const int lane = lane_id();
         err = 0;
         KAT_DECL;
         const int ridx = (int)t.ridx;
+        v_ridx = t.ridx; v_gord = t.gord; v_region = t.region;
         const mm_read_t& rd = p.reads[ridx];
         tid = uni(rd.tid); pos = uni(rd.pos);
         L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); ml_len = uniu(rd.ml_len);
@@ -1103,10 +1116,10 @@ struct KC {
     }
 };
 
-template <typename RefWord>
+template <typename RefWord, bool kView>
 __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
-    KC<RefWord> k(P, lds[threadIdx.x >> 6]);
+    KC<RefWord, kView> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
     // static round-robin: wave g serves region g % kTileRegions, striding over that region's tiles with the other
     // waves of the same residue (tiles cost about the same; no shared work counter to serialise on)
@@ -1120,9 +1133,9 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     for (unsigned int ti = g / kTileRegions; ti < n_tiles; ti += n_waves / kTileRegions) {
         // the tile record as wave-uniform scalars
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
-        typename KC<RefWord>::TileArgs t;
+        typename KC<RefWord, kView>::TileArgs t;
         t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.read_first = uniu(src[2]); t.group_first = uniu(src[3]);
-        t.flags = uniu(src[4]); t.index = ti;
+        t.flags = uniu(src[4]); t.index = ti; t.gord = uniu(src[7]); t.region = region;
         uint32_t gc01 = uniu(src[5]), gc23 = uniu(src[6]);
         if (!(t.flags & 1u)) continue;
         int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));

@@ -8,7 +8,7 @@ import numpy as np
 
 from .build import build_hip, lib_path
 
-MM_ABI_VERSION = 1
+MM_ABI_VERSION = 2
 MM_MAX_MODS = 13
 MM_CODE_LEN = 16
 
@@ -20,7 +20,9 @@ READ_DTYPE = np.dtype([
 ])
 ROW_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("strand", "u1"), ("rsvd", "u1"), ("ins_offset", "<u2"),
                       ("code", "<i2"), ("hp", "<i2"), ("n_called", "<u4"), ("n_mod", "<u4")])
-assert READ_DTYPE.itemsize == 64 and ROW_DTYPE.itemsize == 24
+VIEW_ROW_DTYPE = np.dtype([("read", "<u4"), ("pos", "<i4"), ("read_pos", "<u4"), ("ins_offset", "<u2"), ("code", "u1"),
+                           ("prob", "u1")])
+assert READ_DTYPE.itemsize == 64 and ROW_DTYPE.itemsize == 24 and VIEW_ROW_DTYPE.itemsize == 16
 
 
 class mm_batch_t(ctypes.Structure):
@@ -40,7 +42,7 @@ class mm_mod_t(ctypes.Structure):
 class mm_freq_opts_t(ctypes.Structure):
     _fields_ = [("abi_version", ctypes.c_int32), ("n_mods", ctypes.c_int32), ("insertions", ctypes.c_int32),
                 ("haplotypes", ctypes.c_int32), ("device", ctypes.c_int32), ("n_hp_planes", ctypes.c_int32),
-                ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("rsvd", ctypes.c_int32),
+                ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
                 ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
@@ -55,7 +57,7 @@ class mm_interval_t(ctypes.Structure):
 
 
 EXPORTS = ["mm_freq_plan_batch", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
-           "mm_freq_wait", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
+           "mm_freq_wait", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
 
@@ -93,6 +95,9 @@ def load_library(build=True):
     L.mm_freq_submit_device.argtypes = [vp, ctypes.POINTER(mm_batch_t), vp]
     L.mm_freq_wait.restype = i32
     L.mm_freq_wait.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    for f in ("mm_view_fetch", "mm_view_fetch_device"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i32)]
     L.mm_freq_plan_batch.restype = i32
     L.mm_freq_plan_batch.argtypes = [vp, i32, vp, i32]
     L.mm_freq_intern_code.restype = i32
@@ -176,13 +181,14 @@ def batch_struct(batch, order=None, device=False):
 
 
 class FreqEngine(object):
-    """One handle = one `minimod freq` run on one GPU.
+    """One handle = one `minimod freq` run on one GPU (or, with view=True, one `minimod view` run: per-read rows
+    from fetch_view() instead of counters from finalize()).
 
     mods: [(code, context, threshold)] as parse_mod_codes/parse_mod_threshes of the reference would produce;
     contigs: [(name, target_len, raw_sequence_bytes_or_None)] in BAM-header (tid) order."""
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
-                 n_hp_planes=0, side_capacity=0, n_wild_planes=0):
+                 n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -190,6 +196,7 @@ class FreqEngine(object):
         o.abi_version, o.n_mods = MM_ABI_VERSION, len(mods)
         o.insertions, o.haplotypes, o.device = int(insertions), int(haplotypes), int(device)
         o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
+        o.view = int(view)
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
             o.mods[i].context = ctx.encode()
@@ -267,6 +274,25 @@ class FreqEngine(object):
 
     def process(self, batch, order=None):
         self.wait(self.submit(batch, order))
+
+    def fetch_view(self, ticket, device=False):
+        """Rows of a view-mode ticket in print_view_output order: a VIEW_ROW_DTYPE array, or with device=True
+        (device pointer, row count)."""
+        bad = ctypes.c_int32(-1)
+        p = ctypes.c_void_p()
+        f = self.L.mm_view_fetch_device if device else self.L.mm_view_fetch
+        n = f(self.h, ticket, ctypes.byref(p), ctypes.byref(bad))
+        if n < 0:
+            raise MinimodHipError(int(-n), "read %d: %s" % (bad.value, self.L.mm_strerror(int(-n)).decode()), bad.value)
+        if device:
+            return p.value, int(n)
+        if n == 0:
+            return np.zeros(0, dtype=VIEW_ROW_DTYPE)
+        buf = (ctypes.c_char * (n * VIEW_ROW_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=VIEW_ROW_DTYPE).copy()
+
+    def view(self, batch, order=None):
+        return self.fetch_view(self.submit(batch, order))
 
     def kernel_ms(self, ticket):
         return float(self.L.mm_freq_last_kernel_ms(self.h, ticket))

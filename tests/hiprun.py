@@ -48,3 +48,47 @@ def hip_rows_from_records(recs, ref, c, **kw):
     eng.close()
     return [(int(r["pos"]), "+-"[r["strand"]], int(r["n_called"]), int(r["n_mod"]), int(r["ins_off"]), int(r["hp"]),
              codes[r["code"]]) for r in rows]
+
+
+def to_oracle_view_rows(rows, reads, base, haplotypes):
+    """engine VIEW_ROW_DTYPE rows of one batch -> oracle VIEW_DTYPE rows (read index running over batches from `base`)."""
+    out = np.zeros(len(rows), dtype=O.VIEW_DTYPE)
+    rd = reads[rows["read"]]
+    out["read"] = rows["read"].astype(np.int64) + base
+    out["tid"], out["pos"], out["strand"] = rd["tid"], rows["pos"], (rd["flag"] & 0x10) != 0
+    out["code"], out["ins_off"], out["read_pos"], out["prob"] = rows["code"], rows["ins_offset"], rows["read_pos"], rows["prob"]
+    out["hp"] = rd["hp"] if haplotypes else -1
+    return out
+
+
+def hip_view(bam_path, contigs, c="m", insertions=False, haplotypes=False, allow_secondary=False,
+             skip_supplementary=False, K=512, B=20 * 1000 * 1000, **ekw):
+    """`minimod view` with the hot path on the GPU; returns (rows as oracle view dtype, qnames, names, code names)."""
+    mods = O.parse_mod_codes(c)
+    th = O.parse_mod_threshes(None, len(mods))
+    eng = None
+    parts, qnames = [], []
+    for bam, batch, _st in pybam.load_batches(bam_path, K=K, B=B, allow_secondary=allow_secondary,
+                                             skip_supplementary=skip_supplementary):
+        if eng is None:
+            eng = make_engine(mods, th, bam.target_name, bam.target_len, contigs, insertions=insertions,
+                              haplotypes=haplotypes, view=True, **ekw)
+        if len(batch["reads"]):
+            rows = eng.view(batch)
+            parts.append(to_oracle_view_rows(rows, batch["reads"], len(qnames), haplotypes))
+            qnames += batch["qnames"]
+    rows = np.concatenate(parts) if parts else np.zeros(0, dtype=O.VIEW_DTYPE)
+    names, codes = eng.names, eng.code_names()
+    eng.close()
+    return rows, qnames, names, codes
+
+
+def hip_view_from_records(recs, ref, c, **kw):
+    mods = O.parse_mod_codes(c)
+    th = O.parse_mod_threshes(None, len(mods))
+    eng = make_engine(mods, th, ["chrT"], [len(ref)], {"chrT": ref.encode()}, view=True, **kw)
+    batch = pybam.flatten(recs)
+    rows = eng.view(batch)
+    codes = eng.code_names()
+    eng.close()
+    return [(int(r["read"]), int(r["pos"]), int(r["read_pos"]), codes[r["code"]], int(r["prob"]), int(r["ins_offset"])) for r in rows]
