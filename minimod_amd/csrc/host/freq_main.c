@@ -1,7 +1,9 @@
-/* freq_main.c -- `minimod freq` with the hot path on the MI355X library.  Same options, defaults, progress lines,
- * output and exit behaviour as the reference's freq_main (src/freq_main.c:46-64 option table, :166-519 driver),
- * with load(N+1) overlapping process(N) like its 3-stage pipeline (:404-474): the batch is handed to
- * mm_freq_submit (H2D + kernel, asynchronous) and the next batch is decoded meanwhile. */
+/* freq_main.c -- `minimod freq` and `minimod view` with the hot path on the MI355X library.  Same options, defaults,
+ * progress lines, output and exit behaviour as the reference's freq_main (src/freq_main.c:46-64 option table, :166-519
+ * driver) and view_main (src/view_main.c:46-63, :166-470), with load(N+1) overlapping process(N) like their 3-stage
+ * pipeline (freq_main.c:404-474): the batch is handed to mm_freq_submit (H2D + kernels, asynchronous) and the next
+ * batch is decoded meanwhile.  view prints a batch's rows when the batch is retired (print_view_output per db_t,
+ * src/view_main.c:142-160); freq prints once at the end. */
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,19 +32,39 @@ static struct option long_options[] = {
     {"device", required_argument, 0, 0},           /* 17 (new: HIP device ordinal) */
     {0, 0, 0, 0}};
 
+/* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
+static struct option view_long_options[] = {
+    {"mod_codes", required_argument, 0, 'c'},
+    {"threads", required_argument, 0, 't'},
+    {"batchsize", required_argument, 0, 'K'},
+    {"max-bytes", required_argument, 0, 'B'},
+    {"verbose", required_argument, 0, 'v'},
+    {"help", no_argument, 0, 'h'},
+    {"version", no_argument, 0, 'V'},
+    {"prog-interval", required_argument, 0, 'p'},
+    {"debug-break", required_argument, 0, 0},
+    {"output", required_argument, 0, 'o'},
+    {"insertions", no_argument, 0, 0},
+    {"haplotypes", no_argument, 0, 0},
+    {"allow-secondary", no_argument, 0, 0},
+    {"include-non-ref", no_argument, 0, 0},
+    {"skip-supplementary", no_argument, 0, 0},
+    {"device", required_argument, 0, 0},
+    {0, 0, 0, 0}};
+
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device;
+    int progress_interval, device, view;
     const char *codes, *threshes, *out_path;
     FILE *out;
 } fopt_t;
 
 static void print_help(FILE *fp, const fopt_t *o) {
-    fprintf(fp, "Usage: minimod freq ref.fa reads.bam\n");
+    fprintf(fp, "Usage: minimod %s ref.fa reads.bam\n", o->view ? "view" : "freq");
     fprintf(fp, "\nbasic options:\n");
-    fprintf(fp, "   -b                         output in bedMethyl format [%s]\n", o->bedmethyl ? "yes" : "not set");
-    fprintf(fp, "   -c STR                     modification code(s) (eg. m, h or mh or as ChEBI) [%s]\n", o->codes ? o->codes : "(null)");
-    fprintf(fp, "   -m FLOAT                   min modification threshold(s). Comma separated values for each modification code given in -c [%s]\n", o->threshes ? o->threshes : "(null)");
+    if (!o->view) fprintf(fp, "   -b                         output in bedMethyl format [%s]\n", o->bedmethyl ? "yes" : "not set");
+    fprintf(fp, "   -c STR                     modification code(s) (eg. m, h or mh or as ChEBI) [%s]\n", o->codes ? o->codes : (o->view ? "m" : "(null)"));
+    if (!o->view) fprintf(fp, "   -m FLOAT                   min modification threshold(s). Comma separated values for each modification code given in -c [%s]\n", o->threshes ? o->threshes : "(null)");
     fprintf(fp, "   -t INT                     number of BAM decoding threads [%d]\n", o->threads);
     fprintf(fp, "   -K INT                     batch size (max number of reads loaded at once) [%d]\n", o->K);
     fprintf(fp, "   -B FLOAT[K/M/G]            max number of bases loaded at once [%.1fM]\n", o->B / (float)(1000 * 1000));
@@ -107,15 +129,39 @@ static void intern_batch_codes(mm_freq_t *h, const mm_batch_t *b) {
     }
 }
 
-int mmh_freq_main(int argc, char **argv) {
+/* merge_db's place in the pipeline: wait for the batch; freq has nothing to merge, view prints the batch's rows
+ * (print_view_output, src/mod.c:560-626).  `pool_set` is the loader pool set the batch was read into. */
+static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, int pool_set, const mm_bam_hdr_t *hdr, const fopt_t *o,
+                         double *wait_time, double *output_time) {
+    double tw = mmh_realtime();
+    int32_t bad = -1;
+    if (!o->view) {
+        int e = mm_freq_wait(h, ticket, &bad);
+        *wait_time += mmh_realtime() - tw;
+        if (e) die_read_error(e, bad, b, hdr);
+        return;
+    }
+    const mm_view_row_t *rows = NULL;
+    int64_t n = mm_view_fetch(h, ticket, &rows, &bad);
+    *wait_time += mmh_realtime() - tw;
+    if (n < 0) die_read_error((int)-n, bad, b, hdr);
+    double to = mmh_realtime();
+    mmh_print_view_rows(o->out, rows, n, b, pool_set, hdr, h, o->insertions, o->haplotypes);
+    *output_time += mmh_realtime() - to;
+}
+
+static int run_main(int argc, char **argv, int view) {
     double realtime0 = mmh_realtime();
-    const char *optstring = "m:c:t:B:K:v:p:o:hVb";
+    const char *optstring = view ? "c:t:B:K:v:p:o:hV" : "m:c:t:B:K:v:p:o:hVb";   /* src/view_main.c:168, src/freq_main.c:185 */
+    const struct option *lopts = view ? view_long_options : long_options;
     int longindex = 0, c;
     FILE *fp_help = stderr;
     fopt_t o;
     memset(&o, 0, sizeof(o));
     o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    while ((c = getopt_long(argc, argv, optstring, long_options, &longindex)) >= 0) {
+    o.view = view;
+    while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
+        const char *lname = c == 0 ? lopts[longindex].name : "";
         if (c == 'B') {
             o.B = mmh_parse_num(optarg);
             if (o.B <= 0) { MMH_ERROR("%s", "Maximum number of bases should be larger than 0."); exit(EXIT_FAILURE); }
@@ -130,7 +176,7 @@ int mmh_freq_main(int argc, char **argv) {
         } else if (c == 'p') {
             if (atoi(optarg) < 0) { MMH_ERROR("Progress interval should be 0 or positive. You entered %d", atoi(optarg)); exit(EXIT_FAILURE); }
             o.progress_interval = atoi(optarg);
-        } else if (c == 'o' || (c == 0 && longindex == 11)) {
+        } else if (c == 'o') {
             FILE *fp = fopen(optarg, "w");
             if (fp == NULL) { MMH_ERROR("Cannot open file %s for writing", optarg); exit(EXIT_FAILURE); }
             o.out_path = optarg; o.out = fp;
@@ -145,13 +191,13 @@ int mmh_freq_main(int argc, char **argv) {
             o.codes = optarg;
         } else if (c == 'b') {
             o.bedmethyl = 1;
-        } else if (c == 0 && longindex == 10) { o.debug_break = atoi(optarg);
-        } else if (c == 0 && longindex == 12) { o.insertions = 1;
-        } else if (c == 0 && longindex == 13) { o.haplotypes = 1;
-        } else if (c == 0 && longindex == 14) { o.allow_secondary = 1;
-        } else if (c == 0 && longindex == 15) { /* include-non-ref: accepted and ignored like the reference */
-        } else if (c == 0 && longindex == 16) { o.skip_supplementary = 1;
-        } else if (c == 0 && longindex == 17) { o.device = atoi(optarg);
+        } else if (c == 0 && strcmp(lname, "debug-break") == 0) { o.debug_break = atoi(optarg);
+        } else if (c == 0 && strcmp(lname, "insertions") == 0) { o.insertions = 1;
+        } else if (c == 0 && strcmp(lname, "haplotypes") == 0) { o.haplotypes = 1;
+        } else if (c == 0 && strcmp(lname, "allow-secondary") == 0) { o.allow_secondary = 1;
+        } else if (c == 0 && strcmp(lname, "include-non-ref") == 0) { /* accepted and ignored like the reference */
+        } else if (c == 0 && strcmp(lname, "skip-supplementary") == 0) { o.skip_supplementary = 1;
+        } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
         } else {
             print_help(fp_help, &o);
             exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
@@ -166,7 +212,7 @@ int mmh_freq_main(int argc, char **argv) {
     if (mmh_parse_mod_codes(o.codes, &mods, err, sizeof err)) { MMH_ERROR("%s", err); exit(EXIT_FAILURE); }
     char defthr[MM_MAX_MODS * 4 + 1];
     if (o.threshes == NULL || strlen(o.threshes) == 0) {
-        MMH_INFO("%s", "Modification threshold not provided. Using default threshold 0.8");
+        if (!view) MMH_INFO("%s", "Modification threshold not provided. Using default threshold 0.8");   /* view has no thresholds */
         defthr[0] = 0;
         for (int i = 0; i < mods.n_mods; i++) { strcat(defthr, "0.8"); if (i < mods.n_mods - 1) strcat(defthr, ","); }
         o.threshes = defthr;
@@ -201,6 +247,7 @@ int mmh_freq_main(int argc, char **argv) {
     }
     mm_freq_opts_t fo;
     mmh_fill_opts(&mods, o.insertions, o.haplotypes, o.device, &fo);
+    fo.view = view;
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     free(ctg);
@@ -209,9 +256,10 @@ int mmh_freq_main(int argc, char **argv) {
     int wildcard = 0;
     for (int i = 0; i < mods.n_mods; i++) if (strcmp(mods.code[i], "*") == 0) wildcard = 1;
 
-    mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
+    if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
+    else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
 
-    double load_time = 0, process_wait_time = 0;
+    double load_time = 0, process_wait_time = 0, output_time = 0;
     int more = 1, counter = 0, set = 0;
     int32_t pending_ticket = -1;
     mm_batch_t pending_batch, batch;
@@ -226,11 +274,7 @@ int mmh_freq_main(int argc, char **argv) {
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (pending_ticket >= 0) {
-            double tw = mmh_realtime();
-            int32_t bad = -1;
-            int e = mm_freq_wait(h, pending_ticket, &bad);
-            process_wait_time += mmh_realtime() - tw;
-            if (e) die_read_error(e, bad, &pending_batch, hdr);
+            retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, &process_wait_time, &output_time);
             pending_ticket = -1;
         }
         if (n > 0) {
@@ -254,22 +298,19 @@ int mmh_freq_main(int argc, char **argv) {
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (pending_ticket >= 0) {
-        double tw = mmh_realtime();
-        int32_t bad = -1;
-        int e = mm_freq_wait(h, pending_ticket, &bad);
-        process_wait_time += mmh_realtime() - tw;
-        if (e) die_read_error(e, bad, &pending_batch, hdr);
+    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, &process_wait_time, &output_time);
+    double sort_time = 0;
+    if (!view) {
+        double ts = mmh_realtime();
+        const mm_row_t *rows = NULL;
+        int64_t nrows = mm_freq_finalize(h, &rows);
+        if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
+        sort_time = mmh_realtime() - ts;
+        double to = mmh_realtime();
+        mmh_print_freq_rows(o.out, rows, nrows, hdr, h, o.bedmethyl, o.insertions, o.haplotypes);
+        output_time += mmh_realtime() - to;
     }
-    double ts = mmh_realtime();
-    const mm_row_t *rows = NULL;
-    int64_t nrows = mm_freq_finalize(h, &rows);
-    if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
-    double sort_time = mmh_realtime() - ts;
-    double to = mmh_realtime();
-    mmh_print_freq_rows(o.out, rows, nrows, hdr, h, o.bedmethyl, o.insertions, o.haplotypes);
     if (o.out != stdout) fclose(o.out);
-    double output_time = mmh_realtime() - to;
 
     fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
     fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, ld->total_bytes / (float)(1000 * 1000));
@@ -288,3 +329,6 @@ int mmh_freq_main(int argc, char **argv) {
     mmh_loader_close(ld);
     return 0;
 }
+
+int mmh_freq_main(int argc, char **argv) { return run_main(argc, argv, 0); }
+int mmh_view_main(int argc, char **argv) { return run_main(argc, argv, 1); }

@@ -6,8 +6,8 @@
 
 #include "mmhost.h"
 
-enum { P_READS = 0, P_CIGAR, P_SEQ, P_MM, P_ML };
-#define NPOOL 5
+enum { P_READS = 0, P_CIGAR, P_SEQ, P_MM, P_ML, P_QOFF, P_QNAME };   /* the last two stay on the host (view prints read names) */
+#define NPOOL 7
 
 typedef struct { uint8_t *p; size_t n, cap; } pool_t;
 
@@ -95,6 +95,13 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
         rd->tid = rec.tid; rd->pos = rec.pos; rd->l_qseq = (uint32_t)rec.l_qseq; rd->n_cigar = rec.n_cigar;
         rd->mm_len = (uint32_t)mm_len; rd->ml_len = ml_len; rd->flag = rec.flag;
         rd->hp = hpt ? (uint8_t)aux2i(hpt) : 0;
+        {   /* bam_get_qname, printed by view (src/mod.c:571) */
+            size_t ql = strlen(rec.qname);
+            uint8_t *q = pool_take(&P[P_QNAME], ql + 1, 1);
+            memcpy(q, rec.qname, ql + 1);
+            uint64_t qo = (uint64_t)(q - P[P_QNAME].p);
+            memcpy(pool_take(&P[P_QOFF], sizeof qo, 8), &qo, sizeof qo);
+        }
         if (rec.n_cigar > max_cig) max_cig = rec.n_cigar;
         if ((uint32_t)rec.l_qseq > max_l) max_l = (uint32_t)rec.l_qseq;
         n++;
@@ -119,6 +126,13 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     *more = (n >= ld->K || proc_bytes >= ld->B);         /* freq_main.c:410 */
     if (rc < 0) return -1;
     return n;
+}
+
+const char *mmh_loader_qname(int set, int32_t read) {
+    const pool_t *P = g_sets[set & 1];
+    uint64_t qo;
+    memcpy(&qo, P[P_QOFF].p + 8 * (size_t)read, sizeof qo);
+    return (const char *)P[P_QNAME].p + qo;
 }
 
 void mmh_loader_close(mmh_loader_t *ld) {

@@ -1,4 +1,4 @@
-/* mmhost.h -- C host side of `minimod freq` on the MI355X library (include/minimod_hip.h).
+/* mmhost.h -- C host side of `minimod freq` and `minimod view` on the MI355X library (include/minimod_hip.h).
  * Mirrors the reference's driver layer: options (src/freq_main.c:46-64,182-296, src/mod.c:204-398), reference load
  * (src/ref.c:46-89), load_db (src/minimod.c:235-333) and print_freq_output (src/mod.c:628-728). */
 #ifndef MMHOST_H
@@ -38,7 +38,7 @@ typedef struct mmh_mods {
 int mmh_parse_mod_codes(const char *s, mmh_mods_t *out, char *err, size_t errlen);
 int mmh_parse_mod_threshes(const char *s, mmh_mods_t *m, char *err, size_t errlen);
 void mmh_klass_lut(double thresh, uint8_t lut[256]);   /* src/mod.c:56,1180-1191 */
-void mmh_fill_opts(const mmh_mods_t *m, int insertions, int haplotypes, int device, mm_freq_opts_t *o);
+void mmh_fill_opts(const mmh_mods_t *m, int insertions, int haplotypes, int device, mm_freq_opts_t *o);   /* o->view = 0 */
 
 /* ---- reference ---- */
 typedef struct mmh_ref {
@@ -60,14 +60,14 @@ typedef struct mmh_loader {
     /* statistics of the last batch / totals (db_t / core_t counters, src/minimod.h:147-150,190-194) */
     int32_t last_total_reads; int64_t last_total_bytes, last_processed_bytes;
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
-    /* growable pools reused between batches */
-    struct { uint8_t *p; size_t n, cap; } pool[5];
 } mmh_loader_t;
 mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary);
 /* Fills `out` with the next batch (pointers into the loader's pools, valid until the next call with the same pool set).
  * Returns the number of accepted reads, or -1 on a read error.  *more = 0 when the reference's loop would stop
  * (src/freq_main.c:410). */
 int32_t mmh_loader_next(mmh_loader_t *ld, int pool_set, mm_batch_t *out, int *more);
+/* read name of read `read` of the batch last loaded into `pool_set` */
+const char *mmh_loader_qname(int pool_set, int32_t read);
 void mmh_loader_close(mmh_loader_t *ld);
 
 /* ---- output ---- */
@@ -75,7 +75,13 @@ void mmh_print_freq_header(FILE *fp, int bedmethyl, int insertions, int haplotyp
 void mmh_print_freq_rows(FILE *fp, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, mm_freq_t *h, int bedmethyl,
                          int insertions, int haplotypes);
 
+/* print_view_header / print_view_output (src/mod.c:545-626) for one batch's rows */
+void mmh_print_view_header(FILE *fp, int insertions, int haplotypes);
+void mmh_print_view_rows(FILE *fp, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, int pool_set,
+                         const mm_bam_hdr_t *hdr, mm_freq_t *h, int insertions, int haplotypes);
+
 int mmh_freq_main(int argc, char **argv);
+int mmh_view_main(int argc, char **argv);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,58 @@ def test_cli_on_synthetic_bam_matches_oracle(tmp_path):
     want = O.format_rows(orc.rows(), ["chrS"], orc.code_names(), bedmethyl=True)
     assert len(want) > 100000 and r.stdout.decode() == want
     assert b"total processed entries: 1400" in r.stderr
+
+
+# ---- view (reference test/test.sh:66-111,186-247)
+from tests.cases import VIEW_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", VIEW_CASES, ids=["view-" + c[0] for c in VIEW_CASES])
+def test_cli_view_matches_reference_golden(exp, bam, ctg, kw, exact, fastas, tmp_path):
+    cmd = [BIN, "view"] + _args(kw) + [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    got = r.stdout.decode()
+    if exact:
+        assert got == want
+    else:
+        assert sorted(got.splitlines()) == sorted(want.splitlines())
+
+
+def test_cli_view_output_file_and_batch_invariance(fastas, tmp_path):
+    """Test 13 of the reference (view -o) and: the rows do not depend on -K / -B / -t."""
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    outs = []
+    for i, extra in enumerate((["-K", "1"], ["-K", "4096", "-B", "100M", "-t", "4"], ["-B", "50K"])):
+        o = str(tmp_path / ("v%d.tsv" % i))
+        r = subprocess.run([BIN, "view", "-o", o] + extra + [fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()[-2000:]
+        outs.append(open(o).read())
+    assert outs[0] == outs[1] == outs[2] == open(os.path.join(GOLDEN, "expected", "test10.tsv")).read()
+
+
+def test_cli_view_rejects_freq_only_options(fastas):
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    for opt in (["-b"], ["-m", "0.8"]):   # not in view's option table (src/view_main.c:46-63,168): help + failure
+        r = subprocess.run([BIN, "view"] + opt + [fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"Usage: minimod view ref.fa reads.bam" in r.stderr
+
+
+def test_cli_view_on_synthetic_bam_matches_oracle(tmp_path):
+    """Synthetic ONT-shape reads as a real BGZF BAM + FASTA through `minimod view` (several batches, both strands,
+    insertions): byte-identical to the oracle's view of the same file."""
+    from minimod_amd import synth
+    from oracle import oracle as O
+    ref = synth.reference(13, 1 << 20)
+    bs = [synth.batch(ref, i * 100, 100, seed=5, n_reads_total=300) for i in range(3)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    for extra, kw in (([], dict()), (["--insertions"], dict(insertions=True))):
+        r = subprocess.run([BIN, "view", "-c", "m[CG]", "-K", "128", "-t", "4"] + extra + [fa, bam],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        rows, qn, names, codes = O.view(bam, {"chrS": ref}, c="m[CG]", K=128, threads=4, **kw)
+        want = O.format_view(rows, qn, names, codes, **kw)
+        assert len(want) > 100000 and r.stdout.decode() == want
