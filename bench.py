@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra overlapped-streams measurement (use when profiling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
+    ap.add_argument("--mode", default="freq", choices=["freq", "view"],
+                    help="freq = the headline metric (default); view = the same batches through `minimod view` (SURVEY.md 8f row 1), "
+                         "rows ordered and left in HBM; an extra measurement, not the driver's contract line")
     return ap.parse_args()
 
 
@@ -134,8 +137,11 @@ def main():
         host_batches = list(ex.map(gen, range(n_batches)))
     t_gen = time.time() - t0
 
-    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank,
-                                 intervals=[(0, plan["begin"], plan["end"], plan["halo"])])
+    if args.mode == "view":
+        eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank, view=True)
+    else:
+        eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank,
+                                     intervals=[(0, plan["begin"], plan["end"], plan["halo"])])
     # ---- make the batches resident in HBM (torch owns the memory: plumbing only)
     dev_batches = []
     keep = []
@@ -159,6 +165,9 @@ def main():
     tstream = torch.cuda.Stream(device=dev)   # one explicit HIP stream carries every K1 launch
     stream = tstream.cuda_stream
     batch_bases = [hb["n_bases"] for hb in host_batches]
+
+    if args.mode == "view":
+        return bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, world, dist, dev, plan, ref, t_gen)
 
     # ---- untimed tally pass: lookups/updates per batch for the algorithmic-bytes figure
     eng.stats_enable(True)
@@ -276,6 +285,103 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, host_batches, plan, ref)
         if args.verify:
             result["verify"] = verify(host_batches[:2], plan, ref, local_rank)
+        print(json.dumps(result))
+        sys.stdout.flush()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, world, dist, dev, plan, ref, t_gen):
+    """`minimod view` on the same resident batches: a step = call kernels + device-side ordering of the batch's rows
+    (counting sort by read, one small sort per read; view_kernels.hip.h), rows left in HBM (mm_view_fetch_device).  Reads shard by interval
+    exactly as for freq; rows are per read, so there is no exchange at all."""
+    import torch
+    n_batches = len(dev_batches)
+    # untimed tally pass: reference-word lookups per batch (kernel tallies) and rows per batch
+    eng.stats_enable(True)
+    alg_bytes, rows_per_batch = [], []
+    for hb, db in zip(host_batches, dev_batches):
+        _, n = eng.fetch_view(eng.submit_device(db, stream), device=True)
+        st = eng.stats_get()
+        rows_per_batch.append(n)
+        alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], 0) + 16 * n)
+    eng.stats_enable(False)
+
+    def run_steps(n, first_step=0):
+        tickets, bases, kms, abytes, rows = [], 0, [], 0, 0
+        for s in range(n):
+            bi = (first_step + s) % n_batches
+            tickets.append(eng.submit_device(dev_batches[bi], stream))
+            bases += batch_bases[bi]
+            abytes += alg_bytes[bi]
+            if len(tickets) >= 3:
+                tk = tickets.pop(0)
+                rows += eng.fetch_view(tk, device=True)[1]
+                kms.append(eng.kernel_ms(tk))
+        for tk in tickets:
+            rows += eng.fetch_view(tk, device=True)[1]
+            kms.append(eng.kernel_ms(tk))
+        return bases, kms, abytes, rows
+
+    run_steps(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bases, kms, abytes, rows = run_steps(args.steps, first_step=args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total_bases = bases
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([bases], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = int(tb.item())
+    result = None
+    if rank == 0:
+        mean_ms = float(np.mean(kms))
+        step_ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "minimod view Mbases/sec", "value": total_bases / elapsed / 1e6, "unit": "Mbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "C2 batches through view: %d ONT-shape reads per GPU, -c m[CG], -K %d, batches resident in HBM, "
+                                   "ordered rows left in HBM" % (args.reads, args.batch),
+                       "rows_per_step": rows / args.steps, "sharding": "interval per GPU, no exchange" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": (abytes / args.steps) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (abytes / args.steps) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step = k_scan_reads + k_sum_tiles + k_call_tiles<view> + k_view_offsets + k_view_scatter + "
+                                   "k_view_sort + k_view_sort_big, wall clock per step; HIP events around the same launches: kernel_ms_mean",
+                         "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / args.steps},
+            "gen_seconds": t_gen,
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            cores = os.cpu_count() or 1
+            orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+            orc.set_view(True)
+            orc.add_contig("chrS", ref)
+            tc = time.perf_counter()
+            orc.process(host_batches[0], threads=cores)
+            tc = time.perf_counter() - tc
+            ok = None
+            if args.verify:
+                got = eng.view(host_batches[0])
+                w = orc.view_rows()
+                ok = bool(len(got) == len(w) and (got["read"] == w["read"]).all() and (got["pos"] == w["pos"]).all() and
+                          (got["read_pos"] == w["read_pos"]).all() and (got["prob"] == w["prob"]).all())
+                result["verify"] = {"rows": int(len(w)), "bit_exact": ok}
+            orc.close()
+            result["cpu_baseline"] = {"value": batch_bases[0] / tc / 1e6, "unit": "Mbases/s", "cores": cores, "kind": "port",
+                                      "sample": "first -K %d batch (%d bases), oracle view mode with %d threads, process step only"
+                                                % (args.batch, batch_bases[0], cores)}
         print(json.dumps(result))
         sys.stdout.flush()
     eng.close()

@@ -60,14 +60,16 @@ struct Slot {
     unsigned int* d_vcount = nullptr;      // [kViewRegions * kViewCountStride] + [1] selected rows
     unsigned int* h_vcount = nullptr;      // pinned copy
     unsigned int view_cap = 0;             // records per region
-    unsigned long long* d_ka = nullptr; size_t cap_ka = 0;
-    unsigned long long* d_kb = nullptr; size_t cap_kb = 0;
+    unsigned long long* d_ka = nullptr; size_t cap_ka = 0;   // records grouped by read, then sorted inside each read
     unsigned long long* d_va = nullptr; size_t cap_va = 0;
-    unsigned long long* d_vb = nullptr; size_t cap_vb = 0;
-    ViewRow* d_vrows = nullptr; size_t cap_vrows = 0;
-    ViewRow* d_vout = nullptr; size_t cap_vout = 0;
-    uint8_t* d_vkeep = nullptr; size_t cap_vkeep = 0;
-    void* d_vtmp = nullptr; size_t cap_vtmp = 0;
+    ViewRow* d_vrows = nullptr; size_t cap_vrows = 0;        // rows in print order (dropped duplicates still in place)
+    ViewRow* d_vout = nullptr; size_t cap_vout = 0;          // rows after compaction (only batches with duplicate keys)
+    unsigned int* d_vreadcount = nullptr; size_t cap_vreadcount = 0;   // per read: records
+    unsigned int* d_voff = nullptr; size_t cap_voff = 0;               // per read: segment start (+ total at [n_reads])
+    unsigned int* d_vcursor = nullptr; size_t cap_vcursor = 0;
+    unsigned int* d_vkept = nullptr; size_t cap_vkept = 0;             // per read: rows kept
+    unsigned int* d_vnewoff = nullptr; size_t cap_vnewoff = 0;
+    const ViewRow* view_dev_rows = nullptr;                             // where the ticket's final rows are
     ViewRow* h_vrows = nullptr; size_t cap_hrows = 0;   // pinned
     mm_batch_t last_batch;       // device-side batch of the ticket (view mode may have to run it again)
     hipStream_t last_stream = nullptr;
@@ -206,8 +208,18 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 return r;
             s.view_cap = (unsigned int)std::min<size_t>(std::min(s.cap_vkeys, s.cap_vvals) / (8 * kViewRegions), 0xFFFFFFFFu / kViewRegions);
         }
+        // the ordering pass works on at most what the regions can hold
+        const size_t cap_total = (size_t)s.view_cap * kViewRegions, nr = (size_t)std::max(b->n_reads, 1);
+        if ((r = grow(h, (void**)&s.d_ka, &s.cap_ka, 8 * cap_total)) || (r = grow(h, (void**)&s.d_va, &s.cap_va, 8 * cap_total)) ||
+            (r = grow(h, (void**)&s.d_vrows, &s.cap_vrows, sizeof(ViewRow) * cap_total)) ||
+            (r = grow(h, (void**)&s.d_vreadcount, &s.cap_vreadcount, 4 * nr)) || (r = grow(h, (void**)&s.d_voff, &s.cap_voff, 4 * (nr + 1))) ||
+            (r = grow(h, (void**)&s.d_vcursor, &s.cap_vcursor, 4 * nr)) || (r = grow(h, (void**)&s.d_vkept, &s.cap_vkept, 4 * nr)) ||
+            (r = grow(h, (void**)&s.d_vnewoff, &s.cap_vnewoff, 4 * (nr + 1))))
+            return r;
         p.view = 1; p.view_cap = s.view_cap; p.view_keys = s.d_vkeys; p.view_vals = s.d_vvals; p.view_count = s.d_vcount;
-        HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1), st));
+        p.view_read_count = s.d_vreadcount;
+        HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), st));
+        HIPCHK(hipMemsetAsync(s.d_vreadcount, 0, 4 * nr, st));
     }
     p.queue = s.d_ctl; p.err_summary = s.d_ctl + 1;
     TileParams tp;
@@ -266,10 +278,25 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         }
         HIPCHK(hipGetLastError());
     }
+    if (h->opts.view && b->n_reads > 0) {
+        // order the rows (view_kernels.hip.h): counting sort by read, then one small sort per read.  Everything takes its
+        // sizes from device memory, so nothing here waits for the call kernels.
+        unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates, [1] reads on the big list
+        const uint32_t nr = (uint32_t)b->n_reads;
+        hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
+        hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount,
+                           s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
+        // big-read list: d_vnewoff doubles as the list (it is only needed again when rows were dropped, after the sorts)
+        hipLaunchKernelGGL(k_view_sort, dim3(std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 5)), dim3(256), 0, st,
+                           s.d_ka, s.d_va, s.d_voff, nr, b->reads, s.d_vrows, s.d_vkept, tail, s.d_vnewoff, tail + 1);
+        hipLaunchKernelGGL(k_view_sort_big, dim3(std::min<uint32_t>(nr, (uint32_t)h->n_cu * 2)), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff,
+                           b->reads, s.d_vrows, s.d_vkept, tail, s.d_vnewoff, tail + 1);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(s.ev_stop, st));
     HIPCHK(hipMemcpyAsync(s.h_ctl + 80, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (h->opts.view)
-        HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * kViewRegions * kViewCountStride, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s.ev_done, st));
     s.busy = true; s.timed = true; s.n_reads = b->n_reads;
     s.last_batch = *b; s.last_stream = st; s.view_rows = -1; s.view_on_host = false;
@@ -328,7 +355,8 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_tiles, s.d_fb,
-                      s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_kb, s.d_va, s.d_vb, s.d_vrows, s.d_vout, s.d_vkeep, s.d_vtmp};
+                      s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
+                      s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_vcount) (void)hipHostFree(s.h_vcount);
@@ -388,8 +416,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         if (dev_alloc(h, (void**)&s.d_ctl, 128 * sizeof(unsigned int))) return fail(h, "alloc failed");
         if (hipHostMalloc((void**)&s.h_ctl, 160 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
         if (opts->view) {
-            if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1))) return fail(h, "alloc failed");
-            if (hipHostMalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 1), hipHostMallocDefault) != hipSuccess)
+            if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2))) return fail(h, "alloc failed");
+            if (hipHostMalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipHostMallocDefault) != hipSuccess)
                 return fail(h, "pinned alloc failed");
         }
     }
@@ -828,7 +856,7 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
             if (hipHostMalloc((void**)&s.h_vrows, sizeof(ViewRow) * cap, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
             s.cap_hrows = cap;
         }
-        HIPCHK(hipMemcpyAsync(s.h_vrows, s.d_vout, sizeof(ViewRow) * nsel, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s.h_vrows, s.view_dev_rows, sizeof(ViewRow) * nsel, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         s.view_on_host = true;
         return 0;
@@ -861,38 +889,27 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
         mm_batch_t again = s.last_batch;
         if ((r = launch_k1(h, s, &again, st))) return r;
     }
-    if (n >= (1ull << 32)) return -MM_E_TOOMANY;
     s.view_rows = 0;
+    s.view_dev_rows = s.d_vrows;
     if (n == 0) return 0;
-    int r;
-    if ((r = grow(h, (void**)&s.d_ka, &s.cap_ka, 8 * (size_t)n)) || (r = grow(h, (void**)&s.d_kb, &s.cap_kb, 8 * (size_t)n)) ||
-        (r = grow(h, (void**)&s.d_va, &s.cap_va, 8 * (size_t)n)) || (r = grow(h, (void**)&s.d_vb, &s.cap_vb, 8 * (size_t)n)) ||
-        (r = grow(h, (void**)&s.d_vrows, &s.cap_vrows, sizeof(ViewRow) * (size_t)n)) ||
-        (r = grow(h, (void**)&s.d_vout, &s.cap_vout, sizeof(ViewRow) * (size_t)n)) ||
-        (r = grow(h, (void**)&s.d_vkeep, &s.cap_vkeep, (size_t)n)))
-        return r;
-    unsigned int rbits = 1;
-    while ((1u << rbits) <= (unsigned int)std::max(s.n_reads, 1)) rbits++;
-    const unsigned int key_bits = 28 + rbits;
-    size_t tmp_sort = 0, tmp_sel = 0;
-    uint4* rows_in = reinterpret_cast<uint4*>(s.d_vrows);
-    uint4* rows_out = reinterpret_cast<uint4*>(s.d_vout);
-    unsigned int* d_nsel = s.d_vcount + kViewRegions * kViewCountStride;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_sort, s.d_ka, s.d_kb, s.d_va, s.d_vb, (size_t)n, 0u, key_bits, st));
-    HIPCHK(rocprim::select(nullptr, tmp_sel, rows_in, s.d_vkeep, rows_out, d_nsel, (size_t)n, st));
-    if ((r = grow(h, &s.d_vtmp, &s.cap_vtmp, std::max(tmp_sort, tmp_sel)))) return r;
-    const int blocks = (int)std::min<unsigned long long>((n + 255) / 256, (unsigned long long)h->n_cu * 16);
-    hipLaunchKernelGGL(k_view_pack, dim3(blocks), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount, s.view_cap, s.d_ka, s.d_va);
-    HIPCHK(hipGetLastError());
-    HIPCHK(rocprim::radix_sort_pairs(s.d_vtmp, tmp_sort, s.d_ka, s.d_kb, s.d_va, s.d_vb, (size_t)n, 0u, key_bits, st));
-    hipLaunchKernelGGL(k_view_rows, dim3(blocks), dim3(256), 0, st, s.d_kb, s.d_vb, n, key_bits, s.last_batch.reads, s.d_vrows, s.d_vkeep);
-    HIPCHK(hipGetLastError());
-    HIPCHK(rocprim::select(s.d_vtmp, tmp_sel, rows_in, s.d_vkeep, rows_out, d_nsel, (size_t)n, st));
-    HIPCHK(hipMemcpyAsync(s.h_vcount + kViewRegions * kViewCountStride, d_nsel, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const size_t nsel = s.h_vcount[kViewRegions * kViewCountStride];
+    size_t nsel = (size_t)n;
+    const unsigned int dropped = s.h_vcount[kViewRegions * kViewCountStride];
+    if (dropped) {
+        // some read carried two entries of one key (add_view_entry keeps the first): close the gaps
+        int r;
+        if ((r = grow(h, (void**)&s.d_vout, &s.cap_vout, sizeof(ViewRow) * (size_t)n))) return r;
+        const uint32_t nr = (uint32_t)s.n_reads;
+        hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vkept, nr, s.d_vnewoff, s.d_vcursor);
+        hipLaunchKernelGGL(k_view_compact, dim3(std::min<uint32_t>(nr, (uint32_t)h->n_cu * 8)), dim3(256), 0, st, s.d_vrows, s.d_voff, s.d_vnewoff, nr,
+                           s.d_vout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        nsel -= dropped;
+        s.view_dev_rows = s.d_vout;
+    }
     s.view_rows = (int64_t)nsel;
-    if ((r = copy_out(nsel))) return r;
+    int r2 = copy_out(nsel);
+    if (r2) return r2;
     return (int64_t)nsel;
 }
 
@@ -905,7 +922,7 @@ int64_t mm_view_fetch(mm_freq_t* h, int32_t ticket, const mm_view_row_t** rows, 
 }
 int64_t mm_view_fetch_device(mm_freq_t* h, int32_t ticket, const void** dev_rows, int32_t* bad_read) {
     int64_t n = view_finish(h, ticket, bad_read, false);
-    if (n >= 0 && dev_rows) *dev_rows = h->slots[ticket].d_vout;
+    if (n >= 0 && dev_rows) *dev_rows = h->slots[ticket].view_dev_rows;
     return n;
 }
 

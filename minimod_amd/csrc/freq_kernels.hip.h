@@ -114,6 +114,7 @@ struct DevParams {
     unsigned long long* view_keys;   // [kViewRegions][view_cap]  prob << 56 | read << 28 | (ref_pos - read.pos + 1)
     unsigned long long* view_vals;   // [kViewRegions][view_cap]  code << 56 | ins_offset << 40 | group << 29 | implicit << 28 | fastq read_pos
     unsigned int* view_count;        // [kViewRegions * kViewCountStride]; counts past view_cap mean "grow and run again"
+    unsigned int* view_read_count;   // [n_reads] records per read (sizes the per-read segments of the ordering pass)
 };
 constexpr uint32_t kViewRegions = 64;
 constexpr uint32_t kViewCountStride = 32;
@@ -148,7 +149,13 @@ __device__ __forceinline__ void view_append(const DevParams& p, uint32_t region,
     uint64_t m = __ballot(1);
     int leader = __ffsll((unsigned long long)m) - 1;
     unsigned int base = 0;
-    if (lane_id() == leader) base = atomicAdd(p.view_count + region * kViewCountStride, (unsigned int)__popcll(m));
+    if (lane_id() == leader) {
+        const unsigned int cnt = (unsigned int)__popcll(m);
+        base = atomicAdd(p.view_count + region * kViewCountStride, cnt);
+        // all lanes of a wave work on one read; only records that found room are counted for the ordering pass
+        const unsigned int room = base < p.view_cap ? p.view_cap - base : 0u;
+        atomicAdd(p.view_read_count + ridx, cnt < room ? cnt : room);
+    }
     base = __shfl(base, leader, 64);
     unsigned int idx = base + (unsigned int)__popcll(m & lanemask_lt());
     if (idx < p.view_cap) {

@@ -564,7 +564,11 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         else e = k.run_dir(ridx);
         e = uni(e);
 #ifdef MM_PHASE_TIMING
-        if (lane_id() == 0 && p.stats) { unsigned long long dt = __builtin_amdgcn_s_memrealtime() - kt0; atomicMax(p.stats + 4 + kind, dt); atomicAdd(p.stats + 7, 1ull); }
+        if (lane_id() == 0 && p.stats) {
+            unsigned long long kt1 = __builtin_amdgcn_s_memrealtime(), dt = kt1 - kt0;
+            atomicMax(p.stats + 4 + kind, dt); atomicAdd(p.stats + 7, 1ull);
+            atomicMax(p.stats + 13, ~kt0); atomicMax(p.stats + 14, kt1);   // kernel span in the same ticks: [~stats[13], stats[14]]
+        }
 #endif
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;

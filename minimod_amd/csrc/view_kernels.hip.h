@@ -2,18 +2,17 @@
 // src/mod.c:560-626: per read, rows sorted by reference position; add_view_entry, src/mod.c:931-946: the first entry
 // of a key wins).
 //
-// The call kernels append (key, value) records to kViewRegions regions in no particular order.  Here they are
-//   1. packed into one contiguous array                                       (k_view_pack)
-//   2. radix-sorted on (read, reference position) -- rocPRIM's device radix sort, a plain library primitive
-//   3. put into canonical order inside every (read, position) run -- (code, ins_offset), then the order the reference
-//      met the calls in -- duplicates of a key dropped in favour of the earliest, and expanded to the 16-byte rows of the C ABI  (k_view_rows)
-//   4. compacted (rocPRIM select on the keep flags).
+// The call kernels append (key, value) records to kViewRegions regions in no particular order and count them per
+// read.  A read's rows are independent of every other read's, so the ordering is a counting sort by read followed by
+// one small sort per read -- no global sort:
+//   1. k_view_offsets  exclusive scan of the per-read record counts                       (one block)
+//   2. k_view_scatter  every record to its read's segment (one cursor atomic per record, ~100 records per cursor)
+//   3. k_view_sort     one wavefront per read: bitonic sort of the segment on (position, code, ins_offset, the order the
+//                      reference met the calls in) in LDS, later entries of a key marked, rows expanded to the 16-byte form
+//                      of the C ABI; reads with more than 512 records go to k_view_sort_big (one workgroup per read, LDS up
+//                      to 4096 records, in place in global memory beyond)
+//   4. k_view_compact  only when some read had duplicate keys: rows of every read moved down over the dropped ones.
 #pragma once
-#include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
-
 #include "freq_kernels.hip.h"
 
 namespace mmhip {
@@ -28,89 +27,212 @@ struct ViewRow {   // == mm_view_row_t
 };
 static_assert(sizeof(ViewRow) == 16, "ViewRow must be 16 bytes");
 
-// regions -> one array.  Every block recomputes the 64-entry prefix of the region counts (cheaper than another launch).
-__global__ __launch_bounds__(256) void k_view_pack(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ rv,
-                                                   const unsigned int* __restrict__ counts, unsigned int cap,
-                                                   unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals) {
-    __shared__ unsigned long long start[kViewRegions + 1];
-    if (threadIdx.x < 64) {
-        unsigned int c = counts[threadIdx.x * kViewCountStride];
-        if (c > cap) c = cap;
-        uint32_t incl = wave_incl_scan(c);   // fewer than 2^32 records per batch (checked by the host)
-        start[threadIdx.x + 1] = incl;
-        if (threadIdx.x == 0) start[0] = 0;
-    }
+constexpr uint32_t kViewDropped = 0xFFFFFFFFu;   // ViewRow.read of a dropped duplicate (before k_view_compact)
+constexpr uint32_t kViewWaveRecs = 512;          // records one wavefront sorts in its 8 KB of LDS
+constexpr uint32_t kViewLdsRecs = 4096;          // records a workgroup sorts in LDS (64 KB)
+
+// offsets[r] = number of records of reads < r; offsets[n_reads] = total.  One block; thread t owns the reads
+// [t*chunk, (t+1)*chunk): sum them, scan the 256 sums, write the offsets (cursors are zeroed on the way).
+__global__ __launch_bounds__(256) void k_view_offsets(const unsigned int* __restrict__ counts, uint32_t n_reads,
+                                                      unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t chunk = (n_reads + 255u) / 256u;
+    const uint32_t lo = min(n_reads, threadIdx.x * chunk), hi = min(n_reads, lo + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += counts[i];
+    uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    const unsigned long long n = start[kViewRegions];
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
-        uint32_t lo = 0;
-#pragma unroll
-        for (uint32_t step = 32; step; step >>= 1) {
-            uint32_t cand = lo + step;
-            if (cand < kViewRegions && start[cand] <= i) lo = cand;
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wv; w++) run += wsum[w];
+    for (uint32_t i = lo; i < hi; i++) { offsets[i] = run; cursor[i] = 0u; run += counts[i]; }
+    if (threadIdx.x == 255) offsets[n_reads] = run;
+}
+
+// regions -> per-read segments
+__global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ rv,
+                                                      const unsigned int* __restrict__ region_counts, unsigned int cap, uint32_t read_mask,
+                                                      const unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
+                                                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals) {
+    for (uint32_t region = blockIdx.y; region < kViewRegions; region += gridDim.y) {
+        unsigned int n = region_counts[region * kViewCountStride];
+        if (n > cap) n = cap;
+        const size_t base = (size_t)region * cap;
+        for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            unsigned long long k = rk[base + i], v = rv[base + i];
+            uint32_t read = (uint32_t)(k >> 28) & read_mask;
+            // neighbours in a region mostly belong to one read (a tile appends its records together): one cursor atomic per
+            // distinct read of the wave instead of one per record
+            unsigned int slot = 0;
+            bool pending = true;
+            while (pending) {
+                uint32_t first = uniu(read);   // the first still-pending lane's read
+                bool same = read == first;
+                uint64_t m = __ballot(same);
+                unsigned int at = 0;
+                int leader = __ffsll((unsigned long long)m) - 1;
+                if (lane_id() == leader) at = atomicAdd(cursor + first, (unsigned int)__popcll(m));
+                at = __shfl(at, leader, 64);
+                if (same) { slot = offsets[first] + at + (unsigned int)__popcll(m & lanemask_lt()); pending = false; }
+            }
+            keys[slot] = k;
+            vals[slot] = v;
         }
-        size_t src = (size_t)lo * cap + (size_t)(i - start[lo]);
-        keys[i] = rk[src];
-        vals[i] = rv[src];
     }
 }
 
-// order of two records of one (read, position) run: (code, ins_offset), then the order the reference met them in
-// (group, listed before implicit, position in the read) -- the whole value
-__device__ __forceinline__ bool view_before(unsigned long long va, unsigned long long vb) { return va < vb; }
+// (position, value) order of two records of one read; position = the key's low 28 bits
+__device__ __forceinline__ bool view_less(unsigned long long ka, unsigned long long va, unsigned long long kb, unsigned long long vb) {
+    uint32_t pa = (uint32_t)ka & 0x0FFFFFFFu, pb = (uint32_t)kb & 0x0FFFFFFFu;
+    return pa != pb ? pa < pb : va < vb;
+}
 
-// One thread per record; the first record of every (read, position) run orders the run and writes its rows.
-__global__ __launch_bounds__(256) void k_view_rows(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
-                                                   unsigned long long n, unsigned int key_bits, const mm_read_t* __restrict__ reads,
-                                                   ViewRow* __restrict__ rows, uint8_t* __restrict__ keep) {
-    const unsigned long long kmask = (1ull << key_bits) - 1ull;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
-        const unsigned long long k = keys[i] & kmask;
-        if (i > 0 && (keys[i - 1] & kmask) == k) continue;   // not the head of its run
-        unsigned long long j = i + 1;
-        while (j < n && (keys[j] & kmask) == k) j++;
-        const unsigned long long len = j - i;
-        if (len > 1) {
-            if (len <= 16) {   // insertion sort
-                for (unsigned long long a = i + 1; a < j; a++) {
-                    unsigned long long kv = keys[a], vv = vals[a];
-                    unsigned long long b = a;
-                    while (b > i && view_before(vv, vals[b - 1])) { keys[b] = keys[b - 1]; vals[b] = vals[b - 1]; b--; }
-                    keys[b] = kv; vals[b] = vv;
-                }
-            } else {           // heap sort in place (a long insertion puts thousands of records on one anchor)
-                unsigned long long* K = keys + i;
-                unsigned long long* V = vals + i;
-                auto sift = [&](unsigned long long root, unsigned long long end) {
-                    for (;;) {
-                        unsigned long long child = 2 * root + 1;
-                        if (child >= end) break;
-                        if (child + 1 < end && view_before(V[child], V[child + 1])) child++;
-                        if (!view_before(V[root], V[child])) break;
-                        unsigned long long tk = K[root], tv = V[root];
-                        K[root] = K[child]; V[root] = V[child]; K[child] = tk; V[child] = tv;
-                        root = child;
-                    }
-                };
-                for (unsigned long long s = len / 2; s-- > 0;) sift(s, len);
-                for (unsigned long long e = len - 1; e > 0; e--) {
-                    unsigned long long tk = K[0], tv = V[0];
-                    K[0] = K[e]; V[0] = V[e]; K[e] = tk; V[e] = tv;
-                    sift(0, e);
+// Bitonic network in its normalised form (every compare-exchange puts the smaller record at the lower index), which
+// sorts any n: the positions from n up to the next power of two behave as +infinity and never have to exist.
+// kThreads cooperating threads (one wavefront, or a 256-thread workgroup), `tid` this thread's index among them.
+template <int kThreads, typename Ptr>
+__device__ __forceinline__ void view_bitonic(Ptr K, Ptr V, uint32_t n, uint32_t tid) {
+    uint32_t l2 = 0;
+    while ((1u << l2) < n) l2++;
+    const uint32_t half = (1u << l2) >> 1;
+    for (uint32_t lk = 1; lk <= l2; lk++) {
+        const uint32_t k = 1u << lk;
+        for (uint32_t lj = lk; lj-- > 0;) {
+            const uint32_t j = 1u << lj;
+            const bool flip = lj + 1u == lk;
+            for (uint32_t t = tid; t < half; t += kThreads) {
+                // t-th pair of this step
+                uint32_t lo = ((t >> lj) << (lj + 1u)) | (t & (j - 1u));
+                uint32_t hi = flip ? (lo ^ (k - 1u)) : (lo + j);   // first step of a stage: the mirror position inside the k-block
+                if (hi < n) {
+                    unsigned long long ka = K[lo], va = V[lo], kb = K[hi], vb = V[hi];
+                    if (view_less(kb, vb, ka, va)) { K[lo] = kb; V[lo] = vb; K[hi] = ka; V[hi] = va; }
                 }
             }
+            if (kThreads == 64) wave_sync(); else __syncthreads();
         }
-        const uint32_t read = (uint32_t)(k >> 28);
-        const int32_t pos = reads[read].pos + (int32_t)(k & 0x0FFFFFFFull) - 1;
-        unsigned long long prev = ~0ull;
-        for (unsigned long long a = i; a < j; a++) {
-            const unsigned long long kv = keys[a], vv = vals[a];
-            ViewRow r;
-            r.read = read; r.pos = pos; r.read_pos = (uint32_t)(vv & 0x0FFFFFFFull);
-            r.ins_offset = (uint16_t)((vv >> 40) & 0xFFFFull); r.code = (uint8_t)(vv >> 56); r.prob = (uint8_t)(kv >> 56);
-            rows[a] = r;
-            keep[a] = (vv >> 40) != prev;   // same (code, ins_offset) as the record in front: a later entry of the same key
-            prev = vv >> 40;
+    }
+}
+
+// sorted records -> rows; a record with the key (position, code, ins_offset) of the one in front is a later entry of that
+// key and is dropped.  Returns this thread's number of dropped rows.
+template <int kThreads, typename Ptr>
+__device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uint32_t tid, uint32_t r, int32_t rpos, ViewRow* __restrict__ out) {
+    uint32_t dropped = 0;
+    for (uint32_t i = tid; i < n; i += kThreads) {
+        unsigned long long k = K[i], v = V[i];
+        bool dup = false;
+        if (i > 0) {
+            unsigned long long kp = K[i - 1], vp = V[i - 1];
+            dup = ((uint32_t)kp & 0x0FFFFFFFu) == ((uint32_t)k & 0x0FFFFFFFu) && (vp >> 40) == (v >> 40);
+        }
+        ViewRow o;
+        o.read = dup ? kViewDropped : r;
+        o.pos = rpos + (int32_t)((uint32_t)k & 0x0FFFFFFFu) - 1;
+        o.read_pos = (uint32_t)(v & 0x0FFFFFFFull);
+        o.ins_offset = (uint16_t)((v >> 40) & 0xFFFFull); o.code = (uint8_t)(v >> 56); o.prob = (uint8_t)(k >> 56);
+        out[i] = o;
+        dropped += dup;
+    }
+    return dropped;
+}
+
+// Reads with up to kViewWaveRecs records (nearly all of them): one WAVEFRONT per read, records in the wave's 8 KB of LDS,
+// no workgroup barriers.  Bigger reads are put on a list for k_view_sort_big.
+__global__ __launch_bounds__(256) void k_view_sort(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+                                                   const unsigned int* __restrict__ offsets, uint32_t n_reads,
+                                                   const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows,
+                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped,
+                                                   unsigned int* __restrict__ big_list, unsigned int* __restrict__ big_count) {
+    __shared__ unsigned long long sk[kWavesPerBlock][kViewWaveRecs];
+    __shared__ unsigned long long sv[kWavesPerBlock][kViewWaveRecs];
+    const uint32_t wv = threadIdx.x >> 6, lane = (uint32_t)lane_id();
+    unsigned long long* K = sk[wv];
+    unsigned long long* V = sv[wv];
+    for (uint32_t r = blockIdx.x * kWavesPerBlock + wv; r < n_reads; r += gridDim.x * kWavesPerBlock) {
+        const uint32_t off = uniu(offsets[r]), n = uniu(offsets[r + 1]) - off;
+        if (n == 0) { if (lane == 0) kept[r] = 0; continue; }
+        if (n > kViewWaveRecs) {
+            if (lane == 0) big_list[atomicAdd(big_count, 1u)] = r;
+            continue;
+        }
+        wave_sync();
+        for (uint32_t i = lane; i < n; i += 64) { K[i] = keys[off + i]; V[i] = vals[off + i]; }
+        wave_sync();
+        view_bitonic<64>(K, V, n, lane);
+        uint32_t dropped = view_emit_rows<64>(K, V, n, lane, r, reads[r].pos, rows + off);
+        uint32_t tot = lane_valu(wave_incl_scan(dropped), 63);
+        if (lane == 0) {
+            kept[r] = n - tot;
+            if (tot) atomicAdd(n_dropped, tot);
+        }
+    }
+}
+
+// The reads k_view_sort left over: one workgroup per read; up to kViewLdsRecs records in LDS, beyond that the same
+// network on the records where they lie in global memory.
+__global__ __launch_bounds__(256) void k_view_sort_big(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
+                                                       const unsigned int* __restrict__ offsets, const mm_read_t* __restrict__ reads,
+                                                       ViewRow* __restrict__ rows, unsigned int* __restrict__ kept,
+                                                       unsigned int* __restrict__ n_dropped, const unsigned int* __restrict__ big_list,
+                                                       const unsigned int* __restrict__ big_count) {
+    __shared__ unsigned long long sk[kViewLdsRecs];
+    __shared__ unsigned long long sv[kViewLdsRecs];
+    __shared__ uint32_t drop_s;
+    const uint32_t n_big = *big_count;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t r = big_list[b];
+        const uint32_t off = offsets[r], n = offsets[r + 1] - off;
+        if (threadIdx.x == 0) drop_s = 0;
+        __syncthreads();
+        unsigned long long* gk = keys + off;
+        unsigned long long* gv = vals + off;
+        uint32_t dropped;
+        if (n <= kViewLdsRecs) {
+            for (uint32_t i = threadIdx.x; i < n; i += 256) { sk[i] = gk[i]; sv[i] = gv[i]; }
+            __syncthreads();
+            view_bitonic<256>(sk, sv, n, threadIdx.x);
+            dropped = view_emit_rows<256>(sk, sv, n, threadIdx.x, r, reads[r].pos, rows + off);
+        } else {
+            view_bitonic<256>(gk, gv, n, threadIdx.x);
+            dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
+        }
+        if (dropped) atomicAdd(&drop_s, dropped);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            kept[r] = n - drop_s;
+            if (drop_s) atomicAdd(n_dropped, drop_s);
+        }
+        __syncthreads();
+    }
+}
+
+// Only when rows were dropped: out[new_offsets[r] ...] = the kept rows of read r, in order (one workgroup per read).
+__global__ __launch_bounds__(256) void k_view_compact(const ViewRow* __restrict__ rows, const unsigned int* __restrict__ offsets,
+                                                      const unsigned int* __restrict__ new_offsets, uint32_t n_reads,
+                                                      ViewRow* __restrict__ out) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint32_t off = offsets[r], n = offsets[r + 1] - off;
+        if (threadIdx.x == 0) carry_s = new_offsets[r];
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += 256) {
+            uint32_t i = base + threadIdx.x;
+            ViewRow row;
+            bool keep = false;
+            if (i < n) { row = rows[off + i]; keep = row.read != kViewDropped; }
+            uint64_t b = __ballot(keep);
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t before = carry_s;
+            for (int w = 0; w < wv; w++) before += wsum[w];
+            if (keep) out[before + __popcll(b & lanemask_lt())] = row;
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            __syncthreads();
         }
     }
 }

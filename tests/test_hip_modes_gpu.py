@@ -39,6 +39,13 @@ for name, cs in cases.items():
     want = orc.rows()
     key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
     out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max())}
+    # the same batch through view mode: rows in print_view_output order, element for element
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, **cs["kw"])
+    v = eng.view(b); eng.close()
+    orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.set_view(True); orc.add_contig("chrS", ref); orc.process(b, threads=8)
+    w = orc.view_rows()
+    vk = lambda r, io: list(zip(r["read"].tolist(), r["pos"].tolist(), r["read_pos"].tolist(), r["code"].tolist(), r[io].tolist(), r["prob"].tolist()))
+    out[name]["view_rows"] = int(len(w)); out[name]["view_equal"] = vk(v, "ins_offset") == vk(w, "ins_off")
 print(json.dumps(out))
 '''
 
@@ -53,6 +60,7 @@ def test_synthetic_shapes_match_oracle(fused):
     for name, v in res.items():
         assert v["rows"] > 1000, (name, v)
         assert v["equal"], (name, v)
+        assert v["view_rows"] > 1000 and v["view_equal"], (name, v)
     assert res["ont_long"]["max_l"] > 40000
 
 
