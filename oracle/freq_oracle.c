@@ -4,7 +4,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call
  * this file.  The product path (minimod_amd/) never routes through it.
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against the
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement (freq and view modes) against the
  * reference's own golden files (reference test/expected/test3,4,5,5a,5b,5c,6,7,8,9,12,16) on the
  * reference's bundled BAMs, using the pseudo-references of tests/golden/make_fixtures.py, plus the
  * hand-built known-answer reads of SURVEY.md section 8(c).  The reference binary itself cannot be
