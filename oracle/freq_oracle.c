@@ -5,7 +5,8 @@
  * this file.  The product path (minimod_amd/) never routes through it.
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement (freq and view modes) against the
- * reference's own golden files (reference test/expected/test3,4,5,5a,5b,5c,6,7,8,9,12,16) on the
+ * reference's own golden files (reference test/expected/test3,4,5,5a,5b,5c,6,7,8,9,12,16 for freq and
+ * test1,2,2a,2b,2c,2c_wild,10,11,15,17a for view) on the
  * reference's bundled BAMs, using the pseudo-references of tests/golden/make_fixtures.py, plus the
  * hand-built known-answer reads of SURVEY.md section 8(c).  The reference binary itself cannot be
  * built here: it needs htslib 1.9 (reference scripts/install-hts.sh:9, Makefile:29-30), which this
