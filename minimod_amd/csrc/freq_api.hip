@@ -40,7 +40,9 @@ struct Slot {
     void* d_order = nullptr; size_t cap_order = 0;
     int32_t* d_status = nullptr; size_t cap_status = 0;
     uint32_t* d_spill = nullptr; size_t cap_spill = 0;
-    unsigned int* d_ctl = nullptr;   // [0] read queue, [1] err_summary, [4] fb_count, [5] fb_queue, [8..8+64) tile_count per region
+    unsigned int* d_ctl = nullptr;   // two sets of 128 words, used alternately: [0] read queue, [1] err_summary, [4] fb_count,
+                                     // [5] fb_queue, [8..8+64) tile_count per region.  A launch's last kernel resets the other set.
+    int ctl_set = 0;
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
     uint32_t* d_gdir = nullptr; size_t cap_gdir = 0;
@@ -221,7 +223,10 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), st));
         HIPCHK(hipMemsetAsync(s.d_vreadcount, 0, 4 * nr, st));
     }
-    p.queue = s.d_ctl; p.err_summary = s.d_ctl + 1;
+    unsigned int* const ctl = s.d_ctl + 128 * s.ctl_set;
+    unsigned int* const ctl_other = s.d_ctl + 128 * (s.ctl_set ^ 1);
+    p.queue = ctl; p.err_summary = ctl + 1;
+    p.ctl_next = ctl_other;
     TileParams tp;
     std::memset(&tp, 0, sizeof(tp));
     if (h->use_tiles) {
@@ -239,13 +244,14 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             return r;
         tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot; tp.g_nb = s.d_gnb; tp.g_sum = s.d_gsum; tp.g_qdir = s.d_gqdir; tp.g_rdir = s.d_grdir;
         tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap / kTileRegions + 64, 0x3FFFFFFu);
-        tp.tile_count = s.d_ctl + 8; tp.tile_queue = s.d_ctl + 3;
-        tp.fb_list = s.d_fb; tp.fb_count = s.d_ctl + 4;
+        tp.tile_count = ctl + 8; tp.tile_queue = ctl + 3;
+        tp.fb_list = s.d_fb; tp.fb_count = ctl + 4;
     }
-    for (int i = 0; i < 80; i++) s.h_ctl[i] = 0u;
-    s.h_ctl[1] = 0xFFFFFFFFu;
-    HIPCHK(hipMemcpyAsync(s.d_ctl, s.h_ctl, 80 * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(s.d_status, 0, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1), st));
+    if (b->n_reads <= 0) {   // no kernel will run: the set the next launch uses is reset from the host
+        for (int i = 0; i < kCtlWords; i++) s.h_ctl[i] = 0u;
+        s.h_ctl[1] = 0xFFFFFFFFu;
+        HIPCHK(hipMemcpyAsync(ctl_other, s.h_ctl, kCtlWords * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    }
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
         if (h->use_tiles) {
@@ -267,7 +273,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             }
             HIPCHK(hipGetLastError());
             // reads the tile form does not cover: the fused kernel over the fallback list (usually empty)
-            p.order = s.d_fb; p.n_items = 0; p.n_items_dev = s.d_ctl + 4; p.queue = s.d_ctl + 5;
+            p.order = s.d_fb; p.n_items = 0; p.n_items_dev = ctl + 4; p.queue = ctl + 5;
         }
         if (h->wide) {
             if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, st, p);
@@ -294,7 +300,8 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
-    HIPCHK(hipMemcpyAsync(s.h_ctl + 80, s.d_ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s.h_ctl + 80, ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    s.ctl_set ^= 1;
     if (h->opts.view)
         HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s.ev_done, st));
@@ -413,7 +420,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     for (auto& s : h->slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
-        if (dev_alloc(h, (void**)&s.d_ctl, 128 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        if (dev_alloc(h, (void**)&s.d_ctl, 256 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        {
+            unsigned int init[256];
+            for (int i = 0; i < 256; i++) init[i] = (i & 127) == 1 ? 0xFFFFFFFFu : 0u;
+            if (hipMemcpy(s.d_ctl, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) return fail(h, "control word init failed");
+        }
         if (hipHostMalloc((void**)&s.h_ctl, 160 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
         if (opts->view) {
             if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2))) return fail(h, "alloc failed");

@@ -115,7 +115,11 @@ struct DevParams {
     unsigned long long* view_vals;   // [kViewRegions][view_cap]  code << 56 | ins_offset << 40 | group << 29 | implicit << 28 | fastq read_pos
     unsigned int* view_count;        // [kViewRegions * kViewCountStride]; counts past view_cap mean "grow and run again"
     unsigned int* view_read_count;   // [n_reads] records per read (sizes the per-read segments of the ordering pass)
+    // the control words (queue, error summary, tile counters) the slot's NEXT launch will use: reset by this launch's
+    // last kernel, which saves a host-to-device copy per batch (a slot alternates between two sets)
+    unsigned int* ctl_next;
 };
+constexpr int kCtlWords = 80;
 constexpr uint32_t kViewRegions = 64;
 constexpr uint32_t kViewCountStride = 32;
 constexpr uint32_t kViewMaxGroup = 2047;   // group ordinals that fit the record; a read with more MM groups fails loudly
@@ -927,6 +931,7 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     const int wv = threadIdx.x >> 6;
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
     K1<RefWord, kView> k(p, lds[wv]);
+    if (p.ctl_next && blockIdx.x == 0 && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
     if (p.n_items_dev && *p.n_items_dev == 0u) return;   // empty fallback list: do not even touch the work counter
     for (;;) {
         int r = 0;

@@ -544,12 +544,12 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
     __shared__ ScanLds lds[kWavesPerBlock];
     KA<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
-    // three items per read (CIGAR scan, MM headers -> tiles, rank directory), the heaviest kind first; static
-    // round-robin over the (costliest-first) item list: a shared work counter would serialise ~12k dequeues
+    // three items per read (CIGAR scan, MM headers -> tiles, rank directory); static round-robin over the
+    // (costliest-first) item list: a shared work counter would serialise ~12k dequeues
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
     const int n = p.n_items;
     for (int r = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6); r < 3 * n; r += n_waves) {
-        const int kind = r / n, ri = r - kind * n;
+        const int ri = r / 3, kind = r - 3 * ri;   // kinds interleaved: the three items of the costliest reads all start at once
         uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
         item = uniu(item);
         const uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
