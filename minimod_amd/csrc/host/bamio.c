@@ -1,7 +1,12 @@
 /* bamio.c -- see bamio.h.  BGZF = a series of gzip members, each with a 'BC' extra subfield giving the block
- * size, at most 64 KiB of payload per block (SAM/BAM specification section 4.1).  The reader pulls a group of
- * blocks from the file, inflates them in parallel (raw deflate, zlib) into one contiguous window and parses BAM
- * records out of that window, carrying a partial record over to the next group. */
+ * size, at most 64 KiB of payload per block (SAM/BAM specification section 4.1).
+ *
+ * Pipeline: a producer thread reads groups of up to 256 BGZF blocks from the file and has the shared worker pool
+ * inflate them (raw deflate, zlib) into a CHUNK -- up to 16 MiB of decoded stream behind 4 MiB of head room -- while
+ * the consumer parses BAM records out of the chunks decoded earlier.  A record that straddles two chunks is made
+ * contiguous by copying its first part into the head room of the second chunk (or, for a record bigger than that,
+ * into a spill buffer).  Record views stay valid until mm_bam_release(): the loader parses a whole batch first and
+ * then copies it into the flattened pools with the same worker pool (mm_pool_for). */
 #include "bamio.h"
 
 #include <pthread.h>
@@ -10,8 +15,104 @@
 #include <zlib.h>
 
 #define GROUP_BLOCKS 256
-#define RAW_CAP (GROUP_BLOCKS * 65536 + 65536)
+#define CHUNK_HEAD ((size_t)4 << 20)
+#define CHUNK_PAYLOAD ((size_t)GROUP_BLOCKS * 65536)
+#define GROUP_CBYTES ((size_t)8 << 20)   /* compressed bytes read per group (a group is the whole blocks among them) */
+#define CHUNKS_AHEAD 4                   /* decoded chunks the producer may run ahead of the consumer */
 
+/* ------------------------------------------------------------------ worker pool */
+typedef struct pool_group {
+    int pending;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} pool_group_t;
+
+typedef struct pool_job {
+    void (*fn)(void *arg, int64_t lo, int64_t hi);
+    void *arg;
+    int64_t lo, hi;
+    pool_group_t *grp;
+} pool_job_t;
+
+#define POOL_QCAP 4096
+struct mm_pool {
+    int n_threads;
+    pthread_t *th;
+    pool_job_t q[POOL_QCAP];
+    int qhead, qtail, qlen;
+    int stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_job, cv_room;
+};
+
+static void *pool_worker(void *arg) {
+    mm_pool_t *p = (mm_pool_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (p->qlen == 0 && !p->stop) pthread_cond_wait(&p->cv_job, &p->mu);
+        if (p->qlen == 0 && p->stop) { pthread_mutex_unlock(&p->mu); return NULL; }
+        pool_job_t j = p->q[p->qhead];
+        p->qhead = (p->qhead + 1) % POOL_QCAP; p->qlen--;
+        pthread_cond_signal(&p->cv_room);
+        pthread_mutex_unlock(&p->mu);
+        j.fn(j.arg, j.lo, j.hi);
+        pthread_mutex_lock(&j.grp->mu);
+        if (--j.grp->pending == 0) pthread_cond_broadcast(&j.grp->cv);
+        pthread_mutex_unlock(&j.grp->mu);
+    }
+}
+
+mm_pool_t *mm_pool_create(int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    mm_pool_t *p = (mm_pool_t *)calloc(1, sizeof(*p));
+    if (!p) return NULL;
+    p->n_threads = n_threads;
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv_job, NULL);
+    pthread_cond_init(&p->cv_room, NULL);
+    p->th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int i = 0; i < n_threads; i++) pthread_create(&p->th[i], NULL, pool_worker, p);
+    return p;
+}
+
+void mm_pool_destroy(mm_pool_t *p) {
+    if (!p) return;
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->cv_job);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_job); pthread_cond_destroy(&p->cv_room);
+    free(p->th); free(p);
+}
+
+int mm_pool_threads(const mm_pool_t *p) { return p ? p->n_threads : 1; }
+
+void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *arg) {
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    if (!p || n <= grain) { fn(arg, 0, n); return; }
+    pool_group_t g;
+    g.pending = (int)((n + grain - 1) / grain);
+    pthread_mutex_init(&g.mu, NULL);
+    pthread_cond_init(&g.cv, NULL);
+    for (int64_t lo = 0; lo < n; lo += grain) {
+        pthread_mutex_lock(&p->mu);
+        while (p->qlen == POOL_QCAP) pthread_cond_wait(&p->cv_room, &p->mu);
+        pool_job_t *j = &p->q[p->qtail];
+        j->fn = fn; j->arg = arg; j->lo = lo; j->hi = lo + grain < n ? lo + grain : n; j->grp = &g;
+        p->qtail = (p->qtail + 1) % POOL_QCAP; p->qlen++;
+        pthread_cond_signal(&p->cv_job);
+        pthread_mutex_unlock(&p->mu);
+    }
+    pthread_mutex_lock(&g.mu);
+    while (g.pending > 0) pthread_cond_wait(&g.cv, &g.mu);
+    pthread_mutex_unlock(&g.mu);
+    pthread_mutex_destroy(&g.mu); pthread_cond_destroy(&g.cv);
+}
+
+/* ------------------------------------------------------------------ chunks */
 typedef struct {
     const uint8_t *cdata;
     uint32_t clen, isize;
@@ -19,21 +120,39 @@ typedef struct {
     int err;
 } blk_t;
 
+typedef struct chunk {
+    uint8_t *buf;        /* CHUNK_HEAD + CHUNK_PAYLOAD */
+    uint8_t *cbuf;       /* compressed bytes of the group */
+    size_t len;          /* decoded bytes at buf + CHUNK_HEAD */
+    int n_blk;
+    blk_t blk[GROUP_BLOCKS];
+    int err, last;       /* last: the file ended with this group */
+    struct chunk *next;
+} chunk_t;
+
 struct mm_bam {
     FILE *fp;
-    int n_threads;
+    mm_pool_t *pool;
+    int own_pool;
     mm_bam_hdr_t hdr;
-    /* compressed side */
-    uint8_t *cbuf;
-    size_t ccap, clen, cpos;
-    int eof;
-    /* decompressed window */
-    uint8_t *win;
-    size_t wcap, wlen, wpos;
-    blk_t blk[GROUP_BLOCKS];
-    /* pool */
-    int job_n, job_next;
+    /* producer */
+    pthread_t producer;
+    int producer_started;
     pthread_mutex_t mu;
+    pthread_cond_t cv_ready, cv_room;
+    chunk_t *ready_head, *ready_tail;   /* decoded, not yet taken by the consumer */
+    int n_ready;
+    chunk_t *free_list;
+    int quit;
+    uint8_t *carry;                     /* compressed bytes read past the last whole block of a group */
+    size_t carry_len, carry_cap;
+    /* consumer */
+    chunk_t *cur;                       /* chunk b->p points into (NULL while it points into a spill buffer) */
+    const uint8_t *p, *end;             /* unread decoded bytes */
+    chunk_t *held;                      /* chunks the consumer has left but whose records may still be in use */
+    uint8_t **spills; int n_spills;     /* assembled oversized records */
+    uint8_t *cur_spill;                 /* the spill buffer b->p points into, if any */
+    int eof, failed;
 };
 
 static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -51,168 +170,267 @@ static int inflate_block(blk_t *b) {
     return (r == Z_STREAM_END && zs.avail_out == 0) ? 0 : -1;
 }
 
-static void *worker(void *arg) {
-    mm_bam_t *b = (mm_bam_t *)arg;
-    for (;;) {
-        pthread_mutex_lock(&b->mu);
-        int i = b->job_next < b->job_n ? b->job_next++ : -1;
-        pthread_mutex_unlock(&b->mu);
-        if (i < 0) break;
-        b->blk[i].err = inflate_block(&b->blk[i]);
-    }
-    return NULL;
+static void inflate_range(void *arg, int64_t lo, int64_t hi) {
+    chunk_t *c = (chunk_t *)arg;
+    for (int64_t i = lo; i < hi; i++) c->blk[i].err = inflate_block(&c->blk[i]);
 }
 
-/* refill the compressed buffer so that at least `need` bytes are available at cpos (or EOF) */
-static void cfill(mm_bam_t *b, size_t need) {
-    if (b->clen - b->cpos >= need || b->eof) return;
-    memmove(b->cbuf, b->cbuf + b->cpos, b->clen - b->cpos);
-    b->clen -= b->cpos; b->cpos = 0;
-    while (b->clen < b->ccap && !b->eof) {
-        size_t n = fread(b->cbuf + b->clen, 1, b->ccap - b->clen, b->fp);
-        if (n == 0) { b->eof = 1; break; }
-        b->clen += n;
-    }
+static chunk_t *chunk_new(void) {
+    chunk_t *c = (chunk_t *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    c->buf = (uint8_t *)malloc(CHUNK_HEAD + CHUNK_PAYLOAD);
+    c->cbuf = (uint8_t *)malloc(GROUP_CBYTES + 65536 + 1024);
+    return c;
 }
+static void chunk_free(chunk_t *c) { if (c) { free(c->buf); free(c->cbuf); free(c); } }
 
-/* inflate the next group of blocks behind the unread tail of the window; returns bytes added, 0 at EOF, <0 on error */
-static long refill(mm_bam_t *b) {
-    size_t tail = b->wlen - b->wpos;
-    memmove(b->win, b->win + b->wpos, tail);
-    b->wlen = tail; b->wpos = 0;
-    cfill(b, (size_t)GROUP_BLOCKS * 65536);
+/* read one group of whole BGZF blocks into c->cbuf and lay out its blocks; 0 ok, -1 error */
+static int read_group(mm_bam_t *b, chunk_t *c) {
+    size_t have = 0;
+    const size_t ccap = GROUP_CBYTES + 65536 + 1024;
+    if (b->carry_len) { memcpy(c->cbuf, b->carry, b->carry_len); have = b->carry_len; b->carry_len = 0; }
+    int file_end = 0;
+    while (have < GROUP_CBYTES) {
+        size_t n = fread(c->cbuf + have, 1, GROUP_CBYTES - have, b->fp);
+        if (n == 0) { file_end = 1; break; }
+        have += n;
+    }
+    size_t pos = 0, out = 0;
     int n = 0;
-    size_t added = 0;
-    while (n < GROUP_BLOCKS) {
-        /* never move the compressed buffer while earlier blocks of this group still point into it */
-        if (b->clen - b->cpos < 28) {
-            if (n > 0) break;
-            cfill(b, 65536 + 28);
-            if (b->clen - b->cpos < 28) break;
+    for (;;) {
+        if (n == GROUP_BLOCKS) break;
+        if (have - pos < 18) {   /* not even a block header: need more bytes (or the file is over) */
+            if (file_end || n > 0) break;
+            size_t m = fread(c->cbuf + have, 1, ccap - have, b->fp);
+            if (m == 0) { file_end = 1; break; }
+            have += m;
+            continue;
         }
-        const uint8_t *h = b->cbuf + b->cpos;
+        const uint8_t *h = c->cbuf + pos;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
         uint32_t xlen = rd_u16(h + 10);
-        if (b->clen - b->cpos < 12 + (size_t)xlen) { if (n > 0) break; return -1; }
-        const uint8_t *x = h + 12, *xe = x + xlen;
-        int bsize = -1;
-        while (x + 4 <= xe) {
-            uint32_t sl = rd_u16(x + 2);
-            if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
-            x += 4 + sl;
+        size_t total = 0;
+        if (have - pos >= 12 + (size_t)xlen) {
+            const uint8_t *x = h + 12, *xe = x + xlen;
+            int bsize = -1;
+            while (x + 4 <= xe) {
+                uint32_t sl = rd_u16(x + 2);
+                if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
+                x += 4 + sl;
+            }
+            if (bsize < 0) return -1;
+            total = (size_t)bsize + 1;
+            if (total < 12 + (size_t)xlen + 8) return -1;
         }
-        if (bsize < 0) return -1;
-        size_t total = (size_t)bsize + 1;
-        if (b->clen - b->cpos < total) {
-            if (n > 0) break;
-            cfill(b, total);
-            h = b->cbuf + b->cpos;
-            if (b->clen - b->cpos < total) return -1;
+        if (total == 0 || have - pos < total) {   /* the block is cut off by the end of what was read */
+            if (n > 0) break;                      /* it starts the next group */
+            if (file_end) return -1;               /* truncated file */
+            size_t m = fread(c->cbuf + have, 1, ccap - have, b->fp);   /* a first block always fits: ccap > 64 KiB + header */
+            if (m == 0) file_end = 1;
+            have += m;
+            if (file_end && (total == 0 || have - pos < total)) return -1;
+            continue;
         }
-        blk_t *k = &b->blk[n];
+        blk_t *k = &c->blk[n];
         k->cdata = h + 12 + xlen;
         k->clen = (uint32_t)(total - xlen - 12 - 8);
         k->isize = rd_u32(h + total - 4);
         if (k->isize > 65536) return -1;
-        if (b->wlen + added + k->isize > b->wcap) {
-            /* cannot happen: the window holds a whole group plus the largest record tail; grow to be safe */
-            size_t ncap = b->wcap * 2;
-            uint8_t *nw = (uint8_t *)realloc(b->win, ncap);
-            if (!nw) return -1;
-            for (int j = 0; j < n; j++) b->blk[j].out = nw + (b->blk[j].out - b->win);
-            b->win = nw; b->wcap = ncap;
-        }
-        k->out = b->win + b->wlen + added;
+        k->out = c->buf + CHUNK_HEAD + out;
         k->err = 0;
-        added += k->isize;
-        b->cpos += total;
+        out += k->isize;
+        pos += total;
         n++;
-        /* cdata pointers stay valid: cfill only moves data when it needs more, and we asked for a whole group */
     }
-    if (n == 0) return 0;
-    b->job_n = n; b->job_next = 0;
-    int nt = b->n_threads;
-    if (nt > n) nt = n;
-    if (nt <= 1) worker(b);
-    else {
-        pthread_t th[64];
-        if (nt > 64) nt = 64;
-        for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, worker, b);
-        for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    size_t rest = have - pos;
+    if (rest) {
+        if (file_end && n == 0) return -1;   /* trailing bytes that are not a block */
+        if (rest > b->carry_cap) { b->carry = (uint8_t *)realloc(b->carry, rest); b->carry_cap = rest; }
+        memcpy(b->carry, c->cbuf + pos, rest);
+        b->carry_len = rest;
     }
-    for (int i = 0; i < n; i++) if (b->blk[i].err) return -1;
-    b->wlen += added;
-    return (long)added + 1; /* +1: a group of empty blocks (EOF marker) is not EOF by itself */
+    c->n_blk = n; c->len = out;
+    c->last = file_end && rest == 0;
+    return 0;
 }
 
-/* make `need` bytes available at wpos; 1 ok, 0 clean EOF, -1 error/truncated */
-static int want(mm_bam_t *b, size_t need) {
-    while (b->wlen - b->wpos < need) {
-        if (need + 65536 > b->wcap - (size_t)GROUP_BLOCKS * 65536) {
-            size_t ncap = need + (size_t)GROUP_BLOCKS * 65536 + 65536;
-            size_t tail = b->wlen - b->wpos;
-            uint8_t *nw = (uint8_t *)malloc(ncap);
-            if (!nw) return -1;
-            memcpy(nw, b->win + b->wpos, tail);
-            free(b->win);
-            b->win = nw; b->wcap = ncap; b->wlen = tail; b->wpos = 0;
+static void *producer_main(void *arg) {
+    mm_bam_t *b = (mm_bam_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(&b->mu);
+        while (!b->quit && b->n_ready >= CHUNKS_AHEAD) pthread_cond_wait(&b->cv_room, &b->mu);
+        if (b->quit) { pthread_mutex_unlock(&b->mu); return NULL; }
+        chunk_t *c = b->free_list;
+        if (c) b->free_list = c->next;
+        pthread_mutex_unlock(&b->mu);
+        if (!c) c = chunk_new();
+        if (!c) {   /* out of memory: tell the consumer through the failed flag */
+            pthread_mutex_lock(&b->mu);
+            b->failed = 1; b->n_ready = -1;
+            pthread_cond_broadcast(&b->cv_ready);
+            pthread_mutex_unlock(&b->mu);
+            return NULL;
         }
-        long r = refill(b);
-        if (r < 0) return -1;
-        if (r == 0) return (b->wlen - b->wpos) == 0 ? 0 : -1;
+        c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0;
+        if (!c->buf || !c->cbuf || read_group(b, c) != 0) c->err = 1;
+        else {
+            mm_pool_for(b->pool, c->n_blk, 4, inflate_range, c);
+            for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
+        }
+        int stop = c->err || c->last;
+        pthread_mutex_lock(&b->mu);
+        if (b->ready_tail) b->ready_tail->next = c; else b->ready_head = c;
+        b->ready_tail = c;
+        b->n_ready++;
+        pthread_cond_broadcast(&b->cv_ready);
+        pthread_mutex_unlock(&b->mu);
+        if (stop) return NULL;
+    }
+}
+
+static void hold(mm_bam_t *b, chunk_t *c) { c->next = b->held; b->held = c; }
+
+/* next decoded chunk (blocks until one is ready); NULL at end of file or on error (b->failed) */
+static chunk_t *take_chunk(mm_bam_t *b) {
+    if (b->eof) return NULL;
+    pthread_mutex_lock(&b->mu);
+    while (!b->ready_head && b->n_ready >= 0) pthread_cond_wait(&b->cv_ready, &b->mu);
+    chunk_t *c = b->ready_head;
+    if (c) {
+        b->ready_head = c->next;
+        if (!b->ready_head) b->ready_tail = NULL;
+        b->n_ready--;
+        pthread_cond_signal(&b->cv_room);
+    }
+    pthread_mutex_unlock(&b->mu);
+    if (!c) { b->failed = 1; b->eof = 1; return NULL; }
+    c->next = NULL;
+    if (c->err) { b->failed = 1; b->eof = 1; hold(b, c); return NULL; }
+    if (c->last) b->eof = 1;
+    return c;
+}
+
+/* make `need` contiguous bytes available at b->p; 1 ok, 0 clean end of file, -1 error / truncated */
+static int want(mm_bam_t *b, size_t need) {
+    while ((size_t)(b->end - b->p) < need) {
+        const size_t tail = (size_t)(b->end - b->p);
+        chunk_t *nx = take_chunk(b);
+        if (!nx) return (b->failed || tail) ? -1 : 0;
+        if (nx->len == 0 && tail == 0) { hold(b, nx); continue; }   /* a group of empty blocks (the EOF marker) */
+        if (tail <= CHUNK_HEAD && tail + nx->len >= need) {
+            /* the usual case: the unread tail moves into the head room of the next chunk */
+            uint8_t *start = nx->buf + CHUNK_HEAD - tail;
+            if (tail) memcpy(start, b->p, tail);
+            if (b->cur) hold(b, b->cur);
+            b->cur = nx; b->cur_spill = NULL;
+            b->p = start; b->end = nx->buf + CHUNK_HEAD + nx->len;
+        } else {
+            /* a record bigger than the head room, or spanning more than two chunks: assemble it in a spill buffer */
+            size_t have = tail + nx->len;
+            uint8_t *sp = (uint8_t *)malloc(have + 64);
+            if (!sp) { hold(b, nx); return -1; }
+            if (tail) memcpy(sp, b->p, tail);
+            memcpy(sp + tail, nx->buf + CHUNK_HEAD, nx->len);
+            hold(b, nx);   /* fully copied: nothing will point into it */
+            while (have < need) {
+                chunk_t *more = take_chunk(b);
+                if (!more) { free(sp); return -1; }
+                uint8_t *grown = (uint8_t *)realloc(sp, have + more->len + 64);
+                if (!grown) { free(sp); hold(b, more); return -1; }
+                sp = grown;
+                memcpy(sp + have, more->buf + CHUNK_HEAD, more->len);
+                have += more->len;
+                hold(b, more);
+            }
+            b->spills = (uint8_t **)realloc(b->spills, sizeof(uint8_t *) * (size_t)(b->n_spills + 1));
+            b->spills[b->n_spills++] = sp;
+            if (b->cur) hold(b, b->cur);
+            b->cur = NULL; b->cur_spill = sp;
+            b->p = sp; b->end = sp + have;
+        }
     }
     return 1;
 }
 
-mm_bam_t *mm_bam_open(const char *path, int n_threads) {
+void mm_bam_release(mm_bam_t *b) {
+    /* chunks the consumer has left behind go back to the producer; the one b->p points into stays */
+    pthread_mutex_lock(&b->mu);
+    while (b->held) {
+        chunk_t *c = b->held;
+        b->held = c->next;
+        c->next = b->free_list; b->free_list = c;
+    }
+    pthread_mutex_unlock(&b->mu);
+    int k = 0;
+    for (int i = 0; i < b->n_spills; i++) {
+        if (b->spills[i] == b->cur_spill) b->spills[k++] = b->spills[i];
+        else free(b->spills[i]);
+    }
+    b->n_spills = k;
+}
+
+mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
     FILE *fp = fopen(path, "rb");
     if (!fp) return NULL;
     mm_bam_t *b = (mm_bam_t *)calloc(1, sizeof(*b));
     b->fp = fp;
-    b->n_threads = n_threads < 1 ? 1 : n_threads;
-    b->ccap = (size_t)GROUP_BLOCKS * 65536 * 2 + 65536;
-    b->cbuf = (uint8_t *)malloc(b->ccap);
-    b->wcap = (size_t)RAW_CAP * 2;
-    b->win = (uint8_t *)malloc(b->wcap);
+    b->pool = pool;
     pthread_mutex_init(&b->mu, NULL);
-    if (!b->cbuf || !b->win) { mm_bam_close(b); return NULL; }
+    pthread_cond_init(&b->cv_ready, NULL);
+    pthread_cond_init(&b->cv_room, NULL);
+    if (pthread_create(&b->producer, NULL, producer_main, b) != 0) { mm_bam_close(b); return NULL; }
+    b->producer_started = 1;
     /* header */
-    if (want(b, 12) != 1 || memcmp(b->win + b->wpos, "BAM\1", 4) != 0) { mm_bam_close(b); return NULL; }
-    uint32_t l_text = rd_u32(b->win + b->wpos + 4);
+    if (want(b, 12) != 1 || memcmp(b->p, "BAM\1", 4) != 0) { mm_bam_close(b); return NULL; }
+    uint32_t l_text = rd_u32(b->p + 4);
     if (want(b, 12 + (size_t)l_text) != 1) { mm_bam_close(b); return NULL; }
-    b->wpos += 8 + l_text;
-    int32_t n_ref = (int32_t)rd_u32(b->win + b->wpos);
-    b->wpos += 4;
+    b->p += 8 + l_text;
+    int32_t n_ref = (int32_t)rd_u32(b->p);
+    b->p += 4;
+    if (n_ref < 0) { mm_bam_close(b); return NULL; }
     b->hdr.n_targets = n_ref;
     b->hdr.target_name = (char **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char *));
     b->hdr.target_len = (uint32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint32_t));
     for (int32_t i = 0; i < n_ref; i++) {
         if (want(b, 4) != 1) { mm_bam_close(b); return NULL; }
-        uint32_t l_name = rd_u32(b->win + b->wpos);
+        uint32_t l_name = rd_u32(b->p);
         if (want(b, 8 + (size_t)l_name) != 1) { mm_bam_close(b); return NULL; }
         b->hdr.target_name[i] = (char *)malloc(l_name + 1);
-        memcpy(b->hdr.target_name[i], b->win + b->wpos + 4, l_name);
+        memcpy(b->hdr.target_name[i], b->p + 4, l_name);
         b->hdr.target_name[i][l_name] = 0;
-        b->hdr.target_len[i] = rd_u32(b->win + b->wpos + 4 + l_name);
-        b->wpos += 8 + l_name;
+        b->hdr.target_len[i] = rd_u32(b->p + 4 + l_name);
+        b->p += 8 + l_name;
     }
+    mm_bam_release(b);
     return b;
 }
+
+mm_bam_t *mm_bam_open(const char *path, int n_threads) {
+    mm_pool_t *pool = mm_pool_create(n_threads);
+    if (!pool) return NULL;
+    mm_bam_t *b = mm_bam_open_pool(path, pool);
+    if (!b) { mm_pool_destroy(pool); return NULL; }
+    b->own_pool = 1;
+    return b;
+}
+
+mm_pool_t *mm_bam_pool(mm_bam_t *b) { return b->pool; }
 
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b) { return &b->hdr; }
 
 int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *r) {
     int w = want(b, 4);
     if (w <= 0) return w;
-    uint32_t bs = rd_u32(b->win + b->wpos);
+    uint32_t bs = rd_u32(b->p);
     if (bs < 32) return -1;
     w = want(b, 4 + (size_t)bs);
     if (w <= 0) return -1;
-    const uint8_t *p = b->win + b->wpos + 4;
+    const uint8_t *p = b->p + 4;
     r->tid = (int32_t)rd_u32(p); r->pos = (int32_t)rd_u32(p + 4);
     r->l_read_name = p[8]; r->mapq = p[9];
     r->n_cigar = rd_u16(p + 12); r->flag = rd_u16(p + 14);
     r->l_qseq = (int32_t)rd_u32(p + 16);
+    if (r->l_qseq < 0) return -1;
     size_t o = 32;
     r->qname = (const char *)(p + o); o += r->l_read_name;
     r->cigar = (const uint32_t *)(p + o); o += 4 * (size_t)r->n_cigar;
@@ -221,17 +439,29 @@ int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *r) {
     if (o > bs) return -1;
     r->aux = p + o; r->l_aux = (int32_t)(bs - o);
     r->l_data = (int32_t)(bs - 32 + ((4 - (r->l_read_name & 3)) & 3)); /* htslib pads qname to a multiple of 4 */
-    b->wpos += 4 + (size_t)bs;
+    b->p += 4 + (size_t)bs;
     return 1;
 }
 
 void mm_bam_close(mm_bam_t *b) {
     if (!b) return;
+    if (b->producer_started) {
+        pthread_mutex_lock(&b->mu);
+        b->quit = 1;
+        pthread_cond_broadcast(&b->cv_room);
+        pthread_mutex_unlock(&b->mu);
+        pthread_join(b->producer, NULL);
+    }
     if (b->fp) fclose(b->fp);
-    for (int32_t i = 0; i < b->hdr.n_targets; i++) free(b->hdr.target_name[i]);
+    for (int32_t i = 0; i < b->hdr.n_targets; i++) free(b->hdr.target_name ? b->hdr.target_name[i] : NULL);
     free(b->hdr.target_name); free(b->hdr.target_len);
-    free(b->cbuf); free(b->win);
-    pthread_mutex_destroy(&b->mu);
+    chunk_t *lists[3] = {b->ready_head, b->free_list, b->held};
+    for (int k = 0; k < 3; k++) for (chunk_t *c = lists[k]; c;) { chunk_t *n = c->next; chunk_free(c); c = n; }
+    chunk_free(b->cur);
+    for (int i = 0; i < b->n_spills; i++) free(b->spills[i]);
+    free(b->spills); free(b->carry);
+    if (b->own_pool) mm_pool_destroy(b->pool);
+    pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv_ready); pthread_cond_destroy(&b->cv_room);
     free(b);
 }
 
@@ -247,8 +477,8 @@ const uint8_t *mm_aux_get(const uint8_t *aux, int32_t l_aux, const char tag[2]) 
             case 'i': case 'I': case 'f': sz = 4; break;
             case 'd': sz = 8; break;
             case 'Z': case 'H': {
-                const uint8_t *z = t + 1;
-                while (z < e && *z) z++;
+                const uint8_t *z = (const uint8_t *)memchr(t + 1, 0, (size_t)(e - (t + 1)));
+                if (!z) z = e;
                 sz = (size_t)(z - (t + 1)) + 1;
                 break;
             }

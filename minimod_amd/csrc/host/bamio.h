@@ -1,6 +1,7 @@
 /* bamio.h -- minimal BGZF/BAM reader for the freq path (own code; replaces the htslib calls the reference makes:
  * sam_open/sam_hdr_read/sam_read1 reference src/minimod.c:73-90,250 and the aux accessors of src/mod.c:123-202).
- * BGZF blocks are inflated by a small thread pool (the reference gets this from hts_set_threads, minimod.c:76-78). */
+ * BGZF blocks are inflated by a worker pool, one group ahead of the parser (the reference gets block-level
+ * parallelism from hts_set_threads, minimod.c:76-78). */
 #ifndef MM_BAMIO_H
 #define MM_BAMIO_H
 #include <stdint.h>
@@ -12,7 +13,7 @@ typedef struct mm_bam_hdr {
     uint32_t *target_len;
 } mm_bam_hdr_t;
 
-/* a view of one alignment record inside the reader's buffer (valid until the next mm_bam_next) */
+/* a view of one alignment record inside the reader's buffers (valid until mm_bam_release) */
 typedef struct mm_bam_rec {
     int32_t tid, pos;
     uint16_t flag;
@@ -29,7 +30,19 @@ typedef struct mm_bam_rec {
 
 typedef struct mm_bam mm_bam_t;
 
-mm_bam_t *mm_bam_open(const char *path, int n_threads);
+/* worker pool shared by the reader (block inflate) and the loader (parallel copy into the flattened pools) */
+typedef struct mm_pool mm_pool_t;
+mm_pool_t *mm_pool_create(int n_threads);
+void mm_pool_destroy(mm_pool_t *p);
+int mm_pool_threads(const mm_pool_t *p);
+/* fn(arg, lo, hi) over [0, n) in pieces of `grain` items; returns when every piece is done */
+void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *arg);
+
+mm_bam_t *mm_bam_open(const char *path, int n_threads);        /* with its own pool of n_threads workers */
+mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool);  /* on a pool the caller owns */
+mm_pool_t *mm_bam_pool(mm_bam_t *b);
+/* record views handed out since the last release are no longer needed: their buffers may be reused */
+void mm_bam_release(mm_bam_t *b);
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b);
 /* 1 = record read, 0 = end of file, <0 = error */
 int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *rec);

@@ -1,6 +1,9 @@
 /* loader.c -- load_db (reference src/minimod.c:235-333) writing straight into the flattened batch of
  * include/minimod_hip.h instead of per-read mallocs: read filters, MM/ML/HP extraction (src/mod.c:123-202),
- * -K / -B batch limits.  Two pool sets let the caller fill batch N+1 while batch N is still being uploaded. */
+ * -K / -B batch limits.  A batch is built in two steps: the records are framed and filtered in file order (that part is
+ * sequential by definition: the -K / -B limits count ACCEPTED reads), then the worker pool copies them into the pools
+ * in parallel, every record to offsets fixed beforehand.  Two pool sets let the caller fill batch N+1 while batch N is
+ * still being uploaded. */
 #include <stdlib.h>
 #include <string.h>
 
@@ -13,21 +16,31 @@ typedef struct { uint8_t *p; size_t n, cap; } pool_t;
 
 static pool_t g_sets[2][NPOOL];
 
-static uint8_t *pool_take(pool_t *b, size_t bytes, size_t align) {
-    size_t pad = (align - (b->n % align)) % align;
-    size_t need = b->n + pad + bytes + 128;
-    if (need > b->cap) {
-        size_t nc = b->cap ? b->cap * 2 : (1 << 22);
-        while (nc < need) nc *= 2;
-        b->p = (uint8_t *)realloc(b->p, nc);
+/* one accepted record: where its parts lie in the reader's buffers and where they go in the pools */
+typedef struct {
+    const uint8_t *cigar, *seq, *mm, *ml;
+    const char *qname;
+    uint32_t n_cigar, l_qseq, mm_len, ml_len, qlen;
+    int32_t tid, pos;
+    uint16_t flag;
+    uint8_t hp;
+    size_t o_cigar, o_seq, o_mm, o_ml, o_qname;   /* byte offsets */
+} item_t;
+
+static item_t *g_items;
+static size_t g_items_cap;
+
+static void pool_reserve(pool_t *b, size_t bytes) {
+    if (bytes > b->cap) {
+        size_t nc = b->cap ? b->cap : ((size_t)1 << 22);
+        while (nc < bytes) nc *= 2;
+        free(b->p);                       /* contents are rebuilt for every batch */
+        b->p = (uint8_t *)malloc(nc);
         b->cap = nc;
     }
-    memset(b->p + b->n, 0, pad);
-    b->n += pad;
-    uint8_t *r = b->p + b->n;
-    b->n += bytes;
-    return r;
+    b->n = bytes;
 }
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary) {
     mm_bam_t *bam = mm_bam_open(bam_path, threads);
@@ -49,14 +62,51 @@ static int aux2i(const uint8_t *t) {   /* bam_aux2i on the type byte */
     }
 }
 
+typedef struct { pool_t *P; const item_t *it; } copy_ctx_t;
+
+/* copy records [lo, hi): every byte of the pools between the items (alignment padding) is zeroed by the item behind it */
+static void copy_range(void *arg, int64_t lo, int64_t hi) {
+    const copy_ctx_t *c = (const copy_ctx_t *)arg;
+    pool_t *P = c->P;
+    for (int64_t i = lo; i < hi; i++) {
+        const item_t *it = &c->it[i];
+        const item_t *pv = i > 0 ? &c->it[i - 1] : NULL;
+        size_t e;
+        mm_read_t *rd = (mm_read_t *)P[P_READS].p + i;
+        memset(rd, 0, sizeof(*rd));
+        e = pv ? pv->o_cigar + 4 * (size_t)pv->n_cigar : 0;
+        memset(P[P_CIGAR].p + e, 0, it->o_cigar - e);
+        memcpy(P[P_CIGAR].p + it->o_cigar, it->cigar, 4 * (size_t)it->n_cigar);
+        size_t sb = ((size_t)it->l_qseq + 1) / 2;
+        e = pv ? pv->o_seq + ((size_t)pv->l_qseq + 1) / 2 : 0;
+        memset(P[P_SEQ].p + e, 0, it->o_seq - e);
+        memcpy(P[P_SEQ].p + it->o_seq, it->seq, sb);
+        if (it->l_qseq & 1) P[P_SEQ].p[it->o_seq + sb - 1] &= 0xF0;   /* the unused low nibble must be zero for the device's base counts */
+        e = pv ? pv->o_mm + pv->mm_len + 1 : 0;
+        memset(P[P_MM].p + e, 0, it->o_mm - e);
+        memcpy(P[P_MM].p + it->o_mm, it->mm, it->mm_len);
+        P[P_MM].p[it->o_mm + it->mm_len] = 0;
+        e = pv ? pv->o_ml + pv->ml_len : 0;
+        memset(P[P_ML].p + e, 0, it->o_ml - e);
+        if (it->ml_len) memcpy(P[P_ML].p + it->o_ml, it->ml, it->ml_len);
+        memcpy(P[P_QNAME].p + it->o_qname, it->qname, it->qlen + 1);   /* bam_get_qname, printed by view (src/mod.c:571) */
+        uint64_t qo = it->o_qname;
+        memcpy(P[P_QOFF].p + 8 * (size_t)i, &qo, sizeof qo);
+        rd->cigar_off = it->o_cigar / 4; rd->seq_off = it->o_seq; rd->mm_off = it->o_mm; rd->ml_off = it->o_ml;
+        rd->tid = it->tid; rd->pos = it->pos; rd->l_qseq = it->l_qseq; rd->n_cigar = it->n_cigar;
+        rd->mm_len = it->mm_len; rd->ml_len = it->ml_len; rd->flag = it->flag; rd->hp = it->hp;
+    }
+}
+
 int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     pool_t *P = g_sets[set & 1];
-    for (int i = 0; i < NPOOL; i++) P[i].n = 0;
     int32_t n = 0, total = 0;
     int64_t total_bytes = 0, proc_bytes = 0;
     uint32_t max_cig = 0, max_l = 0;
+    size_t o_cigar = 0, o_seq = 0, o_mm = 0, o_ml = 0, o_qname = 0;
     mm_bam_rec_t rec;
     int rc = 1;
+    /* ---- step 1: frame + filter, in file order (minimod.c:249-333) */
     while (n < ld->K && proc_bytes < ld->B) {           /* minimod.c:249 */
         rc = mm_bam_next(ld->bam, &rec);
         if (rc <= 0) break;
@@ -65,55 +115,54 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
         if (!ld->allow_secondary && (rec.flag & 0x100)) continue;           /* secondary, :265 */
         if (ld->skip_supplementary && (rec.flag & 0x800)) continue;         /* supplementary, :270 */
         if (rec.l_qseq == 0) continue;                                      /* :275 */
-        const uint8_t *mmt = mm_aux_get(rec.aux, rec.l_aux, "MM");          /* get_mm_tag_ptr */
+        /* one walk over the tags: first MM (get_mm_tag_ptr), first ML (get_ml_tag: B:C with len > 0), first HP (get_hp_tag) */
+        const uint8_t *mmt = mm_aux_get(rec.aux, rec.l_aux, "MM");
         if (!mmt || (*mmt != 'Z' && *mmt != 'H')) continue;                 /* :280-284 */
         const char *mm = (const char *)(mmt + 1);
         size_t mm_len = strlen(mm);
-        const uint8_t *mlt = mm_aux_get(rec.aux, rec.l_aux, "ML");          /* get_ml_tag: B:C with len > 0, else none */
+        const uint8_t *mlt = mm_aux_get(rec.aux, rec.l_aux, "ML");
         const uint8_t *ml = NULL; uint32_t ml_len = 0;
         if (mlt && mlt[0] == 'B' && mlt[1] == 'C') {
             ml_len = (uint32_t)mlt[2] | ((uint32_t)mlt[3] << 8) | ((uint32_t)mlt[4] << 16) | ((uint32_t)mlt[5] << 24);
             ml = mlt + 6;
         }
-        const uint8_t *hpt = mm_aux_get(rec.aux, rec.l_aux, "HP");          /* get_hp_tag */
-        mm_read_t *rd = (mm_read_t *)pool_take(&P[P_READS], sizeof(mm_read_t), 64);
-        memset(rd, 0, sizeof(*rd));
-        uint8_t *c = pool_take(&P[P_CIGAR], 4 * (size_t)rec.n_cigar, 16);
-        memcpy(c, rec.cigar, 4 * (size_t)rec.n_cigar);
-        rd->cigar_off = (uint64_t)(c - P[P_CIGAR].p) / 4;
-        size_t sb = ((size_t)rec.l_qseq + 1) / 2;
-        uint8_t *s = pool_take(&P[P_SEQ], sb, 16);
-        memcpy(s, rec.seq, sb);
-        if (rec.l_qseq & 1) s[sb - 1] &= 0xF0;   /* the unused low nibble must be zero for the device's base counts */
-        rd->seq_off = (uint64_t)(s - P[P_SEQ].p);
-        uint8_t *m = pool_take(&P[P_MM], mm_len + 1, 16);
-        memcpy(m, mm, mm_len + 1);
-        rd->mm_off = (uint64_t)(m - P[P_MM].p);
-        uint8_t *l = pool_take(&P[P_ML], ml_len, 4);
-        if (ml_len) memcpy(l, ml, ml_len);
-        rd->ml_off = (uint64_t)(l - P[P_ML].p);
-        rd->tid = rec.tid; rd->pos = rec.pos; rd->l_qseq = (uint32_t)rec.l_qseq; rd->n_cigar = rec.n_cigar;
-        rd->mm_len = (uint32_t)mm_len; rd->ml_len = ml_len; rd->flag = rec.flag;
-        rd->hp = hpt ? (uint8_t)aux2i(hpt) : 0;
-        {   /* bam_get_qname, printed by view (src/mod.c:571) */
-            size_t ql = strlen(rec.qname);
-            uint8_t *q = pool_take(&P[P_QNAME], ql + 1, 1);
-            memcpy(q, rec.qname, ql + 1);
-            uint64_t qo = (uint64_t)(q - P[P_QNAME].p);
-            memcpy(pool_take(&P[P_QOFF], sizeof qo, 8), &qo, sizeof qo);
+        const uint8_t *hpt = mm_aux_get(rec.aux, rec.l_aux, "HP");
+        if ((size_t)n == g_items_cap) {
+            g_items_cap = g_items_cap ? g_items_cap * 2 : 1024;
+            g_items = (item_t *)realloc(g_items, g_items_cap * sizeof(item_t));
         }
+        item_t *it = &g_items[n];
+        it->cigar = (const uint8_t *)rec.cigar; it->seq = rec.seq; it->mm = (const uint8_t *)mm; it->ml = ml;
+        it->qname = rec.qname; it->qlen = (uint32_t)strlen(rec.qname);
+        it->n_cigar = rec.n_cigar; it->l_qseq = (uint32_t)rec.l_qseq; it->mm_len = (uint32_t)mm_len; it->ml_len = ml_len;
+        it->tid = rec.tid; it->pos = rec.pos; it->flag = rec.flag;
+        it->hp = hpt ? (uint8_t)aux2i(hpt) : 0;
+        /* pool offsets: cigar/seq/mm items start on 16-byte boundaries, ml on 4 */
+        o_cigar = align_up(o_cigar, 16); it->o_cigar = o_cigar; o_cigar += 4 * (size_t)rec.n_cigar;
+        o_seq = align_up(o_seq, 16); it->o_seq = o_seq; o_seq += ((size_t)rec.l_qseq + 1) / 2;
+        o_mm = align_up(o_mm, 16); it->o_mm = o_mm; o_mm += mm_len + 1;
+        o_ml = align_up(o_ml, 4); it->o_ml = o_ml; o_ml += ml_len;
+        it->o_qname = o_qname; o_qname += it->qlen + 1;
         if (rec.n_cigar > max_cig) max_cig = rec.n_cigar;
         if ((uint32_t)rec.l_qseq > max_l) max_l = (uint32_t)rec.l_qseq;
         n++;
         proc_bytes += rec.l_data;
         ld->processed_bases += (uint64_t)rec.l_qseq;
     }
-    /* padding between aligned items must not count as slack: add the zero tail every pool needs */
-    (void)pool_take(&P[P_CIGAR], 64, 16); (void)pool_take(&P[P_SEQ], 64, 16);
-    (void)pool_take(&P[P_MM], 64, 16); (void)pool_take(&P[P_ML], 64, 4);
-    memset(P[P_CIGAR].p + P[P_CIGAR].n - 64, 0, 64); memset(P[P_SEQ].p + P[P_SEQ].n - 64, 0, 64);
-    memset(P[P_MM].p + P[P_MM].n - 64, 0, 64); memset(P[P_ML].p + P[P_ML].n - 64, 0, 64);
-    /* reads were taken with 64-byte alignment from an empty pool: contiguous */
+    /* ---- step 2: sizes are known: reserve, copy in parallel, zero the tails (every pool ends in >= 64 zero bytes) */
+    size_t e_cigar = o_cigar, e_seq = o_seq, e_mm = o_mm, e_ml = o_ml;
+    o_cigar = align_up(o_cigar, 16) + 64; o_seq = align_up(o_seq, 16) + 64; o_mm = align_up(o_mm, 16) + 64; o_ml = align_up(o_ml, 4) + 64;
+    pool_reserve(&P[P_READS], sizeof(mm_read_t) * (size_t)(n > 0 ? n : 1));
+    pool_reserve(&P[P_CIGAR], o_cigar); pool_reserve(&P[P_SEQ], o_seq); pool_reserve(&P[P_MM], o_mm); pool_reserve(&P[P_ML], o_ml);
+    pool_reserve(&P[P_QOFF], 8 * (size_t)(n > 0 ? n : 1)); pool_reserve(&P[P_QNAME], o_qname + 1);
+    copy_ctx_t cc = {P, g_items};
+    mm_pool_t *pool = mm_bam_pool(ld->bam);
+    int nt = mm_pool_threads(pool);
+    int64_t grain = n / (4 * (nt > 0 ? nt : 1)) + 1;
+    mm_pool_for(pool, n, grain, copy_range, &cc);
+    memset(P[P_CIGAR].p + e_cigar, 0, o_cigar - e_cigar); memset(P[P_SEQ].p + e_seq, 0, o_seq - e_seq);
+    memset(P[P_MM].p + e_mm, 0, o_mm - e_mm); memset(P[P_ML].p + e_ml, 0, o_ml - e_ml);
+    mm_bam_release(ld->bam);
     memset(out, 0, sizeof(*out));
     out->reads = (const mm_read_t *)P[P_READS].p;
     out->cigar = (const uint32_t *)P[P_CIGAR].p; out->seq = P[P_SEQ].p; out->mm = P[P_MM].p; out->ml = P[P_ML].p;
@@ -139,5 +188,6 @@ void mmh_loader_close(mmh_loader_t *ld) {
     if (!ld) return;
     mm_bam_close(ld->bam);
     for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) { free(g_sets[s][i].p); memset(&g_sets[s][i], 0, sizeof(pool_t)); }
+    free(g_items); g_items = NULL; g_items_cap = 0;
     free(ld);
 }

@@ -28,6 +28,7 @@ cases = {
   "dot_hp_ins": dict(gen=dict(n=150, dot_fraction=1.0, haplotypes=True, long_insertions=True, max_len=20000.0), c=[("m","C")], th=[0.7],
                      kw=dict(insertions=True, haplotypes=True)),
   "star_ctx_single": dict(gen=dict(n=200, single_code=True), c=[("m","*")], th=[0.9], kw={}),
+  "dot_long": dict(gen=dict(n=60, dot_fraction=1.0), c=[("m","C")], th=[0.8], kw={}),   # view: tens of thousands of rows per read
 }
 for name, cs in cases.items():
     g = dict(cs["gen"]); n = g.pop("n")
@@ -56,7 +57,7 @@ def test_synthetic_shapes_match_oracle(fused):
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single"}
+    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long"}
     for name, v in res.items():
         assert v["rows"] > 1000, (name, v)
         assert v["equal"], (name, v)
