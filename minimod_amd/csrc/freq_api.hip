@@ -731,6 +731,8 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     HIPCHK(hipDeviceSynchronize());
     std::vector<mm_row_t>& rows = h->rows;
     rows.clear();
+    std::vector<size_t> run_starts;   // first row of every (plane, haplotype, strand) run of dense rows
+    size_t n_dense = 0;
     // ---- K2 over all planes at once: the flat counter array is [run][plane_len] with run = (plane*n_hp+hp)*2+strand
     int64_t n = h->n_counter_words;
     if (n > 0) {
@@ -774,7 +776,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
             int64_t last_run = -1;
             for (const DenseRow& d : dr) {
                 int64_t run = d.index / h->plane_len, off = d.index - run * h->plane_len;
-                if (run != last_run) { cursor = 0; last_run = run; }
+                if (run != last_run) { cursor = 0; last_run = run; run_starts.push_back(rows.size()); }
                 while (cursor + 1 < seg_tids.size() && h->cnt_base[seg_tids[cursor + 1]] <= off) cursor++;
                 int t = seg_tids[cursor];
                 int64_t rel = off - h->cnt_base[t];
@@ -792,6 +794,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
             }
         }
     }
+    n_dense = rows.size();
     // ---- side list
     unsigned long long ns = 0;
     HIPCHK(hipMemcpy(&ns, h->d_side_count, sizeof(ns), hipMemcpyDeviceToHost));
@@ -822,7 +825,32 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
         if (a.ins_offset != b.ins_offset) return a.ins_offset < b.ins_offset;
         return hpkey(a.hp) < hpkey(b.hp);
     };
-    std::sort(rows.begin(), rows.end(), less);
+    // The dense rows arrive as one run per (plane, haplotype, strand), each already in (contig segment, position) order:
+    // when every run is in output order (contig ranks follow the segment order, the usual case) the runs are merged
+    // pairwise -- O(n log runs) -- instead of sorting a million rows from scratch; the side rows are sorted on their own.
+    {
+        run_starts.push_back(n_dense);
+        bool runs_sorted = true;
+        for (size_t k = 0; k + 1 < run_starts.size() && runs_sorted; k++)
+            runs_sorted = std::is_sorted(rows.begin() + (ptrdiff_t)run_starts[k], rows.begin() + (ptrdiff_t)run_starts[k + 1], less);
+        if (!runs_sorted) {
+            std::sort(rows.begin(), rows.end(), less);
+        } else {
+            std::sort(rows.begin() + (ptrdiff_t)n_dense, rows.end(), less);
+            run_starts.push_back(rows.size());
+            while (run_starts.size() > 2) {
+                std::vector<size_t> next;
+                for (size_t k = 0; k + 2 < run_starts.size(); k += 2) {
+                    std::inplace_merge(rows.begin() + (ptrdiff_t)run_starts[k], rows.begin() + (ptrdiff_t)run_starts[k + 1],
+                                       rows.begin() + (ptrdiff_t)run_starts[k + 2], less);
+                    next.push_back(run_starts[k]);
+                }
+                if (run_starts.size() % 2 == 0) next.push_back(run_starts[run_starts.size() - 2]);
+                next.push_back(run_starts.back());
+                run_starts.swap(next);
+            }
+        }
+    }
     auto same_site = [](const mm_row_t& a, const mm_row_t& b) {
         return a.tid == b.tid && a.pos == b.pos && a.strand == b.strand && a.code == b.code && a.ins_offset == b.ins_offset;
     };
