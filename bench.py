@@ -219,6 +219,10 @@ def main():
         tstream.synchronize()
 
     if world > 1:
+        # warm the point-to-point path too (RCCL sets up its send/recv channels on first use: that must not land in
+        # the timed region), then start from clean counters again
+        exchange_halos(rank, world, export_fn, add_fn, make_buf, dist)
+        eng.reset()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
