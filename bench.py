@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0x5EED)
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = choose for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="also check rank 0's first batches against the oracle")
+    ap.add_argument("--dump", default="", help="write the device results of rank 0's first batches (freq: rows of the first two "
+                                                 "batches; view: rows of the first batch) to this .npz file; tests/ compare it with the oracle")
     ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
     ap.add_argument("--streams", type=int, default=1, help="1: every launch on one explicit stream; >1: the library's per-slot streams (up to 4 batches overlap)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra overlapped-streams measurement (use when profiling)")
@@ -89,6 +90,24 @@ def exchange_halos(rank, world, export_fn, add_fn, make_buf, dist):
         add_fn(recv)
 
 
+def gen_reference(plan, seed):
+    """A rank's reference: its own interval (+ halo + one read span past it) is generated, the rest stays 'N'."""
+    from minimod_amd import synth
+    ref = np.full(plan["contig_len"], ord("N"), dtype=np.uint8)
+    g_end = min(plan["contig_len"], plan["end"] + plan["halo"] + (1 << 20))
+    ref[plan["begin"]:g_end] = synth.reference_slice(seed, plan["begin"], g_end - plan["begin"])
+    return ref
+
+
+def gen_batch(ref, plan, rank, seed, reads, batch, bi, max_len=0.0):
+    """Batch `bi` of a rank's synthetic reads (deterministic: tests regenerate it to check a --dump file)."""
+    from minimod_amd import synth
+    first = bi * batch
+    n = min(batch, reads - first)
+    return synth.batch(ref, first, n, seed=seed + 7919 * rank, contig_len=plan["contig_len"], n_reads_total=reads,
+                       region_begin=plan["read_begin"], region_len=plan["read_len"], max_len=max_len)
+
+
 def algorithmic_bytes(reads, lookups, updates):
     """bytes the path must touch, summed over a batch."""
     n = len(reads)
@@ -121,17 +140,11 @@ def main():
 
     plan = shard_plan(rank, world)
     t0 = time.time()
-    # every rank generates the reference of its own interval (+ halo + one read span past it); the rest stays 'N'
-    ref = np.full(plan["contig_len"], ord("N"), dtype=np.uint8)
-    g_end = min(plan["contig_len"], plan["end"] + plan["halo"] + (1 << 20))
-    ref[plan["begin"]:g_end] = synth.reference_slice(args.seed, plan["begin"], g_end - plan["begin"])
+    ref = gen_reference(plan, args.seed)
     n_batches = (args.reads + args.batch - 1) // args.batch
 
     def gen(bi):
-        first = bi * args.batch
-        n = min(args.batch, args.reads - first)
-        return synth.batch(ref, first, n, seed=args.seed + 7919 * rank, contig_len=plan["contig_len"],
-                           n_reads_total=args.reads, region_begin=plan["read_begin"], region_len=plan["read_len"], max_len=args.max_len)
+        return gen_batch(ref, plan, rank, args.seed, args.reads, args.batch, bi, args.max_len)
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         host_batches = list(ex.map(gen, range(n_batches)))
@@ -287,8 +300,13 @@ def main():
             result["overlapped_streams"] = overlap
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, host_batches, plan, ref)
-        if args.verify:
-            result["verify"] = verify(host_batches[:2], plan, ref, local_rank)
+        if args.dump:
+            chk = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank)
+            for hb in host_batches[:2]:
+                chk.process(hb)
+            np.savez(args.dump, rows=chk.finalize())
+            chk.close()
+            result["dump"] = {"file": args.dump, "batches": min(2, len(host_batches))}
         print(json.dumps(result))
         sys.stdout.flush()
     eng.close()
@@ -366,6 +384,9 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
                          "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / args.steps},
             "gen_seconds": t_gen,
         }
+        if args.dump:
+            np.savez(args.dump, rows=eng.view(host_batches[0]))
+            result["dump"] = {"file": args.dump, "batches": 1}
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             cores = os.cpu_count() or 1
@@ -375,13 +396,6 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
             tc = time.perf_counter()
             orc.process(host_batches[0], threads=cores)
             tc = time.perf_counter() - tc
-            ok = None
-            if args.verify:
-                got = eng.view(host_batches[0])
-                w = orc.view_rows()
-                ok = bool(len(got) == len(w) and (got["read"] == w["read"]).all() and (got["pos"] == w["pos"]).all() and
-                          (got["read_pos"] == w["read_pos"]).all() and (got["prob"] == w["prob"]).all())
-                result["verify"] = {"rows": int(len(w)), "bit_exact": ok}
             orc.close()
             result["cpu_baseline"] = {"value": batch_bases[0] / tc / 1e6, "unit": "Mbases/s", "cores": cores, "kind": "port",
                                       "sample": "first -K %d batch (%d bases), oracle view mode with %d threads, process step only"
@@ -418,22 +432,6 @@ def cpu_baseline(args, host_batches, plan, ref):
     return {"value": bases / total_t / 1e6, "unit": "Mbases/s", "cores": cores, "kind": "port",
             "sample": "first %d of %d -K %d batches (%d bases), oracle/freq_oracle.c with %d threads, process step only"
                       % (min(n, len(host_batches)), len(host_batches), args.batch, bases, cores)}
-
-
-def verify(batches, plan, ref, device):
-    import minimod_amd
-    from oracle import oracle as O
-    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=device)
-    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
-    orc.add_contig("chrS", ref)
-    for hb in batches:
-        eng.process(hb)
-        orc.process(hb, threads=os.cpu_count() or 1)
-    got, want = eng.finalize(), orc.rows()
-    eng.close()
-    ok = (len(got) == len(want) and (got["pos"] == want["pos"]).all() and (got["strand"] == want["strand"]).all() and
-          (got["n_called"] == want["n_called"]).all() and (got["n_mod"] == want["n_mod"]).all())
-    return {"rows": int(len(got)), "bit_exact": bool(ok)}
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 WORKER = r'''
 import json, sys
@@ -65,14 +66,54 @@ def test_synthetic_shapes_match_oracle(fused):
     assert res["ont_long"]["max_l"] > 40000
 
 
-def test_device_resident_batches_and_bench_verify():
-    """bench.py's own check: resident batches through mm_freq_submit_device, compared with the oracle."""
+def _bench_batches(reads, batch, n):
+    """The batches bench.py generates for rank 0 (same functions, same seed)."""
+    import bench
+    plan = bench.shard_plan(0, 1)
+    ref = bench.gen_reference(plan, 0x5EED)
+    return plan, ref, [bench.gen_batch(ref, plan, 0, 0x5EED, reads, batch, bi) for bi in range(n)]
+
+
+def test_bench_freq_results_match_oracle(tmp_path):
+    """bench.py on device-resident batches (mm_freq_submit_device); its --dump of the first two batches' rows is
+    checked here against the oracle on the regenerated batches."""
+    from oracle import oracle as O
+    dump = str(tmp_path / "freq.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "6000", "--batch", "2048", "--steps", "6", "--warmup", "1",
-                        "--verify", "--cpu-sample-batches", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        "--dump", dump, "--cpu-sample-batches", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert d["verify"]["bit_exact"] and d["verify"]["rows"] > 1000
     assert d["unit"] == "Mbases/s" and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
+    got = np.load(dump)["rows"]
+    plan, ref, batches = _bench_batches(6000, 2048, 2)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    for hb in batches:
+        orc.process(hb, threads=os.cpu_count() or 1)
+    want = orc.rows()
+    assert len(want) > 1000 and len(got) == len(want)
+    for a, b in (("pos", "pos"), ("strand", "strand"), ("n_called", "n_called"), ("n_mod", "n_mod")):
+        assert (got[a] == want[b]).all()
+
+
+def test_bench_view_results_match_oracle(tmp_path):
+    from oracle import oracle as O
+    dump = str(tmp_path / "view.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "view", "--reads", "4096", "--batch", "2048", "--steps", "4",
+                        "--warmup", "1", "--dump", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["metric"] == "minimod view Mbases/sec" and d["value"] > 0
+    got = np.load(dump)["rows"]
+    plan, ref, batches = _bench_batches(4096, 2048, 1)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.set_view(True)
+    orc.add_contig("chrS", ref)
+    orc.process(batches[0], threads=os.cpu_count() or 1)
+    want = orc.view_rows()
+    assert len(want) > 10000 and len(got) == len(want)
+    for a, b in (("read", "read"), ("pos", "pos"), ("read_pos", "read_pos"), ("prob", "prob"), ("ins_offset", "ins_off")):
+        assert (got[a] == want[b]).all()
 
 
 SHARD_WORKER = r'''
