@@ -287,16 +287,17 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     if (h->opts.view && b->n_reads > 0) {
         // order the rows (view_kernels.hip.h): counting sort by read, then one small sort per read.  Everything takes its
         // sizes from device memory, so nothing here waits for the call kernels.
-        unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates, [1] reads on the big list
+        unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates
         const uint32_t nr = (uint32_t)b->n_reads;
         hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
         hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount,
                            s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
-        // big-read list: d_vnewoff doubles as the list (it is only needed again when rows were dropped, after the sorts)
-        hipLaunchKernelGGL(k_view_sort, dim3(std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 5)), dim3(256), 0, st,
-                           s.d_ka, s.d_va, s.d_voff, nr, b->reads, s.d_vrows, s.d_vkept, tail, s.d_vnewoff, tail + 1);
-        hipLaunchKernelGGL(k_view_sort_big, dim3(std::min<uint32_t>(nr, (uint32_t)h->n_cu * 2)), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff,
-                           b->reads, s.d_vrows, s.d_vkept, tail, s.d_vnewoff, tail + 1);
+        {
+            const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
+            const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
+            hipLaunchKernelGGL(k_view_sort, dim3(big_blocks + small_blocks), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff, nr, big_blocks, b->reads,
+                               s.d_vrows, s.d_vkept, tail);
+        }
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));

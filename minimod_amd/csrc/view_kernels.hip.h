@@ -7,10 +7,10 @@
 // one small sort per read -- no global sort:
 //   1. k_view_offsets  exclusive scan of the per-read record counts                       (one block)
 //   2. k_view_scatter  every record to its read's segment (one cursor atomic per record, ~100 records per cursor)
-//   3. k_view_sort     one wavefront per read: bitonic sort of the segment on (position, code, ins_offset, the order the
-//                      reference met the calls in) in LDS, later entries of a key marked, rows expanded to the 16-byte form
-//                      of the C ABI; reads with more than 512 records go to k_view_sort_big (one workgroup per read, LDS up
-//                      to 4096 records, in place in global memory beyond)
+//   3. k_view_sort     bitonic sort of every read's segment on (position, code, ins_offset, the order the reference met
+//                      the calls in), later entries of a key marked, rows expanded to the 16-byte form of the C ABI: one
+//                      wavefront per read up to 512 records (LDS), one workgroup per bigger read (LDS up to 2048 records,
+//                      in place in global memory beyond), both kinds of workers in the same launch
 //   4. k_view_compact  only when some read had duplicate keys: rows of every read moved down over the dropped ones.
 #pragma once
 #include "freq_kernels.hip.h"
@@ -28,8 +28,8 @@ struct ViewRow {   // == mm_view_row_t
 static_assert(sizeof(ViewRow) == 16, "ViewRow must be 16 bytes");
 
 constexpr uint32_t kViewDropped = 0xFFFFFFFFu;   // ViewRow.read of a dropped duplicate (before k_view_compact)
-constexpr uint32_t kViewWaveRecs = 512;          // records one wavefront sorts in its 8 KB of LDS
-constexpr uint32_t kViewLdsRecs = 4096;          // records a workgroup sorts in LDS (64 KB)
+constexpr uint32_t kViewWaveRecs = 512;          // records one wavefront sorts in its slice of the LDS (8 KB)
+constexpr uint32_t kViewLdsRecs = 2048;          // records a workgroup sorts in LDS (32 KB)
 
 // offsets[r] = number of records of reads < r; offsets[n_reads] = total.  One block; thread t owns the reads
 // [t*chunk, (t+1)*chunk): sum them, scan the 256 sums, write the offsets (cursors are zeroed on the way).
@@ -138,25 +138,55 @@ __device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uin
     return dropped;
 }
 
-// Reads with up to kViewWaveRecs records (nearly all of them): one WAVEFRONT per read, records in the wave's 8 KB of LDS,
-// no workgroup barriers.  Bigger reads are put on a list for k_view_sort_big.
-__global__ __launch_bounds__(256) void k_view_sort(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
-                                                   const unsigned int* __restrict__ offsets, uint32_t n_reads,
+// One launch, two kinds of workers, so that the few big reads do not serialise behind the many small ones:
+//   blocks [0, n_big_blocks)   take the reads with MORE than kViewWaveRecs records, one workgroup per read (records in
+//                              the workgroup's 32 KB of LDS up to kViewLdsRecs, in place in global memory beyond);
+//   the other blocks           take the reads with up to kViewWaveRecs records (nearly all of them), one WAVEFRONT per
+//                              read in its own slice of the same LDS, no workgroup barriers.
+__global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
+                                                   const unsigned int* __restrict__ offsets, uint32_t n_reads, uint32_t n_big_blocks,
                                                    const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows,
-                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped,
-                                                   unsigned int* __restrict__ big_list, unsigned int* __restrict__ big_count) {
-    __shared__ unsigned long long sk[kWavesPerBlock][kViewWaveRecs];
-    __shared__ unsigned long long sv[kWavesPerBlock][kViewWaveRecs];
+                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped) {
+    __shared__ unsigned long long sk[kViewLdsRecs];
+    __shared__ unsigned long long sv[kViewLdsRecs];
+    __shared__ uint32_t drop_s;
+    static_assert(kViewLdsRecs >= kWavesPerBlock * kViewWaveRecs, "one LDS layout for both kinds of workers");
+    if (blockIdx.x < n_big_blocks) {
+        for (uint32_t r = blockIdx.x; r < n_reads; r += n_big_blocks) {
+            const uint32_t off = offsets[r], n = offsets[r + 1] - off;
+            if (n <= kViewWaveRecs) continue;   // a wave's job
+            if (threadIdx.x == 0) drop_s = 0;
+            __syncthreads();
+            unsigned long long* gk = keys + off;
+            unsigned long long* gv = vals + off;
+            uint32_t dropped;
+            if (n <= kViewLdsRecs) {
+                for (uint32_t i = threadIdx.x; i < n; i += 256) { sk[i] = gk[i]; sv[i] = gv[i]; }
+                __syncthreads();
+                view_bitonic<256>(sk, sv, n, threadIdx.x);
+                dropped = view_emit_rows<256>(sk, sv, n, threadIdx.x, r, reads[r].pos, rows + off);
+            } else {
+                view_bitonic<256>(gk, gv, n, threadIdx.x);
+                dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
+            }
+            if (dropped) atomicAdd(&drop_s, dropped);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                kept[r] = n - drop_s;
+                if (drop_s) atomicAdd(n_dropped, drop_s);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const uint32_t wv = threadIdx.x >> 6, lane = (uint32_t)lane_id();
-    unsigned long long* K = sk[wv];
-    unsigned long long* V = sv[wv];
-    for (uint32_t r = blockIdx.x * kWavesPerBlock + wv; r < n_reads; r += gridDim.x * kWavesPerBlock) {
+    unsigned long long* K = sk + wv * kViewWaveRecs;
+    unsigned long long* V = sv + wv * kViewWaveRecs;
+    const uint32_t n_small_waves = (gridDim.x - n_big_blocks) * kWavesPerBlock;
+    for (uint32_t r = (blockIdx.x - n_big_blocks) * kWavesPerBlock + wv; r < n_reads; r += n_small_waves) {
         const uint32_t off = uniu(offsets[r]), n = uniu(offsets[r + 1]) - off;
         if (n == 0) { if (lane == 0) kept[r] = 0; continue; }
-        if (n > kViewWaveRecs) {
-            if (lane == 0) big_list[atomicAdd(big_count, 1u)] = r;
-            continue;
-        }
+        if (n > kViewWaveRecs) continue;        // a workgroup's job
         wave_sync();
         for (uint32_t i = lane; i < n; i += 64) { K[i] = keys[off + i]; V[i] = vals[off + i]; }
         wave_sync();
@@ -167,44 +197,6 @@ __global__ __launch_bounds__(256) void k_view_sort(const unsigned long long* __r
             kept[r] = n - tot;
             if (tot) atomicAdd(n_dropped, tot);
         }
-    }
-}
-
-// The reads k_view_sort left over: one workgroup per read; up to kViewLdsRecs records in LDS, beyond that the same
-// network on the records where they lie in global memory.
-__global__ __launch_bounds__(256) void k_view_sort_big(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
-                                                       const unsigned int* __restrict__ offsets, const mm_read_t* __restrict__ reads,
-                                                       ViewRow* __restrict__ rows, unsigned int* __restrict__ kept,
-                                                       unsigned int* __restrict__ n_dropped, const unsigned int* __restrict__ big_list,
-                                                       const unsigned int* __restrict__ big_count) {
-    __shared__ unsigned long long sk[kViewLdsRecs];
-    __shared__ unsigned long long sv[kViewLdsRecs];
-    __shared__ uint32_t drop_s;
-    const uint32_t n_big = *big_count;
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
-        const uint32_t r = big_list[b];
-        const uint32_t off = offsets[r], n = offsets[r + 1] - off;
-        if (threadIdx.x == 0) drop_s = 0;
-        __syncthreads();
-        unsigned long long* gk = keys + off;
-        unsigned long long* gv = vals + off;
-        uint32_t dropped;
-        if (n <= kViewLdsRecs) {
-            for (uint32_t i = threadIdx.x; i < n; i += 256) { sk[i] = gk[i]; sv[i] = gv[i]; }
-            __syncthreads();
-            view_bitonic<256>(sk, sv, n, threadIdx.x);
-            dropped = view_emit_rows<256>(sk, sv, n, threadIdx.x, r, reads[r].pos, rows + off);
-        } else {
-            view_bitonic<256>(gk, gv, n, threadIdx.x);
-            dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
-        }
-        if (dropped) atomicAdd(&drop_s, dropped);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            kept[r] = n - drop_s;
-            if (drop_s) atomicAdd(n_dropped, drop_s);
-        }
-        __syncthreads();
     }
 }
 
