@@ -326,6 +326,7 @@ static int want(mm_bam_t *b, size_t need) {
             b->p = start; b->end = nx->buf + CHUNK_HEAD + nx->len;
         } else {
             /* a record bigger than the head room, or spanning more than two chunks: assemble it in a spill buffer */
+            if (getenv("MM_BAM_DEBUG")) fprintf(stderr, "[bamio] spill: tail %zu need %zu\n", tail, need);
             size_t have = tail + nx->len;
             uint8_t *sp = (uint8_t *)malloc(have + 64);
             if (!sp) { hold(b, nx); return -1; }

@@ -187,3 +187,69 @@ def test_synthetic_bam_roundtrip(tmp_path):
         _same_batch(a, c)
     n_records = sum(1 for _ in pybam.BamFile(p))
     assert n_records > 800      # the unmapped / secondary / tag-less copies are in the file
+
+
+def _raw_batch(lengths):
+    """Reads of the given lengths built straight into the flattened layout (random bases, one `N+m?` call each)."""
+    rng = np.random.default_rng(5)
+    n = len(lengths)
+    reads = np.zeros(n, dtype=pybam.READ_DTYPE)
+    cig, seq, mm, ml = [], [], [], []
+    co = so = mo = lo = 0
+    for i, L in enumerate(lengths):
+        nib = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, L + (L & 1))]
+        if L & 1:
+            nib[-1] = 0
+        packed = (nib[0::2] << 4) | nib[1::2]
+        text = b"N+m?,%d;" % (i % 7)
+        r = reads[i]
+        r["cigar_off"], r["seq_off"], r["mm_off"], r["ml_off"] = co, so, mo, lo
+        r["tid"], r["pos"], r["l_qseq"], r["n_cigar"], r["mm_len"], r["ml_len"], r["flag"] = 0, 10 + i, L, 1, len(text), 1, 0
+        c = np.zeros(4, dtype="<u4"); c[0] = (L << 4) | 0
+        cig.append(c); co += 4
+        s = np.zeros((len(packed) + 15) // 16 * 16, dtype=np.uint8); s[:len(packed)] = packed
+        seq.append(s); so += len(s)
+        m = np.zeros((len(text) + 1 + 15) // 16 * 16, dtype=np.uint8); m[:len(text)] = np.frombuffer(text, dtype=np.uint8)
+        mm.append(m); mo += len(m)
+        l = np.zeros(4, dtype=np.uint8); l[0] = 200 + i
+        ml.append(l); lo += 4
+    pad = lambda parts, dt: np.concatenate(parts + [np.zeros(64, dtype=dt)])
+    return {"reads": reads, "cigar": pad(cig, "<u4"), "seq": pad(seq, np.uint8), "mm": pad(mm, np.uint8), "ml": pad(ml, np.uint8)}
+
+
+def test_loader_record_bigger_than_head_room_and_many_chunks(tmp_path):
+    """Records of 5, 5, 9 and 0.1 MB: the 9 MB one starts 6 MB before the end of the first 16 MiB chunk of decoded stream,
+    more than the reader's 4 MiB head room (the spill path of bamio.c); then a 60 MB stream of ordinary reads (several
+    chunks, records straddling them through the head room).  1 and 5 worker threads; same batches as the Python reader."""
+    from minimod_amd import hostlib, synth
+    b = _raw_batch([50, 3_300_000, 3_300_000, 6_000_000, 70_000, 33])
+    p = str(tmp_path / "giant.bam")
+    synth.write_bam(p, [("chrT", 8_000_000)], [b], filter_fodder=False)
+    want = [x for _, x, _ in pybam.load_batches(p, K=4, B=10 ** 9)]
+    for th in (1, 5):
+        got = list(hostlib.load_batches(p, K=4, B=10 ** 9, threads=th))
+        assert [len(g["reads"]) for g in got] == [4, 2] == [len(w["reads"]) for w in want]
+        for a, c in zip(want, got):
+            _same_batch(a, c)
+    ref = synth.reference(9, 4 << 20)
+    bs = [synth.batch(ref, i * 700, 700, seed=4, n_reads_total=2100) for i in range(3)]
+    p2 = str(tmp_path / "multi.bam")
+    synth.write_bam(p2, [("chrS", len(ref))], bs)
+    want = [x for _, x, _ in pybam.load_batches(p2, K=333, B=10 ** 9) if len(x["reads"])]
+    for th in (1, 5):
+        got = [g for g in hostlib.load_batches(p2, K=333, B=10 ** 9, threads=th) if len(g["reads"])]
+        assert len(got) == len(want) and sum(len(g["reads"]) for g in got) == 2100
+        for a, c in zip(want, got):
+            _same_batch(a, c)
+
+
+def test_loader_reports_truncated_file(tmp_path):
+    from minimod_amd import hostlib, synth
+    ref = synth.reference(9, 1 << 20)
+    p = str(tmp_path / "t.bam")
+    synth.write_bam(p, [("chrS", len(ref))], [synth.batch(ref, 0, 200, seed=4, n_reads_total=200)])
+    raw = open(p, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(raw[:len(raw) * 2 // 3])
+    with pytest.raises(IOError):
+        list(hostlib.load_batches(cut, K=4096, B=10 ** 9, threads=3))
