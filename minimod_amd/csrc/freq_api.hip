@@ -41,8 +41,9 @@ struct Slot {
     int32_t* d_status = nullptr; size_t cap_status = 0;
     uint32_t* d_spill = nullptr; size_t cap_spill = 0;
     unsigned int* d_ctl = nullptr;   // two sets of 128 words, used alternately: [0] read queue, [1] err_summary, [4] fb_count,
-                                     // [5] fb_queue, [8..8+64) tile_count per region.  A launch's last kernel resets the other set.
+                                     // [5] fb_queue, [8..72) tile_count per region.  A launch's last kernel resets the other set.
     int ctl_set = 0;
+    unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue counters, 128 bytes apart, alternating with the control sets
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
     uint32_t* d_gdir = nullptr; size_t cap_gdir = 0;
@@ -223,10 +224,11 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), st));
         HIPCHK(hipMemsetAsync(s.d_vreadcount, 0, 4 * nr, st));
     }
-    unsigned int* const ctl = s.d_ctl + 128 * s.ctl_set;
-    unsigned int* const ctl_other = s.d_ctl + 128 * (s.ctl_set ^ 1);
+    unsigned int* const ctl = s.d_ctl + kCtlSetWords * s.ctl_set;
+    unsigned int* const ctl_other = s.d_ctl + kCtlSetWords * (s.ctl_set ^ 1);
     p.queue = ctl; p.err_summary = ctl + 1;
     p.ctl_next = ctl_other;
+    p.queue_next = s.d_tq + 64 * kQueueStride * (s.ctl_set ^ 1);
     TileParams tp;
     std::memset(&tp, 0, sizeof(tp));
     if (h->use_tiles) {
@@ -244,13 +246,14 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             return r;
         tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot; tp.g_nb = s.d_gnb; tp.g_sum = s.d_gsum; tp.g_qdir = s.d_gqdir; tp.g_rdir = s.d_grdir;
         tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap / kTileRegions + 64, 0x3FFFFFFu);
-        tp.tile_count = ctl + 8; tp.tile_queue = ctl + 3;
+        tp.tile_count = ctl + 8; tp.tile_queue = s.d_tq + 64 * kQueueStride * s.ctl_set;
         tp.fb_list = s.d_fb; tp.fb_count = ctl + 4;
     }
     if (b->n_reads <= 0) {   // no kernel will run: the set the next launch uses is reset from the host
         for (int i = 0; i < kCtlWords; i++) s.h_ctl[i] = 0u;
         s.h_ctl[1] = 0xFFFFFFFFu;
         HIPCHK(hipMemcpyAsync(ctl_other, s.h_ctl, kCtlWords * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(s.d_tq + 64 * kQueueStride * (s.ctl_set ^ 1), 0, 64 * kQueueStride * sizeof(unsigned int), st));
     }
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
@@ -301,7 +304,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
-    HIPCHK(hipMemcpyAsync(s.h_ctl + 80, ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s.h_ctl + 128, ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     s.ctl_set ^= 1;
     if (h->opts.view)
         HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, st));
@@ -361,7 +364,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
-        void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl,
+        void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_tiles, s.d_fb,
                       s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
@@ -421,13 +424,15 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     for (auto& s : h->slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
-        if (dev_alloc(h, (void**)&s.d_ctl, 256 * sizeof(unsigned int))) return fail(h, "alloc failed");
+        if (dev_alloc(h, (void**)&s.d_ctl, 2 * kCtlSetWords * sizeof(unsigned int))) return fail(h, "alloc failed");
         {
-            unsigned int init[256];
-            for (int i = 0; i < 256; i++) init[i] = (i & 127) == 1 ? 0xFFFFFFFFu : 0u;
+            unsigned int init[2 * kCtlSetWords];
+            for (int i = 0; i < 2 * kCtlSetWords; i++) init[i] = (i % kCtlSetWords) == 1 ? 0xFFFFFFFFu : 0u;
             if (hipMemcpy(s.d_ctl, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) return fail(h, "control word init failed");
+            if (dev_alloc(h, (void**)&s.d_tq, 2 * 64 * kQueueStride * sizeof(unsigned int))) return fail(h, "alloc failed");
+            if (hipMemset(s.d_tq, 0, 2 * 64 * kQueueStride * sizeof(unsigned int)) != hipSuccess) return fail(h, "control word init failed");
         }
-        if (hipHostMalloc((void**)&s.h_ctl, 160 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        if (hipHostMalloc((void**)&s.h_ctl, 512 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
         if (opts->view) {
             if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2))) return fail(h, "alloc failed");
             if (hipHostMalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipHostMallocDefault) != hipSuccess)
@@ -682,7 +687,7 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_done) != hipSuccess) return MM_E_HIP;
     s.busy = false;
-    unsigned int sum = s.h_ctl[81];
+    unsigned int sum = s.h_ctl[129];
     if (sum != 0xFFFFFFFFu) {
         if (bad_read) *bad_read = (int32_t)(sum >> 8);
         return (int32_t)(sum & 0xFFu);
@@ -910,7 +915,7 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipEventSynchronize(s.ev_done));
         s.busy = false;
-        unsigned int sum = s.h_ctl[81];
+        unsigned int sum = s.h_ctl[129];
         if (sum != 0xFFFFFFFFu) {
             if (bad_read) *bad_read = (int32_t)(sum >> 8);
             return -(int64_t)(sum & 0xFFu);

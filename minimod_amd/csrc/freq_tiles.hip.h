@@ -57,7 +57,7 @@ struct TileParams {
     uint2* g_sum;             // per tile: x = tokens | n_codes << 16, y = sum(skip+1)
     unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
     unsigned int tile_cap;    // records per region
-    unsigned int* tile_queue; // unused (kept for layout)
+    unsigned int* tile_queue; // [kTileRegions * kQueueStride] next tile of each region for k_call_tiles (dynamic hand-out behind the static first round)
     int32_t* fb_list;         // reads left to the fused kernel
     unsigned int* fb_count;
 };
@@ -1134,19 +1134,29 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     if (n_tiles > P.tile_cap) n_tiles = P.tile_cap;
     n_tiles = uniu(n_tiles);
     const TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
-    for (unsigned int ti = g / kTileRegions; ti < n_tiles; ti += n_waves / kTileRegions) {
+    // A wave's first tile is fixed (its index among the region's waves); the following ones are handed out by the region's
+    // counter: tiles differ a lot in cost (a group nobody asked for is skipped in a microsecond, a full tile of wanted
+    // calls takes twenty) and with a fixed stride the launch lasted twice as long as its average wave.  64 counters, a few
+    // hundred increments each: nothing like the single shared work queue that serialised the first version.
+    const unsigned int region_waves = n_waves / kTileRegions;
+    unsigned int ti = g / kTileRegions;
+    while (ti < n_tiles) {
         // the tile record as wave-uniform scalars
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
         typename KC<RefWord, kView>::TileArgs t;
         t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.read_first = uniu(src[2]); t.group_first = uniu(src[3]);
         t.flags = uniu(src[4]); t.index = ti; t.gord = uniu(src[7]); t.region = region;
         uint32_t gc01 = uniu(src[5]), gc23 = uniu(src[6]);
-        if (!(t.flags & 1u)) continue;
-        int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
-        if (e != 0 && lane_id() == 0) {
-            p.status[t.ridx] = e;
-            atomicMin(p.err_summary, ((unsigned int)t.ridx << 8) | (unsigned int)e);
+        if (t.flags & 1u) {
+            int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
+            if (e != 0 && lane_id() == 0) {
+                p.status[t.ridx] = e;
+                atomicMin(p.err_summary, ((unsigned int)t.ridx << 8) | (unsigned int)e);
+            }
         }
+        unsigned int nxt = 0;
+        if (lane_id() == 0) nxt = atomicAdd(P.tile_queue + region * kQueueStride, 1u);
+        ti = region_waves + uniu(nxt);
     }
     if (p.stats) k.flush_stats(g & (kStatSlots - 1));
 #ifdef MM_PHASE_TIMING
