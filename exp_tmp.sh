@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/exp_$m -o e -
 python3 - <<PY
 import csv
 for r in csv.DictReader(open('gpurun_out/exp_$m/e_kernel_stats.csv')):
-    if 'k_call' in r['Name']: print('$m', r['Name'][:50], float(r['AverageNs'])/1000)
+    if "k_call" in r["Name"] or "k_scan" in r["Name"]: print('$m', r['Name'][:50], float(r['AverageNs'])/1000)
 PY
 grep '^{"metric' gpurun_out/exp_$m.log | cut -c1-90
 done

@@ -26,6 +26,7 @@ using namespace mmhip;
 namespace {
 
 constexpr int kSlots = 4;
+constexpr int kQueueWords = 128 * kQueueStride;   // per set: 64 tile-queue counters, then 64 scan-queue counters, 128 bytes apart
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -43,7 +44,7 @@ struct Slot {
     unsigned int* d_ctl = nullptr;   // two sets of 128 words, used alternately: [0] read queue, [1] err_summary, [4] fb_count,
                                      // [5] fb_queue, [8..72) tile_count per region.  A launch's last kernel resets the other set.
     int ctl_set = 0;
-    unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue counters, 128 bytes apart, alternating with the control sets
+    unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue + 64 scan-queue counters, 128 bytes apart, alternating with the control sets
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
     uint32_t* d_gdir = nullptr; size_t cap_gdir = 0;
@@ -228,7 +229,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     unsigned int* const ctl_other = s.d_ctl + kCtlSetWords * (s.ctl_set ^ 1);
     p.queue = ctl; p.err_summary = ctl + 1;
     p.ctl_next = ctl_other;
-    p.queue_next = s.d_tq + 64 * kQueueStride * (s.ctl_set ^ 1);
+    p.queue_next = s.d_tq + kQueueWords * (s.ctl_set ^ 1);
     TileParams tp;
     std::memset(&tp, 0, sizeof(tp));
     if (h->use_tiles) {
@@ -246,14 +247,15 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             return r;
         tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot; tp.g_nb = s.d_gnb; tp.g_sum = s.d_gsum; tp.g_qdir = s.d_gqdir; tp.g_rdir = s.d_grdir;
         tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap / kTileRegions + 64, 0x3FFFFFFu);
-        tp.tile_count = ctl + 8; tp.tile_queue = s.d_tq + 64 * kQueueStride * s.ctl_set;
+        tp.tile_count = ctl + 8; tp.tile_queue = s.d_tq + kQueueWords * s.ctl_set;
+        tp.scan_queue = tp.tile_queue + 64 * kQueueStride;
         tp.fb_list = s.d_fb; tp.fb_count = ctl + 4;
     }
     if (b->n_reads <= 0) {   // no kernel will run: the set the next launch uses is reset from the host
         for (int i = 0; i < kCtlWords; i++) s.h_ctl[i] = 0u;
         s.h_ctl[1] = 0xFFFFFFFFu;
         HIPCHK(hipMemcpyAsync(ctl_other, s.h_ctl, kCtlWords * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(s.d_tq + 64 * kQueueStride * (s.ctl_set ^ 1), 0, 64 * kQueueStride * sizeof(unsigned int), st));
+        HIPCHK(hipMemsetAsync(s.d_tq + kQueueWords * (s.ctl_set ^ 1), 0, kQueueWords * sizeof(unsigned int), st));
     }
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
@@ -429,8 +431,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             unsigned int init[2 * kCtlSetWords];
             for (int i = 0; i < 2 * kCtlSetWords; i++) init[i] = (i % kCtlSetWords) == 1 ? 0xFFFFFFFFu : 0u;
             if (hipMemcpy(s.d_ctl, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) return fail(h, "control word init failed");
-            if (dev_alloc(h, (void**)&s.d_tq, 2 * 64 * kQueueStride * sizeof(unsigned int))) return fail(h, "alloc failed");
-            if (hipMemset(s.d_tq, 0, 2 * 64 * kQueueStride * sizeof(unsigned int)) != hipSuccess) return fail(h, "control word init failed");
+            if (dev_alloc(h, (void**)&s.d_tq, 2 * kQueueWords * sizeof(unsigned int))) return fail(h, "alloc failed");
+            if (hipMemset(s.d_tq, 0, 2 * kQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(h, "control word init failed");
         }
         if (hipHostMalloc((void**)&s.h_ctl, 512 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
         if (opts->view) {

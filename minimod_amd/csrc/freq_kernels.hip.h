@@ -118,7 +118,7 @@ struct DevParams {
     // the control words (queue, error summary, tile counters) the slot's NEXT launch will use: reset by this launch's
     // last kernel, which saves a host-to-device copy per batch (a slot alternates between two sets)
     unsigned int* ctl_next;
-    unsigned int* queue_next;      // likewise: the 64 tile-queue counters (kQueueStride words apart) of the next launch
+    unsigned int* queue_next;      // likewise: the 64 tile-queue + 64 scan-queue counters (kQueueStride words apart) of the next launch
 };
 constexpr int kCtlWords = 80;    // words of a control set that are reset: [0..8) scalars, [8..72) tile counts
 constexpr int kCtlSetWords = 128;
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
     K1<RefWord, kView> k(p, lds[wv]);
     if (p.ctl_next && blockIdx.x == 0 && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
-    if (p.queue_next && blockIdx.x == 0 && threadIdx.x < 64) p.queue_next[threadIdx.x * kQueueStride] = 0u;
+    if (p.queue_next && blockIdx.x == 0 && threadIdx.x < 128) p.queue_next[threadIdx.x * kQueueStride] = 0u;   // tile queues, then scan queues
     if (p.n_items_dev && *p.n_items_dev == 0u) return;   // empty fallback list: do not even touch the work counter
     for (;;) {
         int r = 0;

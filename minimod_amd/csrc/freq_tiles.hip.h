@@ -57,6 +57,7 @@ struct TileParams {
     uint2* g_sum;             // per tile: x = tokens | n_codes << 16, y = sum(skip+1)
     unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
     unsigned int tile_cap;    // records per region
+    unsigned int* scan_queue; // [kTileRegions * kQueueStride] hand-out counters of k_scan_reads (items behind the static first round)
     unsigned int* tile_queue; // [kTileRegions * kQueueStride] next tile of each region for k_call_tiles (dynamic hand-out behind the static first round)
     int32_t* fb_list;         // reads left to the fused kernel
     unsigned int* fb_count;
@@ -544,12 +545,25 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
     __shared__ ScanLds lds[kWavesPerBlock];
     KA<RefWord> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
-    // three items per read (CIGAR scan, MM headers -> tiles, rank directory); static round-robin over the
-    // (costliest-first) item list: a shared work counter would serialise ~12k dequeues
+    // three items per read (CIGAR scan, MM headers -> tiles, rank directory) over the costliest-first item list.  A wave's
+    // first item is fixed (item g); the items behind the first round are handed out by 64 padded counters (item j of the
+    // remainder belongs to counter j % 64): the wave that drew the longest read then takes nothing else, and a single
+    // shared counter would serialise ~12k dequeues.
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
     const int n = p.n_items;
-    for (int r = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6); r < 3 * n; r += n_waves) {
-        const int ri = r / 3, kind = r - 3 * ri;   // kinds interleaved: the three items of the costliest reads all start at once
+    const int g = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    const bool dynamic = n_waves >= (int)kTileRegions && P.scan_queue != nullptr;
+    for (int r = g; r < 3 * n;) {
+        const int r_cur = r;
+        if (dynamic) {
+            unsigned int c = 0;
+            if (lane_id() == 0) c = atomicAdd(P.scan_queue + (unsigned int)(g % (int)kTileRegions) * kQueueStride, 1u);
+            r = n_waves + (int)(uniu(c) * kTileRegions) + g % (int)kTileRegions;
+        } else {
+            r += n_waves;
+        }
+        const int r_use = r_cur;
+        const int ri = r_use / 3, kind = r_use - 3 * ri;   // kinds interleaved: the three items of the costliest reads all start at once
         uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
         item = uniu(item);
         const uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
