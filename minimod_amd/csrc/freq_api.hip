@@ -716,6 +716,9 @@ int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     std::vector<unsigned long long> all(16 + 4 * (size_t)kStatSlots);
     HIPCHK(hipMemcpy(all.data(), h->d_stats, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stats, 0, all.size() * sizeof(unsigned long long)));
+    if (const char* dump = std::getenv("MM_STATS_DUMP")) {   // diagnostic builds: the raw per-wave rows
+        if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(all.data(), sizeof(unsigned long long), all.size(), f); std::fclose(f); }
+    }
     for (int i = 0; i < 16; i++) out[i] = all[i];
     for (int i = 0; i < 4; i++) out[i] = 0;
     for (size_t w = 0; w < kStatSlots; w++) for (int i = 0; i < 4; i++) out[i] += all[16 + 4 * w + i];

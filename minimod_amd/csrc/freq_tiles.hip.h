@@ -385,8 +385,23 @@ struct KA {
         return cls;
     }
 
+    // class members among the 32 bases of block b (the read's last block may be partial)
+    __device__ __forceinline__ uint32_t block_count(uint4 v, int cls, uint32_t b, uint32_t L) const {
+        if (cls == 0) {
+            int valid = (int)min(32u, L - b * 32u);
+            uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
+                         __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
+                         __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
+                         __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
+            return (uint32_t)valid - o;
+        }
+        return __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) + __popc(class_bits(v.w, cls));
+    }
+
     // ---------------- item kind 2: rank directory of the read's one class -> global (mod.c:972-981)
-    __device__ int run_dir(int ridx) {
+    // Like the CIGAR scan, a long read's directory is cut into `nparts` chunks of blocks, one wave each: a chunk first
+    // COUNTS the class members in front of it (no scans, no stores), then scans only its own blocks.
+    __device__ int run_dir(int ridx, uint32_t part, uint32_t nparts) {
         const int lane = lane_id();
         const mm_read_t& rd = p.reads[ridx];
         const uint32_t L = uniu(rd.l_qseq), mlen = uniu(rd.mm_len);
@@ -398,34 +413,39 @@ struct KA {
         if (cls >= 0) {
             const uint4* sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
             uint32_t* const rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
+            const uint32_t b_lo = (uint32_t)(((uint64_t)nblk * part) / nparts) & ~63u;   // chunks start on a 64-block boundary
+            const uint32_t b_hi = part + 1u >= nparts ? nblk : ((uint32_t)(((uint64_t)nblk * (part + 1u)) / nparts) & ~63u);
             uint32_t carry = 0;
-            for (uint32_t b0 = 0; b0 < nblk; b0 += 512) {
+            {   // class members in blocks [0, b_lo)
+                uint32_t sum = 0;
+                for (uint32_t b0 = 0; b0 < b_lo; b0 += 512) {
+                    uint4 vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        uint32_t b = b0 + 64u * u + lane;
+                        vv[u] = b < b_lo ? sq[b] : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        uint32_t b = b0 + 64u * u + lane;
+                        if (b < b_lo) sum += block_count(vv[u], cls, b, L);
+                    }
+                }
+                carry = lane_valu(wave_incl_scan(sum), 63);
+            }
+            for (uint32_t b0 = b_lo; b0 < b_hi; b0 += 512) {
                 uint4 vv[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     uint32_t b = b0 + 64u * u + lane;
-                    vv[u] = b < nblk ? sq[b] : make_uint4(0, 0, 0, 0);
+                    vv[u] = b < b_hi ? sq[b] : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     uint32_t b = b0 + 64u * u + lane;
-                    uint32_t cnt = 0;
-                    if (b < nblk) {
-                        uint4 v = vv[u];
-                        int valid = (int)min(32u, L - b * 32u);
-                        if (cls == 0) {
-                            uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
-                                         __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
-                                         __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
-                                         __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
-                            cnt = (uint32_t)valid - o;
-                        } else {
-                            cnt = __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) +
-                                  __popc(class_bits(v.z, cls)) + __popc(class_bits(v.w, cls));
-                        }
-                    }
+                    uint32_t cnt = b < b_hi ? block_count(vv[u], cls, b, L) : 0u;
                     uint32_t incl = wave_incl_scan(cnt);
-                    if (b < nblk) {
+                    if (b < b_hi) {
                         uint32_t ex = carry + incl - cnt;
                         P.g_dir[dir_off + b] = ex;
                         uint32_t k = (ex + 63u) >> 6;          // a 32-base block holds at most one multiple of 64 ranks
@@ -436,7 +456,7 @@ struct KA {
             }
             nb = carry;
         }
-        if (lane == 0) P.g_nb[ridx] = nb;
+        if (lane == 0 && part + 1u >= nparts) P.g_nb[ridx] = nb;
         return 0;
     }
 
@@ -567,7 +587,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
         item = uniu(item);
         const uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
-        if (kind != 0 && part != 0u) continue;   // a long read's parts split its CIGAR scan; the other kinds visit a read once
+        if (kind == 1 && part != 0u) continue;   // a long read's parts split its CIGAR and directory scans; its MM headers are visited once
         int ridx = (int)(item & 0xFFFFFFu);
         int e = 0;
 #ifdef MM_PHASE_TIMING
@@ -575,13 +595,14 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
 #endif
         if (kind == 0) e = k.run_cigar(ridx, part, nparts);
         else if (kind == 1) e = k.run_mm(ridx, (uint32_t)ri % kTileRegions);
-        else e = k.run_dir(ridx);
+        else e = k.run_dir(ridx, part, nparts);
         e = uni(e);
 #ifdef MM_PHASE_TIMING
-        if (lane_id() == 0 && p.stats) {
+        if (lane_id() == 0 && p.stats) {   // this wave's own row: longest item of each kind, and when the wave went idle
             unsigned long long kt1 = __builtin_amdgcn_s_memrealtime(), dt = kt1 - kt0;
-            atomicMax(p.stats + 4 + kind, dt); atomicAdd(p.stats + 7, 1ull);
-            atomicMax(p.stats + 13, ~kt0); atomicMax(p.stats + 14, kt1);   // kernel span in the same ticks: [~stats[13], stats[14]]
+            unsigned long long* row = p.stats + 16 + 4 * (size_t)(g & (int)(kStatSlots - 1));
+            if (dt > row[kind]) row[kind] = dt;
+            row[3] = kt1;
         }
 #endif
         if (e != 0 && lane_id() == 0) {
