@@ -31,6 +31,7 @@ constexpr int kQueueWords = 128 * kQueueStride;   // per set: 64 tile-queue coun
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    hipEvent_t ev_wait = nullptr;   // what wait() synchronises on: ev_stop, or ev_done when copies follow the kernels (view)
     bool busy = false, timed = false;
     // staging for host batches
     void* d_reads = nullptr; size_t cap_reads = 0;
@@ -44,6 +45,7 @@ struct Slot {
     unsigned int* d_ctl = nullptr;   // two sets of 128 words, used alternately: [0] read queue, [1] err_summary, [4] fb_count,
                                      // [5] fb_queue, [8..72) tile_count per region.  A launch's last kernel resets the other set.
     int ctl_set = 0;
+    unsigned int* d_err_word = nullptr;   // err_summary of the slot's last launch
     unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue + 64 scan-queue counters, 128 bytes apart, alternating with the control sets
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
@@ -228,6 +230,9 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     unsigned int* const ctl = s.d_ctl + kCtlSetWords * s.ctl_set;
     unsigned int* const ctl_other = s.d_ctl + kCtlSetWords * (s.ctl_set ^ 1);
     p.queue = ctl; p.err_summary = ctl + 1;
+    s.h_ctl[129] = 0xFFFFFFFFu;   // host_flag: a failing read stores 0 here
+    p.host_flag = s.h_ctl + 129;
+    s.d_err_word = ctl + 1;
     p.ctl_next = ctl_other;
     p.queue_next = s.d_tq + kQueueWords * (s.ctl_set ^ 1);
     TileParams tp;
@@ -306,11 +311,12 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s.ev_stop, st));
-    HIPCHK(hipMemcpyAsync(s.h_ctl + 128, ctl, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    // no copy back on the good path: kernels flag a failure in pinned host memory (DevParams.host_flag)
     s.ctl_set ^= 1;
     if (h->opts.view)
         HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(s.ev_done, st));
+    if (h->opts.view) { HIPCHK(hipEventRecord(s.ev_done, st)); s.ev_wait = s.ev_done; }
+    else s.ev_wait = s.ev_stop;   // nothing follows the kernels: one event less per batch
     s.busy = true; s.timed = true; s.n_reads = b->n_reads;
     s.last_batch = *b; s.last_stream = st; s.view_rows = -1; s.view_on_host = false;
     return 0;
@@ -320,7 +326,7 @@ int acquire_slot(mm_freq* h) {
     int i = h->next_slot;
     h->next_slot = (h->next_slot + 1) % kSlots;
     Slot& s = h->slots[i];
-    if (s.busy) (void)hipEventSynchronize(s.ev_done);
+    if (s.busy) (void)hipEventSynchronize(s.ev_wait);
     return i;
 }
 
@@ -687,10 +693,11 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     Slot& s = h->slots[ticket];
     if (!s.busy) return MM_OK;
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
-    if (hipEventSynchronize(s.ev_done) != hipSuccess) return MM_E_HIP;
+    if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
-    unsigned int sum = s.h_ctl[129];
-    if (sum != 0xFFFFFFFFu) {
+    if (s.h_ctl[129] != 0xFFFFFFFFu) {
+        unsigned int sum = 0xFFFFFFFFu;
+        if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
         if (bad_read) *bad_read = (int32_t)(sum >> 8);
         return (int32_t)(sum & 0xFFu);
     }
@@ -918,10 +925,11 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
     }
     unsigned long long n = 0;
     for (int attempt = 0;; attempt++) {
-        HIPCHK(hipEventSynchronize(s.ev_done));
+        HIPCHK(hipEventSynchronize(s.ev_wait));
         s.busy = false;
-        unsigned int sum = s.h_ctl[129];
-        if (sum != 0xFFFFFFFFu) {
+        if (s.h_ctl[129] != 0xFFFFFFFFu) {
+            unsigned int sum = 0xFFFFFFFFu;
+            HIPCHK(hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost));
             if (bad_read) *bad_read = (int32_t)(sum >> 8);
             return -(int64_t)(sum & 0xFFu);
         }

@@ -97,6 +97,7 @@ struct DevParams {
     // outputs
     int32_t* status;               // per read
     unsigned int* err_summary;     // min over failing reads of (read index << 8 | code), 0xFFFFFFFF = none
+    unsigned int* host_flag;       // pinned host word, set to 0 by any failing read: the host copies err_summary back only then
     SideRec* side;
     unsigned long long* side_count;
     unsigned long long side_cap;
@@ -146,6 +147,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// A read failed: the first failing read of the batch is the minimum of err_summary; the host learns that there is
+// something to fetch from a plain store into pinned host memory (complete when the launch's event is).
+__device__ __forceinline__ void report_error(const DevParams& p, unsigned int ridx, int e) {
+    atomicMin(p.err_summary, (ridx << 8) | (unsigned int)e);
+    if (p.host_flag) *p.host_flag = 0u;
+}
 
 // Append one view record per active lane (called under divergence: the ballot is the set of lanes with a record).
 // The value orders the records of one (read, position): by key (code, ins_offset), then in the order the reference
@@ -950,7 +958,7 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
         if (p.stats) k.flush_stats((uint32_t)wave_slot & (kStatSlots - 1));
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
-            atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
+            report_error(p, (unsigned int)ridx, e);
         }
     }
 }

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
 #endif
         if (e != 0 && lane_id() == 0) {
             p.status[ridx] = e;
-            atomicMin(p.err_summary, ((unsigned int)ridx << 8) | (unsigned int)e);
+            report_error(p, (unsigned int)ridx, e);
         }
     }
 }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
             uint64_t eb = __ballot(terr != 0);
             if (eb) {
                 int e = lane_val(terr, __ffsll((unsigned long long)eb) - 1);
-                if (lane == 0) { p.status[ridx] = e; atomicMin(p.err_summary, (ridx << 8) | (unsigned int)e); }
+                if (lane == 0) { p.status[ridx] = e; report_error(p, ridx, e); }
             }
         }
         if (lane == 0) rsum[ti] = make_uint2(ntok | (((flags >> 12) & 7u) << 16), rsum_v);
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
             int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
             if (e != 0 && lane_id() == 0) {
                 p.status[t.ridx] = e;
-                atomicMin(p.err_summary, ((unsigned int)t.ridx << 8) | (unsigned int)e);
+                report_error(p, t.ridx, e);
             }
         }
         unsigned int nxt = 0;
