@@ -155,19 +155,38 @@ __device__ __forceinline__ SubParse parse_sub(const uint8_t* mb8, int base, bool
     r.v = 0;
     r.err = 0;
     {
-        // decimal fold over the look-ahead window; the loop ends as soon as every token of the sub-chunk has met its
-        // delimiter (skip counts are mostly one to three digits), at most 10 characters (mod.c:1074-1081)
+        // decimal fold from the token's first character (mod.c:1074-1081): at most nine digits, then the delimiter.  The
+        // first four characters are requested from LDS together and folded from registers (skip counts are mostly one
+        // to three digits; a loop that reads, tests and branches per character spends its time in dependent LDS round
+        // trips and in issue slots: it was most of k_sum_tiles); the other six only when some token is still open.
         bool open = r.tstart;
         int len = 0;
-#pragma unroll 1
-        for (int j = 0; j < 10 && __ballot(open); j++) {
-            int d = open ? (int)mb8[base + lane + j] : ',';
-            bool delim = d == ',' || d == ';';
-            open = open && !delim;
-            if (open) {
-                if (d < '0' || d > '9') r.err = MM_E_SKIPVAL;
-                r.v = r.v * 10u + (uint32_t)(d - '0');
-                len++;
+        {
+            uint32_t d[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[j] = mb8[base + lane + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                open = open && d[j] != ',' && d[j] != ';';
+                if (open) {
+                    if (d[j] - '0' > 9u) r.err = MM_E_SKIPVAL;
+                    r.v = r.v * 10u + (d[j] - '0');
+                    len++;
+                }
+            }
+        }
+        if (__ballot(open)) {
+            uint32_t d[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) d[j] = mb8[base + lane + 4 + j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                open = open && d[j] != ',' && d[j] != ';';
+                if (open) {
+                    if (d[j] - '0' > 9u) r.err = MM_E_SKIPVAL;
+                    r.v = r.v * 10u + (d[j] - '0');
+                    len++;
+                }
             }
         }
         if (len == 10) r.err = MM_E_SKIPLEN;
