@@ -63,10 +63,12 @@ struct TileParams {
     unsigned int* fb_count;
 };
 
+constexpr uint32_t kGroupEnds = 32;
 struct ScanLds {
     uint32_t mmw[260];   // 1024 MM characters + 16 of look-ahead
     char hdr[16];
     int16_t g_code[16];
+    uint32_t gend[kGroupEnds];   // run_mm: where the read's first groups end (found once, used by both passes)
 };
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
 constexpr uint32_t kSliceC = 640;   // CIGAR ops staged in LDS per tile
@@ -85,38 +87,41 @@ __device__ __forceinline__ uint32_t semi_bytes(uint32_t w) {
     uint32_t y = w ^ 0x3B3B3B3Bu;
     return (y - 0x01010101u) & ~y & 0x80808080u;
 }
-// position of the first ';' at or after `from` (or mlen): 1024 characters per trip (four dwords per lane in flight), no LDS
+// position of the first ';' at or after `from` (or mlen): 4096 characters per trip (four 16-byte loads per lane in
+// flight: a long read's group is tens of kilobytes and every trip is a full memory round trip), no LDS.  Loads may run up
+// to 15 bytes past the string: inside the pool (16-byte padding per read, 64 bytes of slack at the end).
 __device__ __forceinline__ uint32_t find_semicolon(const uint8_t* mm, uint32_t mlen, uint32_t from) {
     const int lane = lane_id();
     uint32_t pos = from;
     uint32_t found = mlen;
     bool hit = false;
     while (pos < mlen && !hit) {
-        uint32_t w[4];
+        uint4 w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t off = pos + 16u * lane + 4u * j;
-            w[j] = 0;
-            if (off < mlen) {
-                __builtin_memcpy(&w[j], mm + off, 4);
-                uint32_t left = mlen - off;
-                if (left < 4u) w[j] &= (1u << (8u * left)) - 1u;
-            }
+            uint32_t off = pos + 64u * lane + 16u * j;
+            w[j] = make_uint4(0, 0, 0, 0);
+            if (off < mlen) __builtin_memcpy(&w[j], mm + off, 16);
         }
-        // first ';' among this lane's 16 characters
+        // first ';' among this lane's 64 characters (characters at or past mlen do not count)
         uint32_t first = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 3; j >= 0; j--) {
-            uint32_t z = semi_bytes(w[j]);
-            if (z) first = 4u * j + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+            const uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+            for (int q = 3; q >= 0; q--) {
+                uint32_t z = semi_bytes(d[q]);
+                if (z) first = 16u * j + 4u * q + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+            }
         }
+        if (first != 0xFFFFFFFFu && pos + 64u * lane + first >= mlen) first = 0xFFFFFFFFu;
         uint64_t b = __ballot(first != 0xFFFFFFFFu);
         if (b) {
             int l = __ffsll((unsigned long long)b) - 1;
-            found = pos + 16u * (uint32_t)l + lane_valu(first, l);
+            found = pos + 64u * (uint32_t)l + lane_valu(first, l);
             hit = true;
         }
-        pos += 1024u;
+        pos += 4096u;
     }
     return found < mlen ? found : mlen;
 }
@@ -316,18 +321,25 @@ struct KA {
             const uint32_t op_hi = part + 1u >= nparts ? ncig : ((uint32_t)(((uint64_t)ncig * (part + 1u)) / nparts) & ~63u);
             {   // carries of the chunk: sums over ops [0, op_lo)
                 uint32_t sq = 0, sr = 0;
-                for (uint32_t i0 = 0; i0 < op_lo; i0 += 512) {
-                    uint32_t wv[8];
+                // 2048 ops per trip (eight 16-byte loads per lane in flight): this pass is nothing but memory round
+                // trips, and the last part of a 200 kb read has ten thousand ops in front of it.  op_lo is a multiple
+                // of 64 ops, so whole 4-op groups never straddle it.
+                for (uint32_t i0 = 0; i0 < op_lo; i0 += 2048) {
+                    uint4 wv[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        uint32_t i = i0 + 64u * u + lane;
-                        wv[u] = i < op_lo ? cg[i] : 0x6u;   // pad op (consumes nothing)
+                        uint32_t i = i0 + 256u * u + 4u * lane;
+                        wv[u] = i < op_lo ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(6u, 6u, 6u, 6u);   // pad op (consumes nothing)
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        uint32_t op = wv[u] & 15u, len = wv[u] >> 4;
-                        sq += ((0x193u >> op) & 1u) ? len : 0u;
-                        sr += ((0x18Du >> op) & 1u) ? len : 0u;
+                        const uint32_t w4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t op = w4[k] & 15u, len = w4[k] >> 4;
+                            sq += ((0x193u >> op) & 1u) ? len : 0u;
+                            sr += ((0x18Du >> op) & 1u) ? len : 0u;
+                        }
                     }
                 }
                 carry_q = lane_valu(wave_incl_scan(sq), 63);
@@ -494,7 +506,7 @@ struct KA {
         // pass 1: regular or not, and how many tiles
         int first_cls = -1;
         bool irregular = false;
-        uint32_t need = 0;
+        uint32_t need = 0, ngrp = 0;
         if (have_ref) {
             uint32_t mpos = 0;
             int guard = 0;
@@ -510,11 +522,14 @@ struct KA {
                         else if (cls != first_cls) irregular = true;
                     }
                     uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                    if (ngrp < kGroupEnds && lane == 0) S.gend[ngrp] = endp;
+                    ngrp++;
                     need += (endp - g.lstart) / kTileChars + 1u;
                     if (dot) need += L / kTailRanks + 1u;
                     mpos = endp + 1u;
                 }
             }
+            wave_sync();
         }
         uint32_t tbase = 0;
         if (have_ref && !irregular && need > 0) {
@@ -542,7 +557,7 @@ struct KA {
                 const bool unwanted = gc0 < 0 && gc1 < 0 && gc2 < 0 && gc3 < 0;   // none of the group's codes was asked for with -c
                 uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) | (unwanted ? 64u : 0u) |
                                   ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
-                uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                uint32_t endp = gord < kGroupEnds ? uniu(S.gend[gord]) : find_semicolon(mm, mlen, g.lstart);
                 uint32_t nlist = (endp - g.lstart) / kTileChars + 1u;
                 uint32_t ntail = dot ? L / kTailRanks + 1u : 0u;
                 uint32_t gfirst = tcur;
