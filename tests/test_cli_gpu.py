@@ -174,3 +174,25 @@ def test_cli_view_on_synthetic_bam_matches_oracle(tmp_path):
         rows, qn, names, codes = O.view(bam, {"chrS": ref}, c="m[CG]", K=128, threads=4, **kw)
         want = O.format_view(rows, qn, names, codes, **kw)
         assert len(want) > 100000 and r.stdout.decode() == want
+
+
+def test_cli_on_bam_without_records(tmp_path):
+    """A BAM that holds only its header: both subtools print their header line (bedmethyl: nothing) and exit 0."""
+    from minimod_amd import synth
+    ref = synth.reference(3, 1 << 16)
+    bam, fa = str(tmp_path / "e.bam"), str(tmp_path / "e.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], [])
+    synth.write_fasta(fa, "chrS", ref)
+    r = subprocess.run([BIN, "freq", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout.decode() == "contig\tstart\tend\tstrand\tn_called\tn_mod\tfreq\tmod_code\n", r.stderr.decode()[-1000:]
+    r = subprocess.run([BIN, "freq", "-b", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout == b""
+    r = subprocess.run([BIN, "view", "--insertions", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout.decode() == "ref_contig\tref_pos\tstrand\tread_id\tread_pos\tmod_code\tmod_prob\tins_offset\n"
+
+
+def test_cli_view_hard_clip_exits_like_reference(fastas):
+    r = subprocess.run([BIN, "view", "--allow-secondary", fastas["chr22"], os.path.join(GOLDEN, "data", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    if r.returncode != 0:
+        assert r.returncode == 1 and b"Hard clipping" in r.stderr
