@@ -168,7 +168,9 @@ mm_freq_t *mm_freq_create(const mm_freq_opts_t *opts, int32_t n_contigs, const m
 int32_t mm_freq_submit(mm_freq_t *h, const mm_batch_t *host_batch);
 
 /* Process one batch already RESIDENT in device memory (all mm_batch_t pointers are device pointers) on the given
- * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*. */
+ * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*.  The batch
+ * must stay resident until mm_freq_wait(ticket) has returned: reads the tile kernels do not cover (more than four
+ * codes in an MM group, groups on different canonical bases) are processed when the host waits for the batch. */
 int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *hip_stream);
 
 /* Wait for a ticket.  Returns 0, or the first failing read's MM_E_* code with its batch index in *bad_read. */

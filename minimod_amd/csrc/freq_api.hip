@@ -46,6 +46,8 @@ struct Slot {
                                      // [5] fb_queue, [8..72) tile_count per region.  A launch's last kernel resets the other set.
     int ctl_set = 0;
     unsigned int* d_err_word = nullptr;   // err_summary of the slot's last launch
+    bool fb_deferred = false;             // the fused kernel for the fallback list was not launched with the batch:
+    DevParams fb_params;                  // it runs when the host waits, and only if some read went on the list (h_ctl[130])
     unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue + 64 scan-queue counters, 128 bytes apart, alternating with the control sets
     uint32_t* d_gcq = nullptr; size_t cap_gcq = 0;
     uint32_t* d_gcr = nullptr; size_t cap_gcr = 0;
@@ -255,6 +257,9 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         tp.tile_count = ctl + 8; tp.tile_queue = s.d_tq + kQueueWords * s.ctl_set;
         tp.scan_queue = tp.tile_queue + 64 * kQueueStride;
         tp.fb_list = s.d_fb; tp.fb_count = ctl + 4;
+        s.h_ctl[130] = 0u;
+        tp.host_fb_flag = s.h_ctl + 130;
+        tp.reset_in_call = h->opts.view ? 0 : 1;   // view orders its rows right behind the call kernels: it keeps the fused launch inline
     }
     if (b->n_reads <= 0) {   // no kernel will run: the set the next launch uses is reset from the host
         for (int i = 0; i < kCtlWords; i++) s.h_ctl[i] = 0u;
@@ -282,15 +287,21 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 else hipLaunchKernelGGL((k_call_tiles<uint16_t, false>), dim3(gc), dim3(256), 0, st, tp);
             }
             HIPCHK(hipGetLastError());
-            // reads the tile form does not cover: the fused kernel over the fallback list (usually empty)
+            // reads the tile form does not cover: the fused kernel over the fallback list.  The list is nearly always
+            // empty, so in freq mode that launch is not made now: a read that goes on the list raises a flag in pinned
+            // host memory and mm_freq_wait runs the kernel then (finish_deferred).
             p.order = s.d_fb; p.n_items = 0; p.n_items_dev = ctl + 4; p.queue = ctl + 5;
+            s.fb_deferred = !h->opts.view;
+            s.fb_params = p;
         }
+        if (!(h->use_tiles && s.fb_deferred)) {
         if (h->wide) {
             if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, st, p);
         } else {
             if (p.view) hipLaunchKernelGGL((k_freq_reads<uint16_t, true>), dim3(blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, st, p);
+        }
         }
         HIPCHK(hipGetLastError());
     }
@@ -322,11 +333,46 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     return 0;
 }
 
+// The batch's kernels are complete (its event has been waited for): if a read went on the fallback list, run the fused
+// kernel for the list now.
+int finish_deferred(mm_freq* h, Slot& s) {
+    if (!s.fb_deferred) return 0;
+    s.fb_deferred = false;
+    if (s.h_ctl[130] == 0u) return 0;
+    const DevParams& p = s.fb_params;
+    const int blocks = std::min(h->n_cu * h->blocks_per_cu, 128);
+    if (h->wide) hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+    else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.last_stream));
+    return 0;
+}
+
+// batches that were never waited for may still owe their fallback list (slab functions run on a caller's stream and do not
+// synchronise the device; this only blocks when such a batch exists)
+int settle(mm_freq* h) {
+    for (auto& s : h->slots) {
+        if (!s.fb_deferred) continue;
+        HIPCHK(hipEventSynchronize(s.ev_wait));
+        int r = finish_deferred(h, s);
+        if (r) return r;
+    }
+    return 0;
+}
+
+// every batch submitted so far is complete, fallback lists included (before counters are read or changed)
+int drain(mm_freq* h) {
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& s : h->slots) { int r = finish_deferred(h, s); if (r) return r; }
+    return 0;
+}
+
 int acquire_slot(mm_freq* h) {
     int i = h->next_slot;
     h->next_slot = (h->next_slot + 1) % kSlots;
     Slot& s = h->slots[i];
     if (s.busy) (void)hipEventSynchronize(s.ev_wait);
+    (void)finish_deferred(h, s);
     return i;
 }
 
@@ -695,6 +741,7 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
+    if (finish_deferred(h, s) != 0) return MM_E_HIP;
     if (s.h_ctl[129] != 0xFFFFFFFFu) {
         unsigned int sum = 0xFFFFFFFFu;
         if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
@@ -719,7 +766,7 @@ int32_t mm_freq_stats_enable(mm_freq_t* h, int32_t enable) {
 int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     if (!h || !out) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipDeviceSynchronize());
+    { int r = drain(h); if (r) return r; }
     std::vector<unsigned long long> all(16 + 4 * (size_t)kStatSlots);
     HIPCHK(hipMemcpy(all.data(), h->d_stats, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stats, 0, all.size() * sizeof(unsigned long long)));
@@ -737,7 +784,7 @@ int64_t mm_freq_device_bytes(const mm_freq_t* h) { return h ? h->device_bytes : 
 void mm_freq_reset_counters(mm_freq_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipDeviceSynchronize();
+    (void)drain(h);
     (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1));
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
     (void)hipDeviceSynchronize();
@@ -746,7 +793,7 @@ void mm_freq_reset_counters(mm_freq_t* h) {
 int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     if (!h || h->opts.view) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipDeviceSynchronize());
+    { int r = drain(h); if (r) return r; }
     std::vector<mm_row_t>& rows = h->rows;
     rows.clear();
     std::vector<size_t> run_starts;   // first row of every (plane, haplotype, strand) run of dense rows
@@ -1001,6 +1048,7 @@ int32_t mm_freq_slab_export(mm_freq_t* h, int32_t tid, int64_t begin, int64_t le
     int r = slab_range(h, tid, begin, len, &off);
     if (r || len == 0) return r;
     HIPCHK(hipSetDevice(h->device));
+    { int rs = settle(h); if (rs) return rs; }
     int runs = h->n_code_planes * h->n_hp * 2;
     int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
     hipLaunchKernelGGL(k_slab_export, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off,
@@ -1014,6 +1062,7 @@ int32_t mm_freq_slab_add(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, 
     int r = slab_range(h, tid, begin, len, &off);
     if (r || len == 0) return r;
     HIPCHK(hipSetDevice(h->device));
+    { int rs = settle(h); if (rs) return rs; }
     int runs = h->n_code_planes * h->n_hp * 2;
     int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
     hipLaunchKernelGGL(k_slab_add, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len,
@@ -1027,6 +1076,7 @@ int32_t mm_freq_slab_clear(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len
     int r = slab_range(h, tid, begin, len, &off);
     if (r || len == 0) return r;
     HIPCHK(hipSetDevice(h->device));
+    { int rs = settle(h); if (rs) return rs; }
     int runs = h->n_code_planes * h->n_hp * 2;
     int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
     hipLaunchKernelGGL(k_slab_clear, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len, runs);

@@ -61,6 +61,9 @@ struct TileParams {
     unsigned int* tile_queue; // [kTileRegions * kQueueStride] next tile of each region for k_call_tiles (dynamic hand-out behind the static first round)
     int32_t* fb_list;         // reads left to the fused kernel
     unsigned int* fb_count;
+    unsigned int* host_fb_flag;  // pinned host word: set when a read went on the fallback list (the host then runs the fused
+                                 // kernel for it when it waits for the batch; otherwise that launch is saved)
+    int32_t reset_in_call;       // 1: k_call_tiles is the launch's last kernel and resets the next launch's control words
 };
 
 constexpr uint32_t kGroupEnds = 32;
@@ -540,7 +543,7 @@ struct KA {
         uint32_t tcur = tbase;
         TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
         if (have_ref && irregular) {
-            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; }
+            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; if (P.host_fb_flag) *P.host_fb_flag = 1u; }
         }
         // pass 2: the tile records (no text is parsed here beyond the headers)
         if (have_ref && !irregular) {
@@ -1194,6 +1197,10 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord, kView> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
+    if (P.reset_in_call && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
+        if (p.ctl_next && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
+        if (p.queue_next && threadIdx.x < 128) p.queue_next[threadIdx.x * kQueueStride] = 0u;
+    }
     // static round-robin: wave g serves region g % kTileRegions, striding over that region's tiles with the other
     // waves of the same residue (tiles cost about the same; no shared work counter to serialise on)
     const unsigned int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
