@@ -144,3 +144,29 @@ def test_long_read_spills_past_lds_caps(chr22):
     bam = pybam.BamFile(path)
     recs = [r for r in bam if pybam.accept(r)]
     assert max(r.l_qseq for r in recs) > 32768 and max(r.n_cigar for r in recs) > 1024
+
+
+def test_unwaited_tickets_and_fallback_reads(chr22):
+    """dRNA.bam's reads carry MM groups on different canonical bases: the tile kernels leave them to the fused kernel,
+    which runs when the host waits for the batch.  Here nobody waits: slots are reused (more batches than slots) and
+    finalize has to settle what is outstanding.  Same rows as with a wait after every batch, and as the oracle."""
+    path = os.path.join(GOLDEN, "data", "dRNA.bam")
+    kw = dict(c="17802[*],a,m[C]")
+    want, names, wcodes = O.freq(path, chr22, **kw)
+    mods = O.parse_mod_codes(kw["c"])
+    th = O.parse_mod_threshes(None, len(mods))
+    eng = None
+    n_batches = 0
+    for bam, batch, _st in pybam.load_batches(path, K=8):
+        if eng is None:
+            eng = make_engine(mods, th, bam.target_name, bam.target_len, chr22)
+        if len(batch["reads"]):
+            eng.submit(batch)          # no wait
+            n_batches += 1
+    assert n_batches > 4
+    got = to_oracle_rows(eng.finalize())
+    codes = eng.code_names()
+    eng.close()
+    a = O.format_rows(want, names, wcodes)
+    b = O.format_rows(got, names, codes)
+    assert len(want) > 1000 and sorted(a.splitlines()) == sorted(b.splitlines())
