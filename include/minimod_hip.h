@@ -163,7 +163,8 @@ typedef struct mm_freq mm_freq_t;
 mm_freq_t *mm_freq_create(const mm_freq_opts_t *opts, int32_t n_contigs, const mm_contig_t *contigs,
                           int32_t n_intervals, const mm_interval_t *intervals, char *err, size_t err_len);
 
-/* Process one batch from HOST memory: H2D on an internal stream, then the per-read kernel (K1).  Asynchronous;
+/* Process one batch from HOST memory: H2D on an internal stream, then the hot-path kernels (k_scan_reads,
+ * k_sum_tiles, k_call_tiles).  Asynchronous;
  * the batch memory must stay valid until mm_freq_wait(ticket) returns.  Returns a ticket >= 0 or -MM_E_*. */
 int32_t mm_freq_submit(mm_freq_t *h, const mm_batch_t *host_batch);
 
@@ -208,10 +209,10 @@ int32_t mm_freq_slab_export(mm_freq_t *h, int32_t tid, int64_t begin, int64_t le
 int32_t mm_freq_slab_add(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *src_dev, void *hip_stream);
 int32_t mm_freq_slab_clear(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *hip_stream);
 
-/* Measurement hooks (bench.py): device time of the last K1 launch of a ticket in milliseconds (HIP events on
- * the launch stream), and the number of K1 launches so far. */
+/* Measurement hook (bench.py): device time of a ticket's hot-path kernels in milliseconds (HIP events recorded on the
+ * launch stream around them). */
 float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
-/* Work tallies for the algorithmic-bytes figure: enable!=0 makes K1 count reference-word
+/* Work tallies for the algorithmic-bytes figure: enable!=0 makes the kernels count reference-word
  * lookups, ML bytes read, dense counter updates and side-list updates; get copies and clears the four totals. */
 int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
 int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[16]);   /* [4..15]: phase time sums in diagnostic builds, else 0 */
