@@ -29,7 +29,7 @@ static_assert(sizeof(ViewRow) == 16, "ViewRow must be 16 bytes");
 
 constexpr uint32_t kViewDropped = 0xFFFFFFFFu;   // ViewRow.read of a dropped duplicate (before k_view_compact)
 constexpr uint32_t kViewWaveRecs = 512;          // records one wavefront sorts in its slice of the LDS (8 KB)
-constexpr uint32_t kViewLdsRecs = 2048;          // records a workgroup sorts in LDS (32 KB)
+constexpr uint32_t kViewLdsRecs = 4096;          // records a workgroup sorts in LDS (one packed 64-bit word each: 32 KB)
 
 // offsets[r] = number of records of reads < r; offsets[n_reads] = total.  One block; thread t owns the reads
 // [t*chunk, (t+1)*chunk): sum them, scan the 256 sums, write the offsets (cursors are zeroed on the way).
@@ -138,17 +138,81 @@ __device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uin
     return dropped;
 }
 
+// ---- the same two steps on ONE 64-bit word per record, for segments of up to 4096 records (nearly all reads): the word
+// packs what the order depends on -- position << 36 | code << 28 | ins_offset << 12 | index of the record in the segment
+// -- so a compare-exchange moves 8 bytes instead of 16 and compares one integer.  The records themselves stay where they
+// are in global memory and are fetched once, in sorted order, when the rows are written.  Entries of one key then stand
+// next to each other in arbitrary order: the first of them looks through the run and keeps the one the reference met
+// first (smallest value word).
+__device__ __forceinline__ unsigned long long view_pack(unsigned long long k, unsigned long long v, uint32_t idx) {
+    return ((k & 0x0FFFFFFFull) << 36) | ((v >> 56) << 28) | (((v >> 40) & 0xFFFFull) << 12) | (unsigned long long)idx;
+}
+
+template <int kThreads>
+__device__ __forceinline__ void view_bitonic1(unsigned long long* P, uint32_t n, uint32_t tid) {
+    uint32_t l2 = 0;
+    while ((1u << l2) < n) l2++;
+    const uint32_t half = (1u << l2) >> 1;
+    for (uint32_t lk = 1; lk <= l2; lk++) {
+        const uint32_t k = 1u << lk;
+        for (uint32_t lj = lk; lj-- > 0;) {
+            const uint32_t j = 1u << lj;
+            const bool flip = lj + 1u == lk;
+            for (uint32_t t = tid; t < half; t += kThreads) {
+                uint32_t lo = ((t >> lj) << (lj + 1u)) | (t & (j - 1u));
+                uint32_t hi = flip ? (lo ^ (k - 1u)) : (lo + j);
+                if (hi < n) {
+                    unsigned long long a = P[lo], b = P[hi];
+                    if (b < a) { P[lo] = b; P[hi] = a; }
+                }
+            }
+            if (kThreads == 64) wave_sync(); else __syncthreads();
+        }
+    }
+}
+
+template <int kThreads>
+__device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P, const unsigned long long* __restrict__ gk,
+                                                    const unsigned long long* __restrict__ gv, uint32_t n, uint32_t tid, uint32_t r,
+                                                    int32_t rpos, ViewRow* __restrict__ out) {
+    uint32_t dropped = 0;
+    for (uint32_t i = tid; i < n; i += kThreads) {
+        const unsigned long long pi = P[i];
+        const bool head = i == 0 || (P[i - 1] >> 12) != (pi >> 12);
+        ViewRow o;
+        if (head) {
+            uint32_t best = (uint32_t)(pi & 0xFFFull);
+            unsigned long long bv = gv[best];
+            for (uint32_t j = i + 1; j < n && (P[j] >> 12) == (pi >> 12); j++) {   // other entries of the same key: rare, short
+                uint32_t cand = (uint32_t)(P[j] & 0xFFFull);
+                unsigned long long cv = gv[cand];
+                if (cv < bv) { bv = cv; best = cand; }
+            }
+            const unsigned long long k = gk[best];
+            o.read = r;
+            o.pos = rpos + (int32_t)((uint32_t)k & 0x0FFFFFFFu) - 1;
+            o.read_pos = (uint32_t)(bv & 0x0FFFFFFFull);
+            o.ins_offset = (uint16_t)((bv >> 40) & 0xFFFFull); o.code = (uint8_t)(bv >> 56); o.prob = (uint8_t)(k >> 56);
+        } else {
+            o.read = kViewDropped; o.pos = 0; o.read_pos = 0; o.ins_offset = 0; o.code = 0; o.prob = 0;
+            dropped++;
+        }
+        out[i] = o;
+    }
+    return dropped;
+}
+
 // One launch, two kinds of workers, so that the few big reads do not serialise behind the many small ones:
-//   blocks [0, n_big_blocks)   take the reads with MORE than kViewWaveRecs records, one workgroup per read (records in
-//                              the workgroup's 32 KB of LDS up to kViewLdsRecs, in place in global memory beyond);
+//   blocks [0, n_big_blocks)   take the reads with MORE than kViewWaveRecs records, one workgroup per read (packed
+//                              sort words in the workgroup's 32 KB of LDS up to kViewLdsRecs, whole records in place in
+//                              global memory beyond);
 //   the other blocks           take the reads with up to kViewWaveRecs records (nearly all of them), one WAVEFRONT per
 //                              read in its own slice of the same LDS, no workgroup barriers.
 __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
                                                    const unsigned int* __restrict__ offsets, uint32_t n_reads, uint32_t n_big_blocks,
                                                    const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows,
                                                    unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped) {
-    __shared__ unsigned long long sk[kViewLdsRecs];
-    __shared__ unsigned long long sv[kViewLdsRecs];
+    __shared__ unsigned long long sp[kViewLdsRecs];   // packed sort words: a workgroup's segment, or four waves' slices
     __shared__ uint32_t drop_s;
     static_assert(kViewLdsRecs >= kWavesPerBlock * kViewWaveRecs, "one LDS layout for both kinds of workers");
     if (blockIdx.x < n_big_blocks) {
@@ -161,10 +225,10 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
             unsigned long long* gv = vals + off;
             uint32_t dropped;
             if (n <= kViewLdsRecs) {
-                for (uint32_t i = threadIdx.x; i < n; i += 256) { sk[i] = gk[i]; sv[i] = gv[i]; }
+                for (uint32_t i = threadIdx.x; i < n; i += 256) sp[i] = view_pack(gk[i], gv[i], i);
                 __syncthreads();
-                view_bitonic<256>(sk, sv, n, threadIdx.x);
-                dropped = view_emit_rows<256>(sk, sv, n, threadIdx.x, r, reads[r].pos, rows + off);
+                view_bitonic1<256>(sp, n, threadIdx.x);
+                dropped = view_emit_rows1<256>(sp, gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
             } else {
                 view_bitonic<256>(gk, gv, n, threadIdx.x);
                 dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
@@ -180,18 +244,17 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
         return;
     }
     const uint32_t wv = threadIdx.x >> 6, lane = (uint32_t)lane_id();
-    unsigned long long* K = sk + wv * kViewWaveRecs;
-    unsigned long long* V = sv + wv * kViewWaveRecs;
+    unsigned long long* Pw = sp + wv * kViewWaveRecs;
     const uint32_t n_small_waves = (gridDim.x - n_big_blocks) * kWavesPerBlock;
     for (uint32_t r = (blockIdx.x - n_big_blocks) * kWavesPerBlock + wv; r < n_reads; r += n_small_waves) {
         const uint32_t off = uniu(offsets[r]), n = uniu(offsets[r + 1]) - off;
         if (n == 0) { if (lane == 0) kept[r] = 0; continue; }
         if (n > kViewWaveRecs) continue;        // a workgroup's job
         wave_sync();
-        for (uint32_t i = lane; i < n; i += 64) { K[i] = keys[off + i]; V[i] = vals[off + i]; }
+        for (uint32_t i = lane; i < n; i += 64) Pw[i] = view_pack(keys[off + i], vals[off + i], i);
         wave_sync();
-        view_bitonic<64>(K, V, n, lane);
-        uint32_t dropped = view_emit_rows<64>(K, V, n, lane, r, reads[r].pos, rows + off);
+        view_bitonic1<64>(Pw, n, lane);
+        uint32_t dropped = view_emit_rows1<64>(Pw, keys + off, vals + off, n, lane, r, reads[r].pos, rows + off);
         uint32_t tot = lane_valu(wave_incl_scan(dropped), 63);
         if (lane == 0) {
             kept[r] = n - tot;
