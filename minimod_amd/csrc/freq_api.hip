@@ -184,6 +184,22 @@ DevParams base_params(mm_freq* h) {
     return p;
 }
 
+// order the rows of a view batch (view_kernels.hip.h): counting sort by read, then one small sort per read.  Everything
+// takes its sizes from device memory, so nothing here waits for the call kernels.
+int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
+    unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates
+    const uint32_t nr = (uint32_t)b->n_reads;
+    hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
+    hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount,
+                       s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
+    const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
+    const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
+    hipLaunchKernelGGL(k_view_sort, dim3(big_blocks + small_blocks), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff, nr, big_blocks, b->reads,
+                       s.d_vrows, s.d_vkept, tail);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     DevParams p = base_params(h);
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
@@ -259,7 +275,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         tp.fb_list = s.d_fb; tp.fb_count = ctl + 4;
         s.h_ctl[130] = 0u;
         tp.host_fb_flag = s.h_ctl + 130;
-        tp.reset_in_call = h->opts.view ? 0 : 1;   // view orders its rows right behind the call kernels: it keeps the fused launch inline
+        tp.reset_in_call = 1;
     }
     if (b->n_reads <= 0) {   // no kernel will run: the set the next launch uses is reset from the host
         for (int i = 0; i < kCtlWords; i++) s.h_ctl[i] = 0u;
@@ -288,10 +304,10 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             }
             HIPCHK(hipGetLastError());
             // reads the tile form does not cover: the fused kernel over the fallback list.  The list is nearly always
-            // empty, so in freq mode that launch is not made now: a read that goes on the list raises a flag in pinned
-            // host memory and mm_freq_wait runs the kernel then (finish_deferred).
+            // empty, so that launch is not made now: a read that goes on the list raises a flag in pinned host memory and
+            // mm_freq_wait / mm_view_fetch run the kernel then (finish_deferred; view orders its rows again afterwards).
             p.order = s.d_fb; p.n_items = 0; p.n_items_dev = ctl + 4; p.queue = ctl + 5;
-            s.fb_deferred = !h->opts.view;
+            s.fb_deferred = true;
             s.fb_params = p;
         }
         if (!(h->use_tiles && s.fb_deferred)) {
@@ -305,22 +321,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         }
         HIPCHK(hipGetLastError());
     }
-    if (h->opts.view && b->n_reads > 0) {
-        // order the rows (view_kernels.hip.h): counting sort by read, then one small sort per read.  Everything takes its
-        // sizes from device memory, so nothing here waits for the call kernels.
-        unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates
-        const uint32_t nr = (uint32_t)b->n_reads;
-        hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
-        hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount,
-                           s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
-        {
-            const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
-            const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
-            hipLaunchKernelGGL(k_view_sort, dim3(big_blocks + small_blocks), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff, nr, big_blocks, b->reads,
-                               s.d_vrows, s.d_vkept, tail);
-        }
-        HIPCHK(hipGetLastError());
-    }
+    if (h->opts.view && b->n_reads > 0) { int rv = enqueue_view_ordering(h, s, b, st); if (rv) return rv; }
     HIPCHK(hipEventRecord(s.ev_stop, st));
     // no copy back on the good path: kernels flag a failure in pinned host memory (DevParams.host_flag)
     s.ctl_set ^= 1;
@@ -341,11 +342,24 @@ int finish_deferred(mm_freq* h, Slot& s) {
     if (s.h_ctl[130] == 0u) return 0;
     const DevParams& p = s.fb_params;
     const int blocks = std::min(h->n_cu * h->blocks_per_cu, 128);
-    if (h->wide) hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
-    else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+    if (h->wide) {
+        if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+        else hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+    } else {
+        if (p.view) hipLaunchKernelGGL((k_freq_reads<uint16_t, true>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+        else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+    }
     HIPCHK(hipGetLastError());
+    if (p.view) {
+        // the fused kernel appended records: order the batch's rows again (the ordering pass only reads the regional
+        // buffers and the per-read counts, so running it twice is harmless) and fetch the counts it works from
+        HIPCHK(hipMemsetAsync(s.d_vcount + kViewRegions * kViewCountStride, 0, 2 * sizeof(unsigned int), s.last_stream));
+        int rv = enqueue_view_ordering(h, s, &s.last_batch, s.last_stream);
+        if (rv) return rv;
+        HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, s.last_stream));
+    }
     HIPCHK(hipStreamSynchronize(s.last_stream));
-    return 0;
+    return 1;
 }
 
 // batches that were never waited for may still owe their fallback list (slab functions run on a caller's stream and do not
@@ -355,7 +369,7 @@ int settle(mm_freq* h) {
         if (!s.fb_deferred) continue;
         HIPCHK(hipEventSynchronize(s.ev_wait));
         int r = finish_deferred(h, s);
-        if (r) return r;
+        if (r < 0) return r;
     }
     return 0;
 }
@@ -363,7 +377,7 @@ int settle(mm_freq* h) {
 // every batch submitted so far is complete, fallback lists included (before counters are read or changed)
 int drain(mm_freq* h) {
     HIPCHK(hipDeviceSynchronize());
-    for (auto& s : h->slots) { int r = finish_deferred(h, s); if (r) return r; }
+    for (auto& s : h->slots) { int r = finish_deferred(h, s); if (r < 0) return r; }
     return 0;
 }
 
@@ -741,7 +755,7 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
-    if (finish_deferred(h, s) != 0) return MM_E_HIP;
+    if (finish_deferred(h, s) < 0) return MM_E_HIP;
     if (s.h_ctl[129] != 0xFFFFFFFFu) {
         unsigned int sum = 0xFFFFFFFFu;
         if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
@@ -974,6 +988,7 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipEventSynchronize(s.ev_wait));
         s.busy = false;
+        { int rf = finish_deferred(h, s); if (rf < 0) return rf; }
         if (s.h_ctl[129] != 0xFFFFFFFFu) {
             unsigned int sum = 0xFFFFFFFFu;
             HIPCHK(hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost));
