@@ -30,6 +30,8 @@ cases = {
                      kw=dict(insertions=True, haplotypes=True)),
   "star_ctx_single": dict(gen=dict(n=200, single_code=True), c=[("m","*")], th=[0.9], kw={}),
   "dot_long": dict(gen=dict(n=60, dot_fraction=1.0), c=[("m","C")], th=[0.8], kw={}),   # view: tens of thousands of rows per read
+  # BASELINE.json configs[2]: multi-mod -c m[CG],h[CG] -m 0.8,0.7 on PacBio-HiFi-shape reads with the MM '?' flag
+  "hifi_q_multimod": dict(gen=dict(n=600, shape=1, dot_fraction=0.0), c=[("m","CG"),("h","CG")], th=[0.8,0.7], kw={}),
 }
 for name, cs in cases.items():
     g = dict(cs["gen"]); n = g.pop("n")
@@ -58,7 +60,7 @@ def test_synthetic_shapes_match_oracle(fused):
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long"}
+    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long", "hifi_q_multimod"}
     for name, v in res.items():
         assert v["rows"] > 1000, (name, v)
         assert v["equal"], (name, v)
@@ -114,6 +116,49 @@ def test_bench_view_results_match_oracle(tmp_path):
     assert len(want) > 10000 and len(got) == len(want)
     for a, b in (("read", "read"), ("pos", "pos"), ("read_pos", "read_pos"), ("prob", "prob"), ("ins_offset", "ins_off")):
         assert (got[a] == want[b]).all()
+
+
+DEPTH_WORKER = r'''
+import json, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+# BASELINE.json configs[4]: --haplotypes --insertions, 200x depth on a 5 Mb region (per-HP planes, atomic contention)
+region = 5 << 20
+ref = synth.reference(31, region + (1 << 20))
+n = 66000
+bs = [synth.batch(ref, i * 4096, min(4096, n - i * 4096), seed=41, n_reads_total=n, region_begin=0, region_len=region, haplotypes=True)
+      for i in range((n + 4095) // 4096)]
+bases = sum(b["n_bases"] for b in bs)
+eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], insertions=True, haplotypes=True, side_capacity=32 << 20)
+t0 = time.time()
+tk = []
+for b in bs:
+    tk.append(eng.submit(b))
+    if len(tk) >= 3: eng.wait(tk.pop(0))
+for t in tk: eng.wait(t)
+got = eng.finalize(); eng.close()
+t_gpu = time.time() - t0
+orc = O.Oracle([("m", "CG")], [0.8], ["chrS"], insertions=True, haplotypes=True); orc.add_contig("chrS", ref)
+for b in bs: orc.process(b, threads=64)
+want = orc.rows()
+key = lambda r, io: (r["pos"].astype(np.int64) << 24) | (r["strand"].astype(np.int64) << 23) | ((r["hp"].astype(np.int64) + 1) << 17) | r[io].astype(np.int64)
+ga, wa = np.argsort(key(got, "ins_offset"), kind="stable"), np.argsort(key(want, "ins_off"), kind="stable")
+eq = len(got) == len(want) and (key(got, "ins_offset")[ga] == key(want, "ins_off")[wa]).all() and \
+     (got["n_called"][ga] == want["n_called"][wa]).all() and (got["n_mod"][ga] == want["n_mod"][wa]).all()
+print(json.dumps({"rows": int(len(want)), "equal": bool(eq), "depth": bases / region, "max_called": int(want["n_called"].max()), "gpu_s": t_gpu}))
+'''
+
+
+def test_deep_region_haplotypes_insertions():
+    """200x depth on a 5 Mb region with --haplotypes --insertions (BASELINE.json configs[4]): every counter takes
+    hundreds of atomic updates, the side list takes the inserted calls; bit-exact against the oracle."""
+    r = subprocess.run([sys.executable, "-c", DEPTH_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["depth"] > 150 and res["max_called"] > 60 and res["rows"] > 100000 and res["equal"], res
 
 
 SHARD_WORKER = r'''
