@@ -57,6 +57,7 @@ struct Slot {
     uint32_t* d_gqdir = nullptr; size_t cap_gqdir = 0;
     uint32_t* d_grdir = nullptr; size_t cap_grdir = 0;
     uint2* d_gsum = nullptr; size_t cap_gsum = 0;
+    uint32_t* d_gtok = nullptr; size_t cap_gtok = 0;
     TileRec* d_tiles = nullptr; size_t cap_tiles = 0;
     int32_t* d_fb = nullptr; size_t cap_fb = 0;
     unsigned int* h_ctl = nullptr;   // pinned copy
@@ -264,11 +265,12 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             (r = grow(h, (void**)&s.d_gnb, &s.cap_gnb, 4 * (size_t)std::max(b->n_reads, 1))) ||
             (r = grow(h, (void**)&s.d_gqdir, &s.cap_gqdir, 4 * ((size_t)b->n_seq_bytes / 128 + 2 * (size_t)b->n_reads + 16))) ||
             (r = grow(h, (void**)&s.d_grdir, &s.cap_grdir, 4 * ((size_t)b->n_seq_bytes / 32 + 2 * (size_t)b->n_reads + 16))) ||
+            (r = grow(h, (void**)&s.d_gtok, &s.cap_gtok, 4 * ((size_t)b->n_mm_bytes / 2 + 256))) ||
             (r = grow(h, (void**)&s.d_gsum, &s.cap_gsum, sizeof(uint2) * (tile_cap / kTileRegions + 64) * kTileRegions)) ||
             (r = grow(h, (void**)&s.d_tiles, &s.cap_tiles, sizeof(TileRec) * (tile_cap / kTileRegions + 64) * kTileRegions)) ||
             (r = grow(h, (void**)&s.d_fb, &s.cap_fb, 4 * (size_t)std::max(b->n_reads, 1))))
             return r;
-        tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot; tp.g_nb = s.d_gnb; tp.g_sum = s.d_gsum; tp.g_qdir = s.d_gqdir; tp.g_rdir = s.d_grdir;
+        tp.g_cq = s.d_gcq; tp.g_cr = s.d_gcr; tp.g_dir = s.d_gdir; tp.g_qtot = s.d_gqtot; tp.g_nb = s.d_gnb; tp.g_sum = s.d_gsum; tp.g_tok = s.d_gtok; tp.g_qdir = s.d_gqdir; tp.g_rdir = s.d_grdir;
         tp.tiles = s.d_tiles; tp.tile_cap = (unsigned int)std::min<size_t>(tile_cap / kTileRegions + 64, 0x3FFFFFFu);
         tp.tile_count = ctl + 8; tp.tile_queue = s.d_tq + kQueueWords * s.ctl_set;
         tp.scan_queue = tp.tile_queue + 64 * kQueueStride;
@@ -433,7 +435,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
-                      s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_tiles, s.d_fb,
+                      s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
                       s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);

@@ -55,6 +55,9 @@ struct TileParams {
     uint32_t* g_rdir;         // coarse: directory block containing rank 64*k       (base (seq_off >> 5) + 2*ridx)
     TileRec* tiles;           // kTileRegions regions of tile_cap records each
     uint2* g_sum;             // per tile: x = tokens | n_codes << 16, y = sum(skip+1)
+    uint32_t* g_tok;          // the listed tokens of every tile of a requested group, as k_sum_tiles parsed them: running sum of
+                              // (skip+1) inside the tile.  A token is at least two characters, so the tokens of the tile at
+                              // character c of the MM pool fit from index c/2 on: [n_mm_bytes / 2 + 128]
     unsigned int* tile_count; // [kTileRegions] tiles reserved so far in each region (one shared counter would serialise)
     unsigned int tile_cap;    // records per region
     unsigned int* scan_queue; // [kTileRegions * kQueueStride] hand-out counters of k_scan_reads (items behind the static first round)
@@ -76,7 +79,6 @@ struct ScanLds {
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
 constexpr uint32_t kSliceC = 640;   // CIGAR ops staged in LDS per tile
 struct CallLds {
-    uint32_t mmw[68];
     uint32_t tok[128];
     uint32_t gap[64];
     uint32_t gstart[64];
@@ -678,6 +680,8 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
             const mm_read_t& rd = p.reads[ridx];
             const uint32_t mlen = uniu(rd.mm_len);
             const uint8_t* mm = p.mm + rd.mm_off;
+            const bool keep = !(flags & 64u);   // a group nobody asked for is only counted
+            uint32_t* const tok_out = P.g_tok + ((rd.mm_off + cpos) >> 1);
             uint32_t wd = mm_dword(mm, mlen, cpos + 4u * lane);
             uint32_t la = lane < 4 ? mm_dword(mm, mlen, cpos + 256u + 4u * lane) : 0u;
             bool prev_delim = tile_prev_delim(mm, cpos, flags);
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
                 if (sp.err) terr = sp.err;
                 uint64_t tb = __ballot(sp.tstart);
                 uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
+                if (keep && sp.tstart) tok_out[ntok + (uint32_t)__popcll(tb & lanemask_lt())] = rsum_v + sm;   // k_call_tiles does not parse again
                 rsum_v += lane_valu(sm, 63);
                 ntok += (uint32_t)__popcll(tb);
                 if (sp.endl < 64) closed = true;
@@ -1086,39 +1091,17 @@ struct KC {
                 process_calls<1>(r2, k2, l2, false);
             }
         } else {
-            // the tile's 256 characters (+16 of look-ahead) -> LDS, tokens compacted into tok[]
-            uint32_t wd = mm_dword(mm, mlen, t.cpos + 4u * lane);
-            uint32_t la = lane < 4 ? mm_dword(mm, mlen, t.cpos + 256u + 4u * lane) : 0u;
-            bool prev_delim = tile_prev_delim(mm, t.cpos, fl), closed = false;
-            S.mmw[lane] = wd;
-            if (lane < 4) S.mmw[64 + lane] = la;
-            wave_sync();
-            const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-            uint32_t ntok = 0;
-#pragma unroll 1
-            for (int sub = 0; sub < 4; sub++) {
-                if (closed) continue;
-                SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
-                uint64_t tb = __ballot(sp.tstart);
-                if (sp.tstart) S.tok[ntok + __popcll(tb & lanemask_lt())] = sp.v;
-                ntok += (uint32_t)__popcll(tb);
-                if (sp.endl < 64) closed = true;
-                else prev_delim = sp.last_char == ',';
+            // the tile's listed tokens as k_sum_tiles left them (running sums of skip+1 inside the tile) -> ranks in tok[]
+            // (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
+            const uint32_t ntok = uniu(rsum[t.index].x) & 0xFFFFu;
+            const uint32_t* const tok_in = P.g_tok + ((rd.mm_off + t.cpos) >> 1);
+            {
+                uint32_t v0 = (uint32_t)lane < ntok ? tok_in[lane] : 0u, v1 = (uint32_t)lane + 64u < ntok ? tok_in[lane + 64] : 0u;
+                if ((uint32_t)lane < ntok) S.tok[lane] = rank_carry0 + v0 - 1u;
+                if ((uint32_t)lane + 64u < ntok) S.tok[lane + 64] = rank_carry0 + v1 - 1u;
             }
             wave_sync();
             KAT_LAP(9);
-            // skip counts -> ranks, in place (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
-            uint32_t carry = rank_carry0;
-#pragma unroll 1
-            for (uint32_t t64 = 0; t64 < ntok; t64 += 64u) {
-                uint32_t ti = t64 + lane;
-                bool lv = ti < ntok;
-                uint32_t su = lv ? S.tok[ti] : 0u;
-                uint32_t incl = wave_incl_scan(lv ? su + 1u : 0u);
-                if (lv) S.tok[ti] = carry + incl - 1u;
-                carry += lane_valu(incl, 63);
-            }
-            wave_sync();
             if (ntok > 0) {
                 // listed ranks rise with the token index: the first and last token bound everything this tile touches;
                 // both slices are staged before the first call ('.' groups also visit the gap in front of the first token)
