@@ -62,6 +62,9 @@ ORACLE_CASES = [
     ("dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", dict(c="*[CG]", allow_secondary=True)),
     ("dRNA.bam", dict(c="17802[*],a,m[C]")),
     ("dna_5mCG_5hmCG_mm_chr22.bam", dict(c="m,h", m="0.8,0.7", insertions=True, haplotypes=True, K=7)),
+    # more than five -c entries: 32-bit reference words (two context bits per entry), the kernels' uint32 instantiation
+    ("example-ont.bam", dict(c="m[CG],h[CG],a[A],c[C],f[C],e[T],b[T]", m="0.8,0.7,0.6,0.8,0.8,0.8,0.8")),
+    ("dRNA.bam", dict(c="17802[*],a,m[C],17596[A],19228[C],19227[T],69426[A],19229[G],o,n,g,e,b", insertions=True)),
 ]
 
 

@@ -77,6 +77,8 @@ ORACLE_VIEW_CASES = [
     ("dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", dict(c="*[CG]", allow_secondary=True)),
     ("dRNA.bam", dict(c="17802[*],a,m[C]")),
     ("dna_5mCG_5hmCG_mm_chr22.bam", dict(c="m,h", insertions=True, haplotypes=True, K=7)),
+    ("example-ont.bam", dict(c="m[CG],h[CG],a[A],c[C],f[C],e[T],b[T]")),      # > 5 entries: 32-bit reference words
+    ("dRNA.bam", dict(c="17802[*],a,m[C],17596[A],19228[C],19227[T],69426[A],19229[G],o,n,g,e,b")),
 ]
 
 
