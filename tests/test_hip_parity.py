@@ -173,3 +173,18 @@ def test_unwaited_tickets_and_fallback_reads(chr22):
     a = O.format_rows(want, names, wcodes)
     b = O.format_rows(got, names, codes)
     assert len(want) > 1000 and sorted(a.splitlines()) == sorted(b.splitlines())
+
+
+def test_wildcard_codes_beyond_the_dense_planes_and_side_list_full(chr22):
+    """-c '*' on dRNA.bam interns eight code strings; with two dense planes the other six count through the side list.
+    A side list that is too small is reported (MM_E_SIDEFULL), not silently truncated."""
+    import minimod_amd
+    path = os.path.join(GOLDEN, "data", "dRNA.bam")
+    want, names, wcodes = O.freq(path, chr22, c="*")
+    got, _, gcodes = hip_freq(path, chr22, c="*", n_wild_planes=2)
+    assert len(wcodes) >= 8 and len(want) > 1000
+    a, b = O.format_rows(want, names, wcodes), O.format_rows(got, names, gcodes)
+    assert sorted(a.splitlines()) == sorted(b.splitlines())
+    with pytest.raises(minimod_amd.engine.MinimodHipError) as e:
+        hip_freq(path, chr22, c="*", n_wild_planes=1, side_capacity=64)
+    assert e.value.code == 32
