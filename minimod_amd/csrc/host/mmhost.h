@@ -82,6 +82,7 @@ void mmh_print_view_rows(FILE *fp, const mm_view_row_t *rows, int64_t n, const m
 
 int mmh_freq_main(int argc, char **argv);
 int mmh_view_main(int argc, char **argv);
+int mmh_summary_main(int argc, char **argv);   /* host only */
 
 #ifdef __cplusplus
 }

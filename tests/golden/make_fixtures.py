@@ -33,7 +33,10 @@ BAMS = ["example-ont.bam", "example-hifi.bam", "hap.bam", "eb.bam", "dna_5mCG_5h
 EXPECTED = ["test3.tsv", "test4.bedmethyl", "test5.tsv", "test5a.tsv", "test5b.tsv", "test5c.tsv",
             "test6.bedmethyl", "test7.tsv", "test8.tsv", "test9.tsv", "test12.tsv", "test16.tsv",
             "test2.tsv", "test2c.tsv", "test10.tsv", "test11.tsv", "test15.tsv",
-            "test1.tsv", "test2a.tsv", "test2b.tsv", "test2c_wild.tsv", "test17a.tsv"]
+            "test1.tsv", "test2a.tsv", "test2b.tsv", "test2c_wild.tsv", "test17a.tsv",
+            "test18.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22_summary.tsv",
+            "dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_sec.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_nosup.tsv",
+            "dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_sec_nosup.tsv"]
 
 
 def chr22_patches():

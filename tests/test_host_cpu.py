@@ -253,3 +253,28 @@ def test_loader_reports_truncated_file(tmp_path):
     open(cut, "wb").write(raw[:len(raw) * 2 // 3])
     with pytest.raises(IOError):
         list(hostlib.load_batches(cut, K=4096, B=10 ** 9, threads=3))
+
+
+SUMMARY_CASES = [
+    ("test18.tsv", "dRNA.bam", []),
+    ("dna_5mCG_5hmCG_mm_with_secondary_chr22_summary.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", []),
+    ("dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_sec.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", ["--allow-secondary"]),
+    ("dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_nosup.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", ["--skip-supplementary"]),
+    ("dna_5mCG_5hmCG_mm_with_secondary_chr22_summary_sec_nosup.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam",
+     ["--allow-secondary", "--skip-supplementary"]),
+]
+
+
+@pytest.mark.parametrize("exp,bam,extra", SUMMARY_CASES, ids=[c[0] for c in SUMMARY_CASES])
+def test_cli_summary_matches_reference_golden(exp, bam, extra):
+    """`minimod summary` (host only, no GPU needed): byte-identical to the reference's goldens, which the reference's tests
+    compare with a plain diff (test/test.sh:252-256,494-503) -- including the order of a read's keys, which is the slot
+    order of the reference's hash table."""
+    import subprocess
+    import minimod_amd
+    minimod_amd.build_all()
+    binp = os.path.join(os.path.dirname(GOLDEN), "..", "minimod_amd", "bin", "minimod")
+    for more in ([], ["-K", "7", "-t", "3"]):
+        r = subprocess.run([binp, "summary"] + extra + more + [os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout.decode() == open(os.path.join(GOLDEN, "expected", exp)).read()
