@@ -697,7 +697,7 @@ const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
 }
 
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
-    if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24)) return -MM_E_ARG;
+    if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     int si = acquire_slot(h);
     Slot& s = h->slots[si];
@@ -710,7 +710,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
 }
 
 int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
-    if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24)) return -MM_E_ARG;
+    if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     int si = acquire_slot(h);
     Slot& s = h->slots[si];

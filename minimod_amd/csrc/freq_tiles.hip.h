@@ -69,6 +69,9 @@ struct TileParams {
     int32_t reset_in_call;       // 1: k_call_tiles is the launch's last kernel and resets the next launch's control words
 };
 
+// g_sum between k_scan_reads and k_sum_tiles: x = offset of the tile's first character in the MM pool, y = these bits |
+// n_codes << 16 | characters left in the read's MM string from there (capped at 511)
+constexpr uint32_t kSumParse = 0x80000000u, kSumFirst = 0x40000000u, kSumKeep = 0x20000000u;
 constexpr uint32_t kGroupEnds = 32;
 struct ScanLds {
     uint32_t mmw[260];   // 1024 MM characters + 16 of look-ahead
@@ -144,66 +147,28 @@ __device__ __forceinline__ uint32_t mm_dword(const uint8_t* mm, uint32_t mlen, u
     return w;
 }
 
-// One 64-character sub-chunk of a skip list held in LDS bytes mb8[0..]: token starts, values, where the group ends.
-struct SubParse {
-    bool tstart;
-    uint32_t v;
-    int endl;       // 64 = no ';' here
-    int err;
-    int last_char;
-};
-__device__ __forceinline__ SubParse parse_sub(const uint8_t* mb8, int base, bool prev_delim) {
-    const int lane = lane_id();
-    SubParse r;
-    int x = mb8[base + lane];
-    uint64_t semi = __ballot(x == ';');
-    r.endl = semi ? __ffsll((unsigned long long)semi) - 1 : 64;
-    bool in = lane < r.endl;
-    int pv = __shfl_up(x, 1, 64);
-    bool pdel = lane == 0 ? prev_delim : (pv == ',');
-    r.tstart = in && x != ',' && pdel;
-    r.v = 0;
-    r.err = 0;
-    {
-        // decimal fold from the token's first character (mod.c:1074-1081): at most nine digits, then the delimiter.  The
-        // first four characters are requested from LDS together and folded from registers (skip counts are mostly one
-        // to three digits; a loop that reads, tests and branches per character spends its time in dependent LDS round
-        // trips and in issue slots: it was most of k_sum_tiles); the other six only when some token is still open.
-        bool open = r.tstart;
-        int len = 0;
-        {
-            uint32_t d[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) d[j] = mb8[base + lane + j];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                open = open && d[j] != ',' && d[j] != ';';
-                if (open) {
-                    if (d[j] - '0' > 9u) r.err = MM_E_SKIPVAL;
-                    r.v = r.v * 10u + (d[j] - '0');
-                    len++;
-                }
-            }
-        }
-        if (__ballot(open)) {
-            uint32_t d[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) d[j] = mb8[base + lane + 4 + j];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                open = open && d[j] != ',' && d[j] != ';';
-                if (open) {
-                    if (d[j] - '0' > 9u) r.err = MM_E_SKIPVAL;
-                    r.v = r.v * 10u + (d[j] - '0');
-                    len++;
-                }
-            }
-        }
-        if (len == 10) r.err = MM_E_SKIPLEN;
+// ---- skip lists as sums over characters (k_sum_tiles)
+// A token "123" is 1*100 + 2*10 + 3*1: every digit knows its weight from the distance to the next delimiter, so the
+// running sum of (skip + 1) at a token's LAST digit is an inclusive scan over characters of
+//     digit * 10^(distance to the delimiter - 1)  +  (1 on a token's first character)
+// with no per-token loop, no multiply (the product comes from a 11 x 16 table in LDS) and the delimiter bitmaps held in
+// scalar registers.  kSumTabWords words: row e (distance 0..10), column d (digit value & 15).
+constexpr int kSumTabWords = 11 * 16;
+__device__ __forceinline__ void fill_sum_table(uint32_t* tab) {
+    for (int i = threadIdx.x; i < kSumTabWords; i += blockDim.x) {
+        int e = i >> 4, d = i & 15;
+        uint32_t w = 1;
+        for (int k = 1; k < e; k++) w *= 10u;
+        tab[i] = (e >= 1 && e <= 9 && d <= 9) ? (uint32_t)d * w : 0u;
     }
-    r.last_char = lane_val(x, 63);
-    return r;
 }
+// 32 bits of the 128-bit value (hi:lo) from bit `lane` on
+__device__ __forceinline__ uint32_t window32(uint64_t lo, uint64_t hi, int lane) {
+    uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = (uint32_t)hi;
+    uint32_t a = lane < 32 ? w0 : w1, b = lane < 32 ? w1 : w2;
+    return __builtin_amdgcn_alignbit(b, a, (uint32_t)lane & 31u);
+}
+__device__ __forceinline__ uint64_t low_bits(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
 
 // ------------------------------------------------------------------------------------------------ KA
 struct GroupHdr {
@@ -544,6 +509,8 @@ struct KA {
         }
         uint32_t tcur = tbase;
         TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
+        uint2* const rdesc = P.g_sum + (size_t)region * P.tile_cap;
+        const uint32_t mm_abs0 = (uint32_t)rd.mm_off;   // the MM pool of a batch is below 4 GiB (checked at submit)
         if (have_ref && irregular) {
             if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; if (P.host_fb_flag) *P.host_fb_flag = 1u; }
         }
@@ -580,6 +547,13 @@ struct KA {
                             t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
                             t.gord = gord;
                             rtiles[gfirst + j] = t;
+                            // what k_sum_tiles needs of a list tile, so that it goes from here straight to the text
+                            // (not record -> read -> text); it overwrites this with the tile's summary.  Tail tiles
+                            // get their summary here.
+                            uint32_t rem = mlen - t.cpos;
+                            rdesc[gfirst + j] = tail ? make_uint2((uint32_t)g.n << 16, 0u)
+                                                     : make_uint2(mm_abs0 + t.cpos, kSumParse | (j == 0 ? kSumFirst : 0u) | (unwanted ? 0u : kSumKeep) |
+                                                                                        ((uint32_t)g.n << 16) | (rem < 511u ? rem : 511u));
                         }
                     }
                     tcur += nlist + ntail;
@@ -593,7 +567,7 @@ struct KA {
         if (have_ref && need > 0) {
             uint32_t hi = tbase + need;
             if (hi > P.tile_cap) hi = P.tile_cap;
-            for (uint32_t i = tcur + lane; i < hi; i += 64) rtiles[i].flags = 0u;
+            for (uint32_t i = tcur + lane; i < hi; i += 64) { rtiles[i].flags = 0u; rdesc[i] = make_uint2(0u, 0u); }
         }
         return result;
     }
@@ -652,14 +626,13 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
 }
 
 // first-character state of a list tile: its first character starts a token iff the previous one is a delimiter
-__device__ __forceinline__ bool tile_prev_delim(const uint8_t* mm, uint32_t cpos, uint32_t flags) {
-    return (flags & 32u) ? true : (mm[cpos - 1u] == ',');
-}
-
 // ------------------------------------------------------------------------------------------------ KS
 template <typename RefWord>
 __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
     __shared__ uint32_t lds[kWavesPerBlock][68];
+    __shared__ uint32_t ptab[kSumTabWords];
+    fill_sum_table(ptab);
+    __syncthreads();
     const DevParams& p = P.d;
     const int lane = lane_id();
     uint32_t* mmw = lds[threadIdx.x >> 6];
@@ -671,46 +644,109 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
     n_tiles = uniu(n_tiles);
     const TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
     uint2* const rsum = P.g_sum + (size_t)region * P.tile_cap;
-    for (unsigned int ti = g / kTileRegions; ti < n_tiles; ti += n_waves / kTileRegions) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
-        const uint32_t ridx = uniu(src[0]), cpos = uniu(src[1]), flags = uniu(src[4]);
-        uint32_t ntok = 0, rsum_v = 0;
-        int terr = 0;
-        if ((flags & 1u) && !(flags & 2u)) {
-            const mm_read_t& rd = p.reads[ridx];
-            const uint32_t mlen = uniu(rd.mm_len);
-            const uint8_t* mm = p.mm + rd.mm_off;
-            const bool keep = !(flags & 64u);   // a group nobody asked for is only counted
-            uint32_t* const tok_out = P.g_tok + ((rd.mm_off + cpos) >> 1);
-            uint32_t wd = mm_dword(mm, mlen, cpos + 4u * lane);
-            uint32_t la = lane < 4 ? mm_dword(mm, mlen, cpos + 256u + 4u * lane) : 0u;
-            bool prev_delim = tile_prev_delim(mm, cpos, flags);
-            wave_sync();
-            mmw[lane] = wd;
-            if (lane < 4) mmw[64 + lane] = la;
-            wave_sync();
-            const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mmw);
-            bool closed = false;
-#pragma unroll 1
-            for (int sub = 0; sub < 4; sub++) {
-                if (closed) continue;
-                SubParse sp = parse_sub(mb8, 64 * sub, prev_delim);
-                if (sp.err) terr = sp.err;
-                uint64_t tb = __ballot(sp.tstart);
-                uint32_t sm = wave_incl_scan(sp.tstart ? sp.v + 1u : 0u);
-                if (keep && sp.tstart) tok_out[ntok + (uint32_t)__popcll(tb & lanemask_lt())] = rsum_v + sm;   // k_call_tiles does not parse again
-                rsum_v += lane_valu(sm, 63);
-                ntok += (uint32_t)__popcll(tb);
-                if (sp.endl < 64) closed = true;
-                else prev_delim = sp.last_char == ',';
-            }
-            uint64_t eb = __ballot(terr != 0);
-            if (eb) {
-                int e = lane_val(terr, __ffsll((unsigned long long)eb) - 1);
-                if (lane == 0) { p.status[ridx] = e; report_error(p, ridx, e); }
-            }
+    const unsigned int stride = n_waves / kTileRegions;
+    unsigned int ti = g / kTileRegions;
+    uint2 d = ti < n_tiles ? rsum[ti] : make_uint2(0u, 0u);
+    for (; ti < n_tiles; ti += stride) {
+        // the next tile's descriptor is requested before this tile's text
+        const unsigned int tn = ti + stride;
+        uint2 dn = tn < n_tiles ? rsum[tn] : make_uint2(0u, 0u);
+        const uint32_t dx = uniu(d.x), dy = uniu(d.y);
+        d = dn;
+        if (!(dy & kSumParse)) continue;   // tail and unused slots already hold their summary
+        const uint32_t rem = dy & 511u;
+        const uint8_t* mm = p.mm + dx;
+        const bool keep = (dy & kSumKeep) != 0;   // a group nobody asked for is only counted
+        uint32_t* const tok_out = P.g_tok + (dx >> 1);
+        uint32_t wd = mm_dword(mm, rem, 4u * lane);
+        uint32_t la = lane < 4 ? mm_dword(mm, rem, 256u + 4u * lane) : 0u;
+        const bool prev_delim = (dy & kSumFirst) ? true : (*(mm - 1) == ',');
+        wave_sync();
+        mmw[lane] = wd;
+        if (lane < 4) mmw[64 + lane] = la;
+        wave_sync();
+        const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mmw);
+        // characters: lane l holds 64*s + l of the four sub-chunks, lanes 0..15 the look-ahead; delimiter bitmaps
+        uint32_t x[4];
+#pragma unroll
+        for (int sc = 0; sc < 4; sc++) x[sc] = mb8[64 * sc + lane];
+        const uint32_t x4 = mb8[256 + (lane & 15)];
+        uint64_t D[5], Sm[4];
+#pragma unroll
+        for (int sc = 0; sc < 4; sc++) {
+            Sm[sc] = __ballot(x[sc] == ';');
+            D[sc] = Sm[sc] | __ballot(x[sc] == ',');
         }
-        if (lane == 0) rsum[ti] = make_uint2(ntok | (((flags >> 12) & 7u) << 16), rsum_v);
+        D[4] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;   // past the look-ahead: as if delimited
+        uint32_t nends = 0, rsum_v = 0;
+        uint64_t bad = 0;
+        bool closed = false, open_tail = false;
+#pragma unroll
+        for (int sc = 0; sc < 4; sc++) {
+            if (closed) break;
+            // the tile owns characters [lo, hi) of this sub-chunk: up to the group's ';', and not the rest of a token
+            // that began in the tile before
+            int lo = 0, hi = 64;
+            if (Sm[sc]) { hi = __ffsll((unsigned long long)Sm[sc]) - 1; closed = true; }
+            if (sc == 0 && !prev_delim) lo = D[0] ? __ffsll((unsigned long long)D[0]) - 1 : 64;
+            const uint64_t pd = sc == 0 ? (prev_delim ? 1ull : 0ull) : (D[sc > 0 ? sc - 1 : 0] >> 63);
+            // bit 0 of a lane's window: the character before it is a delimiter; bit 1: it is one; bit 2: the next is ...
+            const uint32_t w = window32((D[sc] << 1) | pd, (D[sc + 1] << 1) | (D[sc] >> 63), lane);
+            const bool own = (uint32_t)(lane - lo) < (uint32_t)(hi - lo) && lo < hi;
+            const bool start = own && (w & 3u) == 1u;
+            const bool end = own && (w & 6u) == 4u;
+            uint32_t e = (uint32_t)__ffs((int)(w >> 1)) - 1u;   // characters up to the delimiter (0: this is one)
+            e = e < 10u ? e : 10u;
+            const uint32_t dv = x[sc] - (uint32_t)'0';
+            uint32_t c = ptab[(e << 4) | (dv & 15u)];
+            c = own ? c : 0u;
+            c += start ? 1u : 0u;
+            const uint32_t run = wave_incl_scan(c);
+            const uint64_t eb = __ballot(end);
+            if (keep && end) tok_out[nends + (uint32_t)__popcll(eb & lanemask_lt())] = rsum_v + run;   // k_call_tiles does not parse again
+            bad |= __ballot(own && !(w & 2u) && dv > 9u) | __ballot(start && e >= 10u);
+            rsum_v += lane_valu(run, 63);
+            nends += (uint32_t)__popcll(eb);
+            if (sc == 3 && !closed) open_tail = ((D[3] >> 63) == 0) && ((D[4] & 1ull) == 0);
+        }
+        uint32_t ntok = nends;
+        if (open_tail) {
+            // the tile's last token runs into the look-ahead: its remaining digits
+            const int k = __ffsll((unsigned long long)D[4]) - 1;   // 1..16
+            const uint32_t dv = x4 - (uint32_t)'0';
+            uint32_t e = (uint32_t)(k - lane);
+            e = e < 10u ? e : 10u;
+            uint32_t c = lane < k ? ptab[(e << 4) | (dv & 15u)] : 0u;
+            bad |= __ballot(lane < k && dv > 9u);
+            rsum_v += lane_valu(wave_incl_scan(c), 15);
+            if (keep && lane == 0) tok_out[nends] = rsum_v;
+            ntok = nends + 1u;
+        }
+        if (bad) {
+            // rare: name the error as a sequential reader would (mod.c:1074-1081: a non-digit is seen before the
+            // tenth character is counted); one lane walks the tile's characters
+            int e = 0;
+            if (lane == 0) {
+                uint32_t i = 0;
+                if (!prev_delim) while (i < 272u && mb8[i] != ',' && mb8[i] != ';') i++;
+                while (i < 256u && !e) {
+                    uint32_t ch = mb8[i];
+                    if (ch == ';') break;
+                    if (ch == ',') { i++; continue; }
+                    int l = 0;
+                    while (i < 272u && mb8[i] != ',' && mb8[i] != ';') {
+                        if ((uint32_t)mb8[i] - (uint32_t)'0' > 9u) { e = MM_E_SKIPVAL; break; }
+                        i++; l++;
+                        if (l >= 10) { e = MM_E_SKIPLEN; break; }
+                    }
+                }
+                if (!e) e = MM_E_SKIPVAL;
+            }
+            e = lane_val(e, 0);
+            const uint32_t ridx = uniu(rtiles[ti].ridx);
+            if (lane == 0) { p.status[ridx] = e; report_error(p, ridx, e); }
+        }
+        if (lane == 0) rsum[ti] = make_uint2(ntok | (dy & 0x70000u), rsum_v);
     }
 }
 
@@ -734,6 +770,9 @@ struct KC {
     uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
     int32_t gc0, gc1, gc2, gc3;
+    // what a call needs of its code's table entries, fetched once per tile (wave-uniform; read per call they were
+    // three dependent global loads in every round): t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 | (plane + 1) << 23
+    uint32_t ci0, ci1, ci2, ci3;
     uint32_t v_ridx, v_gord, v_region;   // view mode: read index, group ordinal, append region
     // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
     // CIGAR ops [cs_lo, cs_lo+cs_cnt) answer read positions in [cs_q_lo, cs_q_hi)
@@ -741,6 +780,7 @@ struct KC {
     unsigned long long tacc[5] = {0, 0, 0, 0, 0};   // diagnostic builds: time per phase, flushed once per wave
 
     __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
+    __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
 
     __device__ KC(const TileParams& tp, CallLds& s) : P(tp), p(tp.d), S(s), err(0), st_look(0), st_ml(0), st_dense(0), st_side(0) {}
 
@@ -971,12 +1011,12 @@ struct KC {
             for (int m = 0; m < ncg; m++) {
                 int ci = gcode_at(m);
                 if (ci < 0) continue;
-                const DevCode& dc = p.codes[ci];
-                int req = dc.req;
-                const DevMod& dm = p.mods[req];
+                const uint32_t cinfo = cinfo_at(m);
+                const int req = (int)((cinfo >> 19) & 15u), dc_plane = (int)((cinfo >> 23) & 127u) - 1;
+                const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
                 if (!p.insertions) {
                     bool in_ctx = (w[u] >> (5 + 2 * req + rev)) & 1u;
-                    bool matches = dm.ctx_is_star || mb_is_N || refcode == code[u];
+                    bool matches = ((cinfo >> 18) & 1u) || mb_is_N || refcode == code[u];
                     if (!(in_ctx && matches)) continue;
                 }
                 int is_mod = 0;
@@ -990,8 +1030,8 @@ struct KC {
                                     (uint32_t)ci, v_gord, 0u, (uint32_t)mv);
                         continue;
                     }
-                    if (mv >= dm.t_hi) is_mod = 1;
-                    else if (mv <= dm.t_lo) is_mod = 0;
+                    if (mv >= t_hi) is_mod = 1;
+                    else if (mv <= t_lo) is_mod = 0;
                     else continue;
                 } else if (kView) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
                     view_append(p, v_region, v_ridx, (uint32_t)(ref_pos[u] - pos + 1), rev ? L - 1u - q[u] : q[u], ins_off[u],
@@ -999,8 +1039,8 @@ struct KC {
                     continue;
                 }
                 int64_t off = ref_pos[u] - seg_begin;
-                if (ins_off[u] == 0 && dc.plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
-                    unsigned long long* dst = p.counters + ((int64_t)(dc.plane * p.n_hp + hpi) * 2 + rev) * p.plane_len + cnt_base + off;
+                if (ins_off[u] == 0 && dc_plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
+                    unsigned long long* dst = p.counters + ((int64_t)(dc_plane * p.n_hp + hpi) * 2 + rev) * p.plane_len + cnt_base + off;
                     atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
                     st_dense++;
                 } else {
@@ -1080,6 +1120,18 @@ struct KC {
         const bool tail = fl & 2u, dot = fl & 4u;
         direct = (fl >> 3) & 1; mb_is_N = (fl >> 4) & 1; cls = (int)((fl >> 8) & 7u); ncg = (int)((fl >> 12) & 7u);
         gc0 = (int16_t)(gc01 & 0xFFFFu); gc1 = (int16_t)(gc01 >> 16); gc2 = (int16_t)(gc23 & 0xFFFFu); gc3 = (int16_t)(gc23 >> 16);
+        {
+            const int ci = lane == 0 ? gc0 : (lane == 1 ? gc1 : (lane == 2 ? gc2 : gc3));
+            uint32_t info = 0;
+            if (lane < ncg && lane < 4 && ci >= 0) {
+                const DevCode& dc = p.codes[ci];
+                const int req = dc.req, plane = dc.plane;
+                const DevMod& dm = p.mods[req];
+                info = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
+                       ((uint32_t)(plane + 1) << 23);
+            }
+            ci0 = lane_valu(info, 0); ci1 = lane_valu(info, 1); ci2 = lane_valu(info, 2); ci3 = lane_valu(info, 3);
+        }
         if (tail) {
             // bases after the last listed one (mod.c:1289-1365): this tile's slice of [rank_carry0, nb)
             const uint64_t lo64 = (uint64_t)rank_carry0 + (uint64_t)kTailRanks * t.cpos;
