@@ -180,6 +180,20 @@ __device__ __forceinline__ void view_append(const DevParams& p, uint32_t region,
                           ((unsigned long long)group << 29) | ((unsigned long long)implicit << 28) | (unsigned long long)fq_pos;
     }
 }
+// A wave-uniform address of data that no wave writes during the launch, read through the scalar cache: the value lands in
+// scalar registers (no vector register per load in flight, no readfirstlane) and several loads overlap freely.  The
+// compiler cannot prove either property for a plain global pointer and would issue vector loads.
+template <typename T> using kptr = const __attribute__((address_space(4))) T*;
+template <typename T> __device__ __forceinline__ kptr<T> scalar_ptr(const T* p) { return (kptr<T>)(uintptr_t)p; }
+template <typename T> __device__ __forceinline__ T scalar_load(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    T out;
+    const kptr<uint32_t> s = scalar_ptr(reinterpret_cast<const uint32_t*>(p));
+    uint32_t* d = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) d[i] = s[i];
+    return out;
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // value of lane `l` (wave-uniform l) as a wave-uniform scalar

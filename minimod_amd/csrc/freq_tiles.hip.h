@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
     const DevParams& p = P.d;
     const int lane = lane_id();
     uint32_t* mmw = lds[threadIdx.x >> 6];
-    const unsigned int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int g = uniu(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // the wave's index, as a scalar
     const unsigned int n_waves = gridDim.x * kWavesPerBlock;
     const unsigned int region = g % kTileRegions;
     unsigned int n_tiles = P.tile_count[region];
@@ -1068,21 +1068,33 @@ struct KC {
         KAT_DECL;
         const int ridx = (int)t.ridx;
         v_ridx = t.ridx; v_gord = t.gord; v_region = t.region;
-        const mm_read_t& rd = p.reads[ridx];
+        // Everything below is a chain of dependent memory round trips, a microsecond each under load; what does not depend
+        // on the read record is requested before it: the summaries of the read's tiles in front of this one (first 64)
+        // and the tile's own.
+        const bool list_tile = !(t.flags & 2u);
+        uint2 sv0 = make_uint2(0u, 0u), own_sv = make_uint2(0u, 0u);
+        if (t.read_first + (uint32_t)lane < t.index) sv0 = rsum[t.read_first + lane];
+        if (list_tile) own_sv = scalar_load(rsum + t.index);
+        const mm_read_t rd = scalar_load(p.reads + ridx);
         tid = uni(rd.tid); pos = uni(rd.pos);
         L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); ml_len = uniu(rd.ml_len);
         rev = (uni(rd.flag) & 0x10) ? 1 : 0;
-        const uint32_t mlen = uniu(rd.mm_len);
         seq = p.seq + rd.seq_off; ml = p.ml + rd.ml_off;
-        const uint8_t* mm = p.mm + rd.mm_off;
+        // ... and what only needs the read record goes out together: the tile's tokens, the per-contig bases, the read's totals
+        uint32_t tv0 = 0, tv1 = 0;
+        if (list_tile && !(t.flags & 64u)) {
+            const uint32_t* const tok_in = P.g_tok + ((rd.mm_off + t.cpos) >> 1);   // 128 words belong to the tile: no bound needed
+            tv0 = tok_in[lane]; tv1 = tok_in[lane + 64];
+        }
         gq = P.g_cq + rd.cigar_off; gr = P.g_cr + rd.cigar_off; gd = P.g_dir + (rd.seq_off >> 4);
         qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx; rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
         nblk = (L + 31u) >> 5;
-        q_total = P.g_qtot[ridx];
-        nb = P.g_nb[ridx];
+        q_total = scalar_load(P.g_qtot + ridx);
+        nb = scalar_load(P.g_nb + ridx);
         hp = p.haplotypes ? (int)rd.hp : -1;
         hpi = p.haplotypes ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
-        ref_base = p.ref_base[tid]; seg_begin = p.seg_begin[tid]; seg_len = p.seg_len[tid]; cnt_base = p.cnt_base[tid];
+        ref_base = scalar_load(p.ref_base + tid); seg_begin = scalar_load(p.seg_begin + tid);
+        seg_len = scalar_load(p.seg_len + tid); cnt_base = scalar_load(p.cnt_base + tid);
         // carries = prefix over the summaries of the read's tiles in front of this one:
         //   ml_start  = sum over earlier groups of tokens * n_codes      (mod.c:1200)
         //   k_carry   = tokens of this group in front of the tile
@@ -1091,7 +1103,7 @@ struct KC {
         for (uint32_t i0 = t.read_first; i0 < t.index; i0 += 64) {
             uint32_t i = i0 + lane;
             if (i < t.index) {
-                uint2 sv = rsum[i];
+                uint2 sv = i0 == t.read_first ? sv0 : rsum[i];
                 uint32_t nt = sv.x & 0xFFFFu, nc = (sv.x >> 16) & 7u;
                 if (i < t.group_first) a_ml += nt * nc;
                 else { a_k += nt; a_r += sv.y; }
@@ -1106,8 +1118,8 @@ struct KC {
             // No code of this group was requested: every call would be discarded (mod.c:1157).  The only thing the
             // reference still does with such a group is assert its read positions (mod.c:1116): the last listed rank
             // must exist.  (Its tokens still count towards ML indices: that is k_sum_tiles' job.)
-            if (!(t.flags & 2u)) {
-                uint2 own = rsum[t.index];
+            if (list_tile) {
+                const uint2 own = own_sv;
                 if ((own.x & 0xFFFFu) != 0u) {
                     uint32_t r_last = rank_carry0 + own.y - 1u;
                     if (r_last >= (((t.flags >> 3) & 1u) ? L : nb)) err = MM_E_READPOS;
@@ -1145,13 +1157,9 @@ struct KC {
         } else {
             // the tile's listed tokens as k_sum_tiles left them (running sums of skip+1 inside the tile) -> ranks in tok[]
             // (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
-            const uint32_t ntok = uniu(rsum[t.index].x) & 0xFFFFu;
-            const uint32_t* const tok_in = P.g_tok + ((rd.mm_off + t.cpos) >> 1);
-            {
-                uint32_t v0 = (uint32_t)lane < ntok ? tok_in[lane] : 0u, v1 = (uint32_t)lane + 64u < ntok ? tok_in[lane + 64] : 0u;
-                if ((uint32_t)lane < ntok) S.tok[lane] = rank_carry0 + v0 - 1u;
-                if ((uint32_t)lane + 64u < ntok) S.tok[lane + 64] = rank_carry0 + v1 - 1u;
-            }
+            const uint32_t ntok = uniu(own_sv.x) & 0xFFFFu;
+            if ((uint32_t)lane < ntok) S.tok[lane] = rank_carry0 + tv0 - 1u;
+            if ((uint32_t)lane + 64u < ntok) S.tok[lane + 64] = rank_carry0 + tv1 - 1u;
             wave_sync();
             KAT_LAP(9);
             if (ntok > 0) {
@@ -1238,7 +1246,7 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     }
     // static round-robin: wave g serves region g % kTileRegions, striding over that region's tiles with the other
     // waves of the same residue (tiles cost about the same; no shared work counter to serialise on)
-    const unsigned int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned int g = uniu(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // the wave's index, as a scalar
     const unsigned int n_waves = gridDim.x * kWavesPerBlock;
     const unsigned int region = g % kTileRegions;
     unsigned int n_tiles = P.tile_count[region];
@@ -1253,11 +1261,11 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     unsigned int ti = g / kTileRegions;
     while (ti < n_tiles) {
         // the tile record as wave-uniform scalars
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(rtiles + ti);
+        const kptr<uint32_t> src = scalar_ptr(reinterpret_cast<const uint32_t*>(rtiles + ti));
         typename KC<RefWord, kView>::TileArgs t;
-        t.ridx = uniu(src[0]); t.cpos = uniu(src[1]); t.read_first = uniu(src[2]); t.group_first = uniu(src[3]);
-        t.flags = uniu(src[4]); t.index = ti; t.gord = uniu(src[7]); t.region = region;
-        uint32_t gc01 = uniu(src[5]), gc23 = uniu(src[6]);
+        t.ridx = src[0]; t.cpos = src[1]; t.read_first = src[2]; t.group_first = src[3];
+        t.flags = src[4]; t.index = ti; t.gord = src[7]; t.region = region;
+        uint32_t gc01 = src[5], gc23 = src[6];
         if (t.flags & 1u) {
             int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
             if (e != 0 && lane_id() == 0) {
