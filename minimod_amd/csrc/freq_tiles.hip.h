@@ -274,17 +274,17 @@ struct KA {
     // front of it (cheap: no scans, no stores) to get its carries, then scans only its own ops.
     __device__ int run_cigar(int ridx, uint32_t part, uint32_t nparts) {
         const int lane = lane_id();
-        const mm_read_t& rd = p.reads[ridx];
+        const mm_read_t rd = scalar_load(p.reads + ridx);
         err = 0;
         const int tid = uni(rd.tid), pos = uni(rd.pos);
         const uint32_t L = uniu(rd.l_qseq), ncig = uniu(rd.n_cigar);
         const uint64_t cig_off = rd.cigar_off;
         bool have_ref = tid >= 0 && tid < p.n_contigs;
-        if (have_ref) have_ref = p.ref_base[tid] >= 0;
+        if (have_ref) have_ref = scalar_load(p.ref_base + tid) >= 0;
         int result = have_ref ? 0 : MM_E_NOCONTIG;
         if (have_ref) {
             const uint32_t* cg = p.cigar + cig_off;
-            const int64_t ctg_len = p.ctg_len[tid];
+            const int64_t ctg_len = scalar_load(p.ctg_len + tid);
             uint32_t* const qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx;
             uint32_t carry_q = 0, carry_r = 0;
             const uint32_t op_lo = (uint32_t)(((uint64_t)ncig * part) / nparts) & ~63u;   // chunk starts on a 64-op boundary
@@ -404,7 +404,7 @@ struct KA {
     // COUNTS the class members in front of it (no scans, no stores), then scans only its own blocks.
     __device__ int run_dir(int ridx, uint32_t part, uint32_t nparts) {
         const int lane = lane_id();
-        const mm_read_t& rd = p.reads[ridx];
+        const mm_read_t rd = scalar_load(p.reads + ridx);
         const uint32_t L = uniu(rd.l_qseq), mlen = uniu(rd.mm_len);
         const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
         const uint64_t dir_off = rd.seq_off >> 4;
@@ -464,14 +464,14 @@ struct KA {
     // ---------------- item kind 1: MM group headers -> tiles (or the fallback list)
     __device__ int run_mm(int ridx, uint32_t region) {
         const int lane = lane_id();
-        const mm_read_t& rd = p.reads[ridx];
+        const mm_read_t rd = scalar_load(p.reads + ridx);
         err = 0;
         const int tid = uni(rd.tid);
         const uint32_t L = uniu(rd.l_qseq), mlen = uniu(rd.mm_len);
         const int rev = (uni(rd.flag) & 0x10) ? 1 : 0;
         const uint8_t* mm = p.mm + rd.mm_off;
         bool have_ref = tid >= 0 && tid < p.n_contigs;
-        if (have_ref) have_ref = p.ref_base[tid] >= 0;
+        if (have_ref) have_ref = scalar_load(p.ref_base + tid) >= 0;
         int result = 0;   // a missing contig is reported by the CIGAR item
         // pass 1: regular or not, and how many tiles
         int first_cls = -1;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
     // shared counter would serialise ~12k dequeues.
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
     const int n = p.n_items;
-    const int g = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    const int g = uni((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));   // the wave's index, as a scalar
     const bool dynamic = n_waves >= (int)kTileRegions && P.scan_queue != nullptr;
     for (int r = g; r < 3 * n;) {
         const int r_cur = r;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
         }
         const int r_use = r_cur;
         const int ri = r_use / 3, kind = r_use - 3 * ri;   // kinds interleaved: the three items of the costliest reads all start at once
-        uint32_t item = p.order ? (uint32_t)p.order[ri] : (uint32_t)ri;
+        uint32_t item = p.order ? (uint32_t)scalar_load(p.order + ri) : (uint32_t)ri;
         item = uniu(item);
         const uint32_t part = (item >> 24) & 15u, nparts = ((item >> 28) & 15u) + 1u;
         if (kind == 1 && part != 0u) continue;   // a long read's parts split its CIGAR and directory scans; its MM headers are visited once
@@ -807,9 +807,9 @@ struct KC {
     // the coarse directory the prepass left (block of every 64th rank): one load instead of a search
     __device__ void setup_dir_slice(uint32_t rr_a, uint32_t rr_b, uint32_t& b1, uint32_t& b2) {
         const uint32_t lane = (uint32_t)lane_id();
-        const uint32_t ka = rr_a >> 6, kb = (rr_b >> 6) + 1u;
-        b1 = rdir[ka];
-        b2 = kb <= ((nb - 1u) >> 6) ? rdir[kb] : nblk - 1u;
+        const uint32_t ka = uniu(rr_a >> 6), kb = uniu(rr_b >> 6) + 1u;
+        b1 = scalar_load(rdir + ka);
+        b2 = kb <= ((nb - 1u) >> 6) ? scalar_load(rdir + kb) : nblk - 1u;
         uint32_t cnt = b2 - b1 + 1u;
         ds_cnt = 0;
         if (cnt <= kSliceD) {
@@ -827,9 +827,9 @@ struct KC {
     // 256th read position, from the prepass)
     __device__ void setup_cig_slice(uint32_t q_a, uint32_t q_b) {
         const uint32_t lane = (uint32_t)lane_id();
-        const uint32_t ka = q_a >> 8, kb = (q_b >> 8) + 1u;
-        uint32_t i1 = qdir[ka];
-        uint32_t i2 = kb <= ((q_total - 1u) >> 8) ? qdir[kb] : ncig - 1u;
+        const uint32_t ka = uniu(q_a >> 8), kb = uniu(q_b >> 8) + 1u;
+        uint32_t i1 = scalar_load(qdir + ka);
+        uint32_t i2 = kb <= ((q_total - 1u) >> 8) ? scalar_load(qdir + kb) : ncig - 1u;
         uint32_t cnt = i2 - i1 + 1u;
         cs_cnt = 0;
         if (cnt <= kSliceC) {
