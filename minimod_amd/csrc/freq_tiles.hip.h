@@ -639,19 +639,19 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
     const unsigned int g = uniu(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // the wave's index, as a scalar
     const unsigned int n_waves = gridDim.x * kWavesPerBlock;
     const unsigned int region = g % kTileRegions;
-    unsigned int n_tiles = P.tile_count[region];
+    unsigned int n_tiles = scalar_load(P.tile_count + region);
     if (n_tiles > P.tile_cap) n_tiles = P.tile_cap;
-    n_tiles = uniu(n_tiles);
     const TileRec* const rtiles = P.tiles + (size_t)region * P.tile_cap;
     uint2* const rsum = P.g_sum + (size_t)region * P.tile_cap;
     const unsigned int stride = n_waves / kTileRegions;
     unsigned int ti = g / kTileRegions;
-    uint2 d = ti < n_tiles ? rsum[ti] : make_uint2(0u, 0u);
+    // descriptors through the scalar cache: the slots this wave reads are written by this wave only
+    uint2 d = ti < n_tiles ? scalar_load(rsum + ti) : make_uint2(0u, 0u);
     for (; ti < n_tiles; ti += stride) {
         // the next tile's descriptor is requested before this tile's text
         const unsigned int tn = ti + stride;
-        uint2 dn = tn < n_tiles ? rsum[tn] : make_uint2(0u, 0u);
-        const uint32_t dx = uniu(d.x), dy = uniu(d.y);
+        uint2 dn = tn < n_tiles ? scalar_load(rsum + tn) : make_uint2(0u, 0u);
+        const uint32_t dx = d.x, dy = d.y;
         d = dn;
         if (!(dy & kSumParse)) continue;   // tail and unused slots already hold their summary
         const uint32_t rem = dy & 511u;
