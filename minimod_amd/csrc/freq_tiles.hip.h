@@ -1277,8 +1277,9 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
         if (lane_id() == 0) nxt = atomicAdd(P.tile_queue + region * kQueueStride, 1u);
         ti = region_waves + uniu(nxt);
     }
+#ifndef MM_PHASE_TIMING
     if (p.stats) k.flush_stats(g & (kStatSlots - 1));
-#ifdef MM_PHASE_TIMING
+#else   // diagnostic builds keep the per-wave rows for k_scan_reads' timings
     if (lane_id() == 0 && p.stats) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, k.tacc[i]);
 #endif
 }
