@@ -166,7 +166,7 @@ def test_plan_batch_splits_long_reads_and_orders_by_cost():
     for r, ps in seen.items():
         n_ = ps[0][1]
         assert sorted(p_ for p_, _ in ps) == list(range(n_)) and all(x == n_ for _, x in ps)
-        assert n_ == min(16, max(1, -(-int(rd["l_qseq"][r]) // 16384)))
+        assert n_ == min(16, max(1, -(-int(rd["l_qseq"][r]) // 24576)))
     cost = rd["l_qseq"][ridx] // nparts // 256
     assert (cost[:-1] >= cost[1:]).all()      # costliest first
     assert len(engine.plan_batch(rd[:0])) == 0
