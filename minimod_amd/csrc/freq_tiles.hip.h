@@ -854,6 +854,7 @@ struct KC {
                 if (cand < ds_cnt && S.ds[cand] <= rr) lo = cand;
             }
             base = S.ds[lo];
+            asm volatile("" : "+v"(base));   // keeps this an LDS read: merged with the global read below it becomes a flat load
             return ds_lo + lo;
         }
         while (step < nblk) step <<= 1;
@@ -874,6 +875,7 @@ struct KC {
                 if (cand < cs_cnt && S.csq[cand] <= q) lo = cand;
             }
             qs = S.csq[lo]; rv = S.csr[lo];
+            asm volatile("" : "+v"(qs), "+v"(rv));   // likewise
             return cs_lo + lo;
         }
         while (step < ncig) step <<= 1;
