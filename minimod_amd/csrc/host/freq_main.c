@@ -84,6 +84,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
 static void die_read_error(int code, int32_t read, const mm_batch_t *b, const mm_bam_hdr_t *hdr) {
+    (void)mmh_emit_flush();   /* rows of earlier batches reach the output as they did with stdio */
     const mm_read_t *rd = (read >= 0 && read < b->n_reads) ? &b->reads[read] : NULL;
     const char *tname = (rd && rd->tid >= 0 && rd->tid < hdr->n_targets) ? hdr->target_name[rd->tid] : "*";
     switch (code) {
@@ -131,8 +132,15 @@ static void intern_batch_codes(mm_freq_t *h, const mm_batch_t *b) {
 
 /* merge_db's place in the pipeline: wait for the batch; freq has nothing to merge, view prints the batch's rows
  * (print_view_output, src/mod.c:560-626).  `pool_set` is the loader pool set the batch was read into. */
+static int code_names(mm_freq_t *h, const char **codes) {
+    int n = mm_freq_n_codes(h);
+    if (n > MM_MAX_CODES) n = MM_MAX_CODES;
+    for (int i = 0; i < n; i++) codes[i] = mm_freq_code_name(h, i);
+    return n;
+}
+
 static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, int pool_set, const mm_bam_hdr_t *hdr, const fopt_t *o,
-                         double *wait_time, double *output_time) {
+                         mm_pool_t *pool, double *wait_time, double *output_time) {
     double tw = mmh_realtime();
     int32_t bad = -1;
     if (!o->view) {
@@ -146,7 +154,9 @@ static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, int 
     *wait_time += mmh_realtime() - tw;
     if (n < 0) die_read_error((int)-n, bad, b, hdr);
     double to = mmh_realtime();
-    mmh_print_view_rows(o->out, rows, n, b, pool_set, hdr, h, o->insertions, o->haplotypes);
+    const char *codes[MM_MAX_CODES];
+    int n_codes = code_names(h, codes);
+    mmh_print_view_rows(o->out, pool, rows, n, b, pool_set, hdr, codes, n_codes, o->insertions, o->haplotypes);
     *output_time += mmh_realtime() - to;
 }
 
@@ -274,7 +284,7 @@ static int run_main(int argc, char **argv, int view) {
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (pending_ticket >= 0) {
-            retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, &process_wait_time, &output_time);
+            retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
             pending_ticket = -1;
         }
         if (n > 0) {
@@ -298,7 +308,7 @@ static int run_main(int argc, char **argv, int view) {
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, &process_wait_time, &output_time);
+    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
     double sort_time = 0;
     if (!view) {
         double ts = mmh_realtime();
@@ -307,10 +317,15 @@ static int run_main(int argc, char **argv, int view) {
         if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
         sort_time = mmh_realtime() - ts;
         double to = mmh_realtime();
-        mmh_print_freq_rows(o.out, rows, nrows, hdr, h, o.bedmethyl, o.insertions, o.haplotypes);
+        const char *codes[MM_MAX_CODES];
+        int n_codes = code_names(h, codes);
+        mmh_print_freq_rows(o.out, mm_bam_pool(ld->bam), rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+        if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
     }
+    if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o.out != stdout) fclose(o.out);
+    else fflush(stdout);
 
     fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
     fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, ld->total_bytes / (float)(1000 * 1000));

@@ -71,14 +71,19 @@ const char *mmh_loader_qname(int pool_set, int32_t read);
 void mmh_loader_close(mmh_loader_t *ld);
 
 /* ---- output ---- */
+/* Rows are formatted on `pool` (NULL: on the calling thread) and written by a writer thread in row order; the text of
+ * the rows is complete when a print call returns, the write may still be under way: call mmh_emit_flush() before
+ * closing the file or writing to it otherwise (returns -1 if a write failed), mmh_emit_finish() when done with output.  `codes[c]` names mod code c. */
 void mmh_print_freq_header(FILE *fp, int bedmethyl, int insertions, int haplotypes);
-void mmh_print_freq_rows(FILE *fp, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, mm_freq_t *h, int bedmethyl,
-                         int insertions, int haplotypes);
+void mmh_print_freq_rows(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr,
+                         const char *const *codes, int n_codes, int bedmethyl, int insertions, int haplotypes);
 
 /* print_view_header / print_view_output (src/mod.c:545-626) for one batch's rows */
 void mmh_print_view_header(FILE *fp, int insertions, int haplotypes);
-void mmh_print_view_rows(FILE *fp, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, int pool_set,
-                         const mm_bam_hdr_t *hdr, mm_freq_t *h, int insertions, int haplotypes);
+void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, int pool_set,
+                         const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes);
+int mmh_emit_flush(void);
+int mmh_emit_finish(void);   /* flush, then stop the writer thread and free the recycled buffers */
 
 int mmh_freq_main(int argc, char **argv);
 int mmh_view_main(int argc, char **argv);

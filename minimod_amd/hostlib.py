@@ -103,3 +103,44 @@ def load_batches(path, K=512, B=20 * 1000 * 1000, threads=2, allow_secondary=Fal
             s ^= 1
     finally:
         L.mmh_loader_close(ld)
+
+
+class mm_bam_hdr_t(ctypes.Structure):
+    _fields_ = [("n_targets", ctypes.c_int32), ("target_name", ctypes.POINTER(ctypes.c_char_p)),
+                ("target_len", ctypes.POINTER(ctypes.c_uint32))]
+
+
+def format_freq_rows(rows, names, code_names, path, threads=1, bedmethyl=False, insertions=False, haplotypes=False):
+    """print_freq_output through the C emitter (rows: engine.ROW_DTYPE) into the file `path`; threads > 1 formats on a
+    worker pool.  The header is written too, like the CLI does."""
+    from .engine import ROW_DTYPE
+    L = _lib()
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    L.mm_pool_create.restype = ctypes.c_void_p
+    L.mm_pool_create.argtypes = [ctypes.c_int]
+    L.mm_pool_destroy.argtypes = [ctypes.c_void_p]
+    L.mmh_print_freq_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.mmh_print_freq_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(mm_bam_hdr_t),
+                                      ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    tn = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    tl = (ctypes.c_uint32 * len(names))(*([0] * len(names)))
+    hdr = mm_bam_hdr_t(len(names), tn, tl)
+    cn = (ctypes.c_char_p * len(code_names))(*[c.encode() for c in code_names])
+    fp = libc.fopen(path.encode(), b"wb")
+    if not fp:
+        raise OSError("cannot open " + path)
+    pool = L.mm_pool_create(threads) if threads > 1 else None
+    try:
+        L.mmh_print_freq_header(fp, int(bedmethyl), int(insertions), int(haplotypes))
+        L.mmh_print_freq_rows(fp, pool, rows.ctypes.data, len(rows), ctypes.byref(hdr), cn, len(code_names), int(bedmethyl),
+                              int(insertions), int(haplotypes))
+        if L.mmh_emit_finish() != 0:
+            raise OSError("write failed")
+    finally:
+        libc.fclose(fp)
+        if pool:
+            L.mm_pool_destroy(pool)

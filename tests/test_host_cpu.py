@@ -278,3 +278,35 @@ def test_cli_summary_matches_reference_golden(exp, bam, extra):
         r = subprocess.run([binp, "summary"] + extra + more + [os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert r.stdout.decode() == open(os.path.join(GOLDEN, "expected", exp)).read()
+
+
+@pytest.mark.parametrize("mode", [dict(), dict(bedmethyl=True), dict(insertions=True, haplotypes=True)],
+                         ids=["tsv", "bedmethyl", "ins_hap"])
+def test_c_row_formatter_serial_and_parallel_match_the_oracle_formatter(tmp_path, mode):
+    """print_freq_output in C, formatted by a worker pool in pieces and written in order by the writer thread, is
+    byte-identical to the serial run and to the oracle's formatter (which is pinned on the reference's goldens)."""
+    from minimod_amd import engine, hostlib
+    rng = np.random.default_rng(5)
+    n = 200_000                                            # ~50 pieces: several rounds at 8 threads
+    rows = np.zeros(n, dtype=engine.ROW_DTYPE)
+    rows["tid"] = np.sort(rng.integers(0, 3, size=n))
+    rows["pos"] = rng.integers(0, 250_000_000, size=n)
+    rows["strand"] = rng.integers(0, 2, size=n)
+    rows["code"] = rng.integers(0, 3, size=n)
+    rows["n_called"] = np.where(rng.random(n) < 0.02, rng.integers(256, 100000, size=n), rng.integers(1, 256, size=n))
+    rows["n_mod"] = (rows["n_called"] * rng.random(n)).astype(np.uint32)
+    if mode.get("insertions"):
+        rows["ins_offset"] = np.where(rng.random(n) < 0.1, rng.integers(1, 500, size=n), 0)
+    rows["hp"] = rng.integers(-1, 3, size=n) if mode.get("haplotypes") else -1
+    names, codes = ["chr1", "chr22_KI270731v1_random", "chrM"], ["m", "h", "21839"]
+    outs = []
+    for threads in (1, 8):
+        path = str(tmp_path / ("rows_t%d.txt" % threads))
+        hostlib.format_freq_rows(rows, names, codes, path, threads=threads, **mode)
+        outs.append(open(path).read())
+    assert outs[0] == outs[1]
+    orows = np.zeros(n, dtype=O.ROW_DTYPE)
+    for a, b in (("tid", "tid"), ("pos", "pos"), ("strand", "strand"), ("code", "code"), ("ins_off", "ins_offset"), ("hp", "hp"),
+                 ("n_called", "n_called"), ("n_mod", "n_mod")):
+        orows[a] = rows[b]
+    assert outs[0] == O.format_rows(orows, names, codes, **mode)

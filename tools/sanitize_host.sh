@@ -1,6 +1,7 @@
 #!/bin/bash
-# Build the C ingestion path (bamio.c + loader.c) with AddressSanitizer+UBSan and with ThreadSanitizer and run it over the
-# bundled BAMs (and any BAMs given as arguments).  CPU only: GPU sanitizers are not available on this pool.
+# Build the C ingestion path (bamio.c + loader.c) and the row formatter (emit.c) with AddressSanitizer+UBSan and with
+# ThreadSanitizer; run the former over the bundled BAMs (and any BAMs given as arguments), the latter over synthetic rows
+# (pool-parallel pieces + writer thread vs the serial run).  CPU only: GPU sanitizers are not available on this pool.
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 H="$here/../minimod_amd/csrc/host"
@@ -13,5 +14,9 @@ for mode in address,undefined thread; do
         ASAN_OPTIONS=detect_leaks=1 "$bin" "$f" 5 > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): $f"; exit 1; }
         if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): $f"; exit 1; fi
     done
+    ebin="$out/emit_check_${mode%%,*}"
+    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu11 -I"$H" -I"$here/../include" -o "$ebin" "$here/emit_check.c" "$H/emit.c" "$H/loader.c" "$H/bamio.c" -lz -lpthread
+    ASAN_OPTIONS=detect_leaks=1 "$ebin" 300000 6 "$out/emit.txt" > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): emit_check"; exit 1; }
+    if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): emit_check"; exit 1; fi
     echo "$mode: clean"
 done
