@@ -75,7 +75,7 @@ typedef struct mm_batch {
     int32_t n_order;         /* entries of order[] (ignored when order is NULL) */
     uint64_t n_cigar_words;  /* pool sizes incl. slack (elements / bytes) */
     uint64_t n_seq_bytes;
-    uint64_t n_mm_bytes;
+    uint64_t n_mm_bytes;     /* below 4 GiB per batch (tiles address the MM pool with 32 bits; more is -MM_E_ARG) */
     uint64_t n_ml_bytes;
     uint32_t max_n_cigar;    /* largest n_cigar / l_qseq in the batch (sizes the spill scratch) */
     uint32_t max_l_qseq;
