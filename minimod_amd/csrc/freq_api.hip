@@ -812,6 +812,70 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     { int r = drain(h); if (r) return r; }
     std::vector<mm_row_t>& rows = h->rows;
     rows.clear();
+    // ---- every row a dense one (no haplotype planes, nothing on the side list): the device walks the positions and
+    // writes finished rows in output order (k_site_count / k_site_emit); the host only copies them
+    if (!h->opts.haplotypes && h->n_counter_words > 0 && !std::getenv("MM_K2_RUNS")) {
+        unsigned long long ns0 = 0;
+        HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
+        if (ns0 == 0) {
+            std::vector<int> order;
+            for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return h->ctg_rank[a] < h->ctg_rank[b]; });
+            std::vector<SiteSeg> segs(order.size());
+            int64_t tiles = 0;
+            for (size_t k = 0; k < order.size(); k++) {
+                int t = order[k];
+                segs[k].cnt_base = h->cnt_base[t]; segs[k].seg_begin = h->seg_begin[t]; segs[k].seg_len = h->seg_len[t];
+                segs[k].tile_start = tiles; segs[k].tid = t; segs[k].pad = 0;
+                tiles += (h->seg_len[t] + kTile - 1) / kTile;
+            }
+            if (tiles > 0 && tiles < (int64_t)0x7FFFFFFF) {
+                if ((size_t)tiles > h->cap_tiles) {
+                    if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
+                    if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
+                    h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
+                    if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles) ||
+                        dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * (size_t)tiles)) return -MM_E_NOMEM;
+                    h->cap_tiles = (size_t)tiles;
+                }
+                SiteSeg* d_segs = nullptr;
+                if (dev_alloc(h, (void**)&d_segs, sizeof(SiteSeg) * segs.size())) return -MM_E_NOMEM;
+                int64_t result = 0;
+                do {
+                    if (hipMemcpyAsync(d_segs, segs.data(), sizeof(SiteSeg) * segs.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    hipLaunchKernelGGL(k_site_count, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
+                                       d_segs, (int)segs.size(), h->d_tile_counts);
+                    std::vector<uint32_t> tc((size_t)tiles);
+                    if (hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                        hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    std::vector<unsigned long long> to((size_t)tiles);
+                    unsigned long long total = 0;
+                    for (size_t i = 0; i < (size_t)tiles; i++) { to[i] = total; total += tc[i]; }
+                    if (total > 0) {
+                        size_t units = (size_t)((total * sizeof(mm_row_t) + sizeof(DenseRow) - 1) / sizeof(DenseRow));   // d_rows is sized in DenseRow units
+                        if (units > h->cap_rows) {
+                            if (h->d_rows) (void)hipFree(h->d_rows);
+                            h->d_rows = nullptr; h->cap_rows = 0;
+                            size_t cap = units + units / 8 + 1024;
+                            if (dev_alloc(h, (void**)&h->d_rows, sizeof(DenseRow) * cap)) { result = -MM_E_NOMEM; break; }
+                            h->cap_rows = cap;
+                        }
+                        rows.resize((size_t)total);
+                        if (hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * (size_t)tiles, hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                        hipLaunchKernelGGL(k_site_emit, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
+                                           d_segs, (int)segs.size(), h->d_tile_offsets, reinterpret_cast<mm_row_t*>(h->d_rows));
+                        if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                            hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    }
+                    result = (int64_t)rows.size();
+                } while (0);
+                (void)hipFree(d_segs);
+                if (result < 0) return result;
+                if (out_rows) *out_rows = rows.data();
+                return result;
+            }
+        }
+    }
     std::vector<size_t> run_starts;   // first row of every (plane, haplotype, strand) run of dense rows
     size_t n_dense = 0;
     // ---- K2 over all planes at once: the flat counter array is [run][plane_len] with run = (plane*n_hp+hp)*2+strand

@@ -1022,6 +1022,78 @@ __global__ __launch_bounds__(256) void k_emit_rows(const unsigned long long* __r
     }
 }
 
+// K2, site-major: the same compaction walking POSITIONS, each position's runs in output order (strand, then code), so
+// that the rows come out in the order print_freq_output sorts them into (src/mod.c:644-664 with cmp_key_fast :59-93;
+// ties in this build's canonical order) and as finished mm_row_t records: the host copies them and is done -- no decode,
+// no merge of per-run lists.  Used when every row is a dense one (no haplotype planes, empty side list).
+struct SiteSeg {        // one contig segment, listed in output order
+    int64_t cnt_base;   // offset of the segment inside a run
+    int64_t seg_begin, seg_len;
+    int64_t tile_start; // first tile (of kTile positions) of the segment
+    int32_t tid, pad;
+};
+__device__ __forceinline__ int site_segment(const SiteSeg* segs, int n_seg, int64_t tile) {
+    int lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+constexpr int kSitePerThread = kTile / 256;   // consecutive positions per thread
+__global__ __launch_bounds__(256) void k_site_count(const unsigned long long* __restrict__ cnt, int64_t plane_len, int n_planes,
+                                                    const SiteSeg* __restrict__ segs, int n_seg, uint32_t* __restrict__ tile_counts) {
+    __shared__ uint32_t part[4];
+    const SiteSeg sg = segs[site_segment(segs, n_seg, blockIdx.x)];
+    const int64_t p0 = ((int64_t)blockIdx.x - sg.tile_start) * kTile + (int64_t)threadIdx.x * kSitePerThread;
+    uint32_t c = 0;
+    for (int run = 0; run < 2 * n_planes; run++) {
+        const unsigned long long* src = cnt + (int64_t)run * plane_len + sg.cnt_base;
+#pragma unroll
+        for (int k = 0; k < kSitePerThread; k++) { int64_t q = p0 + k; if (q < sg.seg_len && src[q] != 0ull) c++; }
+    }
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void k_site_emit(const unsigned long long* __restrict__ cnt, int64_t plane_len, int n_planes,
+                                                   const SiteSeg* __restrict__ segs, int n_seg,
+                                                   const unsigned long long* __restrict__ tile_offsets, mm_row_t* __restrict__ rows) {
+    __shared__ uint32_t wsum[4];
+    const SiteSeg sg = segs[site_segment(segs, n_seg, blockIdx.x)];
+    const int64_t p0 = ((int64_t)blockIdx.x - sg.tile_start) * kTile + (int64_t)threadIdx.x * kSitePerThread;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t c = 0;
+    for (int run = 0; run < 2 * n_planes; run++) {
+        const unsigned long long* src = cnt + (int64_t)run * plane_len + sg.cnt_base;
+#pragma unroll
+        for (int k = 0; k < kSitePerThread; k++) { int64_t q = p0 + k; if (q < sg.seg_len && src[q] != 0ull) c++; }
+    }
+    // exclusive scan of the threads' row counts in position order
+    uint32_t incl = wave_incl_scan(c);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (int w = 0; w < wv; w++) before += wsum[w];
+    unsigned long long out = tile_offsets[blockIdx.x] + before;
+    if (c == 0) return;
+    for (int k = 0; k < kSitePerThread; k++) {
+        const int64_t q = p0 + k;
+        if (q >= sg.seg_len) break;
+        for (int strand = 0; strand < 2; strand++) {
+            for (int plane = 0; plane < n_planes; plane++) {   // run = plane * 2 + strand (one haplotype plane)
+                const unsigned long long v = cnt[(int64_t)(plane * 2 + strand) * plane_len + sg.cnt_base + q];
+                if (v == 0ull) continue;
+                mm_row_t r;
+                r.tid = sg.tid; r.pos = (int32_t)(sg.seg_begin + q); r.strand = (uint8_t)strand; r.rsvd = 0; r.ins_offset = 0;
+                r.code = (int16_t)plane; r.hp = -1; r.n_called = (uint32_t)v; r.n_mod = (uint32_t)(v >> 32);
+                rows[out++] = r;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- halo slabs
 __global__ void k_slab_export(const unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len,
                               int n_runs, unsigned long long* __restrict__ dst) {
