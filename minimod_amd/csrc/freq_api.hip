@@ -293,16 +293,21 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             int gc = h->n_cu * h->call_blocks_per_cu;
             int gs = h->n_cu * 6;   // measured: 8 waves per SIMD 16.0 us, 6 14.8 us, 4 16.9 us
             if (ga < 1) ga = 1;
+            const bool plain = !p.insertions && !p.haplotypes;
             if (h->wide) {
                 hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
                 hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
-                if (p.view) hipLaunchKernelGGL((k_call_tiles<uint32_t, true>), dim3(gc), dim3(256), 0, st, tp);
-                else hipLaunchKernelGGL((k_call_tiles<uint32_t, false>), dim3(gc), dim3(256), 0, st, tp);
+                if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
+                              else hipLaunchKernelGGL((k_call_tiles<uint32_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
+                else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
+                       else hipLaunchKernelGGL((k_call_tiles<uint32_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
             } else {
                 hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
                 hipLaunchKernelGGL(k_sum_tiles<uint16_t>, dim3(gs), dim3(256), 0, st, tp);
-                if (p.view) hipLaunchKernelGGL((k_call_tiles<uint16_t, true>), dim3(gc), dim3(256), 0, st, tp);
-                else hipLaunchKernelGGL((k_call_tiles<uint16_t, false>), dim3(gc), dim3(256), 0, st, tp);
+                if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
+                              else hipLaunchKernelGGL((k_call_tiles<uint16_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
+                else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
+                       else hipLaunchKernelGGL((k_call_tiles<uint16_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
             }
             HIPCHK(hipGetLastError());
             // reads the tile form does not cover: the fused kernel over the fallback list.  The list is nearly always
@@ -480,10 +485,10 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         int na = 0, nc = 0;
         if (h->wide) {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint32_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, false>, 256, 0);
         } else {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint16_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, false>, 256, 0);
         }
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;

@@ -751,8 +751,11 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------ KC
-template <typename RefWord, bool kView>
+// kPlain: neither --insertions nor --haplotypes (the usual run): those paths and the values they keep alive are compiled out
+template <typename RefWord, bool kView, bool kPlain>
 struct KC {
+    __device__ __forceinline__ bool opt_insertions() const { return !kPlain && p.insertions; }
+    __device__ __forceinline__ bool opt_haplotypes() const { return !kPlain && p.haplotypes; }
     const TileParams& P;
     const DevParams& p;
     CallLds& S;
@@ -973,12 +976,12 @@ struct KC {
                 uint32_t op = rv >> 28;
                 if ((0x181u >> op) & 1u) {
                     rp = (int64_t)pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
-                } else if (op == 1u && p.insertions) {
+                } else if (op == 1u && opt_insertions()) {
                     ins_off[u] = (q[u] - qs + 1u) & 0xFFFFu;
                     anchor = (int64_t)pos + (rv & 0x0FFFFFFFu) - 1;
                 }
             }
-            if (rp < 0 && p.insertions) {
+            if (rp < 0 && opt_insertions()) {
                 if (is_explicit || !rev) {
                     rp = anchor;
                 } else {   // mod.c:1234,1314 quirk: the mirrored base's insertion anchor
@@ -1016,7 +1019,7 @@ struct KC {
                 const uint32_t cinfo = cinfo_at(m);
                 const int req = (int)((cinfo >> 19) & 15u), dc_plane = (int)((cinfo >> 23) & 127u) - 1;
                 const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
-                if (!p.insertions) {
+                if (!opt_insertions()) {
                     bool in_ctx = (w[u] >> (5 + 2 * req + rev)) & 1u;
                     bool matches = ((cinfo >> 18) & 1u) || mb_is_N || refcode == code[u];
                     if (!(in_ctx && matches)) continue;
@@ -1042,7 +1045,8 @@ struct KC {
                 }
                 int64_t off = ref_pos[u] - seg_begin;
                 if (ins_off[u] == 0 && dc_plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
-                    unsigned long long* dst = p.counters + ((int64_t)(dc_plane * p.n_hp + hpi) * 2 + rev) * p.plane_len + cnt_base + off;
+                    const int64_t run = kPlain ? (int64_t)dc_plane * 2 + rev : ((int64_t)(dc_plane * p.n_hp + hpi) * 2 + rev);
+                    unsigned long long* dst = p.counters + run * p.plane_len + cnt_base + off;
                     atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
                     st_dense++;
                 } else {
@@ -1093,8 +1097,8 @@ struct KC {
         nblk = (L + 31u) >> 5;
         q_total = scalar_load(P.g_qtot + ridx);
         nb = scalar_load(P.g_nb + ridx);
-        hp = p.haplotypes ? (int)rd.hp : -1;
-        hpi = p.haplotypes ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
+        hp = opt_haplotypes() ? (int)rd.hp : -1;
+        hpi = opt_haplotypes() ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
         ref_base = scalar_load(p.ref_base + tid); seg_begin = scalar_load(p.seg_begin + tid);
         seg_len = scalar_load(p.seg_len + tid); cnt_base = scalar_load(p.cnt_base + tid);
         // carries = prefix over the summaries of the read's tiles in front of this one:
@@ -1237,10 +1241,10 @@ struct KC {
     }
 };
 
-template <typename RefWord, bool kView>
+template <typename RefWord, bool kView, bool kPlain>
 __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
-    KC<RefWord, kView> k(P, lds[threadIdx.x >> 6]);
+    KC<RefWord, kView, kPlain> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
     if (P.reset_in_call && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
         if (p.ctl_next && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
     while (ti < n_tiles) {
         // the tile record as wave-uniform scalars
         const kptr<uint32_t> src = scalar_ptr(reinterpret_cast<const uint32_t*>(rtiles + ti));
-        typename KC<RefWord, kView>::TileArgs t;
+        typename KC<RefWord, kView, kPlain>::TileArgs t;
         t.ridx = src[0]; t.cpos = src[1]; t.read_first = src[2]; t.group_first = src[3];
         t.flags = src[4]; t.index = ti; t.gord = src[7]; t.region = region;
         uint32_t gc01 = src[5], gc23 = src[6];
