@@ -483,12 +483,19 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t, false>, 256, 0);
         h->blocks_per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
         int na = 0, nc = 0;
+        const bool plain = !opts->insertions && !opts->haplotypes;
         if (h->wide) {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint32_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, false>, 256, 0);
+            if (opts->view) { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, true, true>, 256, 0);
+                              else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, true, false>, 256, 0); }
+            else { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, true>, 256, 0);
+                   else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, false>, 256, 0); }
         } else {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint16_t>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, false>, 256, 0);
+            if (opts->view) { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, true, true>, 256, 0);
+                              else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, true, false>, 256, 0); }
+            else { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, true>, 256, 0);
+                   else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, false>, 256, 0); }
         }
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;

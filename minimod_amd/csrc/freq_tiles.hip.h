@@ -80,14 +80,15 @@ struct ScanLds {
     uint32_t gend[kGroupEnds];   // run_mm: where the read's first groups end (found once, used by both passes)
 };
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
-constexpr uint32_t kSliceC = 640;   // CIGAR ops staged in LDS per tile
+constexpr uint32_t kSliceC = 1024;  // CIGAR ops staged in LDS per tile, one packed word each
+constexpr uint32_t kSliceSpan = 16384;   // ... when the slice spans fewer read and reference positions than this
 struct CallLds {
     uint32_t tok[128];
     uint32_t gap[64];
     uint32_t gstart[64];
     uint32_t ds[kSliceD];    // slice of the rank directory covering the tile's listed ranks
-    uint32_t csq[kSliceC];   // slice of the CIGAR query-offset array covering the tile's read positions
-    uint32_t csr[kSliceC];   //   ... and of the reference-offset | op array
+    uint32_t cs[kSliceC];    // slice of the CIGAR prefix arrays covering the tile's read positions, relative to its first op:
+                             // query offset << 18 | reference offset << 4 | op (ordered like the query offsets)
 };
 
 // 0x80 in every byte of w that equals ';' (exact for the lowest such byte, which is all that is used)
@@ -779,7 +780,7 @@ struct KC {
     uint32_t v_ridx, v_gord, v_region;   // view mode: read index, group ordinal, append region
     // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
     // CIGAR ops [cs_lo, cs_lo+cs_cnt) answer read positions in [cs_q_lo, cs_q_hi)
-    uint32_t ds_lo, ds_cnt, ds_rr_lo, ds_rr_hi, cs_lo, cs_cnt, cs_q_lo, cs_q_hi;
+    uint32_t ds_lo, ds_cnt, ds_rr_lo, ds_rr_hi, cs_lo, cs_cnt, cs_q_lo, cs_q_hi, cs_q_base, cs_r_base;
     unsigned long long tacc[5] = {0, 0, 0, 0, 0};   // diagnostic builds: time per phase, flushed once per wave
 
     __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
@@ -836,14 +837,28 @@ struct KC {
         uint32_t cnt = i2 - i1 + 1u;
         cs_cnt = 0;
         if (cnt <= kSliceC) {
-            uint32_t vq[kSliceC / 64], vr[kSliceC / 64];
+            const uint32_t qb0 = scalar_load(gq + i1), rb0 = scalar_load(gr + i1) & 0x0FFFFFFFu;
+            bool ok = q_b - qb0 < kSliceSpan;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 320u) {   // ten loads in flight per trip
+                uint32_t vq[5], vr[5];
 #pragma unroll
-            for (uint32_t j = 0; j < kSliceC / 64; j++) { uint32_t i = lane + 64u * j; vq[j] = i < cnt ? gq[i1 + i] : 0u; vr[j] = i < cnt ? gr[i1 + i] : 0u; }
+                for (uint32_t j = 0; j < 5; j++) { uint32_t i = c0 + lane + 64u * j; vq[j] = i < cnt ? gq[i1 + i] : 0u; vr[j] = i < cnt ? gr[i1 + i] : 0u; }
 #pragma unroll
-            for (uint32_t j = 0; j < kSliceC / 64; j++) { uint32_t i = lane + 64u * j; if (i < cnt) { S.csq[i] = vq[j]; S.csr[i] = vr[j]; } }
+                for (uint32_t j = 0; j < 5; j++) {
+                    uint32_t i = c0 + lane + 64u * j;
+                    if (i < cnt) {
+                        const uint32_t dq = vq[j] - qb0, dr = (vr[j] & 0x0FFFFFFFu) - rb0;
+                        ok = ok && dq < kSliceSpan && dr < kSliceSpan;
+                        S.cs[i] = (dq << 18) | (dr << 4) | (vr[j] >> 28);
+                    }
+                }
+            }
             wave_sync();
-            cs_lo = i1; cs_cnt = cnt;
-            cs_q_lo = q_a; cs_q_hi = q_b + 1u;
+            if (!__ballot(!ok)) {   // a slice that spans more (a long deletion or intron) is searched in global memory
+                cs_lo = i1; cs_cnt = cnt;
+                cs_q_lo = q_a; cs_q_hi = q_b + 1u;
+                cs_q_base = qb0; cs_r_base = rb0;
+            }
         }
     }
 
@@ -872,12 +887,14 @@ struct KC {
     __device__ __forceinline__ uint32_t find_op(uint32_t q, uint32_t& qs, uint32_t& rv) const {
         uint32_t lo = 0, step = 1;
         if (cs_cnt && q >= cs_q_lo && q < cs_q_hi) {
+            const uint32_t target = ((q - cs_q_base) << 18) | 0x3FFFFu;
             while (step < cs_cnt) step <<= 1;
             for (step >>= 1; step; step >>= 1) {
                 uint32_t cand = lo + step;
-                if (cand < cs_cnt && S.csq[cand] <= q) lo = cand;
+                if (cand < cs_cnt && S.cs[cand] <= target) lo = cand;
             }
-            qs = S.csq[lo]; rv = S.csr[lo];
+            const uint32_t w = S.cs[lo];
+            qs = cs_q_base + (w >> 18); rv = (cs_r_base + ((w >> 4) & 0x3FFFu)) | (w << 28);
             asm volatile("" : "+v"(qs), "+v"(rv));   // likewise
             return cs_lo + lo;
         }
@@ -1242,7 +1259,7 @@ struct KC {
 };
 
 template <typename RefWord, bool kView, bool kPlain>
-__global__ __launch_bounds__(256, 5) void k_call_tiles(const TileParams P) {
+__global__ __launch_bounds__(256, kPlain ? 6 : 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord, kView, kPlain> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
