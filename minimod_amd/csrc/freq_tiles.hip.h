@@ -80,7 +80,7 @@ struct ScanLds {
     uint32_t gend[kGroupEnds];   // run_mm: where the read's first groups end (found once, used by both passes)
 };
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
-constexpr uint32_t kSliceC = 1024;  // CIGAR ops staged in LDS per tile, one packed word each
+constexpr uint32_t kSliceC = 768;   // CIGAR ops staged in LDS per tile, one packed word each
 constexpr uint32_t kSliceSpan = 16384;   // ... when the slice spans fewer read and reference positions than this
 struct CallLds {
     uint32_t tok[128];
@@ -1259,7 +1259,7 @@ struct KC {
 };
 
 template <typename RefWord, bool kView, bool kPlain>
-__global__ __launch_bounds__(256, kPlain ? 6 : 5) void k_call_tiles(const TileParams P) {
+__global__ __launch_bounds__(256, kPlain ? 7 : 5) void k_call_tiles(const TileParams P) {
     __shared__ CallLds lds[kWavesPerBlock];
     KC<RefWord, kView, kPlain> k(P, lds[threadIdx.x >> 6]);
     const DevParams& p = P.d;
