@@ -150,3 +150,33 @@ def test_list_without_trailing_semicolon_and_empty_tokens():
         mm2 = "C+m?,," + ",".join(toks) + ",,;"                  # empty tokens are skipped by the parser
         recs.append(pybam.make_record(0, 0, 0, seq, "2500M", mm2, [255] * n))
     assert hip_rows_from_records(recs, ref, "m") == oracle_rows(recs, ref, "m")
+
+
+def test_tiles_whose_cigar_slice_spans_more_than_the_packed_range():
+    """k_call_tiles packs a tile's CIGAR slice as 14-bit offsets from its first op; a long deletion / intron or a huge skip
+    inside one tile exceeds that and the tile must fall back to the global arrays: same rows."""
+    rng = np.random.default_rng(21)
+    ref = make_ref(rng, 70000)
+    recs = []
+    # (a) 20 kb deletion and (b) 20 kb intron in the middle of densely listed calls
+    for op in ("D", "N"):
+        seq = ref[100:3100] + ref[23100:26100]
+        n_c = seq.count("C")
+        toks = ["0"] * n_c
+        ml = [int(x) for x in rng.integers(0, 256, size=n_c)]
+        recs.append(pybam.make_record(0, 100, 0, seq, "3000M20000%s3000M" % op, "C+m?" + "".join("," + t for t in toks) + ";", ml))
+    # (c) one tile whose calls are 25 kb of read apart: a few listed calls, a skip over ~6000 Cs, a few more
+    seq = ref[30000:65000]
+    n_c = seq.count("C")
+    toks = ["0"] * 20 + [str(n_c - 60)] + ["0"] * 20
+    ml = [int(x) for x in rng.integers(0, 256, size=len(toks))]
+    recs.append(pybam.make_record(0, 30000, 0, seq, "%dM" % len(seq), "C+m?" + "".join("," + t for t in toks) + ";", ml))
+    # (d) the same with an insertion of 18 kb between the two clusters (read positions far apart, reference close)
+    seq = ref[1000:1500] + make_ref(rng, 18000) + ref[1500:2000]
+    n_c = seq.count("C")
+    n_first = ref[1000:1500].count("C")
+    toks = ["0"] * n_first + [str(n_c - n_first - ref[1500:2000].count("C"))] + ["0"] * (ref[1500:2000].count("C") - 1)
+    ml = [int(x) for x in rng.integers(0, 256, size=len(toks))]
+    recs.append(pybam.make_record(0, 1000, 0, seq, "500M18000I500M", "C+m?" + "".join("," + t for t in toks) + ";", ml))
+    for c, kw in (("m", {}), ("m[*]", {}), ("m", dict(insertions=True))):
+        assert hip_rows_from_records(recs, ref, c, **kw) == oracle_rows(recs, ref, c, **kw)
