@@ -35,19 +35,29 @@ constexpr uint32_t kViewLdsRecs = 4096;          // records a workgroup sorts in
 // [t*chunk, (t+1)*chunk): sum them, scan the 256 sums, write the offsets (cursors are zeroed on the way).
 __global__ __launch_bounds__(256) void k_view_offsets(const unsigned int* __restrict__ counts, uint32_t n_reads,
                                                       unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor) {
+    // one workgroup; 256 consecutive reads per round, sixteen rounds' counts requested together (a thread walking its own
+    // chunk of reads waited for one load after the other)
     __shared__ uint32_t wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t chunk = (n_reads + 255u) / 256u;
-    const uint32_t lo = min(n_reads, threadIdx.x * chunk), hi = min(n_reads, lo + chunk);
-    uint32_t mine = 0;
-    for (uint32_t i = lo; i < hi; i++) mine += counts[i];
-    uint32_t incl = wave_incl_scan(mine);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    uint32_t run = incl - mine;
-    for (int w = 0; w < wv; w++) run += wsum[w];
-    for (uint32_t i = lo; i < hi; i++) { offsets[i] = run; cursor[i] = 0u; run += counts[i]; }
-    if (threadIdx.x == 255) offsets[n_reads] = run;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_reads; base += 256u * 16u) {
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { uint32_t i = base + 256u * k + threadIdx.x; v[k] = i < n_reads ? counts[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t i = base + 256u * k + threadIdx.x;
+            uint32_t incl = wave_incl_scan(v[k]);
+            __syncthreads();
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();
+            uint32_t before = carry + incl - v[k];
+            for (int w = 0; w < wv; w++) before += wsum[w];
+            if (i < n_reads) { offsets[i] = before; cursor[i] = 0u; }
+            carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        }
+    }
+    if (threadIdx.x == 0) offsets[n_reads] = carry;
 }
 
 // regions -> per-read segments
