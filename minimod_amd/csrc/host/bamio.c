@@ -8,6 +8,7 @@
  * into a spill buffer).  Record views stay valid until mm_bam_release(): the loader parses a whole batch first and
  * then copies it into the flattened pools with the same worker pool (mm_pool_for). */
 #include "bamio.h"
+#include "inflate_fast.h"
 
 #include <pthread.h>
 #include <stdlib.h>
@@ -160,6 +161,8 @@ static uint16_t rd_u16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8))
 
 static int inflate_block(blk_t *b) {
     if (b->isize == 0) return 0;
+    if (mm_inflate_raw(b->cdata, b->clen, b->out, b->isize) == 0) return 0;
+    /* malformed or not understood: zlib has the last word (and decides what counts as an error) */
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return -1;

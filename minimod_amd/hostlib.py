@@ -144,3 +144,14 @@ def format_freq_rows(rows, names, code_names, path, threads=1, bedmethyl=False, 
         libc.fclose(fp)
         if pool:
             L.mm_pool_destroy(pool)
+
+
+def inflate_raw(data, out_len):
+    """The BGZF reader's own raw-DEFLATE decoder (inflate_fast.c): bytes -> bytes of exactly out_len, or None if it
+    rejects the stream."""
+    L = _lib()
+    L.mm_inflate_raw.restype = ctypes.c_int
+    L.mm_inflate_raw.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    out = ctypes.create_string_buffer(out_len + 16)
+    r = L.mm_inflate_raw(bytes(data), len(data), out, out_len)
+    return out.raw[:out_len] if r == 0 else None

@@ -310,3 +310,44 @@ def test_c_row_formatter_serial_and_parallel_match_the_oracle_formatter(tmp_path
                  ("n_called", "n_called"), ("n_mod", "n_mod")):
         orows[a] = rows[b]
     assert outs[0] == O.format_rows(orows, names, codes, **mode)
+
+
+def test_own_inflate_matches_zlib_on_every_block_type_and_rejects_damage():
+    """inflate_fast.c (the BGZF reader's DEFLATE decoder) against zlib: stored, fixed and dynamic blocks, long and short
+    matches, literal-heavy and run-heavy data, empty input; truncated streams and wrong sizes are rejected."""
+    import zlib
+    from minimod_amd import hostlib
+    rng = np.random.default_rng(12)
+    makers = [
+        lambda n: rng.integers(0, 256, size=n, dtype=np.uint8).tobytes(),                          # incompressible -> stored
+        lambda n: rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n).tobytes(),            # two bits of entropy
+        lambda n: np.repeat(rng.integers(0, 256, size=n // 50 + 1, dtype=np.uint8), 50)[:n].tobytes(),   # runs (distance 1)
+        lambda n: (rng.integers(33, 75, size=n, dtype=np.uint8)).tobytes(),                        # quality-like literals
+        lambda n: (bytes(rng.integers(0, 256, size=400, dtype=np.uint8)) * (n // 400 + 1))[:n],    # far, long matches
+    ]
+    n_cases = 0
+    for mk in makers:
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                for n in (0, 1, 2, 300, 65280, int(rng.integers(1000, 65536))):
+                    raw = mk(n)
+                    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                    comp = co.compress(raw) + co.flush()
+                    assert hostlib.inflate_raw(comp, len(raw)) == raw
+                    n_cases += 1
+                    if n > 300:
+                        assert hostlib.inflate_raw(comp[:len(comp) // 2], len(raw)) is None      # truncated
+                        assert hostlib.inflate_raw(comp, len(raw) - 1) is None                    # more data than room
+                        assert hostlib.inflate_raw(comp, len(raw) + 1) is None                    # less data than promised
+    assert n_cases == len(makers) * 4 * 4 * 6
+    # the bundled BAMs, block by block
+    for name in ("example-ont.bam", "hap.bam", "dRNA.bam"):
+        d = open(os.path.join(GOLDEN, "data", name), "rb").read()
+        p = 0
+        while p + 18 < len(d):
+            xlen = d[p + 10] | (d[p + 11] << 8)
+            bsize = (d[p + 16] | (d[p + 17] << 8)) + 1
+            comp = d[p + 12 + xlen:p + bsize - 8]
+            isize = int.from_bytes(d[p + bsize - 4:p + bsize], "little")
+            assert hostlib.inflate_raw(comp, isize) == zlib.decompress(comp, -15)
+            p += bsize

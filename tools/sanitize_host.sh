@@ -9,13 +9,13 @@ out="${TMPDIR:-/tmp}/mm_sanitize"
 mkdir -p "$out"
 for mode in address,undefined thread; do
     bin="$out/loader_bench_${mode%%,*}"
-    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu99 -I"$H" -I"$here/../include" -o "$bin" "$here/loader_bench.c" "$H/loader.c" "$H/bamio.c" -lz -lpthread
+    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu99 -I"$H" -I"$here/../include" -o "$bin" "$here/loader_bench.c" "$H/loader.c" "$H/bamio.c" "$H/inflate_fast.c" -lz -lpthread
     for f in "$here"/../tests/golden/data/*.bam "$@"; do
         ASAN_OPTIONS=detect_leaks=1 "$bin" "$f" 5 > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): $f"; exit 1; }
         if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): $f"; exit 1; fi
     done
     ebin="$out/emit_check_${mode%%,*}"
-    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu11 -I"$H" -I"$here/../include" -o "$ebin" "$here/emit_check.c" "$H/emit.c" "$H/loader.c" "$H/bamio.c" -lz -lpthread
+    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu11 -I"$H" -I"$here/../include" -o "$ebin" "$here/emit_check.c" "$H/emit.c" "$H/loader.c" "$H/bamio.c" "$H/inflate_fast.c" -lz -lpthread
     ASAN_OPTIONS=detect_leaks=1 "$ebin" 300000 6 "$out/emit.txt" > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): emit_check"; exit 1; }
     if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): emit_check"; exit 1; fi
     echo "$mode: clean"
