@@ -11,6 +11,8 @@
 #include "inflate_fast.h"
 
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
@@ -147,6 +149,9 @@ struct mm_bam {
     int quit;
     uint8_t *carry;                     /* compressed bytes read past the last whole block of a group */
     size_t carry_len, carry_cap;
+    const uint8_t *map;                 /* the whole file mapped (regular files): blocks are inflated straight from the page
+                                         * cache, the workers take the page faults; NULL = read with fread into cbuf */
+    size_t map_len, map_pos;
     /* consumer */
     chunk_t *cur;                       /* chunk b->p points into (NULL while it points into a spill buffer) */
     const uint8_t *p, *end;             /* unread decoded bytes */
@@ -186,6 +191,52 @@ static chunk_t *chunk_new(void) {
     return c;
 }
 static void chunk_free(chunk_t *c) { if (c) { free(c->buf); free(c->cbuf); free(c); } }
+
+/* one BGZF block header at h (avail bytes are there): total block size, or 0 if the header itself is cut off, -1 if bad */
+static long block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) {
+    if (avail < 18) return 0;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
+    uint32_t xlen = rd_u16(h + 10);
+    if (avail < 12 + (size_t)xlen) return 0;
+    const uint8_t *x = h + 12, *xe = x + xlen;
+    int bsize = -1;
+    while (x + 4 <= xe) {
+        uint32_t sl = rd_u16(x + 2);
+        if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
+        x += 4 + sl;
+    }
+    if (bsize < 0) return -1;
+    long total = (long)bsize + 1;
+    if ((size_t)total < 12 + (size_t)xlen + 8) return -1;
+    *xlen_out = xlen;
+    return total;
+}
+
+/* the same group layout over the mapped file: no copy of the compressed bytes at all */
+static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
+    size_t out = 0, cbytes = 0;
+    int n = 0;
+    while (n < GROUP_BLOCKS && cbytes < GROUP_CBYTES && b->map_pos < b->map_len) {
+        const uint8_t *h = b->map + b->map_pos;
+        uint32_t xlen = 0;
+        long total = block_total(h, b->map_len - b->map_pos, &xlen);
+        if (total <= 0 || (size_t)total > b->map_len - b->map_pos) return -1;   /* bad header, or the file ends inside a block */
+        blk_t *k = &c->blk[n];
+        k->cdata = h + 12 + xlen;
+        k->clen = (uint32_t)((size_t)total - xlen - 12 - 8);
+        k->isize = rd_u32(h + total - 4);
+        if (k->isize > 65536) return -1;
+        k->out = c->buf + CHUNK_HEAD + out;
+        k->err = 0;
+        out += k->isize;
+        b->map_pos += (size_t)total;
+        cbytes += (size_t)total;
+        n++;
+    }
+    c->n_blk = n; c->len = out;
+    c->last = b->map_pos >= b->map_len;
+    return 0;
+}
 
 /* read one group of whole BGZF blocks into c->cbuf and lay out its blocks; 0 ok, -1 error */
 static int read_group(mm_bam_t *b, chunk_t *c) {
@@ -275,7 +326,7 @@ static void *producer_main(void *arg) {
             return NULL;
         }
         c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0;
-        if (!c->buf || !c->cbuf || read_group(b, c) != 0) c->err = 1;
+        if (!c->buf || !c->cbuf || (b->map ? read_group_mapped(b, c) : read_group(b, c)) != 0) c->err = 1;
         else {
             mm_pool_for(b->pool, c->n_blk, 4, inflate_range, c);
             for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
@@ -379,6 +430,16 @@ mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
     mm_bam_t *b = (mm_bam_t *)calloc(1, sizeof(*b));
     b->fp = fp;
     b->pool = pool;
+    {   /* regular file: map it (pipes and the like keep the fread path) */
+        struct stat st;
+        if (fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("MM_BAM_NO_MMAP")) {
+            void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (m != MAP_FAILED) {
+                b->map = (const uint8_t *)m; b->map_len = (size_t)st.st_size; b->map_pos = 0;
+                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            }
+        }
+    }
     pthread_mutex_init(&b->mu, NULL);
     pthread_cond_init(&b->cv_ready, NULL);
     pthread_cond_init(&b->cv_room, NULL);
@@ -456,6 +517,7 @@ void mm_bam_close(mm_bam_t *b) {
         pthread_mutex_unlock(&b->mu);
         pthread_join(b->producer, NULL);
     }
+    if (b->map) munmap((void *)b->map, b->map_len);
     if (b->fp) fclose(b->fp);
     for (int32_t i = 0; i < b->hdr.n_targets; i++) free(b->hdr.target_name ? b->hdr.target_name[i] : NULL);
     free(b->hdr.target_name); free(b->hdr.target_len);
