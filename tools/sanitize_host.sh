@@ -1,7 +1,8 @@
 #!/bin/bash
 # Build the C ingestion path (bamio.c + loader.c) and the row formatter (emit.c) with AddressSanitizer+UBSan and with
 # ThreadSanitizer; run the former over the bundled BAMs (and any BAMs given as arguments), the latter over synthetic rows
-# (pool-parallel pieces + writer thread vs the serial run).  CPU only: GPU sanitizers are not available on this pool.
+# (pool-parallel pieces + writer thread vs the serial run); the DEFLATE decoder (inflate_fast.c) on round trips and 20 000 damaged
+# streams under ASan+UBSan.  CPU only: GPU sanitizers are not available on this pool.
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 H="$here/../minimod_amd/csrc/host"
@@ -18,5 +19,11 @@ for mode in address,undefined thread; do
     gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu11 -I"$H" -I"$here/../include" -o "$ebin" "$here/emit_check.c" "$H/emit.c" "$H/loader.c" "$H/bamio.c" "$H/inflate_fast.c" -lz -lpthread
     ASAN_OPTIONS=detect_leaks=1 "$ebin" 300000 6 "$out/emit.txt" > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): emit_check"; exit 1; }
     if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): emit_check"; exit 1; fi
+    if [ "$mode" != thread ]; then
+        ibin="$out/inflate_check_${mode%%,*}"
+        gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu11 -I"$H" -o "$ibin" "$here/inflate_check.c" "$H/inflate_fast.c" -lz
+        ASAN_OPTIONS=detect_leaks=1 "$ibin" 20000 > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): inflate_check"; exit 1; }
+        if grep -q "ERROR: \|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): inflate_check"; exit 1; fi
+    fi
     echo "$mode: clean"
 done
