@@ -43,14 +43,16 @@ static uint32_t sym_entry(int is_dist, int sym, int len_here) {
     return E_INVALID;   /* 286, 287: never valid in a stream */
 }
 
-/* Canonical Huffman code (lens[0..n)) -> two-level table.  Returns 0, or -1 for an over-subscribed code.  An incomplete
- * code is accepted (zlib accepts a single distance code of length 1; unused slots stay invalid). */
+/* Canonical Huffman code (lens[0..n)) -> two-level table.  Returns 0, or -1 for a code zlib would refuse too: an
+ * over-subscribed one, or an incomplete one unless it has no symbols at all or a single one-bit code (unused slots stay
+ * invalid). */
 static int build_table(const uint8_t *lens, int n, int is_dist, int root, uint32_t *tab, int sub_max) {
     int count[16] = {0}, next[16];
     for (int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
-    int left = 1;
-    for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return -1; }
+    int left = 1, max_len = 0;
+    for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return -1; if (count[l]) max_len = l; }
+    if (left > 0 && max_len > 1) return -1;
     int code = 0;
     for (int l = 1; l <= 15; l++) { code = (code + count[l - 1]) << 1; next[l] = code; }
     const int root_size = 1 << root;
@@ -176,6 +178,7 @@ int mm_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_le
                 for (int i = 0; i < 19; i++) count[cl[i]]++;
                 count[0] = 0;
                 for (int l = 1; l <= 7; l++) { left = (left << 1) - count[l]; if (left < 0) return -1; }
+                if (left > 0) return -1;   /* the code-length code must be complete */
                 for (int l = 1; l <= 7; l++) { code = (code + count[l - 1]) << 1; next[l] = code; }
                 for (int i = 0; i < 128; i++) cl_tab[i] = 0;
                 for (int s = 0; s < 19; s++) {

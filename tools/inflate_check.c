@@ -68,7 +68,19 @@ int main(int argc, char **argv) {
         memcpy(in_exact, cmp, in_len);
         size_t out_len = (rnd() % 4 == 0) ? rnd() % (2 * n + 1) : n;
         unsigned char *dst = malloc(out_len ? out_len : 1);
-        if (mm_inflate_raw(in_exact, in_len, dst, out_len) == 0) accepted++;
+        if (mm_inflate_raw(in_exact, in_len, dst, out_len) == 0) {
+            accepted++;
+            /* whatever the own decoder accepts, zlib must accept too and decode to the same bytes */
+            unsigned char *ref = malloc(out_len ? out_len : 1);
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            inflateInit2(&z, -15);
+            z.next_in = in_exact; z.avail_in = (uInt)in_len; z.next_out = ref; z.avail_out = (uInt)out_len;
+            int zr = inflate(&z, Z_FINISH);
+            if (zr != Z_STREAM_END || z.total_out != out_len || memcmp(ref, dst, out_len) != 0) { fails++; if (fails < 10) printf("accepted a stream zlib does not decode the same way (zlib %d, %lu of %zu bytes)\n", zr, z.total_out, out_len); }
+            inflateEnd(&z);
+            free(ref);
+        }
         free(src); free(cmp); free(in_exact); free(dst);
     }
     printf("%d round trips, %d failures; %d damaged streams, %d of them still decoded to the promised size\n", cases, fails, n_fuzz, accepted);
