@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3
 #define MM_MAX_MODS 13    /* requested -c entries (2 context bits each + 5 base bits in one 32-bit ref word) */
 #define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
 #define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
@@ -100,6 +100,11 @@ typedef struct mm_freq_opts {
     int64_t side_capacity;   /* sparse side-list records (16 B each); 0 = default */
     int32_t n_wild_planes;   /* with -c '*': dense planes for the first n interned codes; 0 = default */
     int32_t view;            /* 1 = `minimod view`: per-read rows (mm_view_fetch) instead of counters (mm_freq_finalize) */
+    /* test / diagnostic switches (0 = the product's behaviour) */
+    int32_t force_fused;     /* 1: every read through the fused one-wavefront-per-read kernel instead of the tile pipeline */
+    int32_t view_cap;        /* view: records per append region before the grow-and-rerun path (0 = sized from the ML pool) */
+    int32_t finalize_by_runs;/* 1: mm_freq_finalize takes the per-run compaction + host merge even when all rows are dense */
+    int32_t rsvd;
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
 
@@ -153,7 +158,8 @@ enum {
     MM_E_MMEMPTY = 6, MM_E_MMMIXED = 7, MM_E_SKIPLEN = 8, MM_E_SKIPVAL = 9, MM_E_READPOS = 10,
     MM_E_MLIDX = 11, MM_E_NOCONTIG = 12, MM_E_REFPOS = 13, MM_E_QOVER = 14,
     /* library-level */
-    MM_E_SIDEFULL = 32, MM_E_ARG = 33, MM_E_HIP = 34, MM_E_NOMEM = 35, MM_E_TOOMANY = 36, MM_E_NOCODE = 37
+    MM_E_SIDEFULL = 32, MM_E_ARG = 33, MM_E_HIP = 34, MM_E_NOMEM = 35, MM_E_TOOMANY = 36, MM_E_NOCODE = 37,
+    MM_E_OVERFLOW = 38   /* a counter passed 2^32 - 1 calls (the reference exits on n_called overflow, src/mod.c:900-904) */
 };
 
 typedef struct mm_freq mm_freq_t;

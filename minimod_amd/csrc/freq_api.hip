@@ -92,7 +92,7 @@ struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
     int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4;
-    bool use_tiles = true;   // MM_FUSED=1 forces the fused one-wave-per-read kernel
+    bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
     bool wide = false;  // 32-bit reference words (n_mods > 5)
     int n_contigs = 0;
     std::vector<std::string> names;
@@ -118,6 +118,9 @@ struct mm_freq {
     hipStream_t stream = nullptr;  // set-up / finalize stream
     std::vector<mm_row_t> rows;
     int64_t device_bytes = 0;
+    // an error of a batch whose ticket was never waited for (its slot was recycled), or of a deferred launch that failed:
+    // reported by the next submit / wait / finalize instead of being lost
+    int sticky_err = 0, sticky_read = -1;
     // finalize scratch
     uint32_t* d_tile_counts = nullptr; unsigned long long* d_tile_offsets = nullptr; size_t cap_tiles = 0;
     DenseRow* d_rows = nullptr; size_t cap_rows = 0;
@@ -226,7 +229,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         // every explicit row consumes one ML byte, so the ML pool bounds them; implicit rows ('.' groups) are not bounded
         // by anything cheap: mm_view_fetch grows the buffer and runs the batch again when a region overflows
         size_t want = (size_t)(b->n_ml_bytes / kViewRegions) * 3 / 2 + 4096;
-        if (const char* ev = std::getenv("MM_VIEW_CAP")) want = (size_t)std::max(1, std::atoi(ev));   // tests: force the overflow path
+        if (h->opts.view_cap > 0) want = (size_t)h->opts.view_cap;   // tests: force the overflow path
         if (want > s.view_cap) {
             if ((r = grow(h, (void**)&s.d_vkeys, &s.cap_vkeys, 8 * want * kViewRegions)) ||
                 (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)))
@@ -381,19 +384,49 @@ int settle(mm_freq* h) {
     return 0;
 }
 
+int slot_status(mm_freq* h, Slot& s, int32_t* bad_read);
+
 // every batch submitted so far is complete, fallback lists included (before counters are read or changed)
 int drain(mm_freq* h) {
     HIPCHK(hipDeviceSynchronize());
-    for (auto& s : h->slots) { int r = finish_deferred(h, s); if (r < 0) return r; }
+    for (auto& s : h->slots) {
+        int r = finish_deferred(h, s);
+        if (r < 0) return r;
+        if (s.busy) {   // never waited for: its reads' errors still count
+            int32_t bad = -1;
+            int e = slot_status(h, s, &bad);
+            if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; }
+            s.busy = false;
+        }
+    }
     return 0;
+}
+
+// status of a slot whose kernels are complete: 0, or the first failing read's code (its batch index in *bad_read)
+int slot_status(mm_freq* h, Slot& s, int32_t* bad_read) {
+    (void)h;
+    if (s.h_ctl[129] == 0xFFFFFFFFu) return 0;
+    unsigned int sum = 0xFFFFFFFFu;
+    if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
+    if (bad_read) *bad_read = (int32_t)(sum >> 8);
+    return (int)(sum & 0xFFu);
 }
 
 int acquire_slot(mm_freq* h) {
     int i = h->next_slot;
     h->next_slot = (h->next_slot + 1) % kSlots;
     Slot& s = h->slots[i];
-    if (s.busy) (void)hipEventSynchronize(s.ev_wait);
-    (void)finish_deferred(h, s);
+    if (s.busy) {
+        // the ticket was never waited for: its outcome must not vanish with the slot
+        int e = hipEventSynchronize(s.ev_wait) == hipSuccess ? 0 : MM_E_HIP;
+        if (!e && finish_deferred(h, s) < 0) e = MM_E_HIP;
+        int32_t bad = -1;
+        if (!e) e = slot_status(h, s, &bad);
+        if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; }
+        s.busy = false;
+    } else if (finish_deferred(h, s) < 0 && !h->sticky_err) {
+        h->sticky_err = MM_E_HIP;
+    }
     return i;
 }
 
@@ -426,6 +459,7 @@ const char* mm_strerror(int32_t code) {
         case MM_E_NOMEM: return "out of device memory";
         case MM_E_TOOMANY: return "too many modification codes (or, in view mode, more than 2048 MM groups in one read)";
         case MM_E_NOCODE: return "modification code not interned";
+        case MM_E_OVERFLOW: return "n_called overflowed (more than 4294967295 calls on one key)";
         default: return "unknown error";
     }
 }
@@ -499,8 +533,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
-        const char* ef = std::getenv("MM_FUSED");
-        h->use_tiles = !(ef && std::atoi(ef) != 0);
+        h->use_tiles = opts->force_fused == 0;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
     for (auto& s : h->slots) {
@@ -663,12 +696,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
 
 int32_t mm_freq_plan_batch(const mm_read_t* reads, int32_t n, int32_t* items, int32_t cap) {
     if (n < 0 || (n > 0 && (!reads || !items)) || n >= (1 << 24)) return -MM_E_ARG;
-    static int split = 0;
-    if (!split) {
-        const char* e = std::getenv("MM_SPLIT_BASES");
-        split = e ? std::atoi(e) : 24576;   // measured on C2: 8192 479, 16384 507, 24576 519, 49152 517, 131072 456 Gbases/s
-        if (split < 1024) split = 1024;
-    }
+    const int split = 24576;   // measured on C2: 8192 479, 16384 507, 24576 519, 49152 517, 131072 456 Gbases/s
     // counting sort on estimated cost (bases per part, 256-base buckets), costliest first
     enum { NB = 4096 };
     std::vector<uint32_t> cnt(NB + 1, 0);
@@ -712,6 +740,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     int si = acquire_slot(h);
+    if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s.stream;
     // all slots of the handle share the code table; make sure it is current (sync only when it changed)
@@ -725,6 +754,7 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     int si = acquire_slot(h);
+    if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
     hipStream_t st = s.stream;
     int r = upload_codes(h, st);
@@ -765,18 +795,13 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
 int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (!h || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
     Slot& s = h->slots[ticket];
+    if (h->sticky_err) { if (bad_read) *bad_read = h->sticky_read; return h->sticky_err; }
     if (!s.busy) return MM_OK;
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
     if (finish_deferred(h, s) < 0) return MM_E_HIP;
-    if (s.h_ctl[129] != 0xFFFFFFFFu) {
-        unsigned int sum = 0xFFFFFFFFu;
-        if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
-        if (bad_read) *bad_read = (int32_t)(sum >> 8);
-        return (int32_t)(sum & 0xFFu);
-    }
-    return MM_OK;
+    return slot_status(h, s, bad_read);
 }
 
 float mm_freq_last_kernel_ms(mm_freq_t* h, int32_t ticket) {
@@ -798,9 +823,6 @@ int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     std::vector<unsigned long long> all(16 + 4 * (size_t)kStatSlots);
     HIPCHK(hipMemcpy(all.data(), h->d_stats, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stats, 0, all.size() * sizeof(unsigned long long)));
-    if (const char* dump = std::getenv("MM_STATS_DUMP")) {   // diagnostic builds: the raw per-wave rows
-        if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(all.data(), sizeof(unsigned long long), all.size(), f); std::fclose(f); }
-    }
     for (int i = 0; i < 16; i++) out[i] = all[i];
     for (int i = 0; i < 4; i++) out[i] = 0;
     for (size_t w = 0; w < kStatSlots; w++) for (int i = 0; i < 4; i++) out[i] += all[16 + 4 * w + i];
@@ -816,17 +838,22 @@ void mm_freq_reset_counters(mm_freq_t* h) {
     (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1));
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
     (void)hipDeviceSynchronize();
+    h->sticky_err = 0; h->sticky_read = -1;
 }
 
 int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     if (!h || h->opts.view) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     { int r = drain(h); if (r) return r; }
+    if (h->sticky_err) return -h->sticky_err;
     std::vector<mm_row_t>& rows = h->rows;
     rows.clear();
+    // n_called is the low half of a packed 64-bit counter: a carry out of it lands in n_mod, which can then exceed it
+    // (never otherwise: every modified call is a call).  The reference exits on such an overflow (src/mod.c:900-904).
+    auto overflowed = [&]() { for (const mm_row_t& r : rows) if (r.n_mod > r.n_called) return true; return false; };
     // ---- every row a dense one (no haplotype planes, nothing on the side list): the device walks the positions and
     // writes finished rows in output order (k_site_count / k_site_emit); the host only copies them
-    if (!h->opts.haplotypes && h->n_counter_words > 0 && !std::getenv("MM_K2_RUNS")) {
+    if (!h->opts.haplotypes && h->n_counter_words > 0 && !h->opts.finalize_by_runs) {
         unsigned long long ns0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
         if (ns0 == 0) {
@@ -857,6 +884,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
                     if (hipMemcpyAsync(d_segs, segs.data(), sizeof(SiteSeg) * segs.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
                     hipLaunchKernelGGL(k_site_count, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
                                        d_segs, (int)segs.size(), h->d_tile_counts);
+                    if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
                     std::vector<uint32_t> tc((size_t)tiles);
                     if (hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                         hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
@@ -876,6 +904,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
                         if (hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * (size_t)tiles, hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
                         hipLaunchKernelGGL(k_site_emit, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
                                            d_segs, (int)segs.size(), h->d_tile_offsets, reinterpret_cast<mm_row_t*>(h->d_rows));
+                        if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
                         if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                             hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
                     }
@@ -883,6 +912,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
                 } while (0);
                 (void)hipFree(d_segs);
                 if (result < 0) return result;
+                if (overflowed()) return -MM_E_OVERFLOW;
                 if (out_rows) *out_rows = rows.data();
                 return result;
             }
@@ -1032,6 +1062,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
         i = j;
     }
     rows.swap(merged);
+    if (overflowed()) return -MM_E_OVERFLOW;
     if (out_rows) *out_rows = rows.data();
     return (int64_t)rows.size();
 }

@@ -9,6 +9,7 @@
  * then copies it into the flattened pools with the same worker pool (mm_pool_for). */
 #include "bamio.h"
 #include "inflate_fast.h"
+#include "crc32_fast.h"
 
 #include <pthread.h>
 #include <sys/mman.h>
@@ -75,7 +76,14 @@ mm_pool_t *mm_pool_create(int n_threads) {
     pthread_cond_init(&p->cv_job, NULL);
     pthread_cond_init(&p->cv_room, NULL);
     p->th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
-    for (int i = 0; i < n_threads; i++) pthread_create(&p->th[i], NULL, pool_worker, p);
+    if (!p->th) { p->n_threads = 0; mm_pool_destroy(p); return NULL; }
+    int started = 0;
+    for (int i = 0; i < n_threads; i++) {
+        if (pthread_create(&p->th[started], NULL, pool_worker, p) != 0) break;
+        started++;
+    }
+    p->n_threads = started;   /* fewer workers than asked for still work; none at all is a failure */
+    if (started == 0) { mm_pool_destroy(p); return NULL; }
     return p;
 }
 
@@ -118,7 +126,7 @@ void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int6
 /* ------------------------------------------------------------------ chunks */
 typedef struct {
     const uint8_t *cdata;
-    uint32_t clen, isize;
+    uint32_t clen, isize, crc;   /* crc: the block's CRC32 trailer (RFC 1952) */
     uint8_t *out;
     int err;
 } blk_t;
@@ -164,18 +172,34 @@ struct mm_bam {
 static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint16_t rd_u16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-static int inflate_block(blk_t *b) {
-    if (b->isize == 0) return 0;
-    if (mm_inflate_raw(b->cdata, b->clen, b->out, b->isize) == 0) return 0;
-    /* malformed or not understood: zlib has the last word (and decides what counts as an error) */
+/* MM_BAM_VERIFY_ZLIB=1 (debug switch): every block is also inflated by zlib and the two outputs must agree */
+static int verify_zlib = -1;
+
+static int zlib_inflate(const blk_t *b, uint8_t *out) {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return -1;
     zs.next_in = (Bytef *)b->cdata; zs.avail_in = b->clen;
-    zs.next_out = b->out; zs.avail_out = b->isize;
+    zs.next_out = out; zs.avail_out = b->isize;
     int r = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     return (r == Z_STREAM_END && zs.avail_out == 0) ? 0 : -1;
+}
+
+static int inflate_block(blk_t *b) {
+    if (b->isize == 0) return b->crc == 0 ? 0 : -1;   /* crc32 of nothing */
+    /* malformed or not understood by the own decoder: zlib has the last word (and decides what counts as an error) */
+    if (mm_inflate_raw(b->cdata, b->clen, b->out, b->isize) != 0 && zlib_inflate(b, b->out) != 0) return -1;
+    /* the trailer's CRC32 covers the decoded bytes: a damaged block (or a decoder bug) that still yields ISIZE bytes
+     * must not reach the counters -- htslib fails such a file too */
+    if (mm_crc32(b->out, b->isize) != b->crc) return -1;
+    if (verify_zlib > 0) {
+        uint8_t *chk = (uint8_t *)malloc(b->isize);
+        int bad = !chk || zlib_inflate(b, chk) != 0 || memcmp(chk, b->out, b->isize) != 0;
+        free(chk);
+        if (bad) { fprintf(stderr, "[bamio] MM_BAM_VERIFY_ZLIB: own decoder and zlib disagree on a block\n"); return -1; }
+    }
+    return 0;
 }
 
 static void inflate_range(void *arg, int64_t lo, int64_t hi) {
@@ -202,6 +226,7 @@ static long block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) {
     int bsize = -1;
     while (x + 4 <= xe) {
         uint32_t sl = rd_u16(x + 2);
+        if (x + 4 + sl > xe) return -1;   /* a subfield that runs past XLEN */
         if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
         x += 4 + sl;
     }
@@ -225,6 +250,7 @@ static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
         k->cdata = h + 12 + xlen;
         k->clen = (uint32_t)((size_t)total - xlen - 12 - 8);
         k->isize = rd_u32(h + total - 4);
+        k->crc = rd_u32(h + total - 8);
         if (k->isize > 65536) return -1;
         k->out = c->buf + CHUNK_HEAD + out;
         k->err = 0;
@@ -269,6 +295,7 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
             int bsize = -1;
             while (x + 4 <= xe) {
                 uint32_t sl = rd_u16(x + 2);
+                if (x + 4 + sl > xe) return -1;   /* a subfield that runs past XLEN */
                 if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
                 x += 4 + sl;
             }
@@ -289,6 +316,7 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
         k->cdata = h + 12 + xlen;
         k->clen = (uint32_t)(total - xlen - 12 - 8);
         k->isize = rd_u32(h + total - 4);
+        k->crc = rd_u32(h + total - 8);
         if (k->isize > 65536) return -1;
         k->out = c->buf + CHUNK_HEAD + out;
         k->err = 0;
@@ -428,6 +456,8 @@ mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
     FILE *fp = fopen(path, "rb");
     if (!fp) return NULL;
     mm_bam_t *b = (mm_bam_t *)calloc(1, sizeof(*b));
+    if (!b) { fclose(fp); return NULL; }
+    if (verify_zlib < 0) { const char *ev = getenv("MM_BAM_VERIFY_ZLIB"); verify_zlib = ev && atoi(ev) != 0; }
     b->fp = fp;
     b->pool = pool;
     {   /* regular file: map it (pipes and the like keep the fread path) */
@@ -456,11 +486,13 @@ mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
     b->hdr.n_targets = n_ref;
     b->hdr.target_name = (char **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char *));
     b->hdr.target_len = (uint32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint32_t));
+    if (!b->hdr.target_name || !b->hdr.target_len) { b->hdr.n_targets = 0; mm_bam_close(b); return NULL; }
     for (int32_t i = 0; i < n_ref; i++) {
         if (want(b, 4) != 1) { mm_bam_close(b); return NULL; }
         uint32_t l_name = rd_u32(b->p);
         if (want(b, 8 + (size_t)l_name) != 1) { mm_bam_close(b); return NULL; }
-        b->hdr.target_name[i] = (char *)malloc(l_name + 1);
+        b->hdr.target_name[i] = (char *)malloc((size_t)l_name + 1);
+        if (!b->hdr.target_name[i]) { mm_bam_close(b); return NULL; }
         memcpy(b->hdr.target_name[i], b->p + 4, l_name);
         b->hdr.target_name[i][l_name] = 0;
         b->hdr.target_len[i] = rd_u32(b->p + 4 + l_name);
@@ -497,6 +529,7 @@ int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *r) {
     r->l_qseq = (int32_t)rd_u32(p + 16);
     if (r->l_qseq < 0) return -1;
     size_t o = 32;
+    if (r->l_read_name == 0 || o + r->l_read_name > bs || p[o + r->l_read_name - 1] != 0) return -1;   /* NUL-terminated inside l_read_name */
     r->qname = (const char *)(p + o); o += r->l_read_name;
     r->cigar = (const uint32_t *)(p + o); o += 4 * (size_t)r->n_cigar;
     r->seq = p + o; o += ((size_t)r->l_qseq + 1) / 2;
@@ -532,6 +565,8 @@ void mm_bam_close(mm_bam_t *b) {
 }
 
 const uint8_t *mm_aux_get(const uint8_t *aux, int32_t l_aux, const char tag[2]) {
+    /* like bam_aux_get, a tag whose payload does not fit [aux, aux + l_aux) -- a B array longer than the record, a Z
+     * string without its NUL -- ends the walk: the record is treated as not carrying the tag */
     const uint8_t *p = aux, *e = aux + l_aux;
     while (p + 3 <= e) {
         const uint8_t *t = p + 2;
@@ -544,19 +579,26 @@ const uint8_t *mm_aux_get(const uint8_t *aux, int32_t l_aux, const char tag[2]) 
             case 'd': sz = 8; break;
             case 'Z': case 'H': {
                 const uint8_t *z = (const uint8_t *)memchr(t + 1, 0, (size_t)(e - (t + 1)));
-                if (!z) z = e;
+                if (!z) return NULL;
                 sz = (size_t)(z - (t + 1)) + 1;
                 break;
             }
             case 'B': {
                 if (t + 6 > e) return NULL;
                 uint32_t n = rd_u32(t + 2);
-                size_t es = (t[1] == 'c' || t[1] == 'C') ? 1 : (t[1] == 's' || t[1] == 'S') ? 2 : 4;
+                size_t es;
+                switch (t[1]) {
+                    case 'c': case 'C': es = 1; break;
+                    case 's': case 'S': es = 2; break;
+                    case 'i': case 'I': case 'f': es = 4; break;
+                    default: return NULL;
+                }
                 sz = 5 + (size_t)n * es;
                 break;
             }
             default: return NULL;
         }
+        if (sz > (size_t)(e - (t + 1))) return NULL;
         if (match) return t;
         p = t + 1 + sz;
     }

@@ -242,6 +242,7 @@ static void view_init(void) {
 typedef struct {
     const mm_view_row_t *rows;
     const mm_batch_t *batch;
+    const mmh_loader_t *ld;
     int pool_set;
     const mm_bam_hdr_t *hdr;
     const char *const *codes;
@@ -259,7 +260,7 @@ static void view_piece(const void *vctx, int64_t lo, int64_t hi, mbuf_t *out) {
         if (r->read != last_read) {
             last_read = r->read;
             rd = &c->batch->reads[r->read];
-            qname = mmh_loader_qname(c->pool_set, (int32_t)r->read);
+            qname = mmh_loader_qname(c->ld, c->pool_set, (int32_t)r->read);
             qlen = strlen(qname);
             contig = (rd->tid >= 0 && rd->tid < c->hdr->n_targets) ? c->hdr->target_name[rd->tid] : "*";
             clen = strlen(contig);
@@ -282,9 +283,9 @@ static void view_piece(const void *vctx, int64_t lo, int64_t hi, mbuf_t *out) {
 }
 
 /* The rows' text is complete when this returns (the batch and its pools may be reused); writing it may still be under way. */
-void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, int pool_set,
+void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, const mmh_loader_t *ld, int pool_set,
                          const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes) {
     pthread_once(&view_once, view_init);
-    view_ctx_t c = {rows, batch, pool_set, hdr, codes, n_codes, insertions, haplotypes};
+    view_ctx_t c = {rows, batch, ld, pool_set, hdr, codes, n_codes, insertions, haplotypes};
     emit_rows(fp, pool, n, view_piece, &c);
 }

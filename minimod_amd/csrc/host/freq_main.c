@@ -139,7 +139,7 @@ static int code_names(mm_freq_t *h, const char **codes) {
     return n;
 }
 
-static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, int pool_set, const mm_bam_hdr_t *hdr, const fopt_t *o,
+static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, const mmh_loader_t *ld, int pool_set, const mm_bam_hdr_t *hdr, const fopt_t *o,
                          mm_pool_t *pool, double *wait_time, double *output_time) {
     double tw = mmh_realtime();
     int32_t bad = -1;
@@ -156,7 +156,7 @@ static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, int 
     double to = mmh_realtime();
     const char *codes[MM_MAX_CODES];
     int n_codes = code_names(h, codes);
-    mmh_print_view_rows(o->out, pool, rows, n, b, pool_set, hdr, codes, n_codes, o->insertions, o->haplotypes);
+    mmh_print_view_rows(o->out, pool, rows, n, b, ld, pool_set, hdr, codes, n_codes, o->insertions, o->haplotypes);
     *output_time += mmh_realtime() - to;
 }
 
@@ -284,7 +284,7 @@ static int run_main(int argc, char **argv, int view) {
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (pending_ticket >= 0) {
-            retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+            retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
             pending_ticket = -1;
         }
         if (n > 0) {
@@ -308,7 +308,7 @@ static int run_main(int argc, char **argv, int view) {
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
     double sort_time = 0;
     if (!view) {
         double ts = mmh_realtime();

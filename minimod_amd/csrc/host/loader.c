@@ -14,7 +14,6 @@ enum { P_READS = 0, P_CIGAR, P_SEQ, P_MM, P_ML, P_QOFF, P_QNAME };   /* the last
 
 typedef struct { uint8_t *p; size_t n, cap; } pool_t;
 
-static pool_t g_sets[2][NPOOL];
 
 /* one accepted record: where its parts lie in the reader's buffers and where they go in the pools */
 typedef struct {
@@ -27,8 +26,13 @@ typedef struct {
     size_t o_cigar, o_seq, o_mm, o_ml, o_qname;   /* byte offsets */
 } item_t;
 
-static item_t *g_items;
-static size_t g_items_cap;
+/* per-loader state: two pool sets and the item array (two loaders in one process do not share anything) */
+typedef struct loader_priv {
+    pool_t sets[2][NPOOL];
+    item_t *items;
+    size_t items_cap;
+} loader_priv_t;
+#define PRIV(ld) ((loader_priv_t *)(ld)->priv)
 
 static void pool_reserve(pool_t *b, size_t bytes) {
     if (bytes > b->cap) {
@@ -46,6 +50,9 @@ mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int6
     mm_bam_t *bam = mm_bam_open(bam_path, threads);
     if (!bam) return NULL;
     mmh_loader_t *ld = (mmh_loader_t *)calloc(1, sizeof(*ld));
+    loader_priv_t *pv = (loader_priv_t *)calloc(1, sizeof(*pv));
+    if (!ld || !pv) { free(ld); free(pv); mm_bam_close(bam); return NULL; }
+    ld->priv = pv;
     ld->bam = bam; ld->K = K; ld->B = B;
     ld->allow_secondary = allow_secondary; ld->skip_supplementary = skip_supplementary;
     return ld;
@@ -99,7 +106,8 @@ static void copy_range(void *arg, int64_t lo, int64_t hi) {
 }
 
 int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
-    pool_t *P = g_sets[set & 1];
+    loader_priv_t *lp = PRIV(ld);
+    pool_t *P = lp->sets[set & 1];
     int32_t n = 0, total = 0;
     int64_t total_bytes = 0, proc_bytes = 0;
     uint32_t max_cig = 0, max_l = 0;
@@ -125,13 +133,16 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
         if (mlt && mlt[0] == 'B' && mlt[1] == 'C') {
             ml_len = (uint32_t)mlt[2] | ((uint32_t)mlt[3] << 8) | ((uint32_t)mlt[4] << 16) | ((uint32_t)mlt[5] << 24);
             ml = mlt + 6;
+            if ((size_t)ml_len > (size_t)(rec.aux + rec.l_aux - ml)) continue;   /* cannot happen after mm_aux_get's bounds check */
         }
         const uint8_t *hpt = mm_aux_get(rec.aux, rec.l_aux, "HP");
-        if ((size_t)n == g_items_cap) {
-            g_items_cap = g_items_cap ? g_items_cap * 2 : 1024;
-            g_items = (item_t *)realloc(g_items, g_items_cap * sizeof(item_t));
+        if ((size_t)n == lp->items_cap) {
+            size_t ncap = lp->items_cap ? lp->items_cap * 2 : 1024;
+            item_t *grown = (item_t *)realloc(lp->items, ncap * sizeof(item_t));
+            if (!grown) { rc = -1; break; }
+            lp->items = grown; lp->items_cap = ncap;
         }
-        item_t *it = &g_items[n];
+        item_t *it = &lp->items[n];
         it->cigar = (const uint8_t *)rec.cigar; it->seq = rec.seq; it->mm = (const uint8_t *)mm; it->ml = ml;
         it->qname = rec.qname; it->qlen = (uint32_t)strlen(rec.qname);
         it->n_cigar = rec.n_cigar; it->l_qseq = (uint32_t)rec.l_qseq; it->mm_len = (uint32_t)mm_len; it->ml_len = ml_len;
@@ -155,7 +166,7 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     pool_reserve(&P[P_READS], sizeof(mm_read_t) * (size_t)(n > 0 ? n : 1));
     pool_reserve(&P[P_CIGAR], o_cigar); pool_reserve(&P[P_SEQ], o_seq); pool_reserve(&P[P_MM], o_mm); pool_reserve(&P[P_ML], o_ml);
     pool_reserve(&P[P_QOFF], 8 * (size_t)(n > 0 ? n : 1)); pool_reserve(&P[P_QNAME], o_qname + 1);
-    copy_ctx_t cc = {P, g_items};
+    copy_ctx_t cc = {P, lp->items};
     mm_pool_t *pool = mm_bam_pool(ld->bam);
     int nt = mm_pool_threads(pool);
     int64_t grain = n / (4 * (nt > 0 ? nt : 1)) + 1;
@@ -177,8 +188,8 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     return n;
 }
 
-const char *mmh_loader_qname(int set, int32_t read) {
-    const pool_t *P = g_sets[set & 1];
+const char *mmh_loader_qname(const mmh_loader_t *ld, int set, int32_t read) {
+    const pool_t *P = PRIV(ld)->sets[set & 1];
     uint64_t qo;
     memcpy(&qo, P[P_QOFF].p + 8 * (size_t)read, sizeof qo);
     return (const char *)P[P_QNAME].p + qo;
@@ -187,7 +198,9 @@ const char *mmh_loader_qname(int set, int32_t read) {
 void mmh_loader_close(mmh_loader_t *ld) {
     if (!ld) return;
     mm_bam_close(ld->bam);
-    for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) { free(g_sets[s][i].p); memset(&g_sets[s][i], 0, sizeof(pool_t)); }
-    free(g_items); g_items = NULL; g_items_cap = 0;
+    loader_priv_t *lp = PRIV(ld);
+    for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) free(lp->sets[s][i].p);
+    free(lp->items);
+    free(lp);
     free(ld);
 }

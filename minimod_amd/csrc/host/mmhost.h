@@ -60,6 +60,7 @@ typedef struct mmh_loader {
     /* statistics of the last batch / totals (db_t / core_t counters, src/minimod.h:147-150,190-194) */
     int32_t last_total_reads; int64_t last_total_bytes, last_processed_bytes;
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
+    void *priv;   /* pool sets and framing scratch (loader.c) */
 } mmh_loader_t;
 mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary);
 /* Fills `out` with the next batch (pointers into the loader's pools, valid until the next call with the same pool set).
@@ -67,7 +68,7 @@ mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int6
  * (src/freq_main.c:410). */
 int32_t mmh_loader_next(mmh_loader_t *ld, int pool_set, mm_batch_t *out, int *more);
 /* read name of read `read` of the batch last loaded into `pool_set` */
-const char *mmh_loader_qname(int pool_set, int32_t read);
+const char *mmh_loader_qname(const mmh_loader_t *ld, int pool_set, int32_t read);
 void mmh_loader_close(mmh_loader_t *ld);
 
 /* ---- output ---- */
@@ -80,7 +81,7 @@ void mmh_print_freq_rows(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_
 
 /* print_view_header / print_view_output (src/mod.c:545-626) for one batch's rows */
 void mmh_print_view_header(FILE *fp, int insertions, int haplotypes);
-void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, int pool_set,
+void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, const mmh_loader_t *ld, int pool_set,
                          const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes);
 int mmh_emit_flush(void);
 int mmh_emit_finish(void);   /* flush, then stop the writer thread and free the recycled buffers */

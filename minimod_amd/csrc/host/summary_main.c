@@ -235,7 +235,7 @@ int mmh_summary_main(int argc, char **argv) {
             slotset_t keys;
             memset(&keys, 0, sizeof keys);
             summarise_read((const char *)batch.mm + rd->mm_off, rd->mm_len, &keys);
-            fprintf(out, "%s\t", mmh_loader_qname(set, i));
+            fprintf(out, "%s\t", mmh_loader_qname(ld, set, i));
             for (uint32_t s = 0; s < keys.n_slots; s++) if (keys.key[s]) fprintf(out, "%s ", keys.key[s]);
             fputc('\n', out);
             slotset_clear(&keys);

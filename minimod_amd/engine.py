@@ -8,7 +8,7 @@ import numpy as np
 
 from .build import build_hip, lib_path
 
-MM_ABI_VERSION = 2
+MM_ABI_VERSION = 3
 MM_MAX_MODS = 13
 MM_CODE_LEN = 16
 
@@ -43,7 +43,8 @@ class mm_freq_opts_t(ctypes.Structure):
     _fields_ = [("abi_version", ctypes.c_int32), ("n_mods", ctypes.c_int32), ("insertions", ctypes.c_int32),
                 ("haplotypes", ctypes.c_int32), ("device", ctypes.c_int32), ("n_hp_planes", ctypes.c_int32),
                 ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
-                ("mods", mm_mod_t * MM_MAX_MODS)]
+                ("force_fused", ctypes.c_int32), ("view_cap", ctypes.c_int32), ("finalize_by_runs", ctypes.c_int32),
+                ("rsvd", ctypes.c_int32), ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
 class mm_contig_t(ctypes.Structure):
@@ -188,7 +189,8 @@ class FreqEngine(object):
     contigs: [(name, target_len, raw_sequence_bytes_or_None)] in BAM-header (tid) order."""
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
-                 n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False):
+                 n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False, force_fused=False, view_cap=0,
+                 finalize_by_runs=False):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -197,6 +199,7 @@ class FreqEngine(object):
         o.insertions, o.haplotypes, o.device = int(insertions), int(haplotypes), int(device)
         o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
         o.view = int(view)
+        o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
             o.mods[i].context = ctx.encode()

@@ -1,5 +1,5 @@
 """Both device forms of the hot path -- the tile pipeline (default) and the fused one-wave-per-read kernel
-(MM_FUSED=1, also the fallback for reads the tiles do not cover) -- against the oracle on synthetic reads that
+(opts.force_fused, also the fallback for reads the tiles do not cover) -- against the oracle on synthetic reads that
 exercise what the bundled BAMs do not at scale: long reads (spills past the LDS caps, many tiles), HiFi shape, '.'
 groups (implicit calls, tail tiles), haplotypes, insertions, the side list."""
 import json
@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 WORKER = r'''
 import json, sys
 sys.path.insert(0, %r)
+FUSED = bool(%d)
 import numpy as np
 import minimod_amd
 from minimod_amd import synth
@@ -36,7 +37,7 @@ cases = {
 for name, cs in cases.items():
     g = dict(cs["gen"]); n = g.pop("n")
     b = synth.batch(ref, 0, n, seed=77, n_reads_total=n, **g)
-    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], **cs["kw"])
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], force_fused=FUSED, **cs["kw"])
     eng.process(b)
     got = eng.finalize(); eng.close()
     orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
@@ -44,7 +45,7 @@ for name, cs in cases.items():
     key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
     out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max())}
     # the same batch through view mode: rows in print_view_output order, element for element
-    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, **cs["kw"])
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, force_fused=FUSED, **cs["kw"])
     v = eng.view(b); eng.close()
     orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.set_view(True); orc.add_contig("chrS", ref); orc.process(b, threads=8)
     w = orc.view_rows()
@@ -56,8 +57,7 @@ print(json.dumps(out))
 
 @pytest.mark.parametrize("fused", [0, 1], ids=["tiles", "fused"])
 def test_synthetic_shapes_match_oracle(fused):
-    env = dict(os.environ, MM_FUSED=str(fused))
-    r = subprocess.run([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, fused)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long", "hifi_q_multimod"}

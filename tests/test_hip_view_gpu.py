@@ -95,11 +95,10 @@ def test_view_against_oracle(bam, kw, chr22):
         assert a == b
 
 
-def test_view_region_overflow_reruns(chr22, monkeypatch):
+def test_view_region_overflow_reruns(chr22):
     """A record buffer too small for the batch: fetch grows it and runs the batch again; same rows."""
     path = os.path.join(GOLDEN, "data", "example-ont.bam")
     kw = dict(c="m,h")
     want = _text(hip_view(path, chr22, **kw), kw)
-    monkeypatch.setenv("MM_VIEW_CAP", "16")
-    got = _text(hip_view(path, chr22, **kw), kw)
+    got = _text(hip_view(path, chr22, view_cap=16, **kw), kw)
     assert got == want

@@ -255,6 +255,104 @@ def test_loader_reports_truncated_file(tmp_path):
         list(hostlib.load_batches(cut, K=4096, B=10 ** 9, threads=3))
 
 
+def _bgzf_blocks(raw):
+    """(offset, total size) of every BGZF block of a file image."""
+    out, pos = [], 0
+    while pos < len(raw):
+        xlen = int.from_bytes(raw[pos + 10:pos + 12], "little")
+        assert raw[pos + 12:pos + 14] == b"BC"
+        total = int.from_bytes(raw[pos + 16:pos + 18], "little") + 1
+        out.append((pos, total, xlen))
+        pos += total
+    return out
+
+
+def test_loader_checks_block_crc32(tmp_path):
+    """A BGZF block whose CRC32 trailer does not match its payload fails the file, as with htslib: here a flipped CRC and a
+    payload whose stored-block bytes were altered (same ISIZE, inflates fine).  The CRC itself equals zlib's on every length."""
+    import ctypes
+    import zlib
+    from minimod_amd import hostlib, synth
+    L = synth.host_lib()
+    L.mm_crc32.restype = ctypes.c_uint32
+    L.mm_crc32.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(3)
+    blob = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    for n in list(range(0, 200)) + [255, 256, 4095, 4096, 65280, 65536, 70000]:
+        assert L.mm_crc32(blob[:n], n) == zlib.crc32(blob[:n])
+    ref = synth.reference(9, 1 << 20)
+    p = str(tmp_path / "t.bam")
+    synth.write_bam(p, [("chrS", len(ref))], [synth.batch(ref, 0, 300, seed=4, n_reads_total=300)])
+    raw = bytearray(open(p, "rb").read())
+    assert sum(len(b["reads"]) for b in hostlib.load_batches(p, K=4096, B=10 ** 9, threads=3)) == 300
+    blocks = _bgzf_blocks(bytes(raw))
+    assert len(blocks) > 4
+    off, total, _ = blocks[2]
+    bad = bytearray(raw)
+    bad[off + total - 8] ^= 0x01                      # CRC32 trailer
+    q = str(tmp_path / "crc.bam")
+    open(q, "wb").write(bad)
+    for env in ({}, {"MM_BAM_NO_MMAP": "1"}):       # mapped file and fread path
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with pytest.raises(IOError):
+                list(hostlib.load_batches(q, K=4096, B=10 ** 9, threads=3))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    # a block re-deflated from altered bytes, ISIZE and CRC left as they were
+    off, total, xlen = blocks[1]
+    payload = bytearray(zlib.decompress(bytes(raw[off + 12 + xlen:off + total - 8]), -15))
+    payload[len(payload) // 2] ^= 0x40
+    comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+    cdata = comp.compress(bytes(payload)) + comp.flush()
+    nb = bytearray(raw[off:off + 12 + xlen]) + cdata + raw[off + total - 8:off + total]
+    nb[16:18] = (len(nb) - 1).to_bytes(2, "little")
+    q2 = str(tmp_path / "payload.bam")
+    open(q2, "wb").write(bytes(raw[:off]) + bytes(nb) + bytes(raw[off + total:]))
+    with pytest.raises(IOError):
+        list(hostlib.load_batches(q2, K=4096, B=10 ** 9, threads=2))
+
+
+def test_aux_walk_rejects_payloads_that_leave_the_record():
+    """mm_aux_get (bam_aux_get): a B array longer than the record, a Z string without its NUL or an unknown type end the
+    walk with "no such tag"; well-formed tags behind well-formed ones are found."""
+    import ctypes
+    from minimod_amd import synth
+    L = synth.host_lib()
+    L.mm_aux_get.restype = ctypes.c_void_p
+    L.mm_aux_get.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p]
+
+    def get(aux, tag):
+        buf = ctypes.create_string_buffer(aux, len(aux))
+        r = L.mm_aux_get(buf, len(aux), tag)
+        return None if not r else r - ctypes.addressof(buf)
+    good = b"NMC\x05" + b"MMZC+m?,1;\x00" + b"MLBC\x01\x00\x00\x00\xc8" + b"HPC\x02"
+    assert get(good, b"MM") == 6 and get(good, b"ML") == 17 and get(good, b"HP") == len(good) - 2 and get(good, b"XX") is None
+    assert get(b"MMZC+m?,1;", b"MM") is None                                  # no NUL inside the record
+    assert get(b"MLBC\xff\xff\xff\x7f\xc8", b"ML") is None                 # 2 G entries in a 9-byte record
+    assert get(b"MLBC\x02\x00\x00\x00\xc8", b"ML") is None                 # two entries promised, one present
+    assert get(b"HPi\x01\x00", b"HP") is None                                 # a 4-byte integer cut off after two
+    assert get(b"XYq\x00" + good, b"MM") is None                               # unknown type: the walk cannot continue
+    assert get(b"MLBq\x01\x00\x00\x00\xc8", b"ML") is None                 # unknown array subtype
+
+
+def test_two_loaders_in_one_process_do_not_share_state(tmp_path):
+    from minimod_amd import hostlib, synth
+    ref = synth.reference(9, 1 << 20)
+    pa, pb = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    ba = [synth.batch(ref, i * 150, 150, seed=4, n_reads_total=300) for i in range(2)]
+    bb = [synth.batch(ref, i * 150, 150, seed=8, n_reads_total=300, shape=1) for i in range(2)]
+    synth.write_bam(pa, [("chrS", len(ref))], ba, filter_fodder=False)
+    synth.write_bam(pb, [("chrS", len(ref))], bb, filter_fodder=False)
+    ga, gb = hostlib.load_batches(pa, K=150, B=10 ** 9), hostlib.load_batches(pb, K=150, B=10 ** 9)
+    for a, b in zip(ba, bb):              # interleaved: each generator owns an open loader
+        _same_batch(a, next(ga))
+        _same_batch(b, next(gb))
+    ga.close(); gb.close()
+
+
 SUMMARY_CASES = [
     ("test18.tsv", "dRNA.bam", []),
     ("dna_5mCG_5hmCG_mm_with_secondary_chr22_summary.tsv", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam", []),
