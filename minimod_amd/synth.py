@@ -99,6 +99,78 @@ def batch(ref, first_read, n_reads, seed=0x5EED, contig_len=None, n_reads_total=
     return out
 
 
+def concat(batches):
+    """Several numpy batches as one (reads in the order given): pools joined without the 64-byte slack between them,
+    read offsets shifted.  A coordinate-sorted BAM over several contigs gives batches like this: reads of more than one
+    contig in one -K batch."""
+    batches = [b for b in batches if len(b["reads"])]
+    if not batches:
+        raise ValueError("nothing to concatenate")
+    reads, cig, seq, mm, ml = [], [], [], [], []
+    oc = os_ = om = ol = 0
+    for b in batches:
+        r = b["reads"].copy()
+        r["cigar_off"] += oc; r["seq_off"] += os_; r["mm_off"] += om; r["ml_off"] += ol
+        reads.append(r)
+        c, q, m, l = b["cigar"][:len(b["cigar"]) - 16], b["seq"][:len(b["seq"]) - 64], b["mm"][:len(b["mm"]) - 64], b["ml"][:len(b["ml"]) - 64]
+        assert len(c) % 4 == 0 and len(q) % 16 == 0 and len(m) % 16 == 0 and len(l) % 4 == 0
+        cig.append(c); seq.append(q); mm.append(m); ml.append(l)
+        oc += len(c); os_ += len(q); om += len(m); ol += len(l)
+    z = lambda n, dt: np.zeros(n, dtype=dt)
+    rd = np.concatenate(reads)
+    return {"reads": rd, "cigar": np.concatenate(cig + [z(16, "<u4")]), "seq": np.concatenate(seq + [z(64, np.uint8)]),
+            "mm": np.concatenate(mm + [z(64, np.uint8)]), "ml": np.concatenate(ml + [z(64, np.uint8)]), "order": None,
+            "n_bases": int(sum(b["n_bases"] for b in batches)), "n_listed_calls": int(sum(b["n_listed_calls"] for b in batches)),
+            "max_n_cigar": int(rd["n_cigar"].max()), "max_l_qseq": int(rd["l_qseq"].max())}
+
+
+def split(batch, sizes):
+    """The reads of a numpy batch cut into consecutive batches of the given sizes (pools shared, offsets unchanged)."""
+    out, lo = [], 0
+    for n in sizes:
+        b = dict(batch)
+        b["reads"] = np.ascontiguousarray(batch["reads"][lo:lo + n])
+        b["order"] = None
+        b["n_bases"] = int(b["reads"]["l_qseq"].sum())
+        b["max_n_cigar"] = int(b["reads"]["n_cigar"].max()) if n else 0
+        b["max_l_qseq"] = int(b["reads"]["l_qseq"].max()) if n else 0
+        out.append(b)
+        lo += n
+    assert lo == len(batch["reads"])
+    return out
+
+
+def multi_contig(refs, reads_per_contig, batch_reads, seed=0x5EED, **kw):
+    """A coordinate-sorted read set over several contigs as -K sized batches.  refs: [reference array or None by tid]
+    (None = the contig carries no reads); reads_per_contig: reads on each.  Batches hold `batch_reads` reads and run
+    across contig boundaries like load_db's do on a sorted BAM."""
+    parts = []
+    for tid, (ref, n) in enumerate(zip(refs, reads_per_contig)):
+        if ref is None or n == 0:
+            continue
+        parts.append(batch(ref, 0, n, seed=seed + 101 * tid, n_reads_total=n, tid=tid, with_order=False, **kw))
+    whole = concat(parts)
+    n = len(whole["reads"])
+    sizes = [min(batch_reads, n - i) for i in range(0, n, batch_reads)]
+    return split(whole, sizes)
+
+
+def write_fasta_multi(path, contigs):
+    """contigs: [(name, sequence array)] as one FASTA file (80 columns)."""
+    with open(path, "wb") as f:
+        for name, seq in contigs:
+            f.write(b">" + name.encode() + b" synthetic\n")
+            a = np.ascontiguousarray(seq, dtype=np.uint8)
+            n = len(a) // 80 * 80
+            if n:
+                body = np.empty((n // 80, 81), dtype=np.uint8)
+                body[:, :80] = a[:n].reshape(-1, 80)
+                body[:, 80] = 10
+                f.write(body.tobytes())
+            if n < len(a):
+                f.write(a[n:].tobytes() + b"\n")
+
+
 def write_bam(path, contigs, batches, filter_fodder=True):
     """Write numpy batches (dicts as returned by batch()) as one coordinate-sorted BGZF BAM.  contigs: [(name, length)]."""
     from .engine import batch_struct

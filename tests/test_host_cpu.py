@@ -189,6 +189,38 @@ def test_synthetic_bam_roundtrip(tmp_path):
     assert n_records > 800      # the unmapped / secondary / tag-less copies are in the file
 
 
+def test_multi_contig_bam_roundtrip_and_oracle_contig_order(tmp_path):
+    """Reads on four contigs whose names sort differently by strcmp than by tid, batches that run across contig
+    boundaries: BAM writer -> C loader == Python reader == the generated batches; the oracle's rows come out in strcmp
+    order of the contig names (cmp_key_fast, reference src/mod.c:59-87) and do not depend on how the reads are batched."""
+    from minimod_amd import hostlib, synth
+    names, lens = ["chr1", "chr2", "chr10", "chrX", "chrM"], [1 << 19, 1 << 19, 1 << 18, 1 << 19, 16569]
+    refs = [synth.reference(100 + i, L) for i, L in enumerate(lens[:4])] + [None]
+    bs = synth.multi_contig(refs, [120, 90, 60, 100, 0], 128, seed=5, median_len=3000.0, max_len=20000.0)
+    assert any(len(set(b["reads"]["tid"].tolist())) > 1 for b in bs)
+    p = str(tmp_path / "g.bam")
+    synth.write_bam(p, list(zip(names, lens)), bs, filter_fodder=True)
+    got = [g for g in hostlib.load_batches(p, K=128, B=10 ** 9, threads=3) if len(g["reads"])]
+    want = [b for _, b, _ in pybam.load_batches(p, K=128, B=10 ** 9) if len(b["reads"])]
+    assert [len(g["reads"]) for g in got] == [len(b["reads"]) for b in bs] == [len(w["reads"]) for w in want]
+    for a, b, c in zip(bs, got, want):
+        assert (a["reads"]["tid"] == b["reads"]["tid"]).all() and (a["reads"]["pos"] == c["reads"]["pos"]).all()
+        for k in ("l_qseq", "n_cigar", "mm_len", "ml_len", "flag"):
+            assert (a["reads"][k] == b["reads"][k]).all() and (a["reads"][k] == c["reads"][k]).all()
+
+    def rows(batches, threads):
+        o = O.Oracle([("m", "CG"), ("h", "CG")], [0.8, 0.7], names)
+        for n, r in zip(names, refs):
+            if r is not None:
+                o.add_contig(n, r)
+        for b in batches:
+            o.process(b, threads=threads)
+        return o.rows()
+    a, b = rows(bs, 3), rows(got, 1)
+    assert len(a) > 5000 and (a == b).all()
+    assert [names[t] for t in dict.fromkeys(a["tid"].tolist())] == ["chr1", "chr10", "chr2", "chrX"]
+
+
 def _raw_batch(lengths):
     """Reads of the given lengths built straight into the flattened layout (random bases, one `N+m?` call each)."""
     rng = np.random.default_rng(5)
