@@ -20,7 +20,21 @@ four kernels, not just the largest one: the conservative reading); algorithmic b
 with n_lookups / n_updates tallied by the kernel itself in an untimed pass.
 `cpu_baseline` = the oracle (oracle/freq_oracle.c, a bit-exact CPU restatement of the reference's algorithm: the
 reference binary itself needs htslib, which this image lacks) on a bounded sample of the same batches, kind "port".
+
+At N=1 the line also carries the END-TO-END leg: the same reads written as a real BGZF BAM +
+FASTA, `minimod_amd/bin/minimod freq -b -c m[CG] -m 0.8 -K 4096 -B 200M -t <cores>` run as a child process BEFORE this
+process touches the GPU (`end_to_end`: wall, Mbases/s, the CLI's stage timers), and beside it the CPU path end to end
+(`cpu_baseline_e2e`: oracle/freq_cpu_main.c = the oracle behind the same reader and formatter, `-t <cores>` on the same
+file and `-t 1` on a bounded sample), with the two bedmethyl outputs compared byte for byte.
+
+`--config C3` (HiFi-shape reads, `-c m[CG],h[CG] -m 0.8,0.7`) and `--config C5` (`--haplotypes --insertions`, 200x on a
+5 Mb region) run the other BASELINE.json workloads through the same steps; extra measurements, not the driver's line.
 """
+import hashlib
+import re
+import shutil
+import subprocess
+import tempfile
 import argparse
 import json
 import os
@@ -54,7 +68,16 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1, help="1: every launch on one explicit stream; >1: the library's per-slot streams (up to 4 batches overlap)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra overlapped-streams measurement (use when profiling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
-    ap.add_argument("--natural-order", action="store_true", help="do not process longest reads first")
+    ap.add_argument("--host-plan", action="store_true", help="experiment: hand the library a host-made plan (mm_freq_plan_batch) "
+                                                           "uploaded before the timed region instead of planning on the device inside it")
+    ap.add_argument("--coalesce", type=int, default=8, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
+                                                             "one launch (1 = every step is its own launch)")
+    ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
+    ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"], help="BASELINE.json workload: C2 = the headline (default)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
+    ap.add_argument("--cpu-t1-batches", type=int, default=2, help="batches in the BAM the `-t 1` CPU run reads")
     ap.add_argument("--mode", default="freq", choices=["freq", "view"],
                     help="freq = the headline metric (default); view = the same batches through `minimod view` (SURVEY.md 8f row 1), "
                          "rows ordered and left in HBM; an extra measurement, not the driver's contract line")
@@ -102,13 +125,27 @@ def gen_reference(plan, seed):
     return ref
 
 
-def gen_batch(ref, plan, rank, seed, reads, batch, bi, max_len=0.0):
+# The BASELINE.json workloads this file can run.  `gen` = synthetic-read options, `mods` = -c / -m, `eng` = engine options.
+WORKLOADS = {
+    "C2": dict(gen=dict(), mods=[("m", "CG", 0.8)], eng=dict(), cli=["-c", "m[CG]", "-m", "0.8"],
+               what="C2: %(reads)d ONT-shape reads (~15 kb) per GPU on a %(mb).1f Mb interval, -c m[CG] -m 0.8, -K %(batch)d, batches resident in HBM"),
+    "C3": dict(gen=dict(shape=1), mods=[("m", "CG", 0.8), ("h", "CG", 0.7)], eng=dict(), cli=["-c", "m[CG],h[CG]", "-m", "0.8,0.7"],
+               what="C3: %(reads)d PacBio-HiFi-shape reads (~15 kb, MM '?' flag) per GPU on a %(mb).1f Mb interval, -c m[CG],h[CG] -m 0.8,0.7, "
+                    "-K %(batch)d, batches resident in HBM"),
+    "C5": dict(gen=dict(haplotypes=True, long_insertions=True), mods=[("m", "CG", 0.8)], eng=dict(insertions=True, haplotypes=True),
+               cli=["-c", "m[CG]", "-m", "0.8", "--insertions", "--haplotypes"], region=5 << 20, reads=66000,
+               what="C5: %(reads)d ONT-shape reads = 200x on a %(mb).1f Mb region, HP tags, CpG-carrying insertions, -c m[CG] -m 0.8 "
+                    "--insertions --haplotypes, -K %(batch)d, batches resident in HBM"),
+}
+
+
+def gen_batch(ref, plan, rank, seed, reads, batch, bi, max_len=0.0, **gen):
     """Batch `bi` of a rank's synthetic reads (deterministic: tests regenerate it to check a --dump file)."""
     from minimod_amd import synth
     first = bi * batch
     n = min(batch, reads - first)
     return synth.batch(ref, first, n, seed=seed + 7919 * rank, contig_len=plan["contig_len"], n_reads_total=reads,
-                       region_begin=plan["read_begin"], region_len=plan["read_len"], max_len=max_len)
+                       region_begin=plan["read_begin"], region_len=plan["read_len"], max_len=max_len, with_order=False, **gen)
 
 
 def algorithmic_bytes(reads, lookups, updates):
@@ -118,13 +155,121 @@ def algorithmic_bytes(reads, lookups, updates):
                int(reads["mm_len"].sum()) + int(reads["ml_len"].sum()) + 2 * lookups + 16 * updates)
 
 
+def _stage_timers(stderr_text):
+    """The reference-format stage timers a CLI run prints at exit (src/freq_main.c:505-509) as a dict of seconds."""
+    out = {}
+    for key, pat in (("load", r"Data loading time: ([0-9.]+)"), ("process", r"Data processing time: ([0-9.]+)"),
+                     ("merge", r"Data merging time: ([0-9.]+)"), ("sort", r"Data sorting time: ([0-9.]+)"),
+                     ("output", r"Data output time: ([0-9.]+)"), ("reference", r"Reference genome loaded in ([0-9.]+)"),
+                     ("reference", r"Reference loading time: ([0-9.]+)"), ("contexts", r"Reference contexts loaded in ([0-9.]+)"),
+                     ("contexts", r"Reference contexts time: ([0-9.]+)")):
+        m = re.search(pat, stderr_text)
+        if m:
+            out[key] = float(m.group(1))
+    return out
+
+
+def run_end_to_end(args, wl, host_batches, plan, ref):
+    """The END-TO-END leg: the workload's reads as a BGZF BAM + FASTA, through the product CLI (GPU) and through the CPU
+    path (oracle behind the same reader and formatter), every run a child process.  Called before this process initialises
+    the GPU.  Returns (end_to_end, cpu_baseline_e2e)."""
+    from minimod_amd import synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = args.e2e_threads if args.e2e_threads > 0 else min(cores, 128)
+    cli = os.path.join(ROOT, "minimod_amd", "bin", "minimod")
+    cpu_cli = O.build_cpu_cli()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (8 << 30) else None
+    tmp = tempfile.mkdtemp(prefix="mm_e2e_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        bam, bam1, fa = os.path.join(tmp, "reads.bam"), os.path.join(tmp, "reads_t1.bam"), os.path.join(tmp, "ref.fa")
+        contigs = [("chrS", plan["contig_len"])]
+        synth.write_bam_parallel(bam, contigs, host_batches, filter_fodder=True, threads=min(32, cores))
+        n1 = max(1, min(args.cpu_t1_batches, len(host_batches)))
+        synth.write_bam_parallel(bam1, contigs, host_batches[:n1], filter_fodder=True, threads=min(32, cores))
+        synth.write_fasta(fa, "chrS", ref)
+        t_write = time.perf_counter() - t0
+        bases = int(sum(hb["n_bases"] for hb in host_batches))
+        reads = int(sum(len(hb["reads"]) for hb in host_batches))
+        bases1 = int(sum(hb["n_bases"] for hb in host_batches[:n1]))
+        common = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M"]
+
+        def run(cmd, out_path):
+            t = time.perf_counter()
+            r = subprocess.run(cmd + ["-o", out_path, fa] + [cmd_bam[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.perf_counter() - t
+            if r.returncode != 0:
+                raise SystemExit("end-to-end run failed: %s\n%s" % (" ".join(cmd), r.stderr.decode(errors="replace")[-2000:]))
+            return wall, r.stderr.decode(errors="replace")
+
+        def digest(path):
+            h = hashlib.md5()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            return h.hexdigest(), os.path.getsize(path)
+        cmd_bam = [bam]
+        out_gpu, out_cpu, out_cpu1 = os.path.join(tmp, "gpu.bed"), os.path.join(tmp, "cpu.bed"), os.path.join(tmp, "cpu1.bed")
+        gpu_cmd = [cli, "freq"] + common + ["-t", str(threads)]
+        walls = []
+        for _ in range(2):      # the first run also pages the file in and brings the HIP runtime up cold
+            w, err_gpu = run(gpu_cmd, out_gpu)
+            walls.append(w)
+        cpu_cmd = [cpu_cli] + common + ["-t", str(threads)]
+        w_cpu, err_cpu = run(cpu_cmd, out_cpu)
+        cmd_bam = [bam1]
+        w_cpu1, err_cpu1 = run([cpu_cli] + common + ["-t", "1"], out_cpu1)
+        (md_g, sz_g), (md_c, sz_c) = digest(out_gpu), digest(out_cpu)
+        e2e = {"value": bases / min(walls) / 1e6, "unit": "Mbases/s", "wall_s": min(walls), "wall_s_first_run": walls[0], "bases": bases,
+               "reads": reads, "threads": threads, "cmd": "minimod freq " + " ".join(common + ["-t", str(threads)]) + " ref.fa reads.bam",
+               "what": "whole child process: start, HIP initialisation, FASTA load + context kernel, BGZF/BAM decode of a %d MB file with "
+                       "filter fodder, batches through host memory, finalize, %d MB of bedmethyl written" % (os.path.getsize(bam) >> 20, sz_g >> 20),
+               "stages_s": _stage_timers(err_gpu), "bam_bytes": os.path.getsize(bam), "input_build_s": t_write,
+               "parity_vs_cpu": {"byte_identical": md_g == md_c and sz_g == sz_c, "bytes": sz_g, "md5": md_g}}
+        cpu = {"kind": "port", "unit": "Mbases/s", "cores": cores,
+               "t_all": {"value": bases / w_cpu / 1e6, "wall_s": w_cpu, "threads": threads, "bases": bases, "stages_s": _stage_timers(err_cpu),
+                         "cmd": "oracle/_build/freq_cpu " + " ".join(common + ["-t", str(threads)]) + " ref.fa reads.bam"},
+               "t_1": {"value": bases1 / w_cpu1 / 1e6, "wall_s": w_cpu1, "threads": 1, "bases": bases1, "stages_s": _stage_timers(err_cpu1),
+                       "sample": "first %d of %d -K %d batches as their own BAM" % (n1, len(host_batches), args.batch)},
+               "what": "oracle/freq_cpu_main.c: the oracle (bit-exact CPU restatement) behind the same BGZF/BAM reader, -K/-B batching and "
+                       "row formatter as the product CLI, load(N+1) overlapping process(N) like the reference's pipeline"}
+        return e2e, cpu
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
+    wl = WORKLOADS[args.config]
+    if args.config == "C5" and args.reads == 100000:
+        args.reads = wl["reads"]
+    import torch                      # importing torch does not initialise the GPU
     import torch.distributed as dist
+
+    import minimod_amd
+    from minimod_amd import engine, synth
+
+    plan = shard_plan(rank, world, wl.get("region", INTERVAL), HALO)
+    t0 = time.time()
+    ref = gen_reference(plan, args.seed)
+    n_batches = (args.reads + args.batch - 1) // args.batch
+
+    def gen(bi):
+        return gen_batch(ref, plan, rank, args.seed, args.reads, args.batch, bi, args.max_len, **wl["gen"])
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        host_batches = list(ex.map(gen, range(n_batches)))
+    t_gen = time.time() - t0
+
+    # ---- the end-to-end leg runs in child processes, before this process has touched the GPU
+    e2e = cpu_e2e = None
+    if world == 1 and args.mode == "freq" and not args.no_e2e:
+        e2e, cpu_e2e = run_end_to_end(args, wl, host_batches, plan, ref)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.backend != "nccl":
@@ -138,45 +283,37 @@ def main():
             dist.init_process_group(backend=args.backend)
     host_staged = world > 1 and args.backend != "nccl"   # gloo moves CPU tensors
 
-    import minimod_amd
-    from minimod_amd import engine, synth
-
-    plan = shard_plan(rank, world)
-    t0 = time.time()
-    ref = gen_reference(plan, args.seed)
-    n_batches = (args.reads + args.batch - 1) // args.batch
-
-    def gen(bi):
-        return gen_batch(ref, plan, rank, args.seed, args.reads, args.batch, bi, args.max_len)
-
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        host_batches = list(ex.map(gen, range(n_batches)))
-    t_gen = time.time() - t0
-
+    contig = [("chrS", plan["contig_len"], ref)]
     if args.mode == "view":
-        eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank, view=True)
+        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, view=True, **wl["eng"])
     else:
-        eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank,
-                                     intervals=[(0, plan["begin"], plan["end"], plan["halo"])])
-    # ---- make the batches resident in HBM (torch owns the memory: plumbing only)
-    dev_batches = []
-    keep = []
+        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, intervals=[(0, plan["begin"], plan["end"], plan["halo"])],
+                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce,
+                                     **wl["eng"])
+    # ---- make the reads resident in HBM (torch owns the memory: plumbing only): ONE read set -- the pools of all batches
+    # end to end, as a decoder writing into device memory would leave them -- and a step's batch is a window of -K reads of
+    # it (the same pool pointers, `reads` advanced).  Consecutive windows are what mm_freq_opts_t.coalesce may gather.
+    whole = synth.concat(host_batches)
+    keep, base = [], {}
+    for k in ("reads", "cigar", "seq", "mm", "ml"):
+        t = torch.from_numpy(whole[k].view(np.uint8).reshape(-1)).to(dev)
+        keep.append(t)
+        base[k] = t.data_ptr()
+    dev_batches, first = [], 0
     for hb in host_batches:
-        d = {}
-        for k in ("reads", "cigar", "seq", "mm", "ml"):
-            t = torch.from_numpy(hb[k].view(np.uint8).reshape(-1)).to(dev)
-            keep.append(t)
-            d[k] = t.data_ptr()
-        if not args.natural_order:
+        n = len(hb["reads"])
+        d = dict(reads=base["reads"] + 64 * first, cigar=base["cigar"], seq=base["seq"], mm=base["mm"], ml=base["ml"],
+                 n_reads=n, n_cigar_words=len(whole["cigar"]), n_seq_bytes=len(whole["seq"]), n_mm_bytes=len(whole["mm"]),
+                 n_ml_bytes=len(whole["ml"]), max_n_cigar=hb["max_n_cigar"], max_l_qseq=hb["max_l_qseq"])
+        if args.host_plan:
             items = engine.plan_batch(hb["reads"])
             t = torch.from_numpy(items.view(np.uint8).reshape(-1)).to(dev)
             keep.append(t)
             d["order"] = t.data_ptr()
             d["n_order"] = len(items)
-        d.update(n_reads=len(hb["reads"]), n_cigar_words=len(hb["cigar"]), n_seq_bytes=len(hb["seq"]),
-                 n_mm_bytes=len(hb["mm"]), n_ml_bytes=len(hb["ml"]), max_n_cigar=hb["max_n_cigar"],
-                 max_l_qseq=hb["max_l_qseq"])
         dev_batches.append(d)
+        first += n
+    del whole
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)   # one explicit HIP stream carries every K1 launch
     stream = tstream.cuda_stream
@@ -187,36 +324,47 @@ def main():
 
     # ---- untimed tally pass: lookups/updates per batch for the algorithmic-bytes figure
     eng.stats_enable(True)
-    alg_bytes = []
+    alg_bytes, side_per_pass = [], 0
     for hb, db in zip(host_batches, dev_batches):
         eng.wait(eng.submit_device(db, stream))
         st = eng.stats_get()
+        side_per_pass += st["side_updates"]
         alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], st["dense_updates"] + st["side_updates"]))
     eng.stats_enable(False)
     eng.reset()
+    # the side list (calls inside insertions: --insertions only) grows with every step and is only emptied by reset()
+    side_cap = 96 << 20
+    if side_per_pass * ((args.steps + n_batches - 1) // n_batches + 1) > side_cap:
+        raise SystemExit("--config %s: %d side-list records per pass over the batches: too many steps for a list of %d"
+                         % (args.config, side_per_pass, side_cap))
 
     def run_steps(n, first_step=0, use_stream=stream):
-        tickets, bases, kms, abytes = [], 0, [], 0
+        """n steps = n -K windows submitted in order; returns bases, device time per LAUNCH (a launch carries one window, or
+        up to --coalesce consecutive ones: submits of one group return the same ticket), algorithmic bytes."""
+        groups, bases, kms, abytes = [], 0, [], 0
+
+        def retire(g):
+            eng.wait(g[0])
+            kms.append(eng.kernel_ms(g[0]))
         for s in range(n):
             bi = (first_step + s) % n_batches
             t = eng.submit_device(dev_batches[bi], use_stream)
-            tickets.append((t, bi))
+            if groups and groups[-1][0] == t:
+                groups[-1][1] += 1
+            else:
+                groups.append([t, 1])
             bases += batch_bases[bi]
             abytes += alg_bytes[bi]
-            if len(tickets) >= 3:   # the library has 4 slots; keep the host a few launches ahead of the device
-                tk, _ = tickets.pop(0)
-                eng.wait(tk)
-                kms.append(eng.kernel_ms(tk))
-        for tk, _ in tickets:
-            eng.wait(tk)
-            kms.append(eng.kernel_ms(tk))
+            if len(groups) > 3:   # the library has 4 slots; keep the host a few launches ahead of the device
+                retire(groups.pop(0))
+        for g in groups:
+            retire(g)
         return bases, kms, abytes
 
     # ---- warm-up, then the timed region: barrier + sync on both sides, max over ranks
     run_steps(args.warmup)
     eng.reset()
     slab_words = eng.slab_words(HALO)
-
     def make_buf():
         return torch.empty(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
 
@@ -270,6 +418,8 @@ def main():
     # batches in flight as the CLI's load/process overlap gives (kernels of consecutive batches overlap on the device)
     overlap = None
     if world == 1 and args.streams <= 1 and not args.no_extra:
+        if side_per_pass:
+            eng.reset()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ob, _, _ = run_steps(args.steps, first_step=args.warmup, use_stream=None)
@@ -280,30 +430,37 @@ def main():
     result = None
     if rank == 0:
         mean_ms = float(np.mean(kms))
-        achieved = (abytes / len(kms)) / (mean_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_k1.json")
+        achieved = abytes / (float(np.sum(kms)) * 1e-3) / 1e9
+        # HBM traffic per batch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) of this same command, which cannot
+        # run inside it: the figure is read from the committed profile and labelled as such
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config.lower())
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; not measured in this run)" % os.path.basename(tpath)
             except Exception:
                 traffic = None
+        reads_all = np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches])
         result = {
             "metric": "minimod freq Mbases/sec", "value": total_bases / elapsed / 1e6, "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "C2: %d ONT-shape reads (~15 kb) per GPU on a %.1f Mb interval, -c m[CG] -m 0.8, -K %d, "
-                                   "batches resident in HBM" % (args.reads, INTERVAL / 1e6, args.batch),
-                       "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(
-                           np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches]))),
+            "config": {"workload": wl["what"] % dict(reads=args.reads, mb=wl.get("region", INTERVAL) / 1e6, batch=args.batch),
+                       "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(reads_all)),
                        "sharding": "interval per GPU + halo slab to the right neighbour" if world > 1 else "single GPU",
-                       "read_order": "natural, unsplit" if args.natural_order else "mm_freq_plan_batch (long reads split, costliest first)"},
+                       "read_order": "caller's plan (mm_freq_plan_batch on the host, uploaded before the timed region)" if args.host_plan else
+                                     "planned on the device inside every step (k_plan_items: long reads cut into parts, costliest first)",
+                       "coalesce": "up to %d consecutive -K windows of the resident read set per launch (mm_freq_opts_t.coalesce)" % args.coalesce
+                                   if args.coalesce > 1 and not args.host_plan else "off: one launch per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "freq hot path per batch = k_scan_reads + k_sum_tiles + k_call_tiles (+ k_freq_reads on the fallback list), HIP events around the four launches",
-                         "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms),
-                         "bytes_per_base": abytes / max(bases, 1)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "freq hot path per batch = k_plan_items + k_scan_reads + k_sum_tiles + k_call_tiles (+ k_freq_reads on the "
+                                   "fallback list), HIP events around the launches on their stream",
+                         "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms), "launches": len(kms),
+                         "batches_per_launch": args.steps / len(kms), "kernel_ms_per_batch": float(np.sum(kms)) / args.steps,
+                         "bytes_per_base": abytes / max(bases, 1), "side_list_updates_per_pass": side_per_pass},
             "gen_seconds": t_gen,
         }
         if world > 1:
@@ -314,9 +471,12 @@ def main():
         if overlap:
             result["overlapped_streams"] = overlap
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, host_batches, plan, ref)
+            result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, ref)
+        if e2e:
+            result["end_to_end"] = e2e
+            result["cpu_baseline_e2e"] = cpu_e2e
         if args.dump:
-            chk = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plan["contig_len"], ref)], device=local_rank)
+            chk = minimod_amd.FreqEngine(wl["mods"], [("chrS", plan["contig_len"], ref)], device=local_rank, **wl["eng"])
             for hb in host_batches[:2]:
                 chk.process(hb)
             np.savez(args.dump, rows=chk.finalize())
@@ -424,11 +584,11 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
     return result
 
 
-def cpu_baseline(args, host_batches, plan, ref):
+def cpu_baseline(args, wl, host_batches, plan, ref):
     """The oracle (bit-exact CPU restatement) timed on this host's cores over a bounded sample of the same batches."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc = O.Oracle([(c, x) for c, x, _ in wl["mods"]], [t for _, _, t in wl["mods"]], ["chrS"], **wl["eng"])
     orc.add_contig("chrS", ref)
     n = args.cpu_sample_batches
     t0 = time.perf_counter()

@@ -104,6 +104,9 @@ typedef struct mm_freq_opts {
     int32_t force_fused;     /* 1: every read through the fused one-wavefront-per-read kernel instead of the tile pipeline */
     int32_t view_cap;        /* view: records per append region before the grow-and-rerun path (0 = sized from the ML pool) */
     int32_t finalize_by_runs;/* 1: mm_freq_finalize takes the per-run compaction + host merge even when all rows are dense */
+    int32_t split_bases;     /* device planning: reads longer than this are cut into parts of about this many bases (0 = default) */
+    int32_t coalesce;        /* mm_freq_submit_device: up to this many consecutive windows of one resident read set share one launch
+                              * (see there); 0 or 1 = every submit is its own launch */
     int32_t rsvd;
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
@@ -177,8 +180,18 @@ int32_t mm_freq_submit(mm_freq_t *h, const mm_batch_t *host_batch);
 /* Process one batch already RESIDENT in device memory (all mm_batch_t pointers are device pointers) on the given
  * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*.  The batch
  * must stay resident until mm_freq_wait(ticket) has returned: reads the tile kernels do not cover (more than four
- * codes in an MM group, groups on different canonical bases) are processed when the host waits for the batch. */
+ * codes in an MM group, groups on different canonical bases) are processed when the host waits for the batch.
+ *
+ * Coalescing (opts.coalesce > 1, freq mode): a -K batch of 4096 reads fills a quarter of an MI355X, so consecutive
+ * submits that are WINDOWS of one resident read set -- the same four pool pointers and sizes, `reads` continuing where
+ * the previous submit's reads ended, no caller's plan, the same stream -- are gathered and launched together, up to
+ * opts.coalesce of them, as one batch.  The gathered submits return the SAME ticket; the launch is made when the group
+ * is full, when something waits for the ticket, or when any call needs the counters (finalize, reset, slabs, a submit
+ * that does not continue the group).  A per-read error of a group is reported with the read's index counted from the
+ * group's first read. */
 int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *hip_stream);
+/* submits that went into the ticket's launch (1 without coalescing) */
+int32_t mm_freq_ticket_batches(mm_freq_t *h, int32_t ticket);
 
 /* Wait for a ticket.  Returns 0, or the first failing read's MM_E_* code with its batch index in *bad_read. */
 int32_t mm_freq_wait(mm_freq_t *h, int32_t ticket, int32_t *bad_read);

@@ -60,9 +60,10 @@ struct Slot {
     uint32_t* d_gtok = nullptr; size_t cap_gtok = 0;
     TileRec* d_tiles = nullptr; size_t cap_tiles = 0;
     int32_t* d_fb = nullptr; size_t cap_fb = 0;
+    int32_t* d_plan = nullptr; size_t cap_plan = 0;                        // work items planned on the device (k_plan_items)
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
-    std::vector<int32_t> plan;   // host copy of the work items while the upload is in flight
+    int32_t members = 1;         // submits gathered into the slot's launch
     // view mode: regional record buffers filled by the call kernels, then the ordering pipeline's buffers
     unsigned long long* d_vkeys = nullptr; size_t cap_vkeys = 0;
     unsigned long long* d_vvals = nullptr; size_t cap_vvals = 0;
@@ -121,6 +122,10 @@ struct mm_freq {
     // an error of a batch whose ticket was never waited for (its slot was recycled), or of a deferred launch that failed:
     // reported by the next submit / wait / finalize instead of being lost
     int sticky_err = 0, sticky_read = -1;
+    // a group of consecutive windows of one resident read set, gathered but not launched yet (opts.coalesce)
+    int pending_slot = -1, pending_members = 0;
+    mm_batch_t pending_batch;
+    hipStream_t pending_stream = nullptr;
     // finalize scratch
     uint32_t* d_tile_counts = nullptr; unsigned long long* d_tile_offsets = nullptr; size_t cap_tiles = 0;
     DenseRow* d_rows = nullptr; size_t cap_rows = 0;
@@ -291,6 +296,17 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
         if (h->use_tiles) {
+            if (!b->order) {
+                // no plan from the caller: the work items are made on the device (long reads cut into parts, costliest
+                // first), their number stays in device memory (control word 6)
+                const uint32_t split = h->opts.split_bases >= 1024 ? (uint32_t)h->opts.split_bases : kSplitBases;
+                const size_t max_items = (size_t)b->n_reads + 2 * (size_t)b->n_seq_bytes / split + 64;
+                if ((r = grow(h, (void**)&s.d_plan, &s.cap_plan, 4 * max_items))) return r;
+                hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6);
+                p.order = s.d_plan;
+                p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
+                tp.plan_count = ctl + 6;
+            }
             tp.d = p;
             int ga = std::min((3 * p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->scan_blocks_per_cu);
             int gc = h->n_cu * h->call_blocks_per_cu;
@@ -339,7 +355,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipMemcpyAsync(s.h_vcount, s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipMemcpyDeviceToHost, st));
     if (h->opts.view) { HIPCHK(hipEventRecord(s.ev_done, st)); s.ev_wait = s.ev_done; }
     else s.ev_wait = s.ev_stop;   // nothing follows the kernels: one event less per batch
-    s.busy = true; s.timed = true; s.n_reads = b->n_reads;
+    s.busy = true; s.timed = true; s.n_reads = b->n_reads; s.members = 1;
     s.last_batch = *b; s.last_stream = st; s.view_rows = -1; s.view_on_host = false;
     return 0;
 }
@@ -374,7 +390,9 @@ int finish_deferred(mm_freq* h, Slot& s) {
 
 // batches that were never waited for may still owe their fallback list (slab functions run on a caller's stream and do not
 // synchronise the device; this only blocks when such a batch exists)
+int flush_pending(mm_freq* h);
 int settle(mm_freq* h) {
+    { int rf = flush_pending(h); if (rf) return rf; }
     for (auto& s : h->slots) {
         if (!s.fb_deferred) continue;
         HIPCHK(hipEventSynchronize(s.ev_wait));
@@ -386,8 +404,21 @@ int settle(mm_freq* h) {
 
 int slot_status(mm_freq* h, Slot& s, int32_t* bad_read);
 
+// launch the gathered group, if there is one
+int flush_pending(mm_freq* h) {
+    if (h->pending_slot < 0) return 0;
+    Slot& s = h->slots[h->pending_slot];
+    const int members = h->pending_members;
+    h->pending_slot = -1; h->pending_members = 0;
+    int r = launch_k1(h, s, &h->pending_batch, h->pending_stream);
+    s.members = members;
+    if (r) { s.busy = false; if (!h->sticky_err) h->sticky_err = -r; }
+    return r;
+}
+
 // every batch submitted so far is complete, fallback lists included (before counters are read or changed)
 int drain(mm_freq* h) {
+    { int rf = flush_pending(h); if (rf) return rf; }
     HIPCHK(hipDeviceSynchronize());
     for (auto& s : h->slots) {
         int r = finish_deferred(h, s);
@@ -467,6 +498,7 @@ const char* mm_strerror(int32_t code) {
 void mm_freq_destroy(mm_freq_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)flush_pending(h);
     (void)hipDeviceSynchronize();
     for (auto& s : h->slots) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -475,6 +507,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
+                      s.d_plan,
                       s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);
@@ -739,6 +772,23 @@ const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    const bool gather = h->opts.coalesce > 1 && !h->opts.view && h->use_tiles && !b->order && b->n_reads > 0;
+    if (gather && h->pending_slot >= 0) {
+        // does this submit continue the gathered group?  (windows of one resident read set, one after the other)
+        const mm_batch_t& g = h->pending_batch;
+        hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->slots[h->pending_slot].stream;
+        if (b->cigar == g.cigar && b->seq == g.seq && b->mm == g.mm && b->ml == g.ml && b->reads == g.reads + g.n_reads &&
+            b->n_cigar_words == g.n_cigar_words && b->n_seq_bytes == g.n_seq_bytes && b->n_mm_bytes == g.n_mm_bytes &&
+            b->n_ml_bytes == g.n_ml_bytes && st == h->pending_stream && (int64_t)g.n_reads + b->n_reads < (1 << 24)) {
+            h->pending_batch.n_reads += b->n_reads;
+            h->pending_batch.max_n_cigar = std::max(g.max_n_cigar, b->max_n_cigar);
+            h->pending_batch.max_l_qseq = std::max(g.max_l_qseq, b->max_l_qseq);
+            const int si = h->pending_slot;
+            if (++h->pending_members >= h->opts.coalesce) { int r = flush_pending(h); if (r) return r; }
+            return si;
+        }
+    }
+    { int r = flush_pending(h); if (r) return r; }
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
@@ -746,13 +796,25 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     // all slots of the handle share the code table; make sure it is current (sync only when it changed)
     int r = upload_codes(h, st);
     if (r) return r;
+    if (gather) {   // the first window of a group: launched when the group is full or somebody needs it
+        h->pending_slot = si; h->pending_members = 1; h->pending_batch = *b; h->pending_stream = st;
+        s.busy = true; s.timed = false; s.members = 1;
+        return si;
+    }
     r = launch_k1(h, s, b, st);
+    s.members = 1;
     return r ? r : si;
+}
+
+int32_t mm_freq_ticket_batches(mm_freq_t* h, int32_t ticket) {
+    if (!h || ticket < 0 || ticket >= kSlots) return -MM_E_ARG;
+    return ticket == h->pending_slot ? h->pending_members : h->slots[ticket].members;
 }
 
 int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int rf = flush_pending(h); if (rf) return rf; }
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
@@ -772,21 +834,12 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (hb->n_ml_bytes) HIPCHK(hipMemcpyAsync(s.d_ml, hb->ml, hb->n_ml_bytes, hipMemcpyHostToDevice, st));
     db.reads = (const mm_read_t*)s.d_reads; db.cigar = (const uint32_t*)s.d_cigar; db.seq = (const uint8_t*)s.d_seq;
     db.mm = (const uint8_t*)s.d_mm; db.ml = (const uint8_t*)s.d_ml; db.order = nullptr;
-    if (hb->n_reads) {
-        // work items: the caller's plan, or our own (long reads split into parts, costliest first)
-        const int32_t* items = hb->order;
-        int32_t n_items = hb->n_order;
-        std::vector<int32_t>& plan = s.plan;
-        if (!items) {
-            plan.resize((size_t)hb->n_reads * 16);
-            n_items = mm_freq_plan_batch(hb->reads, hb->n_reads, plan.data(), (int32_t)plan.size());
-            if (n_items < 0) return n_items;
-            items = plan.data();
-        }
-        if ((r = grow(h, &s.d_order, &s.cap_order, sizeof(int32_t) * (size_t)n_items))) return r;
-        HIPCHK(hipMemcpyAsync(s.d_order, items, sizeof(int32_t) * (size_t)n_items, hipMemcpyHostToDevice, st));
+    if (hb->n_reads && hb->order) {
+        // the caller's work items go along with the batch (without a plan the items are made on the device, k_plan_items)
+        if ((r = grow(h, &s.d_order, &s.cap_order, sizeof(int32_t) * (size_t)hb->n_order))) return r;
+        HIPCHK(hipMemcpyAsync(s.d_order, hb->order, sizeof(int32_t) * (size_t)hb->n_order, hipMemcpyHostToDevice, st));
         db.order = (const int32_t*)s.d_order;
-        db.n_order = n_items;
+        db.n_order = hb->n_order;
     }
     r = launch_k1(h, s, &db, st);
     return r ? r : si;
@@ -795,9 +848,10 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
 int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (!h || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
     Slot& s = h->slots[ticket];
+    if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
+    if (ticket == h->pending_slot) (void)flush_pending(h);   // a failed launch is the sticky error reported next
     if (h->sticky_err) { if (bad_read) *bad_read = h->sticky_read; return h->sticky_err; }
     if (!s.busy) return MM_OK;
-    if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
     if (finish_deferred(h, s) < 0) return MM_E_HIP;

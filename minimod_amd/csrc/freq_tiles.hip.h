@@ -67,7 +67,13 @@ struct TileParams {
     unsigned int* host_fb_flag;  // pinned host word: set when a read went on the fallback list (the host then runs the fused
                                  // kernel for it when it waits for the batch; otherwise that launch is saved)
     int32_t reset_in_call;       // 1: k_call_tiles is the launch's last kernel and resets the next launch's control words
+    // work items planned on the device (k_plan_items): d.order points at them, their number is read from *plan_count
+    const unsigned int* plan_count;   // null: the caller's plan (d.n_items entries)
 };
+constexpr uint32_t kPartSlots = 16;                       // parts per read (4 bits in a work item)
+constexpr int kPlanBuckets = 4096;                        // cost buckets of 256 bases
+constexpr uint32_t kSplitBases = 24576;                   // default: a read longer than this is cut into parts of about this many bases
+                                                          // (measured on C2: 8192 479, 16384 507, 24576 519, 49152 517, 131072 456 Gbases/s)
 
 // g_sum between k_scan_reads and k_sum_tiles: x = offset of the tile's first character in the MM pool, y = these bits |
 // n_codes << 16 | characters left in the read's MM string from there (capped at 511)
@@ -170,6 +176,67 @@ __device__ __forceinline__ uint32_t window32(uint64_t lo, uint64_t hi, int lane)
     return __builtin_amdgcn_alignbit(b, a, (uint32_t)lane & 31u);
 }
 __device__ __forceinline__ uint64_t low_bits(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+
+// ------------------------------------------------------------------------------------------------ plan
+// Work items for k_scan_reads, costliest first (mm_freq_plan_batch on the device): read index | part << 24 |
+// (parts - 1) << 28, long reads cut into up to kPartSlots parts of about `split` bases.  One workgroup: a counting sort
+// over cost buckets of 256 bases per part (histogram and cursors in LDS).  The order inside a bucket is whatever the LDS
+// atomics give: results do not depend on it (counters add up; view rows are ordered per read afterwards).
+__device__ __forceinline__ uint32_t plan_parts(uint32_t L, uint32_t split) {
+    uint32_t w = (L + split - 1u) / split;
+    return w < 1u ? 1u : (w > kPartSlots ? kPartSlots : w);
+}
+__device__ __forceinline__ uint32_t plan_bucket(uint32_t L, uint32_t w) {
+    uint32_t k = (L / w) >> 8;
+    if (k >= (uint32_t)kPlanBuckets) k = kPlanBuckets - 1;
+    return (uint32_t)(kPlanBuckets - 1) - k;
+}
+__global__ __launch_bounds__(1024) void k_plan_items(const mm_read_t* __restrict__ reads, int n, uint32_t split, int32_t* __restrict__ items,
+                                                     unsigned int* __restrict__ n_items_out) {
+    __shared__ uint32_t hist[kPlanBuckets];
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x;
+    for (int b = t; b < kPlanBuckets; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    // eight reads per thread and trip: the record loads (64 bytes apart) are all in flight before the first LDS atomic
+    for (int i0 = 0; i0 < n; i0 += 8192) {
+        uint32_t L[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + 1024 * u + t; L[u] = i < n ? reads[i].l_qseq : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 1024 * u + t;
+            if (i < n) { const uint32_t w = plan_parts(L[u], split); atomicAdd(&hist[plan_bucket(L[u], w)], w); }
+        }
+    }
+    __syncthreads();
+    // exclusive scan over the buckets: four per thread, wave scan, then the 16 wave totals
+    uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    const uint32_t mine = h0 + h1 + h2 + h3;
+    const uint32_t incl = wave_incl_scan(mine);
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < (t >> 6); w++) before += wsum[w];
+    hist[4 * t] = before; hist[4 * t + 1] = before + h0; hist[4 * t + 2] = before + h0 + h1; hist[4 * t + 3] = before + h0 + h1 + h2;
+    if (t == 1023) *n_items_out = before + mine;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8192) {
+        uint32_t L[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + 1024 * u + t; L[u] = i < n ? reads[i].l_qseq : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 1024 * u + t;
+            if (i < n) {
+                const uint32_t w = plan_parts(L[u], split);
+                const uint32_t at = atomicAdd(&hist[plan_bucket(L[u], w)], w);
+                for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ KA
 struct GroupHdr {
@@ -349,7 +416,9 @@ struct KA {
                         // cross no multiple or one (written by their own lane); the few long ones (soft clips, long
                         // matches) are filled by the whole wave so that one lane never loops alone.
                         uint32_t k_lo = (qs + 255u) >> 8, k_hi = (act && qinc) ? (qs + qinc - 1u) >> 8 : 0u;
-                        bool any = act && qinc && k_lo <= k_hi;
+                        const uint32_t k_max = (L - 1u) >> 8;   // the read's share of g_qdir ends here (a CIGAR longer than the sequence is an error, not a reason to write past it)
+                        k_hi = k_hi < k_max ? k_hi : k_max;
+                        bool any = act && qinc && L > 0u && k_lo <= k_hi;
                         if (any) qdir[k_lo] = i;
                         uint64_t more = __ballot(any && k_hi > k_lo);
                         while (more) {
@@ -584,7 +653,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
     // remainder belongs to counter j % 64): the wave that drew the longest read then takes nothing else, and a single
     // shared counter would serialise ~12k dequeues.
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
-    const int n = p.n_items;
+    const int n = P.plan_count ? (int)scalar_load(P.plan_count) : p.n_items;
     const int g = uni((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));   // the wave's index, as a scalar
     const bool dynamic = n_waves >= (int)kTileRegions && P.scan_queue != nullptr;
     for (int r = g; r < 3 * n;) {

@@ -415,13 +415,20 @@ static int put_record(bgzf_w *w, const mm_batch_t *b, int32_t i, int variant, ui
     return 0;
 }
 
-typedef struct mm_bam_writer { bgzf_w w; uint64_t serial; } mm_bam_writer_t;
+typedef struct mm_bam_writer { bgzf_w w; uint64_t serial; int flags; } mm_bam_writer_t;
 
-mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens) {
+/* flags: MM_BAMW_NO_HEADER = a later piece of a file written in pieces (BGZF members concatenate), MM_BAMW_NO_EOF = a piece
+ * that is not the last; first_serial numbers the records (read names, filter fodder) as one writer would have */
+mm_bam_writer_t *mm_bam_writer_open_piece(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens,
+                                          int flags, uint64_t first_serial) {
     FILE *fp = fopen(path, "wb");
     if (!fp) return NULL;
     mm_bam_writer_t *bw = (mm_bam_writer_t *)calloc(1, sizeof(*bw));
+    if (!bw) { fclose(fp); return NULL; }
     bw->w.fp = fp; bw->w.buf = (uint8_t *)malloc(0x10000);
+    bw->flags = flags; bw->serial = first_serial;
+    if (!bw->w.buf) { fclose(fp); free(bw); return NULL; }
+    if (flags & MM_BAMW_NO_HEADER) return bw;
     char text[256];
     int lt = snprintf(text, sizeof text, "@HD\tVN:1.6\tSO:coordinate\n");
     bgzf_put(&bw->w, "BAM\1", 4);
@@ -433,6 +440,9 @@ mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const c
         bgzf_put(&bw->w, &ln, 4); bgzf_put(&bw->w, names[i], (size_t)ln); bgzf_put(&bw->w, &ll, 4);
     }
     return bw;
+}
+mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens) {
+    return mm_bam_writer_open_piece(path, n_contigs, names, lens, 0, 0);
 }
 int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_filter_fodder) {
     for (int32_t i = 0; i < b->n_reads; i++) {
@@ -449,7 +459,7 @@ int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_f
 int mm_bam_writer_close(mm_bam_writer_t *bw) {
     int r = 0;
     if (bw->w.n) r |= bgzf_flush_block(&bw->w, bw->w.buf, bw->w.n);
-    r |= bgzf_flush_block(&bw->w, bw->w.buf, 0);   /* the 28-byte EOF marker: an empty block */
+    if (!(bw->flags & MM_BAMW_NO_EOF)) r |= bgzf_flush_block(&bw->w, bw->w.buf, 0);   /* the 28-byte EOF marker: an empty block */
     r |= fclose(bw->w.fp);
     free(bw->w.buf); free(bw);
     return r;

@@ -44,7 +44,8 @@ class mm_freq_opts_t(ctypes.Structure):
                 ("haplotypes", ctypes.c_int32), ("device", ctypes.c_int32), ("n_hp_planes", ctypes.c_int32),
                 ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
                 ("force_fused", ctypes.c_int32), ("view_cap", ctypes.c_int32), ("finalize_by_runs", ctypes.c_int32),
-                ("rsvd", ctypes.c_int32), ("mods", mm_mod_t * MM_MAX_MODS)]
+                ("split_bases", ctypes.c_int32), ("coalesce", ctypes.c_int32), ("rsvd", ctypes.c_int32),
+                ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
 class mm_contig_t(ctypes.Structure):
@@ -57,7 +58,7 @@ class mm_interval_t(ctypes.Structure):
                 ("end", ctypes.c_int64), ("halo", ctypes.c_int64)]
 
 
-EXPORTS = ["mm_freq_plan_batch", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
+EXPORTS = ["mm_freq_plan_batch", "mm_freq_ticket_batches", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
            "mm_freq_wait", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
@@ -94,6 +95,8 @@ def load_library(build=True):
     L.mm_freq_submit.argtypes = [vp, ctypes.POINTER(mm_batch_t)]
     L.mm_freq_submit_device.restype = i32
     L.mm_freq_submit_device.argtypes = [vp, ctypes.POINTER(mm_batch_t), vp]
+    L.mm_freq_ticket_batches.restype = i32
+    L.mm_freq_ticket_batches.argtypes = [vp, i32]
     L.mm_freq_wait.restype = i32
     L.mm_freq_wait.argtypes = [vp, i32, ctypes.POINTER(i32)]
     for f in ("mm_view_fetch", "mm_view_fetch_device"):
@@ -190,7 +193,7 @@ class FreqEngine(object):
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
                  n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False, force_fused=False, view_cap=0,
-                 finalize_by_runs=False):
+                 finalize_by_runs=False, split_bases=0, coalesce=0):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -200,6 +203,7 @@ class FreqEngine(object):
         o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
         o.view = int(view)
         o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
+        o.split_bases, o.coalesce = int(split_bases), int(coalesce)
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
             o.mods[i].context = ctx.encode()
@@ -268,6 +272,10 @@ class FreqEngine(object):
         if t < 0:
             raise MinimodHipError(-t, "mm_freq_submit_device: " + self.L.mm_strerror(t).decode())
         return t
+
+    def ticket_batches(self, ticket):
+        """Submits gathered into the ticket's launch (mm_freq_opts_t.coalesce)."""
+        return int(self.L.mm_freq_ticket_batches(self.h, ticket))
 
     def wait(self, ticket):
         bad = ctypes.c_int32(-1)

@@ -38,6 +38,9 @@ def host_lib():
         L.mm_batch_make_order.argtypes = [ctypes.POINTER(mm_host_batch_t)]
         L.mm_bam_writer_open.restype = ctypes.c_void_p
         L.mm_bam_writer_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64)]
+        L.mm_bam_writer_open_piece.restype = ctypes.c_void_p
+        L.mm_bam_writer_open_piece.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64),
+                                               ctypes.c_int, ctypes.c_uint64]
         L.mm_bam_writer_put_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(mm_batch_t), ctypes.c_int]
         L.mm_bam_writer_close.argtypes = [ctypes.c_void_p]
         L.mm_write_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]
@@ -186,6 +189,43 @@ def write_bam(path, contigs, batches, filter_fodder=True):
             raise IOError("write failed")
     if L.mm_bam_writer_close(w):
         raise IOError("close failed")
+
+
+def write_bam_parallel(path, contigs, batches, filter_fodder=True, threads=8):
+    """write_bam with one piece per batch deflated on `threads` threads and the pieces concatenated: the same bytes as
+    write_bam would give when every batch ends its BGZF block (it does not: blocks run on across batches there), the same
+    RECORDS in any case."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    from .engine import batch_struct
+    L = host_lib()
+    names = (ctypes.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
+    lens = (ctypes.c_int64 * len(contigs))(*[int(l) for _, l in contigs])
+    firsts, acc = [], 0
+    for b in batches:
+        firsts.append(acc)
+        acc += len(b["reads"])
+    nb = len(batches)
+
+    def piece(i):
+        flags = (1 if i > 0 else 0) | (2 if i < nb - 1 else 0)
+        pp = "%s.piece%d" % (path, i)
+        w = L.mm_bam_writer_open_piece(pp.encode(), len(contigs), names, lens, flags, firsts[i])
+        if not w:
+            raise IOError("cannot create %s" % pp)
+        bs = batch_struct(batches[i])
+        if L.mm_bam_writer_put_batch(w, ctypes.byref(bs), int(filter_fodder)) or L.mm_bam_writer_close(w):
+            raise IOError("write failed")
+        return pp
+    if nb == 0:
+        return write_bam(path, contigs, batches, filter_fodder)
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        pieces = list(ex.map(piece, range(nb)))
+    with open(path, "wb") as out:
+        for pp in pieces:
+            with open(pp, "rb") as f:
+                shutil.copyfileobj(f, out, 1 << 24)
+            os.remove(pp)
 
 
 def write_fasta(path, name, seq):

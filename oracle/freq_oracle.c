@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- batch layout (same bytes as include/minimod_hip.h mm_read_t; declared independently) ---- */
 typedef struct {
@@ -94,6 +95,7 @@ typedef struct {
     int view;                 /* 1: collect view rows instead of counting */
     orc_view_row_t *vrows;
     int64_t n_vrows, cap_vrows, reads_seen;
+    double merge_seconds;     /* time spent folding per-thread tables into the global one (merge_freq_maps' share) */
 } orc_t;
 
 /* ------------------------------------------------------------------ counter table */
@@ -534,8 +536,10 @@ int orc_process(void *h, const orc_read_t *reads, int n, const uint32_t *cigar, 
         if (n_threads == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
     int err = 0;
+    if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int t = 0; t < n_threads; t++) {
-        if (n_threads > 1) pthread_join(th[t], NULL);
         if (jobs[t].err && !err) { err = jobs[t].err; o->err = err; o->err_read = jobs[t].err_read; }
         if (o->view) {
             for (int64_t k = 0; k < jobs[t].rows.n; k++) {
@@ -551,11 +555,14 @@ int orc_process(void *h, const orc_read_t *reads, int n, const uint32_t *cigar, 
             if (m->s[i].k1) map_add(&o->global, m->s[i].k0, m->s[i].k1, m->s[i].n_called, m->s[i].n_mod);
         free(m->s);
     }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    o->merge_seconds += (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
     free(jobs); free(th);
     o->reads_seen += n;
     return err;
 }
 
+double orc_merge_seconds(void *h) { return ((orc_t *)h)->merge_seconds; }
 void orc_set_view(void *h, int on) { ((orc_t *)h)->view = on; }
 int64_t orc_n_view_rows(void *h) { return ((orc_t *)h)->n_vrows; }
 void orc_view_rows(void *h, orc_view_row_t *out) { orc_t *o = (orc_t *)h; memcpy(out, o->vrows, sizeof(orc_view_row_t) * (size_t)o->n_vrows); }

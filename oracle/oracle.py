@@ -40,6 +40,24 @@ def build(force=False):
     return LIB
 
 
+CPU_BIN = os.path.join(BUILD, "freq_cpu")
+
+
+def build_cpu_cli(force=False):
+    """oracle/freq_cpu_main.c: `minimod freq` end to end on the CPU (the oracle behind the product's own readers and
+    formatter), for bench.py's cpu_baseline leg.  Links the host library built by minimod_amd.build_all()."""
+    root = os.path.dirname(HERE)
+    srcs = [os.path.join(HERE, "freq_cpu_main.c"), os.path.join(HERE, "freq_oracle.c")]
+    libdir = os.path.join(root, "minimod_amd", "lib")
+    deps = srcs + [os.path.join(libdir, "libminimod_host.so")]
+    if force or not os.path.exists(CPU_BIN) or any(os.path.getmtime(CPU_BIN) < os.path.getmtime(d) for d in deps):
+        os.makedirs(BUILD, exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-o", CPU_BIN] + srcs +
+                              ["-I", os.path.join(root, "include"), "-I", os.path.join(root, "minimod_amd", "csrc", "host"),
+                               "-L", libdir, "-lminimod_host", "-lminimod_hip", "-Wl,-rpath," + libdir, "-lpthread", "-lm", "-lz"])
+    return CPU_BIN
+
+
 _lib = None
 
 

@@ -86,6 +86,11 @@ def test_bench_freq_results_match_oracle(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["unit"] == "Mbases/s" and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
+    # the end-to-end leg: the CLI on the same reads as a BGZF BAM, its bedmethyl byte-identical to the CPU path's
+    e2e, ce = d["end_to_end"], d["cpu_baseline_e2e"]
+    assert e2e["reads"] == 6000 and e2e["value"] > 0 and e2e["parity_vs_cpu"]["byte_identical"] and e2e["parity_vs_cpu"]["bytes"] > 100000
+    assert ce["kind"] == "port" and ce["t_all"]["value"] > 0 and ce["t_1"]["value"] > 0 and "process" in ce["t_1"]["stages_s"]
+    assert "load" in e2e["stages_s"] and "device" in d["config"]["read_order"]
     got = np.load(dump)["rows"]
     plan, ref, batches = _bench_batches(6000, 2048, 2)
     orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
@@ -96,6 +101,18 @@ def test_bench_freq_results_match_oracle(tmp_path):
     assert len(want) > 1000 and len(got) == len(want)
     for a, b in (("pos", "pos"), ("strand", "strand"), ("n_called", "n_called"), ("n_mod", "n_mod")):
         assert (got[a] == want[b]).all()
+
+
+@pytest.mark.parametrize("config", ["C3", "C5"])
+def test_bench_other_workloads_run(config):
+    """bench.py --config C3 / C5 (BASELINE.json configs[2] and [4]) on a small read set: a line with a roofline object comes out."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--reads", "3000", "--batch", "1024", "--steps", "4",
+                        "--warmup", "1", "--no-e2e", "--cpu-sample-batches", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["config"]["workload"].startswith(config) and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    if config == "C5":
+        assert d["roofline"]["side_list_updates_per_pass"] > 0
 
 
 def test_bench_view_results_match_oracle(tmp_path):
@@ -211,3 +228,71 @@ def test_interval_sharding_with_halo_slabs_on_device():
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["crossed"] > 0 and res["rows"] > 1000 and res["equal"], res
+
+
+COALESCE_WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+ref = synth.reference(21, 4 << 20)
+bs = [synth.batch(ref, i * 300, 300, seed=9, n_reads_total=2100, with_order=False) for i in range(7)]
+whole = synth.concat(bs)
+dev = {k: torch.from_numpy(whole[k].view(np.uint8).reshape(-1)).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+def window(i):
+    return dict(reads=dev["reads"].data_ptr() + 64 * 300 * i, cigar=dev["cigar"].data_ptr(), seq=dev["seq"].data_ptr(), mm=dev["mm"].data_ptr(),
+                ml=dev["ml"].data_ptr(), n_reads=300, n_cigar_words=len(whole["cigar"]), n_seq_bytes=len(whole["seq"]), n_mm_bytes=len(whole["mm"]),
+                n_ml_bytes=len(whole["ml"]), max_n_cigar=int(bs[i]["max_n_cigar"]), max_l_qseq=int(bs[i]["max_l_qseq"]))
+orc = O.Oracle([("m", "CG"), ("h", "CG")], [0.8, 0.7], ["chrS"]); orc.add_contig("chrS", ref)
+for b in bs: orc.process(b, threads=8)
+want = orc.rows()
+key = lambda r, io: list(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+out = {}
+for name, coalesce, order in (("off", 0, range(7)), ("groups_of_3", 3, range(7)), ("one_group", 16, range(7)), ("broken_runs", 4, [0, 1, 3, 4, 5, 2, 6])):
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8), ("h", "CG", 0.7)], [("chrS", len(ref), ref)], coalesce=coalesce)
+    tickets = [eng.submit_device(window(i)) for i in order]
+    sizes = {}
+    for t in tickets: sizes[t] = eng.ticket_batches(t)
+    if name == "groups_of_3":
+        eng.wait(tickets[-1])          # the open group of one is launched by the wait
+    got = eng.finalize(); eng.close()   # finalize launches whatever is still gathered
+    out[name] = {"equal": key(got, None) == key(want, None), "tickets": tickets, "sizes": [sizes[t] for t in dict.fromkeys(tickets)]}
+# a failing read inside a gathered group: reported with its index counted from the group's first read
+bad = [dict(b) for b in bs[:3]]
+whole2 = synth.concat(bad)
+cg = whole2["cigar"].copy(); r = whole2["reads"][450]; cg[int(r["cigar_off"])] = (5 << 4) | 5   # a hard clip in read 150 of window 1
+dev2 = {k: torch.from_numpy((cg if k == "cigar" else whole2[k]).view(np.uint8).reshape(-1)).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+def window2(i):
+    return dict(reads=dev2["reads"].data_ptr() + 64 * 300 * i, cigar=dev2["cigar"].data_ptr(), seq=dev2["seq"].data_ptr(), mm=dev2["mm"].data_ptr(),
+                ml=dev2["ml"].data_ptr(), n_reads=300, n_cigar_words=len(cg), n_seq_bytes=len(whole2["seq"]), n_mm_bytes=len(whole2["mm"]),
+                n_ml_bytes=len(whole2["ml"]), max_n_cigar=int(bs[i]["max_n_cigar"]), max_l_qseq=int(bs[i]["max_l_qseq"]))
+eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], coalesce=4)
+ts = [eng.submit_device(window2(i)) for i in range(3)]
+try:
+    eng.wait(ts[0]); out["error"] = None
+except minimod_amd.engine.MinimodHipError as e:
+    out["error"] = [e.code, e.read]
+eng.close()
+print(json.dumps(out))
+'''
+
+
+def test_coalesced_windows_of_a_resident_read_set():
+    """mm_freq_opts_t.coalesce: consecutive -K windows of one resident read set share a launch; same rows as the oracle for
+    every grouping, tickets shared inside a group, a submit that does not continue the group starts a new one, and a read
+    error is reported relative to the group's first read."""
+    r = subprocess.run([sys.executable, "-c", COALESCE_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    for name in ("off", "groups_of_3", "one_group", "broken_runs"):
+        assert res[name]["equal"], (name, res[name])
+    assert res["off"]["sizes"] == [1, 1, 1, 1] or len(set(res["off"]["tickets"])) == 4      # four slots, every submit its own launch
+    assert res["groups_of_3"]["tickets"][0] == res["groups_of_3"]["tickets"][2] != res["groups_of_3"]["tickets"][3]
+    assert res["groups_of_3"]["sizes"] == [3, 3, 1]
+    assert res["one_group"]["sizes"] == [7]
+    assert res["broken_runs"]["sizes"] == [2, 3, 1, 1]
+    assert res["error"] == [1, 450]
