@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--host-plan", action="store_true", help="experiment: hand the library a host-made plan (mm_freq_plan_batch) "
                                                            "uploaded before the timed region instead of planning on the device inside it")
-    ap.add_argument("--coalesce", type=int, default=8, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
+    ap.add_argument("--coalesce", type=int, default=16, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
                                                              "one launch (1 = every step is its own launch)")
     ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")

@@ -10,6 +10,8 @@ INCLUDE = os.path.join(ROOT, "include")
 
 
 def lib_path(name="libminimod_hip.so"):
+    if name == "libminimod_hip.so" and os.environ.get("MM_HIP_LIB"):   # developer switch: another build of the device library
+        return os.environ["MM_HIP_LIB"]
     return os.path.join(LIBDIR, name)
 
 
@@ -29,7 +31,7 @@ def build_hip(force=False, verbose=False):
         os.makedirs(LIBDIR, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE,
-               "-o", out, srcs[0]]
+               "-o", out, srcs[0]] + os.environ.get("MM_HIP_DEFS", "").split()   # build-time experiments: -DMM_TILE_CHARS=... etc.
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -61,6 +61,7 @@ struct Slot {
     TileRec* d_tiles = nullptr; size_t cap_tiles = 0;
     int32_t* d_fb = nullptr; size_t cap_fb = 0;
     int32_t* d_plan = nullptr; size_t cap_plan = 0;                        // work items planned on the device (k_plan_items)
+    PlanState* d_plan_state = nullptr; unsigned int plan_serial = 0;      // what the planning workgroups share
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
     int32_t members = 1;         // submits gathered into the slot's launch
@@ -302,7 +303,13 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 const uint32_t split = h->opts.split_bases >= 1024 ? (uint32_t)h->opts.split_bases : kSplitBases;
                 const size_t max_items = (size_t)b->n_reads + 2 * (size_t)b->n_seq_bytes / split + 64;
                 if ((r = grow(h, (void**)&s.d_plan, &s.cap_plan, 4 * max_items))) return r;
-                hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6);
+                if (!s.d_plan_state) {
+                    if (dev_alloc(h, (void**)&s.d_plan_state, sizeof(PlanState))) return -MM_E_NOMEM;
+                    HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
+                }
+                const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
+                hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
+                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag);
                 p.order = s.d_plan;
                 p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
                 tp.plan_count = ctl + 6;
@@ -507,7 +514,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
-                      s.d_plan,
+                      s.d_plan, s.d_plan_state,
                       s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);

@@ -6,7 +6,7 @@
 //
 //   KA  k_scan_reads   three independent waves per read, light and streaming: (1) CIGAR prefix arrays and (2) the rank
 //                      directory go to a global scratch (L2-resident, indexed like the pools they come from); (3) the
-//                      MM group headers are parsed and every group's skip list is cut into TILES of 256 characters
+//                      MM group headers are parsed and every group's skip list is cut into TILES of kTileChars characters
 //                      (plus tail tiles for '.' groups) -- nothing sequential over the text itself.
 //   KS  k_sum_tiles    one wave per tile: tokens and rank sum of the tile (8 bytes per tile).
 //   KC  k_call_tiles   one wave per tile, any order, 1.3 KB of LDS: prefix over the summaries of the tiles in front of
@@ -29,7 +29,13 @@ namespace mmhip {
 #define KAT_LAP(slot) do {} while (0)
 #endif
 
-constexpr uint32_t kTileChars = 256;
+#ifndef MM_TILE_CHARS
+#define MM_TILE_CHARS 320
+#endif
+constexpr uint32_t kTileChars = MM_TILE_CHARS;   // a multiple of 64, at most 448 (the descriptor keeps 9 bits of "characters left")
+constexpr uint32_t kTileSub = kTileChars / 64;   // 64-character sub-chunks k_sum_tiles parses a tile in
+constexpr uint32_t kTileTok = kTileChars / 2;    // most tokens a tile can hold (a token is at least two characters)
+static_assert(kTileChars % 64 == 0 && kTileChars >= 128 && kTileChars <= 448, "tile size");
 constexpr uint32_t kTailRanks = 16384;  // implicit-call ranks per tail tile
 constexpr uint32_t kTileRegions = 64;   // independent reservation counters / tile regions
 
@@ -38,7 +44,8 @@ struct TileRec {  // 32 bytes
     uint32_t cpos;         // list tile: offset of its first character in the MM string; tail tile: its index j in the group's tail
     uint32_t read_first;   // index (inside the region) of the read's first tile
     uint32_t group_first;  // index of the group's first tile
-    uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, bit6 no requested code, 8-10 cls, 12-14 n_codes
+    uint32_t flags;        // bit0 valid, bit1 tail, bit2 dot, bit3 direct, bit4 mb_is_N, bit5 first tile of its list, bit6 no requested code,
+                           // bit7 last tile of its list, 8-10 cls, 12-14 n_codes
     int16_t g_code[4];
     uint32_t gord;         // ordinal of the MM group in the read (view mode: which of two entries with one key came first)
 };
@@ -71,7 +78,8 @@ struct TileParams {
     const unsigned int* plan_count;   // null: the caller's plan (d.n_items entries)
 };
 constexpr uint32_t kPartSlots = 16;                       // parts per read (4 bits in a work item)
-constexpr int kPlanBuckets = 4096;                        // cost buckets of 256 bases
+constexpr int kPlanBuckets = 256;                         // cost buckets of 256 bases per part (a part is at most `split` bases: with the
+                                                          // default 24 576 fewer than a hundred buckets are ever used; longer ones share the last)
 constexpr uint32_t kSplitBases = 24576;                   // default: a read longer than this is cut into parts of about this many bases
                                                           // (measured on C2: 8192 479, 16384 507, 24576 519, 49152 517, 131072 456 Gbases/s)
 
@@ -86,10 +94,14 @@ struct ScanLds {
     uint32_t gend[kGroupEnds];   // run_mm: where the read's first groups end (found once, used by both passes)
 };
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
-constexpr uint32_t kSliceC = 768;   // CIGAR ops staged in LDS per tile, one packed word each
+#ifndef MM_SLICE_C
+#define MM_SLICE_C 704
+#endif
+constexpr uint32_t kSliceC = MM_SLICE_C;   // CIGAR ops staged in LDS per tile, one packed word each (with 384-character tiles
+                                         // 704 keeps the workgroup at 22.5 KB of LDS: seven per CU)
 constexpr uint32_t kSliceSpan = 16384;   // ... when the slice spans fewer read and reference positions than this
 struct CallLds {
-    uint32_t tok[128];
+    uint32_t tok[kTileTok];
     uint32_t gap[64];
     uint32_t gstart[64];
     uint32_t ds[kSliceD];    // slice of the rank directory covering the tile's listed ranks
@@ -180,9 +192,9 @@ __device__ __forceinline__ uint64_t low_bits(int n) { return n >= 64 ? ~0ull : (
 
 // ------------------------------------------------------------------------------------------------ plan
 // Work items for k_scan_reads, costliest first (mm_freq_plan_batch on the device): read index | part << 24 |
-// (parts - 1) << 28, long reads cut into up to kPartSlots parts of about `split` bases.  One workgroup: a counting sort
-// over cost buckets of 256 bases per part (histogram and cursors in LDS).  The order inside a bucket is whatever the LDS
-// atomics give: results do not depend on it (counters add up; view rows are ordered per read afterwards).
+// (parts - 1) << 28, long reads cut into up to kPartSlots parts of about `split` bases: a counting sort over cost buckets
+// of 256 bases per part.  The order inside a bucket is whatever the atomics give: results do not depend on it (counters
+// add up; view rows are ordered per read afterwards).
 __device__ __forceinline__ uint32_t plan_parts(uint32_t L, uint32_t split) {
     uint32_t w = (L + split - 1u) / split;
     return w < 1u ? 1u : (w > kPartSlots ? kPartSlots : w);
@@ -192,46 +204,90 @@ __device__ __forceinline__ uint32_t plan_bucket(uint32_t L, uint32_t w) {
     if (k >= (uint32_t)kPlanBuckets) k = kPlanBuckets - 1;
     return (uint32_t)(kPlanBuckets - 1) - k;
 }
-__global__ __launch_bounds__(1024) void k_plan_items(const mm_read_t* __restrict__ reads, int n, uint32_t split, int32_t* __restrict__ items,
-                                                     unsigned int* __restrict__ n_items_out) {
+// State the planning workgroups share (one per slot, zeroed once at creation; every launch leaves it zeroed again).
+struct PlanState {
+    unsigned int hist[kPlanBuckets];     // parts per bucket, summed over the workgroups
+    unsigned int cursor[kPlanBuckets];   // first free item of every bucket
+    unsigned int done;                   // workgroups that have added their histogram
+    unsigned int ready;                  // the launch serial, once the cursors are valid
+};
+constexpr int kPlanThreads = 256;
+constexpr int kPlanReadsPerBlock = 512;
+// One workgroup per kPlanReadsPerBlock reads (at most 64, all resident at once): a single workgroup is bound by what one
+// CU can gather -- 4096 read records 64 bytes apart and as many scattered item stores took it 11 us, 70 us for a group of
+// eight batches.  Histograms in LDS, added to the shared one; the last workgroup to arrive scans it into cursors and
+// raises `ready`; every workgroup then reserves its share of each bucket with one atomic and hands out places from LDS.
+__global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __restrict__ reads, int n, uint32_t split, int32_t* __restrict__ items,
+                                                             unsigned int* __restrict__ n_items_out, PlanState* __restrict__ st, unsigned int serial,
+                                                             unsigned int* __restrict__ err_summary, unsigned int* __restrict__ host_flag) {
     __shared__ uint32_t hist[kPlanBuckets];
-    __shared__ uint32_t wsum[16];
-    const int t = threadIdx.x;
-    for (int b = t; b < kPlanBuckets; b += 1024) hist[b] = 0u;
+    __shared__ uint32_t base[kPlanBuckets];
+    __shared__ uint32_t wsum[kPlanThreads / 64];
+    __shared__ uint32_t s_last;
+    const int t = threadIdx.x, nb = (int)gridDim.x;
+    const int per = ((n + nb - 1) / nb + kPlanThreads - 1) / kPlanThreads * kPlanThreads;
+    const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
+    for (int b = t; b < kPlanBuckets; b += kPlanThreads) hist[b] = 0u;
     __syncthreads();
-    // eight reads per thread and trip: the record loads (64 bytes apart) are all in flight before the first LDS atomic
-    for (int i0 = 0; i0 < n; i0 += 8192) {
-        uint32_t L[8];
+    for (int i0 = lo; i0 < hi; i0 += 4 * kPlanThreads) {   // four record loads in flight per thread
+        uint32_t L[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + 1024 * u + t; L[u] = i < n ? reads[i].l_qseq : 0u; }
+        for (int u = 0; u < 4; u++) { const int i = i0 + kPlanThreads * u + t; L[u] = i < hi ? reads[i].l_qseq : 0u; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + 1024 * u + t;
-            if (i < n) { const uint32_t w = plan_parts(L[u], split); atomicAdd(&hist[plan_bucket(L[u], w)], w); }
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + kPlanThreads * u + t;
+            if (i < hi) { const uint32_t w = plan_parts(L[u], split); atomicAdd(&hist[plan_bucket(L[u], w)], w); }
         }
     }
     __syncthreads();
-    // exclusive scan over the buckets: four per thread, wave scan, then the 16 wave totals
-    uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
-    const uint32_t mine = h0 + h1 + h2 + h3;
-    const uint32_t incl = wave_incl_scan(mine);
-    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    for (int b = t; b < kPlanBuckets; b += kPlanThreads) if (hist[b]) atomicAdd(&st->hist[b], hist[b]);
+    __threadfence();   // a few dozen per launch: the shared histogram is complete before the ticket is drawn
     __syncthreads();
-    uint32_t before = incl - mine;
-    for (int w = 0; w < (t >> 6); w++) before += wsum[w];
-    hist[4 * t] = before; hist[4 * t + 1] = before + h0; hist[4 * t + 2] = before + h0 + h1; hist[4 * t + 3] = before + h0 + h1 + h2;
-    if (t == 1023) *n_items_out = before + mine;
+    if (t == 0) s_last = atomicAdd(&st->done, 1u) == (unsigned int)(nb - 1) ? 1u : 0u;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 8192) {
-        uint32_t L[8];
+    if (s_last) {
+        // exclusive scan of the shared histogram (read and cleared in one exchange), kPlanBuckets / kPlanThreads bins per thread
+        constexpr int kPer = kPlanBuckets / kPlanThreads;
+        uint32_t v[kPer], mine = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + 1024 * u + t; L[u] = i < n ? reads[i].l_qseq : 0u; }
+        for (int k = 0; k < kPer; k++) { v[k] = atomicExch(&st->hist[kPer * t + k], 0u); mine += v[k]; }
+        const uint32_t incl = wave_incl_scan(mine);
+        if ((t & 63) == 63) wsum[t >> 6] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < (t >> 6); w++) before += wsum[w];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + 1024 * u + t;
-            if (i < n) {
-                const uint32_t w = plan_parts(L[u], split);
-                const uint32_t at = atomicAdd(&hist[plan_bucket(L[u], w)], w);
+        for (int k = 0; k < kPer; k++) { atomicExch(&st->cursor[kPer * t + k], before); before += v[k]; }
+        if (t == kPlanThreads - 1) *n_items_out = before;
+        __threadfence();
+        __syncthreads();
+        if (t == 0) { atomicExch(&st->done, 0u); atomicExch(&st->ready, serial); }
+    }
+    if (t == 0) {
+        uint32_t polls = 0;
+        while (__hip_atomic_load(&st->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial && ++polls < (1u << 24)) __builtin_amdgcn_s_sleep(4);
+        s_last = polls < (1u << 24) ? 1u : 0u;   // seconds without the cursors: the launch must still end, and not quietly
+        if (!s_last) { atomicMin(err_summary, (unsigned int)MM_E_HIP); if (host_flag) *host_flag = 0u; }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // this workgroup's share of every bucket: one reservation per bucket it has parts in, then places from LDS
+    for (int b = t; b < kPlanBuckets; b += kPlanThreads) {
+        const uint32_t cnt = hist[b];
+        if (cnt) base[b] = atomicAdd(&st->cursor[b], cnt);
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    for (int i0 = lo; i0 < hi; i0 += 4 * kPlanThreads) {
+        uint32_t L[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + kPlanThreads * u + t; L[u] = i < hi ? reads[i].l_qseq : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + kPlanThreads * u + t;
+            if (i < hi) {
+                const uint32_t w = plan_parts(L[u], split), b = plan_bucket(L[u], w);
+                const uint32_t at = base[b] + atomicAdd(&hist[b], w);
                 for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));
             }
         }
@@ -613,7 +669,7 @@ struct KA {
                             t.ridx = (uint32_t)ridx;
                             t.cpos = tail ? j - nlist : g.lstart + kTileChars * j;
                             t.read_first = tbase; t.group_first = gfirst;
-                            t.flags = gflags | (tail ? 2u : 0u) | ((!tail && j == 0) ? 32u : 0u);
+                            t.flags = gflags | (tail ? 2u : 0u) | ((!tail && j == 0) ? 32u : 0u) | ((!tail && j + 1u == nlist) ? 128u : 0u);
                             t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
                             t.gord = gord;
                             rtiles[gfirst + j] = t;
@@ -699,7 +755,7 @@ __global__ __launch_bounds__(256) void k_scan_reads(const TileParams P) {
 // ------------------------------------------------------------------------------------------------ KS
 template <typename RefWord>
 __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
-    __shared__ uint32_t lds[kWavesPerBlock][68];
+    __shared__ uint32_t lds[kWavesPerBlock][kTileChars / 4 + 4];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
@@ -728,31 +784,33 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
         const uint8_t* mm = p.mm + dx;
         const bool keep = (dy & kSumKeep) != 0;   // a group nobody asked for is only counted
         uint32_t* const tok_out = P.g_tok + (dx >> 1);
+        // the tile's characters as dwords: kTileChars / 4 of them + four of look-ahead (two loads per lane at most)
+        constexpr uint32_t kDw = kTileChars / 4 + 4;
         uint32_t wd = mm_dword(mm, rem, 4u * lane);
-        uint32_t la = lane < 4 ? mm_dword(mm, rem, 256u + 4u * lane) : 0u;
+        uint32_t wd2 = (uint32_t)lane + 64u < kDw ? mm_dword(mm, rem, 256u + 4u * lane) : 0u;
         const bool prev_delim = (dy & kSumFirst) ? true : (*(mm - 1) == ',');
         wave_sync();
         mmw[lane] = wd;
-        if (lane < 4) mmw[64 + lane] = la;
+        if ((uint32_t)lane + 64u < kDw) mmw[64 + lane] = wd2;
         wave_sync();
         const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mmw);
-        // characters: lane l holds 64*s + l of the four sub-chunks, lanes 0..15 the look-ahead; delimiter bitmaps
-        uint32_t x[4];
+        // characters: lane l holds 64*s + l of the sub-chunks, lanes 0..15 the look-ahead; delimiter bitmaps
+        uint32_t x[kTileSub];
 #pragma unroll
-        for (int sc = 0; sc < 4; sc++) x[sc] = mb8[64 * sc + lane];
-        const uint32_t x4 = mb8[256 + (lane & 15)];
-        uint64_t D[5], Sm[4];
+        for (uint32_t sc = 0; sc < kTileSub; sc++) x[sc] = mb8[64 * sc + lane];
+        const uint32_t x4 = mb8[kTileChars + (lane & 15)];
+        uint64_t D[kTileSub + 1], Sm[kTileSub];
 #pragma unroll
-        for (int sc = 0; sc < 4; sc++) {
+        for (uint32_t sc = 0; sc < kTileSub; sc++) {
             Sm[sc] = __ballot(x[sc] == ';');
             D[sc] = Sm[sc] | __ballot(x[sc] == ',');
         }
-        D[4] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;   // past the look-ahead: as if delimited
+        D[kTileSub] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;   // past the look-ahead: as if delimited
         uint32_t nends = 0, rsum_v = 0;
         uint64_t bad = 0;
         bool closed = false, open_tail = false;
 #pragma unroll
-        for (int sc = 0; sc < 4; sc++) {
+        for (int sc = 0; sc < (int)kTileSub; sc++) {
             if (closed) break;
             // the tile owns characters [lo, hi) of this sub-chunk: up to the group's ';', and not the rest of a token
             // that began in the tile before
@@ -777,12 +835,12 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
             bad |= __ballot(own && !(w & 2u) && dv > 9u) | __ballot(start && e >= 10u);
             rsum_v += lane_valu(run, 63);
             nends += (uint32_t)__popcll(eb);
-            if (sc == 3 && !closed) open_tail = ((D[3] >> 63) == 0) && ((D[4] & 1ull) == 0);
+            if (sc == (int)kTileSub - 1 && !closed) open_tail = ((D[kTileSub - 1] >> 63) == 0) && ((D[kTileSub] & 1ull) == 0);
         }
         uint32_t ntok = nends;
         if (open_tail) {
             // the tile's last token runs into the look-ahead: its remaining digits
-            const int k = __ffsll((unsigned long long)D[4]) - 1;   // 1..16
+            const int k = __ffsll((unsigned long long)D[kTileSub]) - 1;   // 1..16
             const uint32_t dv = x4 - (uint32_t)'0';
             uint32_t e = (uint32_t)(k - lane);
             e = e < 10u ? e : 10u;
@@ -798,13 +856,13 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
             int e = 0;
             if (lane == 0) {
                 uint32_t i = 0;
-                if (!prev_delim) while (i < 272u && mb8[i] != ',' && mb8[i] != ';') i++;
-                while (i < 256u && !e) {
+                if (!prev_delim) while (i < kTileChars + 16u && mb8[i] != ',' && mb8[i] != ';') i++;
+                while (i < kTileChars && !e) {
                     uint32_t ch = mb8[i];
                     if (ch == ';') break;
                     if (ch == ',') { i++; continue; }
                     int l = 0;
-                    while (i < 272u && mb8[i] != ',' && mb8[i] != ';') {
+                    while (i < kTileChars + 16u && mb8[i] != ',' && mb8[i] != ';') {
                         if ((uint32_t)mb8[i] - (uint32_t)'0' > 9u) { e = MM_E_SKIPVAL; break; }
                         i++; l++;
                         if (l >= 10) { e = MM_E_SKIPLEN; break; }
@@ -1173,10 +1231,13 @@ struct KC {
         rev = (uni(rd.flag) & 0x10) ? 1 : 0;
         seq = p.seq + rd.seq_off; ml = p.ml + rd.ml_off;
         // ... and what only needs the read record goes out together: the tile's tokens, the per-contig bases, the read's totals
-        uint32_t tv0 = 0, tv1 = 0;
+        uint32_t tv[(kTileTok + 63) / 64];
+#pragma unroll
+        for (uint32_t j = 0; j < (kTileTok + 63) / 64; j++) tv[j] = 0;
         if (list_tile && !(t.flags & 64u)) {
-            const uint32_t* const tok_in = P.g_tok + ((rd.mm_off + t.cpos) >> 1);   // 128 words belong to the tile: no bound needed
-            tv0 = tok_in[lane]; tv1 = tok_in[lane + 64];
+            const uint32_t* const tok_in = P.g_tok + ((rd.mm_off + t.cpos) >> 1);   // kTileTok words belong to the tile: no bound needed
+#pragma unroll
+            for (uint32_t j = 0; j < (kTileTok + 63) / 64; j++) if (64u * j + (uint32_t)lane < kTileTok) tv[j] = tok_in[64u * j + lane];
         }
         gq = P.g_cq + rd.cigar_off; gr = P.g_cr + rd.cigar_off; gd = P.g_dir + (rd.seq_off >> 4);
         qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx; rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
@@ -1210,9 +1271,11 @@ struct KC {
             // No code of this group was requested: every call would be discarded (mod.c:1157).  The only thing the
             // reference still does with such a group is assert its read positions (mod.c:1116): the last listed rank
             // must exist.  (Its tokens still count towards ML indices: that is k_sum_tiles' job.)
+            // (this is the last tile of the group's list; it may be empty when the list ends on a tile boundary, the
+            // running rank in front of it then is the group's last one)
             if (list_tile) {
                 const uint2 own = own_sv;
-                if ((own.x & 0xFFFFu) != 0u) {
+                if (rank_carry0 + own.y != 0u) {
                     uint32_t r_last = rank_carry0 + own.y - 1u;
                     if (r_last >= (((t.flags >> 3) & 1u) ? L : nb)) err = MM_E_READPOS;
                 }
@@ -1250,8 +1313,8 @@ struct KC {
             // the tile's listed tokens as k_sum_tiles left them (running sums of skip+1 inside the tile) -> ranks in tok[]
             // (the skip of token j is rank[j] - rank[j-1] - 1 again when needed)
             const uint32_t ntok = uniu(own_sv.x) & 0xFFFFu;
-            if ((uint32_t)lane < ntok) S.tok[lane] = rank_carry0 + tv0 - 1u;
-            if ((uint32_t)lane + 64u < ntok) S.tok[lane + 64] = rank_carry0 + tv1 - 1u;
+#pragma unroll
+            for (uint32_t j = 0; j < (kTileTok + 63) / 64; j++) if (64u * j + (uint32_t)lane < ntok) S.tok[64u * j + lane] = rank_carry0 + tv[j] - 1u;
             wave_sync();
             KAT_LAP(9);
             if (ntok > 0) {
@@ -1358,7 +1421,8 @@ __global__ __launch_bounds__(256, kPlain ? 7 : 5) void k_call_tiles(const TilePa
         t.ridx = src[0]; t.cpos = src[1]; t.read_first = src[2]; t.group_first = src[3];
         t.flags = src[4]; t.index = ti; t.gord = src[7]; t.region = region;
         uint32_t gc01 = src[5], gc23 = src[6];
-        if (t.flags & 1u) {
+        // a group nobody asked for only has its last listed rank checked (mod.c:1116): the last tile of its list does that
+        if ((t.flags & 1u) && (!(t.flags & 64u) || (t.flags & 130u) == 128u)) {
             int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
             if (e != 0 && lane_id() == 0) {
                 p.status[t.ridx] = e;

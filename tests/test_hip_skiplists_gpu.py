@@ -1,5 +1,5 @@
 """Skip lists across tile boundaries: k_sum_tiles sums a list per character (digit weights, delimiter bitmaps) in
-tiles of 256 characters with a 16-character look-ahead; these cases move tokens of every width over every boundary
+tiles of kTileChars characters (320; 256 in round 1) with a 16-character look-ahead; these cases move tokens of every width over every boundary
 the kernel has (64-character sub-chunks, tile ends, the look-ahead, the end of the string) and place malformed tokens
 there.  Zero-padded counts ("0007") are legal for the reference's parser (mod.c:1074-1081: digits folded one by one),
 which is what lets short reads carry nine-character tokens.  HIP vs the oracle, bit-exact."""
@@ -100,7 +100,7 @@ def test_two_groups_and_unrequested_group_between():
 def bad_list_cases():
     """(name, position of the malformed token in characters from the list start, token text)"""
     cases = []
-    for at in (0, 60, 63, 64, 250, 254, 255, 256, 257, 300, 511, 512):
+    for at in (0, 60, 63, 64, 250, 254, 255, 256, 257, 300, 318, 319, 320, 321, 383, 384, 511, 512, 639, 640, 641):
         cases.append(("nondigit@%d" % at, at, "1x"))
         cases.append(("tenchars@%d" % at, at, "0000000001"))
         cases.append(("nondigit_in_long@%d" % at, at, "00x0000000001"))
@@ -180,3 +180,35 @@ def test_tiles_whose_cigar_slice_spans_more_than_the_packed_range():
     recs.append(pybam.make_record(0, 1000, 0, seq, "500M18000I500M", "C+m?" + "".join("," + t for t in toks) + ";", ml))
     for c, kw in (("m", {}), ("m[*]", {}), ("m", dict(insertions=True))):
         assert hip_rows_from_records(recs, ref, c, **kw) == oracle_rows(recs, ref, c, **kw)
+
+
+@pytest.mark.parametrize("n_listed", [90, 159, 160, 161, 320, 321, 700])
+def test_unrequested_group_listing_more_bases_than_the_read_has(n_listed):
+    """The reference asserts the read position of every listed base, also in groups -c did not ask for (mod.c:1116): a
+    list that runs past the read's last base of that kind fails the read.  Lists of "0," tokens end on, before and behind
+    tile boundaries (a 320-character tile holds 160 of them): only the last tile of an unrequested list does the check."""
+    import minimod_amd
+    rng = np.random.default_rng(5)
+    ref = make_ref(rng, 4000)
+    seq = ref[:3000]
+    n_a = seq.count("A")
+    good = pybam.make_record(0, 0, 0, seq, "3000M", "C+m?,0,1;", [255, 0])
+    # fine: the A group lists the read's first n_listed As;  bad: its last token skips past the read's last A
+    ok_toks = ["0"] * min(n_listed, n_a)
+    bad_toks = ["0"] * (n_listed - 1) + [str(n_a)]
+    for toks, fails in ((ok_toks, False), (bad_toks, True)):
+        mm = "A+a?" + "".join("," + t for t in toks) + ";C+m?,0,0;"
+        rec = pybam.make_record(0, 0, 0, seq, "3000M", mm, [200] * (len(toks) + 2))
+        o = O.Oracle(O.parse_mod_codes("m"), [0.8], ["chrT"])
+        o.add_contig("chrT", ref.encode())
+        if fails:
+            with pytest.raises(O.OracleError) as oe:
+                o.process(pybam.flatten([good, rec]))
+            assert oe.value.code == 10
+            with pytest.raises(minimod_amd.MinimodHipError) as he:
+                hip_rows_from_records([good, rec, good], ref, "m")
+            assert (he.value.code, he.value.read) == (10, 1)
+        else:
+            o.process(pybam.flatten([good, rec]))
+            assert hip_rows_from_records([good, rec], ref, "m") == oracle_rows([good, rec], ref, "m")
+        o.close()
