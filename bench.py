@@ -74,6 +74,8 @@ def parse_args():
                                                              "one launch (1 = every step is its own launch)")
     ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
+    ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
+                                                               "instead of the 24-contig genome")
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"], help="BASELINE.json workload: C2 = the headline (default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
@@ -116,6 +118,26 @@ def exchange_halos(rank, world, export_fn, add_fn, make_buf, dist):
         add_fn(recv)
 
 
+def exchange_slabs(rank, world, has_send, has_recv, export_fn, add_fn, make_buf, dist):
+    """exchange_halos for a genome plan: only ranks whose share ends inside a contig send, only ranks whose share begins
+    inside one receive (the neighbour relation is the same: rank -> rank + 1)."""
+    if world == 1:
+        return
+    ops, recv = [], None
+    if has_send:
+        send = make_buf()
+        export_fn(send)
+        ops.append(dist.P2POp(dist.isend, send, rank + 1))
+    if has_recv:
+        recv = make_buf()
+        ops.append(dist.P2POp(dist.irecv, recv, rank - 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if recv is not None:
+        add_fn(recv)
+
+
 def gen_reference(plan, seed):
     """A rank's reference: its own interval (+ halo + one read span past it) is generated, the rest stays 'N'."""
     from minimod_amd import synth
@@ -123,6 +145,88 @@ def gen_reference(plan, seed):
     g_end = min(plan["contig_len"], plan["end"] + plan["halo"] + (1 << 20))
     ref[plan["begin"]:g_end] = synth.reference_slice(seed, plan["begin"], g_end - plan["begin"])
     return ref
+
+
+# ---- N > 1: a genome of 24 contigs cut into contiguous shares (BASELINE.json configs[3])
+HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+        133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895,
+        57227415]
+GENOME_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+CUT_ALIGN = 1 << 16          # shares are cut at 64 kb-aligned positions
+
+
+def genome_layout(world, per_gpu=INTERVAL):
+    """24 contigs with hg38's length ratios and world * per_gpu positions in total (weak scaling: every GPU gets per_gpu
+    positions of reference whatever the world size; at 8 GPUs and per_gpu = 388 Mb this is the human genome).  Lengths are
+    multiples of 1 MiB (the synthetic reference comes in MiB chunks)."""
+    mib = 1 << 20
+    total = world * per_gpu
+    lens = [max(mib, int(round(h / sum(HG38) * total / mib)) * mib) for h in HG38]
+    return list(zip(GENOME_NAMES, lens))
+
+
+def genome_plan(rank, world, contigs, halo=HALO, align=CUT_ALIGN):
+    """Rank `rank`'s contiguous share of the concatenated genome (contigs in header order, cut points aligned): the
+    intervals it owns, and the halo slab it sends to the right / receives from the left when a cut falls inside a contig.
+    A read belongs to the owner of its start position (pure function, covered by the CPU tests)."""
+    lens = [l for _, l in contigs]
+    total = sum(lens)
+    cut = lambda k: total if k >= world else (k * total // world) // align * align
+    lo, hi = cut(rank), cut(rank + 1)
+    intervals, off = [], 0
+    for tid, l in enumerate(lens):
+        b, e = max(lo, off), min(hi, off + l)
+        if b < e:
+            intervals.append({"tid": tid, "begin": b - off, "end": e - off, "halo": 0, "read_begin": b - off, "read_len": e - b})
+        off += l
+    send = recv = None
+    if intervals:
+        last, first = intervals[-1], intervals[0]
+        if last["end"] < lens[last["tid"]]:          # the cut is inside a contig: counters past it are kept and sent on
+            last["halo"] = min(halo, lens[last["tid"]] - last["end"])
+            send = (last["tid"], last["end"], last["halo"])
+        if first["begin"] > 0:
+            recv = (first["tid"], first["begin"], min(halo, lens[first["tid"]] - first["begin"]))
+    return {"contigs": list(contigs), "intervals": intervals, "send": send, "recv": recv, "share": hi - lo}
+
+
+def single_contig_plan(rank, world, interval=INTERVAL, halo=HALO):
+    """shard_plan() (one long contig cut into one interval per rank) in the form genome_plan() returns."""
+    p = shard_plan(rank, world, interval, halo)
+    iv = {"tid": 0, "begin": p["begin"], "end": p["end"], "halo": p["halo"], "read_begin": p["read_begin"], "read_len": p["read_len"]}
+    return {"contigs": [("chrS", p["contig_len"])], "intervals": [iv], "send": (0, p["end"], p["halo"]) if p["halo"] else None,
+            "recv": (0, p["begin"], halo) if rank > 0 else None, "share": interval, "single": p}
+
+
+def plan_references(plan, seed):
+    """The reference of every contig the rank owns a piece of: that piece (+ halo + one read span) generated, the rest 'N';
+    contigs it owns nothing of stay None (not uploaded)."""
+    from minimod_amd import synth
+    refs = [None] * len(plan["contigs"])
+    for iv in plan["intervals"]:
+        tid, clen = iv["tid"], plan["contigs"][iv["tid"]][1]
+        if refs[tid] is None:
+            refs[tid] = np.full(clen, ord("N"), dtype=np.uint8)
+        b = iv["begin"] // (1 << 20) * (1 << 20)
+        e = min(clen, iv["end"] + iv["halo"] + (1 << 20))
+        refs[tid][b:e] = synth.reference_slice(seed + 1000 * tid, b, e - b)
+    return refs
+
+
+def plan_reads(plan, refs, rank, seed, reads, max_len=0.0, **gen):
+    """The rank's reads: every interval gets its share of `reads` by length, sorted by (contig, start) like a BAM."""
+    from minimod_amd import synth
+    share = sum(iv["read_len"] for iv in plan["intervals"])
+    parts, left = [], reads
+    for k, iv in enumerate(plan["intervals"]):
+        n = left if k == len(plan["intervals"]) - 1 else min(left, int(round(reads * iv["read_len"] / share)))
+        left -= n
+        if n <= 0:
+            continue
+        clen = plan["contigs"][iv["tid"]][1]
+        parts.append(synth.batch(refs[iv["tid"]], 0, n, seed=seed + 7919 * rank + 101 * k, contig_len=clen, n_reads_total=n, tid=iv["tid"],
+                                 region_begin=iv["read_begin"], region_len=iv["read_len"], max_len=max_len, with_order=False, **gen))
+    return synth.concat(parts)
 
 
 # The BASELINE.json workloads this file can run.  `gen` = synthetic-read options, `mods` = -c / -m, `eng` = engine options.
@@ -169,7 +273,7 @@ def _stage_timers(stderr_text):
     return out
 
 
-def run_end_to_end(args, wl, host_batches, plan, ref):
+def run_end_to_end(args, wl, host_batches, contig, ref):
     """The END-TO-END leg: the workload's reads as a BGZF BAM + FASTA, through the product CLI (GPU) and through the CPU
     path (oracle behind the same reader and formatter), every run a child process.  Called before this process initialises
     the GPU.  Returns (end_to_end, cpu_baseline_e2e)."""
@@ -184,11 +288,11 @@ def run_end_to_end(args, wl, host_batches, plan, ref):
     try:
         t0 = time.perf_counter()
         bam, bam1, fa = os.path.join(tmp, "reads.bam"), os.path.join(tmp, "reads_t1.bam"), os.path.join(tmp, "ref.fa")
-        contigs = [("chrS", plan["contig_len"])]
+        contigs = [contig]
         synth.write_bam_parallel(bam, contigs, host_batches, filter_fodder=True, threads=min(32, cores))
         n1 = max(1, min(args.cpu_t1_batches, len(host_batches)))
         synth.write_bam_parallel(bam1, contigs, host_batches[:n1], filter_fodder=True, threads=min(32, cores))
-        synth.write_fasta(fa, "chrS", ref)
+        synth.write_fasta(fa, contig[0], ref)
         t_write = time.perf_counter() - t0
         bases = int(sum(hb["n_bases"] for hb in host_batches))
         reads = int(sum(len(hb["reads"]) for hb in host_batches))
@@ -253,22 +357,42 @@ def main():
     import minimod_amd
     from minimod_amd import engine, synth
 
-    plan = shard_plan(rank, world, wl.get("region", INTERVAL), HALO)
+    # N = 1: one contig (C2 as BASELINE.json states it).  N > 1: the 24-contig genome, one contiguous share per rank.
+    region = wl.get("region", INTERVAL)
+    if world == 1 or args.single_contig:
+        plan = single_contig_plan(rank, world, region, HALO)
+    else:
+        plan = genome_plan(rank, world, genome_layout(world, region), HALO)
     t0 = time.time()
-    ref = gen_reference(plan, args.seed)
-    n_batches = (args.reads + args.batch - 1) // args.batch
+    refs = plan_references(plan, args.seed)
+    names = [n for n, _ in plan["contigs"]]
+    share = sum(iv["read_len"] for iv in plan["intervals"])
+    jobs, left = [], args.reads      # (interval ordinal, first read, reads): pieces of at most -K reads, generated in parallel
+    for k, iv in enumerate(plan["intervals"]):
+        n_iv = left if k == len(plan["intervals"]) - 1 else min(left, int(round(args.reads * iv["read_len"] / share)))
+        left -= n_iv
+        jobs += [(k, f, min(args.batch, n_iv - f), n_iv) for f in range(0, n_iv, args.batch)]
 
-    def gen(bi):
-        return gen_batch(ref, plan, rank, args.seed, args.reads, args.batch, bi, args.max_len, **wl["gen"])
+    def gen(job):
+        k, first, n, n_iv = job
+        iv = plan["intervals"][k]
+        return synth.batch(refs[iv["tid"]], first, n, seed=args.seed + 7919 * rank + 101 * k, contig_len=plan["contigs"][iv["tid"]][1],
+                           n_reads_total=n_iv, tid=iv["tid"], region_begin=iv["read_begin"], region_len=iv["read_len"], max_len=args.max_len,
+                           with_order=False, **wl["gen"])
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        host_batches = list(ex.map(gen, range(n_batches)))
+        pieces = list(ex.map(gen, jobs))
+    whole = synth.concat(pieces)
+    del pieces
+    n_reads = len(whole["reads"])
+    host_batches = synth.split(whole, [min(args.batch, n_reads - i) for i in range(0, n_reads, args.batch)])   # the -K windows
+    n_batches = len(host_batches)
     t_gen = time.time() - t0
 
     # ---- the end-to-end leg runs in child processes, before this process has touched the GPU
     e2e = cpu_e2e = None
     if world == 1 and args.mode == "freq" and not args.no_e2e:
-        e2e, cpu_e2e = run_end_to_end(args, wl, host_batches, plan, ref)
+        e2e, cpu_e2e = run_end_to_end(args, wl, host_batches, plan["contigs"][0], refs[0])
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -283,17 +407,17 @@ def main():
             dist.init_process_group(backend=args.backend)
     host_staged = world > 1 and args.backend != "nccl"   # gloo moves CPU tensors
 
-    contig = [("chrS", plan["contig_len"], ref)]
+    contig = [(n, l, refs[t]) for t, (n, l) in enumerate(plan["contigs"])]
     if args.mode == "view":
         eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, view=True, **wl["eng"])
     else:
-        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, intervals=[(0, plan["begin"], plan["end"], plan["halo"])],
+        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank,
+                                     intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
                                      side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce,
                                      **wl["eng"])
     # ---- make the reads resident in HBM (torch owns the memory: plumbing only): ONE read set -- the pools of all batches
     # end to end, as a decoder writing into device memory would leave them -- and a step's batch is a window of -K reads of
     # it (the same pool pointers, `reads` advanced).  Consecutive windows are what mm_freq_opts_t.coalesce may gather.
-    whole = synth.concat(host_batches)
     keep, base = [], {}
     for k in ("reads", "cigar", "seq", "mm", "ml"):
         t = torch.from_numpy(whole[k].view(np.uint8).reshape(-1)).to(dev)
@@ -313,14 +437,14 @@ def main():
             d["n_order"] = len(items)
         dev_batches.append(d)
         first += n
-    del whole
+    pool_sizes = {k: len(whole[k]) for k in ("cigar", "seq", "mm", "ml")}
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)   # one explicit HIP stream carries every K1 launch
     stream = tstream.cuda_stream
     batch_bases = [hb["n_bases"] for hb in host_batches]
 
     if args.mode == "view":
-        return bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, world, dist, dev, plan, ref, t_gen)
+        return bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, world, dist, dev, plan, refs, t_gen)
 
     # ---- untimed tally pass: lookups/updates per batch for the algorithmic-bytes figure
     eng.stats_enable(True)
@@ -364,28 +488,39 @@ def main():
     # ---- warm-up, then the timed region: barrier + sync on both sides, max over ranks
     run_steps(args.warmup)
     eng.reset()
-    slab_words = eng.slab_words(HALO)
+    slab_len = max([x[2] for x in (plan["send"], plan["recv"]) if x] + [0])
+    if world > 1:   # every slab of the job has the same size (the halo); ranks without a cut on one side skip that side
+        tl = torch.tensor([slab_len], dtype=torch.int64, device="cpu" if host_staged else dev)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        slab_len = int(tl.item())
+    slab_words = eng.slab_words(slab_len)
+
     def make_buf():
-        return torch.empty(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
+        return torch.zeros(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
 
     def export_fn(buf):
-        dbuf = torch.empty(slab_words, dtype=torch.int64, device=dev) if host_staged else buf
-        eng.slab_export(0, plan["end"], plan["halo"], dbuf.data_ptr(), stream)
-        eng.slab_clear(0, plan["end"], plan["halo"], stream)
+        tid, pos, ln = plan["send"]
+        dbuf = torch.zeros(slab_words, dtype=torch.int64, device=dev) if host_staged else buf
+        eng.slab_export(tid, pos, ln, dbuf.data_ptr(), stream)
+        eng.slab_clear(tid, pos, ln, stream)
         tstream.synchronize()          # the slab must be complete before RCCL (another stream) reads it
         if host_staged:
             buf.copy_(dbuf.cpu())
 
     def add_fn(buf):
+        tid, pos, ln = plan["recv"]
         dbuf = buf.to(dev) if host_staged else buf
         torch.cuda.synchronize()       # the received slab is complete before our stream adds it
-        eng.slab_add(0, plan["begin"], HALO, dbuf.data_ptr(), stream)
+        eng.slab_add(tid, pos, ln, dbuf.data_ptr(), stream)
         tstream.synchronize()
+
+    def exchange():
+        exchange_slabs(rank, world, plan["send"] is not None, plan["recv"] is not None, export_fn, add_fn, make_buf, dist)
 
     if world > 1:
         # warm the point-to-point path too (RCCL sets up its send/recv channels on first use: that must not land in
         # the timed region), then start from clean counters again
-        exchange_halos(rank, world, export_fn, add_fn, make_buf, dist)
+        exchange()
         eng.reset()
         dist.barrier()
     torch.cuda.synchronize()
@@ -398,7 +533,7 @@ def main():
     # The job's one exchange: each rank's halo slab goes to its right neighbour after the LAST batch (once per job, not per
     # step: a 30x genome is thousands of steps).  It runs here, right behind the K timed steps, and is timed on its own.
     t2 = time.perf_counter()
-    exchange_halos(rank, world, export_fn, add_fn, make_buf, dist)
+    exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -449,7 +584,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["what"] % dict(reads=args.reads, mb=wl.get("region", INTERVAL) / 1e6, batch=args.batch),
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(reads_all)),
-                       "sharding": "interval per GPU + halo slab to the right neighbour" if world > 1 else "single GPU",
+                       "sharding": "single GPU, one contig" if world == 1 else
+                                   ("one long contig, one interval per GPU + halo slab to the right neighbour" if args.single_contig else
+                                    "24 contigs with hg38's length ratios, %.1f Mb in all, cut into one contiguous share per GPU at 64 kb-aligned "
+                                    "positions; a halo slab goes to the right neighbour where a cut falls inside a contig (this rank: %d intervals, "
+                                    "send %s, receive %s)" % (sum(l for _, l in plan["contigs"]) / 1e6, len(plan["intervals"]),
+                                                               "yes" if plan["send"] else "no", "yes" if plan["recv"] else "no")),
                        "read_order": "caller's plan (mm_freq_plan_batch on the host, uploaded before the timed region)" if args.host_plan else
                                      "planned on the device inside every step (k_plan_items: long reads cut into parts, costliest first)",
                        "coalesce": "up to %d consecutive -K windows of the resident read set per launch (mm_freq_opts_t.coalesce)" % args.coalesce
@@ -465,18 +605,19 @@ def main():
         }
         if world > 1:
             result["final_reduce"] = {"ms": reduce_s * 1e3, "value_incl": total_bases / (elapsed + reduce_s) / 1e6, "unit": "Mbases/s",
-                                      "note": "halo slabs (%d positions x planes x 8 B) to the right neighbour, once per job after the last "
-                                              "step; timed on its own, max over ranks; value_incl = throughput if these K steps were the "
-                                              "whole job" % HALO}
+                                      "ranks": world, "slab_bytes": slab_words * 8, "backend": args.backend,
+                                      "note": "halo slabs (%d positions x planes x 8 B) to the right neighbour wherever a cut falls inside a "
+                                              "contig, once per job after the last step; timed on its own, max over ranks; value_incl = "
+                                              "throughput if these K steps were the whole job" % slab_len}
         if overlap:
             result["overlapped_streams"] = overlap
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, ref)
+            result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, refs)
         if e2e:
             result["end_to_end"] = e2e
             result["cpu_baseline_e2e"] = cpu_e2e
         if args.dump:
-            chk = minimod_amd.FreqEngine(wl["mods"], [("chrS", plan["contig_len"], ref)], device=local_rank, **wl["eng"])
+            chk = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, **wl["eng"])
             for hb in host_batches[:2]:
                 chk.process(hb)
             np.savez(args.dump, rows=chk.finalize())
@@ -565,9 +706,11 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             cores = os.cpu_count() or 1
-            orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+            orc = O.Oracle([("m", "CG")], [0.8], [n for n, _ in plan["contigs"]])
             orc.set_view(True)
-            orc.add_contig("chrS", ref)
+            for (n, _), rf in zip(plan["contigs"], ref):
+                if rf is not None:
+                    orc.add_contig(n, rf)
             tc = time.perf_counter()
             orc.process(host_batches[0], threads=cores)
             tc = time.perf_counter() - tc
@@ -584,12 +727,14 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
     return result
 
 
-def cpu_baseline(args, wl, host_batches, plan, ref):
+def cpu_baseline(args, wl, host_batches, plan, refs):
     """The oracle (bit-exact CPU restatement) timed on this host's cores over a bounded sample of the same batches."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    orc = O.Oracle([(c, x) for c, x, _ in wl["mods"]], [t for _, _, t in wl["mods"]], ["chrS"], **wl["eng"])
-    orc.add_contig("chrS", ref)
+    orc = O.Oracle([(c, x) for c, x, _ in wl["mods"]], [t for _, _, t in wl["mods"]], [n for n, _ in plan["contigs"]], **wl["eng"])
+    for (n, _), rf in zip(plan["contigs"], refs):
+        if rf is not None:
+            orc.add_contig(n, rf)
     n = args.cpu_sample_batches
     t0 = time.perf_counter()
     orc.process(host_batches[0], threads=cores)

@@ -106,3 +106,109 @@ def test_world2_interval_sharding_equals_unsharded(tmp_path):
     own0 = _oracle_rows([_reads_for(0, plans[0], ref)], ref)
     assert int((own0["pos"] >= plans[0]["end"]).sum()) > 0
     assert sorted(got) == want_l
+
+
+# ---- N > 1 as bench.py runs it by default: a genome of several contigs cut into one contiguous share per rank
+GENOME = [("chrA", 1 << 20), ("chrB", 2 << 20), ("chrC", 1 << 20)]
+
+
+def _genome_reads(rank, plan, refs):
+    import bench
+    return bench.plan_reads(plan, refs, rank, 77, 700, max_len=30000.0, median_len=3000.0)
+
+
+def _genome_oracle(batches, refs):
+    from oracle import oracle as O
+    o = O.Oracle([("m", "CG")], [0.8], [n for n, _ in GENOME])
+    for (n, _), r in zip(GENOME, refs):
+        if r is not None:
+            o.add_contig(n, r)
+    for b in batches:
+        o.process(b)
+    return o.rows()
+
+
+def _genome_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    plan = bench.genome_plan(rank, world, GENOME, HALO)
+    refs = bench.plan_references(plan, 5)
+    rows = _genome_oracle([_genome_reads(rank, plan, refs)], refs)
+    key = lambda r: (int(r["tid"]), int(r["pos"]), int(r["strand"]))
+    counts = {key(r): [int(r["n_called"]), int(r["n_mod"])] for r in rows}
+    slab_len = max([x[2] for x in (plan["send"], plan["recv"]) if x] + [0])
+
+    def make_buf():
+        return torch.zeros(2 * 2 * slab_len, dtype=torch.int64)
+
+    def export_fn(buf):                      # the counters past my right edge leave with the slab
+        tid, pos, ln = plan["send"]
+        a = buf.numpy().reshape(2, 2, slab_len)
+        for k in [k for k in counts if k[0] == tid and pos <= k[1] < pos + ln]:
+            a[k[2], :, k[1] - pos] = counts.pop(k)
+
+    def add_fn(buf):
+        tid, pos, ln = plan["recv"]
+        a = buf.numpy().reshape(2, 2, slab_len)
+        for strand, off in zip(*np.nonzero(a[:, 0, :])):
+            c = counts.setdefault((tid, pos + int(off), int(strand)), [0, 0])
+            c[0] += int(a[strand, 0, off]); c[1] += int(a[strand, 1, off])
+
+    bench.exchange_slabs(rank, world, plan["send"] is not None, plan["recv"] is not None, export_fn, add_fn, make_buf, dist)
+    # what is left must lie inside my intervals
+    for (tid, pos, _s) in counts:
+        assert any(iv["tid"] == tid and iv["begin"] <= pos < iv["end"] for iv in plan["intervals"]), (rank, tid, pos)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), np.array([k + tuple(v) for k, v in counts.items()], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_genome_plan_partitions_the_contigs():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        for contigs in (GENOME, bench.genome_layout(world, 8 << 20)):
+            plans = [bench.genome_plan(r, world, contigs) for r in range(world)]
+            covered = {}
+            for p in plans:
+                for iv in p["intervals"]:
+                    assert iv["begin"] % bench.CUT_ALIGN == 0 and iv["begin"] < iv["end"] <= contigs[iv["tid"]][1]
+                    covered.setdefault(iv["tid"], []).append((iv["begin"], iv["end"]))
+            for tid, (_n, l) in enumerate(contigs):       # every contig tiled exactly once, in order
+                ivs = sorted(covered[tid])
+                assert ivs[0][0] == 0 and ivs[-1][1] == l and all(a[1] == b[0] for a, b in zip(ivs, ivs[1:]))
+            for a, b in zip(plans, plans[1:]):            # a cut inside a contig: left sends what right receives
+                assert (a["send"] is None) == (b["recv"] is None)
+                if a["send"]:
+                    assert a["send"] == b["recv"] and a["intervals"][-1]["halo"] == a["send"][2] > 0
+            assert plans[0]["recv"] is None and plans[-1]["send"] is None
+
+
+@pytest.mark.timeout(300)
+def test_world2_genome_sharding_equals_unsharded(tmp_path):
+    """Two ranks own contiguous shares of a three-contig genome; the cut falls inside chrB, so rank 0's calls past it travel
+    to rank 1 as a halo slab (bench.exchange_slabs over gloo); union == unsharded oracle."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mp.spawn(_genome_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import bench
+    plans = [bench.genome_plan(r, world, GENOME, HALO) for r in range(world)]
+    assert plans[0]["send"] == (1, 1 << 20, HALO) == plans[1]["recv"]
+    refs_all = [bench.plan_references(p, 5) for p in plans]
+    refs = [a if a is not None else b for a, b in zip(*refs_all)]
+    for t in range(len(GENOME)):             # the two ranks' pieces of chrB are slices of one synthetic contig
+        if refs_all[0][t] is not None and refs_all[1][t] is not None:
+            refs[t] = np.where(refs_all[0][t] != ord("N"), refs_all[0][t], refs_all[1][t])
+    want = _genome_oracle([_genome_reads(r, plans[r], refs_all[r]) for r in range(world)], refs)
+    want_l = sorted(zip(want["tid"].tolist(), want["pos"].tolist(), want["strand"].tolist(), want["n_called"].tolist(), want["n_mod"].tolist()))
+    got = []
+    for r in range(world):
+        got += [tuple(x) for x in np.load(str(tmp_path / ("g%d.npy" % r))).tolist()]
+    own0 = _genome_oracle([_genome_reads(0, plans[0], refs_all[0])], refs_all[0])
+    assert int(((own0["tid"] == 1) & (own0["pos"] >= (1 << 20))).sum()) > 0      # rank 0 really has calls past the cut
+    assert len(want_l) > 1000 and sorted(got) == want_l
