@@ -452,7 +452,8 @@ void mm_bam_release(mm_bam_t *b) {
     b->n_spills = k;
 }
 
-mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
+/* open the file and start the producer at compressed offset `coffset` (the start of a BGZF block) */
+static mm_bam_t *reader_start(const char *path, mm_pool_t *pool, uint64_t coffset) {
     FILE *fp = fopen(path, "rb");
     if (!fp) return NULL;
     mm_bam_t *b = (mm_bam_t *)calloc(1, sizeof(*b));
@@ -470,45 +471,131 @@ mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
             }
         }
     }
+    if (coffset) {
+        if (b->map) { if (coffset > b->map_len) coffset = b->map_len; b->map_pos = (size_t)coffset; }
+        else if (fseeko(fp, (off_t)coffset, SEEK_SET) != 0) { fclose(fp); free(b); return NULL; }
+    }
     pthread_mutex_init(&b->mu, NULL);
     pthread_cond_init(&b->cv_ready, NULL);
     pthread_cond_init(&b->cv_room, NULL);
     if (pthread_create(&b->producer, NULL, producer_main, b) != 0) { mm_bam_close(b); return NULL; }
     b->producer_started = 1;
-    /* header */
-    if (want(b, 12) != 1 || memcmp(b->p, "BAM\1", 4) != 0) { mm_bam_close(b); return NULL; }
+    return b;
+}
+
+static int read_header(mm_bam_t *b) {
+    if (want(b, 12) != 1 || memcmp(b->p, "BAM\1", 4) != 0) return -1;
     uint32_t l_text = rd_u32(b->p + 4);
-    if (want(b, 12 + (size_t)l_text) != 1) { mm_bam_close(b); return NULL; }
+    if (want(b, 12 + (size_t)l_text) != 1) return -1;
     b->p += 8 + l_text;
     int32_t n_ref = (int32_t)rd_u32(b->p);
     b->p += 4;
-    if (n_ref < 0) { mm_bam_close(b); return NULL; }
+    if (n_ref < 0) return -1;
     b->hdr.n_targets = n_ref;
     b->hdr.target_name = (char **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char *));
     b->hdr.target_len = (uint32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint32_t));
-    if (!b->hdr.target_name || !b->hdr.target_len) { b->hdr.n_targets = 0; mm_bam_close(b); return NULL; }
+    if (!b->hdr.target_name || !b->hdr.target_len) { b->hdr.n_targets = 0; return -1; }
     for (int32_t i = 0; i < n_ref; i++) {
-        if (want(b, 4) != 1) { mm_bam_close(b); return NULL; }
+        if (want(b, 4) != 1) return -1;
         uint32_t l_name = rd_u32(b->p);
-        if (want(b, 8 + (size_t)l_name) != 1) { mm_bam_close(b); return NULL; }
+        if (want(b, 8 + (size_t)l_name) != 1) return -1;
         b->hdr.target_name[i] = (char *)malloc((size_t)l_name + 1);
-        if (!b->hdr.target_name[i]) { mm_bam_close(b); return NULL; }
+        if (!b->hdr.target_name[i]) return -1;
         memcpy(b->hdr.target_name[i], b->p + 4, l_name);
         b->hdr.target_name[i][l_name] = 0;
         b->hdr.target_len[i] = rd_u32(b->p + 4 + l_name);
         b->p += 8 + l_name;
     }
+    return 0;
+}
+
+mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
+    mm_bam_t *b = reader_start(path, pool, 0);
+    if (!b) return NULL;
+    if (read_header(b) != 0) { mm_bam_close(b); return NULL; }
     mm_bam_release(b);
     return b;
 }
 
-mm_bam_t *mm_bam_open(const char *path, int n_threads) {
+/* the reader positioned on the record at virtual offset `voffset` (compressed block offset << 16 | offset inside the
+ * decoded block, as a .bai gives it); 0 = the first record.  The header is read from the start of the file first. */
+mm_bam_t *mm_bam_open_pool_at(const char *path, mm_pool_t *pool, uint64_t voffset) {
+    if (voffset == 0) return mm_bam_open_pool(path, pool);
+    mm_bam_t *h = mm_bam_open_pool(path, pool);
+    if (!h) return NULL;
+    mm_bam_t *b = reader_start(path, pool, voffset >> 16);
+    if (!b) { mm_bam_close(h); return NULL; }
+    b->hdr = h->hdr;                       /* the header moves over */
+    memset(&h->hdr, 0, sizeof h->hdr);
+    mm_bam_close(h);
+    const size_t skip = (size_t)(voffset & 0xFFFF);
+    if (skip) {
+        if (want(b, skip) != 1) { mm_bam_close(b); return NULL; }
+        b->p += skip;
+    }
+    mm_bam_release(b);
+    return b;
+}
+
+mm_bam_t *mm_bam_open_at(const char *path, int n_threads, uint64_t voffset) {
     mm_pool_t *pool = mm_pool_create(n_threads);
     if (!pool) return NULL;
-    mm_bam_t *b = mm_bam_open_pool(path, pool);
+    mm_bam_t *b = mm_bam_open_pool_at(path, pool, voffset);
     if (!b) { mm_pool_destroy(pool); return NULL; }
     b->own_pool = 1;
     return b;
+}
+mm_bam_t *mm_bam_open(const char *path, int n_threads) { return mm_bam_open_at(path, n_threads, 0); }
+
+/* ------------------------------------------------------------------ .bai (SAM specification section 5.2): the linear index */
+mm_bai_t *mm_bai_load(const char *path) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return NULL;
+    mm_bai_t *x = (mm_bai_t *)calloc(1, sizeof(*x));
+    uint8_t m[8];
+    int ok = x && fread(m, 1, 8, fp) == 8 && memcmp(m, "BAI\1", 4) == 0;
+    int32_t n_ref = ok ? (int32_t)rd_u32(m + 4) : 0;
+    if (ok && (n_ref < 0 || n_ref > (1 << 24))) ok = 0;
+    if (ok) {
+        x->n_ref = n_ref;
+        x->n_intv = (int32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(int32_t));
+        x->ioffset = (uint64_t **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint64_t *));
+        ok = x->n_intv && x->ioffset;
+    }
+    for (int32_t t = 0; ok && t < n_ref; t++) {
+        if (fread(m, 1, 4, fp) != 4) { ok = 0; break; }
+        int32_t n_bin = (int32_t)rd_u32(m);
+        for (int32_t k = 0; ok && k < n_bin; k++) {          /* the bins are skipped: only the linear index is used */
+            if (fread(m, 1, 8, fp) != 8) { ok = 0; break; }
+            int32_t n_chunk = (int32_t)rd_u32(m + 4);
+            if (n_chunk < 0 || fseeko(fp, (off_t)16 * n_chunk, SEEK_CUR) != 0) ok = 0;
+        }
+        if (!ok || fread(m, 1, 4, fp) != 4) { ok = 0; break; }
+        int32_t n_intv = (int32_t)rd_u32(m);
+        if (n_intv < 0) { ok = 0; break; }
+        x->n_intv[t] = n_intv;
+        x->ioffset[t] = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_intv > 0 ? n_intv : 1));
+        if (!x->ioffset[t] || fread(x->ioffset[t], 8, (size_t)n_intv, fp) != (size_t)n_intv) { ok = 0; break; }
+    }
+    fclose(fp);
+    if (!ok) { mm_bai_free(x); return NULL; }
+    return x;
+}
+void mm_bai_free(mm_bai_t *x) {
+    if (!x) return;
+    if (x->ioffset) for (int32_t t = 0; t < x->n_ref; t++) free(x->ioffset[t]);
+    free(x->ioffset); free(x->n_intv); free(x);
+}
+/* where to start reading for alignments that START at or after (tid, pos): the smallest virtual offset the linear index
+ * gives for that window or, when nothing overlaps it, for the next window anything overlaps (on this or a later
+ * reference).  Records in front of (tid, pos) may follow from there: the caller skips them.  UINT64_MAX = nothing left. */
+uint64_t mm_bai_start(const mm_bai_t *x, int32_t tid, int64_t pos) {
+    if (tid < 0) tid = 0, pos = 0;
+    for (int32_t t = tid; t < x->n_ref; t++) {
+        int64_t w0 = t == tid ? pos >> 14 : 0;
+        for (int64_t w = w0; w < x->n_intv[t]; w++) if (x->ioffset[t][w]) return x->ioffset[t][w];
+    }
+    return UINT64_MAX;
 }
 
 mm_pool_t *mm_bam_pool(mm_bam_t *b) { return b->pool; }

@@ -40,6 +40,15 @@ void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int6
 
 mm_bam_t *mm_bam_open(const char *path, int n_threads);        /* with its own pool of n_threads workers */
 mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool);  /* on a pool the caller owns */
+/* positioned readers: start at the record at virtual offset `voffset` of a .bai (0 = the first record) */
+mm_bam_t *mm_bam_open_at(const char *path, int n_threads, uint64_t voffset);
+mm_bam_t *mm_bam_open_pool_at(const char *path, mm_pool_t *pool, uint64_t voffset);
+/* the linear index of a .bai (the reference never reads an index: its region code is commented out, src/minimod.c:92-130;
+ * here it lets every GPU's worker start at its share of the file) */
+typedef struct mm_bai { int32_t n_ref; int32_t *n_intv; uint64_t **ioffset; } mm_bai_t;
+mm_bai_t *mm_bai_load(const char *bai_path);
+void mm_bai_free(mm_bai_t *x);
+uint64_t mm_bai_start(const mm_bai_t *x, int32_t tid, int64_t pos);   /* UINT64_MAX: nothing at or after (tid, pos) */
 mm_pool_t *mm_bam_pool(mm_bam_t *b);
 /* record views handed out since the last release are no longer needed: their buffers may be reused */
 void mm_bam_release(mm_bam_t *b);

@@ -4,9 +4,11 @@
  * pipeline (freq_main.c:404-474): the batch is handed to mm_freq_submit (H2D + kernels, asynchronous) and the next
  * batch is decoded meanwhile.  view prints a batch's rows when the batch is retired (print_view_output per db_t,
  * src/view_main.c:142-160); freq prints once at the end. */
+#include <errno.h>
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "mmhost.h"
@@ -30,6 +32,7 @@ static struct option long_options[] = {
     {"include-non-ref", no_argument, 0, 0},        /* 15 */
     {"skip-supplementary", no_argument, 0, 0},     /* 16 */
     {"device", required_argument, 0, 0},           /* 17 (new: HIP device ordinal) */
+    {"devices", required_argument, 0, 0},          /* 18 (new: one worker process per listed GPU, the genome cut into shares) */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -55,9 +58,26 @@ static struct option view_long_options[] = {
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
     int progress_interval, device, view;
-    const char *codes, *threshes, *out_path;
+    const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
+
+/* one worker of `--devices`: its share of the genome and where its rows go */
+#define MMH_MAX_DEVICES 64
+#define MMH_SHARE_HALO ((int64_t)1 << 18)     /* counters kept past a cut inside a contig (a read's calls reach that far at most) */
+#define MMH_SHARE_ALIGN ((int64_t)1 << 16)
+typedef struct {
+    int sharded, first, last, fd;          /* fd: pipe to the parent (rows + totals) */
+    int n_iv;
+    mm_interval_t iv[64];                  /* dense counters: the share's intervals (+ halo behind a cut) */
+    int32_t lo_tid, hi_tid; int64_t lo_pos, hi_pos;
+    uint64_t voffset;
+} wspec_t;
+typedef struct {                           /* what a worker reports besides its rows */
+    int64_t n_rows;
+    uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
+    double load_time, wait_time, sort_time;
+} wtotals_t;
 
 static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "Usage: minimod %s ref.fa reads.bam\n", o->view ? "view" : "freq");
@@ -80,6 +100,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "\nadvanced options:\n");
     fprintf(fp, "   --debug-break INT          break after processing the specified no. of batches\n");
     fprintf(fp, "   --device INT               GPU to use [%d]\n", o->device);
+    if (!o->view) fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
@@ -160,89 +181,37 @@ static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, cons
     *output_time += mmh_realtime() - to;
 }
 
-static int run_main(int argc, char **argv, int view) {
-    double realtime0 = mmh_realtime();
-    const char *optstring = view ? "c:t:B:K:v:p:o:hV" : "m:c:t:B:K:v:p:o:hVb";   /* src/view_main.c:168, src/freq_main.c:185 */
-    const struct option *lopts = view ? view_long_options : long_options;
-    int longindex = 0, c;
-    FILE *fp_help = stderr;
-    fopt_t o;
-    memset(&o, 0, sizeof(o));
-    o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    o.view = view;
-    while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
-        const char *lname = c == 0 ? lopts[longindex].name : "";
-        if (c == 'B') {
-            o.B = mmh_parse_num(optarg);
-            if (o.B <= 0) { MMH_ERROR("%s", "Maximum number of bases should be larger than 0."); exit(EXIT_FAILURE); }
-        } else if (c == 'K') {
-            o.K = atoi(optarg);
-            if (o.K < 1) { MMH_ERROR("Batch size should larger than 0. You entered %d", o.K); exit(EXIT_FAILURE); }
-        } else if (c == 't') {
-            o.threads = atoi(optarg);
-            if (o.threads < 1) { MMH_ERROR("Number of threads should larger than 0. You entered %d", o.threads); exit(EXIT_FAILURE); }
-        } else if (c == 'v') {
-            mmh_log_level = atoi(optarg);
-        } else if (c == 'p') {
-            if (atoi(optarg) < 0) { MMH_ERROR("Progress interval should be 0 or positive. You entered %d", atoi(optarg)); exit(EXIT_FAILURE); }
-            o.progress_interval = atoi(optarg);
-        } else if (c == 'o') {
-            FILE *fp = fopen(optarg, "w");
-            if (fp == NULL) { MMH_ERROR("Cannot open file %s for writing", optarg); exit(EXIT_FAILURE); }
-            o.out_path = optarg; o.out = fp;
-        } else if (c == 'V') {
-            fprintf(stdout, "minimod %s\n", MMH_VERSION);
-            exit(EXIT_SUCCESS);
-        } else if (c == 'h') {
-            fp_help = stdout;
-        } else if (c == 'm') {
-            o.threshes = optarg;
-        } else if (c == 'c') {
-            o.codes = optarg;
-        } else if (c == 'b') {
-            o.bedmethyl = 1;
-        } else if (c == 0 && strcmp(lname, "debug-break") == 0) { o.debug_break = atoi(optarg);
-        } else if (c == 0 && strcmp(lname, "insertions") == 0) { o.insertions = 1;
-        } else if (c == 0 && strcmp(lname, "haplotypes") == 0) { o.haplotypes = 1;
-        } else if (c == 0 && strcmp(lname, "allow-secondary") == 0) { o.allow_secondary = 1;
-        } else if (c == 0 && strcmp(lname, "include-non-ref") == 0) { /* accepted and ignored like the reference */
-        } else if (c == 0 && strcmp(lname, "skip-supplementary") == 0) { o.skip_supplementary = 1;
-        } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
-        } else {
-            print_help(fp_help, &o);
-            exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
-        }
+static int write_all(int fd, const void *buf, size_t n) {
+    const char *p = (const char *)buf;
+    while (n) {
+        ssize_t k = write(fd, p, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n);
+        if (k < 0) { if (errno == EINTR) continue; return -1; }
+        p += k; n -= (size_t)k;
     }
+    return 0;
+}
+static int read_all(int fd, void *buf, size_t n) {
+    char *p = (char *)buf;
+    while (n) {
+        ssize_t k = read(fd, p, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n);
+        if (k < 0) { if (errno == EINTR) continue; return -1; }
+        if (k == 0) return -1;
+        p += k; n -= (size_t)k;
+    }
+    return 0;
+}
+
+/* Everything behind option parsing and the reference load: the batches of one BAM (or of one share of it) through one
+ * GPU.  A single run prints its rows; a worker of `--devices` sends them to the parent, which merges and prints. */
+static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
+    const fopt_t o = *op;
+    const mmh_mods_t mods = *modsp;
+    const int view = o.view;
     char err[512];
-    mmh_mods_t mods;
-    if (o.codes == NULL || strlen(o.codes) == 0) {
-        MMH_INFO("%s", "Modification codes not provided. Using default modification code m");
-        o.codes = "m";
-    }
-    if (mmh_parse_mod_codes(o.codes, &mods, err, sizeof err)) { MMH_ERROR("%s", err); exit(EXIT_FAILURE); }
-    char defthr[MM_MAX_MODS * 4 + 1];
-    if (o.threshes == NULL || strlen(o.threshes) == 0) {
-        if (!view) MMH_INFO("%s", "Modification threshold not provided. Using default threshold 0.8");   /* view has no thresholds */
-        defthr[0] = 0;
-        for (int i = 0; i < mods.n_mods; i++) { strcat(defthr, "0.8"); if (i < mods.n_mods - 1) strcat(defthr, ","); }
-        o.threshes = defthr;
-    }
-    if (mmh_parse_mod_threshes(o.threshes, &mods, err, sizeof err)) { MMH_ERROR("%s", err); exit(EXIT_FAILURE); }
-    if (argc - optind != 2 || fp_help == stdout) {
-        MMH_WARNING("%s", "Missing arguments");
-        print_help(fp_help, &o);
-        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
-    }
-    const char *ref_file = argv[optind], *bam_file = argv[optind + 1];
-    if (access(bam_file, F_OK) == -1) { MMH_ERROR("BAM file %s does not exist", bam_file); exit(EXIT_FAILURE); }
-
-    double t1 = mmh_realtime();
-    fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);
-    mmh_ref_t *ref = mmh_load_ref(ref_file);
-    if (!ref) { MMH_ERROR("Could not to open file %s", ref_file); exit(EXIT_FAILURE); }
-    fprintf(stderr, "[%s] Reference genome loaded in %.3f sec\n", __func__, mmh_realtime() - t1);
-
-    mmh_loader_t *ld = mmh_loader_open(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary);
+    mmh_loader_t *ld = ws->sharded
+        ? mmh_loader_open_share(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
+                                ws->hi_tid, ws->hi_pos, ws->first, ws->last)
+        : mmh_loader_open(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary);
     if (!ld) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
     const mm_bam_hdr_t *hdr = mm_bam_header(ld->bam);
 
@@ -258,7 +227,7 @@ static int run_main(int argc, char **argv, int view) {
     mm_freq_opts_t fo;
     mmh_fill_opts(&mods, o.insertions, o.haplotypes, o.device, &fo);
     fo.view = view;
-    mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
+    mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     free(ctg);
     mmh_free_ref(ref);   /* the reference now lives in HBM */
@@ -266,8 +235,10 @@ static int run_main(int argc, char **argv, int view) {
     int wildcard = 0;
     for (int i = 0; i < mods.n_mods; i++) if (strcmp(mods.code[i], "*") == 0) wildcard = 1;
 
-    if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
-    else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
+    if (ws->fd < 0) {
+        if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
+        else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
+    }
 
     double load_time = 0, process_wait_time = 0, output_time = 0;
     int more = 1, counter = 0, set = 0;
@@ -316,6 +287,21 @@ static int run_main(int argc, char **argv, int view) {
         int64_t nrows = mm_freq_finalize(h, &rows);
         if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
         sort_time = mmh_realtime() - ts;
+        if (ws->fd >= 0) {   /* a worker: rows and totals go to the parent */
+            wtotals_t tt;
+            memset(&tt, 0, sizeof tt);
+            tt.n_rows = nrows; tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
+            tt.processed_bytes = ld->processed_bytes; tt.processed_bases = ld->processed_bases;
+            tt.load_time = load_time; tt.wait_time = process_wait_time; tt.sort_time = sort_time;
+            if (write_all(ws->fd, &tt, sizeof tt) || write_all(ws->fd, rows, sizeof(mm_row_t) * (size_t)nrows)) {
+                MMH_ERROR("%s", "Could not send the rows to the parent process");
+                exit(EXIT_FAILURE);
+            }
+            close(ws->fd);
+            mm_freq_destroy(h);
+            mmh_loader_close(ld);
+            return 0;
+        }
         double to = mmh_realtime();
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
@@ -343,6 +329,294 @@ static int run_main(int argc, char **argv, int view) {
     mm_freq_destroy(h);
     mmh_loader_close(ld);
     return 0;
+}
+
+
+/* ---- `minimod freq --devices a,b,...`: the genome (BAM-header contigs that the FASTA has, in header order) is cut into one
+ * contiguous share per GPU at 64 kb-aligned positions; a read belongs to the share its start
+ * position lies in.  The parent forks one worker per GPU BEFORE anything touches HIP (it never does itself); a worker
+ * opens the BAM at the virtual offset the .bai gives for its share, counts into dense planes over its intervals (a halo
+ * behind a cut inside a contig) and sends its rows to the parent, which adds up the rows both neighbours have for the
+ * positions behind a cut, puts the contigs in output order and prints. */
+typedef struct { const mm_row_t *rows; int64_t n; } rowrun_t;
+
+static int row_key_cmp(const mm_row_t *a, const mm_row_t *b) {   /* within one contig: mm_freq_finalize's order */
+    if (a->pos != b->pos) return a->pos < b->pos ? -1 : 1;
+    if (a->strand != b->strand) return a->strand < b->strand ? -1 : 1;
+    if (a->code != b->code) return a->code < b->code ? -1 : 1;
+    if (a->ins_offset != b->ins_offset) return a->ins_offset < b->ins_offset ? -1 : 1;
+    int ha = a->hp < 0 ? 100000 : a->hp, hb = b->hp < 0 ? 100000 : b->hp;
+    return ha < hb ? -1 : (ha > hb);
+}
+
+static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, const char *bam_file, double realtime0) {
+    if (o->view) { MMH_ERROR("%s", "--devices is a freq option"); exit(EXIT_FAILURE); }
+    for (int i = 0; i < mods->n_mods; i++)
+        if (strcmp(mods->code[i], "*") == 0) { MMH_ERROR("%s", "--devices cannot be combined with the wildcard code -c '*' (code indices are per worker)"); exit(EXIT_FAILURE); }
+    int dev[MMH_MAX_DEVICES], nd = 0;
+    for (const char *p = o->devices; *p && nd < MMH_MAX_DEVICES;) {
+        dev[nd++] = atoi(p);
+        const char *c = strchr(p, ',');
+        if (!c) break;
+        p = c + 1;
+    }
+    if (nd < 2) { MMH_ERROR("%s", "--devices needs at least two GPUs"); exit(EXIT_FAILURE); }
+    char bai_path[4096];
+    snprintf(bai_path, sizeof bai_path, "%s.bai", bam_file);
+    mm_bai_t *bai = mm_bai_load(bai_path);
+    if (!bai) { MMH_ERROR("Could not read the index %s (--devices needs it: samtools index reads.bam)", bai_path); exit(EXIT_FAILURE); }
+    mm_bam_t *hb = mm_bam_open(bam_file, 1);
+    if (!hb) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
+    const mm_bam_hdr_t *hdr = mm_bam_header(hb);
+    const int nt = hdr->n_targets;
+    /* the genome to share: contigs the FASTA has; the others cannot carry reads (src/mod.c:793) */
+    int64_t *off = (int64_t *)calloc((size_t)nt + 1, sizeof(int64_t));
+    int *has = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int64_t total = 0;
+    for (int t = 0; t < nt; t++) {
+        off[t] = total;
+        has[t] = mmh_ref_find(ref, hdr->target_name[t]) >= 0;
+        if (has[t]) total += hdr->target_len[t];
+    }
+    off[nt] = total;
+    if (total <= 0) { MMH_ERROR("%s", "No contig of the BAM header is in the reference"); exit(EXIT_FAILURE); }
+    wspec_t *ws = (wspec_t *)calloc((size_t)nd, sizeof(wspec_t));
+    for (int r = 0; r < nd; r++) {
+        wspec_t *w = &ws[r];
+        int64_t lo = r == 0 ? 0 : (total / nd * r) / MMH_SHARE_ALIGN * MMH_SHARE_ALIGN;
+        int64_t hi = r == nd - 1 ? total : (total / nd * (r + 1)) / MMH_SHARE_ALIGN * MMH_SHARE_ALIGN;
+        w->sharded = 1; w->first = r == 0; w->last = r == nd - 1; w->fd = -1;
+        w->lo_tid = -1; w->hi_tid = nt; w->hi_pos = 0;
+        for (int t = 0; t < nt; t++) {
+            if (!has[t]) continue;
+            int64_t b = lo > off[t] ? lo : off[t], e = hi < off[t] + hdr->target_len[t] ? hi : off[t] + (int64_t)hdr->target_len[t];
+            if (b >= e) continue;
+            if (w->n_iv >= 64) { MMH_ERROR("%s", "too many contigs in one share"); exit(EXIT_FAILURE); }
+            mm_interval_t *iv = &w->iv[w->n_iv++];
+            iv->tid = t; iv->begin = b - off[t]; iv->end = e - off[t]; iv->halo = 0;
+            if (w->lo_tid < 0) { w->lo_tid = t; w->lo_pos = iv->begin; }
+            w->hi_tid = t; w->hi_pos = iv->end;
+            if (iv->end < (int64_t)hdr->target_len[t]) iv->halo = MMH_SHARE_HALO;   /* the cut is inside the contig */
+        }
+        if (w->n_iv == 0) { w->lo_tid = nt; w->lo_pos = 0; w->hi_tid = nt; w->hi_pos = 0; w->voffset = UINT64_MAX; }
+        else w->voffset = w->first ? 0 : mm_bai_start(bai, w->lo_tid, w->lo_pos);
+        if (w->first) { w->lo_tid = -1; w->lo_pos = 0; }
+    }
+    mm_bai_free(bai);
+    /* the workers: forked before anything in this process has touched HIP */
+    pid_t pid[MMH_MAX_DEVICES];
+    int rfd[MMH_MAX_DEVICES];
+    fflush(NULL);
+    for (int r = 0; r < nd; r++) {
+        int pp[2];
+        if (pipe(pp) != 0) { MMH_ERROR("%s", "pipe failed"); exit(EXIT_FAILURE); }
+        pid[r] = fork();
+        if (pid[r] < 0) { MMH_ERROR("%s", "fork failed"); exit(EXIT_FAILURE); }
+        if (pid[r] == 0) {
+            close(pp[0]);
+            for (int q = 0; q < r; q++) close(rfd[q]);
+            fopt_t wo = *o;
+            wo.device = dev[r];
+            wo.threads = o->threads / nd > 0 ? o->threads / nd : 1;
+            ws[r].fd = pp[1];
+            int rc = run_body(&wo, mods, ref, bam_file, realtime0, &ws[r]);
+            fflush(NULL);
+            _exit(rc);
+        }
+        close(pp[1]);
+        rfd[r] = pp[0];
+    }
+    mmh_free_ref(ref);
+    /* the rows of every worker, in rank order */
+    wtotals_t tot[MMH_MAX_DEVICES];
+    mm_row_t *wrows[MMH_MAX_DEVICES];
+    int failed = 0;
+    for (int r = 0; r < nd; r++) {
+        wrows[r] = NULL;
+        memset(&tot[r], 0, sizeof tot[r]);
+        if (read_all(rfd[r], &tot[r], sizeof tot[r]) != 0) failed = 1;
+        else {
+            wrows[r] = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(tot[r].n_rows > 0 ? tot[r].n_rows : 1));
+            if (!wrows[r] || read_all(rfd[r], wrows[r], sizeof(mm_row_t) * (size_t)tot[r].n_rows) != 0) failed = 1;
+        }
+        close(rfd[r]);
+    }
+    for (int r = 0; r < nd; r++) {
+        int st = 0;
+        if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1;
+    }
+    if (failed) { MMH_ERROR("%s", "A worker of --devices failed"); exit(EXIT_FAILURE); }
+    double ts = mmh_realtime();
+    /* per contig, the workers' runs in rank order (= position order); neighbours overlap only in the halo behind a cut */
+    int64_t n_all = 0;
+    for (int r = 0; r < nd; r++) n_all += tot[r].n_rows;
+    mm_row_t *out_rows = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_all > 0 ? n_all : 1));
+    int *order = (int *)malloc(sizeof(int) * (size_t)(nt > 0 ? nt : 1));
+    for (int t = 0; t < nt; t++) order[t] = t;
+    for (int a = 1; a < nt; a++) {   /* contigs by name like cmp_key_fast (src/mod.c:59-76); insertion sort keeps header order among equal names */
+        int x = order[a], b = a - 1;
+        while (b >= 0 && strcmp(hdr->target_name[order[b]], hdr->target_name[x]) > 0) { order[b + 1] = order[b]; b--; }
+        order[b + 1] = x;
+    }
+    int64_t n_out = 0;
+    for (int k = 0; k < nt; k++) {
+        const int t = order[k];
+        const int64_t contig_start = n_out;
+        for (int r = 0; r < nd; r++) {
+            /* worker r's rows of contig t are contiguous (its rows come sorted by contig, then position) */
+            int64_t a = 0, n = tot[r].n_rows;
+            while (a < n && wrows[r][a].tid != t) a++;   /* few contigs per worker: a linear look is fine ... */
+            int64_t b = a;
+            while (b < n && wrows[r][b].tid == t) b++;
+            if (a == b) continue;
+            /* merge run [a, b) behind what the contig has so far: only the tail of the output can overlap it */
+            int64_t lo = n_out;
+            while (lo > contig_start && row_key_cmp(&out_rows[lo - 1], &wrows[r][a]) >= 0) lo--;
+            if (lo == n_out) { memcpy(out_rows + n_out, wrows[r] + a, sizeof(mm_row_t) * (size_t)(b - a)); n_out += b - a; continue; }
+            int64_t n_tail = n_out - lo;
+            mm_row_t *tail = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)n_tail);
+            memcpy(tail, out_rows + lo, sizeof(mm_row_t) * (size_t)n_tail);
+            int64_t i = 0, j = a, w = lo;
+            while (i < n_tail || j < b) {
+                int c = i >= n_tail ? 1 : (j >= b ? -1 : row_key_cmp(&tail[i], &wrows[r][j]));
+                if (c == 0) { mm_row_t m = tail[i++]; m.n_called += wrows[r][j].n_called; m.n_mod += wrows[r][j].n_mod; j++; out_rows[w++] = m; }
+                else if (c < 0) out_rows[w++] = tail[i++];
+                else out_rows[w++] = wrows[r][j++];
+            }
+            free(tail);
+            n_out = w;
+        }
+    }
+    for (int r = 0; r < nd; r++) free(wrows[r]);
+    double sort_time = mmh_realtime() - ts;
+    double to = mmh_realtime();
+    mm_pool_t *pool = mm_pool_create(o->threads);
+    const char *codes[MM_MAX_MODS];
+    for (int i = 0; i < mods->n_mods; i++) codes[i] = mods->code[i];
+    mmh_print_freq_header(o->out, o->bedmethyl, o->insertions, o->haplotypes);
+    mmh_print_freq_rows(o->out, pool, out_rows, n_out, hdr, codes, mods->n_mods, o->bedmethyl, o->insertions, o->haplotypes);
+    if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+    if (o->out != stdout) fclose(o->out);
+    else fflush(stdout);
+    double output_time = mmh_realtime() - to;
+    wtotals_t s;
+    memset(&s, 0, sizeof s);
+    for (int r = 0; r < nd; r++) {
+        s.total_reads += tot[r].total_reads; s.total_bytes += tot[r].total_bytes; s.processed_reads += tot[r].processed_reads;
+        s.processed_bytes += tot[r].processed_bytes; s.processed_bases += tot[r].processed_bases;
+        if (tot[r].load_time > s.load_time) s.load_time = tot[r].load_time;
+        if (tot[r].wait_time > s.wait_time) s.wait_time = tot[r].wait_time;
+        if (tot[r].sort_time > s.sort_time) s.sort_time = tot[r].sort_time;
+    }
+    fprintf(stderr, "[%s] devices: %d (one worker process each, shares of %.1f Mb)", __func__, nd, total / (double)nd / 1e6);
+    fprintf(stderr, "\n[%s] total entries: %ld", __func__, (long)s.total_reads);
+    fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, s.total_bytes / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(s.total_reads - s.processed_reads));
+    fprintf(stderr, "\n[%s] total skipped bytes: %.1f M", __func__, (s.total_bytes - s.processed_bytes) / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total processed entries: %ld", __func__, (long)s.processed_reads);
+    fprintf(stderr, "\n[%s] total processed bytes: %.1f M", __func__, s.processed_bytes / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total processed bases: %.1f M", __func__, s.processed_bases / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] Data loading time: %.3f sec (slowest worker)", __func__, s.load_time);
+    fprintf(stderr, "\n[%s] Data processing time: %.3f sec (slowest worker waiting for its GPU)", __func__, s.wait_time);
+    fprintf(stderr, "\n[%s] Data merging time: %.3f sec (rows of the workers put together)", __func__, sort_time);
+    fprintf(stderr, "\n[%s] Data sorting time: %.3f sec (slowest worker's finalize)", __func__, s.sort_time);
+    fprintf(stderr, "\n[%s] Data output time: %.3f sec", __func__, output_time);
+    fprintf(stderr, "\n");
+    (void)realtime0;
+    free(out_rows); free(order); free(off); free(has); free(ws);
+    mm_pool_destroy(pool);
+    mm_bam_close(hb);
+    return 0;
+}
+
+static int run_main(int argc, char **argv, int view) {
+    double realtime0 = mmh_realtime();
+    const char *optstring = view ? "c:t:B:K:v:p:o:hV" : "m:c:t:B:K:v:p:o:hVb";   /* src/view_main.c:168, src/freq_main.c:185 */
+    const struct option *lopts = view ? view_long_options : long_options;
+    int longindex = 0, c;
+    FILE *fp_help = stderr;
+    fopt_t o;
+    memset(&o, 0, sizeof(o));
+    o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
+    o.view = view;
+    while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
+        const char *lname = c == 0 ? lopts[longindex].name : "";
+        if (c == 'B') {
+            o.B = mmh_parse_num(optarg);
+            if (o.B <= 0) { MMH_ERROR("%s", "Maximum number of bases should be larger than 0."); exit(EXIT_FAILURE); }
+        } else if (c == 'K') {
+            o.K = atoi(optarg);
+            if (o.K < 1) { MMH_ERROR("Batch size should larger than 0. You entered %d", o.K); exit(EXIT_FAILURE); }
+        } else if (c == 't') {
+            o.threads = atoi(optarg);
+            if (o.threads < 1) { MMH_ERROR("Number of threads should larger than 0. You entered %d", o.threads); exit(EXIT_FAILURE); }
+        } else if (c == 'v') {
+            mmh_log_level = atoi(optarg);
+        } else if (c == 'p') {
+            if (atoi(optarg) < 0) { MMH_ERROR("Progress interval should be 0 or positive. You entered %d", atoi(optarg)); exit(EXIT_FAILURE); }
+            o.progress_interval = atoi(optarg);
+        } else if (c == 'o') {
+            FILE *fp = fopen(optarg, "w");
+            if (fp == NULL) { MMH_ERROR("Cannot open file %s for writing", optarg); exit(EXIT_FAILURE); }
+            o.out_path = optarg; o.out = fp;
+        } else if (c == 'V') {
+            fprintf(stdout, "minimod %s\n", MMH_VERSION);
+            exit(EXIT_SUCCESS);
+        } else if (c == 'h') {
+            fp_help = stdout;
+        } else if (c == 'm') {
+            o.threshes = optarg;
+        } else if (c == 'c') {
+            o.codes = optarg;
+        } else if (c == 'b') {
+            o.bedmethyl = 1;
+        } else if (c == 0 && strcmp(lname, "debug-break") == 0) { o.debug_break = atoi(optarg);
+        } else if (c == 0 && strcmp(lname, "insertions") == 0) { o.insertions = 1;
+        } else if (c == 0 && strcmp(lname, "haplotypes") == 0) { o.haplotypes = 1;
+        } else if (c == 0 && strcmp(lname, "allow-secondary") == 0) { o.allow_secondary = 1;
+        } else if (c == 0 && strcmp(lname, "include-non-ref") == 0) { /* accepted and ignored like the reference */
+        } else if (c == 0 && strcmp(lname, "skip-supplementary") == 0) { o.skip_supplementary = 1;
+        } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
+        } else if (c == 0 && strcmp(lname, "devices") == 0) { o.devices = optarg;
+        } else {
+            print_help(fp_help, &o);
+            exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+        }
+    }
+    char err[512];
+    mmh_mods_t mods;
+    if (o.codes == NULL || strlen(o.codes) == 0) {
+        MMH_INFO("%s", "Modification codes not provided. Using default modification code m");
+        o.codes = "m";
+    }
+    if (mmh_parse_mod_codes(o.codes, &mods, err, sizeof err)) { MMH_ERROR("%s", err); exit(EXIT_FAILURE); }
+    char defthr[MM_MAX_MODS * 4 + 1];
+    if (o.threshes == NULL || strlen(o.threshes) == 0) {
+        if (!view) MMH_INFO("%s", "Modification threshold not provided. Using default threshold 0.8");   /* view has no thresholds */
+        defthr[0] = 0;
+        for (int i = 0; i < mods.n_mods; i++) { strcat(defthr, "0.8"); if (i < mods.n_mods - 1) strcat(defthr, ","); }
+        o.threshes = defthr;
+    }
+    if (mmh_parse_mod_threshes(o.threshes, &mods, err, sizeof err)) { MMH_ERROR("%s", err); exit(EXIT_FAILURE); }
+    if (argc - optind != 2 || fp_help == stdout) {
+        MMH_WARNING("%s", "Missing arguments");
+        print_help(fp_help, &o);
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
+    const char *ref_file = argv[optind], *bam_file = argv[optind + 1];
+    if (access(bam_file, F_OK) == -1) { MMH_ERROR("BAM file %s does not exist", bam_file); exit(EXIT_FAILURE); }
+
+    double t1 = mmh_realtime();
+    fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);
+    mmh_ref_t *ref = mmh_load_ref(ref_file);
+    if (!ref) { MMH_ERROR("Could not to open file %s", ref_file); exit(EXIT_FAILURE); }
+    fprintf(stderr, "[%s] Reference genome loaded in %.3f sec\n", __func__, mmh_realtime() - t1);
+    if (o.devices && strchr(o.devices, ',')) return run_devices(&o, &mods, ref, bam_file, realtime0);
+    if (o.devices) o.device = atoi(o.devices);
+    wspec_t ws;
+    memset(&ws, 0, sizeof ws);
+    ws.fd = -1;
+    return run_body(&o, &mods, ref, bam_file, realtime0, &ws);
 }
 
 int mmh_freq_main(int argc, char **argv) { return run_main(argc, argv, 0); }

@@ -31,6 +31,10 @@ typedef struct loader_priv {
     pool_t sets[2][NPOOL];
     item_t *items;
     size_t items_cap;
+    /* a worker of a sharded run reads only the alignments that START inside its share [lo, hi) of the genome */
+    int ranged, first, last, seen, done;
+    int32_t lo_tid, hi_tid;
+    int64_t lo_pos, hi_pos;
 } loader_priv_t;
 #define PRIV(ld) ((loader_priv_t *)(ld)->priv)
 
@@ -55,6 +59,22 @@ mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int6
     ld->priv = pv;
     ld->bam = bam; ld->K = K; ld->B = B;
     ld->allow_secondary = allow_secondary; ld->skip_supplementary = skip_supplementary;
+    return ld;
+}
+
+mmh_loader_t *mmh_loader_open_share(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary,
+                                    uint64_t voffset, int32_t lo_tid, int64_t lo_pos, int32_t hi_tid, int64_t hi_pos, int first, int last) {
+    mm_bam_t *bam = voffset == UINT64_MAX ? mm_bam_open(bam_path, threads) : mm_bam_open_at(bam_path, threads, voffset);
+    if (!bam) return NULL;
+    mmh_loader_t *ld = (mmh_loader_t *)calloc(1, sizeof(*ld));
+    loader_priv_t *pv = (loader_priv_t *)calloc(1, sizeof(*pv));
+    if (!ld || !pv) { free(ld); free(pv); mm_bam_close(bam); return NULL; }
+    ld->priv = pv;
+    ld->bam = bam; ld->K = K; ld->B = B;
+    ld->allow_secondary = allow_secondary; ld->skip_supplementary = skip_supplementary;
+    pv->ranged = 1; pv->first = first; pv->last = last;
+    pv->lo_tid = lo_tid; pv->lo_pos = lo_pos; pv->hi_tid = hi_tid; pv->hi_pos = hi_pos;
+    pv->done = voffset == UINT64_MAX;   /* the index has nothing at or behind the share's start */
     return ld;
 }
 
@@ -116,8 +136,16 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     int rc = 1;
     /* ---- step 1: frame + filter, in file order (minimod.c:249-333) */
     while (n < ld->K && proc_bytes < ld->B) {           /* minimod.c:249 */
+        if (lp->done) { rc = 0; break; }
         rc = mm_bam_next(ld->bam, &rec);
         if (rc <= 0) break;
+        if (lp->ranged) {
+            if (!(rec.flag & 0x4) && rec.tid >= 0) {
+                if (rec.tid < lp->lo_tid || (rec.tid == lp->lo_tid && rec.pos < lp->lo_pos)) continue;   /* the left neighbour's read */
+                if (!lp->last && (rec.tid > lp->hi_tid || (rec.tid == lp->hi_tid && rec.pos >= lp->hi_pos))) { lp->done = 1; rc = 0; break; }
+                lp->seen = 1;
+            } else if (!lp->seen && !lp->first) continue;   /* unplaced records in front of the share are the left neighbour's to count */
+        }
         total++; total_bytes += rec.l_data;
         if (rec.flag & 0x4) continue;                                        /* unmapped, :260 */
         if (!ld->allow_secondary && (rec.flag & 0x100)) continue;           /* secondary, :265 */

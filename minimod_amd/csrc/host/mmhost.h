@@ -63,6 +63,11 @@ typedef struct mmh_loader {
     void *priv;   /* pool sets and framing scratch (loader.c) */
 } mmh_loader_t;
 mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary);
+/* A worker of a sharded run (`minimod freq --devices`): the reader starts at `voffset` (from the .bai; UINT64_MAX = the
+ * share is empty) and hands out the alignments that start inside [lo, hi) of the genome in (tid, pos) order; `first` /
+ * `last` mark the workers that also take what lies in front of the first / behind the last share. */
+mmh_loader_t *mmh_loader_open_share(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary,
+                                    uint64_t voffset, int32_t lo_tid, int64_t lo_pos, int32_t hi_tid, int64_t hi_pos, int first, int last);
 /* Fills `out` with the next batch (pointers into the loader's pools, valid until the next call with the same pool set).
  * Returns the number of accepted reads, or -1 on a read error.  *more = 0 when the reference's loop would stop
  * (src/freq_main.c:410). */

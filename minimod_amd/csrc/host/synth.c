@@ -345,7 +345,7 @@ void mm_synth_reference(uint64_t seed, int64_t len, uint8_t *out) { mm_synth_ref
 #include <stdio.h>
 #include <zlib.h>
 
-typedef struct { FILE *fp; uint8_t *buf; size_t n; } bgzf_w;
+typedef struct { FILE *fp; uint8_t *buf; size_t n; uint64_t coff; } bgzf_w;   /* coff: file offset of the block being filled */
 static int bgzf_flush_block(bgzf_w *w, const uint8_t *data, size_t len) {
     uint8_t out[65536 + 1024];
     z_stream zs;
@@ -362,6 +362,7 @@ static int bgzf_flush_block(bgzf_w *w, const uint8_t *data, size_t len) {
     out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
     uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len), isz = (uint32_t)len;
     memcpy(out + 18 + clen, &crc, 4); memcpy(out + 18 + clen + 4, &isz, 4);
+    w->coff += total;
     return fwrite(out, 1, total, w->fp) == total ? 0 : -1;
 }
 static int bgzf_put(bgzf_w *w, const void *data, size_t len) {
@@ -415,7 +416,76 @@ static int put_record(bgzf_w *w, const mm_batch_t *b, int32_t i, int variant, ui
     return 0;
 }
 
-typedef struct mm_bam_writer { bgzf_w w; uint64_t serial; int flags; } mm_bam_writer_t;
+/* BAI index under construction (SAM specification section 5.2): per reference the bins with their chunks and the linear
+ * index (smallest virtual offset of an alignment overlapping each 16 kb window) */
+typedef struct { uint32_t bin; uint64_t beg, end; } bai_chunk_t;
+typedef struct { bai_chunk_t *chunks; size_t n, cap; uint64_t *lin; size_t n_lin, cap_lin; } bai_ref_t;
+typedef struct mm_bam_writer { bgzf_w w; uint64_t serial; int flags; bai_ref_t *idx; int32_t n_ref; uint64_t n_no_coor; char *path; } mm_bam_writer_t;
+
+static int reg2bin(int64_t beg, int64_t end) {   /* SAM specification section 5.3 */
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+static uint64_t voffset(const bgzf_w *w) { return (w->coff << 16) | (uint64_t)w->n; }
+static void bai_add(mm_bam_writer_t *bw, int32_t tid, int64_t beg, int64_t end, uint64_t v0, uint64_t v1) {
+    if (!bw->idx) return;
+    if (tid < 0 || tid >= bw->n_ref) { bw->n_no_coor++; return; }
+    bai_ref_t *r = &bw->idx[tid];
+    if (end <= beg) end = beg + 1;
+    uint32_t bin = (uint32_t)reg2bin(beg, end);
+    if (r->n && r->chunks[r->n - 1].bin == bin && r->chunks[r->n - 1].end == v0) r->chunks[r->n - 1].end = v1;   /* the record continues the chunk */
+    else {
+        if (r->n == r->cap) { r->cap = r->cap ? r->cap * 2 : 1024; r->chunks = (bai_chunk_t *)realloc(r->chunks, r->cap * sizeof(bai_chunk_t)); }
+        r->chunks[r->n].bin = bin; r->chunks[r->n].beg = v0; r->chunks[r->n].end = v1; r->n++;
+    }
+    size_t w1 = (size_t)((end - 1) >> 14) + 1;
+    if (w1 > r->cap_lin) {
+        size_t nc = r->cap_lin ? r->cap_lin : 1024;
+        while (nc < w1) nc *= 2;
+        r->lin = (uint64_t *)realloc(r->lin, nc * sizeof(uint64_t));
+        memset(r->lin + r->cap_lin, 0, (nc - r->cap_lin) * sizeof(uint64_t));
+        r->cap_lin = nc;
+    }
+    for (size_t w = (size_t)(beg >> 14); w < w1; w++) if (r->lin[w] == 0) r->lin[w] = v0;
+    if (w1 > r->n_lin) r->n_lin = w1;
+}
+static int chunk_cmp(const void *a, const void *b) {
+    const bai_chunk_t *x = (const bai_chunk_t *)a, *y = (const bai_chunk_t *)b;
+    if (x->bin != y->bin) return x->bin < y->bin ? -1 : 1;
+    return x->beg < y->beg ? -1 : (x->beg > y->beg);
+}
+static int bai_write(mm_bam_writer_t *bw, const char *path) {
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    fwrite("BAI\1", 1, 4, fp);
+    fwrite(&bw->n_ref, 4, 1, fp);
+    for (int32_t t = 0; t < bw->n_ref; t++) {
+        bai_ref_t *r = &bw->idx[t];
+        qsort(r->chunks, r->n, sizeof(bai_chunk_t), chunk_cmp);
+        int32_t n_bin = 0;
+        for (size_t i = 0; i < r->n; i++) if (i == 0 || r->chunks[i].bin != r->chunks[i - 1].bin) n_bin++;
+        fwrite(&n_bin, 4, 1, fp);
+        for (size_t i = 0; i < r->n;) {
+            size_t j = i;
+            while (j < r->n && r->chunks[j].bin == r->chunks[i].bin) j++;
+            int32_t n_chunk = (int32_t)(j - i);
+            fwrite(&r->chunks[i].bin, 4, 1, fp); fwrite(&n_chunk, 4, 1, fp);
+            for (size_t k = i; k < j; k++) { fwrite(&r->chunks[k].beg, 8, 1, fp); fwrite(&r->chunks[k].end, 8, 1, fp); }
+            i = j;
+        }
+        int32_t n_intv = (int32_t)r->n_lin;
+        fwrite(&n_intv, 4, 1, fp);
+        for (size_t w = 1; w < r->n_lin; w++) if (r->lin[w] == 0) r->lin[w] = r->lin[w - 1];   /* windows nothing overlaps, as samtools fills them */
+        if (n_intv) fwrite(r->lin, 8, (size_t)n_intv, fp);
+    }
+    fwrite(&bw->n_no_coor, 8, 1, fp);
+    return fclose(fp);
+}
 
 /* flags: MM_BAMW_NO_HEADER = a later piece of a file written in pieces (BGZF members concatenate), MM_BAMW_NO_EOF = a piece
  * that is not the last; first_serial numbers the records (read names, filter fodder) as one writer would have */
@@ -427,6 +497,11 @@ mm_bam_writer_t *mm_bam_writer_open_piece(const char *path, int32_t n_contigs, c
     if (!bw) { fclose(fp); return NULL; }
     bw->w.fp = fp; bw->w.buf = (uint8_t *)malloc(0x10000);
     bw->flags = flags; bw->serial = first_serial;
+    if (flags & MM_BAMW_INDEX) {
+        bw->n_ref = n_contigs; bw->idx = (bai_ref_t *)calloc((size_t)(n_contigs > 0 ? n_contigs : 1), sizeof(bai_ref_t));
+        bw->path = (char *)malloc(strlen(path) + 5);
+        if (bw->path) { strcpy(bw->path, path); strcat(bw->path, ".bai"); }
+    }
     if (!bw->w.buf) { fclose(fp); free(bw); return NULL; }
     if (flags & MM_BAMW_NO_HEADER) return bw;
     char text[256];
@@ -444,13 +519,31 @@ mm_bam_writer_t *mm_bam_writer_open_piece(const char *path, int32_t n_contigs, c
 mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens) {
     return mm_bam_writer_open_piece(path, n_contigs, names, lens, 0, 0);
 }
+static int64_t ref_end(const mm_batch_t *b, const mm_read_t *rd) {
+    int64_t e = rd->pos;
+    for (uint32_t k = 0; k < rd->n_cigar; k++) {
+        uint32_t w = b->cigar[rd->cigar_off + k], op = w & 15u;
+        if ((0x18Du >> op) & 1u) e += w >> 4;   /* M D N = X consume the reference */
+    }
+    return e;
+}
+static int put_indexed(mm_bam_writer_t *bw, const mm_batch_t *b, int32_t i, int variant) {
+    const uint64_t v0 = voffset(&bw->w);
+    if (put_record(&bw->w, b, i, variant, bw->serial)) return -1;
+    if (bw->idx) {
+        const mm_read_t *rd = &b->reads[i];
+        if (variant == 1) bai_add(bw, -1, 0, 0, v0, voffset(&bw->w));
+        else bai_add(bw, rd->tid, rd->pos, ref_end(b, rd), v0, voffset(&bw->w));
+    }
+    return 0;
+}
 int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_filter_fodder) {
     for (int32_t i = 0; i < b->n_reads; i++) {
-        if (put_record(&bw->w, b, i, 0, bw->serial)) return -1;
+        if (put_indexed(bw, b, i, 0)) return -1;
         if (with_filter_fodder) {
-            if (bw->serial % 97 == 5 && put_record(&bw->w, b, i, 1, bw->serial)) return -1;
-            if (bw->serial % 89 == 7 && put_record(&bw->w, b, i, 2, bw->serial)) return -1;
-            if (bw->serial % 83 == 11 && put_record(&bw->w, b, i, 3, bw->serial)) return -1;
+            if (bw->serial % 97 == 5 && put_indexed(bw, b, i, 1)) return -1;
+            if (bw->serial % 89 == 7 && put_indexed(bw, b, i, 2)) return -1;
+            if (bw->serial % 83 == 11 && put_indexed(bw, b, i, 3)) return -1;
         }
         bw->serial++;
     }
@@ -461,6 +554,11 @@ int mm_bam_writer_close(mm_bam_writer_t *bw) {
     if (bw->w.n) r |= bgzf_flush_block(&bw->w, bw->w.buf, bw->w.n);
     if (!(bw->flags & MM_BAMW_NO_EOF)) r |= bgzf_flush_block(&bw->w, bw->w.buf, 0);   /* the 28-byte EOF marker: an empty block */
     r |= fclose(bw->w.fp);
+    if (bw->idx) {
+        if (!bw->path || bai_write(bw, bw->path)) r |= -1;
+        for (int32_t t = 0; t < bw->n_ref; t++) { free(bw->idx[t].chunks); free(bw->idx[t].lin); }
+        free(bw->idx); free(bw->path);
+    }
     free(bw->w.buf); free(bw);
     return r;
 }

@@ -174,13 +174,14 @@ def write_fasta_multi(path, contigs):
                 f.write(a[n:].tobytes() + b"\n")
 
 
-def write_bam(path, contigs, batches, filter_fodder=True):
-    """Write numpy batches (dicts as returned by batch()) as one coordinate-sorted BGZF BAM.  contigs: [(name, length)]."""
+def write_bam(path, contigs, batches, filter_fodder=True, index=False):
+    """Write numpy batches (dicts as returned by batch()) as one coordinate-sorted BGZF BAM.  contigs: [(name, length)].
+    index=True also writes path + ".bai" (bins, chunks and the 16 kb linear index of the SAM specification)."""
     from .engine import batch_struct
     L = host_lib()
     names = (ctypes.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
     lens = (ctypes.c_int64 * len(contigs))(*[int(l) for _, l in contigs])
-    w = L.mm_bam_writer_open(path.encode(), len(contigs), names, lens)
+    w = L.mm_bam_writer_open_piece(path.encode(), len(contigs), names, lens, 4 if index else 0, 0)
     if not w:
         raise IOError("cannot create %s" % path)
     for b in batches:

@@ -192,3 +192,35 @@ def test_downscaled_whole_genome_shape(tmp_path):
     first_seen = [names[t] for t in dict.fromkeys(rows["tid"].tolist())]
     assert first_seen == sorted(names) and first_seen[:3] == ["chr1", "chr10", "chr11"]
     assert len(rows) > 20000 and r.stdout.decode() == want
+
+
+@pytest.mark.parametrize("flags", [["-b"], [], ["--haplotypes", "--insertions"]], ids=["bedmethyl", "tsv", "hap_ins"])
+def test_cli_devices_shares_of_the_genome_equal_a_single_run(flags, genome, tmp_path):
+    """`minimod freq --devices a,b,c`: one worker process per listed GPU (the test lists the one GPU there is three times),
+    the genome cut into contiguous shares at 64 kb-aligned positions (cuts fall inside contigs here), every worker reading
+    its share of the BAM from the virtual offset the .bai gives, rows merged by the parent: the same bytes as one run."""
+    from minimod_amd import synth
+    gen = dict(haplotypes=True, long_insertions=True) if "--haplotypes" in flags else {}
+    bs = _batches(genome, **gen)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    assert os.path.getsize(bam + ".bai") > 1000
+    base = [BIN, "freq", "-c", "m[CG],h[CG]", "-m", "0.8,0.7", "-K", "200", "-t", "6"] + flags
+    one = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    for devs in ("0,0", "0,0,0"):
+        many = subprocess.run(base + ["--devices", devs, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert many.returncode == 0, many.stderr.decode()[-3000:]
+        assert len(one.stdout) > 100000 and many.stdout == one.stdout
+        assert b"total processed entries: 1100" in many.stderr and b"devices: %d" % len(devs.split(",")) in many.stderr
+
+
+def test_cli_devices_needs_the_index(genome, tmp_path):
+    from minimod_amd import synth
+    bs = _batches(genome)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    r = subprocess.run([BIN, "freq", "--devices", "0,0", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1 and b"Could not read the index" in r.stderr

@@ -481,3 +481,51 @@ def test_own_inflate_matches_zlib_on_every_block_type_and_rejects_damage():
             isize = int.from_bytes(d[p + bsize - 4:p + bsize], "little")
             assert hostlib.inflate_raw(comp, isize) == zlib.decompress(comp, -15)
             p += bsize
+
+
+def test_bai_linear_index_and_positioned_reader(tmp_path):
+    """The writer's .bai (SAM specification 5.2) and the reader's use of it: for a set of (contig, position) starts, opening
+    the BAM at mm_bai_start()'s virtual offset and skipping the records in front of the start gives exactly the records an
+    unpositioned read of the file gives from there on."""
+    import ctypes
+    from minimod_amd import hostlib, synth
+    names, lens = ["chr1", "chr2", "chr10"], [1 << 20, 3 << 19, 1 << 19]
+    refs = [synth.reference(100 + i, L) for i, L in enumerate(lens)]
+    bs = synth.multi_contig(refs, [300, 400, 150], 256, seed=5, median_len=4000.0, max_len=30000.0)
+    p = str(tmp_path / "i.bam")
+    synth.write_bam(p, list(zip(names, lens)), bs, index=True)
+    L = hostlib._lib()
+    L.mm_bai_load.restype = ctypes.c_void_p
+    L.mm_bai_load.argtypes = [ctypes.c_char_p]
+    L.mm_bai_start.restype = ctypes.c_uint64
+    L.mm_bai_start.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64]
+    L.mm_bai_free.argtypes = [ctypes.c_void_p]
+    L.mmh_loader_open_share.restype = ctypes.c_void_p
+    L.mmh_loader_open_share.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                        ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    bai = L.mm_bai_load((p + ".bai").encode())
+    assert bai
+    allr = np.concatenate([b["reads"] for b in bs])
+    key = allr["tid"].astype(np.int64) << 32 | allr["pos"].astype(np.int64)
+    from minimod_amd.engine import READ_DTYPE, mm_batch_t
+    for (lo_t, lo_p), (hi_t, hi_p) in [((0, 0), (0, 400000)), ((0, 400000), (1, 65536)), ((1, 65536), (1, 1 << 20)), ((1, 1 << 20), (2, 1 << 19)),
+                                       ((2, 300000), (3, 0))]:
+        v = L.mm_bai_start(bai, lo_t, lo_p)
+        ld = L.mmh_loader_open_share(p.encode(), 2, 4096, 10 ** 9, 0, 0, v, lo_t, lo_p, hi_t, hi_p, 0, 0)
+        assert ld
+        got, more = [], ctypes.c_int(1)
+        while more.value:
+            b = mm_batch_t()
+            n = L.mmh_loader_next(ld, 0, ctypes.byref(b), ctypes.byref(more))
+            assert n >= 0
+            if n:
+                rd = np.frombuffer((ctypes.c_char * (n * 64)).from_address(b.reads), dtype=READ_DTYPE).copy()
+                got.append(rd)
+        L.mmh_loader_close(ld)
+        got = np.concatenate(got) if got else np.zeros(0, dtype=READ_DTYPE)
+        want = allr[(key >= (lo_t << 32 | lo_p)) & (key < (hi_t << 32 | hi_p))]
+        assert len(want) > 0 and len(got) == len(want)
+        for k in ("tid", "pos", "l_qseq", "n_cigar", "mm_len", "flag"):
+            assert (got[k] == want[k]).all()
+    assert L.mm_bai_start(bai, 3, 0) == 2 ** 64 - 1
+    L.mm_bai_free(bai)
