@@ -205,7 +205,7 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
     const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
     const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
     hipLaunchKernelGGL(k_view_sort, dim3(big_blocks + small_blocks), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff, nr, big_blocks, b->reads,
-                       s.d_vrows, s.d_vkept, tail);
+                       s.d_vrows, s.d_vkept, tail, h->opts.view == 2 ? 1u : 0u);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,7 @@ static struct option long_options[] = {
     {"skip-supplementary", no_argument, 0, 0},     /* 16 */
     {"device", required_argument, 0, 0},           /* 17 (new: HIP device ordinal) */
     {"devices", required_argument, 0, 0},          /* 18 (new: one worker process per listed GPU, the genome cut into shares) */
+    {"canonical-order", no_argument, 0, 0},        /* 19 (new: rows that tie on (contig, start) in a fixed order instead of the reference's hash order) */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -57,7 +58,7 @@ static struct option view_long_options[] = {
 
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device, view;
+    int progress_interval, device, view, canonical_order;
     const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
@@ -100,6 +101,8 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "\nadvanced options:\n");
     fprintf(fp, "   --debug-break INT          break after processing the specified no. of batches\n");
     fprintf(fp, "   --device INT               GPU to use [%d]\n", o->device);
+    if (!o->view) fprintf(fp, "   --canonical-order          rows of one (contig, start) by strand, code, ins_offset, haplotype instead of the order\n"
+                              "                              minimod's hash table leaves them in (skips the replay of that table) [%s]\n", o->canonical_order ? "yes" : "no");
     if (!o->view) fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -201,6 +204,20 @@ static int read_all(int fd, void *buf, size_t n) {
     return 0;
 }
 
+/* a replay run's second handle: the batch's calls (view rows with group ordinals) go into the tie-order replay */
+static void replay_batch(mm_freq_t *hv, mmh_tie_t *tie, int32_t ticket, const mm_batch_t *b, const mm_bam_hdr_t *hdr, mm_pool_t *pool,
+                         const uint8_t *const *klass_of_code, double *seconds) {
+    double t0 = mmh_realtime();
+    int32_t bad = -1;
+    const mm_view_row_t *rows = NULL;
+    int64_t n = mm_view_fetch(hv, ticket, &rows, &bad);
+    if (n < 0) die_read_error((int)-n, bad, b, hdr);
+    const char *codes[MM_MAX_CODES];
+    int n_codes = code_names(hv, codes);
+    (void)mmh_tie_add_batch(tie, pool, b, rows, n, klass_of_code, codes, n_codes);   /* a failed replay is reported once, at the end */
+    *seconds += mmh_realtime() - t0;
+}
+
 /* Everything behind option parsing and the reference load: the batches of one BAM (or of one share of it) through one
  * GPU.  A single run prints its rows; a worker of `--devices` sends them to the parent, which merges and prints. */
 static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
@@ -229,20 +246,43 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fo.view = view;
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
+    int wildcard = 0, star_ctx = 0;
+    for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
+    const int replay = !view && !o.canonical_order && !ws->sharded && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
+    mm_freq_t *hv = NULL;      /* the second handle of a replay run: the same batches in view mode (rows with group ordinals) */
+    mmh_tie_t *tie = NULL;
+    if (replay) {
+        mm_freq_opts_t fv = fo;
+        fv.view = 2;
+        hv = mm_freq_create(&fv, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
+        tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
+        if (!hv || !tie) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
+    }
     free(ctg);
     mmh_free_ref(ref);   /* the reference now lives in HBM */
     fprintf(stderr, "[%s] Reference contexts loaded in %.3f sec\n", __func__, mmh_realtime() - t2);
-    int wildcard = 0;
-    for (int i = 0; i < mods.n_mods; i++) if (strcmp(mods.code[i], "*") == 0) wildcard = 1;
+    /* (replay, above) Rows can tie on (contig, start) when several codes are counted, both strands can be called on one
+     * position (`*` contexts), insertion offsets or haplotypes are keys.  The reference prints such rows in the order its
+     * hash table and its unstable sort leave them in (tieorder.c): that order is replayed from the calls of every read,
+     * which a second handle in view mode delivers for the same batches.  A run whose rows cannot tie (-c m[CG]) needs
+     * none of this. */
+    if (!view && !o.canonical_order && ws->sharded && (mods.n_mods > 1 || star_ctx || o.insertions || o.haplotypes) && ws->first)
+        MMH_WARNING("%s", "--devices prints rows that tie on (contig, start) by strand, code, ins_offset, haplotype: the order of minimod's hash table is not replayed across workers");
 
     if (ws->fd < 0) {
         if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
         else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
     }
 
-    double load_time = 0, process_wait_time = 0, output_time = 0;
+    double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0;
     int more = 1, counter = 0, set = 0;
-    int32_t pending_ticket = -1;
+    int32_t pending_ticket = -1, pending_vticket = -1;
+    const uint8_t *klass_of_code[MM_MAX_CODES];
+    for (int i = 0; i < MM_MAX_CODES; i++) {   /* a wildcard run counts every code under the one `*` entry */
+        int req = i < mods.n_mods ? i : 0;
+        if (wildcard) for (int m2 = 0; m2 < mods.n_mods; m2++) if (strcmp(mods.code[m2], "*") == 0) req = m2;
+        klass_of_code[i] = fo.mods[req].klass;
+    }
     mm_batch_t pending_batch, batch;
     memset(&pending_batch, 0, sizeof pending_batch);
     double prog_t = mmh_realtime();
@@ -256,13 +296,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (pending_ticket >= 0) {
             retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+            if (replay) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
             pending_ticket = -1;
         }
         if (n > 0) {
-            if (wildcard) intern_batch_codes(h, &batch);
+            if (wildcard) { intern_batch_codes(h, &batch); if (replay) intern_batch_codes(hv, &batch); }
             int32_t tk = mm_freq_submit(h, &batch);
             if (tk < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(tk)); exit(EXIT_FAILURE); }
             pending_ticket = tk; pending_batch = batch;
+            if (replay) {
+                pending_vticket = mm_freq_submit(hv, &batch);
+                if (pending_vticket < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(pending_vticket)); exit(EXIT_FAILURE); }
+            }
         }
         if (o.progress_interval <= 0 || mmh_realtime() - prog_t > o.progress_interval) {
             fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bytes) processed\t%d Entries (%.1fM bytes) skipped\n", __func__,
@@ -279,7 +324,10 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (pending_ticket >= 0) retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+    if (pending_ticket >= 0) {
+        retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+        if (replay) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
+    }
     double sort_time = 0;
     if (!view) {
         double ts = mmh_realtime();
@@ -302,13 +350,27 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             mmh_loader_close(ld);
             return 0;
         }
+        mm_row_t *ordered = NULL;
+        if (replay && nrows > 0) {   /* the same rows, in the order the reference's table and sort leave them in */
+            double tr = mmh_realtime();
+            ordered = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
+            if (ordered) memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
+            if (!ordered || mmh_tie_order_rows(tie, ordered, nrows) != 0) {
+                MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
+                free(ordered); ordered = NULL;
+            } else rows = ordered;
+            replay_time += mmh_realtime() - tr;
+            sort_time += mmh_realtime() - tr;
+        }
         double to = mmh_realtime();
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
         mmh_print_freq_rows(o.out, mm_bam_pool(ld->bam), rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
+        free(ordered);
     }
+    if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort): %.3f sec\n", __func__, replay_time);
     if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o.out != stdout) fclose(o.out);
     else fflush(stdout);
@@ -327,6 +389,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fprintf(stderr, "\n[%s] Data output time: %.3f sec", __func__, output_time);
     fprintf(stderr, "\n");
     mm_freq_destroy(h);
+    if (hv) mm_freq_destroy(hv);
+    mmh_tie_destroy(tie);
     mmh_loader_close(ld);
     return 0;
 }
@@ -578,6 +642,7 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "skip-supplementary") == 0) { o.skip_supplementary = 1;
         } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
         } else if (c == 0 && strcmp(lname, "devices") == 0) { o.devices = optarg;
+        } else if (c == 0 && strcmp(lname, "canonical-order") == 0) { o.canonical_order = 1;
         } else {
             print_help(fp_help, &o);
             exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);

@@ -91,6 +91,17 @@ void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, i
 int mmh_emit_flush(void);
 int mmh_emit_finish(void);   /* flush, then stop the writer thread and free the recycled buffers */
 
+/* ---- the reference's order of rows that tie on (contig, start) (tieorder.c) ---- */
+typedef struct mmh_tie mmh_tie_t;
+mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotypes);
+/* one batch's calls: the rows of a handle created with mm_freq_opts_t.view == 2; klass_of_code[c] = the threshold classes
+ * (mmh_klass_lut) of the mod code c counts for */
+int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, const mm_view_row_t *rows, int64_t n,
+                      const uint8_t *const *klass_of_code, const char *const *codes, int n_codes);
+/* mm_freq_finalize's rows, reordered in place into the order print_freq_output prints; -1 = no replay possible (rows untouched) */
+int mmh_tie_order_rows(mmh_tie_t *t, mm_row_t *rows, int64_t n);
+void mmh_tie_destroy(mmh_tie_t *t);
+
 int mmh_freq_main(int argc, char **argv);
 int mmh_view_main(int argc, char **argv);
 int mmh_summary_main(int argc, char **argv);   /* host only */

@@ -1,0 +1,465 @@
+/* tieorder.c -- the reference's order of the rows that tie on (contig, start).
+ *
+ * print_freq_output (reference src/mod.c:644-664) copies the core hash table slot by slot into an array and sorts it
+ * with ks_introsort under a comparator that looks at contig and start only (cmp_key_fast, src/mod.c:59-87).  Rows of one
+ * (contig, start) -- several codes, both strands under a `*` context, insertion offsets, haplotypes and their `*`
+ * aggregate -- therefore come out in an order that is a function of (a) the slot every key has in the core table and
+ * (b) what the unstable sort does to that array.  (a) depends on the order in which keys were first inserted
+ * (merge_freq_maps, src/mod.c:743-774: reads in file order, inside a read the SLOT order of the read's own table, which was
+ * filled in the order freq_view_single met the calls, update_freq_map src/mod.c:883-929: the key with the haplotype, then
+ * the `-1` aggregate) and on the tables' growth history.  None of that carries information about the data; it is
+ * reproduced here because "byte-identical" includes it.
+ *
+ * What is restated (from the behaviour of klib's khash / ksort as the reference instantiates them, not from their text):
+ *   - the string key of a row (make_key, src/mod.c:428-439) and its X31 hash (khash.h kh_str_hash_func);
+ *   - an insert-only open-addressing table with khash's probe sequence (i += ++step), growth rule (n_occupied >= 0.77 n
+ *     at the START of a put: double) and its in-place "kick-out" rehash, whose slot assignment depends on the old slot
+ *     order (khash.h kh_resize / kh_put);
+ *   - introsort as ksort.h runs it: median of three with that file's pivot choice, partitions down to 16 elements, comb
+ *     sort when the depth budget is spent, one insertion sort over everything at the end.
+ * The COUNTS never come from here: they are the GPU's.  This file only decides in which order the GPU's rows are printed.
+ * Input per batch: the calls of every read as `minimod view` rows with group ordinal and implicit flag (mm_freq_opts_t.view
+ * == 2), from a second handle that sees the same batches. */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mmhost.h"
+
+/* ---------------------------------------------------------------- keys */
+typedef struct { int32_t tid, pos; uint16_t ins; int16_t code, hp; uint8_t strand, pad; } tkey_t;   /* 16 bytes */
+
+static inline int tkey_eq(const tkey_t *a, const tkey_t *b) {
+    return a->tid == b->tid && a->pos == b->pos && a->ins == b->ins && a->code == b->code && a->hp == b->hp && a->strand == b->strand;
+}
+static inline uint64_t tkey_mix(const tkey_t *k) {   /* this file's own hash for its bookkeeping sets */
+    uint64_t a = ((uint64_t)(uint32_t)k->tid << 32) | (uint32_t)k->pos;
+    uint64_t b = ((uint64_t)k->ins << 40) | ((uint64_t)(uint16_t)k->code << 24) | ((uint64_t)(uint16_t)k->hp << 8) | k->strand;
+    uint64_t x = a * 0x9E3779B97F4A7C15ull ^ (b + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x;
+}
+
+static size_t put_dec(char *dst, long long v) {
+    char tmp[24];
+    int n = 0, neg = v < 0;
+    unsigned long long u = neg ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    size_t k = 0;
+    if (neg) dst[k++] = '-';
+    while (n) dst[k++] = tmp[--n];
+    return k;
+}
+
+/* X31 over "contig \t pos \t strand \t code \t ins_offset \t haplotype" */
+static uint32_t key_hash(const tkey_t *k, const char *contig, size_t clen, const char *code, size_t colen) {
+    char stack[512], *buf = stack;
+    size_t need = clen + colen + 64;
+    if (need > sizeof stack) buf = (char *)malloc(need);
+    size_t n = 0;
+    memcpy(buf, contig, clen); n += clen;
+    buf[n++] = '\t'; n += put_dec(buf + n, k->pos);
+    buf[n++] = '\t'; buf[n++] = k->strand ? '-' : '+';
+    buf[n++] = '\t'; memcpy(buf + n, code, colen); n += colen;
+    buf[n++] = '\t'; n += put_dec(buf + n, k->ins);
+    buf[n++] = '\t'; n += put_dec(buf + n, k->hp);
+    uint32_t h = n ? (uint32_t)(unsigned char)buf[0] : 0;
+    if (h) for (size_t i = 1; i < n; i++) h = (h << 5) - h + (uint32_t)(unsigned char)buf[i];   /* signed char in the reference; names are ASCII */
+    if (buf != stack) free(buf);
+    return h;
+}
+
+/* ---------------------------------------------------------------- the table */
+typedef struct {
+    uint32_t n_buckets, size, n_occupied, upper;
+    uint8_t *used;        /* 1 = holds a key */
+    uint32_t *id;         /* key id per bucket */
+} ktab_t;
+
+static void ktab_free(ktab_t *t) { free(t->used); free(t->id); memset(t, 0, sizeof *t); }
+
+static int ktab_grow(ktab_t *t, uint32_t want, const uint32_t *hash) {
+    uint32_t nb = want - 1;
+    nb |= nb >> 1; nb |= nb >> 2; nb |= nb >> 4; nb |= nb >> 8; nb |= nb >> 16; nb++;
+    if (nb < 4) nb = 4;
+    if (t->size >= (uint32_t)(nb * 0.77 + 0.5)) return 0;   /* requested size is too small: nothing happens */
+    uint8_t *nused = (uint8_t *)calloc(nb, 1);
+    uint32_t *nid = (uint32_t *)realloc(t->id, sizeof(uint32_t) * nb);
+    if (!nused || !nid) { free(nused); return -1; }
+    t->id = nid;
+    /* the rehash works in place: an element taken out of old bucket j goes to its slot in the new table; if that slot (as a
+     * bucket of the OLD table) still holds an element not yet moved, the two swap and the evicted one goes next */
+    uint8_t *old = t->used;
+    const uint32_t mask = nb - 1;
+    for (uint32_t j = 0; j < t->n_buckets; j++) {
+        if (!old[j]) continue;
+        uint32_t key = t->id[j];
+        old[j] = 0;
+        for (;;) {
+            uint32_t i = hash[key] & mask, step = 0;
+            while (nused[i]) i = (i + (++step)) & mask;
+            nused[i] = 1;
+            if (i < t->n_buckets && old[i]) { uint32_t tmp = t->id[i]; t->id[i] = key; key = tmp; old[i] = 0; }
+            else { t->id[i] = key; break; }
+        }
+    }
+    free(old);
+    t->used = nused; t->n_buckets = nb; t->n_occupied = t->size; t->upper = (uint32_t)(nb * 0.77 + 0.5);
+    return 0;
+}
+
+/* put: returns 1 when the key was new.  `same(ctx, a, b)` compares key ids. */
+static int ktab_put(ktab_t *t, uint32_t key, const uint32_t *hash, const tkey_t *keys) {
+    if (t->n_occupied >= t->upper) {
+        if (ktab_grow(t, t->n_buckets > (t->size << 1) ? t->n_buckets - 1 : t->n_buckets + 1, hash)) return -1;
+    }
+    const uint32_t mask = t->n_buckets - 1;
+    uint32_t i = hash[key] & mask, step = 0;
+    const uint32_t last = i;
+    while (t->used[i] && !tkey_eq(&keys[t->id[i]], &keys[key])) {
+        i = (i + (++step)) & mask;
+        if (i == last) return -1;   /* cannot happen below the load bound */
+    }
+    if (t->used[i]) return 0;
+    t->used[i] = 1; t->id[i] = key; t->size++; t->n_occupied++;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- introsort, as ksort.h runs it */
+typedef struct { const int32_t *rank; const tkey_t *keys; } cmpctx_t;
+static inline int key_lt(const cmpctx_t *c, uint32_t a, uint32_t b) {   /* cmp_key_fast(a, b) < 0 */
+    const tkey_t *x = &c->keys[a], *y = &c->keys[b];
+    if (x->tid != y->tid) { int ra = c->rank[x->tid], rb = c->rank[y->tid]; if (ra != rb) return ra < rb; }
+    return x->pos - y->pos < 0;
+}
+static void ins_sort(const cmpctx_t *c, uint32_t *s, uint32_t *t) {
+    for (uint32_t *i = s + 1; i < t; ++i)
+        for (uint32_t *j = i; j > s && key_lt(c, *j, *(j - 1)); --j) { uint32_t tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+static void comb_sort(const cmpctx_t *c, size_t n, uint32_t *a) {
+    const double shrink = 1.2473309501039786540366528676643;
+    int swapped;
+    size_t gap = n;
+    do {
+        if (gap > 2) { gap = (size_t)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        swapped = 0;
+        for (uint32_t *i = a; i < a + n - gap; ++i) {
+            uint32_t *j = i + gap;
+            if (key_lt(c, *j, *i)) { uint32_t tmp = *i; *i = *j; *j = tmp; swapped = 1; }
+        }
+    } while (swapped || gap > 2);
+    if (gap != 1) ins_sort(c, a, a + n);
+}
+typedef struct { uint32_t *left, *right; int depth; } sstack_t;
+static int intro_sort(const cmpctx_t *c, size_t n, uint32_t *a) {
+    if (n < 1) return 0;
+    if (n == 2) { if (key_lt(c, a[1], a[0])) { uint32_t tmp = a[0]; a[0] = a[1]; a[1] = tmp; } return 0; }
+    int d;
+    for (d = 2; (1ul << d) < n; ++d) {}
+    sstack_t *stack = (sstack_t *)malloc(sizeof(sstack_t) * (sizeof(size_t) * (size_t)d + 2)), *top = stack;
+    if (!stack) return -1;
+    uint32_t *s = a, *t = a + (n - 1);
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { comb_sort(c, (size_t)(t - s) + 1, s); t = s; continue; }
+            uint32_t *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+            if (key_lt(c, *k, *i)) { if (key_lt(c, *k, *j)) k = j; }
+            else k = key_lt(c, *j, *i) ? i : j;
+            const uint32_t rp = *k;
+            if (k != t) { uint32_t tmp = *k; *k = *t; *t = tmp; }
+            for (;;) {
+                do ++i; while (key_lt(c, *i, rp));
+                do --j; while (i <= j && key_lt(c, rp, *j));
+                if (j <= i) break;
+                uint32_t tmp = *i; *i = *j; *j = tmp;
+            }
+            { uint32_t tmp = *i; *i = *t; *t = tmp; }
+            if (i - s > t - i) {
+                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == stack) { free(stack); ins_sort(c, a, a + n); return 0; }
+            --top; s = top->left; t = top->right; d = top->depth;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- the replay */
+struct mmh_tie {
+    const mm_bam_hdr_t *hdr;
+    int insertions, haplotypes;
+    int32_t *rank;                 /* contig tid -> rank of its name in strcmp order */
+    /* first-insertion sequence of the core table */
+    tkey_t *keys; uint32_t *hash; size_t n, cap;
+    /* membership of `keys` (own open addressing on tkey_mix) */
+    uint32_t *set; size_t set_cap;
+    int failed;                    /* a read had more MM groups than the rows can number, or memory ran out */
+};
+
+mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotypes) {
+    mmh_tie_t *t = (mmh_tie_t *)calloc(1, sizeof(*t));
+    if (!t) return NULL;
+    t->hdr = hdr; t->insertions = insertions; t->haplotypes = haplotypes;
+    const int n = hdr->n_targets;
+    t->rank = (int32_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int32_t));
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) idx[i] = i;
+    for (int a = 1; a < n; a++) {
+        int x = idx[a], b = a - 1;
+        while (b >= 0 && strcmp(hdr->target_name[idx[b]], hdr->target_name[x]) > 0) { idx[b + 1] = idx[b]; b--; }
+        idx[b + 1] = x;
+    }
+    for (int r = 0, cur = -1; r < n; r++) {   /* equal names share a rank: the comparator cannot tell them apart */
+        if (r == 0 || strcmp(hdr->target_name[idx[r]], hdr->target_name[idx[r - 1]]) != 0) cur = r;
+        t->rank[idx[r]] = cur;
+    }
+    free(idx);
+    t->set_cap = (size_t)1 << 16;
+    t->set = (uint32_t *)malloc(sizeof(uint32_t) * t->set_cap);
+    if (!t->set) { t->failed = 1; return t; }
+    memset(t->set, 0xFF, sizeof(uint32_t) * t->set_cap);
+    return t;
+}
+
+void mmh_tie_destroy(mmh_tie_t *t) {
+    if (!t) return;
+    free(t->rank); free(t->keys); free(t->hash); free(t->set); free(t);
+}
+
+static int seq_add(mmh_tie_t *t, const tkey_t *k, uint32_t h) {
+    if ((t->n + 1) * 10 > t->set_cap * 6) {   /* grow the membership set */
+        size_t nc = t->set_cap * 2;
+        uint32_t *ns = (uint32_t *)malloc(sizeof(uint32_t) * nc);
+        if (!ns) return -1;
+        memset(ns, 0xFF, sizeof(uint32_t) * nc);
+        for (size_t i = 0; i < t->n; i++) {
+            size_t s = (size_t)tkey_mix(&t->keys[i]) & (nc - 1);
+            while (ns[s] != 0xFFFFFFFFu) s = (s + 1) & (nc - 1);
+            ns[s] = (uint32_t)i;
+        }
+        free(t->set); t->set = ns; t->set_cap = nc;
+    }
+    size_t s = (size_t)tkey_mix(k) & (t->set_cap - 1);
+    while (t->set[s] != 0xFFFFFFFFu) {
+        if (tkey_eq(&t->keys[t->set[s]], k)) return 0;
+        s = (s + 1) & (t->set_cap - 1);
+    }
+    if (t->n == t->cap) {
+        size_t nc = t->cap ? t->cap * 2 : (size_t)1 << 16;
+        tkey_t *nk = (tkey_t *)realloc(t->keys, sizeof(tkey_t) * nc);
+        if (!nk) return -1;
+        t->keys = nk;
+        uint32_t *nh = (uint32_t *)realloc(t->hash, sizeof(uint32_t) * nc);
+        if (!nh) return -1;
+        t->hash = nh; t->cap = nc;
+    }
+    if (t->n >= 0xFFFFFFF0u) return -1;
+    t->keys[t->n] = *k; t->hash[t->n] = h;
+    t->set[s] = (uint32_t)t->n;
+    t->n++;
+    return 0;
+}
+
+/* per read: its keys in the slot order of its own table */
+typedef struct {
+    mmh_tie_t *t;
+    const mm_batch_t *batch;
+    const mm_view_row_t *rows;
+    const int64_t *first;          /* first row of every read (n_reads + 1 entries) */
+    const uint8_t *const *klass;   /* per code: the 256-entry threshold class table of the mod it counts for */
+    const char *const *codes; int n_codes;
+    tkey_t **out_keys; uint32_t **out_hash; uint32_t *out_n;
+    int failed;
+} readjob_t;
+
+typedef struct { uint32_t gord, implicit, fq, m; uint32_t row; } callord_t;
+static int callord_cmp(const void *a, const void *b) {
+    const callord_t *x = (const callord_t *)a, *y = (const callord_t *)b;
+    if (x->gord != y->gord) return x->gord < y->gord ? -1 : 1;
+    if (x->implicit != y->implicit) return x->implicit < y->implicit ? -1 : 1;
+    if (x->fq != y->fq) return x->fq < y->fq ? -1 : 1;
+    if (x->m != y->m) return x->m < y->m ? -1 : 1;
+    return x->row < y->row ? -1 : (x->row > y->row);
+}
+
+/* letter index of device code `ci` inside MM group number `gord` of the read (0 for single-code groups) */
+static uint32_t letter_index(const char *mm, uint32_t mm_len, uint32_t gord, const char *code) {
+    uint32_t p = 0, g = 0;
+    while (p < mm_len && g < gord) { while (p < mm_len && mm[p] != ';') p++; p++; g++; }
+    if (p + 2 >= mm_len) return 0;
+    uint32_t s = p + 2, e = s;
+    while (e < mm_len && mm[e] != ',' && mm[e] != ';' && mm[e] != '?' && mm[e] != '.') e++;
+    if (e <= s || (mm[s] >= '0' && mm[s] <= '9')) return 0;
+    const size_t cl = strlen(code);
+    for (uint32_t m = 0; s + m < e; m++)   /* the code of letter m is the string from m on (src/mod.c:1151) */
+        if ((size_t)(e - s - m) == cl && memcmp(mm + s + m, code, cl) == 0) return m;
+    return 0;
+}
+
+/* does any group of the read carry more than one code letter ("C+hm?")?  Then the letters of one token tie on everything
+ * but their place in the header */
+static int has_multi_letter_group(const char *mm, uint32_t mm_len) {
+    uint32_t p = 0;
+    while (p + 2 < mm_len) {
+        uint32_t s = p + 2, e = s;
+        while (e < mm_len && mm[e] != ',' && mm[e] != ';' && mm[e] != '?' && mm[e] != '.') e++;
+        if (e - s > 1 && !(mm[s] >= '0' && mm[s] <= '9')) return 1;
+        while (p < mm_len && mm[p] != ';') p++;
+        p++;
+    }
+    return 0;
+}
+
+static void read_range(void *arg, int64_t lo, int64_t hi) {
+    readjob_t *j = (readjob_t *)arg;
+    mmh_tie_t *t = j->t;
+    callord_t *ord = NULL; size_t ord_cap = 0;
+    for (int64_t r = lo; r < hi; r++) {
+        const int64_t a = j->first[r], b = j->first[r + 1];
+        j->out_keys[r] = NULL; j->out_hash[r] = NULL; j->out_n[r] = 0;
+        if (a == b) continue;
+        const mm_read_t *rd = &j->batch->reads[r];
+        const char *mm = (const char *)j->batch->mm + rd->mm_off;
+        if ((size_t)(b - a) > ord_cap) { ord_cap = (size_t)(b - a) * 2; free(ord); ord = (callord_t *)malloc(sizeof(callord_t) * ord_cap); if (!ord) { j->failed = 1; return; } }
+        size_t n = 0;
+        const int multi = has_multi_letter_group(mm, rd->mm_len);
+        for (int64_t i = a; i < b; i++) {
+            const mm_view_row_t *w = &j->rows[i];
+            const uint32_t implicit = w->read_pos >> 31, gord = w->read >> 24;
+            if (gord >= 255u) j->failed = 1;
+            if (w->code >= j->n_codes) { j->failed = 1; continue; }
+            if (!implicit && j->klass[w->code][w->prob] == 0) continue;   /* ambiguous: never reaches the table (src/mod.c:1180-1191) */
+            ord[n].gord = gord; ord[n].implicit = implicit; ord[n].fq = w->read_pos & 0x7FFFFFFFu; ord[n].m = 0; ord[n].row = (uint32_t)(i - a);
+            n++;
+        }
+        if (n == 0) continue;
+        /* rows arrive by position; the reference met them group by group, listed calls before implicit ones, along the read */
+        if (multi) for (size_t i = 0; i < n; i++) ord[i].m = letter_index(mm, rd->mm_len, ord[i].gord, j->codes[j->rows[a + ord[i].row].code]);
+        qsort(ord, n, sizeof(callord_t), callord_cmp);
+        const size_t per = t->haplotypes ? 2 : 1;
+        tkey_t *keys = (tkey_t *)malloc(sizeof(tkey_t) * n * per);
+        uint32_t *hash = (uint32_t *)malloc(sizeof(uint32_t) * n * per);
+        if (!keys || !hash) { free(keys); free(hash); j->failed = 1; continue; }
+        ktab_t tab;
+        memset(&tab, 0, sizeof tab);
+        const char *contig = (rd->tid >= 0 && rd->tid < t->hdr->n_targets) ? t->hdr->target_name[rd->tid] : "*";
+        const size_t clen = strlen(contig);
+        size_t nk = 0;
+        for (size_t i = 0; i < n; i++) {
+            const mm_view_row_t *w = &j->rows[a + ord[i].row];
+            const char *code = j->codes[w->code];
+            const size_t colen = strlen(code);
+            for (size_t v = 0; v < per; v++) {   /* update_freq_map: the key with the haplotype, then the aggregate */
+                tkey_t k;
+                memset(&k, 0, sizeof k);
+                k.tid = rd->tid; k.pos = w->pos; k.ins = t->insertions ? w->ins_offset : 0; k.code = (int16_t)w->code;
+                k.strand = (rd->flag & 0x10) ? 1 : 0;
+                k.hp = (int16_t)(t->haplotypes ? (v == 0 ? (int)rd->hp : -1) : -1);
+                keys[nk] = k; hash[nk] = key_hash(&k, contig, clen, code, colen);
+                int pr = ktab_put(&tab, (uint32_t)nk, hash, keys);
+                if (pr < 0) j->failed = 1;
+                if (pr == 1) nk++;
+            }
+        }
+        /* slot order of the read's table = the order merge_freq_maps offers its keys to the core table */
+        tkey_t *sk = (tkey_t *)malloc(sizeof(tkey_t) * (nk ? nk : 1));
+        uint32_t *sh = (uint32_t *)malloc(sizeof(uint32_t) * (nk ? nk : 1));
+        size_t w2 = 0;
+        if (sk && sh) {
+            for (uint32_t s = 0; s < tab.n_buckets; s++) if (tab.used[s]) { sk[w2] = keys[tab.id[s]]; sh[w2] = hash[tab.id[s]]; w2++; }
+        } else {
+            j->failed = 1;
+        }
+        free(keys); free(hash); ktab_free(&tab);
+        j->out_keys[r] = sk; j->out_hash[r] = sh; j->out_n[r] = (uint32_t)w2;
+    }
+    free(ord);
+}
+
+int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, const mm_view_row_t *rows, int64_t n,
+                      const uint8_t *const *klass_of_code, const char *const *codes, int n_codes) {
+    if (!t || t->failed) return -1;
+    const int32_t nr = batch->n_reads;
+    int64_t *first = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nr + 1));
+    tkey_t **ok = (tkey_t **)calloc((size_t)nr + 1, sizeof(tkey_t *));
+    uint32_t **oh = (uint32_t **)calloc((size_t)nr + 1, sizeof(uint32_t *));
+    uint32_t *on = (uint32_t *)calloc((size_t)nr + 1, sizeof(uint32_t));
+    if (!first || !ok || !oh || !on) { free(first); free(ok); free(oh); free(on); t->failed = 1; return -1; }
+    int64_t i = 0;
+    for (int32_t r = 0; r <= nr; r++) {   /* rows come sorted by read */
+        while (i < n && (int32_t)(rows[i].read & 0xFFFFFFu) < r) i++;
+        first[r] = i;
+    }
+    first[nr] = n;
+    readjob_t job;
+    memset(&job, 0, sizeof job);
+    job.t = t; job.batch = batch; job.rows = rows; job.first = first; job.klass = klass_of_code; job.codes = codes; job.n_codes = n_codes;
+    job.out_keys = ok; job.out_hash = oh; job.out_n = on;
+    mm_pool_for(pool, nr, 16, read_range, &job);
+    if (job.failed) t->failed = 1;
+    /* merge_freq_maps: reads in batch order, every read's keys in its table's slot order */
+    for (int32_t r = 0; r < nr && !t->failed; r++)
+        for (uint32_t k = 0; k < on[r]; k++)
+            if (seq_add(t, &ok[r][k], oh[r][k])) { t->failed = 1; break; }
+    for (int32_t r = 0; r < nr; r++) { free(ok[r]); free(oh[r]); }
+    free(first); free(ok); free(oh); free(on);
+    return t->failed ? -1 : 0;
+}
+
+/* rows (any order, one per key) -> the order print_freq_output prints them in.  Returns 0, or -1 when the replay could not
+ * be made (then the rows are left as they were). */
+int mmh_tie_order_rows(mmh_tie_t *t, mm_row_t *rows, int64_t n) {
+    if (!t || t->failed) return -1;
+    if (n == 0) return 0;
+    if ((size_t)n != t->n) return -1;   /* the replay saw another set of keys than the counters hold: do not guess */
+    /* the core table: keys in first-insertion order */
+    ktab_t core;
+    memset(&core, 0, sizeof core);
+    for (size_t i = 0; i < t->n; i++) if (ktab_put(&core, (uint32_t)i, t->hash, t->keys) != 1) { ktab_free(&core); return -1; }
+    uint32_t *arr = (uint32_t *)malloc(sizeof(uint32_t) * t->n);
+    if (!arr) { ktab_free(&core); return -1; }
+    size_t w = 0;
+    for (uint32_t s = 0; s < core.n_buckets; s++) if (core.used[s]) arr[w++] = core.id[s];
+    ktab_free(&core);
+    cmpctx_t c = {t->rank, t->keys};
+    if (intro_sort(&c, w, arr)) { free(arr); return -1; }
+    /* the GPU's row of every key */
+    mm_row_t *out = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)n);
+    uint8_t *taken = (uint8_t *)calloc((size_t)n, 1);
+    size_t cap = 1;
+    while (cap < (size_t)n * 2) cap <<= 1;
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    if (!out || !taken || !idx) { free(out); free(taken); free(idx); free(arr); return -1; }
+    memset(idx, 0xFF, sizeof(uint32_t) * cap);
+    for (int64_t i = 0; i < n; i++) {
+        tkey_t k;
+        memset(&k, 0, sizeof k);
+        k.tid = rows[i].tid; k.pos = rows[i].pos; k.ins = rows[i].ins_offset; k.code = rows[i].code; k.hp = rows[i].hp; k.strand = rows[i].strand;
+        size_t s = (size_t)tkey_mix(&k) & (cap - 1);
+        while (idx[s] != 0xFFFFFFFFu) s = (s + 1) & (cap - 1);
+        idx[s] = (uint32_t)i;
+    }
+    int ok = 1;
+    for (size_t p = 0; p < w && ok; p++) {
+        const tkey_t *k = &t->keys[arr[p]];
+        size_t s = (size_t)tkey_mix(k) & (cap - 1);
+        for (;;) {
+            if (idx[s] == 0xFFFFFFFFu) { ok = 0; break; }
+            const mm_row_t *r = &rows[idx[s]];
+            if (r->tid == k->tid && r->pos == k->pos && r->ins_offset == k->ins && r->code == k->code && r->hp == k->hp && r->strand == k->strand) {
+                if (taken[idx[s]]) ok = 0;
+                taken[idx[s]] = 1;
+                out[p] = *r;
+                break;
+            }
+            s = (s + 1) & (cap - 1);
+        }
+    }
+    if (ok) memcpy(rows, out, sizeof(mm_row_t) * (size_t)n);
+    free(out); free(taken); free(idx); free(arr);
+    return ok ? 0 : -1;
+}

@@ -125,10 +125,23 @@ __device__ __forceinline__ void view_bitonic(Ptr K, Ptr V, uint32_t n, uint32_t 
     }
 }
 
+// opts.view == 2 (rows for the tie-order replay of the host, csrc/host/tieorder.c): a row also says in which MM group the
+// call was made (its ordinal, at most 255, in the top byte of `read`) and whether it was an implicit call of a '.' group
+// (bit 31 of read_pos): with the position in the read as sequenced that is the order the reference met the calls in.
+__device__ __forceinline__ uint32_t view_read_word(uint32_t r, unsigned long long v, uint32_t ordinal) {
+    if (!ordinal) return r;
+    const uint32_t g = (uint32_t)((v >> 29) & 0x7FFull);
+    return r | ((g < 255u ? g : 255u) << 24);
+}
+__device__ __forceinline__ uint32_t view_read_pos_word(unsigned long long v, uint32_t ordinal) {
+    const uint32_t q = (uint32_t)(v & 0x0FFFFFFFull);
+    return ordinal ? (q | ((uint32_t)((v >> 28) & 1ull) << 31)) : q;
+}
+
 // sorted records -> rows; a record with the key (position, code, ins_offset) of the one in front is a later entry of that
 // key and is dropped.  Returns this thread's number of dropped rows.
 template <int kThreads, typename Ptr>
-__device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uint32_t tid, uint32_t r, int32_t rpos, ViewRow* __restrict__ out) {
+__device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uint32_t tid, uint32_t r, int32_t rpos, ViewRow* __restrict__ out, uint32_t ordinal) {
     uint32_t dropped = 0;
     for (uint32_t i = tid; i < n; i += kThreads) {
         unsigned long long k = K[i], v = V[i];
@@ -138,9 +151,9 @@ __device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uin
             dup = ((uint32_t)kp & 0x0FFFFFFFu) == ((uint32_t)k & 0x0FFFFFFFu) && (vp >> 40) == (v >> 40);
         }
         ViewRow o;
-        o.read = dup ? kViewDropped : r;
+        o.read = dup ? kViewDropped : view_read_word(r, v, ordinal);
         o.pos = rpos + (int32_t)((uint32_t)k & 0x0FFFFFFFu) - 1;
-        o.read_pos = (uint32_t)(v & 0x0FFFFFFFull);
+        o.read_pos = view_read_pos_word(v, ordinal);
         o.ins_offset = (uint16_t)((v >> 40) & 0xFFFFull); o.code = (uint8_t)(v >> 56); o.prob = (uint8_t)(k >> 56);
         out[i] = o;
         dropped += dup;
@@ -184,7 +197,7 @@ __device__ __forceinline__ void view_bitonic1(unsigned long long* P, uint32_t n,
 template <int kThreads>
 __device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P, const unsigned long long* __restrict__ gk,
                                                     const unsigned long long* __restrict__ gv, uint32_t n, uint32_t tid, uint32_t r,
-                                                    int32_t rpos, ViewRow* __restrict__ out) {
+                                                    int32_t rpos, ViewRow* __restrict__ out, uint32_t ordinal) {
     uint32_t dropped = 0;
     for (uint32_t i = tid; i < n; i += kThreads) {
         const unsigned long long pi = P[i];
@@ -199,9 +212,9 @@ __device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P,
                 if (cv < bv) { bv = cv; best = cand; }
             }
             const unsigned long long k = gk[best];
-            o.read = r;
+            o.read = view_read_word(r, bv, ordinal);
             o.pos = rpos + (int32_t)((uint32_t)k & 0x0FFFFFFFu) - 1;
-            o.read_pos = (uint32_t)(bv & 0x0FFFFFFFull);
+            o.read_pos = view_read_pos_word(bv, ordinal);
             o.ins_offset = (uint16_t)((bv >> 40) & 0xFFFFull); o.code = (uint8_t)(bv >> 56); o.prob = (uint8_t)(k >> 56);
         } else {
             o.read = kViewDropped; o.pos = 0; o.read_pos = 0; o.ins_offset = 0; o.code = 0; o.prob = 0;
@@ -221,7 +234,7 @@ __device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P,
 __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
                                                    const unsigned int* __restrict__ offsets, uint32_t n_reads, uint32_t n_big_blocks,
                                                    const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows,
-                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped) {
+                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped, uint32_t ordinal) {
     __shared__ unsigned long long sp[kViewLdsRecs];   // packed sort words: a workgroup's segment, or four waves' slices
     __shared__ uint32_t drop_s;
     static_assert(kViewLdsRecs >= kWavesPerBlock * kViewWaveRecs, "one LDS layout for both kinds of workers");
@@ -238,10 +251,10 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
                 for (uint32_t i = threadIdx.x; i < n; i += 256) sp[i] = view_pack(gk[i], gv[i], i);
                 __syncthreads();
                 view_bitonic1<256>(sp, n, threadIdx.x);
-                dropped = view_emit_rows1<256>(sp, gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
+                dropped = view_emit_rows1<256>(sp, gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off, ordinal);
             } else {
                 view_bitonic<256>(gk, gv, n, threadIdx.x);
-                dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off);
+                dropped = view_emit_rows<256>(gk, gv, n, threadIdx.x, r, reads[r].pos, rows + off, ordinal);
             }
             if (dropped) atomicAdd(&drop_s, dropped);
             __syncthreads();
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
         for (uint32_t i = lane; i < n; i += 64) Pw[i] = view_pack(keys[off + i], vals[off + i], i);
         wave_sync();
         view_bitonic1<64>(Pw, n, lane);
-        uint32_t dropped = view_emit_rows1<64>(Pw, keys + off, vals + off, n, lane, r, reads[r].pos, rows + off);
+        uint32_t dropped = view_emit_rows1<64>(Pw, keys + off, vals + off, n, lane, r, reads[r].pos, rows + off, ordinal);
         uint32_t tot = lane_valu(wave_incl_scan(dropped), 63);
         if (lane == 0) {
             kept[r] = n - tot;

@@ -3,10 +3,12 @@ import os
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# (expected file, bam, contig fixture, freq kwargs) -- the reference's own freq tests,
+# (expected file, bam, contig fixture, freq kwargs, exact) -- the reference's own freq tests,
 # reference test/test.sh:116-232 (Test 3,4,5,5a,5b,5c,6,7,8,9,12,16).  `exact` marks configs that
-# cannot tie on (contig,pos), where the raw bytes must match; the rest compare after the same
-# whole-line sort the reference's tests apply (test/test.sh:119-121).
+# cannot tie on (contig,pos), where the raw bytes must match for the LIBRARY rows in canonical order and
+# for the oracle; the rest compare after the same whole-line sort the reference's tests apply
+# (test/test.sh:119-121).  The CLI replays the reference's tie order (csrc/host/tieorder.c) and must match
+# every golden byte for byte except those in CLI_SORTED_ONLY.
 GOLDEN_CASES = [
     ("test3.tsv", "example-hifi.bam", "chr22", dict(), True),
     ("test4.bedmethyl", "example-hifi.bam", "chr22", dict(K=1), True),
@@ -21,6 +23,10 @@ GOLDEN_CASES = [
     ("test12.tsv", "example-ont.bam", "chr22", dict(c="m,h", m="0.8,0.5"), False),
     ("test16.tsv", "eb.bam", "chr1", dict(c="e,b", m="0.5"), False),
 ]
+
+# test16.tsv: the committed golden's raw tie order is not what the current reference source produces (SURVEY.md
+# section 8c: identical after the reference's own sort only), so the CLI is compared sorted there too
+CLI_SORTED_ONLY = {"test16.tsv"}
 
 # the reference's own view tests, reference test/test.sh:66-111,186-247 (Test 1,2,2a,2b,2c_wild,2c,10,11,15,17a).
 # `exact`: one code requested, so a read cannot tie on (contig,pos) and the bytes must match; the others compare as

@@ -5,7 +5,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.cases import GOLDEN, GOLDEN_CASES
+from tests.cases import CLI_SORTED_ONLY, GOLDEN, GOLDEN_CASES
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,10 +61,27 @@ def test_cli_matches_reference_golden(exp, bam, ctg, kw, exact, fastas, tmp_path
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     want = open(os.path.join(GOLDEN, "expected", exp)).read()
     got = r.stdout.decode()
-    if exact:
-        assert got == want
-    else:
+    # byte for byte, ties included: the CLI replays the order the reference's hash table and unstable sort leave them in
+    if exp in CLI_SORTED_ONLY:
         assert sorted(got.splitlines()) == sorted(want.splitlines())
+    else:
+        assert got == want
+    if not exact:   # --canonical-order: the same rows, ties in the fixed order; never the replay
+        r2 = subprocess.run(cmd[:2] + ["--canonical-order"] + cmd[2:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r2.returncode == 0 and sorted(r2.stdout.decode().splitlines()) == sorted(want.splitlines())
+        assert b"Row order replay" not in r2.stderr and b"Row order replay" in r.stderr
+
+
+def test_cli_tie_order_does_not_depend_on_batching(fastas):
+    """The replayed order is a function of the reads in file order only (reference invariance): the
+    same bytes for -K 1, -K 7 and -K 4096 with different thread counts, on the goldens that tie."""
+    for exp, bam, ctg, kw, _ in [c for c in GOLDEN_CASES if c[0] in ("test5a.tsv", "test8.tsv", "test5c.tsv")]:
+        want = open(os.path.join(GOLDEN, "expected", exp)).read()
+        for extra in (["-K", "1", "-t", "2"], ["-K", "7", "-t", "8"], ["-K", "4096", "-B", "100M", "-t", "3"]):
+            r = subprocess.run([BIN, "freq"] + _args(kw) + extra + [fastas[ctg], os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            assert r.stdout.decode() == want, (exp, extra)
 
 
 def test_cli_output_file_and_batch_invariance(fastas, tmp_path):
