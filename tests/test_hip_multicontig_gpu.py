@@ -120,12 +120,22 @@ def test_cli_multi_contig_matches_oracle(c, m, flags, genome, tmp_path):
     th = O.parse_mod_threshes(m, len(mods))
     orc = _oracle(genome, bs, mods, th)
     want = O.format_rows(orc.rows(), NAMES, orc.code_names(), bedmethyl="-b" in flags)
-    outs = []
+    outs, replayed = [], []
     for extra in (["-K", "97", "-t", "3"], ["-K", "4096", "-B", "100M", "-t", "8"]):
-        r = subprocess.run([BIN, "freq", "-c", c, "-m", m] + flags + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        # the oracle puts rows that tie on (contig, start) in the canonical order: so does the CLI with --canonical-order
+        r = subprocess.run([BIN, "freq", "--canonical-order", "-c", c, "-m", m] + flags + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout.decode())
+        r = subprocess.run([BIN, "freq", "-c", c, "-m", m] + flags + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        replayed.append(r.stdout.decode())
     assert len(want) > 100000 and outs[0] == want and outs[1] == want
+    # the reference's order (replayed): the same rows, the same bytes whatever the batching; without ties the same as above
+    assert replayed[0] == replayed[1] and sorted(replayed[0].splitlines()) == sorted(want.splitlines())
+    if "," not in c:
+        assert replayed[0] == want
+    else:
+        assert replayed[0] != want      # two codes on every CpG: the hash order differs from the canonical one somewhere
 
 
 def test_cli_view_multi_contig_matches_oracle(genome, tmp_path):
@@ -206,7 +216,7 @@ def test_cli_devices_shares_of_the_genome_equal_a_single_run(flags, genome, tmp_
     synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
     synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
     assert os.path.getsize(bam + ".bai") > 1000
-    base = [BIN, "freq", "-c", "m[CG],h[CG]", "-m", "0.8,0.7", "-K", "200", "-t", "6"] + flags
+    base = [BIN, "freq", "--canonical-order", "-c", "m[CG],h[CG]", "-m", "0.8,0.7", "-K", "200", "-t", "6"] + flags
     one = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
     for devs in ("0,0", "0,0,0"):
