@@ -19,6 +19,7 @@
 #include "freq_kernels.hip.h"
 #include "freq_tiles.hip.h"
 #include "view_kernels.hip.h"
+#include "sort_kernels.hip.h"
 #include "minimod_hip.h"
 
 using namespace mmhip;
@@ -113,6 +114,11 @@ struct mm_freq {
     SideRec* d_side = nullptr;
     unsigned long long* d_side_count = nullptr;
     int64_t side_cap = 0;
+    // the side table: updates that do not fit the dense planes, counted per 64-bit key (side_insert); [0] occupied slots
+    unsigned long long *d_skeys = nullptr, *d_svals = nullptr, *d_scount = nullptr;
+    unsigned long long stab_slots = 0;
+    unsigned long long *d_sort_k[2] = {nullptr, nullptr}, *d_sort_v[2] = {nullptr, nullptr}; size_t cap_sort = 0;
+    uint32_t* d_sort_hist = nullptr; size_t cap_sort_hist = 0;
     unsigned long long* d_stats = nullptr;
     bool stats_on = false;
     Slot slots[kSlots];
@@ -190,6 +196,7 @@ DevParams base_params(mm_freq* h) {
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
+    p.skeys = h->d_skeys; p.svals = h->d_svals; p.smask = h->stab_slots ? h->stab_slots - 1 : 0; p.scount = h->d_scount;
     p.stats = h->stats_on ? h->d_stats : nullptr;
     return p;
 }
@@ -523,7 +530,8 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.h_vrows) (void)hipHostFree(s.h_vrows);
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
-                  h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows};
+                  h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
+                  h->d_skeys, h->d_svals, h->d_scount, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -633,7 +641,19 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
     }
     h->n_hp = opts->haplotypes ? (opts->n_hp_planes > 0 ? std::min(opts->n_hp_planes, MM_MAX_HP_PLANES) : 4) : 1;
-    h->side_cap = opts->view ? 16 : (opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20));
+    // opts.side_capacity sizes the side TABLE (slots of 16 bytes, rounded up to a power of two; it should stay under ~70 % full);
+    // the list behind it only takes what has no 64-bit key (haplotype tags above 29, positions past 2^35)
+    h->side_cap = opts->view ? 16 : (int64_t)(1 << 16);
+    {
+        unsigned long long want = opts->view ? 16ull : (unsigned long long)(opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20));
+        unsigned long long slots = 16;
+        while (slots < want) slots <<= 1;
+        h->stab_slots = slots;
+        if (dev_alloc(h, (void**)&h->d_skeys, 8 * (size_t)slots) || dev_alloc(h, (void**)&h->d_svals, 8 * (size_t)slots) ||
+            dev_alloc(h, (void**)&h->d_scount, 8)) return fail(h, "side table alloc failed");
+        if (hipMemset(h->d_skeys, 0xFF, 8 * (size_t)slots) != hipSuccess || hipMemset(h->d_svals, 0, 8 * (size_t)slots) != hipSuccess ||
+            hipMemset(h->d_scount, 0, 8) != hipSuccess) return fail(h, "side table init failed");
+    }
     if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_side, sizeof(SideRec) * (size_t)h->side_cap)) return fail(h, "side list alloc failed");
@@ -898,6 +918,9 @@ void mm_freq_reset_counters(mm_freq_t* h) {
     (void)drain(h);
     (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1));
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
+    (void)hipMemset(h->d_skeys, 0xFF, 8 * (size_t)h->stab_slots);
+    (void)hipMemset(h->d_svals, 0, 8 * (size_t)h->stab_slots);
+    (void)hipMemset(h->d_scount, 0, 8);
     (void)hipDeviceSynchronize();
     h->sticky_err = 0; h->sticky_read = -1;
 }
@@ -915,9 +938,10 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     // ---- every row a dense one (no haplotype planes, nothing on the side list): the device walks the positions and
     // writes finished rows in output order (k_site_count / k_site_emit); the host only copies them
     if (!h->opts.haplotypes && h->n_counter_words > 0 && !h->opts.finalize_by_runs) {
-        unsigned long long ns0 = 0;
+        unsigned long long ns0 = 0, nt0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
-        if (ns0 == 0) {
+        HIPCHK(hipMemcpy(&nt0, h->d_scount, sizeof(nt0), hipMemcpyDeviceToHost));
+        if (ns0 == 0 && nt0 == 0) {
             std::vector<int> order;
             for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
             std::sort(order.begin(), order.end(), [&](int a, int b) { return h->ctg_rank[a] < h->ctg_rank[b]; });
@@ -1043,7 +1067,79 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
         }
     }
     n_dense = rows.size();
-    // ---- side list
+    // ---- side table (K3): unique keys with their counts, compacted and ordered on the device
+    size_t n_side_sorted = 0;   // rows.size() up to which the side rows are known to be in output order
+    {
+        unsigned long long nu = 0;
+        HIPCHK(hipMemcpy(&nu, h->d_scount, sizeof(nu), hipMemcpyDeviceToHost));
+        if (nu > h->stab_slots - h->stab_slots / 8) return -MM_E_SIDEFULL;   // beyond 7/8 full the table may have refused updates
+        if (nu) {
+            if ((size_t)nu > h->cap_sort) {
+                for (int i = 0; i < 2; i++) { if (h->d_sort_k[i]) (void)hipFree(h->d_sort_k[i]); if (h->d_sort_v[i]) (void)hipFree(h->d_sort_v[i]); h->d_sort_k[i] = h->d_sort_v[i] = nullptr; }
+                h->cap_sort = 0;
+                size_t cap = (size_t)nu + (size_t)nu / 8 + 1024;
+                for (int i = 0; i < 2; i++)
+                    if (dev_alloc(h, (void**)&h->d_sort_k[i], 8 * cap) || dev_alloc(h, (void**)&h->d_sort_v[i], 8 * cap)) return -MM_E_NOMEM;
+                h->cap_sort = cap;
+            }
+            const uint32_t nblk = (uint32_t)((nu + kSortTile - 1) / kSortTile);
+            if ((size_t)256 * nblk > h->cap_sort_hist) {
+                if (h->d_sort_hist) (void)hipFree(h->d_sort_hist);
+                h->d_sort_hist = nullptr; h->cap_sort_hist = 0;
+                if (dev_alloc(h, (void**)&h->d_sort_hist, 4 * ((size_t)256 * nblk + 256))) return -MM_E_NOMEM;
+                h->cap_sort_hist = (size_t)256 * nblk + 256;
+            }
+            unsigned long long* d_cnt = h->d_tile_offsets;   // any 8 device bytes: the compaction cursor
+            unsigned long long* tmp_cnt = nullptr;
+            if (!d_cnt) { if (dev_alloc(h, (void**)&tmp_cnt, 8)) return -MM_E_NOMEM; d_cnt = tmp_cnt; }
+            HIPCHK(hipMemsetAsync(d_cnt, 0, 8, h->stream));
+            hipLaunchKernelGGL(k_side_compact, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, (unsigned long long)h->n_cu * 16)), dim3(256), 0,
+                               h->stream, h->d_skeys, h->d_svals, h->stab_slots, h->d_sort_k[0], h->d_sort_v[0], d_cnt);
+            int cur = 0;
+            for (int shift = 0; shift < 64; shift += 8) {   // LSD radix sort on the whole key (63 bits used)
+                hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cur], nu, shift, h->d_sort_hist, nblk);
+                hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, h->d_sort_hist, (unsigned long long)256 * nblk);
+                hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cur], h->d_sort_v[cur], nu, shift, h->d_sort_hist, nblk,
+                                   h->d_sort_k[cur ^ 1], h->d_sort_v[cur ^ 1]);
+                cur ^= 1;
+            }
+            HIPCHK(hipGetLastError());
+            std::vector<unsigned long long> sk((size_t)nu), sv((size_t)nu);
+            HIPCHK(hipMemcpyAsync(sk.data(), h->d_sort_k[cur], 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(sv.data(), h->d_sort_v[cur], 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (tmp_cnt) { (void)hipFree(tmp_cnt); h->device_bytes -= 16; }
+            // keys are ordered by (position in the reference-word space, strand, code, ins_offset, haplotype): inside a contig
+            // that is the output order; the contigs' runs are put in name order
+            std::vector<int> seq_tids;
+            for (int t = 0; t < h->n_contigs; t++) if (h->ref_base[t] >= 0) seq_tids.push_back(t);   // ref_base rises with tid
+            struct Run { int rank; size_t lo, hi; };
+            std::vector<Run> runs;
+            std::vector<mm_row_t> srows((size_t)nu);
+            size_t cursor = 0;
+            for (size_t i = 0; i < (size_t)nu; i++) {
+                const unsigned long long k = sk[i];
+                const int64_t rpos = (int64_t)(k >> 28);
+                while (cursor + 1 < seq_tids.size() && h->ref_base[seq_tids[cursor + 1]] <= rpos) cursor++;
+                const int t = seq_tids.empty() ? 0 : seq_tids[cursor];
+                mm_row_t r;
+                std::memset(&r, 0, sizeof(r));
+                r.tid = t; r.pos = (int32_t)(rpos - h->ref_base[t]); r.strand = (uint8_t)((k >> 27) & 1u); r.code = (int16_t)((k >> 21) & 63u);
+                r.ins_offset = (uint16_t)((k >> 5) & 0xFFFFu);
+                const int h5 = (int)(k & 31u);
+                r.hp = (int16_t)((h->opts.haplotypes && h5 != 31) ? h5 : -1);
+                r.n_called = (uint32_t)sv[i]; r.n_mod = (uint32_t)(sv[i] >> 32);
+                srows[i] = r;
+                if (runs.empty() || runs.back().rank != h->ctg_rank[t]) runs.push_back({h->ctg_rank[t], i, i + 1});
+                else runs.back().hi = i + 1;
+            }
+            std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.rank < b.rank; });
+            rows.reserve(rows.size() + (size_t)nu);
+            for (const Run& rn : runs) rows.insert(rows.end(), srows.begin() + (ptrdiff_t)rn.lo, srows.begin() + (ptrdiff_t)rn.hi);
+            n_side_sorted = rows.size();
+        }
+    }
+    // ---- side list (what has no side key: rare)
     unsigned long long ns = 0;
     HIPCHK(hipMemcpy(&ns, h->d_side_count, sizeof(ns), hipMemcpyDeviceToHost));
     if (ns > (unsigned long long)h->side_cap) return -MM_E_SIDEFULL;
@@ -1084,7 +1180,12 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
         if (!runs_sorted) {
             std::sort(rows.begin(), rows.end(), less);
         } else {
-            std::sort(rows.begin() + (ptrdiff_t)n_dense, rows.end(), less);
+            // the table's rows arrive ordered; only the list's (rare) need sorting, and merging in when there are any
+            if (n_side_sorted < rows.size()) {
+                std::sort(rows.begin() + (ptrdiff_t)std::max(n_side_sorted, n_dense), rows.end(), less);
+                if (n_side_sorted > n_dense)
+                    std::inplace_merge(rows.begin() + (ptrdiff_t)n_dense, rows.begin() + (ptrdiff_t)n_side_sorted, rows.end(), less);
+            }
             run_starts.push_back(rows.size());
             while (run_starts.size() > 2) {
                 std::vector<size_t> next;

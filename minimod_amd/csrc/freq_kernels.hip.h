@@ -98,9 +98,15 @@ struct DevParams {
     int32_t* status;               // per read
     unsigned int* err_summary;     // min over failing reads of (read index << 8 | code), 0xFFFFFFFF = none
     unsigned int* host_flag;       // pinned host word, set to 0 by any failing read: the host copies err_summary back only then
-    SideRec* side;
+    SideRec* side;                 // the rare updates that do not even fit a side key (haplotype tags above 29, positions past 2^35)
     unsigned long long* side_count;
     unsigned long long side_cap;
+    // updates that do not fit the dense planes (inside an insertion, haplotype or code without a plane, outside the shard)
+    // are counted in a hash table on one 64-bit key: side_insert below
+    unsigned long long* skeys;     // kSideEmpty = free
+    unsigned long long* svals;     // n_called | n_mod << 32, like a dense counter
+    unsigned long long smask;      // slots - 1 (a power of two)
+    unsigned long long* scount;    // occupied slots
     unsigned long long* stats;     // optional: [0..15] diagnostic timers, then kStatSlots rows of {reference-word lookups, ML bytes
                                    // read, dense updates, side updates}, one row per wave slot (summed by the host)
     // scheduling / scratch
@@ -127,6 +133,37 @@ constexpr int kQueueStride = 32; // the 64 tile-queue counters lie 128 bytes apa
 constexpr uint32_t kViewRegions = 64;
 constexpr uint32_t kViewCountStride = 32;
 constexpr uint32_t kViewMaxGroup = 2047;   // group ordinals that fit the record; a read with more MM groups fails loudly
+
+constexpr unsigned long long kSideEmpty = ~0ull;
+// key of a side update, ordered like the output inside one contig: position in the reference-word space (35 bits) |
+// strand | code (6) | ins_offset (16) | haplotype (5: the tag's value, 31 = none / '*')
+__device__ __forceinline__ bool side_key(int64_t rpos, int rev, int code, uint32_t ins, int hp, unsigned long long& key) {
+    if (rpos < 0 || rpos >= (1ll << 35) || code < 0 || code >= 64 || hp > 29) return false;
+    const unsigned long long h5 = hp < 0 ? 31ull : (unsigned long long)hp;
+    key = ((unsigned long long)rpos << 28) | ((unsigned long long)(rev & 1) << 27) | ((unsigned long long)code << 21) |
+          ((unsigned long long)(ins & 0xFFFFu) << 5) | h5;
+    return true;
+}
+__device__ __forceinline__ unsigned long long side_mix(unsigned long long x) {
+    x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x;
+}
+// one counter update on the table: claim or find the key's slot (linear probing), then the same packed 64-bit add as a
+// dense counter.  Returns 0, or MM_E_SIDEFULL when every slot is taken by another key.
+__device__ __forceinline__ int side_insert(unsigned long long* keys, unsigned long long* vals, unsigned long long mask, unsigned long long* count,
+                                           unsigned long long key, unsigned long long inc) {
+    unsigned long long h = side_mix(key) & mask;
+    for (unsigned long long probes = 0; probes <= mask; probes++) {
+        unsigned long long old = keys[h];
+        if (old == kSideEmpty) {
+            old = atomicCAS(keys + h, kSideEmpty, key);
+            if (old == kSideEmpty) atomicAdd(count, 1ull);
+        }
+        if (old == kSideEmpty || old == key) { atomicAdd(vals + h, inc); return 0; }
+        h = (h + 1ull) & mask;
+    }
+    return MM_E_SIDEFULL;
+}
 
 // ---------------------------------------------------------------------------------- wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -470,6 +507,11 @@ struct K1 {
     }
 
     __device__ __forceinline__ void side_append(int32_t pos, uint32_t ins_off, int is_mod, int code) {
+        unsigned long long key;
+        if (side_key(c.ref_base + pos, c.rev, code, ins_off, c.hp, key)) {
+            if (side_insert(p.skeys, p.svals, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            return;
+        }
         uint64_t m = __ballot(1);
         int leader = __ffsll((unsigned long long)m) - 1;
         unsigned long long base = 0;

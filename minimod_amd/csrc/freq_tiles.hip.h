@@ -1055,6 +1055,11 @@ struct KC {
         return blk * 32u + word * 8u + n;
     }
     __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
+        unsigned long long key;
+        if (side_key(ref_base + spos, rev, code, ins_off, hp, key)) {
+            if (side_insert(p.skeys, p.svals, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            return;
+        }
         uint64_t m = __ballot(1);
         int leader = __ffsll((unsigned long long)m) - 1;
         unsigned long long base = 0;
