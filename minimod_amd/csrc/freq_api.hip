@@ -115,7 +115,7 @@ struct mm_freq {
     unsigned long long* d_side_count = nullptr;
     int64_t side_cap = 0;
     // the side table: updates that do not fit the dense planes, counted per 64-bit key (side_insert); [0] occupied slots
-    unsigned long long *d_skeys = nullptr, *d_svals = nullptr, *d_scount = nullptr;
+    unsigned long long *d_stab = nullptr, *d_scount = nullptr;
     unsigned long long stab_slots = 0;
     unsigned long long *d_sort_k[2] = {nullptr, nullptr}, *d_sort_v[2] = {nullptr, nullptr}; size_t cap_sort = 0;
     uint32_t* d_sort_hist = nullptr; size_t cap_sort_hist = 0;
@@ -169,6 +169,13 @@ int grow(mm_freq* h, void** p, size_t* cap, size_t need) {
     return 0;
 }
 
+// every slot free: key words all ones, count words zero
+int side_table_clear(mm_freq* h) {
+    hipLaunchKernelGGL(k_side_clear, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, 1u << 16)), dim3(256), 0, 0, h->d_stab, h->stab_slots);
+    if (hipGetLastError() != hipSuccess || hipMemset(h->d_scount, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -MM_E_HIP;
+    return 0;
+}
+
 int complement(int c) {
     switch (c) {
         case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
@@ -196,7 +203,7 @@ DevParams base_params(mm_freq* h) {
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
-    p.skeys = h->d_skeys; p.svals = h->d_svals; p.smask = h->stab_slots ? h->stab_slots - 1 : 0; p.scount = h->d_scount;
+    p.stab = h->d_stab; p.smask = h->stab_slots ? h->stab_slots - 1 : 0; p.scount = h->d_scount;
     p.stats = h->stats_on ? h->d_stats : nullptr;
     return p;
 }
@@ -531,7 +538,7 @@ void mm_freq_destroy(mm_freq_t* h) {
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
-                  h->d_skeys, h->d_svals, h->d_scount, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
+                  h->d_stab, h->d_scount, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -649,10 +656,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         unsigned long long slots = 16;
         while (slots < want) slots <<= 1;
         h->stab_slots = slots;
-        if (dev_alloc(h, (void**)&h->d_skeys, 8 * (size_t)slots) || dev_alloc(h, (void**)&h->d_svals, 8 * (size_t)slots) ||
-            dev_alloc(h, (void**)&h->d_scount, 8)) return fail(h, "side table alloc failed");
-        if (hipMemset(h->d_skeys, 0xFF, 8 * (size_t)slots) != hipSuccess || hipMemset(h->d_svals, 0, 8 * (size_t)slots) != hipSuccess ||
-            hipMemset(h->d_scount, 0, 8) != hipSuccess) return fail(h, "side table init failed");
+        if (dev_alloc(h, (void**)&h->d_stab, 16 * (size_t)slots) || dev_alloc(h, (void**)&h->d_scount, 8)) return fail(h, "side table alloc failed");
+        if (side_table_clear(h) != 0) return fail(h, "side table init failed");
     }
     if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
@@ -918,9 +923,7 @@ void mm_freq_reset_counters(mm_freq_t* h) {
     (void)drain(h);
     (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1));
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
-    (void)hipMemset(h->d_skeys, 0xFF, 8 * (size_t)h->stab_slots);
-    (void)hipMemset(h->d_svals, 0, 8 * (size_t)h->stab_slots);
-    (void)hipMemset(h->d_scount, 0, 8);
+    (void)side_table_clear(h);
     (void)hipDeviceSynchronize();
     h->sticky_err = 0; h->sticky_read = -1;
 }
@@ -1094,7 +1097,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
             if (!d_cnt) { if (dev_alloc(h, (void**)&tmp_cnt, 8)) return -MM_E_NOMEM; d_cnt = tmp_cnt; }
             HIPCHK(hipMemsetAsync(d_cnt, 0, 8, h->stream));
             hipLaunchKernelGGL(k_side_compact, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, (unsigned long long)h->n_cu * 16)), dim3(256), 0,
-                               h->stream, h->d_skeys, h->d_svals, h->stab_slots, h->d_sort_k[0], h->d_sort_v[0], d_cnt);
+                               h->stream, h->d_stab, h->stab_slots, h->d_sort_k[0], h->d_sort_v[0], d_cnt);
             int cur = 0;
             for (int shift = 0; shift < 64; shift += 8) {   // LSD radix sort on the whole key (63 bits used)
                 hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cur], nu, shift, h->d_sort_hist, nblk);

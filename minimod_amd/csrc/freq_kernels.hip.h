@@ -103,8 +103,8 @@ struct DevParams {
     unsigned long long side_cap;
     // updates that do not fit the dense planes (inside an insertion, haplotype or code without a plane, outside the shard)
     // are counted in a hash table on one 64-bit key: side_insert below
-    unsigned long long* skeys;     // kSideEmpty = free
-    unsigned long long* svals;     // n_called | n_mod << 32, like a dense counter
+    unsigned long long* stab;      // slots of 16 bytes: [2i] key (kSideEmpty = free), [2i + 1] n_called | n_mod << 32 like a dense counter
+                                   // (key and counts share a cache line: one random line per update)
     unsigned long long smask;      // slots - 1 (a power of two)
     unsigned long long* scount;    // occupied slots
     unsigned long long* stats;     // optional: [0..15] diagnostic timers, then kStatSlots rows of {reference-word lookups, ML bytes
@@ -150,16 +150,16 @@ __device__ __forceinline__ unsigned long long side_mix(unsigned long long x) {
 }
 // one counter update on the table: claim or find the key's slot (linear probing), then the same packed 64-bit add as a
 // dense counter.  Returns 0, or MM_E_SIDEFULL when every slot is taken by another key.
-__device__ __forceinline__ int side_insert(unsigned long long* keys, unsigned long long* vals, unsigned long long mask, unsigned long long* count,
+__device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long mask, unsigned long long* count,
                                            unsigned long long key, unsigned long long inc) {
     unsigned long long h = side_mix(key) & mask;
     for (unsigned long long probes = 0; probes <= mask; probes++) {
-        unsigned long long old = keys[h];
+        unsigned long long old = tab[2 * h];
         if (old == kSideEmpty) {
-            old = atomicCAS(keys + h, kSideEmpty, key);
+            old = atomicCAS(tab + 2 * h, kSideEmpty, key);
             if (old == kSideEmpty) atomicAdd(count, 1ull);
         }
-        if (old == kSideEmpty || old == key) { atomicAdd(vals + h, inc); return 0; }
+        if (old == kSideEmpty || old == key) { atomicAdd(tab + 2 * h + 1, inc); return 0; }
         h = (h + 1ull) & mask;
     }
     return MM_E_SIDEFULL;
@@ -509,7 +509,7 @@ struct K1 {
     __device__ __forceinline__ void side_append(int32_t pos, uint32_t ins_off, int is_mod, int code) {
         unsigned long long key;
         if (side_key(c.ref_base + pos, c.rev, code, ins_off, c.hp, key)) {
-            if (side_insert(p.skeys, p.svals, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

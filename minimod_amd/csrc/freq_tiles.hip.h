@@ -91,7 +91,10 @@ struct ScanLds {
     uint32_t mmw[260];   // 1024 MM characters + 16 of look-ahead
     char hdr[16];
     int16_t g_code[16];
-    uint32_t gend[kGroupEnds];   // run_mm: where the read's first groups end (found once, used by both passes)
+    // run_mm: what the record pass needs of every group, written once by the header pass
+    uint32_t g_lstart[kGroupEnds], g_end[kGroupEnds], g_flags[kGroupEnds], g_c01[kGroupEnds], g_c23[kGroupEnds];
+    uint32_t g_first[kGroupEnds + 1];   // index (inside the read) of the group's first tile; [n_groups] = the read's tile count
+    uint32_t g_nlist[kGroupEnds];
 };
 constexpr uint32_t kSliceD = 384;   // rank-directory entries staged in LDS per tile (12 kb of read)
 #ifndef MM_SLICE_C
@@ -122,6 +125,26 @@ __device__ __forceinline__ uint32_t find_semicolon(const uint8_t* mm, uint32_t m
     uint32_t pos = from;
     uint32_t found = mlen;
     bool hit = false;
+    {   // most groups end within a kilobyte: one 16-byte load per lane first
+        uint4 w = make_uint4(0, 0, 0, 0);
+        const uint32_t off = pos + 16u * lane;
+        if (off < mlen) __builtin_memcpy(&w, mm + off, 16);
+        uint32_t first = 0xFFFFFFFFu;
+        const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 3; q >= 0; q--) {
+            uint32_t z = semi_bytes(d[q]);
+            if (z) first = 4u * q + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+        }
+        if (first != 0xFFFFFFFFu && off + first >= mlen) first = 0xFFFFFFFFu;
+        uint64_t b = __ballot(first != 0xFFFFFFFFu);
+        if (b) {
+            int l = __ffsll((unsigned long long)b) - 1;
+            found = pos + 16u * (uint32_t)l + lane_valu(first, l);
+            hit = true;
+        }
+        pos += 1024u;
+    }
     while (pos < mlen && !hit) {
         uint4 w[4];
 #pragma unroll
@@ -599,16 +622,16 @@ struct KA {
         bool have_ref = tid >= 0 && tid < p.n_contigs;
         if (have_ref) have_ref = scalar_load(p.ref_base + tid) >= 0;
         int result = 0;   // a missing contig is reported by the CIGAR item
-        // pass 1: regular or not, and how many tiles
+        // pass 1: the group headers (mod.c:1003-1062) -> regular or not, and a table of what the records need.  Reads with
+        // more than kGroupEnds groups go the fused kernel's way like the other irregular ones.
         int first_cls = -1;
         bool irregular = false;
         uint32_t need = 0, ngrp = 0;
         if (have_ref) {
             uint32_t mpos = 0;
-            int guard = 0;
             while (mpos < mlen && !irregular) {
                 GroupHdr g = parse_header(mm, mlen, mpos);
-                if (g.herr || g.n > 4 || ++guard > 4096) { irregular = true; }   // errors are reported by the fused kernel
+                if (g.herr || g.n > 4 || ngrp >= kGroupEnds) { irregular = true; }   // errors are reported by the fused kernel
                 else {
                     int mb = rev ? complement_char(g.modbase) : g.modbase;
                     bool direct = g.modbase == 'N', dot = g.flag == '.';
@@ -617,16 +640,28 @@ struct KA {
                         if (first_cls < 0) first_cls = cls;
                         else if (cls != first_cls) irregular = true;
                     }
-                    uint32_t endp = find_semicolon(mm, mlen, g.lstart);
-                    if (ngrp < kGroupEnds && lane == 0) S.gend[ngrp] = endp;
+                    lookup_codes(g);
+                    const int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
+                    const bool unwanted = gc0 < 0 && gc1 < 0 && gc2 < 0 && gc3 < 0;   // none of the group's codes was asked for with -c
+                    const uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) | (unwanted ? 64u : 0u) |
+                                            ((uint32_t)cls << 8) | ((uint32_t)g.n << 12);
+                    const uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                    const uint32_t nlist = (endp - g.lstart) / kTileChars + 1u;
+                    if (lane == 0) {
+                        S.g_lstart[ngrp] = g.lstart; S.g_end[ngrp] = endp; S.g_flags[ngrp] = gflags; S.g_first[ngrp] = need; S.g_nlist[ngrp] = nlist;
+                        S.g_c01[ngrp] = (uint32_t)(uint16_t)gc0 | ((uint32_t)(uint16_t)gc1 << 16);
+                        S.g_c23[ngrp] = (uint32_t)(uint16_t)gc2 | ((uint32_t)(uint16_t)gc3 << 16);
+                    }
                     ngrp++;
-                    need += (endp - g.lstart) / kTileChars + 1u;
-                    if (dot) need += L / kTailRanks + 1u;
+                    need += nlist + (dot ? L / kTailRanks + 1u : 0u);
                     mpos = endp + 1u;
                 }
             }
+            if (lane == 0 && ngrp <= kGroupEnds) S.g_first[ngrp < kGroupEnds ? ngrp : kGroupEnds] = need;
+            if (p.view && ngrp > kViewMaxGroup + 1u) err = MM_E_TOOMANY;
             wave_sync();
         }
+        if (__ballot(err != 0)) irregular = true;   // a code the host did not intern (wildcard runs): reported by the fused kernel in order
         uint32_t tbase = 0;
         if (have_ref && !irregular && need > 0) {
             if (lane == 0) tbase = atomicAdd(P.tile_count + region, need);
@@ -638,55 +673,38 @@ struct KA {
         uint2* const rdesc = P.g_sum + (size_t)region * P.tile_cap;
         const uint32_t mm_abs0 = (uint32_t)rd.mm_off;   // the MM pool of a batch is below 4 GiB (checked at submit)
         if (have_ref && irregular) {
+            err = 0;
             if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; if (P.host_fb_flag) *P.host_fb_flag = 1u; }
         }
-        // pass 2: the tile records (no text is parsed here beyond the headers)
+        // pass 2: the tile records of all groups in one sweep, a lane per record (no text is read here)
         if (have_ref && !irregular) {
-            uint32_t mpos = 0, gord = 0;
-            bool bad = false;
-            while (mpos < mlen && !bad) {
-                GroupHdr g = parse_header(mm, mlen, mpos);
-                lookup_codes(g);
-                if (p.view && gord > kViewMaxGroup) err = MM_E_TOOMANY;
-                bad = __ballot(err != 0) != 0;
-                int mb = rev ? complement_char(g.modbase) : g.modbase;
-                bool direct = g.modbase == 'N', dot = g.flag == '.';
-                int16_t gc0 = S.g_code[0], gc1 = S.g_code[1], gc2 = S.g_code[2], gc3 = S.g_code[3];
-                const bool unwanted = gc0 < 0 && gc1 < 0 && gc2 < 0 && gc3 < 0;   // none of the group's codes was asked for with -c
-                uint32_t gflags = 1u | (dot ? 4u : 0u) | (direct ? 8u : 0u) | (mb == 'N' ? 16u : 0u) | (unwanted ? 64u : 0u) |
-                                  ((uint32_t)base_class_of_char(mb) << 8) | ((uint32_t)g.n << 12);
-                uint32_t endp = gord < kGroupEnds ? uniu(S.gend[gord]) : find_semicolon(mm, mlen, g.lstart);
-                uint32_t nlist = (endp - g.lstart) / kTileChars + 1u;
-                uint32_t ntail = dot ? L / kTailRanks + 1u : 0u;
-                uint32_t gfirst = tcur;
-                if (!bad) {
-                    // lanes write the group's records in parallel: record j of the group
-                    for (uint32_t j0 = 0; j0 < nlist + ntail; j0 += 64) {
-                        uint32_t j = j0 + lane;
-                        if (j < nlist + ntail) {
-                            TileRec t;
-                            bool tail = j >= nlist;
-                            t.ridx = (uint32_t)ridx;
-                            t.cpos = tail ? j - nlist : g.lstart + kTileChars * j;
-                            t.read_first = tbase; t.group_first = gfirst;
-                            t.flags = gflags | (tail ? 2u : 0u) | ((!tail && j == 0) ? 32u : 0u) | ((!tail && j + 1u == nlist) ? 128u : 0u);
-                            t.g_code[0] = gc0; t.g_code[1] = gc1; t.g_code[2] = gc2; t.g_code[3] = gc3;
-                            t.gord = gord;
-                            rtiles[gfirst + j] = t;
-                            // what k_sum_tiles needs of a list tile, so that it goes from here straight to the text
-                            // (not record -> read -> text); it overwrites this with the tile's summary.  Tail tiles
-                            // get their summary here.
-                            uint32_t rem = mlen - t.cpos;
-                            rdesc[gfirst + j] = tail ? make_uint2((uint32_t)g.n << 16, 0u)
-                                                     : make_uint2(mm_abs0 + t.cpos, kSumParse | (j == 0 ? kSumFirst : 0u) | (unwanted ? 0u : kSumKeep) |
-                                                                                        ((uint32_t)g.n << 16) | (rem < 511u ? rem : 511u));
-                        }
-                    }
-                    tcur += nlist + ntail;
-                    mpos = endp + 1u;
-                    gord++;
+            for (uint32_t j0 = 0; j0 < need; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                if (j < need) {
+                    uint32_t gi = 0;
+                    while (gi + 1u < ngrp && S.g_first[gi + 1u] <= j) gi++;
+                    const uint32_t gfirst = S.g_first[gi], nlist = S.g_nlist[gi], lstart = S.g_lstart[gi], gflags = S.g_flags[gi];
+                    const uint32_t k = j - gfirst;           // record k of its group
+                    const bool tail = k >= nlist;
+                    const uint32_t n_codes = (gflags >> 12) & 7u;
+                    TileRec t;
+                    t.ridx = (uint32_t)ridx;
+                    t.cpos = tail ? k - nlist : lstart + kTileChars * k;
+                    t.read_first = tbase; t.group_first = tbase + gfirst;
+                    t.flags = gflags | (tail ? 2u : 0u) | ((!tail && k == 0) ? 32u : 0u) | ((!tail && k + 1u == nlist) ? 128u : 0u);
+                    const uint32_t c01 = S.g_c01[gi], c23 = S.g_c23[gi];
+                    t.g_code[0] = (int16_t)(c01 & 0xFFFFu); t.g_code[1] = (int16_t)(c01 >> 16); t.g_code[2] = (int16_t)(c23 & 0xFFFFu); t.g_code[3] = (int16_t)(c23 >> 16);
+                    t.gord = gi;
+                    rtiles[tbase + j] = t;
+                    // what k_sum_tiles needs of a list tile, so that it goes from here straight to the text (not record ->
+                    // read -> text); it overwrites this with the tile's summary.  Tail tiles get their summary here.
+                    const uint32_t rem = mlen - t.cpos;
+                    rdesc[tbase + j] = tail ? make_uint2(n_codes << 16, 0u)
+                                            : make_uint2(mm_abs0 + t.cpos, kSumParse | (k == 0 ? kSumFirst : 0u) | ((gflags & 64u) ? 0u : kSumKeep) |
+                                                                           (n_codes << 16) | (rem < 511u ? rem : 511u));
                 }
             }
+            tcur = tbase + need;
             result = any_err();
         }
         // reserved slots this read did not fill are marked invalid (flags = 0)
@@ -1057,7 +1075,7 @@ struct KC {
     __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
         unsigned long long key;
         if (side_key(ref_base + spos, rev, code, ins_off, hp, key)) {
-            if (side_insert(p.skeys, p.svals, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

@@ -7,13 +7,19 @@
 
 namespace mmhip {
 
+__global__ __launch_bounds__(256) void k_side_clear(unsigned long long* __restrict__ tab, unsigned long long cap) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * 256u) {
+        tab[2 * i] = kSideEmpty; tab[2 * i + 1] = 0ull;
+    }
+}
+
 // occupied slots -> dense (key, value) arrays, in any order (one wave-aggregated reservation per wave)
-__global__ __launch_bounds__(256) void k_side_compact(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_side_compact(const unsigned long long* __restrict__ tab,
                                                       unsigned long long cap, unsigned long long* __restrict__ out_k,
                                                       unsigned long long* __restrict__ out_v, unsigned long long* __restrict__ counter) {
     for (unsigned long long i0 = (unsigned long long)blockIdx.x * 256u; i0 < cap; i0 += (unsigned long long)gridDim.x * 256u) {
         const unsigned long long i = i0 + threadIdx.x;
-        const unsigned long long k = i < cap ? keys[i] : kSideEmpty;
+        const unsigned long long k = i < cap ? tab[2 * i] : kSideEmpty;
         const bool have = k != kSideEmpty;
         const uint64_t m = __ballot(have);
         if (!m) continue;
@@ -23,7 +29,7 @@ __global__ __launch_bounds__(256) void k_side_compact(const unsigned long long* 
         base = __shfl(base, leader, 64);
         if (have) {
             const unsigned long long at = base + (unsigned long long)__popcll(m & lanemask_lt());
-            out_k[at] = k; out_v[at] = vals[i];
+            out_k[at] = k; out_v[at] = tab[2 * i + 1];
         }
     }
 }
