@@ -72,6 +72,8 @@ def parse_args():
                                                            "uploaded before the timed region instead of planning on the device inside it")
     ap.add_argument("--coalesce", type=int, default=16, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
                                                              "one launch (1 = every step is its own launch)")
+    ap.add_argument("--region-mb", type=float, default=0.0, help="experiment: reads per GPU spread over this many Mb instead of the workload's "
+                                                                  "interval (depth = reads * 15 kb / region: counter contention at depth)")
     ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
     ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
@@ -358,7 +360,7 @@ def main():
     from minimod_amd import engine, synth
 
     # N = 1: one contig (C2 as BASELINE.json states it).  N > 1: the 24-contig genome, one contiguous share per rank.
-    region = wl.get("region", INTERVAL)
+    region = wl.get("region", INTERVAL) if args.region_mb <= 0 else int(args.region_mb * (1 << 20)) // (1 << 20) * (1 << 20)
     if world == 1 or args.single_contig:
         plan = single_contig_plan(rank, world, region, HALO)
     else:
@@ -582,7 +584,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": wl["what"] % dict(reads=args.reads, mb=wl.get("region", INTERVAL) / 1e6, batch=args.batch),
+            "config": {"workload": wl["what"] % dict(reads=args.reads, mb=region / 1e6, batch=args.batch),
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(reads_all)),
                        "sharding": "single GPU, one contig" if world == 1 else
                                    ("one long contig, one interval per GPU + halo slab to the right neighbour" if args.single_contig else

@@ -176,6 +176,17 @@ int side_table_clear(mm_freq* h) {
     return 0;
 }
 
+// occupied slots of the side table (a scan of the table: finalize only)
+int side_table_count(mm_freq* h, unsigned long long* n) {
+    HIPCHK(hipMemsetAsync(h->d_scount, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_side_count, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, (unsigned long long)h->n_cu * 16)), dim3(256), 0,
+                       h->stream, h->d_stab, h->stab_slots, h->d_scount);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(n, h->d_scount, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int complement(int c) {
     switch (c) {
         case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
@@ -203,7 +214,7 @@ DevParams base_params(mm_freq* h) {
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
-    p.stab = h->d_stab; p.smask = h->stab_slots ? h->stab_slots - 1 : 0; p.scount = h->d_scount;
+    p.stab = h->d_stab; p.smask = h->stab_slots ? h->stab_slots - 1 : 0;
     p.stats = h->stats_on ? h->d_stats : nullptr;
     return p;
 }
@@ -943,7 +954,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     if (!h->opts.haplotypes && h->n_counter_words > 0 && !h->opts.finalize_by_runs) {
         unsigned long long ns0 = 0, nt0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&nt0, h->d_scount, sizeof(nt0), hipMemcpyDeviceToHost));
+        { int rc = side_table_count(h, &nt0); if (rc) return rc; }
         if (ns0 == 0 && nt0 == 0) {
             std::vector<int> order;
             for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
@@ -1074,7 +1085,7 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     size_t n_side_sorted = 0;   // rows.size() up to which the side rows are known to be in output order
     {
         unsigned long long nu = 0;
-        HIPCHK(hipMemcpy(&nu, h->d_scount, sizeof(nu), hipMemcpyDeviceToHost));
+        { int rc = side_table_count(h, &nu); if (rc) return rc; }
         if (nu > h->stab_slots - h->stab_slots / 8) return -MM_E_SIDEFULL;   // beyond 7/8 full the table may have refused updates
         if (nu) {
             if ((size_t)nu > h->cap_sort) {

@@ -106,7 +106,6 @@ struct DevParams {
     unsigned long long* stab;      // slots of 16 bytes: [2i] key (kSideEmpty = free), [2i + 1] n_called | n_mod << 32 like a dense counter
                                    // (key and counts share a cache line: one random line per update)
     unsigned long long smask;      // slots - 1 (a power of two)
-    unsigned long long* scount;    // occupied slots
     unsigned long long* stats;     // optional: [0..15] diagnostic timers, then kStatSlots rows of {reference-word lookups, ML bytes
                                    // read, dense updates, side updates}, one row per wave slot (summed by the host)
     // scheduling / scratch
@@ -150,15 +149,12 @@ __device__ __forceinline__ unsigned long long side_mix(unsigned long long x) {
 }
 // one counter update on the table: claim or find the key's slot (linear probing), then the same packed 64-bit add as a
 // dense counter.  Returns 0, or MM_E_SIDEFULL when every slot is taken by another key.
-__device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long mask, unsigned long long* count,
-                                           unsigned long long key, unsigned long long inc) {
+__device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long mask, unsigned long long key, unsigned long long inc) {
     unsigned long long h = side_mix(key) & mask;
     for (unsigned long long probes = 0; probes <= mask; probes++) {
         unsigned long long old = tab[2 * h];
-        if (old == kSideEmpty) {
-            old = atomicCAS(tab + 2 * h, kSideEmpty, key);
-            if (old == kSideEmpty) atomicAdd(count, 1ull);
-        }
+        if (old == kSideEmpty) old = atomicCAS(tab + 2 * h, kSideEmpty, key);   // (occupied slots are counted at finalize: a shared
+                                                                                 // counter here would be the one address every insert hits)
         if (old == kSideEmpty || old == key) { atomicAdd(tab + 2 * h + 1, inc); return 0; }
         h = (h + 1ull) & mask;
     }
@@ -509,7 +505,7 @@ struct K1 {
     __device__ __forceinline__ void side_append(int32_t pos, uint32_t ins_off, int is_mod, int code) {
         unsigned long long key;
         if (side_key(c.ref_base + pos, c.rev, code, ins_off, c.hp, key)) {
-            if (side_insert(p.stab, p.smask, p.scount, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

@@ -13,6 +13,15 @@ __global__ __launch_bounds__(256) void k_side_clear(unsigned long long* __restri
     }
 }
 
+// occupied slots of the table
+__global__ __launch_bounds__(256) void k_side_count(const unsigned long long* __restrict__ tab, unsigned long long cap, unsigned long long* __restrict__ counter) {
+    unsigned long long c = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * 256u)
+        c += tab[2 * i] != kSideEmpty ? 1ull : 0ull;
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
+    if (lane_id() == 0 && c) atomicAdd(counter, c);
+}
+
 // occupied slots -> dense (key, value) arrays, in any order (one wave-aggregated reservation per wave)
 __global__ __launch_bounds__(256) void k_side_compact(const unsigned long long* __restrict__ tab,
                                                       unsigned long long cap, unsigned long long* __restrict__ out_k,
