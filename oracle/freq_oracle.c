@@ -307,6 +307,7 @@ static int walk_cigar(orc_t *o, const orc_read_t *rd, const uint32_t *cigar, scr
 
 typedef struct {
     int n;              /* mod_codes_len (1 for ChEBI) */
+    int gord;           /* ordinal of the group in the read's MM string */
     int has_nums;
     char codes[CODE_LEN];
     int req[CODE_LEN];  /* required-mod index per code letter, -1 = not requested */
@@ -342,6 +343,9 @@ static inline int emit_call(orc_t *o, map_t *m, const orc_read_t *rd, const cont
             orc_view_row_t r;
             r.read = 0; r.tid = rd->tid; r.pos = ref_pos; r.strand = rev; r.code = g->cid[k]; r.ins_off = ins_off; r.hp = hp;
             r.read_pos = fq_pos; r.prob = prob;
+            /* view mode 2 (tests of the product's tie-order replay): rows stay in call order, every call is kept, and the row
+             * also says which group made the call and whether it was an implicit one */
+            if (o->view == 2) r.prob = prob | ((uint32_t)(g->gord & 0xFF) << 8) | (explicit_call ? 0u : 0x80000000u);
             vbuf_push(vb, r);
             continue;
         }
@@ -377,9 +381,10 @@ static int process_read(orc_t *o, map_t *m, const orc_read_t *rd, const uint32_t
     int nb[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < L; i++) { int b = base_class(seq_char(seq, i)); s->bases[b][nb[b]++] = i; }
 
-    int n = (int)rd->mm_len, i = 0, ml_start = 0;
+    int n = (int)rd->mm_len, i = 0, ml_start = 0, gord = 0;
     while (i < n) {
         group_codes_t g; memset(&g, 0, sizeof(g));
+        g.gord = gord++;
         int flag = '.';
         if (!is_valid_base((unsigned char)mm[i])) return ORC_E_MMBASE;
         int modbase = mm[i] == 'U' ? 'T' : mm[i];
@@ -503,7 +508,9 @@ static void *worker(void *arg) {
         vb.n = 0;
         int e = process_read(j->o, &j->map, &j->reads[i], j->cigar, j->seq, j->mm, j->ml, &s, &vb);
         if (e) { j->err = e; j->err_read = i; break; }
-        if (j->o->view && vb.n) {
+        if (j->o->view == 2 && vb.n) {   /* call order, nothing dropped */
+            for (int64_t k = 0; k < vb.n; k++) { orc_view_row_t r = vb.v[k]; r.read = i; vbuf_push(&j->rows, r); }
+        } else if (j->o->view && vb.n) {
             /* per read: sort by key, keep the first entry of every key (add_view_entry), rows by position */
             for (int64_t k = 0; k < vb.n; k++) vb.v[k].read = k;
             qsort(vb.v, (size_t)vb.n, sizeof(orc_view_row_t), vrow_cmp);
