@@ -296,3 +296,50 @@ def test_coalesced_windows_of_a_resident_read_set():
     assert res["one_group"]["sizes"] == [7]
     assert res["broken_runs"]["sizes"] == [2, 3, 1, 1]
     assert res["error"] == [1, 450]
+
+
+FALLBACK_WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
+import minimod_amd
+from oracle import oracle as O
+from oracle import pybam
+from tests.cases import KAT_REF, KAT_SEQ, kat_records, kat2_records
+# reads the tile pipeline hands to the fused kernel (five code letters in one group; groups on different bases) between
+# ordinary ones, as two windows of one flattened read set gathered into one launch
+recs = kat_records() + [
+    pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+abcdm,0,0;", [1, 2, 3, 4, 250, 5, 6, 7, 8, 9]),
+    pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+m?,0;G+m?,1;", [255, 200]),
+] + kat2_records() + kat_records()
+b = pybam.flatten(recs)
+dev = {k: torch.from_numpy(b[k].view(np.uint8).reshape(-1)).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+n = len(recs)
+def window(lo, hi):
+    return dict(reads=dev["reads"].data_ptr() + 64 * lo, cigar=dev["cigar"].data_ptr(), seq=dev["seq"].data_ptr(), mm=dev["mm"].data_ptr(), ml=dev["ml"].data_ptr(),
+                n_reads=hi - lo, n_cigar_words=len(b["cigar"]), n_seq_bytes=len(b["seq"]), n_mm_bytes=len(b["mm"]), n_ml_bytes=len(b["ml"]),
+                max_n_cigar=int(b["reads"]["n_cigar"].max()), max_l_qseq=int(b["reads"]["l_qseq"].max()))
+out = {}
+for name, kw in (("m", {}), ("m_ins_hap", dict(insertions=True, haplotypes=True))):
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrT"], **kw); orc.add_contig("chrT", KAT_REF.encode()); orc.process(b)
+    want = orc.rows()
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrT", len(KAT_REF), KAT_REF.encode())], coalesce=4, **kw)
+    t = [eng.submit_device(window(0, 5)), eng.submit_device(window(5, 9)), eng.submit_device(window(9, n))]
+    sizes = eng.ticket_batches(t[0])
+    got = eng.finalize(); eng.close()
+    key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+    out[name] = {"equal": key(got, "ins_offset") == key(want, "ins_off"), "rows": int(len(want)), "one_ticket": len(set(t)) == 1, "members": sizes}
+print(json.dumps(out))
+'''
+
+
+def test_gathered_windows_with_reads_for_the_fused_kernel():
+    """A gathered launch whose windows hold reads the tile pipeline does not cover (the fallback list is worked off when the
+    group's ticket is waited for or the counters are needed): same rows as the oracle."""
+    r = subprocess.run([sys.executable, "-c", FALLBACK_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    for name in ("m", "m_ins_hap"):
+        assert res[name]["equal"] and res[name]["rows"] > 5 and res[name]["one_ticket"] and res[name]["members"] == 3, res
