@@ -70,11 +70,12 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing of the N>1 path)")
     ap.add_argument("--host-plan", action="store_true", help="experiment: hand the library a host-made plan (mm_freq_plan_batch) "
                                                            "uploaded before the timed region instead of planning on the device inside it")
-    ap.add_argument("--coalesce", type=int, default=16, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
+    ap.add_argument("--coalesce", type=int, default=32, help="mm_freq_opts_t.coalesce: consecutive -K windows of the resident read set that may share "
                                                              "one launch (1 = every step is its own launch)")
     ap.add_argument("--region-mb", type=float, default=0.0, help="experiment: reads per GPU spread over this many Mb instead of the workload's "
                                                                   "interval (depth = reads * 15 kb / region: counter contention at depth)")
     ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
+    ap.add_argument("--no-stream", action="store_true", help="experiment: mm_freq_opts_t.no_stream (every read through the tile pipeline)")
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
     ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
                                                                "instead of the 24-contig genome")
@@ -415,7 +416,7 @@ def main():
     else:
         eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank,
                                      intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
-                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce,
+                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce, no_stream=args.no_stream,
                                      **wl["eng"])
     # ---- make the reads resident in HBM (torch owns the memory: plumbing only): ONE read set -- the pools of all batches
     # end to end, as a decoder writing into device memory would leave them -- and a step's batch is a window of -K reads of
@@ -598,8 +599,8 @@ def main():
                                    if args.coalesce > 1 and not args.host_plan else "off: one launch per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "freq hot path per batch = k_plan_items + k_scan_reads + k_sum_tiles + k_call_tiles (+ k_freq_reads on the "
-                                   "fallback list), HIP events around the launches on their stream",
+                         "kernel": "freq hot path per batch = k_plan_items + k_stream_reads (reads that are one work item) + k_scan_reads + k_sum_tiles + "
+                                   "k_call_tiles (the others) (+ k_freq_reads on the fallback list), HIP events around the launches on their stream",
                          "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / len(kms), "launches": len(kms),
                          "batches_per_launch": args.steps / len(kms), "kernel_ms_per_batch": float(np.sum(kms)) / args.steps,
                          "bytes_per_base": abytes / max(bases, 1), "side_list_updates_per_pass": side_per_pass},

@@ -110,7 +110,9 @@ typedef struct mm_freq_opts {
     int32_t split_bases;     /* device planning: reads longer than this are cut into parts of about this many bases (0 = default) */
     int32_t coalesce;        /* mm_freq_submit_device: up to this many consecutive windows of one resident read set share one launch
                               * (see there); 0 or 1 = every submit is its own launch */
-    int32_t rsvd;
+    int32_t no_stream;       /* 1: no read takes the streaming kernel (k_stream_reads): everything through the tile pipeline
+                              * (a reserved field before: same layout).  0 (default): plain freq runs (no --insertions, no --haplotypes, not view) send
+                              * reads of up to split_bases bases whose MM groups are all `?`-flagged lists of one base to it */
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
 
@@ -237,7 +239,8 @@ float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);
 /* Work tallies for the algorithmic-bytes figure: enable!=0 makes the kernels count reference-word
  * lookups, ML bytes read, dense counter updates and side-list updates; get copies and clears the four totals. */
 int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
-int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[16]);   /* [4..15]: phase time sums in diagnostic builds, else 0 */
+int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[16]);   /* [4..6]: reads k_stream_reads did itself / handed to the tile pipeline /
+                                                                * to the fused kernel; [7..15]: phase time sums in diagnostic builds, else 0 */
 int64_t mm_freq_device_bytes(const mm_freq_t *h);
 
 void mm_freq_reset_counters(mm_freq_t *h);

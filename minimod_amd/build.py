@@ -25,7 +25,8 @@ def _stale(target, sources):
 def build_hip(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     out = lib_path()
-    srcs = [os.path.join(CSRC, "freq_api.hip"), os.path.join(CSRC, "freq_kernels.hip.h"), os.path.join(CSRC, "freq_tiles.hip.h"), os.path.join(CSRC, "view_kernels.hip.h"),
+    srcs = [os.path.join(CSRC, "freq_api.hip"), os.path.join(CSRC, "freq_kernels.hip.h"), os.path.join(CSRC, "freq_tiles.hip.h"), os.path.join(CSRC, "freq_stream.hip.h"), os.path.join(CSRC, "view_kernels.hip.h"),
+            os.path.join(CSRC, "sort_kernels.hip.h"),
             os.path.join(INCLUDE, "minimod_hip.h")]
     if force or _stale(out, srcs):
         os.makedirs(LIBDIR, exist_ok=True)

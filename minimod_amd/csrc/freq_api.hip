@@ -18,6 +18,7 @@
 
 #include "freq_kernels.hip.h"
 #include "freq_tiles.hip.h"
+#include "freq_stream.hip.h"
 #include "view_kernels.hip.h"
 #include "sort_kernels.hip.h"
 #include "minimod_hip.h"
@@ -27,7 +28,7 @@ using namespace mmhip;
 namespace {
 
 constexpr int kSlots = 4;
-constexpr int kQueueWords = 128 * kQueueStride;   // per set: 64 tile-queue counters, then 64 scan-queue counters, 128 bytes apart
+constexpr int kQueueWords = 192 * kQueueStride;   // per set: 64 tile-queue counters, 64 scan-queue counters, 64 stream-queue counters, 128 bytes apart
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -62,6 +63,7 @@ struct Slot {
     TileRec* d_tiles = nullptr; size_t cap_tiles = 0;
     int32_t* d_fb = nullptr; size_t cap_fb = 0;
     int32_t* d_plan = nullptr; size_t cap_plan = 0;                        // work items planned on the device (k_plan_items)
+    int32_t* d_plan_stream = nullptr; size_t cap_plan_stream = 0;          // ... and the reads k_stream_reads takes (one item each)
     PlanState* d_plan_state = nullptr; unsigned int plan_serial = 0;      // what the planning workgroups share
     unsigned int* h_ctl = nullptr;   // pinned copy
     int32_t n_reads = 0;
@@ -94,7 +96,7 @@ struct Slot {
 struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
-    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4;
+    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6;
     bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
     bool wide = false;  // 32-bit reference words (n_mods > 5)
     int n_contigs = 0;
@@ -322,22 +324,29 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
         if (h->use_tiles) {
+            bool stream = false;
             if (!b->order) {
                 // no plan from the caller: the work items are made on the device (long reads cut into parts, costliest
                 // first), their number stays in device memory (control word 6)
                 const uint32_t split = h->opts.split_bases >= 1024 ? (uint32_t)h->opts.split_bases : kSplitBases;
                 const size_t max_items = (size_t)b->n_reads + 2 * (size_t)b->n_seq_bytes / split + 64;
                 if ((r = grow(h, (void**)&s.d_plan, &s.cap_plan, 4 * max_items))) return r;
+                // plain freq runs: reads that are one work item go to k_stream_reads (which hands back what it does not do)
+                stream = !h->opts.no_stream && !p.view && !p.insertions && !p.haplotypes;
+                if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
                 if (!s.d_plan_state) {
                     if (dev_alloc(h, (void**)&s.d_plan_state, sizeof(PlanState))) return -MM_E_NOMEM;
                     HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
                 }
                 const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
                 hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
-                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag);
+                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? split : 0u, s.d_plan_stream, ctl + 7);
                 p.order = s.d_plan;
                 p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
                 tp.plan_count = ctl + 6;
+                tp.stream_items = s.d_plan_stream; tp.stream_count = ctl + 7;
+                tp.stream_queue = tp.tile_queue + 128 * kQueueStride;
+                tp.tile_items = s.d_plan; tp.tile_plan_count = ctl + 6;
             }
             tp.d = p;
             int ga = std::min((3 * p.n_items + kWavesPerBlock - 1) / kWavesPerBlock, h->n_cu * h->scan_blocks_per_cu);
@@ -345,6 +354,11 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             int gs = h->n_cu * 6;   // measured: 8 waves per SIMD 16.0 us, 6 14.8 us, 4 16.9 us
             if (ga < 1) ga = 1;
             const bool plain = !p.insertions && !p.haplotypes;
+            if (stream) {
+                const int gf = h->n_cu * h->stream_blocks_per_cu;
+                if (h->wide) hipLaunchKernelGGL(k_stream_reads<uint32_t>, dim3(gf), dim3(256), 0, st, tp);
+                else hipLaunchKernelGGL(k_stream_reads<uint16_t>, dim3(gf), dim3(256), 0, st, tp);
+            }
             if (h->wide) {
                 hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
                 hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
@@ -539,7 +553,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
-                      s.d_plan, s.d_plan_state,
+                      s.d_plan, s.d_plan_stream, s.d_plan_state,
                       s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);
@@ -599,6 +613,10 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
+        int nf = 0;
+        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint32_t>, 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint16_t>, 256, 0);
+        h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
         h->use_tiles = opts->force_fused == 0;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");

@@ -124,7 +124,7 @@ struct DevParams {
     // the control words (queue, error summary, tile counters) the slot's NEXT launch will use: reset by this launch's
     // last kernel, which saves a host-to-device copy per batch (a slot alternates between two sets)
     unsigned int* ctl_next;
-    unsigned int* queue_next;      // likewise: the 64 tile-queue + 64 scan-queue counters (kQueueStride words apart) of the next launch
+    unsigned int* queue_next;      // likewise: the 64 tile-queue + 64 scan-queue + 64 stream-queue counters (kQueueStride words apart) of the next launch
 };
 constexpr int kCtlWords = 80;    // words of a control set that are reset: [0..8) scalars, [8..72) tile counts
 constexpr int kCtlSetWords = 128;
@@ -345,6 +345,8 @@ struct ReadCtx {
     uint32_t* spill_q; uint32_t* spill_r; uint32_t* spill_d;
     int64_t ref_base, seg_begin, seg_len, cnt_base;
     uint32_t L, ncig, nblk, q_total, ml_len;
+    uint32_t q_shift;   // reverse read whose CIGAR is shorter than its sequence: get_aln walks the ops back to front from read position 0
+                        // of the ORIGINAL orientation (mod.c:813-860), so the aligned part lies at BAM positions [q_shift, L)
     int32_t tid, pos, rev, hp, hpi;
     // current MM group
     int32_t cls, direct, mb_is_N, n_codes_grp;
@@ -411,6 +413,7 @@ struct K1 {
             }
         }
         c.q_total = carry_q;
+        c.q_shift = (c.rev && carry_q < c.L) ? c.L - carry_q : 0u;
         wave_sync();
     }
 
@@ -563,13 +566,14 @@ struct K1 {
             else q[u] = select_in_block(sv[u], blk[u], kk[u], code[u]);
             // (a') of SURVEY.md: proj(q) for aligned bases; with --insertions the anchor insL() left of the insertion
             int64_t rp = -1, anchor = -1;
-            if (q[u] < c.q_total) {
-                uint32_t i = find_op(q[u]);
+            const uint32_t qe = q[u] - c.q_shift;   // (wraps past q_total for the bases in front of the aligned part)
+            if (qe < c.q_total) {
+                uint32_t i = find_op(qe);
                 uint32_t rv = cr(i), op = rv >> 28, qs = cq(i);
                 if ((0x181u >> op) & 1u) {
-                    rp = (int64_t)c.pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
+                    rp = (int64_t)c.pos + (rv & 0x0FFFFFFFu) + (qe - qs);
                 } else if (op == 1u && p.insertions) {
-                    ins_off[u] = (q[u] - qs + 1u) & 0xFFFFu;  // ins_offset, truncated like make_key's uint16 (mod.c:428)
+                    ins_off[u] = (qe - qs + 1u) & 0xFFFFu;  // ins_offset, truncated like make_key's uint16 (mod.c:428)
                     anchor = (int64_t)c.pos + (rv & 0x0FFFFFFFu) - 1;
                 }
             }
@@ -579,7 +583,7 @@ struct K1 {
                 } else {
                     // quirk (mod.c:1234,1314): the implicit path indexes ins[] with the BAM-orientation position,
                     // i.e. for reverse reads it takes the insertion anchor of the MIRRORED base L-1-q.
-                    uint32_t q2 = c.L - 1u - q[u];
+                    uint32_t q2 = c.L - 1u - q[u] - c.q_shift;
                     if (q2 < c.q_total) {
                         uint32_t i2 = find_op(q2);
                         uint32_t rv2 = cr(i2);
@@ -914,7 +918,7 @@ struct K1 {
                         uint32_t v = 0;
                         if (tstart) {
                             // decimal fold over at most 10 look-ahead characters, no early exit (mod.c:1074-1084)
-                            bool open = true;
+                            bool open = true, nondigit = false;
                             int len = 0;
 #pragma unroll
                             for (int j = 0; j < 10; j++) {
@@ -922,12 +926,14 @@ struct K1 {
                                 bool delim = d == ',' || d == ';';
                                 open = open && !delim;
                                 if (open) {
-                                    if (d < '0' || d > '9') err = MM_E_SKIPVAL;
+                                    if (d < '0' || d > '9') nondigit = true;
                                     v = v * 10u + (uint32_t)(d - '0');
                                     len++;
                                 }
                             }
-                            if (len == 10) err = MM_E_SKIPLEN;                         // assert(l < 10), mod.c:1080
+                            // a sequential reader meets a non-digit among the first ten characters before it has counted ten
+                            if (nondigit) err = MM_E_SKIPVAL;
+                            else if (len == 10) err = MM_E_SKIPLEN;                    // assert(l < 10), mod.c:1080
                         }
                         uint64_t tb = __ballot(tstart);
                         uint32_t nt = (uint32_t)__popcll(tb);
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     const int wave_slot = blockIdx.x * kWavesPerBlock + wv;
     K1<RefWord, kView> k(p, lds[wv]);
     if (p.ctl_next && blockIdx.x == 0 && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
-    if (p.queue_next && blockIdx.x == 0 && threadIdx.x < 128) p.queue_next[threadIdx.x * kQueueStride] = 0u;   // tile queues, then scan queues
+    if (p.queue_next && blockIdx.x == 0 && threadIdx.x < 192) p.queue_next[threadIdx.x * kQueueStride] = 0u;   // tile queues, scan queues, stream queues
     if (p.n_items_dev && *p.n_items_dev == 0u) return;   // empty fallback list: do not even touch the work counter
     for (;;) {
         int r = 0;

@@ -1,0 +1,663 @@
+// freq_stream.hip.h -- k_stream_reads: the freq hot path of a whole read in ONE wavefront, as a three-way merge of
+// streams, with nothing written to HBM but the counters (reference src/mod.c:776-1370).
+//
+// The tile pipeline (freq_tiles.hip.h) cuts a read into independent tiles and pays for the independence: per-op CIGAR
+// prefix arrays and a rank directory are written to a scratch and read back, every tile re-derives its carries, stages
+// its own slices, and the three kernels read the read record three times.  For the common read -- plain `freq` (no
+// --insertions, no --haplotypes), every MM group a `?`-flagged skip list on one canonical base, short enough to be one work
+// item -- none of that is needed, because everything a read's calls touch moves in ONE direction:
+//
+//   tokens        the skip list in text order: ranks (k-th base of the class) rise with the token index;
+//   sequence      the rank of a 32-base block's first base rises with the block index (walked from the read's END for a
+//                 reverse-strand read, whose MM counts bases of the original orientation);
+//   CIGAR         the read position at which an op starts rises with the op index (ops walked from the END for a reverse
+//                 read, read positions counted from the end of the aligned query: the mirrored problem is the same
+//                 problem).
+//
+// So a wavefront keeps three cursors and two small windows in LDS and loops over rounds of 64 tokens:
+//   1. parse skip-list text (256 characters per trip, the per-character sum of k_sum_tiles) into a ring of ranks;
+//   2. extend the directory window (popcount + wave scan of 64 blocks per step, four steps requested together) until it
+//      covers the round's last rank; every lane finds its block (branch-free search in LDS) and selects the base in it;
+//   3. extend the CIGAR window (decode + two wave scans per 64 ops, packed one word per op) until it covers the round's last
+//      read position; every lane finds its op, projects, loads the reference word and the ML byte, thresholds, and
+//      makes ONE 64-bit atomic add -- the same update the tile pipeline makes.
+// A window that cannot hold a round's span (sparse tokens, introns) simply covers fewer tokens: the rest stay in the ring.
+//
+// What this kernel does not do, it hands on BEFORE touching a counter: reads with '.' groups (implicit calls), groups on
+// 'N' or on different bases, more than four codes or eight groups, a CIGAR the checks do not pass outright -> appended to
+// the tile pipeline's item list (k_scan_reads runs after this kernel).  Anything that goes wrong once calls have been
+// counted is an input error (malformed token, rank past the last base, ML too short): the read goes on the fallback list
+// and the fused kernel names the error in the reference's order, exactly as for the tile pipeline's irregular reads.
+#pragma once
+#include "freq_tiles.hip.h"
+
+namespace mmhip {
+
+constexpr uint32_t kStreamChunk = 256;      // skip-list characters parsed per trip (+16 of look-ahead)
+constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at most 63 left over + 128 of a chunk (+1)
+constexpr uint32_t kStreamDir = 320;        // directory window: 32-base blocks (10 kb of read) + one sentinel
+constexpr uint32_t kStreamCig = 576;        // CIGAR window: ops, one packed word each
+constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
+constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each)
+constexpr int kStreamDirRounds = 4;         // 64-block steps requested together
+constexpr int kStreamCigRounds = 8;         // 64-op steps requested together
+
+struct StreamLds {
+    uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
+    uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
+    uint32_t dw[kStreamDir + 1];            // class members in front of each block of the window (traversal order), then the running total
+    uint32_t cw[kStreamCig];                // query offset << 18 | reference offset << 4 | op, relative to the window's first op
+    char hdr[16];
+    int16_t g_code[16];
+    uint32_t g_lstart[kStreamGroups], g_end[kStreamGroups], g_flags[kStreamGroups], g_c01[kStreamGroups], g_c23[kStreamGroups];
+};
+
+// class members among the 32 bases of block b (KA::block_count)
+__device__ __forceinline__ uint32_t stream_block_count(uint4 v, int cls, uint32_t b, uint32_t L) {
+    if (cls == 0) {
+        int valid = (int)min(32u, L - b * 32u);
+        uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
+                     __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
+                     __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
+                     __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
+        return (uint32_t)valid - o;
+    }
+    return __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) + __popc(class_bits(v.w, cls));
+}
+// number of set bits below the lowest clear one (64 when all are set)
+__device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint32_t)__ffsll((unsigned long long)~m) - 1u : 64u; }
+
+template <typename RefWord>
+struct KF {
+    const TileParams& P;
+    const DevParams& p;
+    StreamLds& S;
+    const uint32_t* ptab;
+    uint32_t st_look, st_ml, st_dense, st_side;
+    int err;
+    // the read (wave-uniform)
+    const uint8_t* mm;
+    const uint8_t* ml;
+    const uint4* sq;
+    const uint32_t* cg;
+    const RefWord* rwb;
+    int64_t ref_base;
+    uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32;
+    int32_t tid, pos, rev, cls;
+    // the group
+    int32_t ncg, gc0, gc1, gc2, gc3;
+    uint32_t ci0, ci1, ci2, ci3;
+    unsigned long long *cb0, *cb1, *cb2, *cb3;
+    uint32_t ml_start;
+    // text cursor and token ring
+    uint32_t cpos, nx_w0, nx_w1, qhead, qn, kdone, Rcarry, ntok_parsed;
+    bool prev_delim, closed, bad_text;
+    // directory window: blocks [t_w0, t_w0 + wn) in traversal order, t_next the next block to scan, S_next the members in front of it
+    uint32_t t_w0, wn, t_next, S_next;
+    // CIGAR window: ops [.., s_next) in traversal order, xn of them in LDS relative to (A_base, B_base); A_next / B_next =
+    // query / reference positions consumed in front of s_next
+    uint32_t xn, s_next, A_next, B_next, A_base, B_base;
+
+    __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
+        : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0) {}
+
+    __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
+    __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
+    __device__ __forceinline__ unsigned long long* cbase_at(int m) const { return m == 0 ? cb0 : (m == 1 ? cb1 : (m == 2 ? cb2 : cb3)); }
+
+    // ------------------------------------------------------------------ text -> ranks
+    __device__ __forceinline__ void fetch_chunk(uint32_t c) {
+        const uint32_t lane = (uint32_t)lane_id();
+        nx_w0 = mm_dword(mm, mlen, c + 4u * lane);
+        nx_w1 = lane < 4u ? mm_dword(mm, mlen, c + kStreamChunk + 4u * lane) : 0u;
+    }
+    // One chunk of the group's skip list: its tokens appended to the ring as ranks (keep), counted and summed either way.
+    // The parse is k_sum_tiles' (a token belongs to the chunk it starts in; the look-ahead completes the last one).
+    __device__ __forceinline__ void parse_chunk(bool keep) {
+        const int lane = lane_id();
+        constexpr int kSub = (int)(kStreamChunk / 64);
+        wave_sync();
+        S.mmw[lane] = nx_w0;
+        if (lane < 4) S.mmw[64 + lane] = nx_w1;
+        wave_sync();
+        fetch_chunk(cpos + kStreamChunk);   // the next chunk is requested before this one is parsed
+        const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
+        uint32_t x[kSub];
+#pragma unroll
+        for (int sc = 0; sc < kSub; sc++) x[sc] = mb8[64 * sc + lane];
+        const uint32_t x4 = mb8[kStreamChunk + (lane & 15)];
+        uint64_t D[kSub + 1], Sm[kSub];
+#pragma unroll
+        for (int sc = 0; sc < kSub; sc++) {
+            Sm[sc] = __ballot(x[sc] == ';');
+            D[sc] = Sm[sc] | __ballot(x[sc] == ',');
+        }
+        D[kSub] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;
+        const uint32_t qtail = qhead + qn;
+        uint32_t nends = 0, rsum_v = 0;
+        uint64_t bad = 0;
+        bool cl = false, open_tail = false;
+#pragma unroll
+        for (int sc = 0; sc < kSub; sc++) {
+            if (cl) break;
+            int lo = 0, hi = 64;
+            if (Sm[sc]) { hi = __ffsll((unsigned long long)Sm[sc]) - 1; cl = true; }
+            if (sc == 0 && !prev_delim) lo = D[0] ? __ffsll((unsigned long long)D[0]) - 1 : 64;
+            const uint64_t pd = sc == 0 ? (prev_delim ? 1ull : 0ull) : (D[sc > 0 ? sc - 1 : 0] >> 63);
+            const uint32_t w = window32((D[sc] << 1) | pd, (D[sc + 1] << 1) | (D[sc] >> 63), lane);
+            const bool own = (uint32_t)(lane - lo) < (uint32_t)(hi - lo) && lo < hi;
+            const bool start = own && (w & 3u) == 1u;
+            const bool end = own && (w & 6u) == 4u;
+            uint32_t e = (uint32_t)__ffs((int)(w >> 1)) - 1u;
+            e = e < 10u ? e : 10u;
+            const uint32_t dv = x[sc] - (uint32_t)'0';
+            uint32_t c = ptab[(e << 4) | (dv & 15u)];
+            c = own ? c : 0u;
+            c += start ? 1u : 0u;
+            const uint32_t run = wave_incl_scan(c);
+            const uint64_t eb = __ballot(end);
+            if (keep && end) S.tok[(qtail + nends + (uint32_t)__popcll(eb & lanemask_lt())) & (kStreamRing - 1u)] = Rcarry + rsum_v + run - 1u;
+            bad |= __ballot(own && !(w & 2u) && dv > 9u) | __ballot(start && e >= 10u);
+            rsum_v += lane_valu(run, 63);
+            nends += (uint32_t)__popcll(eb);
+            if (sc == kSub - 1 && !cl) open_tail = ((D[kSub - 1] >> 63) == 0) && ((D[kSub] & 1ull) == 0);
+        }
+        uint32_t ntok = nends;
+        if (open_tail) {
+            const int k = __ffsll((unsigned long long)D[kSub]) - 1;   // 1..16
+            const uint32_t dv = x4 - (uint32_t)'0';
+            uint32_t e = (uint32_t)(k - lane);
+            e = e < 10u ? e : 10u;
+            uint32_t c = lane < k ? ptab[(e << 4) | (dv & 15u)] : 0u;
+            bad |= __ballot(lane < k && dv > 9u);
+            rsum_v += lane_valu(wave_incl_scan(c), 15);
+            if (keep && lane == 0) S.tok[(qtail + nends) & (kStreamRing - 1u)] = Rcarry + rsum_v - 1u;
+            ntok = nends + 1u;
+        }
+        if (bad) bad_text = true;
+        prev_delim = lane_valu(x[kSub - 1], 63) == (uint32_t)',';
+        closed = cl;
+        if (keep) qn += ntok;
+        Rcarry += rsum_v;
+        ntok_parsed += ntok;
+        cpos += kStreamChunk;
+        wave_sync();
+    }
+
+    // ------------------------------------------------------------------ sequence -> directory window
+    // blocks are appended until the window covers rank rho_last (S_next > rho_last), the read ends, or the window is full
+    // while it already covers rho_0; a full window that does not even reach rho_0 holds nothing of use and starts over
+    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last) {
+        const uint32_t lane = (uint32_t)lane_id();
+        bool stop = false;
+        while (!stop && S_next <= rho_last && t_next < nblk) {
+            uint4 vv[kStreamDirRounds];
+#pragma unroll
+            for (int r = 0; r < kStreamDirRounds; r++) {
+                const uint32_t t = t_next + 64u * (uint32_t)r + lane;
+                vv[r] = t < nblk ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < kStreamDirRounds; r++) {
+                if (!stop && S_next <= rho_last && t_next < nblk) {
+                    if (wn + 64u > kStreamDir) {
+                        if (S_next > rho_0) stop = true;
+                        else { wn = 0; t_w0 = t_next; }
+                    }
+                    if (!stop) {
+                        const uint32_t t = t_next + lane;
+                        const bool valid = t < nblk;
+                        const uint32_t cnt = valid ? stream_block_count(vv[r], cls, rev ? nblk - 1u - t : t, L) : 0u;
+                        const uint32_t incl = wave_incl_scan(cnt);
+                        if (valid) S.dw[wn + lane] = S_next + incl - cnt;
+                        const uint32_t nv = min(64u, nblk - t_next);
+                        wn += nv; t_next += nv;
+                        S_next += lane_valu(incl, 63);
+                    }
+                }
+            }
+        }
+        if (lane == 0) S.dw[wn] = S_next;
+        wave_sync();
+    }
+    // all class members of the read (only needed to check the last rank of a group nobody asked for)
+    __device__ __forceinline__ uint32_t count_all() {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t sum = 0;
+        for (uint32_t b0 = 0; b0 < nblk; b0 += 512u) {
+            uint4 vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; vv[u] = b < nblk ? sq[b] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; if (b < nblk) sum += stream_block_count(vv[u], cls, b, L); }
+        }
+        return lane_valu(wave_incl_scan(sum), 63);
+    }
+    // k-th (from the block's start) member of the class among the 32 bases of block blk -> read position and base code
+    __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
+        // match bits per word in BAM's nibble order (counts do not care), masked to the read's bases for the "other" class
+        uint32_t m0 = class_bits(v.x, cls), m1 = class_bits(v.y, cls), m2 = class_bits(v.z, cls), m3 = class_bits(v.w, cls);
+        if (cls == 0) {
+            const int valid = (int)min(32u, L - blk * 32u);
+            // base_order maps base n to nibble n; its inverse is itself
+            m0 &= base_order(valid_bits(valid)); m1 &= base_order(valid_bits(valid - 8));
+            m2 &= base_order(valid_bits(valid - 16)); m3 &= base_order(valid_bits(valid - 24));
+        }
+        const uint32_t s1 = __popc(m0), s2 = s1 + __popc(m1), s3 = s2 + __popc(m2);
+        const uint32_t word = (k >= s1 ? 1u : 0u) + (k >= s2 ? 1u : 0u) + (k >= s3 ? 1u : 0u);
+        k -= word == 0u ? 0u : (word == 1u ? s1 : (word == 2u ? s2 : s3));
+        const uint32_t raw = word == 0u ? v.x : (word == 1u ? v.y : (word == 2u ? v.z : v.w));
+        uint32_t mk = base_order(word == 0u ? m0 : (word == 1u ? m1 : (word == 2u ? m2 : m3)));   // bit 4n+3 <-> base n of the word
+        const uint32_t wv = base_order(raw);
+        uint32_t n = 0, cn = __popc(mk & 0xFFFFu);
+        bool ge = k >= cn;
+        k -= ge ? cn : 0u; n += ge ? 4u : 0u; mk = ge ? mk >> 16 : mk;
+        cn = __popc(mk & 0xFFu);
+        ge = k >= cn;
+        k -= ge ? cn : 0u; n += ge ? 2u : 0u; mk = ge ? mk >> 8 : mk;
+        cn = __popc(mk & 0xFu);
+        n += k >= cn ? 1u : 0u;
+        code = (wv >> (4u * n)) & 15u;
+        return blk * 32u + word * 8u + n;
+    }
+
+    // ------------------------------------------------------------------ CIGAR -> window
+    // ops are appended until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more
+    // fits (room, or the 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
+    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi) {
+        const uint32_t lane = (uint32_t)lane_id();
+        bool stop = false;
+        while (!stop && A_next <= u_hi && s_next < ncig) {
+            uint32_t wv[kStreamCigRounds];
+#pragma unroll
+            for (int r = 0; r < kStreamCigRounds; r++) {
+                const uint32_t s = s_next + 64u * (uint32_t)r + lane;
+                wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
+            }
+            bool stale = false;   // the loaded steps no longer line up with s_next
+#pragma unroll
+            for (int r = 0; r < kStreamCigRounds; r++) {
+                if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
+                    if (xn + 64u > kStreamCig) {
+                        if (A_next > u_lo) stop = true;
+                        else xn = 0;
+                    }
+                    if (!stop) {
+                        const bool valid = s_next + lane < ncig;
+                        const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
+                        const uint32_t qinc = (valid && ((0x193u >> op) & 1u)) ? len : 0u;
+                        const uint32_t rinc = (valid && ((0x18Du >> op) & 1u)) ? len : 0u;
+                        const uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
+                        if (xn == 0) { A_base = A_next; B_base = B_next; }
+                        const uint32_t dq = A_next + qs - qinc - A_base, dr = B_next + rs - rinc - B_base;
+                        const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan && dr < kStreamSpan));
+                        const uint32_t nvalid = min(64u, ncig - s_next);
+                        if (nv == 0u) {   // the next op starts beyond what this window's words can say
+                            if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
+                            else { xn = 0; stale = true; }
+                        } else {
+                            if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
+                            xn += nv; s_next += nv;
+                            A_next += nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv);
+                            B_next += nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv);
+                            if (nv < nvalid) stale = true;
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+
+    __device__ __forceinline__ void side_append(int32_t spos, int is_mod, int code) {
+        unsigned long long key;
+        if (side_key(ref_base + spos, rev, code, 0u, -1, key)) {
+            if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            return;
+        }
+        uint64_t m = __ballot(1);
+        int leader = __ffsll((unsigned long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane_id() == leader) base = atomicAdd(p.side_count, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, 64);
+        unsigned long long idx = base + __popcll(m & lanemask_lt());
+        if (idx < p.side_cap) {
+            SideRec r;
+            r.tid = tid; r.pos = spos; r.ins_off = 0; r.strand = (uint8_t)rev;
+            r.is_mod = (uint8_t)is_mod; r.code = (int16_t)code; r.hp = (int16_t)-1;
+            p.side[idx] = r;
+        } else {
+            err = MM_E_SIDEFULL;
+        }
+    }
+
+    // ------------------------------------------------------------------ one round: the ring's first n tokens (n <= 64)
+    // returns the number of tokens done (0: something is wrong with the read)
+    __device__ __forceinline__ uint32_t round(uint32_t n) {
+        const uint32_t lane = (uint32_t)lane_id();
+        const bool lv = lane < n;
+        const uint32_t rho = lv ? S.tok[(qhead + lane) & (kStreamRing - 1u)] : 0xFFFFFFFFu;
+        const uint32_t rho_0 = lane_valu(rho, 0), rho_last = lane_valu(rho, (int)(n - 1u));
+        fill_dir(rho_0, rho_last);
+        const uint32_t n1 = leading_ones(__ballot(lv && rho < S_next));   // tokens whose block is in the window
+        uint32_t n_done = 0;
+        if (n1 > 0u) {
+            // rank -> block: largest j with dw[j] <= rho (dw[0] <= rho_0 by construction)
+            const bool act = lane < n1;
+            uint32_t lo = 0;
+            for (uint32_t nn = wn; nn > 1u;) {
+                const uint32_t half = nn >> 1;
+                lo = S.dw[lo + half] <= rho ? lo + half : lo;
+                nn -= half;
+            }
+            const uint32_t j = act ? lo : 0u;
+            const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
+            const uint32_t t = t_w0 + j, blk = rev ? nblk - 1u - t : t;
+            const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
+            const uint4 sv = act ? sq[blk] : make_uint4(0, 0, 0, 0);
+            uint32_t code = 0;
+            const uint32_t q = act ? select_in_block(sv, blk, kk, code) : 0u;
+            // read position -> position in the direction the CIGAR is walked (get_aln walks a reverse read's ops back to front
+            // from position 0 of the original orientation, mod.c:813-860); positions past the CIGAR's query length have no call
+            const uint32_t u = rev ? L - 1u - q : q;
+            const bool live = act && u < q_total;
+            const uint64_t lm = __ballot(live);
+            if (lm) {
+                const int fl = __ffsll((unsigned long long)lm) - 1, ll = 63 - __clzll((unsigned long long)lm);
+                fill_cig(lane_valu(u, fl), lane_valu(u, ll));
+            }
+            n_done = leading_ones(__ballot(act && (!live || u < A_next)));
+            const bool fin = lane < n_done && live;
+            const uint64_t fm = __ballot(fin);
+            if (fm) {
+                // traversal position -> op: largest s with (query offset of op s) <= u
+                const uint32_t du = u - A_base;
+                const uint32_t target = ((du < kStreamSpan ? du : kStreamSpan - 1u) << 18) | 0x3FFFFu;
+                uint32_t xo = 0;
+                for (uint32_t nn = xn; nn > 1u;) {
+                    const uint32_t half = nn >> 1;
+                    xo = S.cw[xo + half] <= target ? xo + half : xo;
+                    nn -= half;
+                }
+                const uint32_t xw = S.cw[fin ? xo : 0u];
+                const uint32_t op = xw & 15u, a_s = A_base + (xw >> 18), b_s = B_base + ((xw >> 4) & 0x3FFFu);
+                const bool call = fin && ((0x181u >> op) & 1u);
+                const uint32_t e = u - a_s;
+                const int32_t ref_pos = rev ? pos + (int32_t)(r_total - 1u - b_s - e) : pos + (int32_t)(b_s + e);
+                const uint32_t kidx = kdone + lane;
+                uint32_t w = 0, ml0 = 0;
+                if (call) {
+                    w = (uint32_t)rwb[(uint32_t)ref_pos];
+                    st_look++;
+                    const uint64_t mi = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
+                    if (mi < ml_len) ml0 = ml[mi];
+                }
+                if (call) {
+                    const uint32_t refcode = w & 31u;
+                    for (int m = 0; m < ncg; m++) {
+                        const int ci = gcode_at(m);
+                        if (ci < 0) continue;
+                        const uint32_t cinfo = cinfo_at(m);
+                        const int req = (int)((cinfo >> 19) & 15u);
+                        const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
+                        const bool in_ctx = (w >> (5 + 2 * req + rev)) & 1u;
+                        const bool matches = ((cinfo >> 18) & 1u) || refcode == code;
+                        if (!(in_ctx && matches)) continue;
+                        const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                        if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
+                        const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
+                        st_ml++;
+                        int is_mod;
+                        if (mv >= t_hi) is_mod = 1;
+                        else if (mv <= t_lo) is_mod = 0;
+                        else continue;
+                        unsigned long long* const cbm = cbase_at(m);
+                        if (cbm != nullptr && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
+                            atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
+                            st_dense++;
+                        } else {
+                            side_append(ref_pos, is_mod, ci);
+                            st_side++;
+                        }
+                    }
+                }
+                // the CIGAR window keeps what the next round can still need: from the last searched op on
+                const int fll = 63 - __clzll((unsigned long long)fm);
+                const uint32_t xl = lane_valu(xo, fll);
+                if (xl > 0u) {
+                    const uint32_t b0 = S.cw[xl] & ~15u, cnt = xn - xl;
+                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                        const uint32_t i = c0 + lane;
+                        const uint32_t v = i < cnt ? S.cw[xl + i] : 0u;
+                        wave_sync();
+                        if (i < cnt) S.cw[i] = v - b0;
+                        wave_sync();
+                    }
+                    A_base += b0 >> 18; B_base += (b0 >> 4) & 0x3FFFu;
+                    xn = cnt;
+                }
+            }
+            if (n_done > 0u) {
+                // ... and the directory window from the block of the last token done
+                const uint32_t jl = lane_valu(j, (int)(n_done - 1u));
+                if (jl > 0u) {
+                    const uint32_t cnt = wn - jl + 1u;   // with the sentinel
+                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                        const uint32_t i = c0 + lane;
+                        const uint32_t v = i < cnt ? S.dw[jl + i] : 0u;
+                        wave_sync();
+                        if (i < cnt) S.dw[i] = v;
+                        wave_sync();
+                    }
+                    t_w0 += jl; wn -= jl;
+                }
+            }
+        }
+        return n_done;
+    }
+
+    // ------------------------------------------------------------------ one group's skip list [lstart, ...;)
+    // returns 0, or 2 when the read has to go to the fused kernel (an input error); *ntok = tokens of the group
+    __device__ __forceinline__ int run_group(uint32_t lstart, bool wanted, uint32_t& ntok) {
+        cpos = lstart; prev_delim = true; closed = false; bad_text = false;
+        qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
+        t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
+        xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
+        fetch_chunk(cpos);
+        int st = 0;
+        for (;;) {
+            while (qn < 64u && !closed && !bad_text) parse_chunk(wanted);
+            if (bad_text) { st = 2; break; }
+            if (qn == 0u) break;
+            const uint32_t n = qn < 64u ? qn : 64u;
+            const uint32_t nd = round(n);
+            const uint64_t eb = __ballot(err != 0);
+            if (nd == 0u || eb) { st = 2; break; }
+            qhead = (qhead + nd) & (kStreamRing - 1u); qn -= nd; kdone += nd;
+        }
+        ntok = ntok_parsed;
+        return st;
+    }
+
+    // ------------------------------------------------------------------ one read: 0 done, 1 -> tile pipeline, 2 -> fused kernel
+    __device__ int run(int ridx) {
+        const uint32_t lane = (uint32_t)lane_id();
+        const mm_read_t rd = scalar_load(p.reads + ridx);
+        err = 0;
+        tid = uni(rd.tid); pos = uni(rd.pos);
+        L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); mlen = uniu(rd.mm_len); ml_len = uniu(rd.ml_len);
+        rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        mm = p.mm + rd.mm_off; ml = p.ml + rd.ml_off;
+        sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
+        cg = p.cigar + rd.cigar_off;
+        nblk = (L + 31u) >> 5;
+        bool have_ref = tid >= 0 && tid < p.n_contigs;
+        if (have_ref) have_ref = scalar_load(p.ref_base + tid) >= 0;
+        int st = (have_ref && L > 0u && ncig > 0u) ? 0 : 1;
+        if (st == 0) {
+            // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, and the checks reduced to
+            // what a clean record passes outright; anything else is the tile pipeline's to judge op by op
+            uint32_t sumq = 0, sumr = 0;
+            bool badop = false;
+            for (uint32_t i0 = 0; i0 < ncig; i0 += 1024u) {
+                uint4 wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
+                    wv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
+                    const uint32_t w4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool valid = i + (uint32_t)k < ncig;
+                        const uint32_t op = w4[k] & 15u, len = w4[k] >> 4;
+                        sumq += (valid && ((0x193u >> op) & 1u)) ? len : 0u;
+                        sumr += (valid && ((0x18Du >> op) & 1u)) ? len : 0u;
+                        // (a lane's sums cannot wrap unseen: every length is below 2^27 and the sums are looked at after every op)
+                        badop = badop || (valid && (op == 5u || op == 6u || op > 8u || len >= (1u << 27))) || sumq >= (1u << 28) || sumr >= (1u << 28);
+                    }
+                }
+            }
+            // 64 lanes x 2^28 does not fit a word: the halves are added separately
+            const uint64_t tq = (uint64_t)lane_valu(wave_incl_scan(sumq & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumq >> 16), 63) << 16);
+            const uint64_t tr = (uint64_t)lane_valu(wave_incl_scan(sumr & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumr >> 16), 63) << 16);
+            const int64_t ctg_len = scalar_load(p.ctg_len + tid);
+            if (__ballot(badop) || tq > (uint64_t)L || tr >= (1ull << 28) || pos < 0 || (int64_t)pos + (int64_t)tr > ctg_len) st = 1;
+            q_total = (uint32_t)tq; r_total = (uint32_t)tr;
+        }
+        uint32_t ngrp = 0;
+        if (st == 0) {
+            // the group headers (mod.c:1003-1062): is this a read for this kernel, and where are its lists
+            KA<RefWord, StreamLds> hp(P, S);
+            uint32_t mpos = 0;
+            int first_cls = -1;
+            while (mpos < mlen && st == 0) {
+                GroupHdr g = hp.parse_header(mm, mlen, mpos);
+                if (g.herr || g.n > 4 || ngrp >= kStreamGroups) st = 1;
+                else {
+                    const int mb = rev ? complement_char(g.modbase) : g.modbase;
+                    const int c = base_class_of_char(mb);
+                    if (g.modbase == 'N' || g.flag == '.') st = 1;
+                    if (first_cls < 0) first_cls = c;
+                    else if (c != first_cls) st = 1;
+                    hp.err = 0;
+                    hp.lookup_codes(g);
+                    if (__ballot(hp.err != 0)) st = 1;
+                    const int16_t a0 = S.g_code[0], a1 = S.g_code[1], a2 = S.g_code[2], a3 = S.g_code[3];
+                    const bool unwanted = a0 < 0 && a1 < 0 && a2 < 0 && a3 < 0;
+                    const uint32_t endp = find_semicolon(mm, mlen, g.lstart);
+                    wave_sync();
+                    if (lane == 0 && st == 0) {
+                        S.g_lstart[ngrp] = g.lstart; S.g_end[ngrp] = endp;
+                        S.g_flags[ngrp] = (unwanted ? 64u : 0u) | ((uint32_t)g.n << 12);
+                        S.g_c01[ngrp] = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
+                        S.g_c23[ngrp] = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
+                    }
+                    ngrp++;
+                    mpos = endp + 1u;
+                }
+            }
+            cls = first_cls;
+            wave_sync();
+        }
+        if (st == 0 && ngrp > 0u) {
+            ref_base = scalar_load(p.ref_base + tid);
+            const int64_t seg_begin = scalar_load(p.seg_begin + tid), seg_len = scalar_load(p.seg_len + tid), cnt_base = scalar_load(p.cnt_base + tid);
+            seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
+            rwb = reinterpret_cast<const RefWord*>(p.refw) + ref_base;
+            ml_start = 0;
+            uint32_t nb_all = 0;
+            bool have_nb = false;
+            for (uint32_t gi = 0; gi < ngrp && st == 0; gi++) {
+                const uint32_t lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
+                ncg = (int)((gflags >> 12) & 7u);
+                const bool wanted = !(gflags & 64u);
+                if (wanted) {
+                    gc0 = (int16_t)(c01 & 0xFFFFu); gc1 = (int16_t)(c01 >> 16); gc2 = (int16_t)(c23 & 0xFFFFu); gc3 = (int16_t)(c23 >> 16);
+                    const int ci = lane == 0u ? gc0 : (lane == 1u ? gc1 : (lane == 2u ? gc2 : gc3));
+                    uint32_t info = 0;
+                    if ((int)lane < ncg && lane < 4u && ci >= 0) {
+                        const DevCode& dc = p.codes[ci];
+                        const int req = dc.req, plane = dc.plane;
+                        const DevMod& dm = p.mods[req];
+                        info = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
+                               ((uint32_t)(plane + 1) << 23);
+                    }
+                    ci0 = lane_valu(info, 0); ci1 = lane_valu(info, 1); ci2 = lane_valu(info, 2); ci3 = lane_valu(info, 3);
+                    unsigned long long* cb[4];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const uint32_t ci_m = m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3));
+                        const int plane = (int)((ci_m >> 23) & 127u) - 1;
+                        cb[m] = nullptr;
+                        if (plane >= 0 && seg_len > 0) cb[m] = p.counters + ((int64_t)plane * 2 + rev) * p.plane_len + cnt_base - seg_begin;
+                    }
+                    cb0 = cb[0]; cb1 = cb[1]; cb2 = cb[2]; cb3 = cb[3];
+                }
+                uint32_t ntok = 0;
+                st = run_group(lstart, wanted, ntok);
+                if (st == 0 && !wanted && Rcarry != 0u) {
+                    // a group nobody asked for: its last listed rank must exist (mod.c:1116)
+                    if (!have_nb) { nb_all = count_all(); have_nb = true; }
+                    if (Rcarry - 1u >= nb_all) st = 2;
+                }
+                ml_start += ntok * (uint32_t)ncg;
+            }
+        }
+        return st;
+    }
+
+    __device__ void flush_stats(uint32_t stat_slot) {
+        uint32_t v[4] = {st_look, st_ml, st_dense, st_side};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t x = wave_incl_scan(v[i]);
+            uint32_t tt = lane_valu(x, 63);
+            if (lane_id() == 0 && tt) p.stats[16 + 4 * (size_t)stat_slot + i] += (unsigned long long)tt;   // this wave owns the row: no atomics
+        }
+    }
+};
+
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_stream_reads(const TileParams P) {
+    __shared__ StreamLds lds[kWavesPerBlock];
+    __shared__ uint32_t ptab[kSumTabWords];
+    fill_sum_table(ptab);
+    __syncthreads();
+    KF<RefWord> k(P, lds[threadIdx.x >> 6], ptab);
+    const DevParams& p = P.d;
+    // items costliest first; a wave's first item is fixed, the following ones are handed out by 64 padded counters (as in
+    // k_scan_reads)
+    const int n_waves = (int)gridDim.x * kWavesPerBlock;
+    const int n = (int)scalar_load(P.stream_count);
+    const int g = uni((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+    const bool dynamic = n_waves >= (int)kTileRegions;
+    for (int r = g; r < n;) {
+        const int r_cur = r;
+        if (dynamic) {
+            unsigned int c = 0;
+            if (lane_id() == 0) c = atomicAdd(P.stream_queue + (unsigned int)(g % (int)kTileRegions) * kQueueStride, 1u);
+            r = n_waves + (int)(uniu(c) * kTileRegions) + g % (int)kTileRegions;
+        } else {
+            r += n_waves;
+        }
+        const int ridx = uni((int)scalar_load(P.stream_items + r_cur));
+        const int st = uni(k.run(ridx));
+        if (p.stats && lane_id() == 0) atomicAdd(p.stats + 4 + st, 1ull);   // stats pass: reads done here / handed to the tiles / to the fused kernel
+        if (st == 1 && lane_id() == 0) {   // not this kernel's kind of read: one more item for k_scan_reads
+            const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
+            P.tile_items[at] = ridx;
+        }
+        if (st == 2 && lane_id() == 0) {   // an input error somewhere in the read: the fused kernel names it
+            const unsigned int at = atomicAdd(P.fb_count, 1u);
+            P.fb_list[at] = ridx;
+            if (P.host_fb_flag) *P.host_fb_flag = 1u;
+        }
+    }
+    if (p.stats) k.flush_stats((uint32_t)g & (kStatSlots - 1));
+}
+
+}  // namespace mmhip

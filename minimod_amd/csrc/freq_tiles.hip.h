@@ -76,6 +76,13 @@ struct TileParams {
     int32_t reset_in_call;       // 1: k_call_tiles is the launch's last kernel and resets the next launch's control words
     // work items planned on the device (k_plan_items): d.order points at them, their number is read from *plan_count
     const unsigned int* plan_count;   // null: the caller's plan (d.n_items entries)
+    // k_stream_reads (freq_stream.hip.h): its own item list (read indices, costliest first), the hand-out counters behind
+    // the static first round, and where it appends the reads it leaves to the tile pipeline (which runs after it)
+    const int32_t* stream_items;
+    const unsigned int* stream_count;
+    unsigned int* stream_queue;       // [kTileRegions * kQueueStride]
+    int32_t* tile_items;              // == d.order, writable
+    unsigned int* tile_plan_count;    // == plan_count, writable
 };
 constexpr uint32_t kPartSlots = 16;                       // parts per read (4 bits in a work item)
 constexpr int kPlanBuckets = 256;                         // cost buckets of 256 bases per part (a part is at most `split` bases: with the
@@ -228,29 +235,34 @@ __device__ __forceinline__ uint32_t plan_bucket(uint32_t L, uint32_t w) {
     return (uint32_t)(kPlanBuckets - 1) - k;
 }
 // State the planning workgroups share (one per slot, zeroed once at creation; every launch leaves it zeroed again).
+// Two lists are planned at once: class 0 = the tile pipeline's items (parts), class 1 = reads for k_stream_reads.
 struct PlanState {
-    unsigned int hist[kPlanBuckets];     // parts per bucket, summed over the workgroups
-    unsigned int cursor[kPlanBuckets];   // first free item of every bucket
-    unsigned int done;                   // workgroups that have added their histogram
-    unsigned int ready;                  // the launch serial, once the cursors are valid
+    unsigned int hist[2 * kPlanBuckets];     // parts per bucket, summed over the workgroups ([class][bucket])
+    unsigned int cursor[2 * kPlanBuckets];   // first free item of every bucket (each class counts from 0: two item arrays)
+    unsigned int done;                       // workgroups that have added their histogram
+    unsigned int ready;                      // the launch serial, once the cursors are valid
 };
 constexpr int kPlanThreads = 256;
 constexpr int kPlanReadsPerBlock = 512;
+static_assert(kPlanBuckets == kPlanThreads, "one bucket of each class per thread in the scan");
 // One workgroup per kPlanReadsPerBlock reads (at most 64, all resident at once): a single workgroup is bound by what one
 // CU can gather -- 4096 read records 64 bytes apart and as many scattered item stores took it 11 us, 70 us for a group of
 // eight batches.  Histograms in LDS, added to the shared one; the last workgroup to arrive scans it into cursors and
 // raises `ready`; every workgroup then reserves its share of each bucket with one atomic and hands out places from LDS.
+// stream_max: reads of at most this many bases go on the stream list (one item each) instead of the tile list; 0 = none.
 __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __restrict__ reads, int n, uint32_t split, int32_t* __restrict__ items,
                                                              unsigned int* __restrict__ n_items_out, PlanState* __restrict__ st, unsigned int serial,
-                                                             unsigned int* __restrict__ err_summary, unsigned int* __restrict__ host_flag) {
-    __shared__ uint32_t hist[kPlanBuckets];
-    __shared__ uint32_t base[kPlanBuckets];
-    __shared__ uint32_t wsum[kPlanThreads / 64];
+                                                             unsigned int* __restrict__ err_summary, unsigned int* __restrict__ host_flag,
+                                                             uint32_t stream_max, int32_t* __restrict__ items_stream,
+                                                             unsigned int* __restrict__ n_stream_out) {
+    __shared__ uint32_t hist[2 * kPlanBuckets];
+    __shared__ uint32_t base[2 * kPlanBuckets];
+    __shared__ uint32_t wsum[2][kPlanThreads / 64];
     __shared__ uint32_t s_last;
     const int t = threadIdx.x, nb = (int)gridDim.x;
     const int per = ((n + nb - 1) / nb + kPlanThreads - 1) / kPlanThreads * kPlanThreads;
     const int lo = (int)blockIdx.x * per, hi = min(n, lo + per);
-    for (int b = t; b < kPlanBuckets; b += kPlanThreads) hist[b] = 0u;
+    for (int b = t; b < 2 * kPlanBuckets; b += kPlanThreads) hist[b] = 0u;
     __syncthreads();
     for (int i0 = lo; i0 < hi; i0 += 4 * kPlanThreads) {   // four record loads in flight per thread
         uint32_t L[4];
@@ -259,29 +271,33 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + kPlanThreads * u + t;
-            if (i < hi) { const uint32_t w = plan_parts(L[u], split); atomicAdd(&hist[plan_bucket(L[u], w)], w); }
+            if (i < hi) {
+                const bool stream = stream_max != 0u && L[u] <= stream_max;
+                const uint32_t w = stream ? 1u : plan_parts(L[u], split);
+                atomicAdd(&hist[(stream ? kPlanBuckets : 0) + plan_bucket(L[u], w)], w);
+            }
         }
     }
     __syncthreads();
-    for (int b = t; b < kPlanBuckets; b += kPlanThreads) if (hist[b]) atomicAdd(&st->hist[b], hist[b]);
+    for (int b = t; b < 2 * kPlanBuckets; b += kPlanThreads) if (hist[b]) atomicAdd(&st->hist[b], hist[b]);
     __threadfence();   // a few dozen per launch: the shared histogram is complete before the ticket is drawn
     __syncthreads();
     if (t == 0) s_last = atomicAdd(&st->done, 1u) == (unsigned int)(nb - 1) ? 1u : 0u;
     __syncthreads();
     if (s_last) {
-        // exclusive scan of the shared histogram (read and cleared in one exchange), kPlanBuckets / kPlanThreads bins per thread
-        constexpr int kPer = kPlanBuckets / kPlanThreads;
-        uint32_t v[kPer], mine = 0;
+        // exclusive scan of the shared histogram (read and cleared in one exchange), one bucket of each class per thread
+        uint32_t v[2], incl[2];
 #pragma unroll
-        for (int k = 0; k < kPer; k++) { v[k] = atomicExch(&st->hist[kPer * t + k], 0u); mine += v[k]; }
-        const uint32_t incl = wave_incl_scan(mine);
-        if ((t & 63) == 63) wsum[t >> 6] = incl;
+        for (int c = 0; c < 2; c++) { v[c] = atomicExch(&st->hist[c * kPlanBuckets + t], 0u); incl[c] = wave_incl_scan(v[c]); }
+        if ((t & 63) == 63) { wsum[0][t >> 6] = incl[0]; wsum[1][t >> 6] = incl[1]; }
         __syncthreads();
-        uint32_t before = incl - mine;
-        for (int w = 0; w < (t >> 6); w++) before += wsum[w];
 #pragma unroll
-        for (int k = 0; k < kPer; k++) { atomicExch(&st->cursor[kPer * t + k], before); before += v[k]; }
-        if (t == kPlanThreads - 1) *n_items_out = before;
+        for (int c = 0; c < 2; c++) {
+            uint32_t before = incl[c] - v[c];
+            for (int w = 0; w < (t >> 6); w++) before += wsum[c][w];
+            atomicExch(&st->cursor[c * kPlanBuckets + t], before);
+            if (t == kPlanThreads - 1) { if (c == 0) *n_items_out = before + v[c]; else if (n_stream_out) *n_stream_out = before + v[c]; }
+        }
         __threadfence();
         __syncthreads();
         if (t == 0) { atomicExch(&st->done, 0u); atomicExch(&st->ready, serial); }
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
     __syncthreads();
     if (!s_last) return;
     // this workgroup's share of every bucket: one reservation per bucket it has parts in, then places from LDS
-    for (int b = t; b < kPlanBuckets; b += kPlanThreads) {
+    for (int b = t; b < 2 * kPlanBuckets; b += kPlanThreads) {
         const uint32_t cnt = hist[b];
         if (cnt) base[b] = atomicAdd(&st->cursor[b], cnt);
         hist[b] = 0u;
@@ -309,9 +325,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
         for (int u = 0; u < 4; u++) {
             const int i = i0 + kPlanThreads * u + t;
             if (i < hi) {
-                const uint32_t w = plan_parts(L[u], split), b = plan_bucket(L[u], w);
+                const bool stream = stream_max != 0u && L[u] <= stream_max;
+                const uint32_t w = stream ? 1u : plan_parts(L[u], split), b = (stream ? kPlanBuckets : 0) + plan_bucket(L[u], w);
                 const uint32_t at = base[b] + atomicAdd(&hist[b], w);
-                for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));
+                if (stream) items_stream[at] = (int32_t)i;
+                else for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));
             }
         }
     }
@@ -325,14 +343,15 @@ struct GroupHdr {
     uint32_t lstart;   // first character of the skip list
 };
 
-template <typename RefWord>
+// Lds: ScanLds, or any struct with hdr[16] and g_code[16] for the header functions alone (k_stream_reads)
+template <typename RefWord, typename Lds = ScanLds>
 struct KA {
     const TileParams& P;
     const DevParams& p;
-    ScanLds& S;
+    Lds& S;
     int err;
     unsigned long long tacc[5] = {0, 0, 0, 0, 0};   // diagnostic builds: time per phase, flushed once per wave
-    __device__ KA(const TileParams& tp, ScanLds& s) : P(tp), p(tp.d), S(s), err(0) {}
+    __device__ KA(const TileParams& tp, Lds& s) : P(tp), p(tp.d), S(s), err(0) {}
 
     // group header at mpos (mod.c:1003-1062); also leaves the code characters in S.hdr
     __device__ GroupHdr parse_header(const uint8_t* mm, uint32_t mlen, uint32_t mpos) {
@@ -917,6 +936,7 @@ struct KC {
     const uint32_t* rdir;
     int64_t ref_base, seg_begin, seg_len, cnt_base;
     uint32_t L, ncig, nblk, q_total, ml_len, nb, ml_start;
+    uint32_t q_shift;   // reverse read with a CIGAR shorter than its sequence: the aligned part lies at BAM positions [q_shift, L) (mod.c:813-860)
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
     int32_t gc0, gc1, gc2, gc3;
     // what a call needs of its code's table entries, fetched once per tile (wave-uniform; read per call they were
@@ -1137,14 +1157,15 @@ struct KC {
             ins_off[u] = 0; ref_pos[u] = -1;
             if (!live[u]) continue;
             int64_t rp = -1, anchor = -1;
-            if (q[u] < q_total) {
+            const uint32_t qe = q[u] - q_shift;   // (wraps past q_total for the bases in front of the aligned part)
+            if (qe < q_total) {
                 uint32_t qs, rv;
-                (void)find_op(q[u], qs, rv);
+                (void)find_op(qe, qs, rv);
                 uint32_t op = rv >> 28;
                 if ((0x181u >> op) & 1u) {
-                    rp = (int64_t)pos + (rv & 0x0FFFFFFFu) + (q[u] - qs);
+                    rp = (int64_t)pos + (rv & 0x0FFFFFFFu) + (qe - qs);
                 } else if (op == 1u && opt_insertions()) {
-                    ins_off[u] = (q[u] - qs + 1u) & 0xFFFFu;
+                    ins_off[u] = (qe - qs + 1u) & 0xFFFFu;
                     anchor = (int64_t)pos + (rv & 0x0FFFFFFFu) - 1;
                 }
             }
@@ -1152,7 +1173,7 @@ struct KC {
                 if (is_explicit || !rev) {
                     rp = anchor;
                 } else {   // mod.c:1234,1314 quirk: the mirrored base's insertion anchor
-                    uint32_t q2 = L - 1u - q[u];
+                    uint32_t q2 = L - 1u - q[u] - q_shift;
                     if (q2 < q_total) {
                         uint32_t qs2, rv2;
                         (void)find_op(q2, qs2, rv2);
@@ -1266,6 +1287,7 @@ struct KC {
         qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx; rdir = P.g_rdir + (rd.seq_off >> 5) + 2u * (uint32_t)ridx;
         nblk = (L + 31u) >> 5;
         q_total = scalar_load(P.g_qtot + ridx);
+        q_shift = (rev && q_total < L) ? L - q_total : 0u;
         nb = scalar_load(P.g_nb + ridx);
         hp = opt_haplotypes() ? (int)rd.hp : -1;
         hpi = opt_haplotypes() ? ((int)rd.hp < p.n_hp ? (int)rd.hp : -1) : 0;
@@ -1355,7 +1377,11 @@ struct KC {
                         KAT_LAP(10);
                         qa = 32u * b1; qb = min(L - 1u, 32u * b2 + 31u);
                     }
-                    if (q_total > 0 && qa < q_total) setup_cig_slice(qa, min(qb, q_total - 1u));
+                    // (positions of the aligned query: BAM positions less q_shift)
+                    if (qb >= q_shift) {
+                        const uint32_t qa_e = qa > q_shift ? qa - q_shift : 0u, qb_e = qb - q_shift;
+                        if (q_total > 0 && qa_e < q_total) setup_cig_slice(qa_e, min(qb_e, q_total - 1u));
+                    }
                 }
             }
             KAT_LAP(11);
@@ -1420,7 +1446,7 @@ __global__ __launch_bounds__(256, kPlain ? 7 : 5) void k_call_tiles(const TilePa
     const DevParams& p = P.d;
     if (P.reset_in_call && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
         if (p.ctl_next && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
-        if (p.queue_next && threadIdx.x < 128) p.queue_next[threadIdx.x * kQueueStride] = 0u;
+        if (p.queue_next && threadIdx.x < 192) p.queue_next[threadIdx.x * kQueueStride] = 0u;
     }
     // static round-robin: wave g serves region g % kTileRegions, striding over that region's tiles with the other
     // waves of the same residue (tiles cost about the same; no shared work counter to serialise on)

@@ -1,0 +1,236 @@
+"""k_stream_reads (freq_stream.hip.h): a whole read in one wavefront, the skip list, the sequence and the CIGAR merged in
+sliding windows.  These cases aim at what the windows must survive -- sparse lists that run far ahead of the directory
+window, lists denser than the blocks, CIGARs with more ops than the window holds, deletions / introns / insertions longer
+than the 14-bit offsets of the packed words, reads whose CIGAR is shorter than the sequence -- in both orientations, with
+the routing checked through the statistics pass (reads done by the kernel / handed to the tile pipeline / to the fused
+kernel).  HIP vs the oracle, bit-exact; the same input through the tile pipeline alone (no_stream) as a second witness."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import pybam
+from tests.hiprun import make_engine, to_oracle_rows
+
+pytestmark = pytest.mark.gpu
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def make_ref(rng, n):
+    return "".join(rng.choice(list("ACGT"), size=n, p=[0.2, 0.3, 0.3, 0.2]))
+
+
+def revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def oracle_rows(recs, ref, c, th=None):
+    mods = O.parse_mod_codes(c)
+    o = O.Oracle(mods, O.parse_mod_threshes(th, len(mods)), ["chrT"])
+    o.add_contig("chrT", ref.encode())
+    o.process(pybam.flatten(recs))
+    rows = o.rows()
+    codes = o.code_names()
+    o.close()
+    return [(int(r["pos"]), "+-"[r["strand"]], int(r["n_called"]), int(r["n_mod"]), int(r["ins_off"]), int(r["hp"]),
+             codes[r["code"]]) for r in rows]
+
+
+def hip_rows(recs, ref, c, th=None, **kw):
+    """rows and the routing statistics of one batch"""
+    mods = O.parse_mod_codes(c)
+    eng = make_engine(mods, O.parse_mod_threshes(th, len(mods)), ["chrT"], [len(ref)], {"chrT": ref.encode()}, **kw)
+    eng.stats_enable(True)
+    eng.process(pybam.flatten(recs))
+    st = eng.stats_get()
+    rows = to_oracle_rows(eng.finalize())
+    codes = eng.code_names()
+    eng.close()
+    return [(int(r["pos"]), "+-"[r["strand"]], int(r["n_called"]), int(r["n_mod"]), int(r["ins_off"]), int(r["hp"]),
+             codes[r["code"]]) for r in rows], st
+
+
+def listed_read(ref, pos, cigar, seq, base, picks, rng, flag=0, code="m", extra=""):
+    """A read over `seq` (BAM orientation) whose group lists the bases of kind `base` (original orientation) with the
+    indices in `picks` (rising).  For a reverse read the MM counts bases of the reverse complement."""
+    orig = revcomp(seq) if flag & 16 else seq
+    n_b = orig.count(base)
+    picks = [k for k in picks if k < n_b]
+    toks, prev = [], -1
+    for k in picks:
+        toks.append(str(k - prev - 1))
+        prev = k
+    ml = [int(x) for x in rng.integers(0, 256, size=len(toks))]
+    mm = "%s+%s?" % (base, code) + "".join("," + t for t in toks) + ";" + extra
+    return pybam.make_record(0, pos, flag, seq, cigar, mm, ml)
+
+
+def both_ways(recs, ref, c, th=None, expect_stream=None):
+    want = oracle_rows(recs, ref, c, th)
+    got, st = hip_rows(recs, ref, c, th)
+    assert got == want
+    got2, st2 = hip_rows(recs, ref, c, th, no_stream=True)
+    assert got2 == want
+    assert st2["stream_done"] == 0 and st2["stream_to_tiles"] == 0
+    if expect_stream is not None:
+        assert st["stream_done"] == expect_stream, st
+    return st
+
+
+@pytest.mark.parametrize("flag", [0, 16], ids=["fwd", "rev"])
+def test_sparse_and_dense_lists(flag):
+    rng = np.random.default_rng(31 + flag)
+    ref = make_ref(rng, 60000)
+    recs = []
+    # (a) three calls 8-9 kb apart: the directory window starts over between them
+    seq = ref[1000:21000]
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    recs.append(listed_read(ref, 1000, "20000M", seq, "C", [5, n_c // 2, n_c - 3], rng, flag))
+    # (b) every C listed: tens of calls per block, thousands of tokens
+    seq = ref[22000:34000]
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    recs.append(listed_read(ref, 22000, "12000M", seq, "C", list(range(n_c)), rng, flag))
+    # (c) every third A (the "other" class: what is not C, G, T or N), odd read length (half-filled last byte)
+    seq = ref[35000:47001]
+    n_a = (revcomp(seq) if flag else seq).count("A")
+    recs.append(listed_read(ref, 35000, "12001M", seq, "A", list(range(0, n_a, 3)), rng, flag, code="a"))
+    # (d) bursts: 70 listed in a row, a skip over thousands, 70 more, ... (rounds that end inside and outside a window)
+    seq = ref[40000:60000]
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    picks = [k for s in range(0, n_c, 1400) for k in range(s, min(s + 70, n_c))]
+    recs.append(listed_read(ref, 40000, "20000M", seq, "C", picks, rng, flag))
+    both_ways(recs, ref, "m[*]", expect_stream=4)
+    both_ways(recs, ref, "m,a[*]", expect_stream=4)
+
+
+@pytest.mark.parametrize("flag", [0, 16], ids=["fwd", "rev"])
+def test_cigars_the_window_cannot_hold(flag):
+    rng = np.random.default_rng(41 + flag)
+    ref = make_ref(rng, 90000)
+    recs = []
+    # (a) thousands of tiny ops: 2M1I2M1D ... : a 64-token round spans more ops than the window has room for
+    ops, seq, rp = [], [], 500
+    for i in range(3000):
+        seq.append(ref[rp:rp + 2]); ops.append("2M"); rp += 2
+        if i % 2 == 0:
+            seq.append("C"); ops.append("1I")
+        else:
+            ops.append("1D"); rp += 1
+    seq.append(ref[rp:rp + 5]); ops.append("5M")
+    seq = "".join(seq)
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    recs.append(listed_read(ref, 500, "".join(ops), seq, "C", list(range(0, n_c, 2)), rng, flag))
+    # (b) a 20 kb deletion, (c) a 30 kb intron, (d) an 18 kb insertion between densely listed stretches
+    for cig, seq in (("3000M20000D3000M", ref[100:3100] + ref[23100:26100]),
+                     ("3000M30000N3000M", ref[100:3100] + ref[33100:36100]),
+                     ("500M18000I500M", ref[1000:1500] + make_ref(rng, 18000) + ref[1500:2000])):
+        n_c = (revcomp(seq) if flag else seq).count("C")
+        recs.append(listed_read(ref, 100 if cig[0] == "3" else 1000, cig, seq, "C", list(range(n_c)), rng, flag))
+    # (e) soft clips at both ends carrying listed bases, a match of 17 kb (an op longer than the packed offsets), a CIGAR
+    #     that ends before the sequence does (the bases behind it have no call)
+    seq = make_ref(rng, 700) + ref[50000:67000] + make_ref(rng, 900)
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    recs.append(listed_read(ref, 50000, "700S17000M900S", seq, "C", list(range(0, n_c, 5)), rng, flag))
+    seq = ref[70000:76000]
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    recs.append(listed_read(ref, 70000, "100S5000M", seq, "C", list(range(0, n_c, 3)), rng, flag))
+    both_ways(recs, ref, "m[*]", expect_stream=6)
+    both_ways(recs, ref, "m", expect_stream=6)
+
+
+def test_groups_in_sequence_and_what_is_handed_on():
+    rng = np.random.default_rng(51)
+    ref = make_ref(rng, 30000)
+    seq = ref[2000:14000]
+    n_c, n_g = seq.count("C"), seq.count("G")
+    rc = revcomp(seq)
+    recs = []
+    # two requested groups on one base, an unrequested one between them (its tokens still move the ML index)
+    def three(flag):
+        s = rc if flag else seq
+        nc = s.count("C")
+        t1, t2, t3 = list(range(0, nc, 4)), list(range(1, nc, 7)), list(range(2, nc, 5))
+        def toks(p):
+            out, prev = [], -1
+            for k in p:
+                out.append(str(k - prev - 1)); prev = k
+            return out
+        mm = "C+h?" + "".join("," + t for t in toks(t1)) + ";C+x?" + "".join("," + t for t in toks(t2)) + ";C+m?" + "".join("," + t for t in toks(t3)) + ";"
+        ml = [int(x) for x in rng.integers(0, 256, size=len(t1) + len(t2) + len(t3))]
+        return pybam.make_record(0, 2000, flag, seq, "12000M", mm, ml)
+    recs += [three(0), three(16)]
+    # a two-letter group: two ML bytes per token
+    t = list(range(0, n_c, 6))
+    prev, tk = -1, []
+    for k in t:
+        tk.append(str(k - prev - 1)); prev = k
+    recs.append(pybam.make_record(0, 2000, 0, seq, "12000M", "C+hm?" + "".join("," + x for x in tk) + ";", [int(x) for x in rng.integers(0, 256, size=2 * len(tk))]))
+    st = both_ways(recs, ref, "m,h", expect_stream=3)
+    assert st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0
+    st = both_ways(recs, ref, "m[CG]", expect_stream=3)
+    # not this kernel's reads: a '.' group, a group on N, groups on two bases -> the tile pipeline (or its fallback); same rows
+    other = [pybam.make_record(0, 2000, 0, seq, "12000M", "C+m.,3,5,7;", [200, 10, 255]),
+             pybam.make_record(0, 2000, 0, seq, "12000M", "N+m?,30,50,70;", [200, 10, 255]),
+             pybam.make_record(0, 2000, 0, seq, "12000M", "C+m?,3,5,7;G+m?,1,1;", [200, 10, 255, 3, 250]),
+             pybam.make_record(0, 2000, 0, seq, "12000M", "", [])]
+    st = both_ways(recs + other, ref, "m", expect_stream=4)   # the read with an empty MM is done by the stream kernel (nothing to do)
+    assert st["stream_to_tiles"] == 3 and st["stream_to_fused"] == 0
+
+
+def test_errors_after_the_first_counts_go_to_the_fused_kernel():
+    """A malformed token, a rank past the read's last C and an ML array that is too short, each far enough into the list
+    that the stream kernel has counted calls before it meets them: the fused kernel names the error as the reference does."""
+    import minimod_amd
+    rng = np.random.default_rng(61)
+    ref = make_ref(rng, 12000)
+    seq = ref[1000:9000]
+    n_c = seq.count("C")
+    good = pybam.make_record(0, 1000, 0, seq, "8000M", "C+m?,0,1;", [255, 0])
+    cases = []
+    toks = ["0"] * 300
+    toks[250] = "1x"
+    cases.append(("C+m?" + "".join("," + t for t in toks) + ";", [200] * 300))
+    toks = ["0"] * 200 + [str(n_c)]
+    cases.append(("C+m?" + "".join("," + t for t in toks) + ";", [200] * 201))
+    toks = ["0"] * 400
+    cases.append(("C+m?" + "".join("," + t for t in toks) + ";", [200] * 350))
+    for mm, ml in cases:
+        rec = pybam.make_record(0, 1000, 0, seq, "8000M", mm, ml)
+        o = O.Oracle(O.parse_mod_codes("m[*]"), [0.8], ["chrT"])
+        o.add_contig("chrT", ref.encode())
+        with pytest.raises(O.OracleError) as oe:
+            o.process(pybam.flatten([good, rec, good]))
+        o.close()
+        eng = make_engine(O.parse_mod_codes("m[*]"), [0.8], ["chrT"], [len(ref)], {"chrT": ref.encode()})
+        with pytest.raises(minimod_amd.MinimodHipError) as he:
+            eng.process(pybam.flatten([good, rec, good]))
+        eng.close()
+        assert (he.value.code, he.value.read) == (oe.value.code, 1)
+
+
+def test_synthetic_reads_are_streamed():
+    """ONT- and HiFi-shape synthetic reads (the bench's generators): every `?` read of at most split_bases bases is done by
+    the stream kernel, '.' reads and longer ones by the tile pipeline; rows equal the oracle's."""
+    import minimod_amd
+    from minimod_amd import synth
+    ref = synth.reference(23, 4 << 20)
+    for gen, mods, th in ((dict(n=500, max_len=0.0, dot_fraction=0.2), [("m", "CG")], [0.8]),
+                          (dict(n=400, shape=1), [("m", "CG"), ("h", "CG")], [0.8, 0.7]),
+                          (dict(n=300, max_len=0.0), [("h", "CG")], [0.6])):
+        g = dict(gen); n = g.pop("n")
+        b = synth.batch(ref, 0, n, seed=91, n_reads_total=n, **g)
+        eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)])
+        eng.stats_enable(True)
+        eng.process(b)
+        st = eng.stats_get()
+        got = eng.finalize(); eng.close()
+        orc = O.Oracle(mods, th, ["chrS"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
+        want = orc.rows()
+        key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+        assert key(got, "ins_offset") == key(want, "ins_off")
+        rd = b["reads"]
+        dots = np.array([bytes(b["mm"][int(o):int(o) + 4]).endswith(b".") for o in rd["mm_off"]])
+        short = rd["l_qseq"] <= 24576
+        assert st["stream_done"] == int((short & ~dots).sum()), st
+        assert st["stream_to_tiles"] == int((short & dots).sum()), st
+        assert st["stream_to_fused"] == 0
