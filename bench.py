@@ -452,9 +452,12 @@ def main():
     # ---- untimed tally pass: lookups/updates per batch for the algorithmic-bytes figure
     eng.stats_enable(True)
     alg_bytes, side_per_pass = [], 0
+    routing, phases = np.zeros(3, dtype=np.int64), np.zeros(12, dtype=np.int64)
     for hb, db in zip(host_batches, dev_batches):
         eng.wait(eng.submit_device(db, stream))
         st = eng.stats_get()
+        routing += np.array([st["stream_done"], st["stream_to_tiles"], st["stream_to_fused"]], dtype=np.int64)
+        phases += np.array(st["phase_cycles"], dtype=np.int64)
         side_per_pass += st["side_updates"]
         alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], st["dense_updates"] + st["side_updates"]))
     eng.stats_enable(False)
@@ -606,6 +609,12 @@ def main():
                          "bytes_per_base": abytes / max(bases, 1), "side_list_updates_per_pass": side_per_pass},
             "gen_seconds": t_gen,
         }
+        result["config"]["routing"] = {"reads_done_by_k_stream_reads": int(routing[0]), "handed_to_the_tile_pipeline": int(routing[1]),
+                                       "handed_to_the_fused_kernel": int(routing[2]), "reads": int(n_reads),
+                                       "note": "reads of more than split_bases (24 576) bases are the tile pipeline's from the start"}
+        if phases[3:].any():   # diagnostic builds (-DMM_STREAM_TIMING): the tally pass, then the timed steps
+            result["phase_cycles"] = [int(x) for x in phases]
+            result["phase_cycles_timed"] = [int(x) for x in eng.stats_get()["phase_cycles"]]
         if world > 1:
             result["final_reduce"] = {"ms": reduce_s * 1e3, "value_incl": total_bases / (elapsed + reduce_s) / 1e6, "unit": "Mbases/s",
                                       "ranks": world, "slab_bytes": slab_words * 8, "backend": args.backend,

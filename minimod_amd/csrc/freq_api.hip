@@ -218,6 +218,9 @@ DevParams base_params(mm_freq* h) {
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
     p.stab = h->d_stab; p.smask = h->stab_slots ? h->stab_slots - 1 : 0;
     p.stats = h->stats_on ? h->d_stats : nullptr;
+#ifdef MM_STREAM_TIMING
+    p.stats = h->d_stats;   // diagnostic build: phase times of every launch (mm_freq_stats_get reads and clears them)
+#endif
     return p;
 }
 
@@ -339,8 +342,16 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                     HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
                 }
                 const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
+                // A read is one wavefront's work from start to end there, so the longest one bounds the launch from below:
+                // reads of up to `split` bases always go, longer ones when the launch is big enough to hide them (a read
+                // takes a wavefront about 7000 times longer per base than the launch takes per base: measured on MI355X,
+                // gathered launches of 4 to 32 batches)
+                // (the launch's bases are not known here for device batches -- windows of a resident set share pool sizes -- so
+                // its reads are taken as 12 kb each: short-read data never gets past `split` anyway)
+                const uint64_t launch_bases = 12000ull * (uint64_t)b->n_reads;
+                const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, launch_bases / 7350), 0x00FFFFFFu);
                 hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
-                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? split : 0u, s.d_plan_stream, ctl + 7);
+                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? stream_max : 0u, s.d_plan_stream, ctl + 7);
                 p.order = s.d_plan;
                 p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
                 tp.plan_count = ctl + 6;
@@ -617,6 +628,9 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint32_t>, 256, 0);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint16_t>, 256, 0);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
+#ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
+        h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
+#endif
         h->use_tiles = opts->force_fused == 0;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");

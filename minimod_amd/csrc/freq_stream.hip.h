@@ -33,14 +33,37 @@
 
 namespace mmhip {
 
+// diagnostic builds (-DMM_STREAM_TIMING): wave time per phase of k_stream_reads, summed into stats[7..15]
+#ifdef MM_STREAM_TIMING
+#define KFT_LAP(slot) do { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); ftacc[slot] += _n - ft0; ft0 = _n; } while (0)
+#else
+#define KFT_LAP(slot) do {} while (0)
+#endif
+
 constexpr uint32_t kStreamChunk = 256;      // skip-list characters parsed per trip (+16 of look-ahead)
 constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at most 63 left over + 128 of a chunk (+1)
-constexpr uint32_t kStreamDir = 320;        // directory window: 32-base blocks (10 kb of read) + one sentinel
-constexpr uint32_t kStreamCig = 576;        // CIGAR window: ops, one packed word each
+#ifndef MM_STREAM_DIR
+#define MM_STREAM_DIR 320
+#endif
+#ifndef MM_STREAM_CIG
+#define MM_STREAM_CIG 576
+#endif
+#ifndef MM_STREAM_DIR_ROUNDS
+#define MM_STREAM_DIR_ROUNDS 4
+#endif
+#ifndef MM_STREAM_CIG_ROUNDS
+#define MM_STREAM_CIG_ROUNDS 8
+#endif
+#ifndef MM_STREAM_WAVES
+#define MM_STREAM_WAVES 5
+#endif
+constexpr uint32_t kStreamDir = MM_STREAM_DIR;        // directory window: 32-base blocks (10 kb of read) + one sentinel
+constexpr uint32_t kStreamCig = MM_STREAM_CIG;        // CIGAR window: ops, one packed word each
 constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
+constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
 constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each)
-constexpr int kStreamDirRounds = 4;         // 64-block steps requested together
-constexpr int kStreamCigRounds = 8;         // 64-op steps requested together
+constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps requested together
+constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
 
 struct StreamLds {
     uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
@@ -49,7 +72,15 @@ struct StreamLds {
     uint32_t cw[kStreamCig];                // query offset << 18 | reference offset << 4 | op, relative to the window's first op
     char hdr[16];
     int16_t g_code[16];
-    uint32_t g_lstart[kStreamGroups], g_end[kStreamGroups], g_flags[kStreamGroups], g_c01[kStreamGroups], g_c23[kStreamGroups];
+    // what the header pass leaves for the groups: where the group starts and its list begins, flags (bit 6 no requested code,
+    // 12-14 codes per token), the codes and their packed table entries
+    uint32_t g_mpos[kStreamGroups], g_lstart[kStreamGroups], g_flags[kStreamGroups], g_c01[kStreamGroups], g_c23[kStreamGroups];
+    uint32_t g_ci[kStreamGroups][4];
+    // the headers this wave resolved last, by group ordinal: the reads of a file nearly all carry the same ones, and a header
+    // whose characters are those of the memo needs neither the checks nor the code table again
+    uint32_t memo_len[kStreamMemo];          // header characters incl. the flag (0 = empty)
+    uint8_t memo_hdr[kStreamMemo][16];
+    uint32_t memo_flags[kStreamMemo], memo_c01[kStreamMemo], memo_c23[kStreamMemo], memo_ci[kStreamMemo][4];
 };
 
 // class members among the 32 bases of block b (KA::block_count)
@@ -91,12 +122,17 @@ struct KF {
     uint32_t ml_start;
     // text cursor and token ring
     uint32_t cpos, nx_w0, nx_w1, qhead, qn, kdone, Rcarry, ntok_parsed;
+    uint32_t staged_at, skip0;   // text offset of the chunk in LDS; header characters in front of the list in the group's first chunk
     bool prev_delim, closed, bad_text;
     // directory window: blocks [t_w0, t_w0 + wn) in traversal order, t_next the next block to scan, S_next the members in front of it
     uint32_t t_w0, wn, t_next, S_next;
     // CIGAR window: ops [.., s_next) in traversal order, xn of them in LDS relative to (A_base, B_base); A_next / B_next =
     // query / reference positions consumed in front of s_next
     uint32_t xn, s_next, A_next, B_next, A_base, B_base;
+#ifdef MM_STREAM_TIMING
+    unsigned long long ftacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0 = 0;   // 0 record + CIGAR pass, 1 headers, 2 parse, 3 directory window,
+                                                                           // 4 locate, 5 CIGAR window, 6 finish, 7 window upkeep, 8 group set-up
+#endif
 
     __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
         : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0) {}
@@ -113,14 +149,21 @@ struct KF {
     }
     // One chunk of the group's skip list: its tokens appended to the ring as ranks (keep), counted and summed either way.
     // The parse is k_sum_tiles' (a token belongs to the chunk it starts in; the look-ahead completes the last one).
-    __device__ __forceinline__ void parse_chunk(bool keep) {
+    __device__ __forceinline__ void stage_chunk(uint32_t at) {
         const int lane = lane_id();
-        constexpr int kSub = (int)(kStreamChunk / 64);
         wave_sync();
         S.mmw[lane] = nx_w0;
         if (lane < 4) S.mmw[64 + lane] = nx_w1;
         wave_sync();
+        staged_at = at;
+    }
+    __device__ __forceinline__ void parse_chunk(bool keep) {
+        const int lane = lane_id();
+        constexpr int kSub = (int)(kStreamChunk / 64);
+        if (staged_at != cpos) stage_chunk(cpos);
         fetch_chunk(cpos + kStreamChunk);   // the next chunk is requested before this one is parsed
+        const uint32_t skip = skip0;         // the group's first chunk starts at its header: the list begins `skip` characters in
+        skip0 = 0;
         const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
         uint32_t x[kSub];
 #pragma unroll
@@ -133,6 +176,7 @@ struct KF {
             D[sc] = Sm[sc] | __ballot(x[sc] == ',');
         }
         D[kSub] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;
+        if (skip) D[0] |= 1ull << (skip - 1u);   // the list's first character follows the header as if it followed a delimiter
         const uint32_t qtail = qhead + qn;
         uint32_t nends = 0, rsum_v = 0;
         uint64_t bad = 0;
@@ -143,6 +187,7 @@ struct KF {
             int lo = 0, hi = 64;
             if (Sm[sc]) { hi = __ffsll((unsigned long long)Sm[sc]) - 1; cl = true; }
             if (sc == 0 && !prev_delim) lo = D[0] ? __ffsll((unsigned long long)D[0]) - 1 : 64;
+            if (sc == 0 && skip) lo = (int)skip;
             const uint64_t pd = sc == 0 ? (prev_delim ? 1ull : 0ull) : (D[sc > 0 ? sc - 1 : 0] >> 63);
             const uint32_t w = window32((D[sc] << 1) | pd, (D[sc + 1] << 1) | (D[sc] >> 63), lane);
             const bool own = (uint32_t)(lane - lo) < (uint32_t)(hi - lo) && lo < hi;
@@ -187,16 +232,21 @@ struct KF {
     // ------------------------------------------------------------------ sequence -> directory window
     // blocks are appended until the window covers rank rho_last (S_next > rho_last), the read ends, or the window is full
     // while it already covers rho_0; a full window that does not even reach rho_0 holds nothing of use and starts over
-    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last) {
+    __device__ __forceinline__ void load_dir(uint4 (&vv)[kStreamDirRounds]) const {
         const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false;
-        while (!stop && S_next <= rho_last && t_next < nblk) {
-            uint4 vv[kStreamDirRounds];
 #pragma unroll
-            for (int r = 0; r < kStreamDirRounds; r++) {
-                const uint32_t t = t_next + 64u * (uint32_t)r + lane;
-                vv[r] = t < nblk ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
-            }
+        for (int r = 0; r < kStreamDirRounds; r++) {
+            const uint32_t t = t_next + 64u * (uint32_t)r + lane;
+            vv[r] = t < nblk ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // (vv: the steps from t_next on, requested by the caller before it waited for anything)
+    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last, uint4 (&vv)[kStreamDirRounds]) {
+        const uint32_t lane = (uint32_t)lane_id();
+        bool stop = false, first = true;
+        while (!stop && S_next <= rho_last && t_next < nblk) {
+            if (!first) load_dir(vv);
+            first = false;
 #pragma unroll
             for (int r = 0; r < kStreamDirRounds; r++) {
                 if (!stop && S_next <= rho_last && t_next < nblk) {
@@ -264,16 +314,21 @@ struct KF {
     // ------------------------------------------------------------------ CIGAR -> window
     // ops are appended until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more
     // fits (room, or the 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
-    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi) {
+    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds]) const {
         const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false;
-        while (!stop && A_next <= u_hi && s_next < ncig) {
-            uint32_t wv[kStreamCigRounds];
 #pragma unroll
-            for (int r = 0; r < kStreamCigRounds; r++) {
-                const uint32_t s = s_next + 64u * (uint32_t)r + lane;
-                wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
-            }
+        for (int r = 0; r < kStreamCigRounds; r++) {
+            const uint32_t s = s_next + 64u * (uint32_t)r + lane;
+            wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
+        }
+    }
+    // (wv: the steps from s_next on, requested by the caller at the start of the round)
+    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds]) {
+        const uint32_t lane = (uint32_t)lane_id();
+        bool stop = false, first = true;
+        while (!stop && A_next <= u_hi && s_next < ncig) {
+            if (!first) load_cig(wv);
+            first = false;
             bool stale = false;   // the loaded steps no longer line up with s_next
 #pragma unroll
             for (int r = 0; r < kStreamCigRounds; r++) {
@@ -338,7 +393,18 @@ struct KF {
         const bool lv = lane < n;
         const uint32_t rho = lv ? S.tok[(qhead + lane) & (kStreamRing - 1u)] : 0xFFFFFFFFu;
         const uint32_t rho_0 = lane_valu(rho, 0), rho_last = lane_valu(rho, (int)(n - 1u));
-        fill_dir(rho_0, rho_last);
+        KFT_LAP(2);
+        // Requested together, before anything is waited for: the next steps of the sequence and of the CIGAR from where the
+        // cursors stand, and the round's ML bytes (a round then pays one trip to memory for all three, not one each)
+        uint4 dv[kStreamDirRounds];
+        uint32_t cv[kStreamCigRounds];
+        load_dir(dv);
+        load_cig(cv);
+        const uint32_t kidx = kdone + lane;
+        const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
+        const uint32_t ml0 = (lv && mi0 < ml_len) ? ml[mi0] : 0u;
+        fill_dir(rho_0, rho_last, dv);
+        KFT_LAP(3);
         const uint32_t n1 = leading_ones(__ballot(lv && rho < S_next));   // tokens whose block is in the window
         uint32_t n_done = 0;
         if (n1 > 0u) {
@@ -354,7 +420,11 @@ struct KF {
             const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
             const uint32_t t = t_w0 + j, blk = rev ? nblk - 1u - t : t;
             const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
+#ifndef MM_ABL_NOGATHER
             const uint4 sv = act ? sq[blk] : make_uint4(0, 0, 0, 0);
+#else
+            const uint4 sv = make_uint4(0x22222222u ^ blk, 0x44444444u, 0x22224444u, 0x42424242u);
+#endif
             uint32_t code = 0;
             const uint32_t q = act ? select_in_block(sv, blk, kk, code) : 0u;
             // read position -> position in the direction the CIGAR is walked (get_aln walks a reverse read's ops back to front
@@ -362,11 +432,13 @@ struct KF {
             const uint32_t u = rev ? L - 1u - q : q;
             const bool live = act && u < q_total;
             const uint64_t lm = __ballot(live);
+            KFT_LAP(4);
             if (lm) {
                 const int fl = __ffsll((unsigned long long)lm) - 1, ll = 63 - __clzll((unsigned long long)lm);
-                fill_cig(lane_valu(u, fl), lane_valu(u, ll));
+                fill_cig(lane_valu(u, fl), lane_valu(u, ll), cv);
             }
             n_done = leading_ones(__ballot(act && (!live || u < A_next)));
+            KFT_LAP(5);
             const bool fin = lane < n_done && live;
             const uint64_t fm = __ballot(fin);
             if (fm) {
@@ -384,13 +456,14 @@ struct KF {
                 const bool call = fin && ((0x181u >> op) & 1u);
                 const uint32_t e = u - a_s;
                 const int32_t ref_pos = rev ? pos + (int32_t)(r_total - 1u - b_s - e) : pos + (int32_t)(b_s + e);
-                const uint32_t kidx = kdone + lane;
-                uint32_t w = 0, ml0 = 0;
+                uint32_t w = 0;
                 if (call) {
+#ifndef MM_ABL_NOREF
                     w = (uint32_t)rwb[(uint32_t)ref_pos];
+#else
+                    w = 0xFFFFFFE0u | (code & 31u) | ((uint32_t)ref_pos & 0u);
+#endif
                     st_look++;
-                    const uint64_t mi = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
-                    if (mi < ml_len) ml0 = ml[mi];
                 }
                 if (call) {
                     const uint32_t refcode = w & 31u;
@@ -413,7 +486,11 @@ struct KF {
                         else continue;
                         unsigned long long* const cbm = cbase_at(m);
                         if (cbm != nullptr && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
+#ifndef MM_ABL_NOATOMIC
                             atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
+#else
+                            if (ref_pos == -12345 && is_mod) atomicAdd(cbm, 1ull);
+#endif
                             st_dense++;
                         } else {
                             side_append(ref_pos, is_mod, ci);
@@ -421,6 +498,7 @@ struct KF {
                         }
                     }
                 }
+                KFT_LAP(6);
                 // the CIGAR window keeps what the next round can still need: from the last searched op on
                 const int fll = 63 - __clzll((unsigned long long)fm);
                 const uint32_t xl = lane_valu(xo, fll);
@@ -453,17 +531,18 @@ struct KF {
                 }
             }
         }
+        KFT_LAP(7);
         return n_done;
     }
 
     // ------------------------------------------------------------------ one group's skip list [lstart, ...;)
     // returns 0, or 2 when the read has to go to the fused kernel (an input error); *ntok = tokens of the group
-    __device__ __forceinline__ int run_group(uint32_t lstart, bool wanted, uint32_t& ntok) {
-        cpos = lstart; prev_delim = true; closed = false; bad_text = false;
+    __device__ __forceinline__ int run_group(uint32_t mpos, uint32_t lstart, bool wanted, uint32_t& ntok) {
+        cpos = mpos; skip0 = lstart - mpos; prev_delim = true; closed = false; bad_text = false;
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
         t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
         xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
-        fetch_chunk(cpos);
+        if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
         for (;;) {
             while (qn < 64u && !closed && !bad_text) parse_chunk(wanted);
@@ -482,6 +561,9 @@ struct KF {
     // ------------------------------------------------------------------ one read: 0 done, 1 -> tile pipeline, 2 -> fused kernel
     __device__ int run(int ridx) {
         const uint32_t lane = (uint32_t)lane_id();
+#ifdef MM_STREAM_TIMING
+        ft0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const mm_read_t rd = scalar_load(p.reads + ridx);
         err = 0;
         tid = uni(rd.tid); pos = uni(rd.pos);
@@ -491,25 +573,39 @@ struct KF {
         sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
         cg = p.cigar + rd.cigar_off;
         nblk = (L + 31u) >> 5;
-        bool have_ref = tid >= 0 && tid < p.n_contigs;
-        if (have_ref) have_ref = scalar_load(p.ref_base + tid) >= 0;
-        int st = (have_ref && L > 0u && ncig > 0u) ? 0 : 1;
+        // Everything that only needs the record is requested before anything is waited for: the CIGAR (its first 1024 ops),
+        // the first characters of the MM string (the first group's header and the start of its list), the contig's entries
+        uint4 cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = 256u * (uint32_t)u + 4u * lane;
+            cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
+        }
+        staged_at = 0xFFFFFFFFu; skip0 = 0;
+        fetch_chunk(0u);
+        const bool tid_ok = tid >= 0 && tid < p.n_contigs;
+        const int tid_c = tid_ok ? tid : 0;
+        ref_base = scalar_load(p.ref_base + tid_c);
+        const int64_t ctg_len = scalar_load(p.ctg_len + tid_c);
+        const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c), cnt_base = scalar_load(p.cnt_base + tid_c);
+        int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
         if (st == 0) {
             // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, and the checks reduced to
             // what a clean record passes outright; anything else is the tile pipeline's to judge op by op
             uint32_t sumq = 0, sumr = 0;
             bool badop = false;
             for (uint32_t i0 = 0; i0 < ncig; i0 += 1024u) {
-                uint4 wv[4];
+                if (i0 > 0u) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
-                    wv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
+                        cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
-                    const uint32_t w4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+                    const uint32_t w4[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const bool valid = i + (uint32_t)k < ncig;
@@ -524,38 +620,92 @@ struct KF {
             // 64 lanes x 2^28 does not fit a word: the halves are added separately
             const uint64_t tq = (uint64_t)lane_valu(wave_incl_scan(sumq & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumq >> 16), 63) << 16);
             const uint64_t tr = (uint64_t)lane_valu(wave_incl_scan(sumr & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumr >> 16), 63) << 16);
-            const int64_t ctg_len = scalar_load(p.ctg_len + tid);
             if (__ballot(badop) || tq > (uint64_t)L || tr >= (1ull << 28) || pos < 0 || (int64_t)pos + (int64_t)tr > ctg_len) st = 1;
             q_total = (uint32_t)tq; r_total = (uint32_t)tr;
         }
+        KFT_LAP(0);
         uint32_t ngrp = 0;
         if (st == 0) {
-            // the group headers (mod.c:1003-1062): is this a read for this kernel, and where are its lists
+            // The group headers (mod.c:1003-1062): is this a read for this kernel, where are its lists, which codes do they carry.
+            // A group's first kStreamChunk characters are staged in LDS: the header is read from there, and so is the group's
+            // end when it lies that near.
             KA<RefWord, StreamLds> hp(P, S);
+            const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
             uint32_t mpos = 0;
             int first_cls = -1;
             while (mpos < mlen && st == 0) {
-                GroupHdr g = hp.parse_header(mm, mlen, mpos);
-                if (g.herr || g.n > 4 || ngrp >= kStreamGroups) st = 1;
-                else {
-                    const int mb = rev ? complement_char(g.modbase) : g.modbase;
+                if (mpos != 0u) fetch_chunk(mpos);
+                stage_chunk(mpos);
+                const uint32_t ci = mpos + lane;
+                const int ch = ci < mlen ? (int)mb8[lane] : 0;
+                // the header ends at the first of , ; ? . (or the string's end); a flag belongs to it
+                const uint64_t sb = __ballot(lane >= 1u && (ci >= mlen || ch == ',' || ch == ';' || ch == '?' || ch == '.'));
+                const uint32_t e = sb ? (uint32_t)__ffsll((unsigned long long)sb) - 1u : 64u;
+                const int ce = e < 64u ? lane_val(ch, (int)e) : 0;
+                const uint32_t hlen = e + ((ce == '?' || ce == '.') ? 1u : 0u);
+                const uint32_t slot = ngrp < kStreamMemo ? ngrp : 0u;
+                const bool memo_hit = ngrp < kStreamMemo && hlen <= 16u && uniu(S.memo_len[slot]) == hlen &&
+                                      !__ballot(lane < hlen && (uint32_t)ch != (uint32_t)S.memo_hdr[slot][lane & 15u]);
+                uint32_t gflags, c01, c23, lstart, ci_w = 0;
+                const int c0 = lane_val(ch, 0);
+                if (memo_hit) {
+                    gflags = uniu(S.memo_flags[slot]); c01 = uniu(S.memo_c01[slot]); c23 = uniu(S.memo_c23[slot]);
+                    if (lane < 4u) ci_w = S.memo_ci[slot][lane];
+                    lstart = mpos + hlen;
+                } else {
+                    GroupHdr g = hp.parse_header_ch(ch, mlen, mpos);
+                    lstart = g.lstart;
+                    gflags = 0; c01 = 0; c23 = 0;
+                    if (g.herr || g.n > 4 || ngrp >= kStreamGroups) st = 1;
+                    else {
+                        if (g.modbase == 'N' || g.flag == '.') st = 1;   // the tile pipeline has the implicit calls and the direct groups
+                        hp.err = 0;
+                        hp.lookup_codes(g);
+                        if (__ballot(hp.err != 0)) st = 1;
+                        const int16_t a0 = S.g_code[0], a1 = S.g_code[1], a2 = S.g_code[2], a3 = S.g_code[3];
+                        const bool unwanted = a0 < 0 && a1 < 0 && a2 < 0 && a3 < 0;
+                        gflags = (unwanted ? 64u : 0u) | ((uint32_t)g.n << 12);
+                        c01 = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
+                        c23 = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
+                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 | (plane + 1) << 23
+                        const int cix = lane == 0u ? a0 : (lane == 1u ? a1 : (lane == 2u ? a2 : a3));
+                        if ((int)lane < g.n && lane < 4u && cix >= 0) {
+                            const DevCode& dc = p.codes[cix];
+                            const int req = dc.req, plane = dc.plane;
+                            const DevMod& dm = p.mods[req];
+                            ci_w = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
+                                   ((uint32_t)(plane + 1) << 23);
+                        }
+                        wave_sync();
+                        if (st == 0 && ngrp < kStreamMemo && hlen <= 16u && lstart == mpos + hlen) {
+                            if (lane < 16u) S.memo_hdr[slot][lane] = (uint8_t)ch;
+                            if (lane < 4u) S.memo_ci[slot][lane] = ci_w;
+                            if (lane == 0u) { S.memo_len[slot] = hlen; S.memo_flags[slot] = gflags; S.memo_c01[slot] = c01; S.memo_c23[slot] = c23; }
+                        }
+                    }
+                }
+                if (st == 0) {
+                    const int mb = rev ? complement_char(c0 == 'U' ? 'T' : c0) : (c0 == 'U' ? 'T' : c0);
                     const int c = base_class_of_char(mb);
-                    if (g.modbase == 'N' || g.flag == '.') st = 1;
                     if (first_cls < 0) first_cls = c;
                     else if (c != first_cls) st = 1;
-                    hp.err = 0;
-                    hp.lookup_codes(g);
-                    if (__ballot(hp.err != 0)) st = 1;
-                    const int16_t a0 = S.g_code[0], a1 = S.g_code[1], a2 = S.g_code[2], a3 = S.g_code[3];
-                    const bool unwanted = a0 < 0 && a1 < 0 && a2 < 0 && a3 < 0;
-                    const uint32_t endp = find_semicolon(mm, mlen, g.lstart);
-                    wave_sync();
-                    if (lane == 0 && st == 0) {
-                        S.g_lstart[ngrp] = g.lstart; S.g_end[ngrp] = endp;
-                        S.g_flags[ngrp] = (unwanted ? 64u : 0u) | ((uint32_t)g.n << 12);
-                        S.g_c01[ngrp] = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
-                        S.g_c23[ngrp] = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
+                    // the group's end: in the staged characters (from the list's start on), or further on in the string
+                    const uint32_t skip = lstart - mpos;
+                    uint32_t endp = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int sc = 0; sc < (int)(kStreamChunk / 64); sc++) {
+                        const uint32_t xs = mb8[64 * sc + (int)lane];
+                        uint64_t sm = __ballot(xs == (uint32_t)';');
+                        if (sc == 0) sm &= ~low_bits((int)skip);
+                        if (sm && endp == 0xFFFFFFFFu) endp = mpos + 64u * (uint32_t)sc + (uint32_t)__ffsll((unsigned long long)sm) - 1u;
                     }
+                    if (endp == 0xFFFFFFFFu) endp = find_semicolon(mm, mlen, mpos + kStreamChunk);
+                    if (endp > mlen) endp = mlen;
+                    wave_sync();
+                    if (lane == 0u) {
+                        S.g_mpos[ngrp] = mpos; S.g_lstart[ngrp] = lstart; S.g_flags[ngrp] = gflags; S.g_c01[ngrp] = c01; S.g_c23[ngrp] = c23;
+                    }
+                    if (lane < 4u) S.g_ci[ngrp][lane] = ci_w;
                     ngrp++;
                     mpos = endp + 1u;
                 }
@@ -563,30 +713,20 @@ struct KF {
             cls = first_cls;
             wave_sync();
         }
+        KFT_LAP(1);
         if (st == 0 && ngrp > 0u) {
-            ref_base = scalar_load(p.ref_base + tid);
-            const int64_t seg_begin = scalar_load(p.seg_begin + tid), seg_len = scalar_load(p.seg_len + tid), cnt_base = scalar_load(p.cnt_base + tid);
             seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
             rwb = reinterpret_cast<const RefWord*>(p.refw) + ref_base;
             ml_start = 0;
             uint32_t nb_all = 0;
             bool have_nb = false;
             for (uint32_t gi = 0; gi < ngrp && st == 0; gi++) {
-                const uint32_t lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
+                const uint32_t gmpos = uniu(S.g_mpos[gi]), lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
                 ncg = (int)((gflags >> 12) & 7u);
                 const bool wanted = !(gflags & 64u);
                 if (wanted) {
                     gc0 = (int16_t)(c01 & 0xFFFFu); gc1 = (int16_t)(c01 >> 16); gc2 = (int16_t)(c23 & 0xFFFFu); gc3 = (int16_t)(c23 >> 16);
-                    const int ci = lane == 0u ? gc0 : (lane == 1u ? gc1 : (lane == 2u ? gc2 : gc3));
-                    uint32_t info = 0;
-                    if ((int)lane < ncg && lane < 4u && ci >= 0) {
-                        const DevCode& dc = p.codes[ci];
-                        const int req = dc.req, plane = dc.plane;
-                        const DevMod& dm = p.mods[req];
-                        info = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
-                               ((uint32_t)(plane + 1) << 23);
-                    }
-                    ci0 = lane_valu(info, 0); ci1 = lane_valu(info, 1); ci2 = lane_valu(info, 2); ci3 = lane_valu(info, 3);
+                    ci0 = uniu(S.g_ci[gi][0]); ci1 = uniu(S.g_ci[gi][1]); ci2 = uniu(S.g_ci[gi][2]); ci3 = uniu(S.g_ci[gi][3]);
                     unsigned long long* cb[4];
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
@@ -598,7 +738,9 @@ struct KF {
                     cb0 = cb[0]; cb1 = cb[1]; cb2 = cb[2]; cb3 = cb[3];
                 }
                 uint32_t ntok = 0;
-                st = run_group(lstart, wanted, ntok);
+                KFT_LAP(8);
+                st = run_group(gmpos, lstart, wanted, ntok);
+                KFT_LAP(2);
                 if (st == 0 && !wanted && Rcarry != 0u) {
                     // a group nobody asked for: its last listed rank must exist (mod.c:1116)
                     if (!have_nb) { nb_all = count_all(); have_nb = true; }
@@ -622,13 +764,14 @@ struct KF {
 };
 
 template <typename RefWord>
-__global__ __launch_bounds__(256) void k_stream_reads(const TileParams P) {
+__global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const TileParams P) {
     __shared__ StreamLds lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
     KF<RefWord> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
+    if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
     // items costliest first; a wave's first item is fixed, the following ones are handed out by 64 padded counters (as in
     // k_scan_reads)
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
@@ -658,6 +801,9 @@ __global__ __launch_bounds__(256) void k_stream_reads(const TileParams P) {
         }
     }
     if (p.stats) k.flush_stats((uint32_t)g & (kStatSlots - 1));
+#ifdef MM_STREAM_TIMING
+    if (p.stats && lane_id() == 0) for (int i = 0; i < 9; i++) atomicAdd(p.stats + 7 + i, k.ftacc[i]);
+#endif
 }
 
 }  // namespace mmhip

@@ -274,7 +274,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             if (i < hi) {
                 const bool stream = stream_max != 0u && L[u] <= stream_max;
                 const uint32_t w = stream ? 1u : plan_parts(L[u], split);
+#ifdef MM_STREAM_MEMORDER
+                atomicAdd(&hist[stream ? kPlanBuckets + (uint32_t)(((uint64_t)i * kPlanBuckets) / (uint32_t)n) : plan_bucket(L[u], w)], w);
+#else
                 atomicAdd(&hist[(stream ? kPlanBuckets : 0) + plan_bucket(L[u], w)], w);
+#endif
             }
         }
     }
@@ -326,7 +330,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             const int i = i0 + kPlanThreads * u + t;
             if (i < hi) {
                 const bool stream = stream_max != 0u && L[u] <= stream_max;
+#ifdef MM_STREAM_MEMORDER
+                const uint32_t w = stream ? 1u : plan_parts(L[u], split), b = stream ? kPlanBuckets + (uint32_t)(((uint64_t)i * kPlanBuckets) / (uint32_t)n) : plan_bucket(L[u], w);
+#else
                 const uint32_t w = stream ? 1u : plan_parts(L[u], split), b = (stream ? kPlanBuckets : 0) + plan_bucket(L[u], w);
+#endif
                 const uint32_t at = base[b] + atomicAdd(&hist[b], w);
                 if (stream) items_stream[at] = (int32_t)i;
                 else for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));
@@ -355,10 +363,14 @@ struct KA {
 
     // group header at mpos (mod.c:1003-1062); also leaves the code characters in S.hdr
     __device__ GroupHdr parse_header(const uint8_t* mm, uint32_t mlen, uint32_t mpos) {
+        const uint32_t ci = mpos + (uint32_t)lane_id();
+        return parse_header_ch(ci < mlen ? (int)mm[ci] : 0, mlen, mpos);
+    }
+    // ... with the lane's character (0 past the end of the string) already at hand
+    __device__ GroupHdr parse_header_ch(int ch, uint32_t mlen, uint32_t mpos) {
         const int lane = lane_id();
         GroupHdr g;
         uint32_t ci = mpos + lane;
-        int ch = ci < mlen ? (int)mm[ci] : 0;
         int c0 = lane_val(ch, 0), c1 = lane_val(ch, 1);
         int herr = 0;
         if (!valid_base_char(c0)) herr = MM_E_MMBASE;
