@@ -367,8 +367,13 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             const bool plain = !p.insertions && !p.haplotypes;
             if (stream) {
                 const int gf = h->n_cu * h->stream_blocks_per_cu;
-                if (h->wide) hipLaunchKernelGGL(k_stream_reads<uint32_t>, dim3(gf), dim3(256), 0, st, tp);
-                else hipLaunchKernelGGL(k_stream_reads<uint16_t>, dim3(gf), dim3(256), 0, st, tp);
+                if (p.stats) {
+                    if (h->wide) hipLaunchKernelGGL((k_stream_reads<uint32_t, true>), dim3(gf), dim3(256), 0, st, tp);
+                    else hipLaunchKernelGGL((k_stream_reads<uint16_t, true>), dim3(gf), dim3(256), 0, st, tp);
+                } else {
+                    if (h->wide) hipLaunchKernelGGL((k_stream_reads<uint32_t, false>), dim3(gf), dim3(256), 0, st, tp);
+                    else hipLaunchKernelGGL((k_stream_reads<uint16_t, false>), dim3(gf), dim3(256), 0, st, tp);
+                }
             }
             if (h->wide) {
                 hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
@@ -625,8 +630,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
         int nf = 0;
-        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint32_t>, 256, 0);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, k_stream_reads<uint16_t>, 256, 0);
+        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false>), 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false>), 256, 0);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);

@@ -49,19 +49,21 @@ constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at mo
 #define MM_STREAM_CIG 576
 #endif
 #ifndef MM_STREAM_DIR_ROUNDS
-#define MM_STREAM_DIR_ROUNDS 4
+#define MM_STREAM_DIR_ROUNDS 2
 #endif
 #ifndef MM_STREAM_CIG_ROUNDS
-#define MM_STREAM_CIG_ROUNDS 8
+#define MM_STREAM_CIG_ROUNDS 4
 #endif
 #ifndef MM_STREAM_WAVES
-#define MM_STREAM_WAVES 5
+#define MM_STREAM_WAVES 6
 #endif
 constexpr uint32_t kStreamDir = MM_STREAM_DIR;        // directory window: 32-base blocks (10 kb of read) + one sentinel
 constexpr uint32_t kStreamCig = MM_STREAM_CIG;        // CIGAR window: ops, one packed word each
 constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
 constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
-constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each)
+constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each); query offsets stay one
+                                            // below that, so that no word reaches the padding's 0xFFFFFFFF
+constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // what both windows hold behind their last entry: the searches run over the whole array
 constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps requested together
 constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
 
@@ -98,7 +100,23 @@ __device__ __forceinline__ uint32_t stream_block_count(uint4 v, int cls, uint32_
 // number of set bits below the lowest clear one (64 when all are set)
 __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint32_t)__ffsll((unsigned long long)~m) - 1u : 64u; }
 
-template <typename RefWord>
+// largest i in [0, N) with arr[i] <= key: arr rises, arr[0] <= key, and what lies behind the entries in use is kStreamInf.
+// N is fixed, so the loop unrolls into its ceil(log2 N) steps: a read, a compare and a select each, no loop control.
+template <uint32_t N>
+__device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t n = N; n > 1u; n -= n >> 1) {
+        const uint32_t half = n >> 1;
+        lo = arr[lo + half] <= key ? lo + half : lo;
+    }
+    return lo;
+}
+__device__ __forceinline__ void inf_fill(uint32_t* arr, uint32_t from, uint32_t to) {
+    for (uint32_t i = from + (uint32_t)lane_id(); i < to; i += 64u) arr[i] = kStreamInf;
+}
+
+template <typename RefWord, bool kStats>
 struct KF {
     const TileParams& P;
     const DevParams& p;
@@ -252,7 +270,7 @@ struct KF {
                 if (!stop && S_next <= rho_last && t_next < nblk) {
                     if (wn + 64u > kStreamDir) {
                         if (S_next > rho_0) stop = true;
-                        else { wn = 0; t_w0 = t_next; }
+                        else { inf_fill(S.dw, 0u, wn + 1u); wn = 0; t_w0 = t_next; }
                     }
                     if (!stop) {
                         const uint32_t t = t_next + lane;
@@ -335,21 +353,28 @@ struct KF {
                 if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
                     if (xn + 64u > kStreamCig) {
                         if (A_next > u_lo) stop = true;
-                        else xn = 0;
+                        else { inf_fill(S.cw, 0u, xn); xn = 0; }
                     }
                     if (!stop) {
                         const bool valid = s_next + lane < ncig;
                         const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
                         const uint32_t qinc = (valid && ((0x193u >> op) & 1u)) ? len : 0u;
                         const uint32_t rinc = (valid && ((0x18Du >> op) & 1u)) ? len : 0u;
-                        const uint32_t qs = wave_incl_scan(qinc), rs = wave_incl_scan(rinc);
+                        // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
+                        uint32_t qs, rs;
+                        if (!__ballot(valid && len >= 1024u)) {
+                            const uint32_t pk = wave_incl_scan(qinc | (rinc << 16));
+                            qs = pk & 0xFFFFu; rs = pk >> 16;
+                        } else {
+                            qs = wave_incl_scan(qinc); rs = wave_incl_scan(rinc);
+                        }
                         if (xn == 0) { A_base = A_next; B_base = B_next; }
                         const uint32_t dq = A_next + qs - qinc - A_base, dr = B_next + rs - rinc - B_base;
-                        const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan && dr < kStreamSpan));
+                        const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan - 1u && dr < kStreamSpan));
                         const uint32_t nvalid = min(64u, ncig - s_next);
                         if (nv == 0u) {   // the next op starts beyond what this window's words can say
                             if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
-                            else { xn = 0; stale = true; }
+                            else { inf_fill(S.cw, 0u, xn); xn = 0; stale = true; }
                         } else {
                             if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
                             xn += nv; s_next += nv;
@@ -410,13 +435,7 @@ struct KF {
         if (n1 > 0u) {
             // rank -> block: largest j with dw[j] <= rho (dw[0] <= rho_0 by construction)
             const bool act = lane < n1;
-            uint32_t lo = 0;
-            for (uint32_t nn = wn; nn > 1u;) {
-                const uint32_t half = nn >> 1;
-                lo = S.dw[lo + half] <= rho ? lo + half : lo;
-                nn -= half;
-            }
-            const uint32_t j = act ? lo : 0u;
+            const uint32_t j = act ? search_le<kStreamDir>(S.dw, rho) : 0u;
             const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
             const uint32_t t = t_w0 + j, blk = rev ? nblk - 1u - t : t;
             const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
@@ -444,14 +463,9 @@ struct KF {
             if (fm) {
                 // traversal position -> op: largest s with (query offset of op s) <= u
                 const uint32_t du = u - A_base;
-                const uint32_t target = ((du < kStreamSpan ? du : kStreamSpan - 1u) << 18) | 0x3FFFFu;
-                uint32_t xo = 0;
-                for (uint32_t nn = xn; nn > 1u;) {
-                    const uint32_t half = nn >> 1;
-                    xo = S.cw[xo + half] <= target ? xo + half : xo;
-                    nn -= half;
-                }
-                const uint32_t xw = S.cw[fin ? xo : 0u];
+                const uint32_t target = ((du < kStreamSpan - 1u ? du : kStreamSpan - 2u) << 18) | 0x3FFFFu;
+                const uint32_t xo = fin ? search_le<kStreamCig>(S.cw, target) : 0u;
+                const uint32_t xw = S.cw[xo];
                 const uint32_t op = xw & 15u, a_s = A_base + (xw >> 18), b_s = B_base + ((xw >> 4) & 0x3FFFu);
                 const bool call = fin && ((0x181u >> op) & 1u);
                 const uint32_t e = u - a_s;
@@ -463,7 +477,7 @@ struct KF {
 #else
                     w = 0xFFFFFFE0u | (code & 31u) | ((uint32_t)ref_pos & 0u);
 #endif
-                    st_look++;
+                    if (kStats) st_look++;
                 }
                 if (call) {
                     const uint32_t refcode = w & 31u;
@@ -479,7 +493,7 @@ struct KF {
                         const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
                         if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
                         const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
-                        st_ml++;
+                        if (kStats) st_ml++;
                         int is_mod;
                         if (mv >= t_hi) is_mod = 1;
                         else if (mv <= t_lo) is_mod = 0;
@@ -491,10 +505,10 @@ struct KF {
 #else
                             if (ref_pos == -12345 && is_mod) atomicAdd(cbm, 1ull);
 #endif
-                            st_dense++;
+                            if (kStats) st_dense++;
                         } else {
                             side_append(ref_pos, is_mod, ci);
-                            st_side++;
+                            if (kStats) st_side++;
                         }
                     }
                 }
@@ -504,11 +518,11 @@ struct KF {
                 const uint32_t xl = lane_valu(xo, fll);
                 if (xl > 0u) {
                     const uint32_t b0 = S.cw[xl] & ~15u, cnt = xn - xl;
-                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                    for (uint32_t c0 = 0; c0 < xn; c0 += 64u) {   // entries move down, the padding follows them
                         const uint32_t i = c0 + lane;
-                        const uint32_t v = i < cnt ? S.cw[xl + i] : 0u;
+                        const uint32_t v = i < cnt ? S.cw[xl + i] - b0 : kStreamInf;
                         wave_sync();
-                        if (i < cnt) S.cw[i] = v - b0;
+                        if (i < xn) S.cw[i] = v;
                         wave_sync();
                     }
                     A_base += b0 >> 18; B_base += (b0 >> 4) & 0x3FFFu;
@@ -519,12 +533,12 @@ struct KF {
                 // ... and the directory window from the block of the last token done
                 const uint32_t jl = lane_valu(j, (int)(n_done - 1u));
                 if (jl > 0u) {
-                    const uint32_t cnt = wn - jl + 1u;   // with the sentinel
-                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                    const uint32_t cnt = wn - jl + 1u;   // with the running total behind the last block
+                    for (uint32_t c0 = 0; c0 < wn + 1u; c0 += 64u) {   // entries move down, the padding follows them
                         const uint32_t i = c0 + lane;
-                        const uint32_t v = i < cnt ? S.dw[jl + i] : 0u;
+                        const uint32_t v = i < cnt ? S.dw[jl + i] : kStreamInf;
                         wave_sync();
-                        if (i < cnt) S.dw[i] = v;
+                        if (i < wn + 1u) S.dw[i] = v;
                         wave_sync();
                     }
                     t_w0 += jl; wn -= jl;
@@ -542,6 +556,7 @@ struct KF {
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
         t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
         xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
+        if (wanted) { inf_fill(S.dw, 0u, kStreamDir + 1u); inf_fill(S.cw, 0u, kStreamCig); }
         if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
         for (;;) {
@@ -559,7 +574,7 @@ struct KF {
     }
 
     // ------------------------------------------------------------------ one read: 0 done, 1 -> tile pipeline, 2 -> fused kernel
-    __device__ int run(int ridx) {
+    __device__ __forceinline__ int run(int ridx) {
         const uint32_t lane = (uint32_t)lane_id();
 #ifdef MM_STREAM_TIMING
         ft0 = __builtin_amdgcn_s_memrealtime();
@@ -763,13 +778,14 @@ struct KF {
     }
 };
 
-template <typename RefWord>
+// kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
+template <typename RefWord, bool kStats>
 __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const TileParams P) {
     __shared__ StreamLds lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
-    KF<RefWord> k(P, lds[threadIdx.x >> 6], ptab);
+    KF<RefWord, kStats> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
     // items costliest first; a wave's first item is fixed, the following ones are handed out by 64 padded counters (as in
@@ -789,7 +805,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
         }
         const int ridx = uni((int)scalar_load(P.stream_items + r_cur));
         const int st = uni(k.run(ridx));
-        if (p.stats && lane_id() == 0) atomicAdd(p.stats + 4 + st, 1ull);   // stats pass: reads done here / handed to the tiles / to the fused kernel
+        if (kStats && p.stats && lane_id() == 0) atomicAdd(p.stats + 4 + st, 1ull);   // stats pass: reads done here / handed to the tiles / to the fused kernel
         if (st == 1 && lane_id() == 0) {   // not this kernel's kind of read: one more item for k_scan_reads
             const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
             P.tile_items[at] = ridx;
@@ -800,7 +816,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
             if (P.host_fb_flag) *P.host_fb_flag = 1u;
         }
     }
-    if (p.stats) k.flush_stats((uint32_t)g & (kStatSlots - 1));
+    if (kStats && p.stats) k.flush_stats((uint32_t)g & (kStatSlots - 1));
 #ifdef MM_STREAM_TIMING
     if (p.stats && lane_id() == 0) for (int i = 0; i < 9; i++) atomicAdd(p.stats + 7 + i, k.ftacc[i]);
 #endif
