@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--region-mb", type=float, default=0.0, help="experiment: reads per GPU spread over this many Mb instead of the workload's "
                                                                   "interval (depth = reads * 15 kb / region: counter contention at depth)")
     ap.add_argument("--force-fused", action="store_true", help="experiment: the fused one-wavefront-per-read kernel for every read")
-    ap.add_argument("--no-stream", action="store_true", help="experiment: mm_freq_opts_t.no_stream (every read through the tile pipeline)")
+    ap.add_argument("--no-stream", action="store_true", help="experiment: mm_freq_opts_t.stream_mode = 1 (every read through the tile pipeline)")
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
     ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
                                                                "instead of the 24-contig genome")
@@ -416,7 +416,7 @@ def main():
     else:
         eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank,
                                      intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
-                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce, no_stream=args.no_stream,
+                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce, stream_mode=1 if args.no_stream else 0,
                                      **wl["eng"])
     # ---- make the reads resident in HBM (torch owns the memory: plumbing only): ONE read set -- the pools of all batches
     # end to end, as a decoder writing into device memory would leave them -- and a step's batch is a window of -K reads of

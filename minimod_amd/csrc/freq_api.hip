@@ -334,22 +334,22 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 const uint32_t split = h->opts.split_bases >= 1024 ? (uint32_t)h->opts.split_bases : kSplitBases;
                 const size_t max_items = (size_t)b->n_reads + 2 * (size_t)b->n_seq_bytes / split + 64;
                 if ((r = grow(h, (void**)&s.d_plan, &s.cap_plan, 4 * max_items))) return r;
-                // plain freq runs: reads that are one work item go to k_stream_reads (which hands back what it does not do)
-                stream = !h->opts.no_stream && !p.view && !p.insertions && !p.haplotypes;
+                // plain freq runs: k_stream_reads takes the reads it can hide in the launch (and hands back what it does not do).
+                // A read is one wavefront's work from start to end there, so the longest one bounds the launch from below: a
+                // read takes a wavefront about 7000 times longer per base than a full launch takes per base (measured on
+                // MI355X, gathered launches of 4 to 32 batches).  The launch's bases are not known here for device batches --
+                // windows of a resident set share pool sizes -- so its reads are taken as 12 kb each; a launch too small to
+                // hide reads of `split` bases (a single -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
+                const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 7350;
+                const int mode = h->opts.stream_mode;
+                stream = mode != 1 && !p.view && !p.insertions && !p.haplotypes && (mode == 2 || hide >= split);
+                const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
                 if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
                 if (!s.d_plan_state) {
                     if (dev_alloc(h, (void**)&s.d_plan_state, sizeof(PlanState))) return -MM_E_NOMEM;
                     HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
                 }
                 const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
-                // A read is one wavefront's work from start to end there, so the longest one bounds the launch from below:
-                // reads of up to `split` bases always go, longer ones when the launch is big enough to hide them (a read
-                // takes a wavefront about 7000 times longer per base than the launch takes per base: measured on MI355X,
-                // gathered launches of 4 to 32 batches)
-                // (the launch's bases are not known here for device batches -- windows of a resident set share pool sizes -- so
-                // its reads are taken as 12 kb each: short-read data never gets past `split` anyway)
-                const uint64_t launch_bases = 12000ull * (uint64_t)b->n_reads;
-                const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, launch_bases / 7350), 0x00FFFFFFu);
                 hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
                                    s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? stream_max : 0u, s.d_plan_stream, ctl + 7);
                 p.order = s.d_plan;

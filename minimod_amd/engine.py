@@ -44,7 +44,7 @@ class mm_freq_opts_t(ctypes.Structure):
                 ("haplotypes", ctypes.c_int32), ("device", ctypes.c_int32), ("n_hp_planes", ctypes.c_int32),
                 ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
                 ("force_fused", ctypes.c_int32), ("view_cap", ctypes.c_int32), ("finalize_by_runs", ctypes.c_int32),
-                ("split_bases", ctypes.c_int32), ("coalesce", ctypes.c_int32), ("no_stream", ctypes.c_int32),
+                ("split_bases", ctypes.c_int32), ("coalesce", ctypes.c_int32), ("stream_mode", ctypes.c_int32),
                 ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
@@ -193,7 +193,7 @@ class FreqEngine(object):
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
                  n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False, force_fused=False, view_cap=0,
-                 finalize_by_runs=False, split_bases=0, coalesce=0, no_stream=False):
+                 finalize_by_runs=False, split_bases=0, coalesce=0, stream_mode=0):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -204,7 +204,7 @@ class FreqEngine(object):
         o.view = int(view)
         o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
         o.split_bases, o.coalesce = int(split_bases), int(coalesce)
-        o.no_stream = 1 if no_stream else 0
+        o.stream_mode = int(stream_mode)   # 0 by launch size, 1 never, 2 always (reads up to split_bases)
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
             o.mods[i].context = ctx.encode()

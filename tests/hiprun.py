@@ -15,6 +15,10 @@ def to_oracle_rows(rows):
 def make_engine(mods, th, target_names, target_lens, contigs, **kw):
     import minimod_amd
     ctg = [(n, l, contigs.get(n)) for n, l in zip(target_names, target_lens)]
+    # the parity tests' batches are far smaller than what the default lets k_stream_reads have: send it every read it can take,
+    # so that the goldens, the KATs and the error cases go through it as well (the tile pipeline still gets what it hands
+    # on, everything with --insertions / --haplotypes / view, and the stream_mode=1 runs)
+    kw.setdefault("stream_mode", 2)
     return minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], ctg, **kw)
 
 

@@ -18,7 +18,7 @@ WORKER = r'''
 import json, sys
 sys.path.insert(0, %r)
 FUSED = bool(%d)
-NOSTREAM = bool(%d)
+STREAM_MODE = %d
 import numpy as np
 import minimod_amd
 from minimod_amd import synth
@@ -38,7 +38,7 @@ cases = {
 for name, cs in cases.items():
     g = dict(cs["gen"]); n = g.pop("n")
     b = synth.batch(ref, 0, n, seed=77, n_reads_total=n, **g)
-    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], force_fused=FUSED, no_stream=NOSTREAM, **cs["kw"])
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], force_fused=FUSED, stream_mode=STREAM_MODE, **cs["kw"])
     eng.process(b)
     got = eng.finalize(); eng.close()
     orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
@@ -56,9 +56,9 @@ print(json.dumps(out))
 '''
 
 
-@pytest.mark.parametrize("fused,no_stream", [(0, 0), (0, 1), (1, 0)], ids=["stream+tiles", "tiles", "fused"])
-def test_synthetic_shapes_match_oracle(fused, no_stream):
-    r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, fused, no_stream)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+@pytest.mark.parametrize("fused,stream_mode", [(0, 2), (0, 1), (1, 1)], ids=["stream+tiles", "tiles", "fused"])
+def test_synthetic_shapes_match_oracle(fused, stream_mode):
+    r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, fused, stream_mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long", "hifi_q_multimod"}

@@ -3,7 +3,7 @@ sliding windows.  These cases aim at what the windows must survive -- sparse lis
 window, lists denser than the blocks, CIGARs with more ops than the window holds, deletions / introns / insertions longer
 than the 14-bit offsets of the packed words, reads whose CIGAR is shorter than the sequence -- in both orientations, with
 the routing checked through the statistics pass (reads done by the kernel / handed to the tile pipeline / to the fused
-kernel).  HIP vs the oracle, bit-exact; the same input through the tile pipeline alone (no_stream) as a second witness."""
+kernel).  HIP vs the oracle, bit-exact; the same input through the tile pipeline alone (stream_mode 1) as a second witness."""
 import numpy as np
 import pytest
 
@@ -39,6 +39,7 @@ def oracle_rows(recs, ref, c, th=None):
 def hip_rows(recs, ref, c, th=None, **kw):
     """rows and the routing statistics of one batch"""
     mods = O.parse_mod_codes(c)
+    kw.setdefault("stream_mode", 2)   # these batches are far too small for the default to stream anything
     eng = make_engine(mods, O.parse_mod_threshes(th, len(mods)), ["chrT"], [len(ref)], {"chrT": ref.encode()}, **kw)
     eng.stats_enable(True)
     eng.process(pybam.flatten(recs))
@@ -69,7 +70,7 @@ def both_ways(recs, ref, c, th=None, expect_stream=None):
     want = oracle_rows(recs, ref, c, th)
     got, st = hip_rows(recs, ref, c, th)
     assert got == want
-    got2, st2 = hip_rows(recs, ref, c, th, no_stream=True)
+    got2, st2 = hip_rows(recs, ref, c, th, stream_mode=1)
     assert got2 == want
     assert st2["stream_done"] == 0 and st2["stream_to_tiles"] == 0
     if expect_stream is not None:
@@ -201,7 +202,7 @@ def test_errors_after_the_first_counts_go_to_the_fused_kernel():
         with pytest.raises(O.OracleError) as oe:
             o.process(pybam.flatten([good, rec, good]))
         o.close()
-        eng = make_engine(O.parse_mod_codes("m[*]"), [0.8], ["chrT"], [len(ref)], {"chrT": ref.encode()})
+        eng = make_engine(O.parse_mod_codes("m[*]"), [0.8], ["chrT"], [len(ref)], {"chrT": ref.encode()}, stream_mode=2)
         with pytest.raises(minimod_amd.MinimodHipError) as he:
             eng.process(pybam.flatten([good, rec, good]))
         eng.close()
@@ -219,7 +220,7 @@ def test_synthetic_reads_are_streamed():
                           (dict(n=300, max_len=0.0), [("h", "CG")], [0.6])):
         g = dict(gen); n = g.pop("n")
         b = synth.batch(ref, 0, n, seed=91, n_reads_total=n, **g)
-        eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)])
+        eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], stream_mode=2)
         eng.stats_enable(True)
         eng.process(b)
         st = eng.stats_get()

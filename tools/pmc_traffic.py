@@ -4,7 +4,7 @@ tools/profile_round.sh): the LAST dispatch of every hot-path kernel is the timed
 --steps batches gathered into one launch); counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section)
 prescribes for gfx950.  usage: pmc_traffic.py FETCH.csv WRITE.csv <batches in the timed launch> <algorithmic bytes per batch> > profiles/traffic_c2.json"""
 import csv, json, sys
-KERNELS = ("k_plan_items", "k_scan_reads", "k_sum_tiles", "k_call_tiles")
+KERNELS = ("k_plan_items", "k_stream_reads", "k_scan_reads", "k_sum_tiles", "k_call_tiles")
 def last(path):
     out = {}
     for r in csv.DictReader(open(path)):
@@ -16,10 +16,10 @@ f, w = last(sys.argv[1]), last(sys.argv[2])
 nb, alg = int(sys.argv[3]), float(sys.argv[4])
 per_launch = sum(2 * f[k] + w[k] for k in KERNELS) * 1024
 print(json.dumps({
-    "what": "HBM traffic of the freq hot path (k_plan_items + k_scan_reads + k_sum_tiles + k_call_tiles), workload C2, one launch of %d gathered -K 4096 batches" % nb,
+    "what": "HBM traffic of the freq hot path (k_plan_items + k_stream_reads + k_scan_reads + k_sum_tiles + k_call_tiles), workload C2, one launch of %d gathered -K 4096 batches" % nb,
     "how": "two separate rocprofv3 passes, `--kernel-trace --pmc FETCH_SIZE` and `--kernel-trace --pmc WRITE_SIZE` (never combined, no sys/hip trace), on "
            "`python3 bench.py --steps %d --warmup 0 --no-cpu-baseline --no-e2e --no-extra`; counters are in KB; per MI355X_MICROARCH.md (HBM section) "
-           "FETCH_SIZE on gfx950 reports half of the bytes fetched, so it is doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024" % nb,
+           "FETCH_SIZE on gfx950 reports half of the bytes fetched, so it is doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (checked on this access mix with tools/fetch_calib.hip: FETCH_SIZE = half of 128 B per line touched for 16-, 4- and 1-byte streaming loads and for 16- and 2-byte gathers alike; WRITE_SIZE exact for stores, 32 B per scattered 64-bit atomic)" % nb,
     "raw_kb_per_launch": {k: {"FETCH_SIZE": f[k], "WRITE_SIZE": w[k]} for k in KERNELS},
     "batches_per_launch": nb,
     "hbm_bytes_per_launch": per_launch,

@@ -27,6 +27,17 @@ timeout 300 $B --mode view --steps 20 --warmup 5 > $out/view_bench.json 2> $out/
 # uncoalesced single launches, for comparison with round 1
 timeout 300 $B --steps 20 --warmup 5 --coalesce 1 --no-e2e --no-cpu-baseline > $out/freq_bench_coalesce1.json 2>/dev/null
 rm -rf $out/ks $out/ks_C3 $out/ks_C5 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+# what FETCH_SIZE / WRITE_SIZE mean for the kernels' access shapes (tools/fetch_calib.hip)
+if [ -x $root/tools/bin/fetch_calib ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/cal_$c -o calib -- $root/tools/bin/fetch_calib > $out/fetch_calib_asked.csv 2>/dev/null
+    cp $out/cal_$c/calib_counter_collection.csv $out/fetch_calib_$c.csv 2>/dev/null
+    rm -rf $out/cal_$c
+  done
+fi
+# the tile pipeline alone, for comparison
+timeout 300 $B --steps 20 --warmup 5 --no-stream --no-e2e --no-cpu-baseline > $out/freq_bench_no_stream.json 2>/dev/null
+timeout 300 $B --config C3 --steps 20 --warmup 5 --no-stream --no-e2e --no-cpu-baseline > $out/C3_bench_no_stream.json 2>/dev/null
 ls -la $out
 for f in $out/*_bench*.json; do echo "== $f"; python3 -c "
 import json,sys
