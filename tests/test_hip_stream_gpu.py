@@ -235,3 +235,57 @@ def test_synthetic_reads_are_streamed():
         assert st["stream_done"] == int((short & ~dots).sum()), st
         assert st["stream_to_tiles"] == int((short & dots).sum()), st
         assert st["stream_to_fused"] == 0
+
+
+def _random_read(rng, ref, flag):
+    """a read with a random CIGAR (M = X I D N, soft clips at the ends, now and then a very long D / N / I) and one to three
+    groups on C with random skip lists"""
+    n_ops = int(rng.integers(1, 60))
+    pos = int(rng.integers(0, 2000))
+    rp, ops, seq = pos, [], []
+    if rng.random() < 0.4:
+        l = int(rng.integers(1, 300)); ops.append("%dS" % l); seq.append(make_ref(rng, l))
+    for i in range(n_ops):
+        l = int(rng.geometric(0.02)) if rng.random() < 0.8 else int(rng.integers(200, 3000))
+        if rp + l >= len(ref) - 40000:
+            break
+        kind = "M" if i == 0 or i == n_ops - 1 else str(rng.choice(list("MMMM=XIDN")))
+        if kind in "M=X":
+            seq.append(ref[rp:rp + l]); rp += l
+        elif kind == "I":
+            l = l if rng.random() < 0.95 else int(rng.integers(16000, 20000))
+            seq.append(make_ref(rng, l))
+        else:
+            l = l if rng.random() < 0.9 else int(rng.integers(16000, 35000))
+            rp += l
+        ops.append("%d%s" % (l, kind))
+    if ops[-1][-1] in "IDN":
+        ops.append("7M"); seq.append(ref[rp:rp + 7]); rp += 7
+    if rng.random() < 0.4:
+        l = int(rng.integers(1, 300)); ops.append("%dS" % l); seq.append(make_ref(rng, l))
+    seq = "".join(seq)
+    orig = revcomp(seq) if flag else seq
+    n_c = orig.count("C")
+    mm, ml = "", []
+    for code in rng.permutation(["m", "h", "x"])[:int(rng.integers(1, 4))]:
+        dens = float(rng.choice([0.02, 0.2, 0.7, 1.0]))
+        picks = [k for k in range(n_c) if rng.random() < dens]
+        if rng.random() < 0.15:
+            picks = picks[:3]
+        toks, prev = [], -1
+        for k in picks:
+            toks.append(str(k - prev - 1).zfill(int(rng.integers(1, 4)) if rng.random() < 0.1 else 1)); prev = k
+        mm += "C+%s?" % code + "".join("," + t for t in toks) + ";"
+        ml += [int(x) for x in rng.integers(0, 256, size=len(toks))]
+    return pybam.make_record(0, pos, flag, seq, "".join(ops), mm, ml)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_reads_against_the_oracle(seed):
+    rng = np.random.default_rng(700 + seed)
+    ref = make_ref(rng, 400000)
+    recs = [_random_read(rng, ref, 16 if rng.random() < 0.5 else 0) for _ in range(120)]
+    for c in ("m,h", "m[*],h[*]", "h[CG]"):
+        st = both_ways(recs, ref, c)
+        short = sum(1 for r in recs if r.l_qseq <= 24576)   # (a read with one of the long insertions can be longer: the tile pipeline's)
+        assert st["stream_done"] == short and st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0, st
