@@ -578,8 +578,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config.lower())
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; not measured in this run)" % os.path.basename(tpath)
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_batch") * args.steps / len(kms)   # per launch, like `achieved`
+                traffic_src = ("profiles/%s: bytes per batch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (not measured "
+                               "in this run), times this run's batches per launch" % os.path.basename(tpath))
             except Exception:
                 traffic = None
         reads_all = np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches])
