@@ -85,17 +85,24 @@ struct StreamLds {
     uint32_t memo_flags[kStreamMemo], memo_c01[kStreamMemo], memo_c23[kStreamMemo], memo_ci[kStreamMemo][4];
 };
 
-// class members among the 32 bases of block b (KA::block_count)
-__device__ __forceinline__ uint32_t stream_block_count(uint4 v, int cls, uint32_t b, uint32_t L) {
-    if (cls == 0) {
-        int valid = (int)min(32u, L - b * 32u);
-        uint32_t o = __popc(nib_eq(v.x, 2) | nib_eq(v.x, 4) | nib_eq(v.x, 8) | nib_eq(v.x, 15)) +
-                     __popc(nib_eq(v.y, 2) | nib_eq(v.y, 4) | nib_eq(v.y, 8) | nib_eq(v.y, 15)) +
-                     __popc(nib_eq(v.z, 2) | nib_eq(v.z, 4) | nib_eq(v.z, 8) | nib_eq(v.z, 15)) +
-                     __popc(nib_eq(v.w, 2) | nib_eq(v.w, 4) | nib_eq(v.w, 8) | nib_eq(v.w, 15));
-        return (uint32_t)valid - o;
+// The read's base class as a nibble pattern (C 2, G 4, T 8, N 15 in every nibble; 0 for the fifth class: whatever is none of
+// those), made once per read: the match bits of a word are then five instructions and no branch on the class.
+__device__ __forceinline__ uint32_t class_pattern(int cls) {
+    return cls == 1 ? 0x22222222u : (cls == 2 ? 0x44444444u : (cls == 3 ? 0x88888888u : (cls == 4 ? 0xFFFFFFFFu : 0u)));
+}
+// bit 4n+3 set iff nibble n of x equals the pattern's nibble (pat != 0), or is none of 2, 4, 8, 15 (pat == 0)
+__device__ __forceinline__ uint32_t pattern_bits(uint32_t x, uint32_t pat) {
+    if (pat != 0u) {
+        const uint32_t y = x ^ pat;
+        return ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
     }
-    return __popc(class_bits(v.x, cls)) + __popc(class_bits(v.y, cls)) + __popc(class_bits(v.z, cls)) + __popc(class_bits(v.w, cls));
+    return 0x88888888u & ~(nib_eq(x, 2) | nib_eq(x, 4) | nib_eq(x, 8) | nib_eq(x, 15));
+}
+// class members among the 32 bases of block b (KA::block_count)
+__device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, uint32_t b, uint32_t L) {
+    uint32_t c = __popc(pattern_bits(v.x, pat)) + __popc(pattern_bits(v.y, pat)) + __popc(pattern_bits(v.z, pat)) + __popc(pattern_bits(v.w, pat));
+    if (pat == 0u) c -= 32u - min(32u, L - b * 32u);   // the padding behind the read's last base is none of C, G, T, N either
+    return c;
 }
 // number of set bits below the lowest clear one (64 when all are set)
 __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint32_t)__ffsll((unsigned long long)~m) - 1u : 64u; }
@@ -130,13 +137,14 @@ struct KF {
     const uint4* sq;
     const uint32_t* cg;
     const RefWord* rwb;
-    int64_t ref_base;
-    uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32;
-    int32_t tid, pos, rev, cls;
+    uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32, cpat;
+    int32_t pos, rev, ridx_cur;
     // the group
-    int32_t ncg, gc0, gc1, gc2, gc3;
+    int32_t ncg;
+    uint32_t gc01, gc23;        // the group's codes, two 16-bit indices a word (0xFFFF: not requested)
     uint32_t ci0, ci1, ci2, ci3;
-    unsigned long long *cb0, *cb1, *cb2, *cb3;
+    unsigned long long* cnt0;   // the read's strand-0... counters of plane 0 of its contig, shifted so that the index is the reference position;
+                                // null when the contig has no dense counters.  A code's counters: + (plane * 2 + rev) * plane_len
     uint32_t ml_start;
     // text cursor and token ring
     uint32_t cpos, nx_w0, nx_w1, qhead, qn, kdone, Rcarry, ntok_parsed;
@@ -155,9 +163,8 @@ struct KF {
     __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
         : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0) {}
 
-    __device__ __forceinline__ int gcode_at(int m) const { return m == 0 ? gc0 : (m == 1 ? gc1 : (m == 2 ? gc2 : gc3)); }
+    __device__ __forceinline__ int gcode_at(int m) const { return (int)(int16_t)(((m < 2 ? gc01 : gc23) >> (16 * (m & 1))) & 0xFFFFu); }
     __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
-    __device__ __forceinline__ unsigned long long* cbase_at(int m) const { return m == 0 ? cb0 : (m == 1 ? cb1 : (m == 2 ? cb2 : cb3)); }
 
     // ------------------------------------------------------------------ text -> ranks
     __device__ __forceinline__ void fetch_chunk(uint32_t c) {
@@ -187,14 +194,14 @@ struct KF {
 #pragma unroll
         for (int sc = 0; sc < kSub; sc++) x[sc] = mb8[64 * sc + lane];
         const uint32_t x4 = mb8[kStreamChunk + (lane & 15)];
-        uint64_t D[kSub + 1], Sm[kSub];
-#pragma unroll
-        for (int sc = 0; sc < kSub; sc++) {
-            Sm[sc] = __ballot(x[sc] == ';');
-            D[sc] = Sm[sc] | __ballot(x[sc] == ',');
-        }
-        D[kSub] = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;
-        if (skip) D[0] |= 1ull << (skip - 1u);   // the list's first character follows the header as if it followed a delimiter
+        // delimiter bitmaps of the sub-chunk at hand and of the one behind it only (all five at once cost eighteen scalar
+        // registers the kernel does not have)
+        const uint64_t D_look = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;
+        uint64_t Sm_cur = __ballot(x[0] == ';');
+        uint64_t D_cur = Sm_cur | __ballot(x[0] == ',');
+        if (skip) D_cur |= 1ull << (skip - 1u);   // the list's first character follows the header as if it followed a delimiter
+        uint64_t pd = prev_delim ? 1ull : 0ull;    // is the character in front of the sub-chunk a delimiter
+        uint64_t D_last = 0;                        // the last sub-chunk's bitmap, for the look-ahead
         const uint32_t qtail = qhead + qn;
         uint32_t nends = 0, rsum_v = 0;
         uint64_t bad = 0;
@@ -202,12 +209,13 @@ struct KF {
 #pragma unroll
         for (int sc = 0; sc < kSub; sc++) {
             if (cl) break;
+            uint64_t Sm_next = 0, D_next = D_look;
+            if (sc + 1 < kSub) { Sm_next = __ballot(x[sc + 1 < kSub ? sc + 1 : 0] == ';'); D_next = Sm_next | __ballot(x[sc + 1 < kSub ? sc + 1 : 0] == ','); }
             int lo = 0, hi = 64;
-            if (Sm[sc]) { hi = __ffsll((unsigned long long)Sm[sc]) - 1; cl = true; }
-            if (sc == 0 && !prev_delim) lo = D[0] ? __ffsll((unsigned long long)D[0]) - 1 : 64;
+            if (Sm_cur) { hi = __ffsll((unsigned long long)Sm_cur) - 1; cl = true; }
+            if (sc == 0 && !prev_delim) lo = D_cur ? __ffsll((unsigned long long)D_cur) - 1 : 64;
             if (sc == 0 && skip) lo = (int)skip;
-            const uint64_t pd = sc == 0 ? (prev_delim ? 1ull : 0ull) : (D[sc > 0 ? sc - 1 : 0] >> 63);
-            const uint32_t w = window32((D[sc] << 1) | pd, (D[sc + 1] << 1) | (D[sc] >> 63), lane);
+            const uint32_t w = window32((D_cur << 1) | pd, (D_next << 1) | (D_cur >> 63), lane);
             const bool own = (uint32_t)(lane - lo) < (uint32_t)(hi - lo) && lo < hi;
             const bool start = own && (w & 3u) == 1u;
             const bool end = own && (w & 6u) == 4u;
@@ -223,11 +231,14 @@ struct KF {
             bad |= __ballot(own && !(w & 2u) && dv > 9u) | __ballot(start && e >= 10u);
             rsum_v += lane_valu(run, 63);
             nends += (uint32_t)__popcll(eb);
-            if (sc == kSub - 1 && !cl) open_tail = ((D[kSub - 1] >> 63) == 0) && ((D[kSub] & 1ull) == 0);
+            if (sc == kSub - 1 && !cl) open_tail = ((D_cur >> 63) == 0) && ((D_look & 1ull) == 0);
+            D_last = D_cur;
+            pd = D_cur >> 63; D_cur = D_next; Sm_cur = Sm_next;
         }
+        (void)D_last;
         uint32_t ntok = nends;
         if (open_tail) {
-            const int k = __ffsll((unsigned long long)D[kSub]) - 1;   // 1..16
+            const int k = __ffsll((unsigned long long)D_look) - 1;   // 1..16
             const uint32_t dv = x4 - (uint32_t)'0';
             uint32_t e = (uint32_t)(k - lane);
             e = e < 10u ? e : 10u;
@@ -275,7 +286,7 @@ struct KF {
                     if (!stop) {
                         const uint32_t t = t_next + lane;
                         const bool valid = t < nblk;
-                        const uint32_t cnt = valid ? stream_block_count(vv[r], cls, rev ? nblk - 1u - t : t, L) : 0u;
+                        const uint32_t cnt = valid ? stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L) : 0u;
                         const uint32_t incl = wave_incl_scan(cnt);
                         if (valid) S.dw[wn + lane] = S_next + incl - cnt;
                         const uint32_t nv = min(64u, nblk - t_next);
@@ -297,15 +308,15 @@ struct KF {
 #pragma unroll
             for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; vv[u] = b < nblk ? sq[b] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; if (b < nblk) sum += stream_block_count(vv[u], cls, b, L); }
+            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; if (b < nblk) sum += stream_block_count(vv[u], cpat, b, L); }
         }
         return lane_valu(wave_incl_scan(sum), 63);
     }
     // k-th (from the block's start) member of the class among the 32 bases of block blk -> read position and base code
     __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
         // match bits per word in BAM's nibble order (counts do not care), masked to the read's bases for the "other" class
-        uint32_t m0 = class_bits(v.x, cls), m1 = class_bits(v.y, cls), m2 = class_bits(v.z, cls), m3 = class_bits(v.w, cls);
-        if (cls == 0) {
+        uint32_t m0 = pattern_bits(v.x, cpat), m1 = pattern_bits(v.y, cpat), m2 = pattern_bits(v.z, cpat), m3 = pattern_bits(v.w, cpat);
+        if (cpat == 0u) {
             const int valid = (int)min(32u, L - blk * 32u);
             // base_order maps base n to nibble n; its inverse is itself
             m0 &= base_order(valid_bits(valid)); m1 &= base_order(valid_bits(valid - 8));
@@ -390,6 +401,9 @@ struct KF {
     }
 
     __device__ __forceinline__ void side_append(int32_t spos, int is_mod, int code) {
+        // (the rare path: what it needs of the read is fetched again rather than kept in registers)
+        const int tid = p.reads[ridx_cur].tid;
+        const int64_t ref_base = p.ref_base[tid];
         unsigned long long key;
         if (side_key(ref_base + spos, rev, code, 0u, -1, key)) {
             if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
@@ -498,8 +512,9 @@ struct KF {
                         if (mv >= t_hi) is_mod = 1;
                         else if (mv <= t_lo) is_mod = 0;
                         else continue;
-                        unsigned long long* const cbm = cbase_at(m);
-                        if (cbm != nullptr && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
+                        const int plane = (int)((cinfo >> 23) & 127u) - 1;
+                        unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
+                        if (cnt0 != nullptr && plane >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
 #ifndef MM_ABL_NOATOMIC
                             atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
 #else
@@ -581,7 +596,8 @@ struct KF {
 #endif
         const mm_read_t rd = scalar_load(p.reads + ridx);
         err = 0;
-        tid = uni(rd.tid); pos = uni(rd.pos);
+        const int tid = uni(rd.tid);
+        pos = uni(rd.pos); ridx_cur = ridx;
         L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); mlen = uniu(rd.mm_len); ml_len = uniu(rd.ml_len);
         rev = (uni(rd.flag) & 0x10) ? 1 : 0;
         mm = p.mm + rd.mm_off; ml = p.ml + rd.ml_off;
@@ -600,7 +616,7 @@ struct KF {
         fetch_chunk(0u);
         const bool tid_ok = tid >= 0 && tid < p.n_contigs;
         const int tid_c = tid_ok ? tid : 0;
-        ref_base = scalar_load(p.ref_base + tid_c);
+        const int64_t ref_base = scalar_load(p.ref_base + tid_c);
         const int64_t ctg_len = scalar_load(p.ctg_len + tid_c);
         const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c), cnt_base = scalar_load(p.cnt_base + tid_c);
         int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
@@ -725,13 +741,14 @@ struct KF {
                     mpos = endp + 1u;
                 }
             }
-            cls = first_cls;
+            cpat = class_pattern(first_cls);
             wave_sync();
         }
         KFT_LAP(1);
         if (st == 0 && ngrp > 0u) {
             seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
             rwb = reinterpret_cast<const RefWord*>(p.refw) + ref_base;
+            cnt0 = seg_len > 0 ? p.counters + cnt_base - seg_begin : nullptr;
             ml_start = 0;
             uint32_t nb_all = 0;
             bool have_nb = false;
@@ -740,17 +757,8 @@ struct KF {
                 ncg = (int)((gflags >> 12) & 7u);
                 const bool wanted = !(gflags & 64u);
                 if (wanted) {
-                    gc0 = (int16_t)(c01 & 0xFFFFu); gc1 = (int16_t)(c01 >> 16); gc2 = (int16_t)(c23 & 0xFFFFu); gc3 = (int16_t)(c23 >> 16);
+                    gc01 = c01; gc23 = c23;
                     ci0 = uniu(S.g_ci[gi][0]); ci1 = uniu(S.g_ci[gi][1]); ci2 = uniu(S.g_ci[gi][2]); ci3 = uniu(S.g_ci[gi][3]);
-                    unsigned long long* cb[4];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const uint32_t ci_m = m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3));
-                        const int plane = (int)((ci_m >> 23) & 127u) - 1;
-                        cb[m] = nullptr;
-                        if (plane >= 0 && seg_len > 0) cb[m] = p.counters + ((int64_t)plane * 2 + rev) * p.plane_len + cnt_base - seg_begin;
-                    }
-                    cb0 = cb[0]; cb1 = cb[1]; cb2 = cb[2]; cb3 = cb[3];
                 }
                 uint32_t ntok = 0;
                 KFT_LAP(8);
