@@ -90,17 +90,25 @@ struct StreamLds {
 __device__ __forceinline__ uint32_t class_pattern(int cls) {
     return cls == 1 ? 0x22222222u : (cls == 2 ? 0x44444444u : (cls == 3 ? 0x88888888u : (cls == 4 ? 0xFFFFFFFFu : 0u)));
 }
-// bit 4n+3 set iff nibble n of x equals the pattern's nibble (pat != 0), or is none of 2, 4, 8, 15 (pat == 0)
-__device__ __forceinline__ uint32_t pattern_bits(uint32_t x, uint32_t pat) {
-    if (pat != 0u) {
-        const uint32_t y = x ^ pat;
-        return ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
-    }
+// bit 4n+3 set iff nibble n of x equals the pattern's nibble
+__device__ __forceinline__ uint32_t pattern_eq(uint32_t x, uint32_t pat) {
+    const uint32_t y = x ^ pat;
+    return ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+}
+// ... or, for the fifth class, is none of 2, 4, 8, 15
+__device__ __forceinline__ uint32_t pattern_other(uint32_t x) {
     return 0x88888888u & ~(nib_eq(x, 2) | nib_eq(x, 4) | nib_eq(x, 8) | nib_eq(x, 15));
+}
+// the match bits of a block's four words (one branch on the class for the block, none per word)
+__device__ __forceinline__ void block_bits(uint4 v, uint32_t pat, uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3) {
+    if (pat != 0u) { m0 = pattern_eq(v.x, pat); m1 = pattern_eq(v.y, pat); m2 = pattern_eq(v.z, pat); m3 = pattern_eq(v.w, pat); }
+    else { m0 = pattern_other(v.x); m1 = pattern_other(v.y); m2 = pattern_other(v.z); m3 = pattern_other(v.w); }
 }
 // class members among the 32 bases of block b (KA::block_count)
 __device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, uint32_t b, uint32_t L) {
-    uint32_t c = __popc(pattern_bits(v.x, pat)) + __popc(pattern_bits(v.y, pat)) + __popc(pattern_bits(v.z, pat)) + __popc(pattern_bits(v.w, pat));
+    uint32_t m0, m1, m2, m3;
+    block_bits(v, pat, m0, m1, m2, m3);
+    uint32_t c = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
     if (pat == 0u) c -= 32u - min(32u, L - b * 32u);   // the padding behind the read's last base is none of C, G, T, N either
     return c;
 }
@@ -286,7 +294,8 @@ struct KF {
                     if (!stop) {
                         const uint32_t t = t_next + lane;
                         const bool valid = t < nblk;
-                        const uint32_t cnt = valid ? stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L) : 0u;
+                        uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);   // (steps past the read's end were loaded as zeros)
+                        cnt = valid ? cnt : 0u;
                         const uint32_t incl = wave_incl_scan(cnt);
                         if (valid) S.dw[wn + lane] = S_next + incl - cnt;
                         const uint32_t nv = min(64u, nblk - t_next);
@@ -315,7 +324,8 @@ struct KF {
     // k-th (from the block's start) member of the class among the 32 bases of block blk -> read position and base code
     __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
         // match bits per word in BAM's nibble order (counts do not care), masked to the read's bases for the "other" class
-        uint32_t m0 = pattern_bits(v.x, cpat), m1 = pattern_bits(v.y, cpat), m2 = pattern_bits(v.z, cpat), m3 = pattern_bits(v.w, cpat);
+        uint32_t m0, m1, m2, m3;
+        block_bits(v, cpat, m0, m1, m2, m3);
         if (cpat == 0u) {
             const int valid = (int)min(32u, L - blk * 32u);
             // base_order maps base n to nibble n; its inverse is itself
