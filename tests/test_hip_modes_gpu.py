@@ -182,6 +182,7 @@ def test_deep_region_haplotypes_insertions():
 SHARD_WORKER = r'''
 import json, sys
 sys.path.insert(0, %r)
+STREAM_MODE = %d
 import torch
 torch.zeros(1, device="cuda")   # torch's HIP runtime comes up before the library's (as in bench.py)
 import minimod_amd
@@ -197,7 +198,7 @@ batches = [synth.batch(ref, 0, 900, seed=11 + 7919 * r, contig_len=plans[r]["con
 engs = []
 for r in range(2):
     e = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", plans[r]["contig_len"], ref)],
-                               intervals=[(0, plans[r]["begin"], plans[r]["end"], plans[r]["halo"])])
+                               intervals=[(0, plans[r]["begin"], plans[r]["end"], plans[r]["halo"])], stream_mode=STREAM_MODE)
     e.process(batches[r])
     engs.append(e)
 words = engs[0].slab_words(halo)
@@ -221,11 +222,12 @@ print(json.dumps({"crossed": crossed, "rows": len(want), "equal": sorted(got) ==
 '''
 
 
-def test_interval_sharding_with_halo_slabs_on_device():
+@pytest.mark.parametrize("stream_mode", [2, 1], ids=["stream", "tiles"])
+def test_interval_sharding_with_halo_slabs_on_device(stream_mode):
     """Two handles own neighbouring intervals of one contig (as two ranks would); the left one's halo slab is exported,
     cleared, and added into the right one's planes with the library's slab kernels; the union equals the unsharded
-    oracle bit for bit."""
-    r = subprocess.run([sys.executable, "-c", SHARD_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    oracle bit for bit.  (Calls past a shard's planes go to the side table from either kernel.)"""
+    r = subprocess.run([sys.executable, "-c", SHARD_WORKER % (ROOT, stream_mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["crossed"] > 0 and res["rows"] > 1000 and res["equal"], res
@@ -234,6 +236,7 @@ def test_interval_sharding_with_halo_slabs_on_device():
 COALESCE_WORKER = r'''
 import json, sys
 sys.path.insert(0, %r)
+STREAM_MODE = %d
 import numpy as np
 import torch
 torch.zeros(1, device="cuda")
@@ -254,7 +257,7 @@ want = orc.rows()
 key = lambda r, io: list(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
 out = {}
 for name, coalesce, order in (("off", 0, range(7)), ("groups_of_3", 3, range(7)), ("one_group", 16, range(7)), ("broken_runs", 4, [0, 1, 3, 4, 5, 2, 6])):
-    eng = minimod_amd.FreqEngine([("m", "CG", 0.8), ("h", "CG", 0.7)], [("chrS", len(ref), ref)], coalesce=coalesce)
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8), ("h", "CG", 0.7)], [("chrS", len(ref), ref)], coalesce=coalesce, stream_mode=STREAM_MODE)
     tickets = [eng.submit_device(window(i)) for i in order]
     sizes = {}
     for t in tickets: sizes[t] = eng.ticket_batches(t)
@@ -271,7 +274,7 @@ def window2(i):
     return dict(reads=dev2["reads"].data_ptr() + 64 * 300 * i, cigar=dev2["cigar"].data_ptr(), seq=dev2["seq"].data_ptr(), mm=dev2["mm"].data_ptr(),
                 ml=dev2["ml"].data_ptr(), n_reads=300, n_cigar_words=len(cg), n_seq_bytes=len(whole2["seq"]), n_mm_bytes=len(whole2["mm"]),
                 n_ml_bytes=len(whole2["ml"]), max_n_cigar=int(bs[i]["max_n_cigar"]), max_l_qseq=int(bs[i]["max_l_qseq"]))
-eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], coalesce=4)
+eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], coalesce=4, stream_mode=STREAM_MODE)
 ts = [eng.submit_device(window2(i)) for i in range(3)]
 try:
     eng.wait(ts[0]); out["error"] = None
@@ -282,11 +285,13 @@ print(json.dumps(out))
 '''
 
 
-def test_coalesced_windows_of_a_resident_read_set():
+@pytest.mark.parametrize("stream_mode", [2, 1], ids=["stream", "tiles"])
+def test_coalesced_windows_of_a_resident_read_set(stream_mode):
     """mm_freq_opts_t.coalesce: consecutive -K windows of one resident read set share a launch; same rows as the oracle for
     every grouping, tickets shared inside a group, a submit that does not continue the group starts a new one, and a read
-    error is reported relative to the group's first read."""
-    r = subprocess.run([sys.executable, "-c", COALESCE_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    error is reported relative to the group's first read (the stream kernel hands the read with the hard clip to the tile
+    pipeline, which names it)."""
+    r = subprocess.run([sys.executable, "-c", COALESCE_WORKER % (ROOT, stream_mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     for name in ("off", "groups_of_3", "one_group", "broken_runs"):
