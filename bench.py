@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0x5EED)
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = choose for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-timed", default="", help="write the rows the TIMED engine holds after the timed steps (its counters were reset "
+                                                     "before the warm-up: with --warmup 0 and --steps = the number of batches they are one pass "
+                                                     "over the workload at full size, through exactly the launches that were timed)")
     ap.add_argument("--dump", default="", help="write the device results of rank 0's first batches (freq: rows of the first two "
                                                  "batches; view: rows of the first batch) to this .npz file; tests/ compare it with the oracle")
     ap.add_argument("--max-len", type=float, default=0.0, help="experiment: cap read length (0 = 200 kb)")
@@ -629,6 +632,9 @@ def main():
         if e2e:
             result["end_to_end"] = e2e
             result["cpu_baseline_e2e"] = cpu_e2e
+        if args.dump_timed:
+            np.savez(args.dump_timed, rows=eng.finalize())
+            result["dump_timed"] = {"file": args.dump_timed, "steps": args.steps, "warmup": args.warmup, "batches": n_batches}
         if args.dump:
             chk = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, **wl["eng"])
             for hb in host_batches[:2]:

@@ -289,3 +289,32 @@ def test_random_reads_against_the_oracle(seed):
         st = both_ways(recs, ref, c)
         short = sum(1 for r in recs if r.l_qseq <= 24576)   # (a read with one of the long insertions can be longer: the tile pipeline's)
         assert st["stream_done"] == short and st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0, st
+
+
+def test_full_size_timed_launch_equals_the_oracle(tmp_path):
+    """BASELINE.json's C2 at full size, through exactly what bench.py times: 100 000 ONT-shape reads as 25 device-resident
+    -K 4096 windows gathered into one launch (every read goes through k_stream_reads there, the 100 kb ones too).  The rows
+    the timed engine holds after one pass equal the oracle's over the same batches, row for row."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dump = str(tmp_path / "timed.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "25", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-extra",
+                        "--dump-timed", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["dump_timed"]["batches"] == 25 and d["roofline"]["launches"] == 1
+    rt = d["config"]["routing"]
+    assert rt["reads"] == 100000 and rt["handed_to_the_fused_kernel"] == 0
+    got = np.load(dump)["rows"]
+    plan = bench.shard_plan(0, 1)
+    ref = bench.gen_reference(plan, 0x5EED)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    for bi in range(25):
+        orc.process(bench.gen_batch(ref, plan, 0, 0x5EED, 100000, 4096, bi), threads=os.cpu_count() or 1)
+    want = orc.rows()
+    assert len(want) > 500000 and len(got) == len(want)
+    for k in ("pos", "strand", "n_called", "n_mod"):
+        assert (got[k] == want[k]).all(), k
