@@ -48,6 +48,9 @@ struct Slot {
                                      // [5] fb_queue, [8..72) tile_count per region.  A launch's last kernel resets the other set.
     int ctl_set = 0;
     unsigned int* d_err_word = nullptr;   // err_summary of the slot's last launch
+    bool tiles_deferred = false;          // every read of the launch was a stream item: the tile kernels run when the host waits, and only
+    TileParams tile_params;               // if k_stream_reads handed a read on (h_ctl[131])
+    int tile_ga = 1, tile_gs = 1, tile_gc = 1;
     bool fb_deferred = false;             // the fused kernel for the fallback list was not launched with the batch:
     DevParams fb_params;                  // it runs when the host waits, and only if some read went on the list (h_ctl[130])
     unsigned int* d_tq = nullptr;    // two sets of 64 tile-queue + 64 scan-queue counters, 128 bytes apart, alternating with the control sets
@@ -240,6 +243,26 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
     return 0;
 }
 
+void launch_tile_kernels(mm_freq* h, const TileParams& tp, int ga, int gs, int gc, hipStream_t st) {
+    const DevParams& p = tp.d;
+    const bool plain = !p.insertions && !p.haplotypes;
+    if (h->wide) {
+        hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
+        hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
+        if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
+                      else hipLaunchKernelGGL((k_call_tiles<uint32_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
+        else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
+               else hipLaunchKernelGGL((k_call_tiles<uint32_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
+    } else {
+        hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
+        hipLaunchKernelGGL(k_sum_tiles<uint16_t>, dim3(gs), dim3(256), 0, st, tp);
+        if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
+                      else hipLaunchKernelGGL((k_call_tiles<uint16_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
+        else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
+               else hipLaunchKernelGGL((k_call_tiles<uint16_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
+    }
+}
+
 int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     DevParams p = base_params(h);
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
@@ -327,7 +350,8 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     HIPCHK(hipEventRecord(s.ev_start, st));
     if (b->n_reads > 0) {
         if (h->use_tiles) {
-            bool stream = false;
+            bool stream = false, all_stream = false;
+            s.tiles_deferred = false;
             if (!b->order) {
                 // no plan from the caller: the work items are made on the device (long reads cut into parts, costliest
                 // first), their number stays in device memory (control word 6)
@@ -335,23 +359,32 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 const size_t max_items = (size_t)b->n_reads + 2 * (size_t)b->n_seq_bytes / split + 64;
                 if ((r = grow(h, (void**)&s.d_plan, &s.cap_plan, 4 * max_items))) return r;
                 // plain freq runs: k_stream_reads takes the reads it can hide in the launch (and hands back what it does not do).
-                // A read is one wavefront's work from start to end there, so the longest one bounds the launch from below: a
-                // read takes a wavefront about 7000 times longer per base than a full launch takes per base (measured on
-                // MI355X, gathered launches of 4 to 32 batches).  The launch's bases are not known here for device batches --
-                // windows of a resident set share pool sizes -- so its reads are taken as 12 kb each; a launch too small to
-                // hide reads of `split` bases (a single -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
-                const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 7350;
+                // A read is one wavefront's work from start to end there, so the longest one bounds the launch from below:
+                // measured on MI355X (gathered launches of 4 to 32 batches) a wavefront spends 4.6 ns per base of its read
+                // while a full launch gets through a base in 0.75 ps, so a read of launch_bases / 6000 bases lasts as long as
+                // the launch itself.  Reads up to about that long go (the costliest start first; one that long costs the launch
+                // less than the tile kernels' three near-empty launches would), longer ones are cut into parts for the tile
+                // pipeline.  The launch's bases are not known here for device batches -- windows of a resident set share pool
+                // sizes -- so its reads are taken as 12 kb each; a launch too small to hide reads of `split` bases (a single
+                // -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
+                const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 4500;
                 const int mode = h->opts.stream_mode;
                 stream = mode != 1 && !p.view && !p.insertions && !p.haplotypes && (mode == 2 || hide >= split);
                 const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
                 if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
+                all_stream = stream && b->max_l_qseq <= stream_max;   // every read is a stream item: k_stream_reads is the launch's last kernel
+                s.h_ctl[131] = 0u;
+                tp.host_tile_flag = s.h_ctl + 131;
+                tp.reset_in_stream = all_stream ? 1 : 0;
+                if (all_stream) tp.reset_in_call = 0;
                 if (!s.d_plan_state) {
                     if (dev_alloc(h, (void**)&s.d_plan_state, sizeof(PlanState))) return -MM_E_NOMEM;
                     HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
                 }
                 const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
                 hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
-                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? stream_max : 0u, s.d_plan_stream, ctl + 7);
+                                   s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? stream_max : 0u, s.d_plan_stream, ctl + 7,
+                                   all_stream ? s.h_ctl + 131 : nullptr);
                 p.order = s.d_plan;
                 p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
                 tp.plan_count = ctl + 6;
@@ -364,7 +397,6 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             int gc = h->n_cu * h->call_blocks_per_cu;
             int gs = h->n_cu * 6;   // measured: 8 waves per SIMD 16.0 us, 6 14.8 us, 4 16.9 us
             if (ga < 1) ga = 1;
-            const bool plain = !p.insertions && !p.haplotypes;
             if (stream) {
                 const int gf = h->n_cu * h->stream_blocks_per_cu;
                 if (p.stats) {
@@ -375,20 +407,13 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                     else hipLaunchKernelGGL((k_stream_reads<uint16_t, false>), dim3(gf), dim3(256), 0, st, tp);
                 }
             }
-            if (h->wide) {
-                hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
-                hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
-                if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
-                              else hipLaunchKernelGGL((k_call_tiles<uint32_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
-                else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
-                       else hipLaunchKernelGGL((k_call_tiles<uint32_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
+            if (all_stream) {
+                // nothing is planned for the tile kernels: they run at wait time, and only if k_stream_reads handed a read on
+                s.tiles_deferred = true;
+                s.tile_params = tp; s.tile_params.reset_in_call = 0;
+                s.tile_ga = ga; s.tile_gs = gs; s.tile_gc = gc;
             } else {
-                hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
-                hipLaunchKernelGGL(k_sum_tiles<uint16_t>, dim3(gs), dim3(256), 0, st, tp);
-                if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
-                              else hipLaunchKernelGGL((k_call_tiles<uint16_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
-                else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
-                       else hipLaunchKernelGGL((k_call_tiles<uint16_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
+                launch_tile_kernels(h, tp, ga, gs, gc, st);
             }
             HIPCHK(hipGetLastError());
             // reads the tile form does not cover: the fused kernel over the fallback list.  The list is nearly always
@@ -425,9 +450,19 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
 // The batch's kernels are complete (its event has been waited for): if a read went on the fallback list, run the fused
 // kernel for the list now.
 int finish_deferred(mm_freq* h, Slot& s) {
-    if (!s.fb_deferred) return 0;
+    int ran = 0;
+    if (s.tiles_deferred) {
+        s.tiles_deferred = false;
+        if (s.h_ctl[131] != 0u) {   // k_stream_reads handed reads to the tile pipeline: its kernels run now
+            launch_tile_kernels(h, s.tile_params, s.tile_ga, s.tile_gs, s.tile_gc, s.last_stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s.last_stream));   // (they may put reads on the fallback list)
+            ran = 1;
+        }
+    }
+    if (!s.fb_deferred) return ran;
     s.fb_deferred = false;
-    if (s.h_ctl[130] == 0u) return 0;
+    if (s.h_ctl[130] == 0u) return ran;
     const DevParams& p = s.fb_params;
     const int blocks = std::min(h->n_cu * h->blocks_per_cu, 128);
     if (h->wide) {

@@ -806,6 +806,10 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
     KF<RefWord, kStats> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
+    if (P.reset_in_stream && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
+        if (p.ctl_next && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
+        if (p.queue_next && threadIdx.x < 192) p.queue_next[threadIdx.x * kQueueStride] = 0u;
+    }
     // items costliest first; a wave's first item is fixed, the following ones are handed out by 64 padded counters (as in
     // k_scan_reads)
     const int n_waves = (int)gridDim.x * kWavesPerBlock;
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
         if (st == 1 && lane_id() == 0) {   // not this kernel's kind of read: one more item for k_scan_reads
             const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
             P.tile_items[at] = ridx;
+            if (P.host_tile_flag) *P.host_tile_flag = 1u;
         }
         if (st == 2 && lane_id() == 0) {   // an input error somewhere in the read: the fused kernel names it
             const unsigned int at = atomicAdd(P.fb_count, 1u);

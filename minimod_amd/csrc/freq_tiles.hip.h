@@ -83,6 +83,9 @@ struct TileParams {
     unsigned int* stream_queue;       // [kTileRegions * kQueueStride]
     int32_t* tile_items;              // == d.order, writable
     unsigned int* tile_plan_count;    // == plan_count, writable
+    unsigned int* host_tile_flag;     // pinned host word: set when k_stream_reads hands a read to the tile pipeline (when every read of
+                                      // the launch is a stream item, the tile kernels are only launched if this says so)
+    int32_t reset_in_stream;          // 1: k_stream_reads is the launch's last kernel and resets the next launch's control words
 };
 constexpr uint32_t kPartSlots = 16;                       // parts per read (4 bits in a work item)
 constexpr int kPlanBuckets = 256;                         // cost buckets of 256 bases per part (a part is at most `split` bases: with the
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
                                                              unsigned int* __restrict__ n_items_out, PlanState* __restrict__ st, unsigned int serial,
                                                              unsigned int* __restrict__ err_summary, unsigned int* __restrict__ host_flag,
                                                              uint32_t stream_max, int32_t* __restrict__ items_stream,
-                                                             unsigned int* __restrict__ n_stream_out) {
+                                                             unsigned int* __restrict__ n_stream_out, unsigned int* __restrict__ host_tile_flag) {
     __shared__ uint32_t hist[2 * kPlanBuckets];
     __shared__ uint32_t base[2 * kPlanBuckets];
     __shared__ uint32_t wsum[2][kPlanThreads / 64];
@@ -303,7 +306,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             uint32_t before = incl[c] - v[c];
             for (int w = 0; w < (t >> 6); w++) before += wsum[c][w];
             atomicExch(&st->cursor[c * kPlanBuckets + t], before);
-            if (t == kPlanThreads - 1) { if (c == 0) *n_items_out = before + v[c]; else if (n_stream_out) *n_stream_out = before + v[c]; }
+            if (t == kPlanThreads - 1) {
+                if (c == 0) {
+                    *n_items_out = before + v[c];
+                    // (the host may have left the tile kernels out of the launch because the batch's longest read is a stream
+                    // item by its reckoning: if anything was planned for them after all, it has to run them when it waits)
+                    if (before + v[c] != 0u && host_tile_flag) *host_tile_flag = 1u;
+                } else if (n_stream_out) *n_stream_out = before + v[c];
+            }
         }
         __threadfence();
         __syncthreads();
