@@ -463,6 +463,16 @@ def main():
         phases += np.array(st["phase_cycles"], dtype=np.int64)
         side_per_pass += st["side_updates"]
         alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], st["dense_updates"] + st["side_updates"]))
+    # ... and where the reads go in launches like the timed ones (the windows gathered as the timed steps gather them: which
+    # reads k_stream_reads takes depends on the size of the launch)
+    routing[:] = 0
+    last = None
+    for db in dev_batches[:max(1, min(n_batches, args.steps))]:
+        last = eng.submit_device(db, stream)
+    eng.wait(last)
+    st = eng.stats_get()
+    routing += np.array([st["stream_done"], st["stream_to_tiles"], st["stream_to_fused"]], dtype=np.int64)
+    routed_reads = int(sum(len(hb["reads"]) for hb in host_batches[:max(1, min(n_batches, args.steps))]))
     eng.stats_enable(False)
     eng.reset()
     # the side list (calls inside insertions: --insertions only) grows with every step and is only emptied by reset()
@@ -614,8 +624,9 @@ def main():
             "gen_seconds": t_gen,
         }
         result["config"]["routing"] = {"reads_done_by_k_stream_reads": int(routing[0]), "handed_to_the_tile_pipeline": int(routing[1]),
-                                       "handed_to_the_fused_kernel": int(routing[2]), "reads": int(n_reads),
-                                       "note": "reads of more than split_bases (24 576) bases are the tile pipeline's from the start"}
+                                       "handed_to_the_fused_kernel": int(routing[2]), "reads": routed_reads,
+                                       "note": "one pass over the first min(steps, batches) windows, gathered like the timed steps; reads too long "
+                                               "to hide in the launch are the tile pipeline's from the start (all of them in a single-batch launch)"}
         if phases[3:].any():   # diagnostic builds (-DMM_STREAM_TIMING): the tally pass, then the timed steps
             result["phase_cycles"] = [int(x) for x in phases]
             result["phase_cycles_timed"] = [int(x) for x in eng.stats_get()["phase_cycles"]]
