@@ -63,7 +63,7 @@ constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pi
 constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
 constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each); query offsets stay one
                                             // below that, so that no word reaches the padding's 0xFFFFFFFF
-constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // what both windows hold behind their last entry: the searches run over the whole array
+constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // what the CIGAR window holds behind its last entry (the directory window: the running total)
 constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps requested together
 constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
 
@@ -71,7 +71,7 @@ struct StreamLds {
     uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
     uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
     uint32_t dw[kStreamDir + 1];            // class members in front of each block of the window (traversal order), then the running total
-    uint32_t cw[kStreamCig];                // query offset << 18 | reference offset << 4 | op, relative to the window's first op
+    uint32_t cw[kStreamCig + 1];            // query offset << 18 | reference offset << 4 | op, relative to the window's first op; then 0xFFFFFFFF
     char hdr[16];
     int16_t g_code[16];
     // what the header pass leaves for the groups: where the group starts and its list begins, flags (bit 6 no requested code,
@@ -115,20 +115,31 @@ __device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, ui
 // number of set bits below the lowest clear one (64 when all are set)
 __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint32_t)__ffsll((unsigned long long)~m) - 1u : 64u; }
 
-// largest i in [0, N) with arr[i] <= key: arr rises, arr[0] <= key, and what lies behind the entries in use is kStreamInf.
-// N is fixed, so the loop unrolls into its ceil(log2 N) steps: a read, a compare and a select each, no loop control.
+// largest i in [0, n) with arr[i] <= key: arr[0 .. n) rises, arr[0] <= key < arr[n] (the entry behind the last one in use is a
+// bound no key of the round reaches).  The steps are those of a search over N entries, so the loop unrolls into ceil(log2 N)
+// steps of a read, a compare and a select with no loop control; a probe beyond n reads the bound instead.
 template <uint32_t N>
-__device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key) {
+__device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key, uint32_t n) {
+#ifdef MM_STREAM_BINARY_SEARCH
     uint32_t lo = 0;
 #pragma unroll
-    for (uint32_t n = N; n > 1u; n -= n >> 1) {
-        const uint32_t half = n >> 1;
-        lo = arr[lo + half] <= key ? lo + half : lo;
+    for (uint32_t m = N; m > 1u; m -= m >> 1) {
+        const uint32_t half = m >> 1;
+        const uint32_t at = min(lo + half, n);
+        lo = arr[at] <= key ? at : lo;
     }
     return lo;
-}
-__device__ __forceinline__ void inf_fill(uint32_t* arr, uint32_t from, uint32_t to) {
-    for (uint32_t i = from + (uint32_t)lane_id(); i < to; i += 64u) arr[i] = kStreamInf;
+#else
+    // four-way: three probes a step, read together -- five dependent LDS round trips for 320 or 576 entries instead of nine or ten
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t m = N; m > 1u; m = (m + 3u) / 4u) {
+        const uint32_t q = (m + 3u) / 4u;
+        const uint32_t a1 = arr[min(lo + q, n)], a2 = arr[min(lo + 2u * q, n)], a3 = arr[min(lo + 3u * q, n)];
+        lo += ((a1 <= key ? 1u : 0u) + (a2 <= key ? 1u : 0u) + (a3 <= key ? 1u : 0u)) * q;
+    }
+    return lo;
+#endif
 }
 
 template <typename RefWord, bool kStats>
@@ -156,6 +167,11 @@ struct KF {
     uint32_t ml_start;
     // text cursor and token ring
     uint32_t cpos, nx_w0, nx_w1, qhead, qn, kdone, Rcarry, ntok_parsed;
+    // a round's counter updates are ISSUED at the top of the next round, behind that round's loads (one per lane: the update of
+    // the group's first code; further codes go out at once): on gfx9 an atomic counts in vmcnt like a load, so the wait for the
+    // next loads would otherwise sit out the atomics' trip to the memory side as well
+    unsigned long long* pend_addr;
+    uint32_t pend_inc;   // 0 none, 1 called, 2 called and modified
     uint32_t staged_at, skip0;   // text offset of the chunk in LDS; header characters in front of the list in the group's first chunk
     bool prev_delim, closed, bad_text;
     // directory window: blocks [t_w0, t_w0 + wn) in traversal order, t_next the next block to scan, S_next the members in front of it
@@ -289,7 +305,7 @@ struct KF {
                 if (!stop && S_next <= rho_last && t_next < nblk) {
                     if (wn + 64u > kStreamDir) {
                         if (S_next > rho_0) stop = true;
-                        else { inf_fill(S.dw, 0u, wn + 1u); wn = 0; t_w0 = t_next; }
+                        else { wn = 0; t_w0 = t_next; }
                     }
                     if (!stop) {
                         const uint32_t t = t_next + lane;
@@ -374,7 +390,7 @@ struct KF {
                 if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
                     if (xn + 64u > kStreamCig) {
                         if (A_next > u_lo) stop = true;
-                        else { inf_fill(S.cw, 0u, xn); xn = 0; }
+                        else xn = 0;
                     }
                     if (!stop) {
                         const bool valid = s_next + lane < ncig;
@@ -395,7 +411,7 @@ struct KF {
                         const uint32_t nvalid = min(64u, ncig - s_next);
                         if (nv == 0u) {   // the next op starts beyond what this window's words can say
                             if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
-                            else { inf_fill(S.cw, 0u, xn); xn = 0; stale = true; }
+                            else { xn = 0; stale = true; }
                         } else {
                             if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
                             xn += nv; s_next += nv;
@@ -407,6 +423,7 @@ struct KF {
                 }
             }
         }
+        if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
         wave_sync();
     }
 
@@ -435,6 +452,11 @@ struct KF {
         }
     }
 
+    __device__ __forceinline__ void flush_pending() {
+        if (pend_inc) atomicAdd(pend_addr, pend_inc == 2u ? 0x100000001ull : 1ull);
+        pend_inc = 0;
+    }
+
     // ------------------------------------------------------------------ one round: the ring's first n tokens (n <= 64)
     // returns the number of tokens done (0: something is wrong with the read)
     __device__ __forceinline__ uint32_t round(uint32_t n) {
@@ -452,6 +474,7 @@ struct KF {
         const uint32_t kidx = kdone + lane;
         const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
         const uint32_t ml0 = (lv && mi0 < ml_len) ? ml[mi0] : 0u;
+        flush_pending();   // the round before's updates, behind this round's loads
         fill_dir(rho_0, rho_last, dv);
         KFT_LAP(3);
         const uint32_t n1 = leading_ones(__ballot(lv && rho < S_next));   // tokens whose block is in the window
@@ -459,7 +482,7 @@ struct KF {
         if (n1 > 0u) {
             // rank -> block: largest j with dw[j] <= rho (dw[0] <= rho_0 by construction)
             const bool act = lane < n1;
-            const uint32_t j = act ? search_le<kStreamDir>(S.dw, rho) : 0u;
+            const uint32_t j = act ? search_le<kStreamDir>(S.dw, rho, wn) : 0u;
             const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
             const uint32_t t = t_w0 + j, blk = rev ? nblk - 1u - t : t;
             const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
@@ -488,7 +511,7 @@ struct KF {
                 // traversal position -> op: largest s with (query offset of op s) <= u
                 const uint32_t du = u - A_base;
                 const uint32_t target = ((du < kStreamSpan - 1u ? du : kStreamSpan - 2u) << 18) | 0x3FFFFu;
-                const uint32_t xo = fin ? search_le<kStreamCig>(S.cw, target) : 0u;
+                const uint32_t xo = fin ? search_le<kStreamCig>(S.cw, target, xn) : 0u;
                 const uint32_t xw = S.cw[xo];
                 const uint32_t op = xw & 15u, a_s = A_base + (xw >> 18), b_s = B_base + ((xw >> 4) & 0x3FFFu);
                 const bool call = fin && ((0x181u >> op) & 1u);
@@ -526,6 +549,10 @@ struct KF {
                         unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
                         if (cnt0 != nullptr && plane >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
 #ifndef MM_ABL_NOATOMIC
+#ifndef MM_STREAM_ATOMICS_AT_ONCE
+                            if (m == 0) { pend_addr = cbm + (uint32_t)ref_pos; pend_inc = is_mod ? 2u : 1u; }
+                            else
+#endif
                             atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
 #else
                             if (ref_pos == -12345 && is_mod) atomicAdd(cbm, 1ull);
@@ -543,11 +570,11 @@ struct KF {
                 const uint32_t xl = lane_valu(xo, fll);
                 if (xl > 0u) {
                     const uint32_t b0 = S.cw[xl] & ~15u, cnt = xn - xl;
-                    for (uint32_t c0 = 0; c0 < xn; c0 += 64u) {   // entries move down, the padding follows them
+                    for (uint32_t c0 = 0; c0 < cnt + 1u; c0 += 64u) {   // with the bound behind the last op (a chunk is read before the one below it is written: xl > 0)
                         const uint32_t i = c0 + lane;
                         const uint32_t v = i < cnt ? S.cw[xl + i] - b0 : kStreamInf;
                         wave_sync();
-                        if (i < xn) S.cw[i] = v;
+                        if (i < cnt + 1u) S.cw[i] = v;
                         wave_sync();
                     }
                     A_base += b0 >> 18; B_base += (b0 >> 4) & 0x3FFFu;
@@ -559,11 +586,11 @@ struct KF {
                 const uint32_t jl = lane_valu(j, (int)(n_done - 1u));
                 if (jl > 0u) {
                     const uint32_t cnt = wn - jl + 1u;   // with the running total behind the last block
-                    for (uint32_t c0 = 0; c0 < wn + 1u; c0 += 64u) {   // entries move down, the padding follows them
+                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
                         const uint32_t i = c0 + lane;
-                        const uint32_t v = i < cnt ? S.dw[jl + i] : kStreamInf;
+                        const uint32_t v = i < cnt ? S.dw[jl + i] : 0u;
                         wave_sync();
-                        if (i < wn + 1u) S.dw[i] = v;
+                        if (i < cnt) S.dw[i] = v;
                         wave_sync();
                     }
                     t_w0 += jl; wn -= jl;
@@ -578,10 +605,10 @@ struct KF {
     // returns 0, or 2 when the read has to go to the fused kernel (an input error); *ntok = tokens of the group
     __device__ __forceinline__ int run_group(uint32_t mpos, uint32_t lstart, bool wanted, uint32_t& ntok) {
         cpos = mpos; skip0 = lstart - mpos; prev_delim = true; closed = false; bad_text = false;
+        pend_inc = 0; pend_addr = nullptr;
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
         t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
         xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
-        if (wanted) { inf_fill(S.dw, 0u, kStreamDir + 1u); inf_fill(S.cw, 0u, kStreamCig); }
         if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
         for (;;) {
@@ -594,6 +621,7 @@ struct KF {
             if (nd == 0u || eb) { st = 2; break; }
             qhead = (qhead + nd) & (kStreamRing - 1u); qn -= nd; kdone += nd;
         }
+        flush_pending();
         ntok = ntok_parsed;
         return st;
     }
