@@ -112,6 +112,8 @@ __device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, ui
     if (pat == 0u) c -= 32u - min(32u, L - b * 32u);   // the padding behind the read's last base is none of C, G, T, N either
     return c;
 }
+// all ones when bit `op` of `mask` is set, else 0 (one signed bit-field extract: which ops consume the read / the reference)
+__device__ __forceinline__ uint32_t op_mask(uint32_t mask, uint32_t op) { return (uint32_t)__builtin_amdgcn_sbfe((int)mask, op, 1u); }
 // number of set bits below the lowest clear one (64 when all are set)
 __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint32_t)__ffsll((unsigned long long)~m) - 1u : 64u; }
 
@@ -369,6 +371,7 @@ struct KF {
     // ------------------------------------------------------------------ CIGAR -> window
     // ops are appended until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more
     // fits (room, or the 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
+#ifndef MM_STREAM_CIG_PAIRS
     __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds]) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
@@ -426,6 +429,86 @@ struct KF {
         if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
         wave_sync();
     }
+#else
+    // Two ops a lane: a step is 128 ops, so the scans, the window's bookkeeping and the loop's conditions are paid half as often
+    // per op (the CIGAR is a third of an ONT read's instructions: ~890 ops against ~150 calls).  Lane l holds ops 2l and 2l + 1
+    // of the step in the order they are walked.
+    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds]) const {
+        const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll
+        for (int r = 0; r < kStreamCigRounds; r += 2) {
+            const uint32_t s = s_next + 64u * (uint32_t)r + 2u * lane;
+            wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
+            wv[r + 1] = s + 1u < ncig ? cg[rev ? ncig - 2u - s : s + 1u] : 0u;
+        }
+    }
+    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds]) {
+        static_assert(kStreamCigRounds % 2 == 0, "steps of two words a lane");
+        const uint32_t lane = (uint32_t)lane_id();
+        bool stop = false, first = true;
+        while (!stop && A_next <= u_hi && s_next < ncig) {
+            if (!first) load_cig(wv);
+            first = false;
+            bool stale = false;   // the loaded steps no longer line up with s_next
+#pragma unroll
+            for (int r = 0; r < kStreamCigRounds; r += 2) {
+                if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
+                    if (xn + 128u > kStreamCig) {
+                        if (A_next > u_lo) stop = true;
+                        else xn = 0;
+                    }
+                    if (!stop) {
+                        const uint32_t s0 = s_next + 2u * lane;
+                        const bool v0 = s0 < ncig, v1 = s0 + 1u < ncig;
+                        const uint32_t w0 = wv[r], w1 = wv[r + 1], op0 = w0 & 15u, op1 = w1 & 15u;
+                        const uint32_t l0 = v0 ? w0 >> 4 : 0u, l1 = v1 ? w1 >> 4 : 0u;
+                        const uint32_t q0 = l0 & op_mask(0x193u, op0), r0 = l0 & op_mask(0x18Du, op0);
+                        const uint32_t q1 = l1 & op_mask(0x193u, op1), r1 = l1 & op_mask(0x18Du, op1);
+                        const uint32_t pq = q0 + q1, pr = r0 + r1;
+                        // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
+                        uint32_t qs, rs;
+                        if (!__ballot((l0 | l1) >= 512u)) {
+                            const uint32_t pk = wave_incl_scan(pq | (pr << 16));
+                            qs = pk & 0xFFFFu; rs = pk >> 16;
+                        } else {
+                            qs = wave_incl_scan(pq); rs = wave_incl_scan(pr);
+                        }
+                        if (xn == 0) { A_base = A_next; B_base = B_next; }
+                        const uint32_t tq = lane_valu(qs, 63), tr = lane_valu(rs, 63);
+                        const uint32_t dq0 = A_next + qs - pq - A_base, dr0 = B_next + rs - pr - B_base;   // op 2l starts here ...
+                        const uint32_t dq1 = dq0 + q0, dr1 = dr0 + r0;                                       // ... op 2l + 1 here
+                        const uint32_t nvalid = min(128u, ncig - s_next);
+                        uint32_t nv = nvalid;
+                        if (!(A_next + tq - A_base < kStreamSpan - 1u && B_next + tr - B_base < kStreamSpan)) {
+                            // (rare) some op of the step starts beyond what the window's words can say: the ops in front of it go in
+                            const uint32_t i0 = leading_ones(__ballot(v0 && dq0 < kStreamSpan - 1u && dr0 < kStreamSpan));
+                            const uint32_t i1 = leading_ones(__ballot(v1 && dq1 < kStreamSpan - 1u && dr1 < kStreamSpan));
+                            nv = min(2u * i0, 2u * i1 + 1u);
+                            nv = min(nv, nvalid);
+                        }
+                        if (nv == 0u) {   // the next op starts beyond what this window's words can say
+                            if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
+                            else { xn = 0; stale = true; }
+                        } else {
+                            if (2u * lane < nv) S.cw[xn + 2u * lane] = (dq0 << 18) | (dr0 << 4) | op0;
+                            if (2u * lane + 1u < nv) S.cw[xn + 2u * lane + 1u] = (dq1 << 18) | (dr1 << 4) | op1;
+                            xn += nv; s_next += nv;
+                            if (nv == nvalid) { A_next += tq; B_next += tr; }
+                            else {   // the sums in front of op nv: the pairs in front of its lane, and its lane's first op if it is the second
+                                const int ln = (int)(nv >> 1);
+                                A_next += lane_valu(qs - pq, ln) + ((nv & 1u) ? lane_valu(q0, ln) : 0u);
+                                B_next += lane_valu(rs - pr, ln) + ((nv & 1u) ? lane_valu(r0, ln) : 0u);
+                                stale = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
+        wave_sync();
+    }
+#endif
 
     __device__ __forceinline__ void side_append(int32_t spos, int is_mod, int code) {
         // (the rare path: what it needs of the read is fetched again rather than kept in registers)
