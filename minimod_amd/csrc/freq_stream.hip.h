@@ -4,30 +4,32 @@
 // The tile pipeline (freq_tiles.hip.h) cuts a read into independent tiles and pays for the independence: per-op CIGAR
 // prefix arrays and a rank directory are written to a scratch and read back, every tile re-derives its carries, stages
 // its own slices, and the three kernels read the read record three times.  For the common read -- plain `freq` (no
-// --insertions, no --haplotypes), every MM group a `?`-flagged skip list on one canonical base, short enough to be one work
-// item -- none of that is needed, because everything a read's calls touch moves in ONE direction:
+// --insertions, no --haplotypes), every MM group a `?`-flagged skip list on one canonical base, in a launch big enough to
+// hide a read inside it -- none of that is needed, because everything a read's calls touch moves in ONE direction:
 //
 //   tokens        the skip list in text order: ranks (k-th base of the class) rise with the token index;
 //   sequence      the rank of a 32-base block's first base rises with the block index (walked from the read's END for a
 //                 reverse-strand read, whose MM counts bases of the original orientation);
 //   CIGAR         the read position at which an op starts rises with the op index (ops walked from the END for a reverse
-//                 read, read positions counted from the end of the aligned query: the mirrored problem is the same
-//                 problem).
+//                 read, read positions counted from position 0 of the original orientation, as get_aln does: the mirrored
+//                 problem is the same problem).
 //
 // So a wavefront keeps three cursors and two small windows in LDS and loops over rounds of 64 tokens:
 //   1. parse skip-list text (256 characters per trip, the per-character sum of k_sum_tiles) into a ring of ranks;
-//   2. extend the directory window (popcount + wave scan of 64 blocks per step, four steps requested together) until it
+//   2. extend the directory window (popcount + wave scan of 64 blocks per step, two steps requested together) until it
 //      covers the round's last rank; every lane finds its block (branch-free search in LDS) and selects the base in it;
-//   3. extend the CIGAR window (decode + two wave scans per 64 ops, packed one word per op) until it covers the round's last
-//      read position; every lane finds its op, projects, loads the reference word and the ML byte, thresholds, and
-//      makes ONE 64-bit atomic add -- the same update the tile pipeline makes.
+//   3. extend the CIGAR window (decode + one wave scan per 64 ops, packed one word per op, four steps requested together)
+//      until it covers the round's last read position; every lane finds its op, projects, loads the reference word and the
+//      ML byte, thresholds, and makes ONE 64-bit atomic add -- the same update the tile pipeline makes.
 // A window that cannot hold a round's span (sparse tokens, introns) simply covers fewer tokens: the rest stay in the ring.
+// What a round needs from memory that depends only on the cursors is requested at its top, before anything is waited for.
 //
 // What this kernel does not do, it hands on BEFORE touching a counter: reads with '.' groups (implicit calls), groups on
 // 'N' or on different bases, more than four codes or eight groups, a CIGAR the checks do not pass outright -> appended to
-// the tile pipeline's item list (k_scan_reads runs after this kernel).  Anything that goes wrong once calls have been
-// counted is an input error (malformed token, rank past the last base, ML too short): the read goes on the fallback list
-// and the fused kernel names the error in the reference's order, exactly as for the tile pipeline's irregular reads.
+// the tile pipeline's item list (k_scan_reads runs after this kernel, or at wait time when nothing else needs it).  Anything
+// that goes wrong once calls have been counted is an input error (malformed token, rank past the last base, ML too short):
+// the read goes on the fallback list and the fused kernel names the error in the reference's order, exactly as for the tile
+// pipeline's irregular reads.  DESIGN.md section 4 ("Streaming kernel") has the measurements.
 #pragma once
 #include "freq_tiles.hip.h"
 
