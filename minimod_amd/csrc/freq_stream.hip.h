@@ -279,9 +279,10 @@ struct KF {
         if (bad) bad_text = true;
         prev_delim = lane_valu(x[kSub - 1], 63) == (uint32_t)',';
         closed = cl;
-        if (keep) qn += ntok;
-        Rcarry += rsum_v;
-        ntok_parsed += ntok;
+        // (the cursors are wave-uniform by construction; saying so keeps them and the arithmetic on them in scalar registers)
+        if (keep) qn = uniu(qn + ntok);
+        Rcarry = uniu(Rcarry + rsum_v);
+        ntok_parsed = uniu(ntok_parsed + ntok);
         cpos += kStreamChunk;
         wave_sync();
     }
@@ -319,8 +320,8 @@ struct KF {
                         const uint32_t incl = wave_incl_scan(cnt);
                         if (valid) S.dw[wn + lane] = S_next + incl - cnt;
                         const uint32_t nv = min(64u, nblk - t_next);
-                        wn += nv; t_next += nv;
-                        S_next += lane_valu(incl, 63);
+                        wn = uniu(wn + nv); t_next = uniu(t_next + nv);
+                        S_next = uniu(S_next + lane_valu(incl, 63));
                     }
                 }
             }
@@ -419,9 +420,9 @@ struct KF {
                             else { xn = 0; stale = true; }
                         } else {
                             if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
-                            xn += nv; s_next += nv;
-                            A_next += nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv);
-                            B_next += nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv);
+                            xn = uniu(xn + nv); s_next = uniu(s_next + nv);
+                            A_next = uniu(A_next + (nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv)));
+                            B_next = uniu(B_next + (nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv)));
                             if (nv < nvalid) stale = true;
                         }
                     }
@@ -662,8 +663,8 @@ struct KF {
                         if (i < cnt + 1u) S.cw[i] = v;
                         wave_sync();
                     }
-                    A_base += b0 >> 18; B_base += (b0 >> 4) & 0x3FFFu;
-                    xn = cnt;
+                    A_base = uniu(A_base + (b0 >> 18)); B_base = uniu(B_base + ((b0 >> 4) & 0x3FFFu));
+                    xn = uniu(cnt);
                 }
             }
             if (n_done > 0u) {
@@ -678,7 +679,7 @@ struct KF {
                         if (i < cnt) S.dw[i] = v;
                         wave_sync();
                     }
-                    t_w0 += jl; wn -= jl;
+                    t_w0 = uniu(t_w0 + jl); wn = uniu(wn - jl);
                 }
             }
         }
@@ -704,7 +705,7 @@ struct KF {
             const uint32_t nd = round(n);
             const uint64_t eb = __ballot(err != 0);
             if (nd == 0u || eb) { st = 2; break; }
-            qhead = (qhead + nd) & (kStreamRing - 1u); qn -= nd; kdone += nd;
+            qhead = uniu((qhead + nd) & (kStreamRing - 1u)); qn = uniu(qn - nd); kdone = uniu(kdone + nd);
         }
         flush_pending();
         ntok = ntok_parsed;
