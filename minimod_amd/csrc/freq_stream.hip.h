@@ -124,7 +124,8 @@ __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint
 // steps of a read, a compare and a select with no loop control; a probe beyond n reads the bound instead.
 template <uint32_t N>
 __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key, uint32_t n) {
-#ifdef MM_STREAM_BINARY_SEARCH
+#ifndef MM_STREAM_FOURWAY_SEARCH
+    // (binary: 4 790 VALU wave instructions per ONT read against 5 010 with the four-way steps below, same time within noise)
     uint32_t lo = 0;
 #pragma unroll
     for (uint32_t m = N; m > 1u; m -= m >> 1) {
@@ -578,7 +579,11 @@ struct KF {
             const uint4 sv = make_uint4(0x22222222u ^ blk, 0x44444444u, 0x22224444u, 0x42424242u);
 #endif
             uint32_t code = 0;
+#ifdef MM_ABL_NOSELECT
+            const uint32_t q = act ? blk * 32u + (kk & 31u) + (sv.x & 0u) : 0u;
+#else
             const uint32_t q = act ? select_in_block(sv, blk, kk, code) : 0u;
+#endif
             // read position -> position in the direction the CIGAR is walked (get_aln walks a reverse read's ops back to front
             // from position 0 of the original orientation, mod.c:813-860); positions past the CIGAR's query length have no call
             const uint32_t u = rev ? L - 1u - q : q;
@@ -593,7 +598,11 @@ struct KF {
             KFT_LAP(5);
             const bool fin = lane < n_done && live;
             const uint64_t fm = __ballot(fin);
+#ifdef MM_ABL_NOFINISH
+            if (false && fm) {
+#else
             if (fm) {
+#endif
                 // traversal position -> op: largest s with (query offset of op s) <= u
                 const uint32_t du = u - A_base;
                 const uint32_t target = ((du < kStreamSpan - 1u ? du : kStreamSpan - 2u) << 18) | 0x3FFFFu;
@@ -749,7 +758,11 @@ struct KF {
             // what a clean record passes outright; anything else is the tile pipeline's to judge op by op
             uint32_t sumq = 0, sumr = 0;
             bool badop = false;
+#ifdef MM_ABL_NOVALIDATE
+            for (uint32_t i0 = 0; i0 < 0u; i0 += 1024u) {
+#else
             for (uint32_t i0 = 0; i0 < ncig; i0 += 1024u) {
+#endif
                 if (i0 > 0u) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
