@@ -114,7 +114,10 @@ typedef struct mm_freq_opts {
                               * tile pipeline, in plain freq runs (no --insertions, no --haplotypes, not view).  0 (default): by the
                               * size of the launch -- none in a launch of fewer than about 15 000 reads (a single -K 4096 batch:
                               * the longest read would be the launch), in bigger (gathered) launches every read short enough to
-                              * hide; 1: none; 2: every read of up to split_bases bases whatever the launch (tests).
+                              * hide; 1: none; 2: every read of up to split_bases bases whatever the launch (tests);
+                              * 3: like 2, with the '.'-capable instantiation of the kernel from the first launch on (otherwise the
+                              * leaner one runs until a read with a '.' group has shown up -- that read goes through the tile
+                              * pipeline -- and the '.'-capable one from the next launch on: a file's reads carry one flag or the other).
                               * (A reserved field before: same layout.) */
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;

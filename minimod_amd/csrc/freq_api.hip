@@ -100,6 +100,7 @@ struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
     int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6;
+    bool stream_dot = false; // a read with a '.' group has been seen: k_stream_reads' '.'-capable instantiation from now on
     bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
     bool wide = false;  // 32-bit reference words (n_mods > 5)
     int n_contigs = 0;
@@ -369,7 +370,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 // -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
                 const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 4500;
                 const int mode = h->opts.stream_mode;
-                stream = mode != 1 && !p.view && !p.insertions && !p.haplotypes && (mode == 2 || hide >= split);
+                stream = mode != 1 && !p.view && !p.insertions && !p.haplotypes && (mode >= 2 || hide >= split);
                 const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
                 if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
                 all_stream = stream && b->max_l_qseq <= stream_max;   // every read is a stream item: k_stream_reads is the launch's last kernel
@@ -399,13 +400,21 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             if (ga < 1) ga = 1;
             if (stream) {
                 const int gf = h->n_cu * h->stream_blocks_per_cu;
+                // which instantiation: the lean one until a read with a '.' group has shown up (the flag of the slot's last
+                // launch is looked at here: a file's reads carry one flag or the other), stream_mode 3 = the '.'-capable one at once
+                for (auto& sl : h->slots) if (sl.h_ctl && sl.h_ctl[132] != 0u) h->stream_dot = true;   // (any slot's finished launch)
+                s.h_ctl[132] = 0u;
+                tp.host_dot_flag = s.h_ctl + 132;
+                const bool kd = h->stream_dot || h->opts.stream_mode == 3;
+#define MM_LAUNCH_STREAM(T, ST, DT) hipLaunchKernelGGL((k_stream_reads<T, ST, DT>), dim3(gf), dim3(256), 0, st, tp)
                 if (p.stats) {
-                    if (h->wide) hipLaunchKernelGGL((k_stream_reads<uint32_t, true>), dim3(gf), dim3(256), 0, st, tp);
-                    else hipLaunchKernelGGL((k_stream_reads<uint16_t, true>), dim3(gf), dim3(256), 0, st, tp);
+                    if (h->wide) { if (kd) MM_LAUNCH_STREAM(uint32_t, true, true); else MM_LAUNCH_STREAM(uint32_t, true, false); }
+                    else { if (kd) MM_LAUNCH_STREAM(uint16_t, true, true); else MM_LAUNCH_STREAM(uint16_t, true, false); }
                 } else {
-                    if (h->wide) hipLaunchKernelGGL((k_stream_reads<uint32_t, false>), dim3(gf), dim3(256), 0, st, tp);
-                    else hipLaunchKernelGGL((k_stream_reads<uint16_t, false>), dim3(gf), dim3(256), 0, st, tp);
+                    if (h->wide) { if (kd) MM_LAUNCH_STREAM(uint32_t, false, true); else MM_LAUNCH_STREAM(uint32_t, false, false); }
+                    else { if (kd) MM_LAUNCH_STREAM(uint16_t, false, true); else MM_LAUNCH_STREAM(uint16_t, false, false); }
                 }
+#undef MM_LAUNCH_STREAM
             }
             if (all_stream) {
                 // nothing is planned for the tile kernels: they run at wait time, and only if k_stream_reads handed a read on
@@ -665,8 +674,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
         int nf = 0;
-        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false>), 256, 0);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false>), 256, 0);
+        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false, true>), 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false, true>), 256, 0);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);

@@ -24,7 +24,11 @@
 // A window that cannot hold a round's span (sparse tokens, introns) simply covers fewer tokens: the rest stay in the ring.
 // What a round needs from memory that depends only on the cursors is requested at its top, before anything is waited for.
 //
-// What this kernel does not do, it hands on BEFORE touching a counter: reads with '.' groups (implicit calls), groups on
+// '.' groups: the unlisted bases of the class are calls too; tokens and the bases of the gaps in front of them are one rising
+// sequence of ranks that goes through the same rounds (run_group).  That generality costs the '?' path 5 %, so the kernel has
+// two instantiations (kDot) and the handle moves to the '.'-capable one when a read with a '.' group has shown up.
+//
+// What this kernel does not do, it hands on BEFORE touching a counter: reads with groups on
 // 'N' or on different bases, more than four codes or eight groups, a CIGAR the checks do not pass outright -> appended to
 // the tile pipeline's item list (k_scan_reads runs after this kernel, or at wait time when nothing else needs it).  Anything
 // that goes wrong once calls have been counted is an input error (malformed token, rank past the last base, ML too short):
@@ -74,6 +78,8 @@ struct StreamLds {
     uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
     uint32_t dw[kStreamDir + 1];            // class members in front of each block of the window (traversal order), then the running total
     uint32_t cw[kStreamCig + 1];            // query offset << 18 | reference offset << 4 | op, relative to the window's first op; then 0xFFFFFFFF
+    uint32_t gap_p[65];                     // '.' groups: first element (gap bases, then the token) of each token of the batch; [n] = all
+    uint32_t gap_r[64];                     //             first rank of the gap in front of each token
     char hdr[16];
     int16_t g_code[16];
     // what the header pass leaves for the groups: where the group starts and its list begins, flags (bit 6 no requested code,
@@ -147,7 +153,9 @@ __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key,
 #endif
 }
 
-template <typename RefWord, bool kStats>
+// kDot: '.' groups (implicit calls) are this kernel's too; without it (the leaner instantiation) reads that have one go to the
+// tile pipeline and a flag tells the host to launch the other instantiation from then on (a file's reads carry one flag or the other)
+template <typename RefWord, bool kStats, bool kDot>
 struct KF {
     const TileParams& P;
     const DevParams& p;
@@ -165,6 +173,8 @@ struct KF {
     int32_t pos, rev, ridx_cur;
     // the group
     int32_t ncg;
+    bool dot_group;             // a '.' group: unlisted bases are calls too
+    bool saw_dot;               // (!kDot) a read was handed on because of a '.' group
     uint32_t gc01, gc23;        // the group's codes, two 16-bit indices a word (0xFFFF: not requested)
     uint32_t ci0, ci1, ci2, ci3;
     unsigned long long* cnt0;   // the read's strand-0... counters of plane 0 of its contig, shifted so that the index is the reference position;
@@ -190,7 +200,7 @@ struct KF {
 #endif
 
     __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
-        : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0) {}
+        : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0), saw_dot(false) {}
 
     __device__ __forceinline__ int gcode_at(int m) const { return (int)(int16_t)(((m < 2 ? gc01 : gc23) >> (16 * (m & 1))) & 0xFFFFu); }
     __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
@@ -546,10 +556,12 @@ struct KF {
 
     // ------------------------------------------------------------------ one round: the ring's first n tokens (n <= 64)
     // returns the number of tokens done (0: something is wrong with the read)
-    __device__ __forceinline__ uint32_t round(uint32_t n) {
+    // n rising ranks, one a lane; expl: the lane's rank is a listed token (its ML bytes are those of token kidx of the group),
+    // else an unlisted base of a '.' group (mod.c:1206-1287, :1289-1365: called, not modified, no ML byte)
+    __device__ __forceinline__ uint32_t round_core(uint32_t rho_in, uint32_t n, bool expl, uint32_t kidx) {
         const uint32_t lane = (uint32_t)lane_id();
         const bool lv = lane < n;
-        const uint32_t rho = lv ? S.tok[(qhead + lane) & (kStreamRing - 1u)] : 0xFFFFFFFFu;
+        const uint32_t rho = lv ? rho_in : 0xFFFFFFFFu;
         const uint32_t rho_0 = lane_valu(rho, 0), rho_last = lane_valu(rho, (int)(n - 1u));
         KFT_LAP(2);
         // Requested together, before anything is waited for: the next steps of the sequence and of the CIGAR from where the
@@ -558,9 +570,8 @@ struct KF {
         uint32_t cv[kStreamCigRounds];
         load_dir(dv);
         load_cig(cv);
-        const uint32_t kidx = kdone + lane;
         const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
-        const uint32_t ml0 = (lv && mi0 < ml_len) ? ml[mi0] : 0u;
+        const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
         fill_dir(rho_0, rho_last, dv);
         KFT_LAP(3);
@@ -632,14 +643,16 @@ struct KF {
                         const bool in_ctx = (w >> (5 + 2 * req + rev)) & 1u;
                         const bool matches = ((cinfo >> 18) & 1u) || refcode == code;
                         if (!(in_ctx && matches)) continue;
-                        const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
-                        if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
-                        const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
-                        if (kStats) st_ml++;
-                        int is_mod;
-                        if (mv >= t_hi) is_mod = 1;
-                        else if (mv <= t_lo) is_mod = 0;
-                        else continue;
+                        int is_mod = 0;
+                        if (expl) {
+                            const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                            if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
+                            const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
+                            if (kStats) st_ml++;
+                            if (mv >= t_hi) is_mod = 1;
+                            else if (mv <= t_lo) is_mod = 0;
+                            else continue;
+                        }
                         const int plane = (int)((cinfo >> 23) & 127u) - 1;
                         unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
                         if (cnt0 != nullptr && plane >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
@@ -706,15 +719,71 @@ struct KF {
         xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
         if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
+        // One loop, one call of round_core: the ranks of a round come from the ring (a batch of up to 64 tokens), or -- in a
+        // '.' group, where every base of the class that the list skips is a call too (called, not modified) -- from the batch's
+        // tokens AND the bases of the gaps in front of them, ONE rising sequence gap, token, gap, token, ... taken 64 elements at
+        // a time, and behind the last token from the rest of the read's bases (mod.c:1206-1287, :1289-1365).
+        const bool dot = kDot && wanted && dot_group;
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t prev_last = 0xFFFFFFFFu;   // rank of the last token so far (-1: none)
+        uint32_t n = 0, E = 0, e_done = 0;   // the batch: tokens, elements, elements done
+        uint32_t r0 = 0, nb_all = 0;         // the tail: next rank, the read's bases of the class
+        bool tail = false;
         for (;;) {
-            while (qn < 64u && !closed && !bad_text) parse_chunk(wanted);
-            if (bad_text) { st = 2; break; }
-            if (qn == 0u) break;
-            const uint32_t n = qn < 64u ? qn : 64u;
-            const uint32_t nd = round(n);
+            if (!tail && e_done == E) {
+                // the batch is done: its tokens leave the ring, the next ones come in
+                if (n != 0u) {
+                    if (dot) prev_last = uniu(S.tok[(qhead + n - 1u) & (kStreamRing - 1u)]);
+                    qhead = uniu((qhead + n) & (kStreamRing - 1u)); qn = uniu(qn - n); kdone = uniu(kdone + n);
+                    n = 0;
+                }
+                while (qn < 64u && !closed && !bad_text) parse_chunk(wanted);
+                if (bad_text) { st = 2; break; }
+                e_done = 0; E = 0;
+                if (qn == 0u) {
+                    if (!dot) break;
+                    tail = true; nb_all = count_all(); r0 = prev_last + 1u;
+                } else {
+                    n = qn < 64u ? qn : 64u;
+                    E = n;
+                    if (dot) {
+                        const uint32_t rho = lane < n ? S.tok[(qhead + lane) & (kStreamRing - 1u)] : 0u;
+                        uint32_t prev = (uint32_t)__shfl_up((int)rho, 1, 64);
+                        if (lane == 0u) prev = prev_last;
+                        const uint32_t gap = lane < n ? rho - prev - 1u : 0u;   // (ranks rise strictly; -1 wraps to the right thing)
+                        const uint32_t pin = wave_incl_scan(lane < n ? gap + 1u : 0u);
+                        E = lane_valu(pin, 63);
+                        wave_sync();
+                        S.gap_p[lane] = lane < n ? pin - gap - 1u : E;   // the first element of token `lane`: its gap's first base
+                        S.gap_r[lane] = prev + 1u;                       // ... whose rank is this
+                        if (lane == 0u) S.gap_p[64] = E;
+                        wave_sync();
+                    }
+                }
+            }
+            uint32_t rank = 0, cnt = 0, kidx = 0;
+            bool is_tok = true;
+            if (tail) {
+                if (r0 >= nb_all) break;
+                cnt = nb_all - r0 < 64u ? nb_all - r0 : 64u;
+                rank = r0 + lane; is_tok = false;
+            } else if (dot) {
+                cnt = E - e_done < 64u ? E - e_done : 64u;
+                const uint32_t e = e_done + lane;
+                const uint32_t i = lane < cnt ? search_le<64>(S.gap_p, e, n) : 0u;   // the token whose gap, or self, this element is
+                rank = S.gap_r[i] + (e - S.gap_p[i]);
+                is_tok = rank == S.tok[(qhead + i) & (kStreamRing - 1u)];
+                kidx = kdone + i;
+            } else {
+                cnt = E - e_done;
+                rank = S.tok[(qhead + e_done + lane) & (kStreamRing - 1u)];
+                kidx = kdone + e_done + lane;
+            }
+            const uint32_t nd = round_core(rank, cnt, is_tok, kidx);
             const uint64_t eb = __ballot(err != 0);
             if (nd == 0u || eb) { st = 2; break; }
-            qhead = uniu((qhead + nd) & (kStreamRing - 1u)); qn = uniu(qn - nd); kdone = uniu(kdone + nd);
+            if (tail) r0 = uniu(r0 + nd);
+            else e_done = uniu(e_done + nd);
         }
         flush_pending();
         ntok = ntok_parsed;
@@ -826,13 +895,14 @@ struct KF {
                     gflags = 0; c01 = 0; c23 = 0;
                     if (g.herr || g.n > 4 || ngrp >= kStreamGroups) st = 1;
                     else {
-                        if (g.modbase == 'N' || g.flag == '.') st = 1;   // the tile pipeline has the implicit calls and the direct groups
+                        if (g.modbase == 'N') st = 1;   // the tile pipeline has the direct groups
+                        if (!kDot && g.flag == '.') { st = 1; saw_dot = true; }   // ... and, for this instantiation, the implicit calls
                         hp.err = 0;
                         hp.lookup_codes(g);
                         if (__ballot(hp.err != 0)) st = 1;
                         const int16_t a0 = S.g_code[0], a1 = S.g_code[1], a2 = S.g_code[2], a3 = S.g_code[3];
                         const bool unwanted = a0 < 0 && a1 < 0 && a2 < 0 && a3 < 0;
-                        gflags = (unwanted ? 64u : 0u) | ((uint32_t)g.n << 12);
+                        gflags = (unwanted ? 64u : 0u) | (g.flag == '.' ? 4u : 0u) | ((uint32_t)g.n << 12);
                         c01 = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
                         c23 = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
                         // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 | (plane + 1) << 23
@@ -892,6 +962,7 @@ struct KF {
             for (uint32_t gi = 0; gi < ngrp && st == 0; gi++) {
                 const uint32_t gmpos = uniu(S.g_mpos[gi]), lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
                 ncg = (int)((gflags >> 12) & 7u);
+                dot_group = (gflags & 4u) != 0u;
                 const bool wanted = !(gflags & 64u);
                 if (wanted) {
                     gc01 = c01; gc23 = c23;
@@ -924,13 +995,13 @@ struct KF {
 };
 
 // kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
-template <typename RefWord, bool kStats>
+template <typename RefWord, bool kStats, bool kDot>
 __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const TileParams P) {
     __shared__ StreamLds lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
-    KF<RefWord, kStats> k(P, lds[threadIdx.x >> 6], ptab);
+    KF<RefWord, kStats, kDot> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
     if (P.reset_in_stream && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
@@ -959,6 +1030,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
             const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
             P.tile_items[at] = ridx;
             if (P.host_tile_flag) *P.host_tile_flag = 1u;
+            if (!kDot && k.saw_dot && P.host_dot_flag) *P.host_dot_flag = 1u;
         }
         if (st == 2 && lane_id() == 0) {   // an input error somewhere in the read: the fused kernel names it
             const unsigned int at = atomicAdd(P.fb_count, 1u);

@@ -85,6 +85,7 @@ struct TileParams {
     unsigned int* tile_plan_count;    // == plan_count, writable
     unsigned int* host_tile_flag;     // pinned host word: set when k_stream_reads hands a read to the tile pipeline (when every read of
                                       // the launch is a stream item, the tile kernels are only launched if this says so)
+    unsigned int* host_dot_flag;      // pinned host word: set when the lean k_stream_reads handed a read on because of a '.' group
     int32_t reset_in_stream;          // 1: k_stream_reads is the launch's last kernel and resets the next launch's control words
 };
 constexpr uint32_t kPartSlots = 16;                       // parts per read (4 bits in a work item)

@@ -204,7 +204,7 @@ class FreqEngine(object):
         o.view = int(view)
         o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
         o.split_bases, o.coalesce = int(split_bases), int(coalesce)
-        o.stream_mode = int(stream_mode)   # 0 by launch size, 1 never, 2 always (reads up to split_bases)
+        o.stream_mode = int(stream_mode)   # 0 by launch size, 1 never, 2 always (reads up to split_bases), 3 always + '.' groups from the first launch
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
             o.mods[i].context = ctx.encode()

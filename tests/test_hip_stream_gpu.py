@@ -39,7 +39,7 @@ def oracle_rows(recs, ref, c, th=None):
 def hip_rows(recs, ref, c, th=None, **kw):
     """rows and the routing statistics of one batch"""
     mods = O.parse_mod_codes(c)
-    kw.setdefault("stream_mode", 2)   # these batches are far too small for the default to stream anything
+    kw.setdefault("stream_mode", 3)   # these batches are far too small for the default to stream anything; 3: '.' groups too
     eng = make_engine(mods, O.parse_mod_threshes(th, len(mods)), ["chrT"], [len(ref)], {"chrT": ref.encode()}, **kw)
     eng.stats_enable(True)
     eng.process(pybam.flatten(recs))
@@ -73,6 +73,8 @@ def both_ways(recs, ref, c, th=None, expect_stream=None):
     got2, st2 = hip_rows(recs, ref, c, th, stream_mode=1)
     assert got2 == want
     assert st2["stream_done"] == 0 and st2["stream_to_tiles"] == 0
+    got3, st3 = hip_rows(recs, ref, c, th, stream_mode=2)   # the lean instantiation: reads with '.' groups go through the tiles
+    assert got3 == want and st3["stream_done"] + st3["stream_to_tiles"] >= st["stream_done"]
     if expect_stream is not None:
         assert st["stream_done"] == expect_stream, st
     return st
@@ -169,13 +171,14 @@ def test_groups_in_sequence_and_what_is_handed_on():
     st = both_ways(recs, ref, "m,h", expect_stream=3)
     assert st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0
     st = both_ways(recs, ref, "m[CG]", expect_stream=3)
-    # not this kernel's reads: a '.' group, a group on N, groups on two bases -> the tile pipeline (or its fallback); same rows
+    # not this kernel's reads: a group on N, groups on two bases -> the tile pipeline (or its fallback); same rows.  (A '.' group
+    # is this kernel's: its unlisted bases are calls too.)
     other = [pybam.make_record(0, 2000, 0, seq, "12000M", "C+m.,3,5,7;", [200, 10, 255]),
              pybam.make_record(0, 2000, 0, seq, "12000M", "N+m?,30,50,70;", [200, 10, 255]),
              pybam.make_record(0, 2000, 0, seq, "12000M", "C+m?,3,5,7;G+m?,1,1;", [200, 10, 255, 3, 250]),
              pybam.make_record(0, 2000, 0, seq, "12000M", "", [])]
-    st = both_ways(recs + other, ref, "m", expect_stream=4)   # the read with an empty MM is done by the stream kernel (nothing to do)
-    assert st["stream_to_tiles"] == 3 and st["stream_to_fused"] == 0
+    st = both_ways(recs + other, ref, "m", expect_stream=5)   # the read with an empty MM is done by the stream kernel (nothing to do)
+    assert st["stream_to_tiles"] == 2 and st["stream_to_fused"] == 0
 
 
 def test_errors_after_the_first_counts_go_to_the_fused_kernel():
@@ -202,7 +205,7 @@ def test_errors_after_the_first_counts_go_to_the_fused_kernel():
         with pytest.raises(O.OracleError) as oe:
             o.process(pybam.flatten([good, rec, good]))
         o.close()
-        eng = make_engine(O.parse_mod_codes("m[*]"), [0.8], ["chrT"], [len(ref)], {"chrT": ref.encode()}, stream_mode=2)
+        eng = make_engine(O.parse_mod_codes("m[*]"), [0.8], ["chrT"], [len(ref)], {"chrT": ref.encode()}, stream_mode=3)
         with pytest.raises(minimod_amd.MinimodHipError) as he:
             eng.process(pybam.flatten([good, rec, good]))
         eng.close()
@@ -210,8 +213,8 @@ def test_errors_after_the_first_counts_go_to_the_fused_kernel():
 
 
 def test_synthetic_reads_are_streamed():
-    """ONT- and HiFi-shape synthetic reads (the bench's generators): every `?` read of at most split_bases bases is done by
-    the stream kernel, '.' reads and longer ones by the tile pipeline; rows equal the oracle's."""
+    """ONT- and HiFi-shape synthetic reads (the bench's generators): every read of at most split_bases bases is done by the
+    stream kernel ('.' reads with their implicit calls included), longer ones by the tile pipeline; rows equal the oracle's."""
     import minimod_amd
     from minimod_amd import synth
     ref = synth.reference(23, 4 << 20)
@@ -220,7 +223,7 @@ def test_synthetic_reads_are_streamed():
                           (dict(n=300, max_len=0.0), [("h", "CG")], [0.6])):
         g = dict(gen); n = g.pop("n")
         b = synth.batch(ref, 0, n, seed=91, n_reads_total=n, **g)
-        eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], stream_mode=2)
+        eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], stream_mode=3)
         eng.stats_enable(True)
         eng.process(b)
         st = eng.stats_get()
@@ -232,9 +235,9 @@ def test_synthetic_reads_are_streamed():
         rd = b["reads"]
         dots = np.array([bytes(b["mm"][int(o):int(o) + 4]).endswith(b".") for o in rd["mm_off"]])
         short = rd["l_qseq"] <= 24576
-        assert st["stream_done"] == int((short & ~dots).sum()), st
-        assert st["stream_to_tiles"] == int((short & dots).sum()), st
-        assert st["stream_to_fused"] == 0
+        assert dots.any() or g.get("dot_fraction", 0) == 0
+        assert st["stream_done"] == int(short.sum()), st          # '?' and '.' reads alike
+        assert st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0, st
 
 
 def _random_read(rng, ref, flag):
@@ -318,3 +321,74 @@ def test_full_size_timed_launch_equals_the_oracle(tmp_path):
     assert len(want) > 500000 and len(got) == len(want)
     for k in ("pos", "strand", "n_called", "n_mod"):
         assert (got[k] == want[k]).all(), k
+
+
+@pytest.mark.parametrize("flag", [0, 16], ids=["fwd", "rev"])
+def test_dot_groups_and_their_implicit_calls(flag):
+    """'.' groups: every base of the class the list skips is a call too (called, not modified), and so are the bases behind the
+    last listed one.  Dense lists (no gaps at all), sparse ones (gaps of thousands: far more implicit calls than tokens), an
+    empty list (the whole read implicit), a two-letter group, a '.' group next to a '?' group and to one nobody asked for."""
+    rng = np.random.default_rng(81 + flag)
+    ref = make_ref(rng, 50000)
+    recs = []
+    def dot(mm):
+        return mm.replace("?", ".", 1)
+    seq = ref[1000:9000]
+    n_c = (revcomp(seq) if flag else seq).count("C")
+    for picks in (list(range(n_c)), list(range(0, n_c, 2)), [7, n_c // 3, n_c // 3 + 1, n_c - 400], list(range(5, n_c, 97)), []):
+        r = listed_read(ref, 1000, "8000M", seq, "C", picks, rng, flag)
+        mm = r.mm().decode() if isinstance(r.mm(), bytes) else r.mm()
+        recs.append(pybam.make_record(0, 1000, flag, seq, "8000M", dot(mm), list(r.ml() or b"")))
+    # soft clips and an insertion / deletion in the way of the implicit calls, a CIGAR shorter than the sequence
+    seq2 = make_ref(rng, 300) + ref[20000:23000] + make_ref(rng, 40) + ref[23500:26000] + make_ref(rng, 200)
+    n_c2 = (revcomp(seq2) if flag else seq2).count("C")
+    r = listed_read(ref, 20000, "300S3000M40I500D2500M200S", seq2, "C", list(range(0, n_c2, 5)), rng, flag)
+    recs.append(pybam.make_record(0, 20000, flag, seq2, "300S3000M40I500D2500M200S", dot(r.mm().decode() if isinstance(r.mm(), bytes) else r.mm()), list(r.ml() or b"")))
+    seq3 = ref[30000:34000]
+    n_c3 = (revcomp(seq3) if flag else seq3).count("C")
+    r = listed_read(ref, 30000, "3500M", seq3, "C", list(range(0, n_c3, 3)), rng, flag)
+    recs.append(pybam.make_record(0, 30000, flag, seq3, "3500M", dot(r.mm().decode() if isinstance(r.mm(), bytes) else r.mm()), list(r.ml() or b"")))
+    # a two-letter '.' group, then a '?' group, then a '.' group with a code nobody asked for
+    s4 = ref[40000:46000]
+    o4 = revcomp(s4) if flag else s4
+    nc4 = o4.count("C")
+    def toks(p):
+        out, prev = [], -1
+        for k in p:
+            out.append(str(k - prev - 1)); prev = k
+        return out
+    t1, t2, t3 = list(range(0, nc4, 6)), list(range(1, nc4, 9)), list(range(2, nc4, 11))
+    mm = "C+hm." + "".join("," + t for t in toks(t1)) + ";C+m?" + "".join("," + t for t in toks(t2)) + ";C+x." + "".join("," + t for t in toks(t3)) + ";"
+    ml = [int(x) for x in rng.integers(0, 256, size=2 * len(t1) + len(t2) + len(t3))]
+    recs.append(pybam.make_record(0, 40000, flag, s4, "6000M", mm, ml))
+    for c in ("m[*]", "m", "m,h", "h[CG]"):
+        st = both_ways(recs, ref, c, expect_stream=len(recs))
+        assert st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0, st
+
+
+def test_the_kernel_switches_to_its_dot_instantiation_by_itself():
+    """stream_mode 2 (and the default): the lean instantiation runs until a read with a '.' group shows up -- that launch's '.'
+    reads go through the tile pipeline -- and the '.'-capable one from the next launch on.  Same rows either way."""
+    import minimod_amd
+    from minimod_amd import synth
+    ref = synth.reference(29, 4 << 20)
+    b = synth.batch(ref, 0, 400, seed=93, n_reads_total=400, max_len=20000.0, dot_fraction=0.5)
+    dots = int(np.array([bytes(b["mm"][int(o):int(o) + 4]).endswith(b".") for o in b["reads"]["mm_off"]]).sum())
+    assert 100 < dots < 300
+    eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], stream_mode=2)
+    eng.stats_enable(True)
+    eng.process(b)
+    st1 = eng.stats_get()
+    eng.process(b)
+    st2 = eng.stats_get()
+    eng.process(b)
+    st3 = eng.stats_get()
+    got = eng.finalize(); eng.close()
+    assert st1["stream_to_tiles"] == dots and st1["stream_done"] == 400 - dots, st1
+    assert st3["stream_to_tiles"] == 0 and st3["stream_done"] == 400, (st2, st3)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"]); orc.add_contig("chrS", ref)
+    for _ in range(3):
+        orc.process(b, threads=8)
+    want = orc.rows()
+    key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+    assert key(got, None) == key(want, None)
