@@ -82,7 +82,8 @@ def parse_args():
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
     ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
                                                                "instead of the 24-contig genome")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"], help="BASELINE.json workload: C2 = the headline (default)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5", "DOT"], help="BASELINE.json workload: C2 = the headline (default); DOT (not a BASELINE config): C2's reads "
+                                                                                     "with the MM '.' flag (every unlisted C an implicit call)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
     ap.add_argument("--cpu-t1-batches", type=int, default=2, help="batches in the BAM the `-t 1` CPU run reads")
@@ -242,6 +243,9 @@ WORKLOADS = {
     "C3": dict(gen=dict(shape=1), mods=[("m", "CG", 0.8), ("h", "CG", 0.7)], eng=dict(), cli=["-c", "m[CG],h[CG]", "-m", "0.8,0.7"],
                what="C3: %(reads)d PacBio-HiFi-shape reads (~15 kb, MM '?' flag) per GPU on a %(mb).1f Mb interval, -c m[CG],h[CG] -m 0.8,0.7, "
                     "-K %(batch)d, batches resident in HBM"),
+    "DOT": dict(gen=dict(dot_fraction=1.0), mods=[("m", "CG", 0.8)], eng=dict(), cli=["-c", "m[CG]", "-m", "0.8"],
+                what="DOT: %(reads)d ONT-shape reads (~15 kb) with the MM '.' flag (all unlisted Cs are implicit calls) per GPU on a %(mb).1f Mb interval, "
+                     "-c m[CG] -m 0.8, -K %(batch)d, batches resident in HBM"),
     "C5": dict(gen=dict(haplotypes=True, long_insertions=True), mods=[("m", "CG", 0.8)], eng=dict(insertions=True, haplotypes=True),
                cli=["-c", "m[CG]", "-m", "0.8", "--insertions", "--haplotypes"], region=5 << 20, reads=66000,
                what="C5: %(reads)d ONT-shape reads = 200x on a %(mb).1f Mb region, HP tags, CpG-carrying insertions, -c m[CG] -m 0.8 "
