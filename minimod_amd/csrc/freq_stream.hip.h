@@ -646,7 +646,9 @@ struct KF {
                         int is_mod = 0;
                         if (expl) {
                             const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
-                            if (ml_idx >= ml_len) { err = MM_E_MLIDX; break; }
+                            if (ml_idx >= ml_len) { err = MM_E_MLIDX; continue; }   // (not `break`: a divergent exit would make m, and all that
+                                                                                     // hangs on it -- the code's table word, its plane, the 64-bit
+                                                                                     // counter offset -- vector values; the read fails either way)
                             const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
                             if (kStats) st_ml++;
                             if (mv >= t_hi) is_mod = 1;
