@@ -419,7 +419,7 @@ def main():
 
     contig = [(n, l, refs[t]) for t, (n, l) in enumerate(plan["contigs"])]
     if args.mode == "view":
-        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, view=True, **wl["eng"])
+        eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank, view=True, coalesce=args.coalesce, **wl["eng"])
     else:
         eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank,
                                      intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
@@ -686,7 +686,9 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
         tickets, bases, kms, abytes, rows = [], 0, [], 0, 0
         for s in range(n):
             bi = (first_step + s) % n_batches
-            tickets.append(eng.submit_device(dev_batches[bi], stream))
+            tk = eng.submit_device(dev_batches[bi], stream)
+            if not tickets or tickets[-1] != tk:   # (consecutive windows may share a launch and its ticket: --coalesce)
+                tickets.append(tk)
             bases += batch_bases[bi]
             abytes += alg_bytes[bi]
             if len(tickets) >= 3:

@@ -896,7 +896,7 @@ const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    const bool gather = h->opts.coalesce > 1 && !h->opts.view && h->use_tiles && !b->order && b->n_reads > 0;
+    const bool gather = h->opts.coalesce > 1 && h->use_tiles && !b->order && b->n_reads > 0;   // (view too: a ticket's rows are then those of the group, `read` counted from its first read)
     if (gather && h->pending_slot >= 0) {
         // does this submit continue the gathered group?  (windows of one resident read set, one after the other)
         const mm_batch_t& g = h->pending_batch;
@@ -1330,6 +1330,7 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
     if (!h || !h->opts.view || ticket < 0 || ticket >= kSlots) return -MM_E_ARG;
     Slot& s = h->slots[ticket];
     HIPCHK(hipSetDevice(h->device));
+    if (ticket == h->pending_slot) { int rf = flush_pending(h); if (rf) return rf; }   // a gathered group is launched by whoever needs it
     if (!s.timed) return -MM_E_ARG;
     hipStream_t st = s.last_stream;
     auto copy_out = [&](size_t nsel) -> int {

@@ -102,3 +102,57 @@ def test_view_region_overflow_reruns(chr22):
     want = _text(hip_view(path, chr22, **kw), kw)
     got = _text(hip_view(path, chr22, view_cap=16, **kw), kw)
     assert got == want
+
+
+GATHER_VIEW_WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+ref = synth.reference(21, 4 << 20)
+bs = [synth.batch(ref, i * 300, 300, seed=9, n_reads_total=1500, with_order=False, dot_fraction=0.3) for i in range(5)]
+whole = synth.concat(bs)
+dev = {k: torch.from_numpy(whole[k].view(np.uint8).reshape(-1)).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+def window(i):
+    return dict(reads=dev["reads"].data_ptr() + 64 * 300 * i, cigar=dev["cigar"].data_ptr(), seq=dev["seq"].data_ptr(), mm=dev["mm"].data_ptr(),
+                ml=dev["ml"].data_ptr(), n_reads=300, n_cigar_words=len(whole["cigar"]), n_seq_bytes=len(whole["seq"]), n_mm_bytes=len(whole["mm"]),
+                n_ml_bytes=len(whole["ml"]), max_n_cigar=int(bs[i]["max_n_cigar"]), max_l_qseq=int(bs[i]["max_l_qseq"]))
+mods, th = [("m", "CG"), ("h", "CG")], [0.8, 0.7]
+# the oracle on the windows of a group taken as one batch: `read` counts from the group's first read
+def oracle_rows(lo, hi):
+    orc = O.Oracle(mods, th, ["chrS"]); orc.set_view(True); orc.add_contig("chrS", ref)
+    orc.process(synth.concat(bs[lo:hi]), threads=8)
+    return orc.view_rows()
+vk = lambda r, io: list(zip(r["read"].tolist(), r["pos"].tolist(), r["read_pos"].tolist(), r["code"].tolist(), r[io].tolist(), r["prob"].tolist()))
+eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], view=True, coalesce=3)
+tickets = [eng.submit_device(window(i)) for i in range(5)]
+out = {"tickets": tickets, "sizes": []}
+groups = [(0, 3), (3, 5)]
+ok, rows = True, 0
+for (lo, hi), tk in zip(groups, list(dict.fromkeys(tickets))):
+    out["sizes"].append(eng.ticket_batches(tk))
+    got = eng.fetch_view(tk)
+    want = oracle_rows(lo, hi)
+    rows += len(want)
+    ok = ok and vk(got, "ins_offset") == vk(want, "ins_off")
+eng.close()
+out["equal"], out["rows"] = ok, rows
+print(json.dumps(out))
+'''
+
+
+def test_gathered_windows_in_view_mode():
+    """mm_freq_opts_t.coalesce in view mode: consecutive windows of a resident read set share a launch and a ticket; the
+    ticket's rows are those of the group in print_view_output order, `read` counted from the group's first read -- the
+    oracle's rows on the same windows taken as one batch, element for element (a third of the reads carry '.' groups)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", GATHER_VIEW_WORKER % root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["tickets"][0] == res["tickets"][2] != res["tickets"][3] and res["sizes"] == [3, 2]
+    assert res["rows"] > 10000 and res["equal"], res
