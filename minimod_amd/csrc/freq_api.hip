@@ -370,10 +370,12 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 // -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
                 const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 4500;
                 const int mode = h->opts.stream_mode;
-                stream = mode != 1 && !p.view && !p.insertions && !p.haplotypes && (mode >= 2 || hide >= split);
+                stream = mode != 1 && !p.insertions && !p.haplotypes && (mode >= 2 || hide >= split);   // (view as well: the records go where the tile kernels' go)
                 const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
                 if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
-                all_stream = stream && b->max_l_qseq <= stream_max;   // every read is a stream item: k_stream_reads is the launch's last kernel
+                // every read is a stream item: k_stream_reads is the launch's last kernel (not in view mode: the ordering pass is
+                // enqueued behind the call kernels and would have to run again behind tile kernels launched at wait time)
+                all_stream = stream && !p.view && b->max_l_qseq <= stream_max;
                 s.h_ctl[131] = 0u;
                 tp.host_tile_flag = s.h_ctl + 131;
                 tp.reset_in_stream = all_stream ? 1 : 0;
@@ -406,7 +408,8 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 s.h_ctl[132] = 0u;
                 tp.host_dot_flag = s.h_ctl + 132;
                 const bool kd = h->stream_dot || h->opts.stream_mode == 3;
-#define MM_LAUNCH_STREAM(T, ST, DT) hipLaunchKernelGGL((k_stream_reads<T, ST, DT>), dim3(gf), dim3(256), 0, st, tp)
+#define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true>), dim3(gf), dim3(256), 0, st, tp); \
+                                           else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
                 if (p.stats) {
                     if (h->wide) { if (kd) MM_LAUNCH_STREAM(uint32_t, true, true); else MM_LAUNCH_STREAM(uint32_t, true, false); }
                     else { if (kd) MM_LAUNCH_STREAM(uint16_t, true, true); else MM_LAUNCH_STREAM(uint16_t, true, false); }
@@ -674,8 +677,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
         int nf = 0;
-        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false, true>), 256, 0);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false, true>), 256, 0);
+        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false, true, false>), 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false, true, false>), 256, 0);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);

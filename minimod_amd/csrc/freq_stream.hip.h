@@ -155,7 +155,8 @@ __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key,
 
 // kDot: '.' groups (implicit calls) are this kernel's too; without it (the leaner instantiation) reads that have one go to the
 // tile pipeline and a flag tells the host to launch the other instantiation from then on (a file's reads carry one flag or the other)
-template <typename RefWord, bool kStats, bool kDot>
+// kView: `minimod view` -- a call that passes the context test becomes a record (view_append) instead of a counter update
+template <typename RefWord, bool kStats, bool kDot, bool kView>
 struct KF {
     const TileParams& P;
     const DevParams& p;
@@ -171,6 +172,7 @@ struct KF {
     const RefWord* rwb;
     uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32, cpat;
     int32_t pos, rev, ridx_cur;
+    uint32_t v_region, v_gord;   // view: append region of the wavefront, ordinal of the group at hand
     // the group
     int32_t ncg;
     bool dot_group;             // a '.' group: unlisted bases are calls too
@@ -644,6 +646,10 @@ struct KF {
                         const bool matches = ((cinfo >> 18) & 1u) || refcode == code;
                         if (!(in_ctx && matches)) continue;
                         int is_mod = 0;
+                        if (kView && !expl) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
+                            view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord, 1u, 0u);
+                            continue;
+                        }
                         if (expl) {
                             const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
                             if (ml_idx >= ml_len) { err = MM_E_MLIDX; continue; }   // (not `break`: a divergent exit would make m, and all that
@@ -651,6 +657,10 @@ struct KF {
                                                                                      // counter offset -- vector values; the read fails either way)
                             const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
                             if (kStats) st_ml++;
+                            if (kView) {   // mod.c:1194-1196: no threshold, the ML byte itself
+                                view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord, 0u, (uint32_t)mv);
+                                continue;
+                            }
                             if (mv >= t_hi) is_mod = 1;
                             else if (mv <= t_lo) is_mod = 0;
                             else continue;
@@ -965,6 +975,7 @@ struct KF {
                 const uint32_t gmpos = uniu(S.g_mpos[gi]), lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
                 ncg = (int)((gflags >> 12) & 7u);
                 dot_group = (gflags & 4u) != 0u;
+                v_gord = gi;
                 const bool wanted = !(gflags & 64u);
                 if (wanted) {
                     gc01 = c01; gc23 = c23;
@@ -997,13 +1008,13 @@ struct KF {
 };
 
 // kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
-template <typename RefWord, bool kStats, bool kDot>
+template <typename RefWord, bool kStats, bool kDot, bool kView>
 __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const TileParams P) {
     __shared__ StreamLds lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
-    KF<RefWord, kStats, kDot> k(P, lds[threadIdx.x >> 6], ptab);
+    KF<RefWord, kStats, kDot, kView> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
     if (P.reset_in_stream && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
@@ -1016,6 +1027,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
     const int n = (int)scalar_load(P.stream_count);
     const int g = uni((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
     const bool dynamic = n_waves >= (int)kTileRegions;
+    k.v_region = (uint32_t)g % kViewRegions;
     for (int r = g; r < n;) {
         const int r_cur = r;
         if (dynamic) {

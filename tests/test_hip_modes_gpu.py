@@ -46,7 +46,7 @@ for name, cs in cases.items():
     key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
     out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max())}
     # the same batch through view mode: rows in print_view_output order, element for element
-    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, force_fused=FUSED, **cs["kw"])
+    eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, force_fused=FUSED, stream_mode=STREAM_MODE, **cs["kw"])
     v = eng.view(b); eng.close()
     orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.set_view(True); orc.add_contig("chrS", ref); orc.process(b, threads=8)
     w = orc.view_rows()
@@ -56,7 +56,7 @@ print(json.dumps(out))
 '''
 
 
-@pytest.mark.parametrize("fused,stream_mode", [(0, 2), (0, 1), (1, 1)], ids=["stream+tiles", "tiles", "fused"])
+@pytest.mark.parametrize("fused,stream_mode", [(0, 2), (0, 3), (0, 1), (1, 1)], ids=["stream+tiles", "stream-dot+tiles", "tiles", "fused"])
 def test_synthetic_shapes_match_oracle(fused, stream_mode):
     r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, fused, stream_mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]

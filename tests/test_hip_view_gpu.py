@@ -128,7 +128,7 @@ def oracle_rows(lo, hi):
     orc.process(synth.concat(bs[lo:hi]), threads=8)
     return orc.view_rows()
 vk = lambda r, io: list(zip(r["read"].tolist(), r["pos"].tolist(), r["read_pos"].tolist(), r["code"].tolist(), r[io].tolist(), r["prob"].tolist()))
-eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], view=True, coalesce=3)
+eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], view=True, coalesce=3, stream_mode=3)
 tickets = [eng.submit_device(window(i)) for i in range(5)]
 out = {"tickets": tickets, "sizes": []}
 groups = [(0, 3), (3, 5)]
