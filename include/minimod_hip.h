@@ -111,7 +111,7 @@ typedef struct mm_freq_opts {
     int32_t coalesce;        /* mm_freq_submit_device: up to this many consecutive windows of one resident read set share one launch
                               * (see there); 0 or 1 = every submit is its own launch */
     int32_t stream_mode;     /* which reads take the streaming kernel (k_stream_reads: a whole read in one wavefront) instead of the
-                              * tile pipeline, in plain freq runs (no --insertions, no --haplotypes, not view).  0 (default): by the
+                              * tile pipeline, in plain runs (freq or view; no --insertions, no --haplotypes).  0 (default): by the
                               * size of the launch -- none in a launch of fewer than about 15 000 reads (a single -K 4096 batch:
                               * the longest read would be the launch), in bigger (gathered) launches every read short enough to
                               * hide; 1: none; 2: every read of up to split_bases bases whatever the launch (tests);

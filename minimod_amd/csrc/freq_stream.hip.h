@@ -3,7 +3,7 @@
 //
 // The tile pipeline (freq_tiles.hip.h) cuts a read into independent tiles and pays for the independence: per-op CIGAR
 // prefix arrays and a rank directory are written to a scratch and read back, every tile re-derives its carries, stages
-// its own slices, and the three kernels read the read record three times.  For the common read -- plain `freq` (no
+// its own slices, and the three kernels read the read record three times.  For the common read -- plain `freq` or `view` (no
 // --insertions, no --haplotypes), every MM group a `?`-flagged skip list on one canonical base, in a launch big enough to
 // hide a read inside it -- none of that is needed, because everything a read's calls touch moves in ONE direction:
 //
