@@ -4,12 +4,16 @@ window, lists denser than the blocks, CIGARs with more ops than the window holds
 than the 14-bit offsets of the packed words, reads whose CIGAR is shorter than the sequence -- in both orientations, with
 the routing checked through the statistics pass (reads done by the kernel / handed to the tile pipeline / to the fused
 kernel).  HIP vs the oracle, bit-exact; the same input through the tile pipeline alone (stream_mode 1) as a second witness."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle as O
 from oracle import pybam
 from tests.hiprun import make_engine, to_oracle_rows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -392,3 +396,45 @@ def test_the_kernel_switches_to_its_dot_instantiation_by_itself():
     want = orc.rows()
     key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
     assert key(got, None) == key(want, None)
+
+
+WAIT_TIME_WORKER = r'''
+import json, sys
+sys.path.insert(0, %r)
+import os
+
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
+import minimod_amd
+from minimod_amd import synth
+from oracle import oracle as O
+ref = synth.reference(37, 4 << 20)
+b = synth.batch(ref, 0, 500, seed=95, n_reads_total=500, max_len=0.0, dot_fraction=0.0, with_order=False)
+dev = {k: torch.from_numpy(b[k].view(np.uint8).reshape(-1)).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+win = dict(reads=dev["reads"].data_ptr(), cigar=dev["cigar"].data_ptr(), seq=dev["seq"].data_ptr(), mm=dev["mm"].data_ptr(), ml=dev["ml"].data_ptr(),
+           n_reads=500, n_cigar_words=len(b["cigar"]), n_seq_bytes=len(b["seq"]), n_mm_bytes=len(b["mm"]), n_ml_bytes=len(b["ml"]),
+           max_n_cigar=int(b["max_n_cigar"]), max_l_qseq=100)
+eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], stream_mode=2)
+eng.stats_enable(True)
+eng.wait(eng.submit_device(win))
+st = eng.stats_get()
+got = eng.finalize(); eng.close()
+orc = O.Oracle([("m", "CG")], [0.8], ["chrS"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
+want = orc.rows()
+key = lambda r: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+print(json.dumps({"equal": key(got) == key(want), "rows": int(len(want)), "stream_done": int(st["stream_done"]),
+                  "long_reads": int((b["reads"]["l_qseq"] > 24576).sum()), "max_l": int(b["reads"]["l_qseq"].max())}))
+'''
+
+
+def test_tile_kernels_run_at_wait_time_when_the_launch_left_them_out():
+    """When the batch's longest read is a stream item by the host's reckoning the tile kernels are not launched with the
+    batch; they run at wait time if k_stream_reads handed a read on, or if the planner found tile items after all -- here
+    because the caller's max_l_qseq is wrong (reads of 40 kb and more in a batch that says 100)."""
+    import subprocess, sys, json
+    r = subprocess.run([sys.executable, "-c", WAIT_TIME_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["max_l"] > 40000 and res["long_reads"] > 10, res
+    assert res["equal"] and res["rows"] > 1000 and res["stream_done"] == 500 - res["long_reads"], res
