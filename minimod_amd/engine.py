@@ -2,7 +2,9 @@
 reference seams cited in that header: create = load_ref + load_ref_contexts + init_core, submit = process_db,
 finalize = output_core."""
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -73,6 +75,26 @@ class MinimodHipError(RuntimeError):
         self.read = read
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels carry their own libamdhip64 (same soname as /opt/rocm's) and load it by path; a process that has both
+    copies only gets a GPU from the one loaded first.  When torch is installed but not imported yet, load its copy first so
+    that this library binds to it by soname and a later `import torch` (device buffers for submit_device) still works."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(build=True):
     """Load the HIP library; fails loudly when it is missing (there is no fallback path)."""
     global _lib
@@ -83,6 +105,7 @@ def load_library(build=True):
         build_hip()
     if not os.path.exists(path):
         raise MinimodHipError(-1, "HIP extension %s is missing: run __graft_entry__.build()" % path)
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(path)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.mm_abi_version.restype = i32

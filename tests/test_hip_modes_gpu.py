@@ -349,3 +349,28 @@ def test_gathered_windows_with_reads_for_the_fused_kernel():
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     for name in ("m", "m_ins_hap"):
         assert res[name]["equal"] and res[name]["rows"] > 5 and res[name]["one_ticket"] and res[name]["members"] == 3, res
+
+
+ORDER_WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+import minimod_amd
+from tests.cases import KAT_REF, kat_records
+from oracle import pybam
+eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrT", len(KAT_REF), KAT_REF.encode())])
+eng.wait(eng.submit(pybam.flatten(kat_records())))
+import torch
+x = torch.arange(8, device="cuda").sum().item()
+rows = eng.finalize(); eng.close()
+hip = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+print(x, len(rows["pos"]), len(hip))
+'''
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """The ctypes loader and torch must end up on one copy of libamdhip64 whichever comes first (INTEGRATION.md section 4):
+    create an engine and run a batch before torch is imported, then use the GPU from torch."""
+    r = subprocess.run([sys.executable, "-c", ORDER_WORKER % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    x, n_rows, n_hip = r.stdout.decode().strip().splitlines()[-1].split()
+    assert int(x) == 28 and int(n_rows) > 0 and int(n_hip) == 1
