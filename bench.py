@@ -631,9 +631,10 @@ def main():
                                        "handed_to_the_fused_kernel": int(routing[2]), "reads": routed_reads,
                                        "note": "one pass over the first min(steps, batches) windows, gathered like the timed steps; reads too long "
                                                "to hide in the launch are the tile pipeline's from the start (all of them in a single-batch launch)"}
-        if phases[3:].any():   # diagnostic builds (-DMM_STREAM_TIMING): the tally pass, then the timed steps
+        timed_phases = eng.stats_get()["phase_cycles"]
+        if phases[3:].any() or any(timed_phases[3:]):   # diagnostic builds (-DMM_STREAM_TIMING): the tally pass, then the timed steps
             result["phase_cycles"] = [int(x) for x in phases]
-            result["phase_cycles_timed"] = [int(x) for x in eng.stats_get()["phase_cycles"]]
+            result["phase_cycles_timed"] = [int(x) for x in timed_phases]
         if world > 1:
             result["final_reduce"] = {"ms": reduce_s * 1e3, "value_incl": total_bases / (elapsed + reduce_s) / 1e6, "unit": "Mbases/s",
                                       "ranks": world, "slab_bytes": slab_words * 8, "backend": args.backend,

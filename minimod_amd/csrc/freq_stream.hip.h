@@ -414,8 +414,7 @@ struct KF {
                     if (!stop) {
                         const bool valid = s_next + lane < ncig;
                         const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
-                        const uint32_t qinc = (valid && ((0x193u >> op) & 1u)) ? len : 0u;
-                        const uint32_t rinc = (valid && ((0x18Du >> op) & 1u)) ? len : 0u;
+                        const uint32_t qinc = len & op_mask(0x193u, op), rinc = len & op_mask(0x18Du, op);   // (steps past the CIGAR's end were loaded as zeros)
                         // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
                         uint32_t qs, rs;
                         if (!__ballot(valid && len >= 1024u)) {
@@ -837,7 +836,7 @@ struct KF {
         if (st == 0) {
             // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, and the checks reduced to
             // what a clean record passes outright; anything else is the tile pipeline's to judge op by op
-            uint32_t sumq = 0, sumr = 0;
+            uint32_t sumq = 0, sumr = 0, okops = 0xFFFFFFFFu, lenor = 0;
             bool badop = false;
 #ifdef MM_ABL_NOVALIDATE
             for (uint32_t i0 = 0; i0 < 0u; i0 += 1024u) {
@@ -854,18 +853,22 @@ struct KF {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
-                    const uint32_t w4[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+                    // a word behind the read's last op counts as 0M: nothing to either sum, nothing wrong with it
+                    const uint32_t w4[4] = {cv[u].x, i + 1u < ncig ? cv[u].y : 0u, i + 2u < ncig ? cv[u].z : 0u, i + 3u < ncig ? cv[u].w : 0u};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const bool valid = i + (uint32_t)k < ncig;
                         const uint32_t op = w4[k] & 15u, len = w4[k] >> 4;
-                        sumq += (valid && ((0x193u >> op) & 1u)) ? len : 0u;
-                        sumr += (valid && ((0x18Du >> op) & 1u)) ? len : 0u;
-                        // (a lane's sums cannot wrap unseen: every length is below 2^27 and the sums are looked at after every op)
-                        badop = badop || (valid && (op == 5u || op == 6u || op > 8u || len >= (1u << 27))) || sumq >= (1u << 28) || sumr >= (1u << 28);
+                        sumq += len & op_mask(0x193u, op);
+                        sumr += len & op_mask(0x18Du, op);
+                        okops &= op_mask(0x19Fu, op);   // M I D N S = X are this kernel's ops
+                        lenor |= len;
                     }
                 }
+                // (a lane's sums cannot wrap unseen: sixteen lengths below 2^27 on top of a sum below 2^28; longer ops and larger
+                // sums are the tile pipeline's to judge)
+                badop = badop || sumq >= (1u << 28) || sumr >= (1u << 28);
             }
+            badop = badop || okops == 0u || lenor >= (1u << 27);
             // 64 lanes x 2^28 does not fit a word: the halves are added separately
             const uint64_t tq = (uint64_t)lane_valu(wave_incl_scan(sumq & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumq >> 16), 63) << 16);
             const uint64_t tr = (uint64_t)lane_valu(wave_incl_scan(sumr & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumr >> 16), 63) << 16);
