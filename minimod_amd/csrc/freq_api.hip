@@ -102,7 +102,7 @@ struct mm_freq {
     int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6;
     bool stream_dot = false; // a read with a '.' group has been seen: k_stream_reads' '.'-capable instantiation from now on
     bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
-    bool wide = false;  // 32-bit reference words (n_mods > 5)
+    int ref_kind = 1;   // reference words: 0 four bits a base (one mod, RefNib), 1 16-bit (up to 5 mods), 2 32-bit
     int n_contigs = 0;
     std::vector<std::string> names;
     std::vector<int64_t> ctg_len, ref_base, seg_begin, seg_len, cnt_base;
@@ -244,24 +244,22 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
     return 0;
 }
 
+// the reference word type of a handle: RW inside the statement
+#define MM_REF_DISPATCH(h, ...) do { \
+        if ((h)->ref_kind == 2) { using RW = uint32_t; __VA_ARGS__; } \
+        else if ((h)->ref_kind == 1) { using RW = uint16_t; __VA_ARGS__; } \
+        else { using RW = RefNib; __VA_ARGS__; } } while (0)
+
 void launch_tile_kernels(mm_freq* h, const TileParams& tp, int ga, int gs, int gc, hipStream_t st) {
     const DevParams& p = tp.d;
     const bool plain = !p.insertions && !p.haplotypes;
-    if (h->wide) {
-        hipLaunchKernelGGL(k_scan_reads<uint32_t>, dim3(ga), dim3(256), 0, st, tp);
-        hipLaunchKernelGGL(k_sum_tiles<uint32_t>, dim3(gs), dim3(256), 0, st, tp);
-        if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
-                      else hipLaunchKernelGGL((k_call_tiles<uint32_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
-        else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint32_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
-               else hipLaunchKernelGGL((k_call_tiles<uint32_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
-    } else {
-        hipLaunchKernelGGL(k_scan_reads<uint16_t>, dim3(ga), dim3(256), 0, st, tp);
-        hipLaunchKernelGGL(k_sum_tiles<uint16_t>, dim3(gs), dim3(256), 0, st, tp);
-        if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, true, true>), dim3(gc), dim3(256), 0, st, tp);
-                      else hipLaunchKernelGGL((k_call_tiles<uint16_t, true, false>), dim3(gc), dim3(256), 0, st, tp); }
-        else { if (plain) hipLaunchKernelGGL((k_call_tiles<uint16_t, false, true>), dim3(gc), dim3(256), 0, st, tp);
-               else hipLaunchKernelGGL((k_call_tiles<uint16_t, false, false>), dim3(gc), dim3(256), 0, st, tp); }
-    }
+    MM_REF_DISPATCH(h,
+        hipLaunchKernelGGL(k_scan_reads<RW>, dim3(ga), dim3(256), 0, st, tp);
+        hipLaunchKernelGGL(k_sum_tiles<RW>, dim3(gs), dim3(256), 0, st, tp);
+        if (p.view) { if (plain) hipLaunchKernelGGL((k_call_tiles<RW, true, true>), dim3(gc), dim3(256), 0, st, tp);
+                      else hipLaunchKernelGGL((k_call_tiles<RW, true, false>), dim3(gc), dim3(256), 0, st, tp); }
+        else { if (plain) hipLaunchKernelGGL((k_call_tiles<RW, false, true>), dim3(gc), dim3(256), 0, st, tp);
+               else hipLaunchKernelGGL((k_call_tiles<RW, false, false>), dim3(gc), dim3(256), 0, st, tp); });
 }
 
 int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
@@ -410,13 +408,9 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 const bool kd = h->stream_dot || h->opts.stream_mode == 3;
 #define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true>), dim3(gf), dim3(256), 0, st, tp); \
                                            else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
-                if (p.stats) {
-                    if (h->wide) { if (kd) MM_LAUNCH_STREAM(uint32_t, true, true); else MM_LAUNCH_STREAM(uint32_t, true, false); }
-                    else { if (kd) MM_LAUNCH_STREAM(uint16_t, true, true); else MM_LAUNCH_STREAM(uint16_t, true, false); }
-                } else {
-                    if (h->wide) { if (kd) MM_LAUNCH_STREAM(uint32_t, false, true); else MM_LAUNCH_STREAM(uint32_t, false, false); }
-                    else { if (kd) MM_LAUNCH_STREAM(uint16_t, false, true); else MM_LAUNCH_STREAM(uint16_t, false, false); }
-                }
+                MM_REF_DISPATCH(h,
+                    if (p.stats) { if (kd) MM_LAUNCH_STREAM(RW, true, true); else MM_LAUNCH_STREAM(RW, true, false); }
+                    else { if (kd) MM_LAUNCH_STREAM(RW, false, true); else MM_LAUNCH_STREAM(RW, false, false); });
 #undef MM_LAUNCH_STREAM
             }
             if (all_stream) {
@@ -436,13 +430,9 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             s.fb_params = p;
         }
         if (!(h->use_tiles && s.fb_deferred)) {
-        if (h->wide) {
-            if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, st, p);
-        } else {
-            if (p.view) hipLaunchKernelGGL((k_freq_reads<uint16_t, true>), dim3(blocks), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, st, p);
-        }
+        MM_REF_DISPATCH(h,
+            if (p.view) hipLaunchKernelGGL((k_freq_reads<RW, true>), dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_freq_reads<RW, false>), dim3(blocks), dim3(256), 0, st, p));
         }
         HIPCHK(hipGetLastError());
     }
@@ -477,13 +467,9 @@ int finish_deferred(mm_freq* h, Slot& s) {
     if (s.h_ctl[130] == 0u) return ran;
     const DevParams& p = s.fb_params;
     const int blocks = std::min(h->n_cu * h->blocks_per_cu, 128);
-    if (h->wide) {
-        if (p.view) hipLaunchKernelGGL((k_freq_reads<uint32_t, true>), dim3(blocks), dim3(256), 0, s.last_stream, p);
-        else hipLaunchKernelGGL((k_freq_reads<uint32_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
-    } else {
-        if (p.view) hipLaunchKernelGGL((k_freq_reads<uint16_t, true>), dim3(blocks), dim3(256), 0, s.last_stream, p);
-        else hipLaunchKernelGGL((k_freq_reads<uint16_t, false>), dim3(blocks), dim3(256), 0, s.last_stream, p);
-    }
+    MM_REF_DISPATCH(h,
+        if (p.view) hipLaunchKernelGGL((k_freq_reads<RW, true>), dim3(blocks), dim3(256), 0, s.last_stream, p);
+        else hipLaunchKernelGGL((k_freq_reads<RW, false>), dim3(blocks), dim3(256), 0, s.last_stream, p));
     HIPCHK(hipGetLastError());
     if (p.view) {
         // the fused kernel appended records: order the batch's rows again (the ordering pass only reads the regional
@@ -652,33 +638,24 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return fail(h, "hipGetDeviceProperties failed");
     h->n_cu = prop.multiProcessorCount;
-    h->wide = opts->n_mods > 5;
+    h->ref_kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 ? 0 : 1);
     {
         int nb = 0;
-        hipError_t e = h->wide
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint32_t, false>, 256, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_freq_reads<uint16_t, false>, 256, 0);
+        hipError_t e = hipSuccess;
+        MM_REF_DISPATCH(h, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_freq_reads<RW, false>), 256, 0));
         h->blocks_per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
         int na = 0, nc = 0;
         const bool plain = !opts->insertions && !opts->haplotypes;
-        if (h->wide) {
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint32_t>, 256, 0);
-            if (opts->view) { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, true, true>, 256, 0);
-                              else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, true, false>, 256, 0); }
-            else { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, true>, 256, 0);
-                   else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint32_t, false, false>, 256, 0); }
-        } else {
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<uint16_t>, 256, 0);
-            if (opts->view) { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, true, true>, 256, 0);
-                              else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, true, false>, 256, 0); }
-            else { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, true>, 256, 0);
-                   else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_call_tiles<uint16_t, false, false>, 256, 0); }
-        }
+        MM_REF_DISPATCH(h,
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, k_scan_reads<RW>, 256, 0);
+            if (opts->view) { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, (k_call_tiles<RW, true, true>), 256, 0);
+                              else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, (k_call_tiles<RW, true, false>), 256, 0); }
+            else { if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, (k_call_tiles<RW, false, true>), 256, 0);
+                   else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, (k_call_tiles<RW, false, false>), 256, 0); });
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
         int nf = 0;
-        if (h->wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint32_t, false, true, false>), 256, 0);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<uint16_t, false, true, false>), 256, 0);
+        MM_REF_DISPATCH(h, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, true, false>), 256, 0));
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
@@ -811,8 +788,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->ctg_rank.assign(n_contigs, 0);
         for (int r = 0; r < n_contigs; r++) h->ctg_rank[idx[r]] = r;
     }
-    size_t wbytes = h->wide ? 4 : 2;
-    if (dev_alloc(h, &h->d_refw, (size_t)std::max<int64_t>(ref_total, 64) * wbytes)) return fail(h, "reference alloc failed");
+    const size_t ref_bytes = h->ref_kind == 0 ? (size_t)std::max<int64_t>(ref_total, 64) / 2 : (size_t)std::max<int64_t>(ref_total, 64) * (h->ref_kind == 2 ? 4 : 2);
+    if (dev_alloc(h, &h->d_refw, ref_bytes)) return fail(h, "reference alloc failed");
     size_t tb = sizeof(int64_t) * (size_t)std::max(n_contigs, 1);
     if (dev_alloc(h, (void**)&h->d_ref_base, tb) || dev_alloc(h, (void**)&h->d_ctg_len, tb) || dev_alloc(h, (void**)&h->d_seg_begin, tb) ||
         dev_alloc(h, (void**)&h->d_seg_len, tb) || dev_alloc(h, (void**)&h->d_cnt_base, tb)) return fail(h, "alloc failed");
@@ -835,10 +812,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 int64_t len = h->ctg_len[t];
                 if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "reference upload failed"); }
                 int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
-                if (h->wide) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                                (uint32_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
-                else hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                        (uint16_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                if (h->ref_kind == 2) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                                         (uint32_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                else if (h->ref_kind == 1) hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                                              (uint16_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                else hipLaunchKernelGGL(k_build_refnibs, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
                 if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "context kernel failed"); }
             }
             (void)hipFree(d_raw);

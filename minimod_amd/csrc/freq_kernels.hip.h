@@ -79,7 +79,7 @@ struct DevParams {
     int32_t n_items;       // entries of order[] (== n_reads when order is null)
     const unsigned int* n_items_dev;  // when set, the item count is read from device memory (fallback list)
     // reference
-    const void* refw;            // uint16 or uint32 per base: bits 0-4 base code, bit 5+2i fwd ctx, 6+2i rev ctx
+    const void* refw;            // uint16 or uint32 per base: bits 0-4 base code, bit 5+2i fwd ctx, 6+2i rev ctx; one mod: four bits a base (RefNib)
     const int64_t* ref_base;     // per tid: offset into refw, -1 = contig absent
     const int64_t* ctg_len;      // per tid
     const int64_t* seg_begin;    // per tid: first position with dense counters
@@ -295,34 +295,72 @@ __device__ __forceinline__ int nt16_code(int c) {
         case 'N': return 15; default: return 16;
     }
 }
+__device__ __forceinline__ uint32_t ref_word_bits(const uint8_t* __restrict__ raw, int64_t len, int64_t p, const DevMod* __restrict__ mods, int n_mods) {
+    uint32_t w = (uint32_t)nt16_code(norm_ref_char(raw[p]));
+    for (int i = 0; i < n_mods; i++) {
+        const DevMod& m = mods[i];
+        if (m.ctx_is_star) { w |= 3u << (5 + 2 * i); continue; }
+        int L = m.ctx_len;
+        if (L <= 0) continue;
+        bool f = false, r = false;
+        for (int64_t s = p - L + 1; s <= p; s++) {
+            if (s < 0 || s + L > len) continue;
+            bool mf = true, mr = true;
+            for (int j = 0; j < L; j++) {
+                int c = norm_ref_char(raw[s + j]);
+                mf = mf && (c == m.ctx_fwd[j]);
+                mr = mr && (c == m.ctx_rev[j]);
+            }
+            f = f || mf; r = r || mr;
+        }
+        w |= (f ? 1u : 0u) << (5 + 2 * i);
+        w |= (r ? 1u : 0u) << (6 + 2 * i);
+    }
+    return w;
+}
 template <typename RefWord>
 __global__ __launch_bounds__(256) void k_build_refwords(const uint8_t* __restrict__ raw, int64_t len,
                                                         RefWord* __restrict__ out, const DevMod* __restrict__ mods,
                                                         int n_mods) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < len; p += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t w = (uint32_t)nt16_code(norm_ref_char(raw[p]));
-        for (int i = 0; i < n_mods; i++) {
-            const DevMod& m = mods[i];
-            if (m.ctx_is_star) { w |= 3u << (5 + 2 * i); continue; }
-            int L = m.ctx_len;
-            if (L <= 0) continue;
-            bool f = false, r = false;
-            for (int64_t s = p - L + 1; s <= p; s++) {
-                if (s < 0 || s + L > len) continue;
-                bool mf = true, mr = true;
-                for (int j = 0; j < L; j++) {
-                    int c = norm_ref_char(raw[s + j]);
-                    mf = mf && (c == m.ctx_fwd[j]);
-                    mr = mr && (c == m.ctx_rev[j]);
-                }
-                f = f || mf; r = r || mr;
-            }
-            w |= (f ? 1u : 0u) << (5 + 2 * i);
-            w |= (r ? 1u : 0u) << (6 + 2 * i);
-        }
-        out[p] = (RefWord)w;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < len; p += (int64_t)gridDim.x * blockDim.x)
+        out[p] = (RefWord)ref_word_bits(raw, len, p, mods, n_mods);
+}
+
+// One requested mod (the usual run): FOUR bits a position, two positions a byte -- a read's calls gather from a quarter of
+// the lines 16-bit words take, and those gathers are two thirds of the path's HBM traffic.  Bits 0-1: the base (A C G T);
+// bit 2: inside a forward-context match; bit 3: inside a reverse-context match.  Any other reference letter is stored as A:
+// the base is only ever compared with the read's where the position lies in a context match, which a letter that is none
+// of A C G T never does -- unless the context is `*`, and then the comparison is not made (mod.c:1139-1152).
+struct RefNib {};
+__device__ __forceinline__ uint32_t ref_nibble(uint32_t w) {
+    const uint32_t b = w & 31u;
+    return (b == 2u ? 1u : (b == 4u ? 2u : (b == 8u ? 3u : 0u))) | (((w >> 5) & 3u) << 2);
+}
+__global__ __launch_bounds__(256) void k_build_refnibs(const uint8_t* __restrict__ raw, int64_t len, uint8_t* __restrict__ out,
+                                                       const DevMod* __restrict__ mods) {
+    const int64_t nbytes = (len + 1) >> 1;   // (a contig starts on an even position of the array: its first byte is its own)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t lo = ref_nibble(ref_word_bits(raw, len, 2 * i, mods, 1));
+        const uint32_t hi = 2 * i + 1 < len ? ref_nibble(ref_word_bits(raw, len, 2 * i + 1, mods, 1)) : 0u;
+        out[i] = (uint8_t)(lo | (hi << 4));
     }
 }
+// a contig's words: from(refw, ref_base) once per read, at(base, position) per call -> the word in the 16 / 32-bit layout
+template <typename RefWord>
+struct RefLoad {
+    typedef const RefWord* Base;
+    static __device__ __forceinline__ Base from(const void* refw, int64_t ref_base) { return reinterpret_cast<const RefWord*>(refw) + ref_base; }
+    static __device__ __forceinline__ uint32_t at(Base b, int64_t pos) { return (uint32_t)b[pos]; }
+};
+template <>
+struct RefLoad<RefNib> {
+    typedef const uint8_t* Base;
+    static __device__ __forceinline__ Base from(const void* refw, int64_t ref_base) { return reinterpret_cast<const uint8_t*>(refw) + (ref_base >> 1); }   // (ref_base: a multiple of 64)
+    static __device__ __forceinline__ uint32_t at(Base b, int64_t pos) {
+        const uint32_t nib = ((uint32_t)b[pos >> 1] >> (4u * ((uint32_t)pos & 1u))) & 15u;
+        return (1u << (nib & 3u)) | ((nib >> 2) << 5);
+    }
+};
 
 // ---------------------------------------------------------------------------------- K1
 struct WaveLds {
@@ -596,13 +634,13 @@ struct K1 {
         }
         // stage 4: reference words and the first code's ML byte (global, J + J loads in flight)
         uint32_t w[J], ml0[J];
-        const RefWord* rw = reinterpret_cast<const RefWord*>(c.refw);
+        const typename RefLoad<RefWord>::Base rw = RefLoad<RefWord>::from(c.refw, c.ref_base);
         const int ncg = c.n_codes_grp;
 #pragma unroll
         for (int u = 0; u < J; u++) {
             w[u] = 0; ml0[u] = 0;
             if (!live[u]) continue;
-            w[u] = (uint32_t)rw[c.ref_base + ref_pos[u]];
+            w[u] = RefLoad<RefWord>::at(rw, ref_pos[u]);
             st_look++;
             if (is_explicit) {
                 uint64_t mi = (uint64_t)c.ml_start + (uint64_t)kidx[u] * ncg;

@@ -169,7 +169,7 @@ struct KF {
     const uint8_t* ml;
     const uint4* sq;
     const uint32_t* cg;
-    const RefWord* rwb;
+    typename RefLoad<RefWord>::Base rwb;
     uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32, cpat;
     int32_t pos, rev, ridx_cur;
     uint32_t v_region, v_gord;   // view: append region of the wavefront, ordinal of the group at hand
@@ -627,7 +627,7 @@ struct KF {
                 uint32_t w = 0;
                 if (call) {
 #ifndef MM_ABL_NOREF
-                    w = (uint32_t)rwb[(uint32_t)ref_pos];
+                    w = RefLoad<RefWord>::at(rwb, (int64_t)(uint32_t)ref_pos);
 #else
                     w = 0xFFFFFFE0u | (code & 31u) | ((uint32_t)ref_pos & 0u);
 #endif
@@ -969,7 +969,7 @@ struct KF {
         KFT_LAP(1);
         if (st == 0 && ngrp > 0u) {
             seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
-            rwb = reinterpret_cast<const RefWord*>(p.refw) + ref_base;
+            rwb = RefLoad<RefWord>::from(p.refw, ref_base);
             cnt0 = seg_len > 0 ? p.counters + cnt_base - seg_begin : nullptr;
             ml_start = 0;
             uint32_t nb_all = 0;

@@ -1207,12 +1207,12 @@ struct KC {
             if (rp < 0) live[u] = false;
         }
         uint32_t w[J], ml0[J];
-        const RefWord* rw = reinterpret_cast<const RefWord*>(p.refw);
+        const typename RefLoad<RefWord>::Base rw = RefLoad<RefWord>::from(p.refw, ref_base);
 #pragma unroll
         for (int u = 0; u < J; u++) {
             w[u] = 0; ml0[u] = 0;
             if (!live[u]) continue;
-            w[u] = (uint32_t)rw[ref_base + ref_pos[u]];
+            w[u] = RefLoad<RefWord>::at(rw, ref_pos[u]);
             st_look++;
             if (is_explicit) {
                 uint64_t mi = (uint64_t)ml_start + (uint64_t)kidx[u] * ncg;
