@@ -638,7 +638,14 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return fail(h, "hipGetDeviceProperties failed");
     h->n_cu = prop.multiProcessorCount;
-    h->ref_kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 ? 0 : 1);
+    // four bits a position need a context made of A C G T (or `*`): only then does no other reference letter ever sit in a match
+    auto plain_context = [&]() {
+        const char* c = opts->mods[0].context;
+        if (std::strcmp(c, "*") == 0) return true;
+        for (size_t j = 0; j < MM_CODE_LEN && c[j]; j++) if (!std::strchr("ACGT", c[j])) return false;
+        return true;
+    };
+    h->ref_kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 && plain_context() ? 0 : 1);
     {
         int nb = 0;
         hipError_t e = hipSuccess;

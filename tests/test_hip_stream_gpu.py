@@ -438,3 +438,40 @@ def test_tile_kernels_run_at_wait_time_when_the_launch_left_them_out():
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["max_l"] > 40000 and res["long_reads"] > 10, res
     assert res["equal"] and res["rows"] > 1000 and res["stream_done"] == 500 - res["long_reads"], res
+
+
+def test_reference_letters_other_than_acgt():
+    """One requested mod keeps the reference at four bits a position (RefNib: base in two bits, any other letter stored as
+    A): N, IUPAC letters and lower case in the reference, N and IUPAC letters in the reads, contexts of one to three letters,
+    `*`, and two with an N in them (the option parser takes A C G T U N; such a run keeps 16-bit words).  Stream kernel, tile pipeline and fused kernel
+    against the oracle."""
+    rng = np.random.default_rng(4242)
+    clean = make_ref(rng, 120000)
+    ref = list(clean)
+    for i in rng.choice(len(ref), size=len(ref) // 25, replace=False):
+        ref[i] = str(rng.choice(list("NNNRYMKSWnacgt")))
+        if ref[i] in "acgt":
+            ref[i] = clean[i].lower()
+    ref = "".join(ref)
+    recs = []
+    for _ in range(80):
+        flag = 16 if rng.random() < 0.5 else 0
+        pos = int(rng.integers(0, 60000)); l = int(rng.integers(200, 9000))
+        seq = list(clean[pos:pos + l])
+        for i in rng.choice(l, size=l // 40, replace=False):
+            seq[i] = str(rng.choice(list("NRYACGT")))
+        seq = "".join(seq)
+        orig = "".join({"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "R": "Y", "Y": "R"}[c] for c in reversed(seq)) if flag else seq
+        n_c = orig.count("C")
+        picks = [k for k in range(n_c) if rng.random() < 0.6]
+        toks, prev = [], -1
+        for k in picks:
+            toks.append(str(k - prev - 1)); prev = k
+        mm = "C+m?" + "".join("," + t for t in toks) + ";"
+        recs.append(pybam.make_record(0, pos, flag, seq, "%dM" % l, mm, [int(x) for x in rng.integers(0, 256, size=len(toks))]))
+    for c in ("m[CG]", "m[*]", "m[C]", "m[CGN]", "m[NG]", "m[CCG]"):
+        want = oracle_rows(recs, ref, c)
+        for kw in (dict(stream_mode=2), dict(stream_mode=1), dict(force_fused=True)):
+            got, _ = hip_rows(recs, ref, c, **kw)
+            assert got == want, (c, kw)
+        assert len(want) > 0 or c in ("m[CGN]", "m[NG]")
