@@ -71,6 +71,14 @@ constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offs
                                             // below that, so that no word reaches the padding's 0xFFFFFFFF
 constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // what the CIGAR window holds behind its last entry (the directory window: the running total)
 constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps requested together
+#ifndef MM_STREAM_DIR_AHEAD
+#define MM_STREAM_DIR_AHEAD 192
+#endif
+#ifndef MM_STREAM_CIG_AHEAD
+#define MM_STREAM_CIG_AHEAD 384
+#endif
+constexpr uint32_t kStreamDirAhead = MM_STREAM_DIR_AHEAD;   // a round's request tops the windows up to this many entries
+constexpr uint32_t kStreamCigAhead = MM_STREAM_CIG_AHEAD;
 constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
 
 struct StreamLds {
@@ -301,43 +309,49 @@ struct KF {
     }
 
     // ------------------------------------------------------------------ sequence -> directory window
-    // blocks are appended until the window covers rank rho_last (S_next > rho_last), the read ends, or the window is full
-    // while it already covers rho_0; a full window that does not even reach rho_0 holds nothing of use and starts over
-    __device__ __forceinline__ void load_dir(uint4 (&vv)[kStreamDirRounds]) const {
+    // The steps (of 64 blocks) a request at the cursor asks for: what the read still has, what the window has room for, and no
+    // further ahead than kStreamDirAhead entries -- every step that is requested goes into the window, so no block is loaded
+    // twice (a step asked for and then left for the next round came back from HBM again: L2 turns over in about a round's time)
+    __device__ __forceinline__ uint32_t dir_steps() const {
+        const uint32_t by_read = (nblk - t_next + 63u) >> 6, by_win = (kStreamDir - wn) >> 6;
+        const uint32_t ahead = wn < kStreamDirAhead ? (kStreamDirAhead - wn + 63u) >> 6 : 0u;
+        return min(min(by_read, by_win), min(ahead, (uint32_t)kStreamDirRounds));
+    }
+    __device__ __forceinline__ void load_dir(uint4 (&vv)[kStreamDirRounds], uint32_t ns) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
         for (int r = 0; r < kStreamDirRounds; r++) {
             const uint32_t t = t_next + 64u * (uint32_t)r + lane;
-            vv[r] = t < nblk ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
+            vv[r] = ((uint32_t)r < ns && t < nblk) ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
         }
     }
-    // (vv: the steps from t_next on, requested by the caller before it waited for anything)
-    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last, uint4 (&vv)[kStreamDirRounds]) {
+    // (vv: the ns steps from t_next on, requested by the caller before it waited for anything.)  They go in; then blocks are
+    // appended until the window covers rank rho_last (S_next > rho_last), the read ends, or the window is full while it already
+    // covers rho_0; a full window that does not even reach rho_0 holds nothing of use and starts over
+    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last, uint4 (&vv)[kStreamDirRounds], uint32_t ns) {
         const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false, first = true;
-        while (!stop && S_next <= rho_last && t_next < nblk) {
-            if (!first) load_dir(vv);
-            first = false;
+        for (;;) {
 #pragma unroll
             for (int r = 0; r < kStreamDirRounds; r++) {
-                if (!stop && S_next <= rho_last && t_next < nblk) {
-                    if (wn + 64u > kStreamDir) {
-                        if (S_next > rho_0) stop = true;
-                        else { wn = 0; t_w0 = t_next; }
-                    }
-                    if (!stop) {
-                        const uint32_t t = t_next + lane;
-                        const bool valid = t < nblk;
-                        uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);   // (steps past the read's end were loaded as zeros)
-                        cnt = valid ? cnt : 0u;
-                        const uint32_t incl = wave_incl_scan(cnt);
-                        if (valid) S.dw[wn + lane] = S_next + incl - cnt;
-                        const uint32_t nv = min(64u, nblk - t_next);
-                        wn = uniu(wn + nv); t_next = uniu(t_next + nv);
-                        S_next = uniu(S_next + lane_valu(incl, 63));
-                    }
+                if ((uint32_t)r < ns) {
+                    const uint32_t t = t_next + lane;
+                    const bool valid = t < nblk;
+                    uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);   // (steps past the read's end were loaded as zeros)
+                    cnt = valid ? cnt : 0u;
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    if (valid) S.dw[wn + lane] = S_next + incl - cnt;
+                    const uint32_t nv = min(64u, nblk - t_next);
+                    wn = uniu(wn + nv); t_next = uniu(t_next + nv);
+                    S_next = uniu(S_next + lane_valu(incl, 63));
                 }
             }
+            if (!(S_next <= rho_last && t_next < nblk)) break;
+            if (wn + 64u > kStreamDir) {
+                if (S_next > rho_0) break;
+                wn = 0; t_w0 = t_next;
+            }
+            ns = min(min((nblk - t_next + 63u) >> 6, (kStreamDir - wn) >> 6), (uint32_t)kStreamDirRounds);
+            load_dir(vv, ns);
         }
         if (lane == 0) S.dw[wn] = S_next;
         wave_sync();
@@ -387,143 +401,68 @@ struct KF {
     // ------------------------------------------------------------------ CIGAR -> window
     // ops are appended until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more
     // fits (room, or the 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
-#ifndef MM_STREAM_CIG_PAIRS
-    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds]) const {
+    __device__ __forceinline__ uint32_t cig_steps() const {   // (as dir_steps)
+        const uint32_t by_read = (ncig - s_next + 63u) >> 6, by_win = (kStreamCig - xn) >> 6;
+        const uint32_t ahead = xn < kStreamCigAhead ? (kStreamCigAhead - xn + 63u) >> 6 : 0u;
+        return min(min(by_read, by_win), min(ahead, (uint32_t)kStreamCigRounds));
+    }
+    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds], uint32_t ns) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
         for (int r = 0; r < kStreamCigRounds; r++) {
             const uint32_t s = s_next + 64u * (uint32_t)r + lane;
-            wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
+            wv[r] = ((uint32_t)r < ns && s < ncig) ? cg[rev ? ncig - 1u - s : s] : 0u;
         }
     }
-    // (wv: the steps from s_next on, requested by the caller at the start of the round)
-    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds]) {
+    // (wv: the ns steps from s_next on, requested by the caller at the start of the round.)  They go in; then ops are appended
+    // until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more fits (room, or the
+    // 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
+    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds], uint32_t ns) {
         const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false, first = true;
-        while (!stop && A_next <= u_hi && s_next < ncig) {
-            if (!first) load_cig(wv);
-            first = false;
+        bool stop = false;
+        for (;;) {
             bool stale = false;   // the loaded steps no longer line up with s_next
 #pragma unroll
             for (int r = 0; r < kStreamCigRounds; r++) {
-                if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
-                    if (xn + 64u > kStreamCig) {
-                        if (A_next > u_lo) stop = true;
-                        else xn = 0;
+                if ((uint32_t)r < ns && !stop && !stale) {
+                    const bool valid = s_next + lane < ncig;
+                    const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
+                    const uint32_t qinc = len & op_mask(0x193u, op), rinc = len & op_mask(0x18Du, op);   // (steps past the CIGAR's end were loaded as zeros)
+                    // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
+                    uint32_t qs, rs;
+                    if (!__ballot(valid && len >= 1024u)) {
+                        const uint32_t pk = wave_incl_scan(qinc | (rinc << 16));
+                        qs = pk & 0xFFFFu; rs = pk >> 16;
+                    } else {
+                        qs = wave_incl_scan(qinc); rs = wave_incl_scan(rinc);
                     }
-                    if (!stop) {
-                        const bool valid = s_next + lane < ncig;
-                        const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
-                        const uint32_t qinc = len & op_mask(0x193u, op), rinc = len & op_mask(0x18Du, op);   // (steps past the CIGAR's end were loaded as zeros)
-                        // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
-                        uint32_t qs, rs;
-                        if (!__ballot(valid && len >= 1024u)) {
-                            const uint32_t pk = wave_incl_scan(qinc | (rinc << 16));
-                            qs = pk & 0xFFFFu; rs = pk >> 16;
-                        } else {
-                            qs = wave_incl_scan(qinc); rs = wave_incl_scan(rinc);
-                        }
-                        if (xn == 0) { A_base = A_next; B_base = B_next; }
-                        const uint32_t dq = A_next + qs - qinc - A_base, dr = B_next + rs - rinc - B_base;
-                        const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan - 1u && dr < kStreamSpan));
-                        const uint32_t nvalid = min(64u, ncig - s_next);
-                        if (nv == 0u) {   // the next op starts beyond what this window's words can say
-                            if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
-                            else { xn = 0; stale = true; }
-                        } else {
-                            if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
-                            xn = uniu(xn + nv); s_next = uniu(s_next + nv);
-                            A_next = uniu(A_next + (nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv)));
-                            B_next = uniu(B_next + (nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv)));
-                            if (nv < nvalid) stale = true;
-                        }
+                    if (xn == 0) { A_base = A_next; B_base = B_next; }
+                    const uint32_t dq = A_next + qs - qinc - A_base, dr = B_next + rs - rinc - B_base;
+                    const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan - 1u && dr < kStreamSpan));
+                    const uint32_t nvalid = min(64u, ncig - s_next);
+                    if (nv == 0u) {   // the next op starts beyond what this window's words can say
+                        if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
+                        else { xn = 0; stale = true; }
+                    } else {
+                        if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
+                        xn = uniu(xn + nv); s_next = uniu(s_next + nv);
+                        A_next = uniu(A_next + (nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv)));
+                        B_next = uniu(B_next + (nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv)));
+                        if (nv < nvalid) stale = true;
                     }
                 }
             }
+            if (stop || !(A_next <= u_hi && s_next < ncig)) break;
+            if (xn + 64u > kStreamCig) {
+                if (A_next > u_lo) break;
+                xn = 0;
+            }
+            ns = min(min((ncig - s_next + 63u) >> 6, (kStreamCig - xn) >> 6), (uint32_t)kStreamCigRounds);
+            load_cig(wv, ns);
         }
         if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
         wave_sync();
     }
-#else
-    // Two ops a lane: a step is 128 ops, so the scans, the window's bookkeeping and the loop's conditions are paid half as often
-    // per op (the CIGAR is a third of an ONT read's instructions: ~890 ops against ~150 calls).  Lane l holds ops 2l and 2l + 1
-    // of the step in the order they are walked.
-    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds]) const {
-        const uint32_t lane = (uint32_t)lane_id();
-#pragma unroll
-        for (int r = 0; r < kStreamCigRounds; r += 2) {
-            const uint32_t s = s_next + 64u * (uint32_t)r + 2u * lane;
-            wv[r] = s < ncig ? cg[rev ? ncig - 1u - s : s] : 0u;
-            wv[r + 1] = s + 1u < ncig ? cg[rev ? ncig - 2u - s : s + 1u] : 0u;
-        }
-    }
-    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds]) {
-        static_assert(kStreamCigRounds % 2 == 0, "steps of two words a lane");
-        const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false, first = true;
-        while (!stop && A_next <= u_hi && s_next < ncig) {
-            if (!first) load_cig(wv);
-            first = false;
-            bool stale = false;   // the loaded steps no longer line up with s_next
-#pragma unroll
-            for (int r = 0; r < kStreamCigRounds; r += 2) {
-                if (!stop && !stale && A_next <= u_hi && s_next < ncig) {
-                    if (xn + 128u > kStreamCig) {
-                        if (A_next > u_lo) stop = true;
-                        else xn = 0;
-                    }
-                    if (!stop) {
-                        const uint32_t s0 = s_next + 2u * lane;
-                        const bool v0 = s0 < ncig, v1 = s0 + 1u < ncig;
-                        const uint32_t w0 = wv[r], w1 = wv[r + 1], op0 = w0 & 15u, op1 = w1 & 15u;
-                        const uint32_t l0 = v0 ? w0 >> 4 : 0u, l1 = v1 ? w1 >> 4 : 0u;
-                        const uint32_t q0 = l0 & op_mask(0x193u, op0), r0 = l0 & op_mask(0x18Du, op0);
-                        const uint32_t q1 = l1 & op_mask(0x193u, op1), r1 = l1 & op_mask(0x18Du, op1);
-                        const uint32_t pq = q0 + q1, pr = r0 + r1;
-                        // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
-                        uint32_t qs, rs;
-                        if (!__ballot((l0 | l1) >= 512u)) {
-                            const uint32_t pk = wave_incl_scan(pq | (pr << 16));
-                            qs = pk & 0xFFFFu; rs = pk >> 16;
-                        } else {
-                            qs = wave_incl_scan(pq); rs = wave_incl_scan(pr);
-                        }
-                        if (xn == 0) { A_base = A_next; B_base = B_next; }
-                        const uint32_t tq = lane_valu(qs, 63), tr = lane_valu(rs, 63);
-                        const uint32_t dq0 = A_next + qs - pq - A_base, dr0 = B_next + rs - pr - B_base;   // op 2l starts here ...
-                        const uint32_t dq1 = dq0 + q0, dr1 = dr0 + r0;                                       // ... op 2l + 1 here
-                        const uint32_t nvalid = min(128u, ncig - s_next);
-                        uint32_t nv = nvalid;
-                        if (!(A_next + tq - A_base < kStreamSpan - 1u && B_next + tr - B_base < kStreamSpan)) {
-                            // (rare) some op of the step starts beyond what the window's words can say: the ops in front of it go in
-                            const uint32_t i0 = leading_ones(__ballot(v0 && dq0 < kStreamSpan - 1u && dr0 < kStreamSpan));
-                            const uint32_t i1 = leading_ones(__ballot(v1 && dq1 < kStreamSpan - 1u && dr1 < kStreamSpan));
-                            nv = min(2u * i0, 2u * i1 + 1u);
-                            nv = min(nv, nvalid);
-                        }
-                        if (nv == 0u) {   // the next op starts beyond what this window's words can say
-                            if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
-                            else { xn = 0; stale = true; }
-                        } else {
-                            if (2u * lane < nv) S.cw[xn + 2u * lane] = (dq0 << 18) | (dr0 << 4) | op0;
-                            if (2u * lane + 1u < nv) S.cw[xn + 2u * lane + 1u] = (dq1 << 18) | (dr1 << 4) | op1;
-                            xn += nv; s_next += nv;
-                            if (nv == nvalid) { A_next += tq; B_next += tr; }
-                            else {   // the sums in front of op nv: the pairs in front of its lane, and its lane's first op if it is the second
-                                const int ln = (int)(nv >> 1);
-                                A_next += lane_valu(qs - pq, ln) + ((nv & 1u) ? lane_valu(q0, ln) : 0u);
-                                B_next += lane_valu(rs - pr, ln) + ((nv & 1u) ? lane_valu(r0, ln) : 0u);
-                                stale = true;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
-        wave_sync();
-    }
-#endif
 
     __device__ __forceinline__ void side_append(int32_t spos, int is_mod, int code) {
         // (the rare path: what it needs of the read is fetched again rather than kept in registers)
@@ -569,12 +508,13 @@ struct KF {
         // cursors stand, and the round's ML bytes (a round then pays one trip to memory for all three, not one each)
         uint4 dv[kStreamDirRounds];
         uint32_t cv[kStreamCigRounds];
-        load_dir(dv);
-        load_cig(cv);
+        const uint32_t nds = dir_steps(), ncs = cig_steps();
+        load_dir(dv, nds);
+        load_cig(cv, ncs);
         const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
         const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
-        fill_dir(rho_0, rho_last, dv);
+        fill_dir(rho_0, rho_last, dv, nds);
         KFT_LAP(3);
         const uint32_t n1 = leading_ones(__ballot(lv && rho < S_next));   // tokens whose block is in the window
         uint32_t n_done = 0;
@@ -604,7 +544,7 @@ struct KF {
             KFT_LAP(4);
             if (lm) {
                 const int fl = __ffsll((unsigned long long)lm) - 1, ll = 63 - __clzll((unsigned long long)lm);
-                fill_cig(lane_valu(u, fl), lane_valu(u, ll), cv);
+                fill_cig(lane_valu(u, fl), lane_valu(u, ll), cv, ncs);
             }
             n_done = leading_ones(__ballot(act && (!live || u < A_next)));
             KFT_LAP(5);
