@@ -58,7 +58,7 @@ constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at mo
 #define MM_STREAM_DIR_ROUNDS 2
 #endif
 #ifndef MM_STREAM_CIG_ROUNDS
-#define MM_STREAM_CIG_ROUNDS 4
+#define MM_STREAM_CIG_ROUNDS 2
 #endif
 #ifndef MM_STREAM_WAVES
 #define MM_STREAM_WAVES 6
