@@ -77,6 +77,7 @@ constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps reque
 #ifndef MM_STREAM_CIG_AHEAD
 #define MM_STREAM_CIG_AHEAD 384
 #endif
+constexpr uint32_t kNoPend = 0xFFFFFFFFu;
 constexpr uint32_t kStreamDirAhead = MM_STREAM_DIR_AHEAD;   // a round's request tops the windows up to this many entries
 constexpr uint32_t kStreamCigAhead = MM_STREAM_CIG_AHEAD;
 constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
@@ -195,8 +196,7 @@ struct KF {
     // a round's counter updates are ISSUED at the top of the next round, behind that round's loads (one per lane: the update of
     // the group's first code; further codes go out at once): on gfx9 an atomic counts in vmcnt like a load, so the wait for the
     // next loads would otherwise sit out the atomics' trip to the memory side as well
-    unsigned long long* pend_addr;
-    uint32_t pend_inc;   // 0 none, 1 called, 2 called and modified
+    uint32_t pend;   // reference position << 1 | modified; kNoPend: none (a position is below 2^31 - 1: contig lengths are int32)
     uint32_t staged_at, skip0;   // text offset of the chunk in LDS; header characters in front of the list in the group's first chunk
     bool prev_delim, closed, bad_text;
     // directory window: blocks [t_w0, t_w0 + wn) in traversal order, t_next the next block to scan, S_next the members in front of it
@@ -490,8 +490,13 @@ struct KF {
     }
 
     __device__ __forceinline__ void flush_pending() {
-        if (pend_inc) atomicAdd(pend_addr, pend_inc == 2u ? 0x100000001ull : 1ull);
-        pend_inc = 0;
+        if (pend != kNoPend) {
+            // (the first code's plane is wave-uniform: the lane keeps one word, not an address and an increment)
+            const int plane = (int)((ci0 >> 23) & 127u) - 1;
+            unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
+            atomicAdd(cbm + (pend >> 1), (pend & 1u) ? 0x100000001ull : 1ull);
+        }
+        pend = kNoPend;
     }
 
     // ------------------------------------------------------------------ one round: the ring's first n tokens (n <= 64)
@@ -609,7 +614,7 @@ struct KF {
                         if (cnt0 != nullptr && plane >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
 #ifndef MM_ABL_NOATOMIC
 #ifndef MM_STREAM_ATOMICS_AT_ONCE
-                            if (m == 0) { pend_addr = cbm + (uint32_t)ref_pos; pend_inc = is_mod ? 2u : 1u; }
+                            if (m == 0) pend = ((uint32_t)ref_pos << 1) | (uint32_t)is_mod;
                             else
 #endif
                             atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
@@ -664,7 +669,7 @@ struct KF {
     // returns 0, or 2 when the read has to go to the fused kernel (an input error); *ntok = tokens of the group
     __device__ __forceinline__ int run_group(uint32_t mpos, uint32_t lstart, bool wanted, uint32_t& ntok) {
         cpos = mpos; skip0 = lstart - mpos; prev_delim = true; closed = false; bad_text = false;
-        pend_inc = 0; pend_addr = nullptr;
+        pend = kNoPend;
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
         t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
         xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
