@@ -704,9 +704,11 @@ struct KA {
         }
         if (__ballot(err != 0)) irregular = true;   // a code the host did not intern (wildcard runs): reported by the fused kernel in order
         uint32_t tbase = 0;
+        bool reserved = false;
         if (have_ref && !irregular && need > 0) {
             if (lane == 0) tbase = atomicAdd(P.tile_count + region, need);
             tbase = uniu(tbase);
+            reserved = true;
             if ((uint64_t)tbase + need > P.tile_cap) irregular = true;   // reserved slots are marked invalid below
         }
         uint32_t tcur = tbase;
@@ -748,8 +750,9 @@ struct KA {
             tcur = tbase + need;
             result = any_err();
         }
-        // reserved slots this read did not fill are marked invalid (flags = 0)
-        if (have_ref && need > 0) {
+        // reserved slots this read did not fill are marked invalid (flags = 0).  Only a read that RESERVED slots: one that was
+        // irregular from its headers on has none, and tbase = 0 would make it wipe the region's first records -- another read's
+        if (reserved) {
             uint32_t hi = tbase + need;
             if (hi > P.tile_cap) hi = P.tile_cap;
             for (uint32_t i = tcur + lane; i < hi; i += 64) { rtiles[i].flags = 0u; rdesc[i] = make_uint2(0u, 0u); }
