@@ -35,6 +35,7 @@
 // the read goes on the fallback list and the fused kernel names the error in the reference's order, exactly as for the tile
 // pipeline's irregular reads.  DESIGN.md section 4 ("Streaming kernel") has the measurements.
 #pragma once
+#include <type_traits>
 #include "freq_tiles.hip.h"
 
 namespace mmhip {
@@ -94,6 +95,7 @@ struct StreamLds {
     // what the header pass leaves for the groups: where the group starts and its list begins, flags (bit 6 no requested code,
     // 12-14 codes per token), the codes and their packed table entries
     uint32_t g_mpos[kStreamGroups], g_lstart[kStreamGroups], g_flags[kStreamGroups], g_c01[kStreamGroups], g_c23[kStreamGroups];
+    uint32_t g_end[kStreamGroups];   // the group's ';' (or the string's end)
     uint32_t g_ci[kStreamGroups][4];
     // the headers this wave resolved last, by group ordinal: the reads of a file nearly all carry the same ones, and a header
     // whose characters are those of the memo needs neither the checks nor the code table again
@@ -191,6 +193,11 @@ struct KF {
     unsigned long long* cnt0;   // the read's strand-0... counters of plane 0 of its contig, shifted so that the index is the reference position;
                                 // null when the contig has no dense counters.  A code's counters: + (plane * 2 + rev) * plane_len
     uint32_t ml_start;
+    // TWIN groups (run()): two one-code `?` lists over the same tokens, done in one pass.  tw = 0: an ordinary group, the ML byte
+    // of token k's code m is ml[ml_start + k * ncg + m]; tw = the list's tokens: ml[ml_start + k + m * tw] (the second list's
+    // bytes follow the first's).  Never with one requested mod (RefNib): two requested codes are what makes a pair.
+    static constexpr bool kTwinOK = !std::is_same<RefWord, RefNib>::value;
+    uint32_t tw;
     // text cursor and token ring
     uint32_t cpos, nx_w0, nx_w1, qhead, qn, kdone, Rcarry, ntok_parsed;
     // a round's counter updates are ISSUED at the top of the next round, behind that round's loads (one per lane: the update of
@@ -516,7 +523,7 @@ struct KF {
         const uint32_t nds = dir_steps(), ncs = cig_steps();
         load_dir(dv, nds);
         load_cig(cv, ncs);
-        const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg;
+        const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * ((kTwinOK && tw) ? 1u : (uint32_t)ncg);
         const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
         fill_dir(rho_0, rho_last, dv, nds);
@@ -591,18 +598,19 @@ struct KF {
                         if (!(in_ctx && matches)) continue;
                         int is_mod = 0;
                         if (kView && !expl) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
-                            view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord, 1u, 0u);
+                            view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), 1u, 0u);
                             continue;
                         }
                         if (expl) {
-                            const uint64_t ml_idx = (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                            const uint64_t ml_idx = (kTwinOK && tw) ? (uint64_t)ml_start + kidx + (uint32_t)m * tw
+                                                                     : (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
                             if (ml_idx >= ml_len) { err = MM_E_MLIDX; continue; }   // (not `break`: a divergent exit would make m, and all that
                                                                                      // hangs on it -- the code's table word, its plane, the 64-bit
                                                                                      // counter offset -- vector values; the read fails either way)
                             const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
                             if (kStats) st_ml++;
                             if (kView) {   // mod.c:1194-1196: no threshold, the ML byte itself
-                                view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord, 0u, (uint32_t)mv);
+                                view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), 0u, (uint32_t)mv);
                                 continue;
                             }
                             if (mv >= t_hi) is_mod = 1;
@@ -744,6 +752,29 @@ struct KF {
         flush_pending();
         ntok = ntok_parsed;
         return st;
+    }
+
+    // Are the skip lists [a, a + len) and [b, b + len) of the MM string the same text, and is that text nothing but
+    // ",digits,digits,...,digits"?  Then its tokens are its commas (returned; 0: not the same, or not that plain).
+    __device__ __forceinline__ uint32_t twin_lists(uint32_t a, uint32_t b, uint32_t len) const {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t bad = 0, commas = 0;
+        for (uint32_t off = 0; off < len; off += 256u) {
+            const uint32_t o = off + 4u * lane;
+            const uint32_t wa = mm_dword(mm, a + len, a + o), wb = mm_dword(mm, b + len, b + o);
+            const uint32_t wp = mm_dword(mm, a + len, a + o - 1u);                 // the same four characters' left neighbours (a >= 1: a header is in front)
+            const uint32_t vm = o >= len ? 0u : (len - o >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * (len - o))) - 1u)));   // bytes inside the list
+            const uint32_t ya = wa ^ 0x2C2C2C2Cu, yp = wp ^ 0x2C2C2C2Cu, yd = wa ^ 0x30303030u;
+            const uint32_t ca = ~(((ya & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ya) & 0x80808080u;   // commas
+            const uint32_t cp = ~(((yp & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yp) & 0x80808080u;   // commas among the left neighbours
+            const uint32_t nd = (((yd & 0x7F7F7F7Fu) + 0x76767676u) | yd) & 0x80808080u;     // not a digit
+            bad |= (wa ^ wb) | ((nd & ~ca) & vm) | (ca & cp & vm);
+            if (o <= len - 1u && len - 1u < o + 4u) bad |= ca & (0x80u << (8u * (len - 1u - o)));   // the last character is a digit
+            if (o == 0u) bad |= (~ca) & 0x80u;                                                    // the first one a comma
+            commas += (uint32_t)__popc(ca & vm);
+        }
+        if (__ballot(bad != 0u)) return 0u;
+        return lane_valu(wave_incl_scan(commas), 63);
     }
 
     // ------------------------------------------------------------------ one read: 0 done, 1 -> tile pipeline, 2 -> fused kernel
@@ -902,6 +933,7 @@ struct KF {
                     wave_sync();
                     if (lane == 0u) {
                         S.g_mpos[ngrp] = mpos; S.g_lstart[ngrp] = lstart; S.g_flags[ngrp] = gflags; S.g_c01[ngrp] = c01; S.g_c23[ngrp] = c23;
+                        S.g_end[ngrp] = endp;
                     }
                     if (lane < 4u) S.g_ci[ngrp][lane] = ci_w;
                     ngrp++;
@@ -930,9 +962,30 @@ struct KF {
                     ci0 = uniu(S.g_ci[gi][0]); ci1 = uniu(S.g_ci[gi][1]); ci2 = uniu(S.g_ci[gi][2]); ci3 = uniu(S.g_ci[gi][3]);
                 }
                 uint32_t ntok = 0;
+                tw = 0;
+                // TWIN groups: this group and the next one are `?` lists of one requested code each over the same tokens -- the
+                // same text, as 5mC + 5hmC callers write them (C+h?,<list>;C+m?,<list>;).  One pass does both codes on every
+                // call; the second list is never parsed and the merge with the sequence and the CIGAR is not made twice.  The
+                // reference walks the groups one after the other (mod.c:1003-1370): the same updates in another order.
+                if (kTwinOK && wanted && !dot_group && ncg == 1 && gi + 1u < ngrp) {
+                    const uint32_t f2 = uniu(S.g_flags[gi + 1u]);
+                    const uint32_t endA = uniu(S.g_end[gi]), lstartB = uniu(S.g_lstart[gi + 1u]), endB = uniu(S.g_end[gi + 1u]);
+                    if (!(f2 & (64u | 4u)) && ((f2 >> 12) & 7u) == 1u && endA > lstart && endA - lstart == endB - lstartB) {
+                        tw = twin_lists(lstart, lstartB, endA - lstart);
+                        if (tw) {
+                            ncg = 2;
+                            gc01 = (c01 & 0xFFFFu) | (uniu(S.g_c01[gi + 1u]) << 16);
+                            ci1 = uniu(S.g_ci[gi + 1u][0]);
+                        }
+                    }
+                }
                 KFT_LAP(8);
                 st = run_group(gmpos, lstart, wanted, ntok);
                 KFT_LAP(2);
+                if (kTwinOK && tw) {
+                    if (st == 0 && ntok != tw) st = 2;   // (cannot happen: a list that plain has as many tokens as commas)
+                    ml_start += 2u * ntok; gi++; continue;
+                }
                 if (st == 0 && !wanted && Rcarry != 0u) {
                     // a group nobody asked for: its last listed rank must exist (mod.c:1116)
                     if (!have_nb) { nb_all = count_all(); have_nb = true; }

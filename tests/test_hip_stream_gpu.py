@@ -541,3 +541,80 @@ def test_mixed_batches_against_the_oracle(seed):
             for _ in range(3 if "force_fused" not in kw else 1):
                 got, _st = hip_rows(recs, ref, c, **kw)
                 assert got == want, (seed, c, kw)
+
+
+def _twin_read(rng, ref, pos, length, flag, variant):
+    """a read whose two groups list the same bases (as 5mC + 5hmC callers write them), or nearly so"""
+    seq = ref[pos:pos + length]
+    orig = revcomp(seq) if flag else seq
+    n_c = orig.count("C")
+    picks = [k for k in range(n_c) if rng.random() < 0.4]
+    toks, prev = [], -1
+    for k in picks:
+        toks.append(str(k - prev - 1)); prev = k
+    la = "".join("," + t for t in toks)
+    lb = la
+    if variant == "padded":           # zero-padded tokens in both lists: still plain text
+        la = lb = "".join("," + t.zfill(int(rng.integers(1, 4))) for t in toks)
+    elif variant == "differs":        # the same length, two neighbouring tokens the other way round: two passes
+        tb = list(toks)
+        for i in range(len(tb) - 1):
+            if tb[i] != tb[i + 1]:
+                tb[i], tb[i + 1] = tb[i + 1], tb[i]
+                break
+        lb = "".join("," + t for t in tb)
+    elif variant == "shorter":        # the second list stops early
+        lb = "".join("," + t for t in toks[:len(toks) // 2])
+    elif variant == "empty_token":    # ",," is not plain: the groups go one after the other
+        la = lb = la.replace(",", ",,", 1)
+    n_a, n_b = la.count(",") - la.count(",,"), lb.count(",") - lb.count(",,")
+    third = "C+x?" + "".join("," + t for t in toks[:5]) + ";" if variant == "third" else ""
+    n_x = min(5, len(toks)) if variant == "third" else 0
+    mm = "C+h?" + la + ";C+m?" + lb + ";" + third
+    ml = [int(x) for x in rng.integers(0, 256, size=n_a + n_b + n_x)]
+    if variant == "ml_short":
+        ml = ml[:n_a + n_b // 2]
+    return pybam.make_record(0, pos, flag, seq, "%dM" % length, mm, ml)
+
+
+@pytest.mark.parametrize("variant", ["same", "padded", "differs", "shorter", "empty_token", "third"])
+def test_twin_groups(variant):
+    """Two `?` groups of one requested code each over the same list are done in one pass (RefWord 16 / 32 bit: two requested
+    codes); lists that only look alike are not.  Rows, and the view rows' order, against the oracle; the tile pipeline as a
+    second witness."""
+    rng = np.random.default_rng(77)
+    ref = make_ref(rng, 60000)
+    recs = [_twin_read(rng, ref, int(rng.integers(0, 30000)), int(rng.integers(300, 9000)), 16 if i % 2 else 0, variant) for i in range(40)]
+    for c in ("m,h", "h[C],m[CG]", "m[*],h[*],x[*]"):
+        st = both_ways(recs, ref, c)
+        assert st["stream_done"] == len(recs), st
+    # one requested code of the pair: nothing to pair (and with one mod the reference array is four bits a base)
+    both_ways(recs, ref, "m")
+    from tests.hiprun import hip_view_from_records
+    mods = O.parse_mod_codes("m,h")
+    o = O.Oracle(mods, O.parse_mod_threshes(None, 2), ["chrT"]); o.set_view(True); o.add_contig("chrT", ref.encode()); o.process(pybam.flatten(recs))
+    codes = o.code_names()
+    want = [(int(r["read"]), int(r["pos"]), int(r["read_pos"]), codes[r["code"]], int(r["prob"]), int(r["ins_off"])) for r in o.view_rows()]
+    o.close()
+    for mode in (2, 1):
+        got = hip_view_from_records(recs, ref, "m,h", stream_mode=mode)
+        assert got == want, mode
+
+
+def test_twin_groups_with_too_few_ml_bytes():
+    """the second list's ML bytes run out: the reference's error (ML index overrun) at the same read"""
+    import minimod_amd
+    rng = np.random.default_rng(78)
+    ref = make_ref(rng, 60000)
+    recs = [_twin_read(rng, ref, 100 + 50 * i, 2000, 0, "same") for i in range(6)]
+    recs[3] = _twin_read(rng, ref, 700, 2500, 0, "ml_short")
+    mods = O.parse_mod_codes("m,h")
+    o = O.Oracle(mods, O.parse_mod_threshes(None, 2), ["chrT"]); o.add_contig("chrT", ref.encode())
+    with pytest.raises(O.OracleError) as oe:
+        o.process(pybam.flatten(recs))
+    o.close()
+    assert (oe.value.code, oe.value.read) == (11, 3)
+    for mode in (2, 3, 1):
+        with pytest.raises(minimod_amd.MinimodHipError) as he:
+            hip_rows(recs, ref, "m,h", stream_mode=mode)
+        assert (he.value.code, he.value.read) == (11, 3), mode

@@ -8,7 +8,12 @@ import numpy as np
 from oracle import pybam
 from tests import test_hip_stream_gpu as T
 
-rread = T._mixed_read
+def rread(rng, ref):
+    # a third of the reads carry twin groups (two one-code `?` lists over the same tokens) in their variants
+    if rng.random() < 0.33:
+        v = str(rng.choice(["same", "same", "padded", "differs", "shorter", "empty_token", "third"]))
+        return T._twin_read(rng, ref, int(rng.integers(0, 3000)), int(rng.integers(50, 6000)), 16 if rng.random() < 0.5 else 0, v)
+    return T._mixed_read(rng, ref)
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 t0 = time.time(); bad = 0
