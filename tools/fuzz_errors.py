@@ -55,7 +55,7 @@ def corrupt(rng, r, ref_len):
     return with_aux(r, mm, ml, tail)
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-t0 = time.time(); bad = 0; n_err = 0
+t0 = time.time(); bad = 0; n_err = 0; known = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     ref = T.make_ref(rng, 120000)
@@ -73,6 +73,12 @@ for seed in range(first, first + count):
         except minimod_amd.MinimodHipError as e:
             got = ("error", e.code, e.read)
         if got != want:
+            # the two deviations DESIGN.md section 7 lists: more than 16 code letters in a group; a reverse read whose CIGAR
+            # overshoots the sequence in its leading soft clip / insertion
+            if "mmmmmmmmmmmmmmmmmm" in aux_parts(recs[k])[0] and got[0] == "error" and got[1] == 5:
+                known += 1; continue
+            if got[0] == "error" and got[1] == 14 and (recs[k].flag & 16) and want[0] == "rows":
+                known += 1; continue
             bad += 1
             print("MISMATCH seed", seed, "read", k, c, kw, "hip", str(got)[:80], "oracle", str(want)[:80], "| MM", aux_parts(recs[k])[0][:60], flush=True)
-print("seeds %d..%d done in %.0f s, %d problems (%d of the batches fail in the oracle)" % (first, first + count - 1, time.time() - t0, bad, n_err))
+print("seeds %d..%d done in %.0f s, %d problems, %d known deviations (%d of the batches fail in the oracle)" % (first, first + count - 1, time.time() - t0, bad, known, n_err))
