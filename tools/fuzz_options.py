@@ -52,7 +52,7 @@ for seed in range(first, first + count):
         for r in recs:   # haplotype tags on some reads
             if rng.random() < 0.6:
                 r.aux += b"HPC" + bytes([int(rng.integers(0, 4))])
-    c = ("m", "m,h", "m[*],a[*]", "h[CG]", "m[C],x[*]")[int(rng.integers(0, 5))]
+    c = ("m", "m,h", "m[*],a[*]", "h[CG]", "m[C],x[*]", "*", "*[C]")[int(rng.integers(0, 7))]   # (the last two: every code the reads carry)
     ins, hap = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
     nb = int(rng.integers(1, 4))
     cut = sorted(rng.integers(0, len(recs) + 1, size=nb - 1).tolist())
