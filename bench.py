@@ -87,6 +87,10 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
     ap.add_argument("--cpu-t1-batches", type=int, default=2, help="batches in the BAM the `-t 1` CPU run reads")
+    ap.add_argument("--reps", type=int, default=11, help="repetitions of the timed region (each exactly --steps steps between barrier + synchronize): "
+                                                          "`value` is the median repetition, `spread` has min / max")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-path leg (the same batches through mm_freq_submit, PCIe included) and the "
+                                                                "one-launch-per-step leg")
     ap.add_argument("--mode", default="freq", choices=["freq", "view"],
                     help="freq = the headline metric (default); view = the same batches through `minimod view` (SURVEY.md 8f row 1), "
                          "rows ordered and left in HBM; an extra measurement, not the driver's contract line")
@@ -353,8 +357,33 @@ def run_end_to_end(args, wl, host_batches, contig, ref):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process never touches
+    the GPU), rank r on GPU r, rendezvous on 127.0.0.1.  Rank 0's JSON line is this process's output."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -393,6 +422,8 @@ def main():
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         pieces = list(ex.map(gen, jobs))
     whole = synth.concat(pieces)
+    # (N = 1: the pieces are the -K batches themselves, each with pools of its own -- what a host caller hands to mm_freq_submit)
+    compact_batches = pieces if (world == 1 and all(len(pc["reads"]) == min(args.batch, len(whole["reads"]) - i * args.batch) for i, pc in enumerate(pieces))) else None
     del pieces
     n_reads = len(whole["reads"])
     host_batches = synth.split(whole, [min(args.batch, n_reads - i) for i in range(0, n_reads, args.batch)])   # the -K windows
@@ -546,44 +577,48 @@ def main():
         exchange()
         eng.reset()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bases, kms, abytes = run_steps(args.steps, first_step=args.warmup, use_stream=stream if args.streams <= 1 else None)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region, --reps times over: each repetition is EXACTLY --steps steps between barrier + synchronize on both
+    # sides (max over ranks), from clean counters; `value` is the median repetition, `spread` says how far they lie apart.
+    reps = []
+    for rep in range(max(1, args.reps)):
+        if rep:
+            eng.reset()
+            if world > 1:
+                dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bases, kms, abytes = run_steps(args.steps, first_step=args.warmup, use_stream=stream if args.streams <= 1 else None)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        reps.append({"elapsed": time.perf_counter() - t0, "kms": kms, "abytes": abytes})
     # The job's one exchange: each rank's halo slab goes to its right neighbour after the LAST batch (once per job, not per
-    # step: a 30x genome is thousands of steps).  It runs here, right behind the K timed steps, and is timed on its own.
+    # step: a 30x genome is thousands of steps).  It runs here, right behind the last repetition's K timed steps, and is timed on its own.
     t2 = time.perf_counter()
     exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     reduce_s = time.perf_counter() - t2
+    el = [r["elapsed"] for r in reps]
     if world > 1:
         rdev = "cpu" if host_staged else dev
-        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64, device=rdev)
+        tt = torch.tensor(el + [reduce_s], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, reduce_s = float(tt[0].item()), float(tt[1].item())
+        el, reduce_s = [float(x) for x in tt[:-1].tolist()], float(tt[-1].item())
         tb = torch.tensor([bases], dtype=torch.int64, device=rdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
     else:
         total_bases = bases
+    mid = int(np.argsort(el)[len(el) // 2])      # the median repetition (the upper one of an even count)
+    elapsed, kms, abytes = el[mid], reps[mid]["kms"], reps[mid]["abytes"]
 
-    # extra, outside the contract's timed region: the same steps with the library's per-slot streams, i.e. up to three
-    # batches in flight as the CLI's load/process overlap gives (kernels of consecutive batches overlap on the device)
-    overlap = None
-    if world == 1 and args.streams <= 1 and not args.no_extra:
-        if side_per_pass:
-            eng.reset()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ob, _, _ = run_steps(args.steps, first_step=args.warmup, use_stream=None)
-        torch.cuda.synchronize()
-        overlap = {"value": ob / (time.perf_counter() - t1) / 1e6, "unit": "Mbases/s",
-                   "note": "same steps on the library's per-slot streams (3 batches in flight); not the contract's timed region"}
+    # extra legs, outside the contract's timed region (N = 1 only): the same steps one launch per step, and through the
+    # product's entry point (host batches, PCIe included)
+    legs = None
+    if world == 1 and not args.no_extra and not args.no_host_path and not args.dump_timed and compact_batches is not None:
+        legs = extra_legs(args, wl, contig, plan, compact_batches, dev_batches, batch_bases, alg_bytes, stream, local_rank)
 
     result = None
     if rank == 0:
@@ -595,9 +630,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config.lower())
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_batch") * args.steps / len(kms)   # per launch, like `achieved`
-                traffic_src = ("profiles/%s: bytes per batch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (not measured "
-                               "in this run), times this run's batches per launch" % os.path.basename(tpath))
+                from minimod_amd.build import source_hash
+                tj = json.load(open(tpath))
+                if tj.get("source_hash") == source_hash():
+                    traffic = tj.get("hbm_bytes_per_batch") * args.steps / len(kms)   # per launch, like `achieved`
+                    traffic_src = ("profiles/%s: bytes per batch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (not measured "
+                                   "in this run; made from these very kernel sources: source_hash %s), times this run's batches per launch"
+                                   % (os.path.basename(tpath), tj.get("source_hash")))
+                else:
+                    traffic_src = ("profiles/%s was measured on other kernel sources (its source_hash %s, now %s): no traffic figure"
+                                   % (os.path.basename(tpath), tj.get("source_hash"), source_hash()))
             except Exception:
                 traffic = None
         reads_all = np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches])
@@ -627,6 +669,12 @@ def main():
                          "bytes_per_base": abytes / max(bases, 1), "side_list_updates_per_pass": side_per_pass},
             "gen_seconds": t_gen,
         }
+        fr = [r["abytes"] / (float(np.sum(r["kms"])) * 1e-3) / 1e9 / HBM_PEAK_GBS for r in reps]
+        result["spread"] = {"reps": len(reps), "what": "the timed region repeated: each repetition exactly %d steps between barrier + synchronize; value / ms_per_step / roofline "
+                                                       "are the median repetition's" % args.steps,
+                            "value": {"median": total_bases / elapsed / 1e6, "min": total_bases / max(el) / 1e6, "max": total_bases / min(el) / 1e6},
+                            "roofline_frac": {"median": float(np.median(fr)), "min": float(min(fr)), "max": float(max(fr))},
+                            "timed_region_ms": {"median": elapsed * 1e3, "min": min(el) * 1e3, "max": max(el) * 1e3}}
         result["config"]["routing"] = {"reads_done_by_k_stream_reads": int(routing[0]), "handed_to_the_tile_pipeline": int(routing[1]),
                                        "handed_to_the_fused_kernel": int(routing[2]), "reads": routed_reads,
                                        "note": "one pass over the first min(steps, batches) windows, gathered like the timed steps; reads too long "
@@ -641,8 +689,8 @@ def main():
                                       "note": "halo slabs (%d positions x planes x 8 B) to the right neighbour wherever a cut falls inside a "
                                               "contig, once per job after the last step; timed on its own, max over ranks; value_incl = "
                                               "throughput if these K steps were the whole job" % slab_len}
-        if overlap:
-            result["overlapped_streams"] = overlap
+        if legs:
+            result.update(legs)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, refs)
         if e2e:
@@ -665,6 +713,83 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def extra_legs(args, wl, contig, plan, host_batches, dev_batches, batch_bases, alg_bytes, stream, local_rank):
+    """Two more readings of the same K steps, each on its own handle: `resident_coalesce1` = the resident windows one launch per
+    step (what a caller gets that waits for every -K batch); `host_path` = the batches handed over from HOST memory through
+    mm_freq_submit -- the call the CLI and the INTEGRATION.md stub make -- which stages them in device memory and gathers them
+    into launches like the timed region's (wall clock includes the PCIe copies; the kernel time is the launches' HIP events)."""
+    import torch
+    import minimod_amd
+    n_batches = len(host_batches)
+    common = dict(device=local_rank, intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
+                  side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, stream_mode=1 if args.no_stream else 0, **wl["eng"])
+    steps = [(args.warmup + s) % n_batches for s in range(args.steps)]
+    bases = int(sum(batch_bases[b] for b in steps))
+    abytes = int(sum(alg_bytes[b] for b in steps))
+    out = {}
+    # ---- one launch per step
+    e1 = minimod_amd.FreqEngine(wl["mods"], contig, coalesce=1, **common)
+    for b in steps[:3]:
+        e1.wait(e1.submit_device(dev_batches[b], stream))
+    e1.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = []
+    for b in steps:
+        tk = e1.submit_device(dev_batches[b], stream)
+        e1.wait(tk)
+        kms.append(e1.kernel_ms(tk))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ach = abytes / (float(np.sum(kms)) * 1e-3) / 1e9
+    out["resident_coalesce1"] = {"value": bases / wall / 1e6, "unit": "Mbases/s", "kernel_ms_per_batch": float(np.mean(kms)), "achieved": ach,
+                                 "frac": ach / HBM_PEAK_GBS, "launches": e1.launch_counts(),
+                                 "what": "the same %d steps, every step its own launch and waited for (mm_freq_opts_t.coalesce = 1)" % args.steps}
+    e1.close()
+    # ---- host batches through mm_freq_submit
+    eh = minimod_amd.FreqEngine(wl["mods"], contig, coalesce=args.coalesce, **common)
+
+    def host_pass():
+        groups, kms = [], []
+        for b in steps:
+            tk = eh.submit(host_batches[b])
+            if not groups or groups[-1] != tk:
+                groups.append(tk)
+            if len(groups) > 2:
+                g = groups.pop(0)
+                eh.wait(g)
+                kms.append(eh.kernel_ms(g))
+        for g in groups:
+            eh.wait(g)
+            kms.append(eh.kernel_ms(g))
+        return kms
+    host_pass()          # staging areas allocated, instantiations loaded
+    eh.reset()
+    walls, kmss = [], []
+    lc0 = eh.launch_counts()
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = host_pass()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        kmss.append(k)
+        eh.reset()
+    lc1 = eh.launch_counts()
+    i = int(np.argsort(walls)[1])
+    ach = abytes / (float(np.sum(kmss[i])) * 1e-3) / 1e9
+    hbytes = int(sum(host_batches[b][k].nbytes for b in steps for k in ("reads", "cigar", "seq", "mm", "ml")))
+    out["host_path"] = {"value": bases / walls[i] / 1e6, "unit": "Mbases/s", "wall_ms": walls[i] * 1e3, "h2d_bytes": hbytes,
+                        "h2d_GBps_incl_kernels": hbytes / walls[i] / 1e9, "kernel_ms_per_batch": float(np.sum(kmss[i])) / args.steps,
+                        "achieved_kernels_only": ach, "frac_kernels_only": ach / HBM_PEAK_GBS,
+                        "launches_per_pass": (lc1["launches"] - lc0["launches"]) // 3, "stream_launches_per_pass": (lc1["stream_launches"] - lc0["stream_launches"]) // 3,
+                        "what": "the same %d steps as HOST batches (pageable numpy memory) through mm_freq_submit with coalesce = %d: copied into a staging "
+                                "area in HBM one behind the other, launched together; median of 3 passes, wall clock with the PCIe copies; "
+                                "never the line's `value`" % (args.steps, args.coalesce)}
+    eh.close()
+    return out
 
 
 def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, world, dist, dev, plan, ref, t_gen):

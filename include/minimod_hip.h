@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3
+#define MM_ABI_VERSION 4
 #define MM_MAX_MODS 13    /* requested -c entries (2 context bits each + 5 base bits in one 32-bit ref word) */
 #define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
 #define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
@@ -108,8 +108,9 @@ typedef struct mm_freq_opts {
     int32_t view_cap;        /* view: records per append region before the grow-and-rerun path (0 = sized from the ML pool) */
     int32_t finalize_by_runs;/* 1: mm_freq_finalize takes the per-run compaction + host merge even when all rows are dense */
     int32_t split_bases;     /* device planning: reads longer than this are cut into parts of about this many bases (0 = default) */
-    int32_t coalesce;        /* mm_freq_submit_device: up to this many consecutive windows of one resident read set share one launch
-                              * (see there); 0 or 1 = every submit is its own launch */
+    int32_t coalesce;        /* up to this many consecutive submits share one launch: for mm_freq_submit_device consecutive windows of
+                              * one resident read set, for mm_freq_submit host batches staged one behind the other in device memory
+                              * (see both); 0 or 1 = every submit is its own launch */
     int32_t stream_mode;     /* which reads take the streaming kernel (k_stream_reads: a whole read in one wavefront) instead of the
                               * tile pipeline, in plain runs (freq or view; no --insertions, no --haplotypes).  0 (default): by the
                               * size of the launch -- none in a launch of fewer than about 15 000 reads (a single -K 4096 batch:
@@ -119,6 +120,7 @@ typedef struct mm_freq_opts {
                               * leaner one runs until a read with a '.' group has shown up -- that read goes through the tile
                               * pipeline -- and the '.'-capable one from the next launch on: a file's reads carry one flag or the other).
                               * (A reserved field before: same layout.) */
+    int32_t gather_mb;       /* mm_freq_submit with coalesce > 1: MiB of staging a launch may gather (0 = 1024) */
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
 
@@ -183,10 +185,23 @@ typedef struct mm_freq mm_freq_t;
 mm_freq_t *mm_freq_create(const mm_freq_opts_t *opts, int32_t n_contigs, const mm_contig_t *contigs,
                           int32_t n_intervals, const mm_interval_t *intervals, char *err, size_t err_len);
 
-/* Process one batch from HOST memory: H2D on an internal stream, then the hot-path kernels (k_scan_reads,
- * k_sum_tiles, k_call_tiles).  Asynchronous;
- * the batch memory must stay valid until mm_freq_wait(ticket) returns.  Returns a ticket >= 0 or -MM_E_*. */
+/* Process one batch from HOST memory: H2D on an internal stream, then the hot-path kernels.
+ * Asynchronous; the batch memory must stay valid until mm_freq_host_done(ticket) or mm_freq_wait(ticket) returns.
+ * Returns a ticket >= 0 or -MM_E_*.
+ *
+ * Gathering (opts.coalesce > 1): process_db is called once per -K batch (src/minimod.c:344-350), and a -K batch is a
+ * fraction of what fills an MI355X.  Consecutive host batches are therefore copied one behind the other into one staging
+ * area in device memory (offsets of the read records rebased by a kernel) and launched TOGETHER, up to opts.coalesce of
+ * them or opts.gather_mb MiB, as one batch: they return the SAME ticket, as with mm_freq_submit_device.  The launch is made
+ * when the group is full, when something waits for the ticket, or when any call needs the counters.  A per-read error is
+ * reported with the read's index counted from the group's first read (mm_freq_read_record returns its record). */
 int32_t mm_freq_submit(mm_freq_t *h, const mm_batch_t *host_batch);
+/* the host memory of every batch submitted under this ticket so far has been copied: the caller may reuse it (the
+ * batches themselves may not have been launched yet).  Returns 0 or MM_E_*. */
+int32_t mm_freq_host_done(mm_freq_t *h, int32_t ticket);
+/* the record of read `index` of the ticket's (gathered) batch as the device holds it: tid, pos, l_qseq, ... as submitted,
+ * pool offsets those of the staging area.  For error messages (the reference prints contig and position).  0 or MM_E_*. */
+int32_t mm_freq_read_record(mm_freq_t *h, int32_t ticket, int32_t index, mm_read_t *out);
 
 /* Process one batch already RESIDENT in device memory (all mm_batch_t pointers are device pointers) on the given
  * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*.  The batch
@@ -248,6 +263,9 @@ int32_t mm_freq_stats_enable(mm_freq_t *h, int32_t enable);
 int32_t mm_freq_stats_get(mm_freq_t *h, uint64_t out[16]);   /* [4..6]: reads k_stream_reads did itself / handed to the tile pipeline /
                                                                 * to the fused kernel; [7..15]: phase time sums in diagnostic builds, else 0 */
 int64_t mm_freq_device_bytes(const mm_freq_t *h);
+/* how the submits so far were launched: [0] hot-path launches, [1] of which with k_stream_reads (the whole read in one
+ * wavefront), [2] submits, [3] reads submitted.  (A gathered group not yet launched is not counted in [0] and [1].) */
+int32_t mm_freq_launch_counts(const mm_freq_t *h, uint64_t out[4]);
 
 void mm_freq_reset_counters(mm_freq_t *h);
 void mm_freq_destroy(mm_freq_t *h);

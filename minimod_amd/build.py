@@ -15,6 +15,17 @@ def lib_path(name="libminimod_hip.so"):
     return os.path.join(LIBDIR, name)
 
 
+def source_hash():
+    """sha256 over the device library's sources (what a measurement made with rocprofv3 outside bench.py is stamped with)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip*"))) + [os.path.join(INCLUDE, "minimod_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, sources):
     if not os.path.exists(target):
         return True

@@ -42,6 +42,10 @@ struct Slot {
     void* d_mm = nullptr;    size_t cap_mm = 0;
     void* d_ml = nullptr;    size_t cap_ml = 0;
     void* d_order = nullptr; size_t cap_order = 0;
+    // host batches gathered in the staging buffers above (opts.coalesce): what is filled so far
+    size_t fill_reads = 0, fill_cigar = 0, fill_seq = 0, fill_mm = 0, fill_ml = 0;   // reads / words / bytes
+    hipEvent_t ev_copied = nullptr;   // behind the last host -> device copy of the slot's batches
+    bool copy_pending = false;
     int32_t* d_status = nullptr; size_t cap_status = 0;
     uint32_t* d_spill = nullptr; size_t cap_spill = 0;
     unsigned int* d_ctl = nullptr;   // two sets of 128 words, used alternately: [0] read queue, [1] err_summary, [4] fb_count,
@@ -139,6 +143,9 @@ struct mm_freq {
     int pending_slot = -1, pending_members = 0;
     mm_batch_t pending_batch;
     hipStream_t pending_stream = nullptr;
+    uint64_t n_launches = 0, n_stream_launches = 0, n_submits = 0, n_reads_submitted = 0;   // mm_freq_launch_counts
+    bool pending_host = false;        // ... of host batches staged one behind the other (mm_freq_submit) instead
+    uint64_t pending_bases = 0;       // bases of the gathered reads when known (host batches), else 0
     // finalize scratch
     uint32_t* d_tile_counts = nullptr; unsigned long long* d_tile_offsets = nullptr; size_t cap_tiles = 0;
     DenseRow* d_rows = nullptr; size_t cap_rows = 0;
@@ -262,7 +269,15 @@ void launch_tile_kernels(mm_freq* h, const TileParams& tp, int ga, int gs, int g
                else hipLaunchKernelGGL((k_call_tiles<RW, false, false>), dim3(gc), dim3(256), 0, st, tp); });
 }
 
-int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
+// a host batch appended to a staging area: its reads' pool offsets move by where its pools went
+__global__ void k_rebase_reads(mm_read_t* reads, int32_t n, uint64_t cigar_words, uint64_t seq_bytes, uint64_t mm_bytes, uint64_t ml_bytes) {
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    reads[i].cigar_off += cigar_words; reads[i].seq_off += seq_bytes; reads[i].mm_off += mm_bytes; reads[i].ml_off += ml_bytes;
+}
+
+// bases_hint: the bases of the launch's reads when the caller knows them (host batches), else 0
+int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t bases_hint = 0) {
     DevParams p = base_params(h);
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
     p.n_reads = b->n_reads;
@@ -347,6 +362,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
         HIPCHK(hipMemsetAsync(s.d_tq + kQueueWords * (s.ctl_set ^ 1), 0, kQueueWords * sizeof(unsigned int), st));
     }
     HIPCHK(hipEventRecord(s.ev_start, st));
+    if (b->n_reads > 0) h->n_launches++;
     if (b->n_reads > 0) {
         if (h->use_tiles) {
             bool stream = false, all_stream = false;
@@ -366,7 +382,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
                 // pipeline.  The launch's bases are not known here for device batches -- windows of a resident set share pool
                 // sizes -- so its reads are taken as 12 kb each; a launch too small to hide reads of `split` bases (a single
                 // -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
-                const uint64_t hide = 12000ull * (uint64_t)b->n_reads / 4500;
+                const uint64_t hide = (bases_hint ? bases_hint : 12000ull * (uint64_t)b->n_reads) / 4500;
                 const int mode = h->opts.stream_mode;
                 stream = mode != 1 && !p.insertions && !p.haplotypes && (mode >= 2 || hide >= split);   // (view as well: the records go where the tile kernels' go)
                 const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
@@ -399,6 +415,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
             int gs = h->n_cu * 6;   // measured: 8 waves per SIMD 16.0 us, 6 14.8 us, 4 16.9 us
             if (ga < 1) ga = 1;
             if (stream) {
+                h->n_stream_launches++;
                 const int gf = h->n_cu * h->stream_blocks_per_cu;
                 // which instantiation: the lean one until a read with a '.' group has shown up (the flag of the slot's last
                 // launch is looked at here: a file's reads carry one flag or the other), stream_mode 3 = the '.'-capable one at once
@@ -504,8 +521,9 @@ int flush_pending(mm_freq* h) {
     if (h->pending_slot < 0) return 0;
     Slot& s = h->slots[h->pending_slot];
     const int members = h->pending_members;
-    h->pending_slot = -1; h->pending_members = 0;
-    int r = launch_k1(h, s, &h->pending_batch, h->pending_stream);
+    const uint64_t bases = h->pending_bases;
+    h->pending_slot = -1; h->pending_members = 0; h->pending_host = false; h->pending_bases = 0;
+    int r = launch_k1(h, s, &h->pending_batch, h->pending_stream, bases);
     s.members = members;
     if (r) { s.busy = false; if (!h->sticky_err) h->sticky_err = -r; }
     return r;
@@ -600,6 +618,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_copied) (void)hipEventDestroy(s.ev_copied);
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
                       s.d_plan, s.d_plan_stream, s.d_plan_state,
@@ -672,7 +691,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
     for (auto& s : h->slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
-        if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
+        if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
         if (dev_alloc(h, (void**)&s.d_ctl, 2 * kCtlSetWords * sizeof(unsigned int))) return fail(h, "alloc failed");
         {
             unsigned int init[2 * kCtlSetWords];
@@ -885,8 +905,9 @@ const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    h->n_submits++; h->n_reads_submitted += (uint64_t)b->n_reads;
     const bool gather = h->opts.coalesce > 1 && h->use_tiles && !b->order && b->n_reads > 0;   // (view too: a ticket's rows are then those of the group, `read` counted from its first read)
-    if (gather && h->pending_slot >= 0) {
+    if (gather && h->pending_slot >= 0 && !h->pending_host && !h->codes_dirty) {   // (a code interned since the group began: the table is uploaded before a launch's FIRST window, so the group ends here)
         // does this submit continue the gathered group?  (windows of one resident read set, one after the other)
         const mm_batch_t& g = h->pending_batch;
         hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->slots[h->pending_slot].stream;
@@ -911,6 +932,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     if (r) return r;
     if (gather) {   // the first window of a group: launched when the group is full or somebody needs it
         h->pending_slot = si; h->pending_members = 1; h->pending_batch = *b; h->pending_stream = st;
+        h->pending_host = false; h->pending_bases = 0;
         s.busy = true; s.timed = false; s.members = 1;
         return si;
     }
@@ -924,9 +946,87 @@ int32_t mm_freq_ticket_batches(mm_freq_t* h, int32_t ticket) {
     return ticket == h->pending_slot ? h->pending_members : h->slots[ticket].members;
 }
 
+// bases of a host batch, near enough for the size of its launch: two a byte of the sequence pool, less the pool's slack and
+// the reads' alignment padding
+static uint64_t batch_bases(const mm_batch_t* b) {
+    const uint64_t pad = 64 + 8ull * (uint64_t)b->n_reads;
+    return b->n_seq_bytes > pad ? 2 * (b->n_seq_bytes - pad) : 0;
+}
+
+static int copy_host_batch(mm_freq* h, Slot& s, const mm_batch_t* hb, hipStream_t st, size_t at_reads, size_t at_cigar, size_t at_seq, size_t at_mm, size_t at_ml) {
+    (void)h;
+    if (hb->n_reads) HIPCHK(hipMemcpyAsync((char*)s.d_reads + sizeof(mm_read_t) * at_reads, hb->reads, sizeof(mm_read_t) * (size_t)hb->n_reads, hipMemcpyHostToDevice, st));
+    if (hb->n_cigar_words) HIPCHK(hipMemcpyAsync((char*)s.d_cigar + 4 * at_cigar, hb->cigar, 4 * hb->n_cigar_words, hipMemcpyHostToDevice, st));
+    if (hb->n_seq_bytes) HIPCHK(hipMemcpyAsync((char*)s.d_seq + at_seq, hb->seq, hb->n_seq_bytes, hipMemcpyHostToDevice, st));
+    if (hb->n_mm_bytes) HIPCHK(hipMemcpyAsync((char*)s.d_mm + at_mm, hb->mm, hb->n_mm_bytes, hipMemcpyHostToDevice, st));
+    if (hb->n_ml_bytes) HIPCHK(hipMemcpyAsync((char*)s.d_ml + at_ml, hb->ml, hb->n_ml_bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+// mm_freq_submit with opts.coalesce > 1: the batch goes behind the ones already staged in the group's slot; the group is
+// launched when it is full (batches, staging room) or when somebody needs it
+static int32_t submit_host_gathered(mm_freq* h, const mm_batch_t* hb) {
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    if (h->pending_slot >= 0) {
+        Slot& s = h->slots[h->pending_slot];
+        const bool fits = h->pending_host && !h->codes_dirty && h->pending_members < h->opts.coalesce &&
+                          sizeof(mm_read_t) * (s.fill_reads + (size_t)hb->n_reads) <= s.cap_reads && 4 * (s.fill_cigar + hb->n_cigar_words) <= s.cap_cigar &&
+                          s.fill_seq + hb->n_seq_bytes <= s.cap_seq && s.fill_mm + hb->n_mm_bytes <= s.cap_mm && s.fill_ml + hb->n_ml_bytes <= s.cap_ml &&
+                          s.fill_mm + hb->n_mm_bytes < 0xFFFFF000ull && s.fill_reads + (size_t)hb->n_reads < ((size_t)1 << 24);
+        if (!fits) { int r = flush_pending(h); if (r) return r; }
+    }
+    if (h->pending_slot < 0) {
+        const int si = acquire_slot(h);
+        if (h->sticky_err) return -h->sticky_err;
+        Slot& s = h->slots[si];
+        int r = upload_codes(h, s.stream);
+        if (r) return r;
+        // staging for as many batches like this one as may be gathered, within the budget
+        const size_t budget = (size_t)(h->opts.gather_mb > 0 ? h->opts.gather_mb : 1024) << 20;
+        const size_t one = sizeof(mm_read_t) * (size_t)hb->n_reads + 4 * hb->n_cigar_words + hb->n_seq_bytes + hb->n_mm_bytes + hb->n_ml_bytes + 80;
+        const size_t f = std::max<size_t>(1, std::min<size_t>((size_t)h->opts.coalesce, budget / one));
+        if ((r = grow(h, &s.d_reads, &s.cap_reads, f * sizeof(mm_read_t) * (size_t)hb->n_reads)) || (r = grow(h, &s.d_cigar, &s.cap_cigar, f * (4 * hb->n_cigar_words + 16))) ||
+            (r = grow(h, &s.d_seq, &s.cap_seq, f * (hb->n_seq_bytes + 16))) || (r = grow(h, &s.d_mm, &s.cap_mm, f * (hb->n_mm_bytes + 16))) ||
+            (r = grow(h, &s.d_ml, &s.cap_ml, f * (hb->n_ml_bytes + 16))))
+            return r;
+        s.fill_reads = s.fill_cigar = s.fill_seq = s.fill_mm = s.fill_ml = 0;
+        h->pending_slot = si; h->pending_members = 0; h->pending_stream = s.stream; h->pending_host = true; h->pending_bases = 0;
+        std::memset(&h->pending_batch, 0, sizeof h->pending_batch);
+        s.busy = true; s.timed = false; s.members = 1;
+    }
+    const int si = h->pending_slot;
+    Slot& s = h->slots[si];
+    hipStream_t st = s.stream;
+    { int r = copy_host_batch(h, s, hb, st, s.fill_reads, s.fill_cigar, s.fill_seq, s.fill_mm, s.fill_ml); if (r) return r; }
+    if (s.fill_reads) {   // (the group's first batch lies at offset 0)
+        hipLaunchKernelGGL(k_rebase_reads, dim3((unsigned)((hb->n_reads + 255) / 256)), dim3(256), 0, st, (mm_read_t*)s.d_reads + s.fill_reads, hb->n_reads,
+                           (uint64_t)s.fill_cigar, (uint64_t)s.fill_seq, (uint64_t)s.fill_mm, (uint64_t)s.fill_ml);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(s.ev_copied, st));
+    s.copy_pending = true;
+    mm_batch_t& g = h->pending_batch;
+    // the group as one batch: its pools end where this batch's end (every batch brings its own zero slack); the next one
+    // starts on a 16-byte boundary behind it
+    g.reads = (const mm_read_t*)s.d_reads; g.cigar = (const uint32_t*)s.d_cigar; g.seq = (const uint8_t*)s.d_seq;
+    g.mm = (const uint8_t*)s.d_mm; g.ml = (const uint8_t*)s.d_ml; g.order = nullptr; g.n_order = 0;
+    g.n_reads = (int32_t)(s.fill_reads + (size_t)hb->n_reads);
+    g.n_cigar_words = s.fill_cigar + hb->n_cigar_words; g.n_seq_bytes = s.fill_seq + hb->n_seq_bytes;
+    g.n_mm_bytes = s.fill_mm + hb->n_mm_bytes; g.n_ml_bytes = s.fill_ml + hb->n_ml_bytes;
+    g.max_n_cigar = std::max(g.max_n_cigar, hb->max_n_cigar); g.max_l_qseq = std::max(g.max_l_qseq, hb->max_l_qseq);
+    s.fill_reads += (size_t)hb->n_reads;
+    s.fill_cigar = (s.fill_cigar + hb->n_cigar_words + 3) & ~(size_t)3; s.fill_seq = up16(s.fill_seq + hb->n_seq_bytes);
+    s.fill_mm = up16(s.fill_mm + hb->n_mm_bytes); s.fill_ml = up16(s.fill_ml + hb->n_ml_bytes);
+    h->pending_bases += batch_bases(hb);
+    if (++h->pending_members >= h->opts.coalesce) { int r = flush_pending(h); if (r) return r; }
+    return si;
+}
+
 int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    h->n_submits++; h->n_reads_submitted += (uint64_t)hb->n_reads;
+    if (h->opts.coalesce > 1 && h->use_tiles && !hb->order && hb->n_reads > 0) return submit_host_gathered(h, hb);
     { int rf = flush_pending(h); if (rf) return rf; }
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
@@ -940,11 +1040,7 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
         (r = grow(h, &s.d_ml, &s.cap_ml, hb->n_ml_bytes)))
         return r;
     mm_batch_t db = *hb;
-    if (hb->n_reads) HIPCHK(hipMemcpyAsync(s.d_reads, hb->reads, nr, hipMemcpyHostToDevice, st));
-    if (hb->n_cigar_words) HIPCHK(hipMemcpyAsync(s.d_cigar, hb->cigar, 4 * hb->n_cigar_words, hipMemcpyHostToDevice, st));
-    if (hb->n_seq_bytes) HIPCHK(hipMemcpyAsync(s.d_seq, hb->seq, hb->n_seq_bytes, hipMemcpyHostToDevice, st));
-    if (hb->n_mm_bytes) HIPCHK(hipMemcpyAsync(s.d_mm, hb->mm, hb->n_mm_bytes, hipMemcpyHostToDevice, st));
-    if (hb->n_ml_bytes) HIPCHK(hipMemcpyAsync(s.d_ml, hb->ml, hb->n_ml_bytes, hipMemcpyHostToDevice, st));
+    if ((r = copy_host_batch(h, s, hb, st, 0, 0, 0, 0, 0))) return r;
     db.reads = (const mm_read_t*)s.d_reads; db.cigar = (const uint32_t*)s.d_cigar; db.seq = (const uint8_t*)s.d_seq;
     db.mm = (const uint8_t*)s.d_mm; db.ml = (const uint8_t*)s.d_ml; db.order = nullptr;
     if (hb->n_reads && hb->order) {
@@ -954,8 +1050,28 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
         db.order = (const int32_t*)s.d_order;
         db.n_order = hb->n_order;
     }
-    r = launch_k1(h, s, &db, st);
+    HIPCHK(hipEventRecord(s.ev_copied, st));
+    s.copy_pending = true;
+    r = launch_k1(h, s, &db, st, batch_bases(hb));
     return r ? r : si;
+}
+
+int32_t mm_freq_host_done(mm_freq_t* h, int32_t ticket) {
+    if (!h || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
+    Slot& s = h->slots[ticket];
+    if (!s.copy_pending) return MM_OK;
+    if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(s.ev_copied) != hipSuccess) return MM_E_HIP;
+    s.copy_pending = false;
+    return MM_OK;
+}
+
+int32_t mm_freq_read_record(mm_freq_t* h, int32_t ticket, int32_t index, mm_read_t* out) {
+    if (!h || !out || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
+    const mm_batch_t& b = ticket == h->pending_slot ? h->pending_batch : h->slots[ticket].last_batch;
+    if (index < 0 || index >= b.n_reads || !b.reads) return MM_E_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
+    if (hipMemcpy(out, b.reads + index, sizeof(mm_read_t), hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
+    return MM_OK;
 }
 
 int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
@@ -997,6 +1113,12 @@ int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
 }
 
 int64_t mm_freq_device_bytes(const mm_freq_t* h) { return h ? h->device_bytes : 0; }
+
+int32_t mm_freq_launch_counts(const mm_freq_t* h, uint64_t out[4]) {
+    if (!h || !out) return -MM_E_ARG;
+    out[0] = h->n_launches; out[1] = h->n_stream_launches; out[2] = h->n_submits; out[3] = h->n_reads_submitted;
+    return 0;
+}
 
 void mm_freq_reset_counters(mm_freq_t* h) {
     if (!h) return;

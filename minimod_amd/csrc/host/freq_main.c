@@ -34,6 +34,7 @@ static struct option long_options[] = {
     {"device", required_argument, 0, 0},           /* 17 (new: HIP device ordinal) */
     {"devices", required_argument, 0, 0},          /* 18 (new: one worker process per listed GPU, the genome cut into shares) */
     {"canonical-order", no_argument, 0, 0},        /* 19 (new: rows that tie on (contig, start) in a fixed order instead of the reference's hash order) */
+    {"gather", required_argument, 0, 0},           /* 20 (new: -K batches that may share one kernel launch) */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -58,14 +59,15 @@ static struct option view_long_options[] = {
 
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device, view, canonical_order;
+    int progress_interval, device, view, canonical_order, gather;
     const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
 
 /* one worker of `--devices`: its share of the genome and where its rows go */
 #define MMH_MAX_DEVICES 64
-#define MMH_SHARE_HALO ((int64_t)1 << 18)     /* counters kept past a cut inside a contig (a read's calls reach that far at most) */
+#define MMH_SHARE_HALO ((int64_t)1 << 18)     /* dense counters kept past a cut inside a contig; the calls of a read that reaches further (>256 kb behind
+                                               * the cut: spliced or ultra-long) go to the side table, which takes any position */
 #define MMH_SHARE_ALIGN ((int64_t)1 << 16)
 typedef struct {
     int sharded, first, last, fd;          /* fd: pipe to the parent (rows + totals) */
@@ -103,13 +105,19 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "   --device INT               GPU to use [%d]\n", o->device);
     if (!o->view) fprintf(fp, "   --canonical-order          rows of one (contig, start) by strand, code, ins_offset, haplotype instead of the order\n"
                               "                              minimod's hash table leaves them in (skips the replay of that table) [%s]\n", o->canonical_order ? "yes" : "no");
+    if (!o->view) fprintf(fp, "   --gather INT               -K batches that may share one kernel launch (they are staged in GPU memory one behind the\n"
+                              "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
     if (!o->view) fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
+static void die_read_record(int code, int32_t read, const mm_read_t *rd, const mm_bam_hdr_t *hdr);
 static void die_read_error(int code, int32_t read, const mm_batch_t *b, const mm_bam_hdr_t *hdr) {
+    die_read_record(code, read, (read >= 0 && read < b->n_reads) ? &b->reads[read] : NULL, hdr);
+}
+/* `read`: the read's index in its -K batch (what the reference prints); rd: its record, or NULL */
+static void die_read_record(int code, int32_t read, const mm_read_t *rd, const mm_bam_hdr_t *hdr) {
     (void)mmh_emit_flush();   /* rows of earlier batches reach the output as they did with stdio */
-    const mm_read_t *rd = (read >= 0 && read < b->n_reads) ? &b->reads[read] : NULL;
     const char *tname = (rd && rd->tid >= 0 && rd->tid < hdr->n_targets) ? hdr->target_name[rd->tid] : "*";
     switch (code) {
         case MM_E_HARDCLIP:   /* :843 */
@@ -204,6 +212,27 @@ static int read_all(int fd, void *buf, size_t n) {
     return 0;
 }
 
+/* freq: the -K batches that share a ticket (mm_freq_submit gathers up to opts.coalesce of them into one launch) */
+#define MMH_MAX_GATHER 256
+typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; } group_t;
+
+/* wait for a group's launch; a failing read is named by its index in its own -K batch, like the reference does */
+static void retire_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr, double *wait_time) {
+    if (g->ticket < 0) return;
+    double tw = mmh_realtime();
+    int32_t bad = -1;
+    int e = mm_freq_wait(h, g->ticket, &bad);
+    *wait_time += mmh_realtime() - tw;
+    if (e) {
+        mm_read_t rec;
+        const int have = bad >= 0 && mm_freq_read_record(h, g->ticket, bad, &rec) == 0;
+        int32_t in_batch = bad;
+        for (int m = 0; m < g->n && in_batch >= g->n_reads[m]; m++) in_batch -= g->n_reads[m];
+        die_read_record(e, in_batch, have ? &rec : NULL, hdr);
+    }
+    g->ticket = -1; g->n = 0;
+}
+
 /* a replay run's second handle: the batch's calls (view rows with group ordinals) go into the tie-order replay */
 static void replay_batch(mm_freq_t *hv, mmh_tie_t *tie, int32_t ticket, const mm_batch_t *b, const mm_bam_hdr_t *hdr, mm_pool_t *pool,
                          const uint8_t *const *klass_of_code, double *seconds) {
@@ -225,6 +254,13 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     const mmh_mods_t mods = *modsp;
     const int view = o.view;
     char err[512];
+    if (ws->sharded && ws->n_iv == 0 && !ws->last && ws->fd >= 0) {   /* more workers than 64 kb pieces of genome: nothing to do, nothing allocated */
+        wtotals_t tt;
+        memset(&tt, 0, sizeof tt);
+        if (write_all(ws->fd, &tt, sizeof tt)) { MMH_ERROR("%s", "Could not send the rows to the parent process"); exit(EXIT_FAILURE); }
+        close(ws->fd);
+        return 0;
+    }
     mmh_loader_t *ld = ws->sharded
         ? mmh_loader_open_share(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
                                 ws->hi_tid, ws->hi_pos, ws->first, ws->last)
@@ -244,6 +280,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mm_freq_opts_t fo;
     mmh_fill_opts(&mods, o.insertions, o.haplotypes, o.device, &fo);
     fo.view = view;
+    /* process_db is called per -K batch (src/minimod.c:344-350); the library stages consecutive batches in GPU memory and
+     * launches them together.  view prints a batch's rows when the batch is retired, so its batches stay their own launches. */
+    fo.coalesce = view ? 0 : (o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather);
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     int wildcard = 0, star_ctx = 0;
@@ -254,6 +293,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (replay) {
         mm_freq_opts_t fv = fo;
         fv.view = 2;
+        fv.coalesce = 0;   /* its rows are fetched batch by batch */
         hv = mm_freq_create(&fv, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
         tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
         if (!hv || !tie) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
@@ -285,25 +325,49 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     }
     mm_batch_t pending_batch, batch;
     memset(&pending_batch, 0, sizeof pending_batch);
+    /* freq: `cur` = the group being gathered, `prev` = the one launched last (waited for one iteration later, so that the
+     * wait costs nothing); copied[set] = the ticket whose host -> device copy last read from that pool set */
+    group_t *cur = (group_t *)calloc(1, sizeof(group_t)), *prev = (group_t *)calloc(1, sizeof(group_t));
+    cur->ticket = prev->ticket = -1;
+    int32_t copied[2] = {-1, -1};
     double prog_t = mmh_realtime();
     while (more) {
         double tl = mmh_realtime();
+        if (copied[set] >= 0) {   /* the batch read into this pool set two iterations ago must have left host memory */
+            int e = mm_freq_host_done(h, copied[set]);
+            if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+            copied[set] = -1;
+        }
         int32_t n = mmh_loader_next(ld, set, &batch, &more);
         if (n < 0) { MMH_ERROR("%s", "Truncated or corrupt BAM file"); exit(EXIT_FAILURE); }
         load_time += mmh_realtime() - tl;
         fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bases) loaded\n", __func__, mmh_realtime() - realtime0,
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
-        if (pending_ticket >= 0) {
+        if (view && pending_ticket >= 0) {
             retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
-            if (replay) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
             pending_ticket = -1;
         }
+        if (replay && pending_vticket >= 0) {
+            replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
+            pending_vticket = -1;
+        }
+        if (!view) retire_group(h, prev, hdr, &process_wait_time);
         if (n > 0) {
             if (wildcard) { intern_batch_codes(h, &batch); if (replay) intern_batch_codes(hv, &batch); }
             int32_t tk = mm_freq_submit(h, &batch);
             if (tk < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(tk)); exit(EXIT_FAILURE); }
-            pending_ticket = tk; pending_batch = batch;
+            pending_batch = batch;
+            if (view) pending_ticket = tk;
+            else {
+                if (tk != cur->ticket) {   /* a new group: the one before it has been launched */
+                    retire_group(h, prev, hdr, &process_wait_time);
+                    group_t *t = prev; prev = cur; cur = t;
+                    cur->ticket = tk; cur->n = 0;
+                }
+                if (cur->n < MMH_MAX_GATHER) cur->n_reads[cur->n++] = n;
+                copied[set] = tk;
+            }
             if (replay) {
                 pending_vticket = mm_freq_submit(hv, &batch);
                 if (pending_vticket < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(pending_vticket)); exit(EXIT_FAILURE); }
@@ -324,10 +388,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (pending_ticket >= 0) {
+    if (view && pending_ticket >= 0)
         retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
-        if (replay) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
-    }
+    if (replay && pending_vticket >= 0) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
+    if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
+    free(cur); free(prev);
     double sort_time = 0;
     if (!view) {
         double ts = mmh_realtime();
@@ -387,6 +452,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fprintf(stderr, "\n[%s] Data merging time: %.3f sec", __func__, 0.0);
     fprintf(stderr, "\n[%s] Data sorting time: %.3f sec", __func__, sort_time);
     fprintf(stderr, "\n[%s] Data output time: %.3f sec", __func__, output_time);
+    {
+        uint64_t lc[4] = {0, 0, 0, 0};
+        (void)mm_freq_launch_counts(h, lc);
+        fprintf(stderr, "\n[%s] GPU launches: %lu for %lu batches (%lu with k_stream_reads)", __func__, (unsigned long)lc[0], (unsigned long)lc[2], (unsigned long)lc[1]);
+    }
     fprintf(stderr, "\n");
     mm_freq_destroy(h);
     if (hv) mm_freq_destroy(hv);
@@ -418,11 +488,15 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
     for (int i = 0; i < mods->n_mods; i++)
         if (strcmp(mods->code[i], "*") == 0) { MMH_ERROR("%s", "--devices cannot be combined with the wildcard code -c '*' (code indices are per worker)"); exit(EXIT_FAILURE); }
     int dev[MMH_MAX_DEVICES], nd = 0;
-    for (const char *p = o->devices; *p && nd < MMH_MAX_DEVICES;) {
-        dev[nd++] = atoi(p);
-        const char *c = strchr(p, ',');
-        if (!c) break;
-        p = c + 1;
+    for (const char *p = o->devices;;) {   /* ordinals separated by commas; one GPU may be listed more than once (a worker each) */
+        char *end = NULL;
+        errno = 0;
+        long v = strtol(p, &end, 10);
+        if (end == p || errno || v < 0 || v > 1023 || (*end != ',' && *end != 0)) { MMH_ERROR("--devices takes GPU ordinals separated by commas, e.g. 0,1,2,3. You entered %s", o->devices); exit(EXIT_FAILURE); }
+        if (nd >= MMH_MAX_DEVICES) { MMH_ERROR("--devices takes at most %d GPUs", MMH_MAX_DEVICES); exit(EXIT_FAILURE); }
+        dev[nd++] = (int)v;
+        if (*end == 0) break;
+        p = end + 1;
     }
     if (nd < 2) { MMH_ERROR("%s", "--devices needs at least two GPUs"); exit(EXIT_FAILURE); }
     char bai_path[4096];
@@ -465,6 +539,17 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         if (w->n_iv == 0) { w->lo_tid = nt; w->lo_pos = 0; w->hi_tid = nt; w->hi_pos = 0; w->voffset = UINT64_MAX; }
         else w->voffset = w->first ? 0 : mm_bai_start(bai, w->lo_tid, w->lo_pos);
         if (w->first) { w->lo_tid = -1; w->lo_pos = 0; }
+        /* a share's reads begin where the share before it stops reading (not at its own first interval): an alignment on a
+         * header contig the FASTA lacks, lying between two shares, is then read by the right-hand worker, which fails on it
+         * like a single run does (src/mod.c:793) */
+        if (r > 0 && w->n_iv > 0) {
+            int q = r - 1;
+            while (q > 0 && ws[q].n_iv == 0) q--;
+            if (ws[q].n_iv > 0 && !(ws[q].hi_tid == w->lo_tid && ws[q].hi_pos == w->lo_pos)) {
+                w->lo_tid = ws[q].hi_tid; w->lo_pos = ws[q].hi_pos;
+                w->voffset = mm_bai_start(bai, w->lo_tid, w->lo_pos);
+            }
+        }
     }
     mm_bai_free(bai);
     /* the workers: forked before anything in this process has touched HIP */
@@ -602,7 +687,7 @@ static int run_main(int argc, char **argv, int view) {
     fopt_t o;
     memset(&o, 0, sizeof(o));
     o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    o.view = view;
+    o.view = view; o.gather = 32;
     while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
         const char *lname = c == 0 ? lopts[longindex].name : "";
         if (c == 'B') {
@@ -643,6 +728,9 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
         } else if (c == 0 && strcmp(lname, "devices") == 0) { o.devices = optarg;
         } else if (c == 0 && strcmp(lname, "canonical-order") == 0) { o.canonical_order = 1;
+        } else if (c == 0 && strcmp(lname, "gather") == 0) {
+            o.gather = atoi(optarg);
+            if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }
         } else {
             print_help(fp_help, &o);
             exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);

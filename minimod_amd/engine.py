@@ -10,7 +10,7 @@ import numpy as np
 
 from .build import build_hip, lib_path
 
-MM_ABI_VERSION = 3
+MM_ABI_VERSION = 4
 MM_MAX_MODS = 13
 MM_CODE_LEN = 16
 
@@ -47,7 +47,7 @@ class mm_freq_opts_t(ctypes.Structure):
                 ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
                 ("force_fused", ctypes.c_int32), ("view_cap", ctypes.c_int32), ("finalize_by_runs", ctypes.c_int32),
                 ("split_bases", ctypes.c_int32), ("coalesce", ctypes.c_int32), ("stream_mode", ctypes.c_int32),
-                ("mods", mm_mod_t * MM_MAX_MODS)]
+                ("gather_mb", ctypes.c_int32), ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
 class mm_contig_t(ctypes.Structure):
@@ -61,9 +61,9 @@ class mm_interval_t(ctypes.Structure):
 
 
 EXPORTS = ["mm_freq_plan_batch", "mm_freq_ticket_batches", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device",
-           "mm_freq_wait", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
+           "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear",
-           "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_reset_counters", "mm_freq_destroy"]
+           "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_launch_counts", "mm_freq_reset_counters", "mm_freq_destroy"]
 
 _lib = None
 
@@ -122,6 +122,10 @@ def load_library(build=True):
     L.mm_freq_ticket_batches.argtypes = [vp, i32]
     L.mm_freq_wait.restype = i32
     L.mm_freq_wait.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.mm_freq_host_done.restype = i32
+    L.mm_freq_host_done.argtypes = [vp, i32]
+    L.mm_freq_read_record.restype = i32
+    L.mm_freq_read_record.argtypes = [vp, i32, i32, vp]
     for f in ("mm_view_fetch", "mm_view_fetch_device"):
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i32)]
@@ -150,6 +154,8 @@ def load_library(build=True):
     L.mm_freq_stats_get.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mm_freq_device_bytes.restype = i64
     L.mm_freq_device_bytes.argtypes = [vp]
+    L.mm_freq_launch_counts.restype = i32
+    L.mm_freq_launch_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mm_freq_reset_counters.argtypes = [vp]
     L.mm_freq_destroy.argtypes = [vp]
     if L.mm_abi_version() != MM_ABI_VERSION:
@@ -216,7 +222,7 @@ class FreqEngine(object):
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
                  n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False, force_fused=False, view_cap=0,
-                 finalize_by_runs=False, split_bases=0, coalesce=0, stream_mode=0):
+                 finalize_by_runs=False, split_bases=0, coalesce=0, stream_mode=0, gather_mb=0):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -226,7 +232,7 @@ class FreqEngine(object):
         o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
         o.view = int(view)
         o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
-        o.split_bases, o.coalesce = int(split_bases), int(coalesce)
+        o.split_bases, o.coalesce, o.gather_mb = int(split_bases), int(coalesce), int(gather_mb)
         o.stream_mode = int(stream_mode)   # 0 by launch size, 1 never, 2 always (reads up to split_bases), 3 always + '.' groups from the first launch
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()
@@ -307,6 +313,20 @@ class FreqEngine(object):
         if e:
             raise MinimodHipError(e, "read %d: %s" % (bad.value, self.L.mm_strerror(e).decode()), bad.value)
 
+    def host_done(self, ticket):
+        """The host memory of every batch submitted under the ticket so far may be reused."""
+        e = self.L.mm_freq_host_done(self.h, ticket)
+        if e:
+            raise MinimodHipError(e, "mm_freq_host_done: " + self.L.mm_strerror(e).decode())
+
+    def read_record(self, ticket, index):
+        """Read `index` of the ticket's (gathered) batch as the device holds it (a READ_DTYPE scalar)."""
+        out = np.zeros(1, dtype=READ_DTYPE)
+        e = self.L.mm_freq_read_record(self.h, ticket, int(index), out.ctypes.data)
+        if e:
+            raise MinimodHipError(e, "mm_freq_read_record: " + self.L.mm_strerror(e).decode())
+        return out[0]
+
     def process(self, batch, order=None):
         self.wait(self.submit(batch, order))
 
@@ -360,6 +380,11 @@ class FreqEngine(object):
 
     def reset(self):
         self.L.mm_freq_reset_counters(self.h)
+
+    def launch_counts(self):
+        out = (ctypes.c_uint64 * 4)()
+        self.L.mm_freq_launch_counts(self.h, out)
+        return {"launches": int(out[0]), "stream_launches": int(out[1]), "submits": int(out[2]), "reads": int(out[3])}
 
     def device_bytes(self):
         return int(self.L.mm_freq_device_bytes(self.h))

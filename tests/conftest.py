@@ -23,6 +23,11 @@ def _gpu_visible():
 def pytest_collection_modifyitems(config, items):
     if _gpu_visible():
         return
+    # `-m gpu` on a box without a GPU must not come out green with nothing run (MM_ALLOW_NO_GPU=1: skip them knowingly)
+    expr = (config.getoption("-m") or "").strip()
+    if "gpu" in expr and "not gpu" not in expr and os.environ.get("MM_ALLOW_NO_GPU") != "1":
+        raise pytest.UsageError("-m gpu was asked for and no MI355X is visible (/dev/kfd or /dev/dri/renderD* missing); "
+                                "set MM_ALLOW_NO_GPU=1 to skip the GPU tests knowingly")
     skip = pytest.mark.skip(reason="no MI355X visible (/dev/kfd missing): GPU parity tests need the HIP path, which has no CPU fallback")
     for it in items:
         if "gpu" in it.keywords:

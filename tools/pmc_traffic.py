@@ -3,7 +3,9 @@
 tools/profile_round.sh): the LAST dispatch of every hot-path kernel is the timed launch of the profiled command (its
 --steps batches gathered into one launch); counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section)
 prescribes for gfx950.  usage: pmc_traffic.py FETCH.csv WRITE.csv <batches in the timed launch> <algorithmic bytes per batch> > profiles/traffic_c2.json"""
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from minimod_amd.build import source_hash
 KERNELS = ("k_plan_items", "k_stream_reads", "k_scan_reads", "k_sum_tiles", "k_call_tiles")
 def last(path):
     out = {}
@@ -16,6 +18,7 @@ f, w = last(sys.argv[1]), last(sys.argv[2])
 nb, alg = int(sys.argv[3]), float(sys.argv[4])
 per_launch = sum(2 * f[k] + w[k] for k in KERNELS) * 1024
 print(json.dumps({
+    "source_hash": source_hash(),
     "what": "HBM traffic of the freq hot path (k_plan_items + k_stream_reads + k_scan_reads + k_sum_tiles + k_call_tiles), workload C2, one launch of %d gathered -K 4096 batches" % nb,
     "how": "two separate rocprofv3 passes, `--kernel-trace --pmc FETCH_SIZE` and `--kernel-trace --pmc WRITE_SIZE` (never combined, no sys/hip trace), on "
            "`python3 bench.py --steps %d --warmup 0 --no-cpu-baseline --no-e2e --no-extra`; counters are in KB; per MI355X_MICROARCH.md (HBM section) "
