@@ -218,7 +218,7 @@ def plan_references(plan, seed):
         tid, clen = iv["tid"], plan["contigs"][iv["tid"]][1]
         if refs[tid] is None:
             refs[tid] = np.full(clen, ord("N"), dtype=np.uint8)
-        b = iv["begin"] // (1 << 20) * (1 << 20)
+        b = max(0, iv["begin"] - 64) // (1 << 20) * (1 << 20)   # (real bases in front of the piece too: a context match may begin there)
         e = min(clen, iv["end"] + iv["halo"] + (1 << 20))
         refs[tid][b:e] = synth.reference_slice(seed + 1000 * tid, b, e - b)
     return refs

@@ -100,9 +100,10 @@ typedef struct mm_freq_opts {
     int64_t side_capacity;   /* sparse side-list records (16 B each); 0 = default */
     int32_t n_wild_planes;   /* with -c '*': dense planes for the first n interned codes; 0 = default */
     int32_t view;            /* 1 = `minimod view`: per-read rows (mm_view_fetch) instead of counters (mm_freq_finalize);
-                              * 2 = the same rows with the MM group's ordinal (<= 255) in the top byte of mm_view_row_t.read and
-                              * bit 31 of read_pos set for the implicit calls of '.' groups: what the host's replay of the
-                              * reference's row order needs (csrc/host/tieorder.c) */
+                              * 2 = the same rows with the MM group's ordinal (<= 2047) in the top eleven bits of mm_view_row_t.read
+                              * (batches of fewer than 2^21 reads), bit 31 of read_pos set for the implicit calls of '.' groups,
+                              * and later entries of a key kept: what the host's replay of the reference's row order needs
+                              * (csrc/host/tieorder.c) */
     /* test / diagnostic switches (0 = the product's behaviour) */
     int32_t force_fused;     /* 1: every read through the fused one-wavefront-per-read kernel instead of the tile pipeline */
     int32_t view_cap;        /* view: records per append region before the grow-and-rerun path (0 = sized from the ML pool) */

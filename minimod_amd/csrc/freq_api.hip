@@ -117,6 +117,15 @@ struct mm_freq {
     int64_t *d_ref_base = nullptr, *d_ctg_len = nullptr, *d_seg_begin = nullptr, *d_seg_len = nullptr, *d_cnt_base = nullptr;
     unsigned long long* d_counters = nullptr;
     int64_t n_counter_words = 0;
+    // context classes and their site index (freq_kernels.hip.h, DevClass)
+    int n_classes = 0;
+    std::vector<int32_t> cls_of_mod;
+    std::vector<DevClass> classes;
+    std::vector<int64_t> adj;                 // [(tid * n_classes + class) * 2 + strand]
+    std::vector<int> plane_cls, plane_slot;   // per code plane
+    DevClass* d_classes = nullptr; int32_t* d_cls_of_mod = nullptr; int64_t* d_adj = nullptr;
+    std::vector<void*> d_site_arrays;
+    unsigned int* d_slab_flag = nullptr;
     DevMod* d_mods = nullptr;
     DevCode* d_codes = nullptr;
     std::vector<DevCode> codes;
@@ -148,7 +157,7 @@ struct mm_freq {
     uint64_t pending_bases = 0;       // bases of the gathered reads when known (host batches), else 0
     // finalize scratch
     uint32_t* d_tile_counts = nullptr; unsigned long long* d_tile_offsets = nullptr; size_t cap_tiles = 0;
-    DenseRow* d_rows = nullptr; size_t cap_rows = 0;
+    mm_row_t* d_rows = nullptr; size_t cap_rows = 0;   // (rows)
 };
 
 namespace {
@@ -223,6 +232,7 @@ DevParams base_params(mm_freq* h) {
     p.seg_begin = h->d_seg_begin; p.seg_len = h->d_seg_len; p.cnt_base = h->d_cnt_base;
     p.n_contigs = h->n_contigs;
     p.counters = h->d_counters; p.plane_len = h->plane_len; p.n_hp = h->n_hp;
+    p.n_classes = h->n_classes; p.classes = h->d_classes; p.cls_of_mod = h->d_cls_of_mod; p.adj = h->d_adj;
     p.n_mods = h->opts.n_mods; p.n_codes = (int)h->codes.size();
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
@@ -233,6 +243,15 @@ DevParams base_params(mm_freq* h) {
     p.stats = h->d_stats;   // diagnostic build: phase times of every launch (mm_freq_stats_get reads and clears them)
 #endif
     return p;
+}
+
+K2Params k2_params(mm_freq* h) {
+    K2Params k;
+    std::memset(&k, 0, sizeof k);
+    k.cnt = h->d_counters; k.classes = h->d_classes; k.adj = h->d_adj; k.ref_base = h->d_ref_base;
+    k.n_classes = h->n_classes; k.n_hp = h->n_hp; k.n_planes = h->n_code_planes; k.haplotypes = h->opts.haplotypes;
+    for (int pl = 0; pl < h->n_code_planes && pl < MM_MAX_CODES; pl++) { k.plane_cls[pl] = (int8_t)h->plane_cls[(size_t)pl]; k.plane_slot[pl] = (int8_t)h->plane_slot[(size_t)pl]; }
+    return k;
 }
 
 // order the rows of a view batch (view_kernels.hip.h): counting sort by read, then one small sort per read.  Everything
@@ -384,7 +403,9 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
                 // -K 4096 batch: 181 against 110 us) leaves everything to the tiles.
                 const uint64_t hide = (bases_hint ? bases_hint : 12000ull * (uint64_t)b->n_reads) / 4500;
                 const int mode = h->opts.stream_mode;
-                stream = mode != 1 && !p.insertions && !p.haplotypes && (mode >= 2 || hide >= split);   // (view as well: the records go where the tile kernels' go)
+                // (view as well: the records go where the tile kernels' go; --insertions / --haplotypes: freq only, the kIns instantiation)
+                const bool general = p.insertions || p.haplotypes;
+                stream = mode != 1 && !(general && p.view) && (mode >= 2 || hide >= split);
                 const uint32_t stream_max = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(split, hide), 0x00FFFFFFu);
                 if (stream && (r = grow(h, (void**)&s.d_plan_stream, &s.cap_plan_stream, 4 * (size_t)b->n_reads))) return r;
                 // every read is a stream item: k_stream_reads is the launch's last kernel (not in view mode: the ordering pass is
@@ -423,10 +444,14 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
                 s.h_ctl[132] = 0u;
                 tp.host_dot_flag = s.h_ctl + 132;
                 const bool kd = h->stream_dot || h->opts.stream_mode == 3;
-#define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true>), dim3(gf), dim3(256), 0, st, tp); \
-                                           else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
+#define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true, false>), dim3(gf), dim3(256), 0, st, tp); \
+                                           else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
                 MM_REF_DISPATCH(h,
-                    if (p.stats) { if (kd) MM_LAUNCH_STREAM(RW, true, true); else MM_LAUNCH_STREAM(RW, true, false); }
+                    if (p.insertions || p.haplotypes) {   // '?' groups only: reads with '.' groups go on to the tile pipeline
+                        if (p.stats) hipLaunchKernelGGL((k_stream_reads<RW, true, false, false, true>), dim3(gf), dim3(256), 0, st, tp);
+                        else hipLaunchKernelGGL((k_stream_reads<RW, false, false, false, true>), dim3(gf), dim3(256), 0, st, tp);
+                    }
+                    else if (p.stats) { if (kd) MM_LAUNCH_STREAM(RW, true, true); else MM_LAUNCH_STREAM(RW, true, false); }
                     else { if (kd) MM_LAUNCH_STREAM(RW, false, true); else MM_LAUNCH_STREAM(RW, false, false); });
 #undef MM_LAUNCH_STREAM
             }
@@ -633,6 +658,11 @@ void mm_freq_destroy(mm_freq_t* h) {
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
                   h->d_stab, h->d_scount, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)hipFree(p);
+    for (void* p : h->d_site_arrays) if (p) (void)hipFree(p);
+    if (h->d_classes) (void)hipFree(h->d_classes);
+    if (h->d_cls_of_mod) (void)hipFree(h->d_cls_of_mod);
+    if (h->d_adj) (void)hipFree(h->d_adj);
+    if (h->d_slab_flag) (void)hipFree(h->d_slab_flag);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -681,7 +711,10 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->scan_blocks_per_cu = na > 0 ? std::min(na, 8) : 4;
         h->call_blocks_per_cu = nc > 0 ? std::min(nc, 8) : 4;
         int nf = 0;
-        MM_REF_DISPATCH(h, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, true, false>), 256, 0));
+        MM_REF_DISPATCH(h,
+            if (!plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, false, false, true>), 256, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, true, false, false>), 256, 0));
+        if (getenv("MM_DEBUG_OCC")) std::fprintf(stderr, "[minimod_hip] k_stream_reads: %d workgroups per CU\n", nf);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
@@ -742,7 +775,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             DevCode c;
             std::memset(&c, 0, sizeof(c));
             std::snprintf(c.str, MM_CODE_LEN, "%s", opts->mods[i].code);
-            c.len = (int16_t)std::strlen(c.str); c.req = (int16_t)i; c.plane = (int16_t)i;
+            c.len = (int16_t)std::strlen(c.str); c.req = (int16_t)i; c.plane = (int16_t)i; c.slot = 0;   // (slot: set with the context classes below)
             h->codes.push_back(c);
         }
     }
@@ -817,6 +850,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     }
     const size_t ref_bytes = h->ref_kind == 0 ? (size_t)std::max<int64_t>(ref_total, 64) / 2 : (size_t)std::max<int64_t>(ref_total, 64) * (h->ref_kind == 2 ? 4 : 2);
     if (dev_alloc(h, &h->d_refw, ref_bytes)) return fail(h, "reference alloc failed");
+    (void)hipMemset(h->d_refw, 0, ref_bytes);   // (the padding behind every contig: no sites there)
     size_t tb = sizeof(int64_t) * (size_t)std::max(n_contigs, 1);
     if (dev_alloc(h, (void**)&h->d_ref_base, tb) || dev_alloc(h, (void**)&h->d_ctg_len, tb) || dev_alloc(h, (void**)&h->d_seg_begin, tb) ||
         dev_alloc(h, (void**)&h->d_seg_len, tb) || dev_alloc(h, (void**)&h->d_cnt_base, tb)) return fail(h, "alloc failed");
@@ -850,8 +884,109 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             (void)hipFree(d_raw);
         }
     }
-    // counters
-    h->n_counter_words = opts->view ? 0 : (int64_t)h->n_code_planes * h->n_hp * 2 * plane_len;   // view keeps no counters
+    // ---- context classes: mods with one context string share a class (their counters lie side by side per site); every position
+    // is a site of a DENSE class: the context `*`, and any class under --insertions, where no context is looked at (mod.c:1167-1172)
+    {
+        h->cls_of_mod.assign(opts->n_mods, 0);
+        std::vector<int> first_mod;   // per class: the mod whose reference-word bits mark its sites
+        for (int i = 0; i < opts->n_mods; i++) {
+            int c = -1;
+            for (size_t k = 0; k < first_mod.size(); k++) if (std::strcmp(opts->mods[first_mod[k]].context, opts->mods[i].context) == 0) c = (int)k;
+            if (c < 0) { c = (int)first_mod.size(); first_mod.push_back(i); }
+            h->cls_of_mod[i] = c;
+        }
+        h->n_classes = (int)first_mod.size();
+        h->classes.assign(h->n_classes, DevClass{});
+        // code planes -> (class, slot): plane i belongs to mod i, or, with -c '*', every plane to the one `*` mod
+        h->plane_cls.assign(h->n_code_planes, 0); h->plane_slot.assign(h->n_code_planes, 0);
+        std::vector<int> np(h->n_classes, 0);
+        for (int pl = 0; pl < h->n_code_planes; pl++) {
+            const int mod = h->wildcard >= 0 ? h->wildcard : pl;
+            const int c = h->cls_of_mod[mod];
+            h->plane_cls[pl] = c; h->plane_slot[pl] = np[c]++;
+        }
+        for (auto& dc : h->codes) if (dc.plane >= 0) dc.slot = (int16_t)h->plane_slot[(size_t)dc.plane];
+        const int64_t n_blocks = (ref_total + 31) / 32;
+        h->adj.assign((size_t)std::max(n_contigs, 1) * h->n_classes * 2, 0);
+        int64_t words = 0;
+        for (int c = 0; c < h->n_classes; c++) {
+            DevClass& k = h->classes[c];
+            k.np = std::max(np[c], 1);
+            k.dense = (opts->insertions || std::strcmp(opts->mods[first_mod[c]].context, "*") == 0) ? 1 : 0;
+            k.site[0] = k.site[1] = nullptr;
+            k.base = words;
+            if (k.dense) {
+                k.nsites = plane_len;
+                for (int t = 0; t < n_contigs; t++) for (int sd = 0; sd < 2; sd++)
+                    h->adj[((size_t)t * h->n_classes + c) * 2 + sd] = h->ref_base[t] >= 0 ? h->cnt_base[t] - h->ref_base[t] - h->seg_begin[t] : 0;
+            } else {
+                // the class's site index over the whole reference-word space: bits, then ranks (an exclusive scan in tiles)
+                uint2* site[2] = {nullptr, nullptr};
+                uint32_t* cnt[2] = {nullptr, nullptr};
+                uint32_t* tsum = nullptr;
+                const int64_t n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
+                for (int sd = 0; sd < 2; sd++) {
+                    if (dev_alloc(h, (void**)&site[sd], sizeof(uint2) * (size_t)std::max<int64_t>(n_blocks, 1))) return fail(h, "site index alloc failed");
+                    h->d_site_arrays.push_back(site[sd]);
+                    if (hipMalloc((void**)&cnt[sd], 4 * (size_t)std::max<int64_t>(n_blocks, 1)) != hipSuccess) return fail(h, "site index alloc failed");
+                }
+                if (hipMalloc((void**)&tsum, 4 * (size_t)(n_tiles + 1)) != hipSuccess) return fail(h, "site index alloc failed");
+                uint32_t total[2] = {0, 0};
+                bool ok = true;
+                if (n_blocks > 0) {
+                    const int blocks = (int)std::min<int64_t>((n_blocks + 255) / 256, (int64_t)h->n_cu * 16);
+                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, first_mod[c], site[0], site[1], cnt[0], cnt[1]));
+                    for (int sd = 0; sd < 2 && ok; sd++) {
+                        (void)hipMemsetAsync(tsum + n_tiles, 0, 4, h->stream);
+                        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum);
+                        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, tsum, (unsigned long long)n_tiles + 1ull);
+                        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum, site[sd]);
+                        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total[sd], tsum + n_tiles, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                             hipStreamSynchronize(h->stream) == hipSuccess;
+                    }
+                }
+                // the contigs' segments in the class's site numbering: ranks at every segment's two ends
+                std::vector<int64_t> gq;
+                std::vector<int> gt;
+                for (int t = 0; t < n_contigs; t++) if (h->ref_base[t] >= 0 && h->seg_len[t] > 0) { gt.push_back(t); gq.push_back(h->ref_base[t] + h->seg_begin[t]); gq.push_back(h->ref_base[t] + h->seg_begin[t] + h->seg_len[t]); }
+                std::vector<uint32_t> rk[2];
+                if (ok && !gq.empty()) {
+                    int64_t* d_g = nullptr; uint32_t* d_o = nullptr;
+                    ok = hipMalloc((void**)&d_g, 8 * gq.size()) == hipSuccess && hipMalloc((void**)&d_o, 4 * gq.size()) == hipSuccess &&
+                         hipMemcpy(d_g, gq.data(), 8 * gq.size(), hipMemcpyHostToDevice) == hipSuccess;
+                    for (int sd = 0; sd < 2 && ok; sd++) {
+                        rk[sd].resize(gq.size());
+                        hipLaunchKernelGGL(k_rank_at, dim3((unsigned)((gq.size() + 255) / 256)), dim3(256), 0, h->stream, site[sd], d_g, (int)gq.size(), n_blocks, total[sd], d_o);
+                        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(rk[sd].data(), d_o, 4 * gq.size(), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                             hipStreamSynchronize(h->stream) == hipSuccess;
+                    }
+                    if (d_g) (void)hipFree(d_g);
+                    if (d_o) (void)hipFree(d_o);
+                }
+                for (int sd = 0; sd < 2; sd++) if (cnt[sd]) (void)hipFree(cnt[sd]);
+                if (tsum) (void)hipFree(tsum);
+                if (!ok) return fail(h, "site index kernels failed");
+                int64_t ns[2] = {0, 0};
+                for (size_t i = 0; i < gt.size(); i++)
+                    for (int sd = 0; sd < 2; sd++) {
+                        h->adj[((size_t)gt[i] * h->n_classes + c) * 2 + sd] = ns[sd] - (int64_t)rk[sd][2 * i];
+                        ns[sd] += (int64_t)rk[sd][2 * i + 1] - (int64_t)rk[sd][2 * i];
+                    }
+                k.nsites = std::max<int64_t>(std::max(ns[0], ns[1]), 1);
+                k.site[0] = site[0]; k.site[1] = site[1];
+            }
+            words += (int64_t)h->n_hp * 2 * k.nsites * k.np;
+        }
+        h->n_counter_words = opts->view ? 0 : words;   // view keeps no counters
+        const size_t nadj = h->adj.size();
+        if (dev_alloc(h, (void**)&h->d_classes, sizeof(DevClass) * (size_t)h->n_classes) || dev_alloc(h, (void**)&h->d_cls_of_mod, 4 * (size_t)opts->n_mods) ||
+            dev_alloc(h, (void**)&h->d_adj, 8 * nadj) || dev_alloc(h, (void**)&h->d_slab_flag, 4)) return fail(h, "alloc failed");
+        (void)hipMemcpy(h->d_classes, h->classes.data(), sizeof(DevClass) * (size_t)h->n_classes, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_cls_of_mod, h->cls_of_mod.data(), 4 * (size_t)opts->n_mods, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_adj, h->adj.data(), 8 * nadj, hipMemcpyHostToDevice);
+        (void)hipMemset(h->d_slab_flag, 0, 4);
+        h->codes_dirty = !h->codes.empty();
+    }
     if (dev_alloc(h, (void**)&h->d_counters, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)))
         return fail(h, "counter plane alloc failed");
     if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)) != hipSuccess)
@@ -892,6 +1027,7 @@ int32_t mm_freq_intern_code(mm_freq_t* h, const char* code) {
     std::snprintf(c.str, MM_CODE_LEN, "%s", code);
     c.len = (int16_t)L; c.req = (int16_t)h->wildcard;
     c.plane = (int16_t)((int)h->codes.size() < h->n_code_planes ? (int)h->codes.size() : -1);
+    c.slot = (int16_t)(c.plane >= 0 ? h->plane_slot[(size_t)c.plane] : 0);
     h->codes.push_back(c);
     h->codes_dirty = true;
     return (int32_t)h->codes.size() - 1;
@@ -905,6 +1041,7 @@ const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) {
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_stream) {
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (h->opts.view == 2 && b->n_reads >= (1 << 21)) return -MM_E_ARG;
     h->n_submits++; h->n_reads_submitted += (uint64_t)b->n_reads;
     const bool gather = h->opts.coalesce > 1 && h->use_tiles && !b->order && b->n_reads > 0;   // (view too: a ticket's rows are then those of the group, `read` counted from its first read)
     if (gather && h->pending_slot >= 0 && !h->pending_host && !h->codes_dirty) {   // (a code interned since the group began: the table is uploaded before a launch's FIRST window, so the group ends here)
@@ -1025,6 +1162,7 @@ static int32_t submit_host_gathered(mm_freq* h, const mm_batch_t* hb) {
 int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (h->opts.view == 2 && hb->n_reads >= (1 << 21)) return -MM_E_ARG;   // (the group ordinal shares mm_view_row_t.read with the read's index)
     h->n_submits++; h->n_reads_submitted += (uint64_t)hb->n_reads;
     if (h->opts.coalesce > 1 && h->use_tiles && !hb->order && hb->n_reads > 0) return submit_host_gathered(h, hb);
     { int rf = flush_pending(h); if (rf) return rf; }
@@ -1136,143 +1274,87 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     HIPCHK(hipSetDevice(h->device));
     { int r = drain(h); if (r) return r; }
     if (h->sticky_err) return -h->sticky_err;
+    {   // a slab that carried counts for positions that are no sites here: the two handles were not built from one reference
+        unsigned int sf = 0;
+        HIPCHK(hipMemcpy(&sf, h->d_slab_flag, 4, hipMemcpyDeviceToHost));
+        if (sf) return -MM_E_ARG;
+    }
     std::vector<mm_row_t>& rows = h->rows;
     rows.clear();
     // n_called is the low half of a packed 64-bit counter: a carry out of it lands in n_mod, which can then exceed it
     // (never otherwise: every modified call is a call).  The reference exits on such an overflow (src/mod.c:900-904).
     auto overflowed = [&]() { for (const mm_row_t& r : rows) if (r.n_mod > r.n_called) return true; return false; };
-    // ---- every row a dense one (no haplotype planes, nothing on the side list): the device walks the positions and
-    // writes finished rows in output order (k_site_count / k_site_emit); the host only copies them
-    if (!h->opts.haplotypes && h->n_counter_words > 0 && !h->opts.finalize_by_runs) {
+    // ---- the dense counters: the device walks the positions and writes finished rows in output order (k_site_count /
+    // k_site_emit: contig by name, position, strand, code plane, haplotype plane); the host copies them
+    size_t n_dense = 0;
+    if (h->n_counter_words > 0) {
+        std::vector<int> order;
+        for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return h->ctg_rank[a] < h->ctg_rank[b]; });
+        std::vector<SiteSeg> segs(order.size());
+        int64_t tiles = 0;
+        for (size_t k = 0; k < order.size(); k++) {
+            int t = order[k];
+            segs[k].seg_begin = h->seg_begin[t]; segs[k].seg_len = h->seg_len[t];
+            segs[k].tile_start = tiles; segs[k].tid = t; segs[k].pad = 0;
+            tiles += (h->seg_len[t] + kTile - 1) / kTile;
+        }
+        if (tiles >= (int64_t)0x7FFFFFFF) return -MM_E_ARG;
+        if (tiles > 0) {
+            if ((size_t)tiles > h->cap_tiles) {
+                if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
+                if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
+                h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
+                if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles) ||
+                    dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * (size_t)tiles)) return -MM_E_NOMEM;
+                h->cap_tiles = (size_t)tiles;
+            }
+            const K2Params kp = k2_params(h);
+            SiteSeg* d_segs = nullptr;
+            if (dev_alloc(h, (void**)&d_segs, sizeof(SiteSeg) * segs.size())) return -MM_E_NOMEM;
+            int64_t result = 0;
+            do {
+                if (hipMemcpyAsync(d_segs, segs.data(), sizeof(SiteSeg) * segs.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                hipLaunchKernelGGL(k_site_count, dim3((unsigned)tiles), dim3(256), 0, h->stream, kp, d_segs, (int)segs.size(), h->d_tile_counts);
+                if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
+                std::vector<uint32_t> tc((size_t)tiles);
+                if (hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                    hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                std::vector<unsigned long long> to((size_t)tiles);
+                unsigned long long total = 0;
+                for (size_t i = 0; i < (size_t)tiles; i++) { to[i] = total; total += tc[i]; }
+                if (total > 0) {
+                    if ((size_t)total > h->cap_rows) {
+                        if (h->d_rows) (void)hipFree(h->d_rows);
+                        h->d_rows = nullptr; h->cap_rows = 0;
+                        size_t cap = (size_t)total + (size_t)total / 8 + 1024;
+                        if (dev_alloc(h, (void**)&h->d_rows, sizeof(mm_row_t) * cap)) { result = -MM_E_NOMEM; break; }
+                        h->cap_rows = cap;
+                    }
+                    rows.resize((size_t)total);
+                    if (hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * (size_t)tiles, hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    hipLaunchKernelGGL(k_site_emit, dim3((unsigned)tiles), dim3(256), 0, h->stream, kp, d_segs, (int)segs.size(), h->d_tile_offsets, h->d_rows);
+                    if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
+                    if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                        hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                }
+            } while (0);
+            (void)hipFree(d_segs); h->device_bytes -= (int64_t)std::max<size_t>(sizeof(SiteSeg) * segs.size(), 16);
+            if (result < 0) return result;
+        }
+    }
+    n_dense = rows.size();
+    // every row a dense one (no haplotype planes, nothing on the side table or list): done
+    if (!h->opts.haplotypes && !h->opts.finalize_by_runs) {
         unsigned long long ns0 = 0, nt0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
         { int rc = side_table_count(h, &nt0); if (rc) return rc; }
         if (ns0 == 0 && nt0 == 0) {
-            std::vector<int> order;
-            for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return h->ctg_rank[a] < h->ctg_rank[b]; });
-            std::vector<SiteSeg> segs(order.size());
-            int64_t tiles = 0;
-            for (size_t k = 0; k < order.size(); k++) {
-                int t = order[k];
-                segs[k].cnt_base = h->cnt_base[t]; segs[k].seg_begin = h->seg_begin[t]; segs[k].seg_len = h->seg_len[t];
-                segs[k].tile_start = tiles; segs[k].tid = t; segs[k].pad = 0;
-                tiles += (h->seg_len[t] + kTile - 1) / kTile;
-            }
-            if (tiles > 0 && tiles < (int64_t)0x7FFFFFFF) {
-                if ((size_t)tiles > h->cap_tiles) {
-                    if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
-                    if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
-                    h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
-                    if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles) ||
-                        dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * (size_t)tiles)) return -MM_E_NOMEM;
-                    h->cap_tiles = (size_t)tiles;
-                }
-                SiteSeg* d_segs = nullptr;
-                if (dev_alloc(h, (void**)&d_segs, sizeof(SiteSeg) * segs.size())) return -MM_E_NOMEM;
-                int64_t result = 0;
-                do {
-                    if (hipMemcpyAsync(d_segs, segs.data(), sizeof(SiteSeg) * segs.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
-                    hipLaunchKernelGGL(k_site_count, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
-                                       d_segs, (int)segs.size(), h->d_tile_counts);
-                    if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
-                    std::vector<uint32_t> tc((size_t)tiles);
-                    if (hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                        hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
-                    std::vector<unsigned long long> to((size_t)tiles);
-                    unsigned long long total = 0;
-                    for (size_t i = 0; i < (size_t)tiles; i++) { to[i] = total; total += tc[i]; }
-                    if (total > 0) {
-                        size_t units = (size_t)((total * sizeof(mm_row_t) + sizeof(DenseRow) - 1) / sizeof(DenseRow));   // d_rows is sized in DenseRow units
-                        if (units > h->cap_rows) {
-                            if (h->d_rows) (void)hipFree(h->d_rows);
-                            h->d_rows = nullptr; h->cap_rows = 0;
-                            size_t cap = units + units / 8 + 1024;
-                            if (dev_alloc(h, (void**)&h->d_rows, sizeof(DenseRow) * cap)) { result = -MM_E_NOMEM; break; }
-                            h->cap_rows = cap;
-                        }
-                        rows.resize((size_t)total);
-                        if (hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * (size_t)tiles, hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
-                        hipLaunchKernelGGL(k_site_emit, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, h->plane_len, h->n_code_planes,
-                                           d_segs, (int)segs.size(), h->d_tile_offsets, reinterpret_cast<mm_row_t*>(h->d_rows));
-                        if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
-                        if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                            hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
-                    }
-                    result = (int64_t)rows.size();
-                } while (0);
-                (void)hipFree(d_segs);
-                if (result < 0) return result;
-                if (overflowed()) return -MM_E_OVERFLOW;
-                if (out_rows) *out_rows = rows.data();
-                return result;
-            }
+            if (overflowed()) return -MM_E_OVERFLOW;
+            if (out_rows) *out_rows = rows.data();
+            return (int64_t)rows.size();
         }
     }
-    std::vector<size_t> run_starts;   // first row of every (plane, haplotype, strand) run of dense rows
-    size_t n_dense = 0;
-    // ---- K2 over all planes at once: the flat counter array is [run][plane_len] with run = (plane*n_hp+hp)*2+strand
-    int64_t n = h->n_counter_words;
-    if (n > 0) {
-        size_t tiles = (size_t)((n + kTile - 1) / kTile);
-        if (tiles > h->cap_tiles) {
-            if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
-            if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
-            h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
-            if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * tiles) ||
-                dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * tiles)) return -MM_E_NOMEM;
-            h->cap_tiles = tiles;
-        }
-        hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, n, h->d_tile_counts);
-        HIPCHK(hipGetLastError());
-        std::vector<uint32_t> tc(tiles);
-        HIPCHK(hipMemcpyAsync(tc.data(), h->d_tile_counts, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        std::vector<unsigned long long> to(tiles);
-        unsigned long long total = 0;
-        for (size_t i = 0; i < tiles; i++) { to[i] = total; total += tc[i]; }
-        if (total > 0) {
-            if (total > h->cap_rows) {
-                if (h->d_rows) (void)hipFree(h->d_rows);
-                h->d_rows = nullptr; h->cap_rows = 0;
-                size_t cap = (size_t)(total + total / 8 + 1024);
-                if (dev_alloc(h, (void**)&h->d_rows, sizeof(DenseRow) * cap)) return -MM_E_NOMEM;
-                h->cap_rows = cap;
-            }
-            HIPCHK(hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * tiles, hipMemcpyHostToDevice, h->stream));
-            hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_counters, n, h->d_tile_offsets, h->d_rows);
-            HIPCHK(hipGetLastError());
-            std::vector<DenseRow> dr((size_t)total);
-            HIPCHK(hipMemcpyAsync(dr.data(), h->d_rows, sizeof(DenseRow) * (size_t)total, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            // decode flat index -> (plane, hp, strand, tid, pos)
-            std::vector<int> seg_tids;
-            for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) seg_tids.push_back(t);
-            std::sort(seg_tids.begin(), seg_tids.end(), [&](int a, int b) { return h->cnt_base[a] < h->cnt_base[b]; });
-            rows.reserve((size_t)total);
-            size_t cursor = 0;
-            int64_t last_run = -1;
-            for (const DenseRow& d : dr) {
-                int64_t run = d.index / h->plane_len, off = d.index - run * h->plane_len;
-                if (run != last_run) { cursor = 0; last_run = run; run_starts.push_back(rows.size()); }
-                while (cursor + 1 < seg_tids.size() && h->cnt_base[seg_tids[cursor + 1]] <= off) cursor++;
-                int t = seg_tids[cursor];
-                int64_t rel = off - h->cnt_base[t];
-                if (rel >= h->seg_len[t]) continue;  // padding, never written
-                int strand = (int)(run & 1);
-                int64_t ph = run >> 1;
-                int plane = (int)(ph / h->n_hp), hp = (int)(ph % h->n_hp);
-                mm_row_t r;
-                std::memset(&r, 0, sizeof(r));
-                r.tid = t; r.pos = (int32_t)(h->seg_begin[t] + rel); r.strand = (uint8_t)strand; r.ins_offset = 0;
-                r.code = (int16_t)plane;   // dense plane i belongs to code i (both orders are interning order)
-                r.hp = (int16_t)(h->opts.haplotypes ? hp : -1);
-                r.n_called = d.n_called; r.n_mod = d.n_mod;
-                rows.push_back(r);
-            }
-        }
-    }
-    n_dense = rows.size();
     // ---- side table (K3): unique keys with their counts, compacted and ordered on the device
     size_t n_side_sorted = 0;   // rows.size() up to which the side rows are known to be in output order
     {
@@ -1375,36 +1457,14 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
         if (a.ins_offset != b.ins_offset) return a.ins_offset < b.ins_offset;
         return hpkey(a.hp) < hpkey(b.hp);
     };
-    // The dense rows arrive as one run per (plane, haplotype, strand), each already in (contig segment, position) order:
-    // when every run is in output order (contig ranks follow the segment order, the usual case) the runs are merged
-    // pairwise -- O(n log runs) -- instead of sorting a million rows from scratch; the side rows are sorted on their own.
+    // the dense rows arrive in output order, the table's rows likewise; only the list's (rare) need sorting: three ordered runs merged
     {
-        run_starts.push_back(n_dense);
-        bool runs_sorted = true;
-        for (size_t k = 0; k + 1 < run_starts.size() && runs_sorted; k++)
-            runs_sorted = std::is_sorted(rows.begin() + (ptrdiff_t)run_starts[k], rows.begin() + (ptrdiff_t)run_starts[k + 1], less);
-        if (!runs_sorted) {
-            std::sort(rows.begin(), rows.end(), less);
-        } else {
-            // the table's rows arrive ordered; only the list's (rare) need sorting, and merging in when there are any
-            if (n_side_sorted < rows.size()) {
-                std::sort(rows.begin() + (ptrdiff_t)std::max(n_side_sorted, n_dense), rows.end(), less);
-                if (n_side_sorted > n_dense)
-                    std::inplace_merge(rows.begin() + (ptrdiff_t)n_dense, rows.begin() + (ptrdiff_t)n_side_sorted, rows.end(), less);
-            }
-            run_starts.push_back(rows.size());
-            while (run_starts.size() > 2) {
-                std::vector<size_t> next;
-                for (size_t k = 0; k + 2 < run_starts.size(); k += 2) {
-                    std::inplace_merge(rows.begin() + (ptrdiff_t)run_starts[k], rows.begin() + (ptrdiff_t)run_starts[k + 1],
-                                       rows.begin() + (ptrdiff_t)run_starts[k + 2], less);
-                    next.push_back(run_starts[k]);
-                }
-                if (run_starts.size() % 2 == 0) next.push_back(run_starts[run_starts.size() - 2]);
-                next.push_back(run_starts.back());
-                run_starts.swap(next);
-            }
+        if (n_side_sorted < rows.size()) {
+            std::sort(rows.begin() + (ptrdiff_t)std::max(n_side_sorted, n_dense), rows.end(), less);
+            if (n_side_sorted > n_dense)
+                std::inplace_merge(rows.begin() + (ptrdiff_t)n_dense, rows.begin() + (ptrdiff_t)n_side_sorted, rows.end(), less);
         }
+        if (n_dense > 0 && n_dense < rows.size()) std::inplace_merge(rows.begin(), rows.begin() + (ptrdiff_t)n_dense, rows.end(), less);
     }
     auto same_site = [](const mm_row_t& a, const mm_row_t& b) {
         return a.tid == b.tid && a.pos == b.pos && a.strand == b.strand && a.code == b.code && a.ins_offset == b.ins_offset;
@@ -1529,53 +1589,23 @@ int64_t mm_view_fetch_device(mm_freq_t* h, int32_t ticket, const void** dev_rows
 int64_t mm_freq_slab_words(const mm_freq_t* h, int64_t len) {
     return h ? (int64_t)h->n_code_planes * h->n_hp * 2 * len : 0;
 }
-static int slab_range(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, int64_t* off) {
-    if (!h || tid < 0 || tid >= h->n_contigs || len < 0) return -MM_E_ARG;
-    int64_t rel = begin - h->seg_begin[tid];
+static int slab_op(mm_freq_t* h, int op, int32_t tid, int64_t begin, int64_t len, void* buf, void* st) {
+    if (!h || tid < 0 || tid >= h->n_contigs || len < 0 || h->opts.view) return -MM_E_ARG;
+    const int64_t rel = begin - h->seg_begin[tid];
     if (rel < 0 || rel + len > h->seg_len[tid]) return -MM_E_ARG;
-    *off = h->cnt_base[tid] + rel;
-    return 0;
-}
-int32_t mm_freq_slab_export(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* dst, void* st) {
-    int64_t off;
-    int r = slab_range(h, tid, begin, len, &off);
-    if (r || len == 0) return r;
+    if (len == 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     { int rs = settle(h); if (rs) return rs; }
-    int runs = h->n_code_planes * h->n_hp * 2;
-    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_slab_export, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off,
-                       len, runs, (unsigned long long*)dst);
+    hipStream_t s = st ? (hipStream_t)st : h->stream;
+    const int64_t total = (int64_t)h->n_code_planes * h->n_hp * 2 * len;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_slab_op, dim3(blocks), dim3(256), 0, s, k2_params(h), op, (int)tid, begin, len, h->d_counters, (unsigned long long*)buf, h->d_slab_flag);
     HIPCHK(hipGetLastError());
     if (!st) HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
-int32_t mm_freq_slab_add(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src, void* st) {
-    int64_t off;
-    int r = slab_range(h, tid, begin, len, &off);
-    if (r || len == 0) return r;
-    HIPCHK(hipSetDevice(h->device));
-    { int rs = settle(h); if (rs) return rs; }
-    int runs = h->n_code_planes * h->n_hp * 2;
-    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_slab_add, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len,
-                       runs, (const unsigned long long*)src);
-    HIPCHK(hipGetLastError());
-    if (!st) HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
-int32_t mm_freq_slab_clear(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* st) {
-    int64_t off;
-    int r = slab_range(h, tid, begin, len, &off);
-    if (r || len == 0) return r;
-    HIPCHK(hipSetDevice(h->device));
-    { int rs = settle(h); if (rs) return rs; }
-    int runs = h->n_code_planes * h->n_hp * 2;
-    int blocks = (int)std::min<int64_t>(((int64_t)runs * len + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_slab_clear, dim3(blocks), dim3(256), 0, st ? (hipStream_t)st : h->stream, h->d_counters, h->plane_len, off, len, runs);
-    HIPCHK(hipGetLastError());
-    if (!st) HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
-}
+int32_t mm_freq_slab_export(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* dst, void* st) { return slab_op(h, 0, tid, begin, len, dst, st); }
+int32_t mm_freq_slab_add(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src, void* st) { return slab_op(h, 1, tid, begin, len, const_cast<void*>(src), st); }
+int32_t mm_freq_slab_clear(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* st) { return slab_op(h, 2, tid, begin, len, nullptr, st); }
 
 }  // extern "C"

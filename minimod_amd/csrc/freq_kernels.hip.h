@@ -45,8 +45,26 @@ struct DevCode {
     int16_t len;
     int16_t req;    // index of the requested mod whose context/threshold applies
     int16_t plane;  // dense counter plane, or -1 (side list only)
-    int16_t rsvd;
+    int16_t slot;   // the plane's place among the planes of its context class (DevClass::np of them lie side by side per site)
 };
+
+// Counters are kept per SITE, not per position.  The requested mods are grouped into context classes (mods with the same
+// context string; with --insertions, where no context is looked at, and for the context `*` every position is a site: a
+// `dense` class).  For a class and a strand the positions inside a context match are numbered through the whole reference-word
+// space: site[strand][g >> 5] = {bits: which of the 32 positions are sites, rank: sites in front of the block}.  A read's
+// consecutive calls then update consecutive counters -- 64-byte lines shared by up to eight calls of one wave instruction,
+// which the memory side takes as ONE atomic request each (scattered, it takes 20 G requests a second: tools/atomic_calib.hip) --
+// and the planes shrink from 8 bytes a position to 8 bytes a site (CpG: 1 % of the positions).
+//   counter of (code plane, haplotype plane hp, strand s, contig t, position pos), g = ref_base[t] + pos:
+//       base + (((hp * 2 + s) * nsites) + adj[(t * n_classes + class) * 2 + s] + rank_s(g)) * np + slot
+struct DevClass {
+    const uint2* site[2];   // null for a dense class (rank(g) = g)
+    int64_t base;           // first counter word of the class
+    int64_t nsites;         // sites per (haplotype plane, strand) block: the larger of the two strands' counts
+    int32_t np;             // code planes of the class, side by side per site
+    int32_t dense;
+};
+__device__ __forceinline__ uint32_t site_rank(uint2 w, uint32_t bit) { return w.y + (uint32_t)__popc(w.x & ((1u << bit) - 1u)); }
 
 struct DevMod {
     uint8_t klass[256];
@@ -87,9 +105,14 @@ struct DevParams {
     const int64_t* cnt_base;     // per tid: offset of the segment inside a plane
     int32_t n_contigs;
     // counters
-    unsigned long long* counters;  // [(plane * n_hp + hp) * 2 + strand][plane_len]
-    int64_t plane_len;
+    unsigned long long* counters;  // per context class: [hp][strand][site][code plane of the class] (DevClass above)
+    int64_t plane_len;             // positions with dense counters (all segments, each padded to 64)
     int32_t n_hp;                  // dense haplotype planes (1 when haplotypes are off)
+    int32_t n_classes;
+    const DevClass* classes;       // [n_classes]
+    const int32_t* cls_of_mod;     // [n_mods]
+    const int64_t* adj;            // [(tid * n_classes + class) * 2 + strand]: what added to rank_strand(ref_base + pos) numbers the contig's
+                                   // sites inside the class's (haplotype, strand) blocks
     // options
     int32_t n_mods, n_codes, insertions, haplotypes, wildcard;
     const DevMod* mods;
@@ -229,6 +252,15 @@ template <typename T> __device__ __forceinline__ T scalar_load(const T* p) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the counter word of (code, haplotype plane, strand) at position g of the reference-word space of contig tid (the general
+// form: one lookup of the class's site word; k_stream_reads keeps the per-read parts in scalar registers instead)
+__device__ __forceinline__ unsigned long long* counter_word(const DevParams& p, const DevCode& dc, int hpi, int rev, int tid, int64_t g) {
+    const int c = p.cls_of_mod[dc.req];
+    const DevClass k = p.classes[c];
+    int64_t r = g;
+    if (!k.dense) { const uint2 w = k.site[rev][g >> 5]; r = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+    return p.counters + k.base + (((int64_t)(hpi * 2 + rev) * k.nsites) + p.adj[((int64_t)tid * p.n_classes + c) * 2 + rev] + r) * k.np + dc.slot;
+}
 // value of lane `l` (wave-uniform l) as a wave-uniform scalar
 __device__ __forceinline__ int lane_val(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 __device__ __forceinline__ uint32_t lane_valu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l)); }
@@ -388,6 +420,7 @@ struct ReadCtx {
     int32_t tid, pos, rev, hp, hpi;
     // current MM group
     int32_t cls, direct, mb_is_N, n_codes_grp;
+    int32_t code_off;   // letters of the group in front of the 16 whose codes S.g_code holds (0 unless the group has more than 16)
     uint32_t nb, ml_start;
     uint32_t ridx, gord, vregion;   // view mode: read index, ordinal of the current MM group, append region
 };
@@ -435,12 +468,14 @@ struct K1 {
                 qs = carry_q + qs - qinc;
                 rs = carry_r + rs - rinc;
                 bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
+                // (read_pos < seq_len is asserted for aligned bases -- and inserted ones with --insertions -- as get_aln MEETS them: a
+                // forward read's ops front to back, so the op's end in stored order decides; a reverse read's back to front: below)
                 if (aligned) {
-                    if ((uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;                        // mod.c:853
+                    if (!c.rev && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;              // mod.c:853
                     int64_t r0 = (int64_t)c.pos + rs;
                     if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;          // mod.c:860
                 }
-                if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;  // mod.c:865
+                if (!c.rev && p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > c.L) err = err ? err : MM_E_QOVER;  // mod.c:865
                 if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
                 if (act) {
                     uint32_t rv = (rs & 0x0FFFFFFFu) | (op << 28);
@@ -451,8 +486,25 @@ struct K1 {
             }
         }
         c.q_total = carry_q;
-        c.q_shift = (c.rev && carry_q < c.L) ? c.L - carry_q : 0u;
+        // a reverse read's BAM position q is query position q - (L - q_total) of the CIGAR (get_aln walks its ops back to front from
+        // read position 0 of the original orientation, mod.c:813-860); the difference wraps when the CIGAR is the longer one
+        c.q_shift = c.rev ? c.L - carry_q : 0u;
         wave_sync();
+        if (c.rev && carry_q > c.L) {
+            // A reverse read whose CIGAR consumes more than the sequence has: walked back to front, an aligned (or, with
+            // --insertions, inserted) base is out of range when its position counted from the CIGAR's END reaches seq_len -- the op
+            // that starts at stored query position qs ends at q_total - qs in that walk.  Excess in the ops the walk meets last
+            // (the stored CIGAR's first: a leading soft clip) is never looked at (mod.c:813-860).
+            for (uint32_t i0 = 0; i0 < c.ncig; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                if (i < c.ncig) {
+                    const uint32_t op = cr(i) >> 28, qs = cq(i);
+                    const uint32_t len = cg[i] >> 4;
+                    const bool counts = (((0x181u >> op) & 1u) || (p.insertions && op == 1u)) && len > 0;
+                    if (counts && carry_q - qs > c.L) err = err ? err : MM_E_QOVER;
+                }
+            }
+        }
     }
 
     // ---- a5 base directory (mod.c:972-981) as a rank directory over 32-base blocks
@@ -653,7 +705,7 @@ struct K1 {
             if (!live[u]) continue;
             uint32_t refcode = w[u] & 31u;
             for (int m = 0; m < ncg; m++) {
-                int ci = S.g_code[m];
+                int ci = m >= c.code_off ? S.g_code[m - c.code_off] : -1;
                 if (ci < 0) continue;
                 const DevCode& dc = p.codes[ci];
                 int req = dc.req;
@@ -684,9 +736,7 @@ struct K1 {
                 }
                 int64_t off = ref_pos[u] - c.seg_begin;
                 if (ins_off[u] == 0 && dc.plane >= 0 && c.hpi >= 0 && off >= 0 && off < c.seg_len) {
-                    unsigned long long* dst = p.counters +
-                        ((int64_t)(dc.plane * p.n_hp + c.hpi) * 2 + c.rev) * p.plane_len + c.cnt_base + off;
-                    atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+                    atomicAdd(counter_word(p, dc, c.hpi, c.rev, c.tid, c.ref_base + ref_pos[u]), is_mod ? 0x100000001ull : 1ull);
                     st_dense++;
                 } else {
                     side_append((int32_t)ref_pos[u], ins_off[u], is_mod, ci);
@@ -874,7 +924,14 @@ struct K1 {
             bool has_nums = __ballot(iscode && dig) != 0, has_alpha = __ballot(iscode && alp) != 0;
             int n = has_nums ? 1 : ncode;
             if (!herr && __ballot(iscode && !dig && !alp)) herr = MM_E_MMCODE;      // mod.c:1029-1032
-            if (!herr && (e == 64 || ncode >= MM_CODE_LEN)) herr = MM_E_MMCODE;
+            // More code letters than a code string of the table holds (15): the reference grows its buffer and goes on
+            // (mod.c:1034-1038) -- n letters, n ML bytes a token; only the suffixes of at most 15 letters can be a requested code
+            // (mod.c:1151 looks up the C string from letter m on), so the last 16 letters are all the lookup needs.  Limits kept:
+            // a header must end within the 64 characters a wavefront looks at, and with -c '*' every suffix would have to be a
+            // code of the table.
+            const bool longcode = ncode >= MM_CODE_LEN;
+            const int coff = ncode > 16 ? ncode - 16 : 0;
+            if (!herr && (e == 64 || (longcode && p.wildcard))) herr = MM_E_MMCODE;
             if (!herr && n <= 0) herr = MM_E_MMEMPTY;                                // mod.c:1053
             if (!herr && has_nums && has_alpha) herr = MM_E_MMMIXED;                 // mod.c:1054
             if (!herr && kView && c.gord > kViewMaxGroup) herr = MM_E_TOOMANY;
@@ -890,7 +947,7 @@ struct K1 {
                     if (ce == '?' || ce == '.') { flag = ce; cpos++; }
                 }
                 // required-code lookup per code letter (mod.c:1146-1160): the C string starting at letter m
-                if (iscode) S.hdr[lane - hl] = (char)ch;
+                if (iscode && lane - hl >= coff) S.hdr[lane - hl - coff] = (char)ch;   // (the last 16 code characters)
                 if (lane < 16) S.g_code[lane] = -1;
                 wave_sync();
                 {
@@ -901,16 +958,16 @@ struct K1 {
                             int m = pi / p.n_codes, t = pi - m * p.n_codes;
                             int slen = has_nums ? ncode : ncode - m;
                             const DevCode& dc = p.codes[t];
-                            bool eq = dc.len == slen;
-                            for (int j = 0; j < slen; j++) eq = eq && (dc.str[j & (MM_CODE_LEN - 1)] == S.hdr[(m + j) & 15]);
-                            if (eq) S.g_code[m] = (int16_t)t;
+                            bool eq = dc.len == slen && slen < MM_CODE_LEN && m >= coff;
+                            if (eq) for (int j = 0; j < slen; j++) eq = eq && (dc.str[j & (MM_CODE_LEN - 1)] == S.hdr[(m + j - coff) & 15]);
+                            if (eq) S.g_code[m - coff] = (int16_t)t;
                         }
                     }
                 }
                 wave_sync();
                 if (p.wildcard && lane < n && S.g_code[lane] < 0) err = MM_E_NOCODE;  // the host interns before submit
                 bad = __ballot(err != 0) != 0;
-                c.n_codes_grp = n;
+                c.n_codes_grp = n; c.code_off = coff;
                 int mb = c.rev ? complement_char(modbase) : modbase;
                 c.mb_is_N = mb == 'N';
                 c.direct = modbase == 'N';
@@ -1059,57 +1116,79 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------- K2
-// Stream compaction of non-zero counters, in position order, per (plane, strand) run.
-constexpr int kTile = 2048;
-__global__ __launch_bounds__(256) void k_count_nonzero(const unsigned long long* __restrict__ cnt, int64_t n,
-                                                       uint32_t* __restrict__ tile_counts) {
-    __shared__ uint32_t part[4];
-    int64_t base = (int64_t)blockIdx.x * kTile;
-    uint32_t c = 0;
-    for (int j = threadIdx.x; j < kTile; j += 256) {
-        int64_t i = base + j;
-        if (i < n && cnt[i] != 0ull) c++;
+// ---------------------------------------------------------------------------------- site index (K0, second half)
+// which positions of the reference-word space are sites of a context class: bit (5 + 2 * mod) / (6 + 2 * mod) of the reference
+// words of the class's first mod (bits 2 / 3 of the four-bit words), 32 positions a word, and how many a block holds
+template <typename RefWord>
+__global__ __launch_bounds__(256) void k_site_bits(const void* __restrict__ refw, int64_t n_blocks, int mod, uint2* __restrict__ fwd,
+                                                   uint2* __restrict__ rev, uint32_t* __restrict__ cnt_fwd, uint32_t* __restrict__ cnt_rev) {
+    const typename RefLoad<RefWord>::Base rw = RefLoad<RefWord>::from(refw, 0);
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t f = 0, r = 0;
+        for (int k = 0; k < 32; k++) {
+            const uint32_t w = RefLoad<RefWord>::at(rw, b * 32 + k);
+            f |= ((w >> (5 + 2 * mod)) & 1u) << k;
+            r |= ((w >> (6 + 2 * mod)) & 1u) << k;
+        }
+        fwd[b].x = f; rev[b].x = r;
+        cnt_fwd[b] = (uint32_t)__popc(f); cnt_rev[b] = (uint32_t)__popc(r);
     }
+}
+// exclusive prefix sums of the blocks' counts into the site words: tiles of 2048 blocks -- (1) a tile's total, (2) the totals
+// scanned by one workgroup (k_radix_scan), (3) every block's rank from its tile's offset
+constexpr int kScanTile = 2048;
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restrict__ cnt, int64_t n, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t part[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    uint32_t c = 0;
+    for (int j = threadIdx.x; j < kScanTile; j += 256) { const int64_t i = base + j; if (i < n) c += cnt[i]; }
     for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-struct DenseRow { int64_t index; uint32_t n_called, n_mod; };  // index = flat index into the counter array
-__global__ __launch_bounds__(256) void k_emit_rows(const unsigned long long* __restrict__ cnt, int64_t n,
-                                                   const unsigned long long* __restrict__ tile_offsets,
-                                                   DenseRow* __restrict__ rows) {
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ cnt, int64_t n, const uint32_t* __restrict__ tile_offsets, uint2* __restrict__ site) {
     __shared__ uint32_t wsum[4];
-    int64_t base = (int64_t)blockIdx.x * kTile;
-    unsigned long long out = tile_offsets[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j0 = 0; j0 < kTile; j0 += 256) {
-        int64_t i = base + j0 + threadIdx.x;
-        unsigned long long v = i < n ? cnt[i] : 0ull;
-        bool nz = v != 0ull;
-        uint64_t b = __ballot(nz);
-        if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+    uint32_t run = tile_offsets[blockIdx.x];
+    for (int j0 = 0; j0 < kScanTile; j0 += 256) {
+        const int64_t i = base + j0 + threadIdx.x;
+        const uint32_t c = i < n ? cnt[i] : 0u;
+        const uint32_t incl = wave_incl_scan(c);
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        uint32_t before = 0;
+        uint32_t before = run + incl - c;
         for (int w = 0; w < wv; w++) before += wsum[w];
-        uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (nz) {
-            DenseRow r;
-            r.index = i; r.n_called = (uint32_t)v; r.n_mod = (uint32_t)(v >> 32);
-            rows[out + before + __popcll(b & ((1ull << lane) - 1ull))] = r;
-        }
-        out += total;
+        if (i < n) site[i].y = before;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
 }
+// rank of a few positions (segment boundaries): out[i] = sites of the strand in front of g[i]
+__global__ void k_rank_at(const uint2* __restrict__ site, const int64_t* __restrict__ g, int n, int64_t n_blocks, uint32_t total, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = g[i] >> 5;
+    out[i] = b >= n_blocks ? total : site_rank(site[b], (uint32_t)g[i] & 31u);
+}
 
-// K2, site-major: the same compaction walking POSITIONS, each position's runs in output order (strand, then code), so
-// that the rows come out in the order print_freq_output sorts them into (src/mod.c:644-664 with cmp_key_fast :59-93;
-// ties in this build's canonical order) and as finished mm_row_t records: the host copies them and is done -- no decode,
-// no merge of per-run lists.  Used when every row is a dense one (no haplotype planes, empty side list).
+// ---------------------------------------------------------------------------------- K2
+// print_freq_output's collect + sort (src/mod.c:644-664 with cmp_key_fast :59-93) as a compaction of the non-zero counters
+// that walks POSITIONS: each position's counters in output order (strand, then code plane, then haplotype plane), contigs in
+// strcmp order -- finished mm_row_t rows in the order the reference prints them (ties in this build's canonical order).
+// Without haplotype planes and side rows the host copies them and is done; otherwise it merges in the side rows and forms
+// the `*` aggregates.
+constexpr int kTile = 2048;
+struct K2Params {
+    const unsigned long long* cnt;
+    const DevClass* classes;
+    const int64_t* adj;
+    const int64_t* ref_base;
+    int32_t n_classes, n_hp, n_planes, haplotypes;
+    int8_t plane_cls[MM_MAX_CODES], plane_slot[MM_MAX_CODES];
+};
 struct SiteSeg {        // one contig segment, listed in output order
-    int64_t cnt_base;   // offset of the segment inside a run
     int64_t seg_begin, seg_len;
     int64_t tile_start; // first tile (of kTile positions) of the segment
     int32_t tid, pad;
@@ -1123,35 +1202,59 @@ __device__ __forceinline__ int site_segment(const SiteSeg* segs, int n_seg, int6
     return lo;
 }
 constexpr int kSitePerThread = kTile / 256;   // consecutive positions per thread
-__global__ __launch_bounds__(256) void k_site_count(const unsigned long long* __restrict__ cnt, int64_t plane_len, int n_planes,
-                                                    const SiteSeg* __restrict__ segs, int n_seg, uint32_t* __restrict__ tile_counts) {
+// the rows of position `pos` of contig tid: counted, and with kEmit written from rows[out] on
+template <bool kEmit>
+__device__ __forceinline__ uint32_t site_rows(const K2Params& P, int tid, int64_t pos, mm_row_t* __restrict__ rows, unsigned long long out) {
+    const int64_t g = P.ref_base[tid] + pos;
+    uint32_t n = 0;
+    for (int strand = 0; strand < 2; strand++) {
+        int last_c = -1;
+        bool is_site = false;
+        int64_t rk = 0;
+        for (int pl = 0; pl < P.n_planes; pl++) {
+            const int c = P.plane_cls[pl];
+            const DevClass& k = P.classes[c];
+            if (c != last_c) {
+                last_c = c;
+                if (k.dense) { is_site = true; rk = g; }
+                else { const uint2 w = k.site[strand][g >> 5]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+            }
+            if (!is_site) continue;
+            const int64_t a = P.adj[((int64_t)tid * P.n_classes + c) * 2 + strand] + rk;
+            for (int hp = 0; hp < P.n_hp; hp++) {
+                const unsigned long long v = P.cnt[k.base + (((int64_t)(hp * 2 + strand) * k.nsites) + a) * k.np + P.plane_slot[pl]];
+                if (v == 0ull) continue;
+                if (kEmit) {
+                    mm_row_t r;
+                    r.tid = tid; r.pos = (int32_t)pos; r.strand = (uint8_t)strand; r.rsvd = 0; r.ins_offset = 0;
+                    r.code = (int16_t)pl; r.hp = (int16_t)(P.haplotypes ? hp : -1); r.n_called = (uint32_t)v; r.n_mod = (uint32_t)(v >> 32);
+                    rows[out + n] = r;
+                }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void k_site_count(const K2Params P, const SiteSeg* __restrict__ segs, int n_seg, uint32_t* __restrict__ tile_counts) {
     __shared__ uint32_t part[4];
     const SiteSeg sg = segs[site_segment(segs, n_seg, blockIdx.x)];
     const int64_t p0 = ((int64_t)blockIdx.x - sg.tile_start) * kTile + (int64_t)threadIdx.x * kSitePerThread;
     uint32_t c = 0;
-    for (int run = 0; run < 2 * n_planes; run++) {
-        const unsigned long long* src = cnt + (int64_t)run * plane_len + sg.cnt_base;
-#pragma unroll
-        for (int k = 0; k < kSitePerThread; k++) { int64_t q = p0 + k; if (q < sg.seg_len && src[q] != 0ull) c++; }
-    }
+    for (int k = 0; k < kSitePerThread; k++) { const int64_t q = p0 + k; if (q < sg.seg_len) c += site_rows<false>(P, sg.tid, sg.seg_begin + q, nullptr, 0ull); }
     for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-__global__ __launch_bounds__(256) void k_site_emit(const unsigned long long* __restrict__ cnt, int64_t plane_len, int n_planes,
-                                                   const SiteSeg* __restrict__ segs, int n_seg,
+__global__ __launch_bounds__(256) void k_site_emit(const K2Params P, const SiteSeg* __restrict__ segs, int n_seg,
                                                    const unsigned long long* __restrict__ tile_offsets, mm_row_t* __restrict__ rows) {
     __shared__ uint32_t wsum[4];
     const SiteSeg sg = segs[site_segment(segs, n_seg, blockIdx.x)];
     const int64_t p0 = ((int64_t)blockIdx.x - sg.tile_start) * kTile + (int64_t)threadIdx.x * kSitePerThread;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t c = 0;
-    for (int run = 0; run < 2 * n_planes; run++) {
-        const unsigned long long* src = cnt + (int64_t)run * plane_len + sg.cnt_base;
-#pragma unroll
-        for (int k = 0; k < kSitePerThread; k++) { int64_t q = p0 + k; if (q < sg.seg_len && src[q] != 0ull) c++; }
-    }
+    for (int k = 0; k < kSitePerThread; k++) { const int64_t q = p0 + k; if (q < sg.seg_len) c += site_rows<false>(P, sg.tid, sg.seg_begin + q, nullptr, 0ull); }
     // exclusive scan of the threads' row counts in position order
     uint32_t incl = wave_incl_scan(c);
     if (lane == 63) wsum[wv] = incl;
@@ -1163,48 +1266,41 @@ __global__ __launch_bounds__(256) void k_site_emit(const unsigned long long* __r
     for (int k = 0; k < kSitePerThread; k++) {
         const int64_t q = p0 + k;
         if (q >= sg.seg_len) break;
-        for (int strand = 0; strand < 2; strand++) {
-            for (int plane = 0; plane < n_planes; plane++) {   // run = plane * 2 + strand (one haplotype plane)
-                const unsigned long long v = cnt[(int64_t)(plane * 2 + strand) * plane_len + sg.cnt_base + q];
-                if (v == 0ull) continue;
-                mm_row_t r;
-                r.tid = sg.tid; r.pos = (int32_t)(sg.seg_begin + q); r.strand = (uint8_t)strand; r.rsvd = 0; r.ins_offset = 0;
-                r.code = (int16_t)plane; r.hp = -1; r.n_called = (uint32_t)v; r.n_mod = (uint32_t)(v >> 32);
-                rows[out++] = r;
-            }
-        }
+        out += site_rows<true>(P, sg.tid, sg.seg_begin + q, rows, out);
     }
 }
 
 // ---------------------------------------------------------------------------------- halo slabs
-__global__ void k_slab_export(const unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len,
-                              int n_runs, unsigned long long* __restrict__ dst) {
-    int64_t total = (int64_t)n_runs * len;
+// A slab is position-dense whatever the counters' layout: [run][len] words with run = (plane * n_hp + hp) * 2 + strand, zero
+// where a position is not a site of the plane's class.  op 0: export to buf, 1: add buf into the counters (two independent
+// 32-bit halves; a count on a position that is no site here -- the two sides disagree about the reference -- raises *flag),
+// 2: clear.
+__global__ void k_slab_op(const K2Params P, int op, int tid, int64_t begin, int64_t len, unsigned long long* __restrict__ cnt,
+                          unsigned long long* __restrict__ buf, unsigned int* __restrict__ flag) {
+    const int64_t total = (int64_t)P.n_planes * P.n_hp * 2 * len;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t run = i / len, j = i - run * len;
-        dst[i] = cnt[run * plane_len + off + j];
-    }
-}
-__global__ void k_slab_add(unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len,
-                           int n_runs, const unsigned long long* __restrict__ src) {
-    int64_t total = (int64_t)n_runs * len;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t run = i / len, j = i - run * len;
-        unsigned long long v = src[i];
-        if (v) {
-            unsigned long long a = cnt[run * plane_len + off + j];
-            // two independent 32-bit lanes (n_called, n_mod)
-            unsigned long long lo = (a & 0xFFFFFFFFull) + (v & 0xFFFFFFFFull);
-            unsigned long long hi = (a >> 32) + (v >> 32);
-            cnt[run * plane_len + off + j] = (lo & 0xFFFFFFFFull) | (hi << 32);
+        const int64_t run = i / len, j = i - run * len;
+        const int strand = (int)(run & 1), hp = (int)((run >> 1) % P.n_hp), pl = (int)((run >> 1) / P.n_hp);
+        const int c = P.plane_cls[pl];
+        const DevClass& k = P.classes[c];
+        const int64_t g = P.ref_base[tid] + begin + j;
+        bool is_site = true;
+        int64_t rk = g;
+        if (!k.dense) { const uint2 w = k.site[strand][g >> 5]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+        unsigned long long* word = cnt + k.base + (((int64_t)(hp * 2 + strand) * k.nsites) + P.adj[((int64_t)tid * P.n_classes + c) * 2 + strand] + rk) * k.np + P.plane_slot[pl];
+        if (op == 0) buf[i] = is_site ? *word : 0ull;
+        else if (op == 2) { if (is_site) *word = 0ull; }
+        else {
+            const unsigned long long v = buf[i];
+            if (v) {
+                if (!is_site) { if (flag) *flag = 1u; }
+                else {
+                    const unsigned long long a = *word;
+                    const unsigned long long lo = (a & 0xFFFFFFFFull) + (v & 0xFFFFFFFFull), hi = (a >> 32) + (v >> 32);
+                    *word = (lo & 0xFFFFFFFFull) | (hi << 32);
+                }
+            }
         }
-    }
-}
-__global__ void k_slab_clear(unsigned long long* __restrict__ cnt, int64_t plane_len, int64_t off, int64_t len, int n_runs) {
-    int64_t total = (int64_t)n_runs * len;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t run = i / len, j = i - run * len;
-        cnt[run * plane_len + off + j] = 0ull;
     }
 }
 

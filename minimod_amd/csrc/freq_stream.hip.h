@@ -1,39 +1,41 @@
-// freq_stream.hip.h -- k_stream_reads: the freq hot path of a whole read in ONE wavefront, as a three-way merge of
-// streams, with nothing written to HBM but the counters (reference src/mod.c:776-1370).
+// freq_stream.hip.h -- k_stream_reads: the freq hot path of a whole read in ONE wavefront, with nothing written to HBM but
+// the counters (reference src/mod.c:776-1370).
 //
 // The tile pipeline (freq_tiles.hip.h) cuts a read into independent tiles and pays for the independence: per-op CIGAR
 // prefix arrays and a rank directory are written to a scratch and read back, every tile re-derives its carries, stages
-// its own slices, and the three kernels read the read record three times.  For the common read -- plain `freq` or `view` (no
-// --insertions, no --haplotypes), every MM group a `?`-flagged skip list on one canonical base, in a launch big enough to
-// hide a read inside it -- none of that is needed, because everything a read's calls touch moves in ONE direction:
+// its own slices, and the three kernels read the read record three times.  In a launch big enough to hide a read inside it
+// none of that is needed: ONE wavefront takes a read through get_aln, the base lists, the MM parse and the calls, with two
+// small tables in LDS that are built ONCE per read (round 3; rounds 1-2 slid two windows along the read instead):
 //
-//   tokens        the skip list in text order: ranks (k-th base of the class) rise with the token index;
-//   sequence      the rank of a 32-base block's first base rises with the block index (walked from the read's END for a
-//                 reverse-strand read, whose MM counts bases of the original orientation);
-//   CIGAR         the read position at which an op starts rises with the op index (ops walked from the END for a reverse
-//                 read, read positions counted from position 0 of the original orientation, as get_aln does: the mirrored
-//                 problem is the same problem).
-//
-// So a wavefront keeps three cursors and two small windows in LDS and loops over rounds of 64 tokens:
-//   1. parse skip-list text (256 characters per trip, the per-character sum of k_sum_tiles) into a ring of ranks;
-//   2. extend the directory window (popcount + wave scan of 64 blocks per step, two steps requested together) until it
-//      covers the round's last rank; every lane finds its block (branch-free search in LDS) and selects the base in it;
-//   3. extend the CIGAR window (decode + one wave scan per 64 ops, packed one word per op, four steps requested together)
-//      until it covers the round's last read position; every lane finds its op, projects, loads the reference word and the
-//      ML byte, thresholds, and makes ONE 64-bit atomic add -- the same update the tile pipeline makes.
-// A window that cannot hold a round's span (sparse tokens, introns) simply covers fewer tokens: the rest stay in the ring.
-// What a round needs from memory that depends only on the cursors is requested at its top, before anything is waited for.
+//   CIGAR table     one pass over the CIGAR (get_aln walks it before anything else, mod.c:776-881) gives the totals, the checks
+//                   AND, for a segment of 1024 ops, a checkpoint every FOUR ops: query / reference positions consumed in
+//                   front of it, in stored order.  A call finds its checkpoint with an 8-step search in LDS, loads the
+//                   checkpoint's four ops (16 bytes the pass has just read) and walks them.  A reverse read needs no mirrored
+//                   walk: get_aln's back-to-front walk with mirrored coordinates (mod.c:813-815, :855-858) is the ordinary
+//                   projection of BAM position q shifted by L - q_total (SURVEY.md section 8a').  Reads of up to 1024 ops --
+//                   18 kb of ONT read -- read their CIGAR from memory once; longer ones move the table a segment at a time.
+//   directory       the read's base class counted per 32-base block (popcount + one wave scan per 64 blocks), a segment of 512
+//                   blocks (16 kb of read) at a time, walked from the read's END for a reverse read (whose MM counts bases of
+//                   the original orientation); every lane finds its block with a 9-step search and selects the base inside it.
+//   tokens          the skip list in text order, 256 characters per trip (the per-character sum of k_sum_tiles), into a ring of
+//                   ranks; a round takes 64 of them: rank -> block -> read position -> checkpoint -> op -> reference position
+//                   -> reference word + ML byte -> threshold -> ONE 64-bit atomic add, the same update the tile pipeline makes.
+// Ranks rise inside a group, so a table only ever moves forward (backward for a reverse read's CIGAR) while a group is
+// walked; all groups of a read share the tables.
 //
 // '.' groups: the unlisted bases of the class are calls too; tokens and the bases of the gaps in front of them are one rising
 // sequence of ranks that goes through the same rounds (run_group).  That generality costs the '?' path 5 %, so the kernel has
 // two instantiations (kDot) and the handle moves to the '.'-capable one when a read with a '.' group has shown up.
+// kIns: runs with --insertions and / or --haplotypes ('?' groups only): a base inside an insertion is a call on the anchor
+// left of it with its offset (mod.c:864-874), counters live in per-haplotype planes, what has no dense counter goes to the
+// side table.
 //
-// What this kernel does not do, it hands on BEFORE touching a counter: reads with groups on
-// 'N' or on different bases, more than four codes or eight groups, a CIGAR the checks do not pass outright -> appended to
-// the tile pipeline's item list (k_scan_reads runs after this kernel, or at wait time when nothing else needs it).  Anything
-// that goes wrong once calls have been counted is an input error (malformed token, rank past the last base, ML too short):
-// the read goes on the fallback list and the fused kernel names the error in the reference's order, exactly as for the tile
-// pipeline's irregular reads.  DESIGN.md section 4 ("Streaming kernel") has the measurements.
+// What this kernel does not do, it hands on BEFORE touching a counter: reads with groups on 'N' or on different bases, more
+// than four codes or eight groups, a CIGAR the checks do not pass outright -> appended to the tile pipeline's item list
+// (k_scan_reads runs after this kernel, or at wait time when nothing else needs it).  Anything that goes wrong once calls have
+// been counted is an input error (malformed token, rank past the last base, ML too short): the read goes on the fallback list
+// and the fused kernel names the error in the reference's order, exactly as for the tile pipeline's irregular reads.
+// DESIGN.md section 4 ("Streaming kernel") has the measurements.
 #pragma once
 #include <type_traits>
 #include "freq_tiles.hip.h"
@@ -49,45 +51,27 @@ namespace mmhip {
 
 constexpr uint32_t kStreamChunk = 256;      // skip-list characters parsed per trip (+16 of look-ahead)
 constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at most 63 left over + 128 of a chunk (+1)
-#ifndef MM_STREAM_DIR
-#define MM_STREAM_DIR 320
-#endif
-#ifndef MM_STREAM_CIG
-#define MM_STREAM_CIG 576
-#endif
-#ifndef MM_STREAM_DIR_ROUNDS
-#define MM_STREAM_DIR_ROUNDS 2
-#endif
-#ifndef MM_STREAM_CIG_ROUNDS
-#define MM_STREAM_CIG_ROUNDS 2
+#ifndef MM_STREAM_SEG_BLOCKS
+#define MM_STREAM_SEG_BLOCKS 512
 #endif
 #ifndef MM_STREAM_WAVES
 #define MM_STREAM_WAVES 6
 #endif
-constexpr uint32_t kStreamDir = MM_STREAM_DIR;        // directory window: 32-base blocks (10 kb of read) + one sentinel
-constexpr uint32_t kStreamCig = MM_STREAM_CIG;        // CIGAR window: ops, one packed word each
+constexpr uint32_t kSegBlocks = MM_STREAM_SEG_BLOCKS;   // directory segment: 32-base blocks (a multiple of 64)
+constexpr uint32_t kSegOps = 1024;          // CIGAR segment: ops
+constexpr uint32_t kSegCk = kSegOps / 4;    // ... and its checkpoints, one per four ops
 constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
 constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
-constexpr uint32_t kStreamSpan = 16384;     // a window's packed words hold offsets below this (14 bits each); query offsets stay one
-                                            // below that, so that no word reaches the padding's 0xFFFFFFFF
-constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // what the CIGAR window holds behind its last entry (the directory window: the running total)
-constexpr int kStreamDirRounds = MM_STREAM_DIR_ROUNDS;   // 64-block steps requested together
-#ifndef MM_STREAM_DIR_AHEAD
-#define MM_STREAM_DIR_AHEAD 192
-#endif
-#ifndef MM_STREAM_CIG_AHEAD
-#define MM_STREAM_CIG_AHEAD 384
-#endif
+constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // the bound behind a table's last entry
+constexpr uint32_t kStreamMaxLen = 1u << 20; // an op this long (a 1 Mb intron) is the tile pipeline's: shorter ones cannot wrap a segment's sums
 constexpr uint32_t kNoPend = 0xFFFFFFFFu;
-constexpr uint32_t kStreamDirAhead = MM_STREAM_DIR_AHEAD;   // a round's request tops the windows up to this many entries
-constexpr uint32_t kStreamCigAhead = MM_STREAM_CIG_AHEAD;
-constexpr int kStreamCigRounds = MM_STREAM_CIG_ROUNDS;   // 64-op steps requested together
 
 struct StreamLds {
     uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
     uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
-    uint32_t dw[kStreamDir + 1];            // class members in front of each block of the window (traversal order), then the running total
-    uint32_t cw[kStreamCig + 1];            // query offset << 18 | reference offset << 4 | op, relative to the window's first op; then 0xFFFFFFFF
+    uint32_t dw[kSegBlocks + 1];            // class members in front of each block of the segment (traversal order), then the running total
+    uint32_t cq[kSegCk + 1];                // query positions consumed in front of every fourth op of the segment (stored order), then 0xFFFFFFFF
+    uint32_t cr[kSegCk];                    // ... reference positions
     uint32_t gap_p[65];                     // '.' groups: first element (gap bases, then the token) of each token of the batch; [n] = all
     uint32_t gap_r[64];                     //             first rank of the gap in front of each token
     char hdr[16];
@@ -141,8 +125,6 @@ __device__ __forceinline__ uint32_t leading_ones(uint64_t m) { return ~m ? (uint
 // steps of a read, a compare and a select with no loop control; a probe beyond n reads the bound instead.
 template <uint32_t N>
 __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key, uint32_t n) {
-#ifndef MM_STREAM_FOURWAY_SEARCH
-    // (binary: 4 790 VALU wave instructions per ONT read against 5 010 with the four-way steps below, same time within noise)
     uint32_t lo = 0;
 #pragma unroll
     for (uint32_t m = N; m > 1u; m -= m >> 1) {
@@ -151,24 +133,15 @@ __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key,
         lo = arr[at] <= key ? at : lo;
     }
     return lo;
-#else
-    // four-way: three probes a step, read together -- five dependent LDS round trips for 320 or 576 entries instead of nine or ten
-    uint32_t lo = 0;
-#pragma unroll
-    for (uint32_t m = N; m > 1u; m = (m + 3u) / 4u) {
-        const uint32_t q = (m + 3u) / 4u;
-        const uint32_t a1 = arr[min(lo + q, n)], a2 = arr[min(lo + 2u * q, n)], a3 = arr[min(lo + 3u * q, n)];
-        lo += ((a1 <= key ? 1u : 0u) + (a2 <= key ? 1u : 0u) + (a3 <= key ? 1u : 0u)) * q;
-    }
-    return lo;
-#endif
 }
 
 // kDot: '.' groups (implicit calls) are this kernel's too; without it (the leaner instantiation) reads that have one go to the
 // tile pipeline and a flag tells the host to launch the other instantiation from then on (a file's reads carry one flag or the other)
 // kView: `minimod view` -- a call that passes the context test becomes a record (view_append) instead of a counter update
-template <typename RefWord, bool kStats, bool kDot, bool kView>
+// kIns: --insertions and / or --haplotypes (freq, '?' groups)
+template <typename RefWord, bool kStats, bool kDot, bool kView, bool kIns>
 struct KF {
+    static_assert(!(kIns && (kDot || kView)), "the --insertions / --haplotypes instantiation is freq with '?' groups");
     const TileParams& P;
     const DevParams& p;
     StreamLds& S;
@@ -181,8 +154,9 @@ struct KF {
     const uint4* sq;
     const uint32_t* cg;
     typename RefLoad<RefWord>::Base rwb;
-    uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, seg_lo32, seg_len32, cpat;
+    uint32_t L, ncig, nblk, mlen, ml_len, q_total, r_total, q_shift, seg_lo32, seg_len32, cpat;
     int32_t pos, rev, ridx_cur;
+    int32_t hp, hpi;            // kIns: the read's haplotype tag (-1: haplotypes off), its dense plane (-1: none)
     uint32_t v_region, v_gord;   // view: append region of the wavefront, ordinal of the group at hand
     // the group
     int32_t ncg;
@@ -190,8 +164,16 @@ struct KF {
     bool saw_dot;               // (!kDot) a read was handed on because of a '.' group
     uint32_t gc01, gc23;        // the group's codes, two 16-bit indices a word (0xFFFF: not requested)
     uint32_t ci0, ci1, ci2, ci3;
-    unsigned long long* cnt0;   // the read's strand-0... counters of plane 0 of its contig, shifted so that the index is the reference position;
-                                // null when the contig has no dense counters.  A code's counters: + (plane * 2 + rev) * plane_len
+    // the group's counters (freq_kernels.hip.h, DevClass): all requested codes of a group belong to one context class (else the
+    // read is the tile pipeline's).  gcb[(site * gnp) + slot] is the counter of the code in `slot` at the read's strand and
+    // haplotype plane, `site` = the rank of the position among the class's sites (gsite: 32 positions a word) -- or, for a dense
+    // class (context `*`, --insertions), the position in the contig itself (gsite null).  Null gcb: no dense counters here.
+    unsigned long long* gcb;
+    const uint2* gsite;
+    uint32_t gnp;
+    int64_t ref_base_g;         // the contig's first position in the reference-word space
+    bool has_dense;             // the contig has dense counters in this handle
+    int32_t tid_cur;
     uint32_t ml_start;
     // TWIN groups (run()): two one-code `?` lists over the same tokens, done in one pass.  tw = 0: an ordinary group, the ML byte
     // of token k's code m is ml[ml_start + k * ncg + m]; tw = the list's tokens: ml[ml_start + k + m * tw] (the second list's
@@ -206,14 +188,15 @@ struct KF {
     uint32_t pend;   // reference position << 1 | modified; kNoPend: none (a position is below 2^31 - 1: contig lengths are int32)
     uint32_t staged_at, skip0;   // text offset of the chunk in LDS; header characters in front of the list in the group's first chunk
     bool prev_delim, closed, bad_text;
-    // directory window: blocks [t_w0, t_w0 + wn) in traversal order, t_next the next block to scan, S_next the members in front of it
-    uint32_t t_w0, wn, t_next, S_next;
-    // CIGAR window: ops [.., s_next) in traversal order, xn of them in LDS relative to (A_base, B_base); A_next / B_next =
-    // query / reference positions consumed in front of s_next
-    uint32_t xn, s_next, A_next, B_next, A_base, B_base;
+    // directory segment: blocks [d_t0, d_t0 + d_n) in traversal order (d_n = 0: none), S_lo / S_hi class members in front of it / through it
+    uint32_t d_t0, d_n, S_lo, S_hi;
+    // CIGAR segment: stored ops [c_o0, c_o0 + 1024) as c_n checkpoints (0: none); Q_lo / Q_hi (R_lo / R_hi) query (reference)
+    // positions consumed in front of its first op / through its last op
+    uint32_t c_o0, c_n, Q_lo, Q_hi, R_lo, R_hi;
+    uint32_t rank_ok;   // 1 + the largest rank that has been found in the read (0: none yet): what an unrequested group's last rank is checked against
 #ifdef MM_STREAM_TIMING
-    unsigned long long ftacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0 = 0;   // 0 record + CIGAR pass, 1 headers, 2 parse, 3 directory window,
-                                                                           // 4 locate, 5 CIGAR window, 6 finish, 7 window upkeep, 8 group set-up
+    unsigned long long ftacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0 = 0;   // 0 record + CIGAR pass, 1 headers, 2 parse, 3 directory,
+                                                                           // 4 locate, 5 CIGAR segment, 6 finish, 7 --, 8 group set-up
 #endif
 
     __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
@@ -315,52 +298,36 @@ struct KF {
         wave_sync();
     }
 
-    // ------------------------------------------------------------------ sequence -> directory window
-    // The steps (of 64 blocks) a request at the cursor asks for: what the read still has, what the window has room for, and no
-    // further ahead than kStreamDirAhead entries -- every step that is requested goes into the window, so no block is loaded
-    // twice (a step asked for and then left for the next round came back from HBM again: L2 turns over in about a round's time)
-    __device__ __forceinline__ uint32_t dir_steps() const {
-        const uint32_t by_read = (nblk - t_next + 63u) >> 6, by_win = (kStreamDir - wn) >> 6;
-        const uint32_t ahead = wn < kStreamDirAhead ? (kStreamDirAhead - wn + 63u) >> 6 : 0u;
-        return min(min(by_read, by_win), min(ahead, (uint32_t)kStreamDirRounds));
-    }
-    __device__ __forceinline__ void load_dir(uint4 (&vv)[kStreamDirRounds], uint32_t ns) const {
+    // ------------------------------------------------------------------ sequence -> directory segment
+    // blocks [t0, t0 + kSegBlocks) of the read in traversal order (from the END for a reverse read), s0 class members in front
+    // of them: every block's count from one wave scan per 64 blocks, four 16-byte loads a lane in flight
+    __device__ __forceinline__ void build_dir(uint32_t t0, uint32_t s0) {
         const uint32_t lane = (uint32_t)lane_id();
+        const uint32_t nb = min(kSegBlocks, nblk - t0);
+        uint32_t run = s0;
+        wave_sync();
+        for (uint32_t h = 0; h < nb; h += 256u) {
+            uint4 vv[4];
 #pragma unroll
-        for (int r = 0; r < kStreamDirRounds; r++) {
-            const uint32_t t = t_next + 64u * (uint32_t)r + lane;
-            vv[r] = ((uint32_t)r < ns && t < nblk) ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
-        }
-    }
-    // (vv: the ns steps from t_next on, requested by the caller before it waited for anything.)  They go in; then blocks are
-    // appended until the window covers rank rho_last (S_next > rho_last), the read ends, or the window is full while it already
-    // covers rho_0; a full window that does not even reach rho_0 holds nothing of use and starts over
-    __device__ __forceinline__ void fill_dir(uint32_t rho_0, uint32_t rho_last, uint4 (&vv)[kStreamDirRounds], uint32_t ns) {
-        const uint32_t lane = (uint32_t)lane_id();
-        for (;;) {
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = t0 + h + 64u * (uint32_t)r + lane;
+                vv[r] = (h + 64u * (uint32_t)r < nb && t < nblk) ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
+            }
 #pragma unroll
-            for (int r = 0; r < kStreamDirRounds; r++) {
-                if ((uint32_t)r < ns) {
-                    const uint32_t t = t_next + lane;
+            for (int r = 0; r < 4; r++) {
+                if (h + 64u * (uint32_t)r < nb) {
+                    const uint32_t t = t0 + h + 64u * (uint32_t)r + lane;
                     const bool valid = t < nblk;
-                    uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);   // (steps past the read's end were loaded as zeros)
+                    uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);
                     cnt = valid ? cnt : 0u;
                     const uint32_t incl = wave_incl_scan(cnt);
-                    if (valid) S.dw[wn + lane] = S_next + incl - cnt;
-                    const uint32_t nv = min(64u, nblk - t_next);
-                    wn = uniu(wn + nv); t_next = uniu(t_next + nv);
-                    S_next = uniu(S_next + lane_valu(incl, 63));
+                    if (valid) S.dw[h + 64u * (uint32_t)r + lane] = run + incl - cnt;
+                    run = uniu(run + lane_valu(incl, 63));
                 }
             }
-            if (!(S_next <= rho_last && t_next < nblk)) break;
-            if (wn + 64u > kStreamDir) {
-                if (S_next > rho_0) break;
-                wn = 0; t_w0 = t_next;
-            }
-            ns = min(min((nblk - t_next + 63u) >> 6, (kStreamDir - wn) >> 6), (uint32_t)kStreamDirRounds);
-            load_dir(vv, ns);
         }
-        if (lane == 0) S.dw[wn] = S_next;
+        if (lane == 0u) S.dw[nb] = run;
+        d_t0 = t0; d_n = nb; S_lo = s0; S_hi = run;
         wave_sync();
     }
     // all class members of the read (only needed to check the last rank of a group nobody asked for)
@@ -405,78 +372,108 @@ struct KF {
         return blk * 32u + word * 8u + n;
     }
 
-    // ------------------------------------------------------------------ CIGAR -> window
-    // ops are appended until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more
-    // fits (room, or the 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
-    __device__ __forceinline__ uint32_t cig_steps() const {   // (as dir_steps)
-        const uint32_t by_read = (ncig - s_next + 63u) >> 6, by_win = (kStreamCig - xn) >> 6;
-        const uint32_t ahead = xn < kStreamCigAhead ? (kStreamCigAhead - xn + 63u) >> 6 : 0u;
-        return min(min(by_read, by_win), min(ahead, (uint32_t)kStreamCigRounds));
-    }
-    __device__ __forceinline__ void load_cig(uint32_t (&wv)[kStreamCigRounds], uint32_t ns) const {
+    // ------------------------------------------------------------------ CIGAR -> checkpoint table
+    // the ops of segment [o0, o0 + 1024) as the lanes hold them: lane's word u = stored ops o0 + 256u + 4 lane .. + 3
+    __device__ __forceinline__ void load_seg(uint4 (&cv)[4], uint32_t o0) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
-        for (int r = 0; r < kStreamCigRounds; r++) {
-            const uint32_t s = s_next + 64u * (uint32_t)r + lane;
-            wv[r] = ((uint32_t)r < ns && s < ncig) ? cg[rev ? ncig - 1u - s : s] : 0u;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = o0 + 256u * (uint32_t)u + 4u * lane;
+            cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
         }
     }
-    // (wv: the ns steps from s_next on, requested by the caller at the start of the round.)  They go in; then ops are appended
-    // until the window covers traversal position u_hi (A_next > u_hi), the CIGAR ends, or nothing more fits (room, or the
-    // 14-bit offsets of the packed words) while u_lo is covered; otherwise the window starts over
-    __device__ __forceinline__ void fill_cig(uint32_t u_lo, uint32_t u_hi, uint32_t (&wv)[kStreamCigRounds], uint32_t ns) {
-        const uint32_t lane = (uint32_t)lane_id();
-        bool stop = false;
-        for (;;) {
-            bool stale = false;   // the loaded steps no longer line up with s_next
+    // query / reference positions the four ops of one word consume (the word holds stored ops i .. i + 3); what the ops are
+    // (okops: all of M I D N S = X) and how long (lenor) is collected for the checks
+    __device__ __forceinline__ void word_sums(uint4 v, uint32_t i, uint32_t& a, uint32_t& b, uint32_t& okops, uint32_t& lenor) const {
+        // a word behind the read's last op counts as 0M: nothing to either sum, nothing wrong with it
+        const uint32_t w4[4] = {v.x, i + 1u < ncig ? v.y : 0u, i + 2u < ncig ? v.z : 0u, i + 3u < ncig ? v.w : 0u};
+        a = 0; b = 0;
 #pragma unroll
-            for (int r = 0; r < kStreamCigRounds; r++) {
-                if ((uint32_t)r < ns && !stop && !stale) {
-                    const bool valid = s_next + lane < ncig;
-                    const uint32_t w = wv[r], op = w & 15u, len = w >> 4;
-                    const uint32_t qinc = len & op_mask(0x193u, op), rinc = len & op_mask(0x18Du, op);   // (steps past the CIGAR's end were loaded as zeros)
-                    // both running sums from ONE scan when no op of the step is long enough for a half to carry into the other
-                    uint32_t qs, rs;
-                    if (!__ballot(valid && len >= 1024u)) {
-                        const uint32_t pk = wave_incl_scan(qinc | (rinc << 16));
-                        qs = pk & 0xFFFFu; rs = pk >> 16;
-                    } else {
-                        qs = wave_incl_scan(qinc); rs = wave_incl_scan(rinc);
-                    }
-                    if (xn == 0) { A_base = A_next; B_base = B_next; }
-                    const uint32_t dq = A_next + qs - qinc - A_base, dr = B_next + rs - rinc - B_base;
-                    const uint32_t nv = leading_ones(__ballot(valid && dq < kStreamSpan - 1u && dr < kStreamSpan));
-                    const uint32_t nvalid = min(64u, ncig - s_next);
-                    if (nv == 0u) {   // the next op starts beyond what this window's words can say
-                        if (A_next > u_lo || xn == 0u) stop = true;   // (xn == 0 cannot happen: the first op of a window has offsets 0, 0)
-                        else { xn = 0; stale = true; }
-                    } else {
-                        if (lane < nv) S.cw[xn + lane] = (dq << 18) | (dr << 4) | op;
-                        xn = uniu(xn + nv); s_next = uniu(s_next + nv);
-                        A_next = uniu(A_next + (nv == 64u ? lane_valu(qs, 63) : lane_valu(qs - qinc, (int)nv)));
-                        B_next = uniu(B_next + (nv == 64u ? lane_valu(rs, 63) : lane_valu(rs - rinc, (int)nv)));
-                        if (nv < nvalid) stale = true;
-                    }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t op = w4[k] & 15u, len = w4[k] >> 4;
+            a += len & op_mask(0x193u, op);
+            b += len & op_mask(0x18Du, op);
+            okops &= op_mask(0x19Fu, op);
+            lenor |= len;
+        }
+    }
+    // Segment o0 of the CIGAR from the words the lanes hold: its totals (tq / tr) and, with `build`, its checkpoint table.
+    // from_end = false: (qa, ra) are the positions consumed in front of op o0; true: through the segment's last op (a reverse
+    // read's tokens walk the CIGAR from its end): the table is then written relative to the segment's start and moved.
+    __device__ __forceinline__ void seg_pass(const uint4 (&cv)[4], uint32_t o0, uint32_t qa, uint32_t ra, bool from_end, bool build,
+                                             uint32_t& okops, uint32_t& lenor, uint32_t& tq_out, uint32_t& tr_out) {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t tq = 0, tr = 0;
+        if (!build) {
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t au, bu;
+                word_sums(cv[u], o0 + 256u * (uint32_t)u + 4u * lane, au, bu, okops, lenor);
+                a += au; b += bu;
+            }
+            tq = lane_valu(wave_incl_scan(a), 63); tr = lane_valu(wave_incl_scan(b), 63);
+        } else {
+            const uint32_t q0 = from_end ? 0u : qa, r0 = from_end ? 0u : ra;
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (o0 + 256u * (uint32_t)u < ncig) {
+                    const uint32_t i = o0 + 256u * (uint32_t)u + 4u * lane;
+                    uint32_t a, b;
+                    word_sums(cv[u], i, a, b, okops, lenor);
+                    const uint32_t iq = wave_incl_scan(a), ir = wave_incl_scan(b);
+                    if (i < ncig) { S.cq[64u * (uint32_t)u + lane] = q0 + tq + iq - a; S.cr[64u * (uint32_t)u + lane] = r0 + tr + ir - b; }
+                    tq = uniu(tq + lane_valu(iq, 63)); tr = uniu(tr + lane_valu(ir, 63));
                 }
             }
-            if (stop || !(A_next <= u_hi && s_next < ncig)) break;
-            if (xn + 64u > kStreamCig) {
-                if (A_next > u_lo) break;
-                xn = 0;
+            const uint32_t nck = (min(kSegOps, ncig - o0) + 3u) >> 2;
+            uint32_t qb = q0, rb = r0;
+            if (from_end) {
+                qb = qa - tq; rb = ra - tr;
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t c = 64u * (uint32_t)u + lane;
+                    if (c < nck) { S.cq[c] += qb; S.cr[c] += rb; }
+                }
             }
-            ns = min(min((ncig - s_next + 63u) >> 6, (kStreamCig - xn) >> 6), (uint32_t)kStreamCigRounds);
-            load_cig(wv, ns);
+            if (lane == 0u) S.cq[nck] = kStreamInf;
+            c_o0 = o0; c_n = nck; Q_lo = qb; Q_hi = qb + tq; R_lo = rb; R_hi = rb + tr;
+            wave_sync();
         }
-        if (lane == 0) S.cw[xn] = kStreamInf;   // the bound behind the last op (no packed word reaches it)
-        wave_sync();
+        tq_out = tq; tr_out = tr;
+    }
+    // the segment that holds query position qf (< q_total): the neighbour in the direction the tokens walk, segment by segment;
+    // with no table yet, from the end of the CIGAR the walk starts at
+    __device__ __forceinline__ void ensure_cig(uint32_t qf) {
+        while (c_n == 0u || qf - Q_lo >= Q_hi - Q_lo) {
+            uint32_t o0, qa, ra;
+            bool from_end;
+            if (c_n == 0u) {
+                from_end = rev != 0;
+                o0 = rev ? ((ncig - 1u) / kSegOps) * kSegOps : 0u;
+                qa = rev ? q_total : 0u; ra = rev ? r_total : 0u;
+            } else if (qf >= Q_hi) {
+                o0 = c_o0 + kSegOps; from_end = false; qa = Q_hi; ra = R_hi;
+            } else {
+                o0 = c_o0 - kSegOps; from_end = true; qa = Q_lo; ra = R_lo;
+            }
+            if (o0 >= ncig) { err = MM_E_QOVER; break; }   // (cannot happen: the totals are this table's own sums)
+            uint4 cv[4];
+            uint32_t okops = 0xFFFFFFFFu, lenor = 0, tq, tr;
+            load_seg(cv, o0);
+            seg_pass(cv, o0, qa, ra, from_end, true, okops, lenor, tq, tr);
+        }
     }
 
-    __device__ __forceinline__ void side_append(int32_t spos, int is_mod, int code) {
+    __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
         // (the rare path: what it needs of the read is fetched again rather than kept in registers)
         const int tid = p.reads[ridx_cur].tid;
         const int64_t ref_base = p.ref_base[tid];
+        const int hpk = kIns ? hp : -1;
         unsigned long long key;
-        if (side_key(ref_base + spos, rev, code, 0u, -1, key)) {
+        if (side_key(ref_base + spos, rev, code, ins_off, hpk, key)) {
             if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
@@ -488,8 +485,8 @@ struct KF {
         unsigned long long idx = base + __popcll(m & lanemask_lt());
         if (idx < p.side_cap) {
             SideRec r;
-            r.tid = tid; r.pos = spos; r.ins_off = 0; r.strand = (uint8_t)rev;
-            r.is_mod = (uint8_t)is_mod; r.code = (int16_t)code; r.hp = (int16_t)-1;
+            r.tid = tid; r.pos = spos; r.ins_off = (uint16_t)ins_off; r.strand = (uint8_t)rev;
+            r.is_mod = (uint8_t)is_mod; r.code = (int16_t)code; r.hp = (int16_t)hpk;
             p.side[idx] = r;
         } else {
             err = MM_E_SIDEFULL;
@@ -498,44 +495,40 @@ struct KF {
 
     __device__ __forceinline__ void flush_pending() {
         if (pend != kNoPend) {
-            // (the first code's plane is wave-uniform: the lane keeps one word, not an address and an increment)
-            const int plane = (int)((ci0 >> 23) & 127u) - 1;
-            unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
-            atomicAdd(cbm + (pend >> 1), (pend & 1u) ? 0x100000001ull : 1ull);
+            // (the first code's slot is wave-uniform: the lane keeps one word, not an address and an increment)
+            const uint32_t slot = ((ci0 >> 23) & 127u) - 1u;
+            atomicAdd(gcb + ((uint64_t)(pend >> 1) * gnp + slot), (pend & 1u) ? 0x100000001ull : 1ull);
         }
         pend = kNoPend;
     }
 
-    // ------------------------------------------------------------------ one round: the ring's first n tokens (n <= 64)
-    // returns the number of tokens done (0: something is wrong with the read)
-    // n rising ranks, one a lane; expl: the lane's rank is a listed token (its ML bytes are those of token kidx of the group),
-    // else an unlisted base of a '.' group (mod.c:1206-1287, :1289-1365: called, not modified, no ML byte)
+    // ------------------------------------------------------------------ one round: n rising ranks, one a lane (n <= 64)
+    // expl: the lane's rank is a listed token (its ML bytes are those of token kidx of the group), else an unlisted base of a
+    // '.' group (mod.c:1206-1287, :1289-1365: called, not modified, no ML byte).  Returns the number of ranks done: those whose
+    // block lies in the directory segment and whose op lies in the CIGAR segment (0: a rank beyond the read's last base of the
+    // class, or something else wrong with the read); the caller comes again with the rest.
     __device__ __forceinline__ uint32_t round_core(uint32_t rho_in, uint32_t n, bool expl, uint32_t kidx) {
         const uint32_t lane = (uint32_t)lane_id();
         const bool lv = lane < n;
         const uint32_t rho = lv ? rho_in : 0xFFFFFFFFu;
-        const uint32_t rho_0 = lane_valu(rho, 0), rho_last = lane_valu(rho, (int)(n - 1u));
+        const uint32_t rho_0 = lane_valu(rho, 0);
         KFT_LAP(2);
-        // Requested together, before anything is waited for: the next steps of the sequence and of the CIGAR from where the
-        // cursors stand, and the round's ML bytes (a round then pays one trip to memory for all three, not one each)
-        uint4 dv[kStreamDirRounds];
-        uint32_t cv[kStreamCigRounds];
-        const uint32_t nds = dir_steps(), ncs = cig_steps();
-        load_dir(dv, nds);
-        load_cig(cv, ncs);
+        // the round's ML bytes are requested before anything else is waited for
         const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * ((kTwinOK && tw) ? 1u : (uint32_t)ncg);
         const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
-        fill_dir(rho_0, rho_last, dv, nds);
+        // the directory segment that holds the round's first rank (ranks rise inside a group; a new group starts over)
+        if (d_n == 0u || rho_0 < S_lo) build_dir(0u, 0u);
+        while (rho_0 >= S_hi && d_t0 + d_n < nblk) build_dir(d_t0 + d_n, S_hi);
+        const uint32_t n1 = leading_ones(__ballot(lv && rho < S_hi));   // ranks whose block is in the segment
         KFT_LAP(3);
-        const uint32_t n1 = leading_ones(__ballot(lv && rho < S_next));   // tokens whose block is in the window
         uint32_t n_done = 0;
         if (n1 > 0u) {
-            // rank -> block: largest j with dw[j] <= rho (dw[0] <= rho_0 by construction)
+            // rank -> block: largest j with dw[j] <= rho (dw[0] = S_lo <= rho_0)
             const bool act = lane < n1;
-            const uint32_t j = act ? search_le<kStreamDir>(S.dw, rho, wn) : 0u;
+            const uint32_t j = act ? search_le<kSegBlocks>(S.dw, rho, d_n) : 0u;
             const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
-            const uint32_t t = t_w0 + j, blk = rev ? nblk - 1u - t : t;
+            const uint32_t t = d_t0 + j, blk = rev ? nblk - 1u - t : t;
             const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
 #ifndef MM_ABL_NOGATHER
             const uint4 sv = act ? sq[blk] : make_uint4(0, 0, 0, 0);
@@ -543,59 +536,73 @@ struct KF {
             const uint4 sv = make_uint4(0x22222222u ^ blk, 0x44444444u, 0x22224444u, 0x42424242u);
 #endif
             uint32_t code = 0;
-#ifdef MM_ABL_NOSELECT
-            const uint32_t q = act ? blk * 32u + (kk & 31u) + (sv.x & 0u) : 0u;
-#else
             const uint32_t q = act ? select_in_block(sv, blk, kk, code) : 0u;
-#endif
-            // read position -> position in the direction the CIGAR is walked (get_aln walks a reverse read's ops back to front
-            // from position 0 of the original orientation, mod.c:813-860); positions past the CIGAR's query length have no call
-            const uint32_t u = rev ? L - 1u - q : q;
-            const bool live = act && u < q_total;
+            // BAM position -> query position of the CIGAR: get_aln walks a reverse read's ops back to front from position 0 of
+            // the original orientation (mod.c:813-860), so its aligned part lies at BAM positions [L - q_total, L); positions
+            // outside the CIGAR's query length have no call
+            const uint32_t qi = q - q_shift;
+            const bool live = act && qi < q_total;
             const uint64_t lm = __ballot(live);
             KFT_LAP(4);
-            if (lm) {
-                const int fl = __ffsll((unsigned long long)lm) - 1, ll = 63 - __clzll((unsigned long long)lm);
-                fill_cig(lane_valu(u, fl), lane_valu(u, ll), cv, ncs);
-            }
-            n_done = leading_ones(__ballot(act && (!live || u < A_next)));
+            if (lm) ensure_cig(lane_valu(qi, __ffsll((unsigned long long)lm) - 1));
+            const bool in_seg = qi - Q_lo < Q_hi - Q_lo;
+            n_done = leading_ones(__ballot(act && (!live || in_seg)));
+            if (__ballot(err != 0)) n_done = 0;
             KFT_LAP(5);
             const bool fin = lane < n_done && live;
-            const uint64_t fm = __ballot(fin);
-#ifdef MM_ABL_NOFINISH
-            if (false && fm) {
-#else
-            if (fm) {
-#endif
-                // traversal position -> op: largest s with (query offset of op s) <= u
-                const uint32_t du = u - A_base;
-                const uint32_t target = ((du < kStreamSpan - 1u ? du : kStreamSpan - 2u) << 18) | 0x3FFFFu;
-                const uint32_t xo = fin ? search_le<kStreamCig>(S.cw, target, xn) : 0u;
-                const uint32_t xw = S.cw[xo];
-                const uint32_t op = xw & 15u, a_s = A_base + (xw >> 18), b_s = B_base + ((xw >> 4) & 0x3FFFu);
-                const bool call = fin && ((0x181u >> op) & 1u);
-                const uint32_t e = u - a_s;
-                const int32_t ref_pos = rev ? pos + (int32_t)(r_total - 1u - b_s - e) : pos + (int32_t)(b_s + e);
+            if (__ballot(fin)) {
+                // query position -> checkpoint (largest c with cq[c] <= qi) -> op: the checkpoint's four ops are walked
+                const uint32_t ck = fin ? search_le<kSegCk>(S.cq, qi, c_n) : 0u;
+                const uint32_t a0 = S.cq[ck], b0 = S.cr[ck];
+                const uint4 ov = fin ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck) : make_uint4(0, 0, 0, 0);
+                const uint32_t o0 = ov.x & 15u, o1 = ov.y & 15u, o2 = ov.z & 15u, o3 = ov.w & 15u;
+                const uint32_t l0 = ov.x >> 4, l1 = ov.y >> 4, l2 = ov.z >> 4;
+                const uint32_t a1 = a0 + (l0 & op_mask(0x193u, o0)), a2 = a1 + (l1 & op_mask(0x193u, o1)), a3 = a2 + (l2 & op_mask(0x193u, o2));
+                const uint32_t b1 = b0 + (l0 & op_mask(0x18Du, o0)), b2 = b1 + (l1 & op_mask(0x18Du, o1)), b3 = b2 + (l2 & op_mask(0x18Du, o2));
+                // the op that holds qi: the first whose end lies behind it (ops that consume no query position are passed over)
+                const uint32_t kq = (qi >= a1 ? 1u : 0u) + (qi >= a2 ? 1u : 0u) + (qi >= a3 ? 1u : 0u);
+                const uint32_t op = kq == 0u ? o0 : (kq == 1u ? o1 : (kq == 2u ? o2 : o3));
+                const uint32_t a_s = kq == 0u ? a0 : (kq == 1u ? a1 : (kq == 2u ? a2 : a3));
+                const uint32_t b_s = kq == 0u ? b0 : (kq == 1u ? b1 : (kq == 2u ? b2 : b3));
+                const uint32_t e = qi - a_s;
+                bool call = fin && ((0x181u >> op) & 1u);
+                int32_t ref_pos = pos + (int32_t)(b_s + e);
+                uint32_t ins_off = 0;
+                if (kIns && p.insertions && fin && op == 1u) {
+                    // a base inside an insertion: a call on the reference base left of it, with its 1-based offset truncated like
+                    // make_key's uint16 (mod.c:428, :864-874); listed calls only here (kIns has no '.' groups)
+                    ins_off = (e + 1u) & 0xFFFFu;
+                    ref_pos = pos + (int32_t)b_s - 1;
+                    call = ref_pos >= 0;
+                }
                 uint32_t w = 0;
-                if (call) {
+                // Is the position a site of the group's context class, and which one: the class's site word (32 positions: which are
+                // sites, how many sites lie in front) answers both.  A dense class (context `*`; --insertions, where neither context
+                // nor base are looked at for ANY call, mod.c:1167-1172) counts every position: nothing to look up.
+                bool in_ctx = true;
+                uint32_t site = (uint32_t)ref_pos;
+                if (call && gsite != nullptr) {
+                    const int64_t gp = ref_base_g + (int64_t)(uint32_t)ref_pos;
 #ifndef MM_ABL_NOREF
+                    const uint2 sw = gsite[gp >> 5];
                     w = RefLoad<RefWord>::at(rwb, (int64_t)(uint32_t)ref_pos);
 #else
+                    const uint2 sw = make_uint2(0xFFFFFFFFu, (uint32_t)(gp >> 5) * 32u);
                     w = 0xFFFFFFE0u | (code & 31u) | ((uint32_t)ref_pos & 0u);
 #endif
+                    in_ctx = (sw.x >> ((uint32_t)gp & 31u)) & 1u;
+                    site = site_rank(sw, (uint32_t)gp & 31u);
                     if (kStats) st_look++;
                 }
+                call = call && in_ctx;
                 if (call) {
                     const uint32_t refcode = w & 31u;
                     for (int m = 0; m < ncg; m++) {
                         const int ci = gcode_at(m);
                         if (ci < 0) continue;
                         const uint32_t cinfo = cinfo_at(m);
-                        const int req = (int)((cinfo >> 19) & 15u);
                         const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
-                        const bool in_ctx = (w >> (5 + 2 * req + rev)) & 1u;
-                        const bool matches = ((cinfo >> 18) & 1u) || refcode == code;
-                        if (!(in_ctx && matches)) continue;
+                        if (gsite != nullptr && !(((cinfo >> 18) & 1u) || refcode == code)) continue;   // the base test (mod.c:1163-1164); a dense class has none
                         int is_mod = 0;
                         if (kView && !expl) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
                             view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), 1u, 0u);
@@ -617,59 +624,26 @@ struct KF {
                             else if (mv <= t_lo) is_mod = 0;
                             else continue;
                         }
-                        const int plane = (int)((cinfo >> 23) & 127u) - 1;
-                        unsigned long long* const cbm = cnt0 + ((int64_t)plane * 2 + rev) * p.plane_len;
-                        if (cnt0 != nullptr && plane >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32) {
+                        const int slot = (int)((cinfo >> 23) & 127u) - 1;
+                        const bool dense = gcb != nullptr && slot >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32 && (!kIns || (ins_off == 0u && hpi >= 0));
+                        if (dense) {
 #ifndef MM_ABL_NOATOMIC
-#ifndef MM_STREAM_ATOMICS_AT_ONCE
-                            if (m == 0) pend = ((uint32_t)ref_pos << 1) | (uint32_t)is_mod;
-                            else
-#endif
-                            atomicAdd(cbm + (uint32_t)ref_pos, is_mod ? 0x100000001ull : 1ull);
+                            if (m == 0) pend = (site << 1) | (uint32_t)is_mod;
+                            else atomicAdd(gcb + ((uint64_t)site * gnp + (uint32_t)slot), is_mod ? 0x100000001ull : 1ull);
 #else
-                            if (ref_pos == -12345 && is_mod) atomicAdd(cbm, 1ull);
+                            if (ref_pos == -12345 && is_mod) atomicAdd(gcb, 1ull);
 #endif
                             if (kStats) st_dense++;
                         } else {
-                            side_append(ref_pos, is_mod, ci);
+                            side_append(ref_pos, ins_off, is_mod, ci);
                             if (kStats) st_side++;
                         }
                     }
                 }
-                KFT_LAP(6);
-                // the CIGAR window keeps what the next round can still need: from the last searched op on
-                const int fll = 63 - __clzll((unsigned long long)fm);
-                const uint32_t xl = lane_valu(xo, fll);
-                if (xl > 0u) {
-                    const uint32_t b0 = S.cw[xl] & ~15u, cnt = xn - xl;
-                    for (uint32_t c0 = 0; c0 < cnt + 1u; c0 += 64u) {   // with the bound behind the last op (a chunk is read before the one below it is written: xl > 0)
-                        const uint32_t i = c0 + lane;
-                        const uint32_t v = i < cnt ? S.cw[xl + i] - b0 : kStreamInf;
-                        wave_sync();
-                        if (i < cnt + 1u) S.cw[i] = v;
-                        wave_sync();
-                    }
-                    A_base = uniu(A_base + (b0 >> 18)); B_base = uniu(B_base + ((b0 >> 4) & 0x3FFFu));
-                    xn = uniu(cnt);
-                }
             }
-            if (n_done > 0u) {
-                // ... and the directory window from the block of the last token done
-                const uint32_t jl = lane_valu(j, (int)(n_done - 1u));
-                if (jl > 0u) {
-                    const uint32_t cnt = wn - jl + 1u;   // with the running total behind the last block
-                    for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
-                        const uint32_t i = c0 + lane;
-                        const uint32_t v = i < cnt ? S.dw[jl + i] : 0u;
-                        wave_sync();
-                        if (i < cnt) S.dw[i] = v;
-                        wave_sync();
-                    }
-                    t_w0 = uniu(t_w0 + jl); wn = uniu(wn - jl);
-                }
-            }
+            KFT_LAP(6);
+            if (n_done > 0u) rank_ok = max(rank_ok, lane_valu(rho, (int)(n_done - 1u)) + 1u);
         }
-        KFT_LAP(7);
         return n_done;
     }
 
@@ -679,8 +653,9 @@ struct KF {
         cpos = mpos; skip0 = lstart - mpos; prev_delim = true; closed = false; bad_text = false;
         pend = kNoPend;
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
-        t_w0 = 0; wn = 0; t_next = 0; S_next = 0;
-        xn = 0; s_next = 0; A_next = 0; B_next = 0; A_base = 0; B_base = 0;
+        // a read of several segments starts the group at the table's first segment again (a short read's tables hold all of it)
+        if (nblk > kSegBlocks) d_n = 0;
+        if (ncig > kSegOps && wanted) c_n = 0;
         if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
         // One loop, one call of round_core: the ranks of a round come from the ring (a batch of up to 64 tokens), or -- in a
@@ -789,6 +764,11 @@ struct KF {
         pos = uni(rd.pos); ridx_cur = ridx;
         L = uniu(rd.l_qseq); ncig = uniu(rd.n_cigar); mlen = uniu(rd.mm_len); ml_len = uniu(rd.ml_len);
         rev = (uni(rd.flag) & 0x10) ? 1 : 0;
+        if (kIns) {
+            const int hpt = (int)(uint32_t)uni((int)rd.hp);
+            hp = p.haplotypes ? hpt : -1;
+            hpi = p.haplotypes ? (hpt < p.n_hp ? hpt : -1) : 0;
+        } else { hp = -1; hpi = 0; }
         mm = p.mm + rd.mm_off; ml = p.ml + rd.ml_off;
         sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
         cg = p.cigar + rd.cigar_off;
@@ -796,60 +776,41 @@ struct KF {
         // Everything that only needs the record is requested before anything is waited for: the CIGAR (its first 1024 ops),
         // the first characters of the MM string (the first group's header and the start of its list), the contig's entries
         uint4 cv[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = 256u * (uint32_t)u + 4u * lane;
-            cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
-        }
+        load_seg(cv, 0u);
         staged_at = 0xFFFFFFFFu; skip0 = 0;
         fetch_chunk(0u);
         const bool tid_ok = tid >= 0 && tid < p.n_contigs;
         const int tid_c = tid_ok ? tid : 0;
         const int64_t ref_base = scalar_load(p.ref_base + tid_c);
         const int64_t ctg_len = scalar_load(p.ctg_len + tid_c);
-        const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c), cnt_base = scalar_load(p.cnt_base + tid_c);
+        const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c);
         int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
+        d_n = 0; c_n = 0; rank_ok = 0;
         if (st == 0) {
-            // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, and the checks reduced to
-            // what a clean record passes outright; anything else is the tile pipeline's to judge op by op
-            uint32_t sumq = 0, sumr = 0, okops = 0xFFFFFFFFu, lenor = 0;
-            bool badop = false;
+            // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, the checks reduced to what a
+            // clean record passes outright (anything else is the tile pipeline's to judge op by op) -- and, on the way, the
+            // checkpoint table of the segment the tokens start in: the first one, or the last one for a reverse read
+            uint32_t okops = 0xFFFFFFFFu, lenor = 0;
+            uint32_t run_q = 0, run_r = 0;
+            bool over = false;
+            const uint32_t want_o0 = rev ? ((ncig - 1u) / kSegOps) * kSegOps : 0u;
 #ifdef MM_ABL_NOVALIDATE
-            for (uint32_t i0 = 0; i0 < 0u; i0 += 1024u) {
+            for (uint32_t i0 = 0; i0 < 0u; i0 += kSegOps) {
 #else
-            for (uint32_t i0 = 0; i0 < ncig; i0 += 1024u) {
+            for (uint32_t i0 = 0; i0 < ncig; i0 += kSegOps) {
 #endif
-                if (i0 > 0u) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
-                        cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + 256u * (uint32_t)u + 4u * lane;
-                    // a word behind the read's last op counts as 0M: nothing to either sum, nothing wrong with it
-                    const uint32_t w4[4] = {cv[u].x, i + 1u < ncig ? cv[u].y : 0u, i + 2u < ncig ? cv[u].z : 0u, i + 3u < ncig ? cv[u].w : 0u};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t op = w4[k] & 15u, len = w4[k] >> 4;
-                        sumq += len & op_mask(0x193u, op);
-                        sumr += len & op_mask(0x18Du, op);
-                        okops &= op_mask(0x19Fu, op);   // M I D N S = X are this kernel's ops
-                        lenor |= len;
-                    }
-                }
-                // (a lane's sums cannot wrap unseen: sixteen lengths below 2^27 on top of a sum below 2^28; longer ops and larger
-                // sums are the tile pipeline's to judge)
-                badop = badop || sumq >= (1u << 28) || sumr >= (1u << 28);
+                if (i0 > 0u) load_seg(cv, i0);
+                uint32_t tq, tr;
+                seg_pass(cv, i0, run_q, run_r, false, i0 == want_o0, okops, lenor, tq, tr);
+                // (no op is as long as 2^20 in a read that stays here, so a segment's sums stay below 2^30; the running totals are
+                // looked at after every segment)
+                run_q += tq; run_r += tr;
+                over = over || run_q >= (1u << 28) || run_r >= (1u << 28);
             }
-            badop = badop || okops == 0u || lenor >= (1u << 27);
-            // 64 lanes x 2^28 does not fit a word: the halves are added separately
-            const uint64_t tq = (uint64_t)lane_valu(wave_incl_scan(sumq & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumq >> 16), 63) << 16);
-            const uint64_t tr = (uint64_t)lane_valu(wave_incl_scan(sumr & 0xFFFFu), 63) + ((uint64_t)lane_valu(wave_incl_scan(sumr >> 16), 63) << 16);
-            if (__ballot(badop) || tq > (uint64_t)L || tr >= (1ull << 28) || pos < 0 || (int64_t)pos + (int64_t)tr > ctg_len) st = 1;
-            q_total = (uint32_t)tq; r_total = (uint32_t)tr;
+            const bool badop = __ballot(okops == 0u || lenor >= kStreamMaxLen) != 0ull;
+            if (badop || over || run_q > L || pos < 0 || (int64_t)pos + (int64_t)run_r > ctg_len) { st = 1; c_n = 0; }
+            q_total = run_q; r_total = run_r;
+            q_shift = (rev && run_q < L) ? L - run_q : 0u;
         }
         KFT_LAP(0);
         uint32_t ngrp = 0;
@@ -857,7 +818,7 @@ struct KF {
             // The group headers (mod.c:1003-1062): is this a read for this kernel, where are its lists, which codes do they carry.
             // A group's first kStreamChunk characters are staged in LDS: the header is read from there, and so is the group's
             // end when it lies that near.
-            KA<RefWord, StreamLds> hp(P, S);
+            KA<RefWord, StreamLds> hp_(P, S);
             const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
             uint32_t mpos = 0;
             int first_cls = -1;
@@ -880,31 +841,40 @@ struct KF {
                     gflags = uniu(S.memo_flags[slot]); c01 = uniu(S.memo_c01[slot]); c23 = uniu(S.memo_c23[slot]);
                     if (lane < 4u) ci_w = S.memo_ci[slot][lane];
                     lstart = mpos + hlen;
+                    if (kIns && (gflags & 4u)) st = 1;   // ('.' groups under --insertions / --haplotypes: the tile pipeline's)
                 } else {
-                    GroupHdr g = hp.parse_header_ch(ch, mlen, mpos);
+                    GroupHdr g = hp_.parse_header_ch(ch, mlen, mpos);
                     lstart = g.lstart;
                     gflags = 0; c01 = 0; c23 = 0;
                     if (g.herr || g.n > 4 || ngrp >= kStreamGroups) st = 1;
                     else {
                         if (g.modbase == 'N') st = 1;   // the tile pipeline has the direct groups
                         if (!kDot && g.flag == '.') { st = 1; saw_dot = true; }   // ... and, for this instantiation, the implicit calls
-                        hp.err = 0;
-                        hp.lookup_codes(g);
-                        if (__ballot(hp.err != 0)) st = 1;
+                        hp_.err = 0;
+                        hp_.lookup_codes(g);
+                        if (__ballot(hp_.err != 0)) st = 1;
                         const int16_t a0 = S.g_code[0], a1 = S.g_code[1], a2 = S.g_code[2], a3 = S.g_code[3];
                         const bool unwanted = a0 < 0 && a1 < 0 && a2 < 0 && a3 < 0;
                         gflags = (unwanted ? 64u : 0u) | (g.flag == '.' ? 4u : 0u) | ((uint32_t)g.n << 12);
                         c01 = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
                         c23 = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
-                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 | (plane + 1) << 23
+                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 |
+                        // (slot of the code's counters among its context class's + 1, 0: no dense counters) << 23
                         const int cix = lane == 0u ? a0 : (lane == 1u ? a1 : (lane == 2u ? a2 : a3));
+                        int kcls = -1;
                         if ((int)lane < g.n && lane < 4u && cix >= 0) {
                             const DevCode& dc = p.codes[cix];
                             const int req = dc.req, plane = dc.plane;
                             const DevMod& dm = p.mods[req];
+                            kcls = p.cls_of_mod[req];
                             ci_w = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
-                                   ((uint32_t)(plane + 1) << 23);
+                                   ((uint32_t)(plane >= 0 ? dc.slot + 1 : 0) << 23);
                         }
+                        // the requested codes of a group share one context class here (one site word answers for all of them)
+                        const uint64_t wl = __ballot(kcls >= 0);
+                        const int cls0 = wl ? lane_val(kcls, __ffsll((unsigned long long)wl) - 1) : 0;
+                        if (__ballot(kcls >= 0 && kcls != cls0)) st = 1;
+                        gflags |= (uint32_t)cls0 << 16;
                         wave_sync();
                         if (st == 0 && ngrp < kStreamMemo && hlen <= 16u && lstart == mpos + hlen) {
                             if (lane < 16u) S.memo_hdr[slot][lane] = (uint8_t)ch;
@@ -947,10 +917,12 @@ struct KF {
         if (st == 0 && ngrp > 0u) {
             seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
             rwb = RefLoad<RefWord>::from(p.refw, ref_base);
-            cnt0 = seg_len > 0 ? p.counters + cnt_base - seg_begin : nullptr;
+            ref_base_g = ref_base; has_dense = seg_len > 0; tid_cur = tid;
+            gcb = nullptr; gsite = nullptr; gnp = 1;
             ml_start = 0;
-            uint32_t nb_all = 0;
-            bool have_nb = false;
+            uint32_t unw_last = 0;   // 1 + the largest last rank of the groups nobody asked for (0: none)
+            uint32_t prev_ntok = 0;
+            bool prev_done = false;   // the group before this one was requested and walked (its tokens are prev_ntok)
             for (uint32_t gi = 0; gi < ngrp && st == 0; gi++) {
                 const uint32_t gmpos = uniu(S.g_mpos[gi]), lstart = uniu(S.g_lstart[gi]), gflags = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
                 ncg = (int)((gflags >> 12) & 7u);
@@ -960,18 +932,44 @@ struct KF {
                 if (wanted) {
                     gc01 = c01; gc23 = c23;
                     ci0 = uniu(S.g_ci[gi][0]); ci1 = uniu(S.g_ci[gi][1]); ci2 = uniu(S.g_ci[gi][2]); ci3 = uniu(S.g_ci[gi][3]);
+                    // the counters of the group's context class for this read: its strand and haplotype plane, its contig's sites
+                    const int kc = (int)((gflags >> 16) & 15u);
+                    const DevClass kd = scalar_load(p.classes + kc);
+                    const int64_t adjv = scalar_load(p.adj + ((int64_t)tid * p.n_classes + kc) * 2 + rev);
+                    gnp = (uint32_t)kd.np;
+                    gsite = kd.dense ? nullptr : kd.site[rev];
+                    const int hpl = kIns ? (hpi >= 0 ? hpi : 0) : 0;
+                    gcb = has_dense ? p.counters + kd.base + (((int64_t)(hpl * 2 + rev) * kd.nsites) + adjv + (kd.dense ? ref_base : 0)) * kd.np : nullptr;
                 }
                 uint32_t ntok = 0;
                 tw = 0;
+                const uint32_t endA = uniu(S.g_end[gi]);
+                // A group nobody asked for only matters for its token count (where the next group's ML bytes begin) and for the
+                // check of its last rank (mod.c:1116).  5mC + 5hmC callers write the SAME list twice (C+h?,<list>;C+m?,<list>;):
+                // when the list is, character for character, that of a requested neighbour -- the one behind it, or the one in
+                // front that has just been walked -- and nothing but ",digits,digits,...", its tokens are its commas and its ranks
+                // are the neighbour's, whose walk checks them: the group costs one comparison of the two texts.
+                if (!wanted && endA > lstart) {
+                    uint32_t same = 0;
+                    if (gi + 1u < ngrp) {
+                        const uint32_t f2 = uniu(S.g_flags[gi + 1u]), lstartB = uniu(S.g_lstart[gi + 1u]), endB = uniu(S.g_end[gi + 1u]);
+                        if (!(f2 & 64u) && endA - lstart == endB - lstartB) same = twin_lists(lstart, lstartB, endA - lstart);
+                    }
+                    if (!same && prev_done && gi > 0u) {
+                        const uint32_t lstartB = uniu(S.g_lstart[gi - 1u]), endB = uniu(S.g_end[gi - 1u]);
+                        if (endA - lstart == endB - lstartB) { same = twin_lists(lstart, lstartB, endA - lstart); if (same != prev_ntok) same = 0; }
+                    }
+                    if (same) { ml_start += same * (uint32_t)ncg; prev_done = false; KFT_LAP(8); continue; }
+                }
                 // TWIN groups: this group and the next one are `?` lists of one requested code each over the same tokens -- the
-                // same text, as 5mC + 5hmC callers write them (C+h?,<list>;C+m?,<list>;).  One pass does both codes on every
-                // call; the second list is never parsed and the merge with the sequence and the CIGAR is not made twice.  The
-                // reference walks the groups one after the other (mod.c:1003-1370): the same updates in another order.
+                // same text.  One pass does both codes on every call; the second list is never parsed and the merge with the
+                // sequence and the CIGAR is not made twice.  The reference walks the groups one after the other
+                // (mod.c:1003-1370): the same updates in another order.
                 if (kTwinOK && wanted && !dot_group && ncg == 1 && gi + 1u < ngrp) {
                     const uint32_t f2 = uniu(S.g_flags[gi + 1u]);
-                    const uint32_t endA = uniu(S.g_end[gi]), lstartB = uniu(S.g_lstart[gi + 1u]), endB = uniu(S.g_end[gi + 1u]);
+                    const uint32_t lstartB = uniu(S.g_lstart[gi + 1u]), endB = uniu(S.g_end[gi + 1u]);
                     if (!(f2 & (64u | 4u)) && ((f2 >> 12) & 7u) == 1u && endA > lstart && endA - lstart == endB - lstartB) {
-                        tw = twin_lists(lstart, lstartB, endA - lstart);
+                        if (((f2 >> 16) & 15u) == ((gflags >> 16) & 15u)) tw = twin_lists(lstart, lstartB, endA - lstart);   // (one context class for both codes)
                         if (tw) {
                             ncg = 2;
                             gc01 = (c01 & 0xFFFFu) | (uniu(S.g_c01[gi + 1u]) << 16);
@@ -982,16 +980,19 @@ struct KF {
                 KFT_LAP(8);
                 st = run_group(gmpos, lstart, wanted, ntok);
                 KFT_LAP(2);
+                prev_done = wanted && st == 0; prev_ntok = ntok;
                 if (kTwinOK && tw) {
                     if (st == 0 && ntok != tw) st = 2;   // (cannot happen: a list that plain has as many tokens as commas)
-                    ml_start += 2u * ntok; gi++; continue;
+                    ml_start += 2u * ntok; gi++; prev_done = false; continue;
                 }
-                if (st == 0 && !wanted && Rcarry != 0u) {
-                    // a group nobody asked for: its last listed rank must exist (mod.c:1116)
-                    if (!have_nb) { nb_all = count_all(); have_nb = true; }
-                    if (Rcarry - 1u >= nb_all) st = 2;
-                }
+                if (st == 0 && !wanted && Rcarry != 0u) unw_last = max(unw_last, Rcarry);
                 ml_start += ntok * (uint32_t)ncg;
+            }
+            // groups nobody asked for: their last listed rank must exist (mod.c:1116).  A rank the requested groups' walks have
+            // found exists; else the class is counted (the whole read's directory, when one segment holds it, has the count)
+            if (st == 0 && unw_last > rank_ok) {
+                const uint32_t nb_all = (d_n != 0u && d_t0 == 0u && d_n == nblk) ? S_hi : count_all();
+                if (unw_last > nb_all) st = 2;
             }
         }
         return st;
@@ -1009,13 +1010,13 @@ struct KF {
 };
 
 // kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
-template <typename RefWord, bool kStats, bool kDot, bool kView>
+template <typename RefWord, bool kStats, bool kDot, bool kView, bool kIns>
 __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const TileParams P) {
     __shared__ StreamLds lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();
-    KF<RefWord, kStats, kDot, kView> k(P, lds[threadIdx.x >> 6], ptab);
+    KF<RefWord, kStats, kDot, kView, kIns> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
     if (P.reset_in_stream && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(256, MM_STREAM_WAVES) void k_stream_reads(const Til
             const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
             P.tile_items[at] = ridx;
             if (P.host_tile_flag) *P.host_tile_flag = 1u;
-            if (!kDot && k.saw_dot && P.host_dot_flag) *P.host_dot_flag = 1u;
+            if (!kDot && !kIns && k.saw_dot && P.host_dot_flag) *P.host_dot_flag = 1u;
         }
         if (st == 2 && lane_id() == 0) {   // an input error somewhere in the read: the fused kernel names it
             const unsigned int at = atomicAdd(P.fb_count, 1u);

@@ -552,6 +552,9 @@ struct KA {
                 }
             }
             if (lane == 0 && part + 1u >= nparts) P.g_qtot[ridx] = carry_q;
+            // a CIGAR that consumes more than the sequence has: whether that is an error depends on where the excess lies and on
+            // the strand (get_aln only looks at aligned bases, in the order it walks them, mod.c:813-860): the fused kernel judges
+            if (part + 1u >= nparts && carry_q > L) err = err ? err : MM_E_QOVER;
             result = any_err();
         }
         return result;
@@ -1258,9 +1261,7 @@ struct KC {
                 }
                 int64_t off = ref_pos[u] - seg_begin;
                 if (ins_off[u] == 0 && dc_plane >= 0 && hpi >= 0 && off >= 0 && off < seg_len) {
-                    const int64_t run = kPlain ? (int64_t)dc_plane * 2 + rev : ((int64_t)(dc_plane * p.n_hp + hpi) * 2 + rev);
-                    unsigned long long* dst = p.counters + run * p.plane_len + cnt_base + off;
-                    atomicAdd(dst, is_mod ? 0x100000001ull : 1ull);
+                    atomicAdd(counter_word(p, p.codes[ci], kPlain ? 0 : hpi, rev, tid, ref_base + ref_pos[u]), is_mod ? 0x100000001ull : 1ull);
                     st_dense++;
                 } else {
                     side_append((int32_t)ref_pos[u], ins_off[u], is_mod, ci);

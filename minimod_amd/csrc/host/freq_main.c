@@ -287,7 +287,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     int wildcard = 0, star_ctx = 0;
     for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
-    const int replay = !view && !o.canonical_order && !ws->sharded && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
+    int replay = !view && !o.canonical_order && !ws->sharded && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
+    if (replay && o.K >= (1 << 21)) {   /* (the rows the replay works from number a batch's reads with 21 bits) */
+        MMH_WARNING("%s", "-K of 2097152 or more: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype (the order of minimod's hash table is replayed for smaller batches)");
+        replay = 0;
+    }
     mm_freq_t *hv = NULL;      /* the second handle of a replay run: the same batches in view mode (rows with group ordinals) */
     mmh_tie_t *tie = NULL;
     if (replay) {

@@ -329,8 +329,7 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
         const int multi = has_multi_letter_group(mm, rd->mm_len);
         for (int64_t i = a; i < b; i++) {
             const mm_view_row_t *w = &j->rows[i];
-            const uint32_t implicit = w->read_pos >> 31, gord = w->read >> 24;
-            if (gord >= 255u) j->failed = 1;
+            const uint32_t implicit = w->read_pos >> 31, gord = w->read >> 21;
             if (w->code >= j->n_codes) { j->failed = 1; continue; }
             if (!implicit && j->klass[w->code][w->prob] == 0) continue;   /* ambiguous: never reaches the table (src/mod.c:1180-1191) */
             ord[n].gord = gord; ord[n].implicit = implicit; ord[n].fq = w->read_pos & 0x7FFFFFFFu; ord[n].m = 0; ord[n].row = (uint32_t)(i - a);
@@ -391,7 +390,7 @@ int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, co
     if (!first || !ok || !oh || !on) { free(first); free(ok); free(oh); free(on); t->failed = 1; return -1; }
     int64_t i = 0;
     for (int32_t r = 0; r <= nr; r++) {   /* rows come sorted by read */
-        while (i < n && (int32_t)(rows[i].read & 0xFFFFFFu) < r) i++;
+        while (i < n && (int32_t)(rows[i].read & 0x1FFFFFu) < r) i++;
         first[r] = i;
     }
     first[nr] = n;

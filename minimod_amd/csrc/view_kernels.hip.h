@@ -126,12 +126,14 @@ __device__ __forceinline__ void view_bitonic(Ptr K, Ptr V, uint32_t n, uint32_t 
 }
 
 // opts.view == 2 (rows for the tie-order replay of the host, csrc/host/tieorder.c): a row also says in which MM group the
-// call was made (its ordinal, at most 255, in the top byte of `read`) and whether it was an implicit call of a '.' group
-// (bit 31 of read_pos): with the position in the read as sequenced that is the order the reference met the calls in.
+// call was made (its ordinal, at most kViewMaxGroup = 2047, in the top eleven bits of `read`: a batch of such a handle has
+// fewer than 2^21 reads) and whether it was an implicit call of a '.' group (bit 31 of read_pos): with the position in the
+// read as sequenced that is the order the reference met the calls in.  Later entries of a key are KEPT there (the replay
+// wants every call: update_freq_map may meet a key whose first entry was ambiguous, src/mod.c:886-904).
 __device__ __forceinline__ uint32_t view_read_word(uint32_t r, unsigned long long v, uint32_t ordinal) {
     if (!ordinal) return r;
     const uint32_t g = (uint32_t)((v >> 29) & 0x7FFull);
-    return r | ((g < 255u ? g : 255u) << 24);
+    return r | (g << 21);
 }
 __device__ __forceinline__ uint32_t view_read_pos_word(unsigned long long v, uint32_t ordinal) {
     const uint32_t q = (uint32_t)(v & 0x0FFFFFFFull);
@@ -146,7 +148,7 @@ __device__ __forceinline__ uint32_t view_emit_rows(Ptr K, Ptr V, uint32_t n, uin
     for (uint32_t i = tid; i < n; i += kThreads) {
         unsigned long long k = K[i], v = V[i];
         bool dup = false;
-        if (i > 0) {
+        if (i > 0 && !ordinal) {
             unsigned long long kp = K[i - 1], vp = V[i - 1];
             dup = ((uint32_t)kp & 0x0FFFFFFFu) == ((uint32_t)k & 0x0FFFFFFFu) && (vp >> 40) == (v >> 40);
         }
@@ -201,12 +203,12 @@ __device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P,
     uint32_t dropped = 0;
     for (uint32_t i = tid; i < n; i += kThreads) {
         const unsigned long long pi = P[i];
-        const bool head = i == 0 || (P[i - 1] >> 12) != (pi >> 12);
+        const bool head = ordinal || i == 0 || (P[i - 1] >> 12) != (pi >> 12);
         ViewRow o;
         if (head) {
             uint32_t best = (uint32_t)(pi & 0xFFFull);
             unsigned long long bv = gv[best];
-            for (uint32_t j = i + 1; j < n && (P[j] >> 12) == (pi >> 12); j++) {   // other entries of the same key: rare, short
+            for (uint32_t j = i + 1; !ordinal && j < n && (P[j] >> 12) == (pi >> 12); j++) {   // other entries of the same key: rare, short
                 uint32_t cand = (uint32_t)(P[j] & 0xFFFull);
                 unsigned long long cv = gv[cand];
                 if (cv < bv) { bv = cv; best = cand; }

@@ -84,7 +84,7 @@ def test_host_batches_gathered_into_launches(stream_mode):
         assert len(set(res[kw + ":one_group"]["tickets"])) == 1 and res[kw + ":one_group"]["launches"]["launches"] == 1
         assert 1 < res[kw + ":small_staging"]["launches"]["launches"] < 7     # the staging budget, not the count, ended the groups
     if stream_mode == 2:
-        assert res["plain:one_group"]["launches"]["stream_launches"] == 1 and res["ins_hap:one_group"]["launches"]["stream_launches"] == 0
+        assert res["plain:one_group"]["launches"]["stream_launches"] == 1 and res["ins_hap:one_group"]["launches"]["stream_launches"] == 1   # (--insertions / --haplotypes stream too: the kIns instantiation)
     assert res["scribbled"]
     assert res["error"] == [1, 300 + 300 + 17 + 150, True, 1]
 

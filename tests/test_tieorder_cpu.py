@@ -68,7 +68,7 @@ def replay_order(bam_path, contigs, c="m", m=None, insertions=False, haplotypes=
         # what the device delivers for the batch: rows by read, then position (the replay puts them back into call order)
         rows = np.zeros(len(v), dtype=VIEW_ROW_DTYPE)
         first_read = batch_first[0]      # the oracle numbers reads over all batches, the device inside the batch
-        rows["read"] = (v["read"] - first_read).astype(np.uint32) | (((v["prob"] >> 8) & 0xFF).astype(np.uint32) << 24)
+        rows["read"] = (v["read"] - first_read).astype(np.uint32) | (((v["prob"] >> 8) & 0xFF).astype(np.uint32) << 21)
         rows["pos"], rows["ins_offset"], rows["code"] = v["pos"], v["ins_off"], v["code"]
         rows["read_pos"] = v["read_pos"].astype(np.uint32) | (v["prob"] & 0x80000000).astype(np.uint32)
         rows["prob"] = (v["prob"] & 0xFF).astype(np.uint8)

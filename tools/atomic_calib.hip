@@ -7,6 +7,10 @@
 //               next round continues behind it; reads start anywhere in a 50 Mb plane
 //   c2_deep     the same with the reads confined to 1 Mb (1000x depth: the same lines hit again and again)
 //   side        C5's side table: a CAS on a random 16-byte slot followed by an add on the slot's second word
+//   pairs / quads / octs   lanes 2k and 2k+1 (4k..4k+3, 8k..8k+7) add to ADJACENT 8-byte words of one random 64-byte line: do the
+//               lanes of one instruction that fall into one line leave as ONE request?  (two codes counted at one site, if
+//               their counters lie side by side)
+//   pair_2instr the same two adjacent words from ONE lane in two instructions back to back
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -o tools/bin/atomic_calib tools/atomic_calib.hip ; prints one JSON line.
 #include <hip/hip_runtime.h>
@@ -34,6 +38,14 @@ __global__ void k_atomics(unsigned long long* plane, uint64_t plane_len, uint64_
             // a site every ~100 positions with a jitter, 64 sites a round
             const uint64_t p = start + (uint64_t)r * 6400 + (uint64_t)lane * 100 + (mix(wave * 977 + r * 64 + lane) & 63);
             idx = strand * plane_len + (p < plane_len ? p : p % plane_len);
+        } else if (mode >= 3 && mode <= 5) {
+            const int g = mode == 3 ? 2 : (mode == 4 ? 4 : 8);
+            idx = (mix(seed ^ (wave * 64 + lane / g) * 0x9E3779B97F4A7C15ull + r) % (2 * plane_len / 8)) * 8 + (lane % g);
+        } else if (mode == 6) {
+            idx = (mix(seed ^ (wave * 64 + lane) * 0x9E3779B97F4A7C15ull + r) % (2 * plane_len / 8)) * 8;
+            atomicAdd(plane + idx, 1ull);
+            atomicAdd(plane + idx + 1, 0x100000001ull);
+            continue;
         } else {
             idx = (mix(seed ^ (wave * 64 + lane) * 0x9E3779B97F4A7C15ull + r) % plane_len) * 2;   // a 16-byte slot
             unsigned long long key = idx | 1ull;
@@ -56,7 +68,8 @@ int main() {
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     struct Case { const char* name; int mode; uint64_t region; } cases[] = {
-        {"random", 0, plane_len}, {"c2", 1, plane_len - 300000}, {"c2_deep", 1, 1u << 20}, {"side_cas_plus_add", 2, plane_len}};
+        {"random", 0, plane_len}, {"c2", 1, plane_len - 300000}, {"c2_deep", 1, 1u << 20}, {"side_cas_plus_add", 2, plane_len},
+        {"pairs", 3, plane_len}, {"quads", 4, plane_len}, {"octs", 5, plane_len}, {"pair_2instr", 6, plane_len}};
     std::printf("{\"device\": \"%s\", \"cus\": %d, \"waves\": %d, \"rounds\": %d", prop.name, prop.multiProcessorCount, blocks * 4, rounds);
     for (const Case& c : cases) {
         float best = 1e30f;
@@ -69,7 +82,7 @@ int main() {
             CHK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 0 && ms < best) best = ms;
         }
-        const double n = (double)blocks * 256 * rounds;
+        const double n = (double)blocks * 256 * rounds * (c.mode == 6 ? 2 : 1);
         std::printf(", \"%s\": {\"updates\": %.0f, \"ms\": %.4f, \"G_updates_per_s\": %.2f}", c.name, n, best, n / (best * 1e-3) / 1e9);
     }
     std::printf("}\n");
