@@ -550,11 +550,14 @@ def main():
     slab_words = eng.slab_words(slab_len)
 
     def make_buf():
-        return torch.zeros(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
+        t = torch.zeros(slab_words, dtype=torch.int64, device="cpu" if host_staged else dev)
+        torch.cuda.synchronize()   # (the fill runs on torch's current stream, the slab kernels on `stream`: not ordered otherwise)
+        return t
 
     def export_fn(buf):
         tid, pos, ln = plan["send"]
         dbuf = torch.zeros(slab_words, dtype=torch.int64, device=dev) if host_staged else buf
+        torch.cuda.synchronize()
         eng.slab_export(tid, pos, ln, dbuf.data_ptr(), stream)
         eng.slab_clear(tid, pos, ln, stream)
         tstream.synchronize()          # the slab must be complete before RCCL (another stream) reads it

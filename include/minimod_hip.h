@@ -254,6 +254,10 @@ int64_t mm_freq_slab_words(const mm_freq_t *h, int64_t len);
 int32_t mm_freq_slab_export(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *dst_dev, void *hip_stream);
 int32_t mm_freq_slab_add(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *src_dev, void *hip_stream);
 int32_t mm_freq_slab_clear(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *hip_stream);
+/* the same through HOST memory (mm_freq_slab_words(h, len) words), for callers that have no device buffers of their own:
+ * the workers of `minimod freq --devices` pass a slab from process to process */
+int32_t mm_freq_slab_export_host(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *dst_host);
+int32_t mm_freq_slab_add_host(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *src_host);
 
 /* Measurement hook (bench.py): device time of a ticket's hot-path kernels in milliseconds (HIP events recorded on the
  * launch stream around them). */

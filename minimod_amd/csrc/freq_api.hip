@@ -135,7 +135,11 @@ struct mm_freq {
     int64_t side_cap = 0;
     // the side table: updates that do not fit the dense planes, counted per 64-bit key (side_insert); [0] occupied slots
     unsigned long long *d_stab = nullptr, *d_scount = nullptr;
-    unsigned long long stab_slots = 0;
+    unsigned long long stab_slots = 0;     // records per region of the side lists
+    unsigned int* d_scur = nullptr;        // the regions' cursors
+    unsigned long long *d_base_k = nullptr, *d_base_v = nullptr; size_t n_base = 0, cap_base = 0;   // what earlier compactions left: unique keys, ordered
+    bool side_possible = false;            // this handle's runs can produce side updates at all
+    unsigned int launches_since_side_check = 0;
     unsigned long long *d_sort_k[2] = {nullptr, nullptr}, *d_sort_v[2] = {nullptr, nullptr}; size_t cap_sort = 0;
     uint32_t* d_sort_hist = nullptr; size_t cap_sort_hist = 0;
     unsigned long long* d_stats = nullptr;
@@ -191,22 +195,98 @@ int grow(mm_freq* h, void** p, size_t* cap, size_t need) {
     return 0;
 }
 
-// every slot free: key words all ones, count words zero
+// all regions empty, nothing compacted
 int side_table_clear(mm_freq* h) {
-    hipLaunchKernelGGL(k_side_clear, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, 1u << 16)), dim3(256), 0, 0, h->d_stab, h->stab_slots);
-    if (hipGetLastError() != hipSuccess || hipMemset(h->d_scount, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -MM_E_HIP;
+    if (hipMemset(h->d_scur, 0, sizeof(unsigned int) * kSideRegions * kSideCurStride) != hipSuccess) return -MM_E_HIP;
+    h->n_base = 0;
     return 0;
 }
 
-// occupied slots of the side table (a scan of the table: finalize only)
-int side_table_count(mm_freq* h, unsigned long long* n) {
-    HIPCHK(hipMemsetAsync(h->d_scount, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_side_count, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, (unsigned long long)h->n_cu * 16)), dim3(256), 0,
-                       h->stream, h->d_stab, h->stab_slots, h->d_scount);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(n, h->d_scount, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+int ensure_sort_buffers(mm_freq* h, size_t n) {
+    if (n > h->cap_sort) {
+        for (int i = 0; i < 2; i++) { if (h->d_sort_k[i]) (void)hipFree(h->d_sort_k[i]); if (h->d_sort_v[i]) (void)hipFree(h->d_sort_v[i]); h->d_sort_k[i] = h->d_sort_v[i] = nullptr; }
+        h->cap_sort = 0;
+        size_t cap = n + n / 8 + 1024;
+        for (int i = 0; i < 2; i++)
+            if (dev_alloc(h, (void**)&h->d_sort_k[i], 8 * cap) || dev_alloc(h, (void**)&h->d_sort_v[i], 8 * cap)) return -MM_E_NOMEM;
+        h->cap_sort = cap;
+    }
+    const size_t nblk = (n + kSortTile - 1) / kSortTile;
+    if (256 * nblk + 256 > h->cap_sort_hist) {
+        if (h->d_sort_hist) (void)hipFree(h->d_sort_hist);
+        h->d_sort_hist = nullptr; h->cap_sort_hist = 0;
+        if (dev_alloc(h, (void**)&h->d_sort_hist, 4 * (256 * nblk + 1024))) return -MM_E_NOMEM;
+        h->cap_sort_hist = 256 * nblk + 1024;
+    }
     return 0;
+}
+
+// The side lists compacted (every launch complete): the regions' records and what the last compaction left are gathered,
+// ordered by key and reduced to one (key, counts) pair per key -- the new base, ordered; the regions are empty again.
+// `fills` (optional): the regions' cursors as just read, to spare the copy.
+int side_compact(mm_freq* h) {
+    std::vector<unsigned int> cur(kSideRegions * kSideCurStride);
+    HIPCHK(hipMemcpy(cur.data(), h->d_scur, sizeof(unsigned int) * cur.size(), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> off(kSideRegions + 1, 0);
+    for (uint32_t r = 0; r < kSideRegions; r++) {
+        if ((unsigned long long)cur[r * kSideCurStride] > h->stab_slots) return -MM_E_SIDEFULL;   // the region refused updates
+        off[r + 1] = off[r] + cur[r * kSideCurStride];
+    }
+    const size_t n_new = (size_t)off[kSideRegions], n = n_new + h->n_base;
+    if (n_new == 0) return 0;
+    { int r = ensure_sort_buffers(h, n); if (r) return r; }
+    unsigned long long* d_off = nullptr;
+    if (hipMalloc((void**)&d_off, 8 * off.size()) != hipSuccess) return -MM_E_NOMEM;
+    int result = 0;
+    do {
+        if (hipMemcpyAsync(d_off, off.data(), 8 * off.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+        hipLaunchKernelGGL(k_side_gather, dim3((unsigned)std::max(1, h->n_cu / 4), kSideRegions), dim3(256), 0, h->stream, h->d_stab, h->stab_slots, d_off, h->d_sort_k[0], h->d_sort_v[0]);
+        if (h->n_base) {
+            if (hipMemcpyAsync(h->d_sort_k[0] + n_new, h->d_base_k, 8 * h->n_base, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(h->d_sort_v[0] + n_new, h->d_base_v, 8 * h->n_base, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+        }
+        const uint32_t nblk = (uint32_t)((n + kSortTile - 1) / kSortTile);
+        int cb = 0;
+        for (int shift = 0; shift < 64; shift += 8) {   // LSD radix sort on the whole key (63 bits used)
+            hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cb], (unsigned long long)n, shift, h->d_sort_hist, nblk);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, h->d_sort_hist, (unsigned long long)256 * nblk);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cb], h->d_sort_v[cb], (unsigned long long)n, shift, h->d_sort_hist, nblk,
+                               h->d_sort_k[cb ^ 1], h->d_sort_v[cb ^ 1]);
+            cb ^= 1;
+        }
+        // one pair per key
+        const uint32_t ntile = (uint32_t)((n + kReduceTile - 1) / kReduceTile);
+        if (hipMemsetAsync(h->d_sort_hist + ntile, 0, 4, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+        hipLaunchKernelGGL(k_reduce_count, dim3(ntile), dim3(256), 0, h->stream, h->d_sort_k[cb], (unsigned long long)n, h->d_sort_hist);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, h->d_sort_hist, (unsigned long long)ntile + 1ull);
+        uint32_t n_unique = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&n_unique, h->d_sort_hist + ntile, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+        if ((size_t)n_unique > h->cap_base) {
+            if (h->d_base_k) { (void)hipFree(h->d_base_k); (void)hipFree(h->d_base_v); h->device_bytes -= (int64_t)(16 * h->cap_base); }
+            h->d_base_k = h->d_base_v = nullptr; h->cap_base = 0;
+            const size_t cap = (size_t)n_unique + (size_t)n_unique / 4 + 1024;
+            if (dev_alloc(h, (void**)&h->d_base_k, 8 * cap) || dev_alloc(h, (void**)&h->d_base_v, 8 * cap)) { result = -MM_E_NOMEM; break; }
+            h->cap_base = cap;
+        }
+        hipLaunchKernelGGL(k_reduce_emit, dim3(ntile), dim3(256), 0, h->stream, h->d_sort_k[cb], h->d_sort_v[cb], (unsigned long long)n, h->d_sort_hist, h->d_base_k, h->d_base_v);
+        if (hipGetLastError() != hipSuccess || hipMemsetAsync(h->d_scur, 0, sizeof(unsigned int) * kSideRegions * kSideCurStride, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+        h->n_base = n_unique;
+    } while (0);
+    (void)hipFree(d_off);
+    return result;
+}
+
+// a launch has completed: should the side lists be compacted before the next one?  (runs that can fill them only; the regions'
+// cursors are 8 KB to look at)
+int side_check(mm_freq* h) {
+    if (!h->side_possible) return 0;
+    std::vector<unsigned int> cur(kSideRegions * kSideCurStride);
+    HIPCHK(hipMemcpy(cur.data(), h->d_scur, sizeof(unsigned int) * cur.size(), hipMemcpyDeviceToHost));
+    unsigned long long worst = 0;
+    for (uint32_t r = 0; r < kSideRegions; r++) worst = std::max<unsigned long long>(worst, cur[r * kSideCurStride]);
+    return worst > h->stab_slots / 2 ? 1 : 0;
 }
 
 int complement(int c) {
@@ -237,7 +317,7 @@ DevParams base_params(mm_freq* h) {
     p.insertions = h->opts.insertions; p.haplotypes = h->opts.haplotypes; p.wildcard = h->wildcard >= 0;
     p.mods = h->d_mods; p.codes = h->d_codes;
     p.side = h->d_side; p.side_count = h->d_side_count; p.side_cap = (unsigned long long)h->side_cap;
-    p.stab = h->d_stab; p.smask = h->stab_slots ? h->stab_slots - 1 : 0;
+    p.stab = h->d_stab; p.smask = h->stab_slots; p.scur = h->d_scur;
     p.stats = h->stats_on ? h->d_stats : nullptr;
 #ifdef MM_STREAM_TIMING
     p.stats = h->d_stats;   // diagnostic build: phase times of every launch (mm_freq_stats_get reads and clears them)
@@ -541,6 +621,19 @@ int settle(mm_freq* h) {
 
 int slot_status(mm_freq* h, Slot& s, int32_t* bad_read);
 
+int drain(mm_freq* h);
+// before a launch: when the side lists are filling up (looked at every few launches; the look waits for the launches under
+// way), everything is brought to an end and the lists are compacted
+int side_room(mm_freq* h) {
+    if (!h->side_possible || (++h->launches_since_side_check & 3u) != 0u) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    const int need = side_check(h);
+    if (need < 0) return need;
+    if (!need) return 0;
+    { int r = drain(h); if (r) return r; }
+    return side_compact(h);
+}
+
 // launch the gathered group, if there is one
 int flush_pending(mm_freq* h) {
     if (h->pending_slot < 0) return 0;
@@ -656,7 +749,7 @@ void mm_freq_destroy(mm_freq_t* h) {
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
-                  h->d_stab, h->d_scount, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
+                  h->d_stab, h->d_scount, h->d_scur, h->d_base_k, h->d_base_v, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (void* p : h->d_site_arrays) if (p) (void)hipFree(p);
     if (h->d_classes) (void)hipFree(h->d_classes);
@@ -780,16 +873,17 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         }
     }
     h->n_hp = opts->haplotypes ? (opts->n_hp_planes > 0 ? std::min(opts->n_hp_planes, MM_MAX_HP_PLANES) : 4) : 1;
-    // opts.side_capacity sizes the side TABLE (slots of 16 bytes, rounded up to a power of two; it should stay under ~70 % full);
-    // the list behind it only takes what has no 64-bit key (haplotype tags above 29, positions past 2^35)
+    // opts.side_capacity sizes the side LISTS (records of 16 bytes in all, shared out to kSideRegions regions; when a region is half
+    // full the lists are compacted to one record per key); the list behind them only takes what has no 64-bit key (haplotype
+    // tags above 29, positions past 2^35)
     h->side_cap = opts->view ? 16 : (int64_t)(1 << 16);
     {
-        unsigned long long want = opts->view ? 16ull : (unsigned long long)(opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(4 << 20));
-        unsigned long long slots = 16;
-        while (slots < want) slots <<= 1;
-        h->stab_slots = slots;
-        if (dev_alloc(h, (void**)&h->d_stab, 16 * (size_t)slots) || dev_alloc(h, (void**)&h->d_scount, 8)) return fail(h, "side table alloc failed");
-        if (side_table_clear(h) != 0) return fail(h, "side table init failed");
+        unsigned long long want = opts->view ? 1024ull : (unsigned long long)(opts->side_capacity > 0 ? opts->side_capacity : (int64_t)(16 << 20));
+        h->stab_slots = std::max<unsigned long long>((want + kSideRegions - 1) / kSideRegions, 16ull);
+        if (dev_alloc(h, (void**)&h->d_stab, 16 * (size_t)h->stab_slots * kSideRegions) || dev_alloc(h, (void**)&h->d_scount, 8) ||
+            dev_alloc(h, (void**)&h->d_scur, sizeof(unsigned int) * kSideRegions * kSideCurStride)) return fail(h, "side list alloc failed");
+        if (side_table_clear(h) != 0) return fail(h, "side list init failed");
+        h->side_possible = !opts->view && (opts->insertions || opts->haplotypes || h->wildcard >= 0 || n_intervals > 0);
     }
     if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
@@ -850,7 +944,9 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     }
     const size_t ref_bytes = h->ref_kind == 0 ? (size_t)std::max<int64_t>(ref_total, 64) / 2 : (size_t)std::max<int64_t>(ref_total, 64) * (h->ref_kind == 2 ? 4 : 2);
     if (dev_alloc(h, &h->d_refw, ref_bytes)) return fail(h, "reference alloc failed");
-    (void)hipMemset(h->d_refw, 0, ref_bytes);   // (the padding behind every contig: no sites there)
+    // (the padding behind every contig: no sites there.  On the stream the context kernels run on: a plain hipMemset is not
+    // ordered with a non-blocking stream and could land on top of their words)
+    if (hipMemsetAsync(h->d_refw, 0, ref_bytes, h->stream) != hipSuccess) return fail(h, "reference memset failed");
     size_t tb = sizeof(int64_t) * (size_t)std::max(n_contigs, 1);
     if (dev_alloc(h, (void**)&h->d_ref_base, tb) || dev_alloc(h, (void**)&h->d_ctg_len, tb) || dev_alloc(h, (void**)&h->d_seg_begin, tb) ||
         dev_alloc(h, (void**)&h->d_seg_len, tb) || dev_alloc(h, (void**)&h->d_cnt_base, tb)) return fail(h, "alloc failed");
@@ -1042,6 +1138,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     if (h->opts.view == 2 && b->n_reads >= (1 << 21)) return -MM_E_ARG;
+    { int rs = side_room(h); if (rs) return rs; }
     h->n_submits++; h->n_reads_submitted += (uint64_t)b->n_reads;
     const bool gather = h->opts.coalesce > 1 && h->use_tiles && !b->order && b->n_reads > 0;   // (view too: a ticket's rows are then those of the group, `read` counted from its first read)
     if (gather && h->pending_slot >= 0 && !h->pending_host && !h->codes_dirty) {   // (a code interned since the group began: the table is uploaded before a launch's FIRST window, so the group ends here)
@@ -1163,6 +1260,7 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     if (!h || !hb || hb->n_reads < 0 || hb->n_reads >= (1 << 24) || hb->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     if (h->opts.view == 2 && hb->n_reads >= (1 << 21)) return -MM_E_ARG;   // (the group ordinal shares mm_view_row_t.read with the read's index)
+    { int rs = side_room(h); if (rs) return rs; }
     h->n_submits++; h->n_reads_submitted += (uint64_t)hb->n_reads;
     if (h->opts.coalesce > 1 && h->use_tiles && !hb->order && hb->n_reads > 0) return submit_host_gathered(h, hb);
     { int rf = flush_pending(h); if (rf) return rf; }
@@ -1244,6 +1342,7 @@ int32_t mm_freq_stats_get(mm_freq_t* h, uint64_t out[16]) {
     std::vector<unsigned long long> all(16 + 4 * (size_t)kStatSlots);
     HIPCHK(hipMemcpy(all.data(), h->d_stats, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stats, 0, all.size() * sizeof(unsigned long long)));
+    HIPCHK(hipDeviceSynchronize());   // (launches go to non-blocking streams: not ordered behind a plain memset)
     for (int i = 0; i < 16; i++) out[i] = all[i];
     for (int i = 0; i < 4; i++) out[i] = 0;
     for (size_t w = 0; w < kStatSlots; w++) for (int i = 0; i < 4; i++) out[i] += all[16 + 4 * w + i];
@@ -1346,10 +1445,10 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     n_dense = rows.size();
     // every row a dense one (no haplotype planes, nothing on the side table or list): done
     if (!h->opts.haplotypes && !h->opts.finalize_by_runs) {
-        unsigned long long ns0 = 0, nt0 = 0;
+        unsigned long long ns0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
-        { int rc = side_table_count(h, &nt0); if (rc) return rc; }
-        if (ns0 == 0 && nt0 == 0) {
+        { int rc = side_compact(h); if (rc) return rc; }
+        if (ns0 == 0 && h->n_base == 0) {
             if (overflowed()) return -MM_E_OVERFLOW;
             if (out_rows) *out_rows = rows.data();
             return (int64_t)rows.size();
@@ -1358,45 +1457,13 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     // ---- side table (K3): unique keys with their counts, compacted and ordered on the device
     size_t n_side_sorted = 0;   // rows.size() up to which the side rows are known to be in output order
     {
-        unsigned long long nu = 0;
-        { int rc = side_table_count(h, &nu); if (rc) return rc; }
-        if (nu > h->stab_slots - h->stab_slots / 8) return -MM_E_SIDEFULL;   // beyond 7/8 full the table may have refused updates
+        { int rc = side_compact(h); if (rc) return rc; }
+        const unsigned long long nu = h->n_base;
         if (nu) {
-            if ((size_t)nu > h->cap_sort) {
-                for (int i = 0; i < 2; i++) { if (h->d_sort_k[i]) (void)hipFree(h->d_sort_k[i]); if (h->d_sort_v[i]) (void)hipFree(h->d_sort_v[i]); h->d_sort_k[i] = h->d_sort_v[i] = nullptr; }
-                h->cap_sort = 0;
-                size_t cap = (size_t)nu + (size_t)nu / 8 + 1024;
-                for (int i = 0; i < 2; i++)
-                    if (dev_alloc(h, (void**)&h->d_sort_k[i], 8 * cap) || dev_alloc(h, (void**)&h->d_sort_v[i], 8 * cap)) return -MM_E_NOMEM;
-                h->cap_sort = cap;
-            }
-            const uint32_t nblk = (uint32_t)((nu + kSortTile - 1) / kSortTile);
-            if ((size_t)256 * nblk > h->cap_sort_hist) {
-                if (h->d_sort_hist) (void)hipFree(h->d_sort_hist);
-                h->d_sort_hist = nullptr; h->cap_sort_hist = 0;
-                if (dev_alloc(h, (void**)&h->d_sort_hist, 4 * ((size_t)256 * nblk + 256))) return -MM_E_NOMEM;
-                h->cap_sort_hist = (size_t)256 * nblk + 256;
-            }
-            unsigned long long* d_cnt = h->d_tile_offsets;   // any 8 device bytes: the compaction cursor
-            unsigned long long* tmp_cnt = nullptr;
-            if (!d_cnt) { if (dev_alloc(h, (void**)&tmp_cnt, 8)) return -MM_E_NOMEM; d_cnt = tmp_cnt; }
-            HIPCHK(hipMemsetAsync(d_cnt, 0, 8, h->stream));
-            hipLaunchKernelGGL(k_side_compact, dim3((unsigned)std::min<unsigned long long>((h->stab_slots + 255) / 256, (unsigned long long)h->n_cu * 16)), dim3(256), 0,
-                               h->stream, h->d_stab, h->stab_slots, h->d_sort_k[0], h->d_sort_v[0], d_cnt);
-            int cur = 0;
-            for (int shift = 0; shift < 64; shift += 8) {   // LSD radix sort on the whole key (63 bits used)
-                hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cur], nu, shift, h->d_sort_hist, nblk);
-                hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, h->d_sort_hist, (unsigned long long)256 * nblk);
-                hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, h->stream, h->d_sort_k[cur], h->d_sort_v[cur], nu, shift, h->d_sort_hist, nblk,
-                                   h->d_sort_k[cur ^ 1], h->d_sort_v[cur ^ 1]);
-                cur ^= 1;
-            }
-            HIPCHK(hipGetLastError());
             std::vector<unsigned long long> sk((size_t)nu), sv((size_t)nu);
-            HIPCHK(hipMemcpyAsync(sk.data(), h->d_sort_k[cur], 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(sv.data(), h->d_sort_v[cur], 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(sk.data(), h->d_base_k, 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(sv.data(), h->d_base_v, 8 * (size_t)nu, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (tmp_cnt) { (void)hipFree(tmp_cnt); h->device_bytes -= 16; }
             // keys are ordered by (position in the reference-word space, strand, code, ins_offset, haplotype): inside a contig
             // that is the output order; the contigs' runs are put in name order
             std::vector<int> seq_tids;
@@ -1607,5 +1674,29 @@ static int slab_op(mm_freq_t* h, int op, int32_t tid, int64_t begin, int64_t len
 int32_t mm_freq_slab_export(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* dst, void* st) { return slab_op(h, 0, tid, begin, len, dst, st); }
 int32_t mm_freq_slab_add(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src, void* st) { return slab_op(h, 1, tid, begin, len, const_cast<void*>(src), st); }
 int32_t mm_freq_slab_clear(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* st) { return slab_op(h, 2, tid, begin, len, nullptr, st); }
+int32_t mm_freq_slab_export_host(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* dst_host) {
+    if (!h || !dst_host || len < 0) return -MM_E_ARG;
+    const size_t bytes = 8 * (size_t)mm_freq_slab_words(h, len);
+    if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
+    int r = slab_op(h, 0, tid, begin, len, d, nullptr);
+    if (!r && hipMemcpy(dst_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) r = -MM_E_HIP;
+    (void)hipFree(d);
+    return r;
+}
+int32_t mm_freq_slab_add_host(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src_host) {
+    if (!h || !src_host || len < 0) return -MM_E_ARG;
+    const size_t bytes = 8 * (size_t)mm_freq_slab_words(h, len);
+    if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
+    int r = hipMemcpy(d, src_host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -MM_E_HIP;
+    if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
+    (void)hipFree(d);
+    return r;
+}
 
 }  // extern "C"

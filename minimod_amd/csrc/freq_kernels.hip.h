@@ -125,10 +125,10 @@ struct DevParams {
     unsigned long long* side_count;
     unsigned long long side_cap;
     // updates that do not fit the dense planes (inside an insertion, haplotype or code without a plane, outside the shard)
-    // are counted in a hash table on one 64-bit key: side_insert below
-    unsigned long long* stab;      // slots of 16 bytes: [2i] key (kSideEmpty = free), [2i + 1] n_called | n_mod << 32 like a dense counter
-                                   // (key and counts share a cache line: one random line per update)
-    unsigned long long smask;      // slots - 1 (a power of two)
+    // are appended to lists as (64-bit key, increment) records: side_insert above
+    unsigned long long* stab;      // kSideRegions lists of `smask` records of 16 bytes: key, n_called | n_mod << 32 like a dense counter
+    unsigned long long smask;      // records per region
+    unsigned int* scur;            // [kSideRegions * kSideCurStride] records appended to each region (more than smask: it ran full)
     unsigned long long* stats;     // optional: [0..15] diagnostic timers, then kStatSlots rows of {reference-word lookups, ML bytes
                                    // read, dense updates, side updates}, one row per wave slot (summed by the host)
     // scheduling / scratch
@@ -166,22 +166,26 @@ __device__ __forceinline__ bool side_key(int64_t rpos, int rev, int code, uint32
           ((unsigned long long)(ins & 0xFFFFu) << 5) | h5;
     return true;
 }
-__device__ __forceinline__ unsigned long long side_mix(unsigned long long x) {
-    x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-    return x;
-}
-// one counter update on the table: claim or find the key's slot (linear probing), then the same packed 64-bit add as a
-// dense counter.  Returns 0, or MM_E_SIDEFULL when every slot is taken by another key.
-__device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long mask, unsigned long long key, unsigned long long inc) {
-    unsigned long long h = side_mix(key) & mask;
-    for (unsigned long long probes = 0; probes <= mask; probes++) {
-        unsigned long long old = tab[2 * h];
-        if (old == kSideEmpty) old = atomicCAS(tab + 2 * h, kSideEmpty, key);   // (occupied slots are counted at finalize: a shared
-                                                                                 // counter here would be the one address every insert hits)
-        if (old == kSideEmpty || old == key) { atomicAdd(tab + 2 * h + 1, inc); return 0; }
-        h = (h + 1ull) & mask;
-    }
-    return MM_E_SIDEFULL;
+// One counter update that has no dense counter: a 16-byte record (key, packed {n_called, n_mod} increment) appended to one of
+// kSideRegions lists -- the lanes of a wave instruction that have one reserve their records with ONE atomic on the region's
+// cursor and store them side by side (plain stores of whole lines run several times the rate of scattered atomics, and a
+// hash table costs two of those per update: a CAS on the key and an add).  Equal keys are added up when the lists are
+// compacted: sorted by key and reduced (sort_kernels.hip.h), at finalize or when a region runs full.  Returns 0, or
+// MM_E_SIDEFULL when the region has no room left.
+constexpr uint32_t kSideRegions = 64;
+constexpr uint32_t kSideCurStride = 32;   // cursors 128 bytes apart
+__device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long cap_r, unsigned int* cur, unsigned long long key, unsigned long long inc) {
+    const uint32_t region = ((uint32_t)blockIdx.x * 4u + ((uint32_t)threadIdx.x >> 6)) & (kSideRegions - 1u);
+    const uint64_t m = __ballot(1);
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cur + region * kSideCurStride, (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, leader, 64);
+    const unsigned long long idx = (unsigned long long)base + (unsigned long long)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    if (idx >= cap_r) return MM_E_SIDEFULL;
+    ulonglong2 rec; rec.x = key; rec.y = inc;
+    *reinterpret_cast<ulonglong2*>(tab + 2ull * ((unsigned long long)region * cap_r + idx)) = rec;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------- wave primitives
@@ -598,7 +602,7 @@ struct K1 {
     __device__ __forceinline__ void side_append(int32_t pos, uint32_t ins_off, int is_mod, int code) {
         unsigned long long key;
         if (side_key(c.ref_base + pos, c.rev, code, ins_off, c.hp, key)) {
-            if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

@@ -474,7 +474,7 @@ struct KF {
         const int hpk = kIns ? hp : -1;
         unsigned long long key;
         if (side_key(ref_base + spos, rev, code, ins_off, hpk, key)) {
-            if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

@@ -1123,7 +1123,7 @@ struct KC {
     __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
         unsigned long long key;
         if (side_key(ref_base + spos, rev, code, ins_off, hp, key)) {
-            if (side_insert(p.stab, p.smask, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
             return;
         }
         uint64_t m = __ballot(1);

@@ -55,6 +55,7 @@ static struct option view_long_options[] = {
     {"include-non-ref", no_argument, 0, 0},
     {"skip-supplementary", no_argument, 0, 0},
     {"device", required_argument, 0, 0},
+    {"devices", required_argument, 0, 0},
     {0, 0, 0, 0}};
 
 typedef struct {
@@ -70,17 +71,25 @@ typedef struct {
                                                * the cut: spliced or ultra-long) go to the side table, which takes any position */
 #define MMH_SHARE_ALIGN ((int64_t)1 << 16)
 typedef struct {
-    int sharded, first, last, fd;          /* fd: pipe to the parent (rows + totals) */
+    int sharded, first, last, fd;          /* fd: pipe to the parent (totals, then sections or rows) */
+    int slab_in, slab_out;                 /* pipes from the left / to the right neighbour: the halo slab behind a cut inside a contig */
+    int rows_in, rows_out;                 /* ... and the rows that lie in a share further right (side rows past the halo) */
+    int tied;                              /* rows can tie on (contig, start) and the reference's order is wanted: the parent orders and formats */
+    char part_path[512];                   /* the worker's own formatted text */
     int n_iv;
     mm_interval_t iv[64];                  /* dense counters: the share's intervals (+ halo behind a cut) */
     int32_t lo_tid, hi_tid; int64_t lo_pos, hi_pos;
     uint64_t voffset;
 } wspec_t;
 typedef struct {                           /* what a worker reports besides its rows */
-    int64_t n_rows;
+    int64_t n_rows;                        /* rows sent to the parent (tied runs), else 0 */
+    int64_t n_sections;                    /* sections of its part file (one per contig it has rows on), sent as wsection_t */
+    int64_t n_tie_keys;                    /* tied runs: keys of its first-insertion sequence, sent behind the rows */
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
     double load_time, wait_time, sort_time;
 } wtotals_t;
+
+typedef struct { int32_t tid, pad; int64_t off, len; } wsection_t;   /* bytes [off, off + len) of the part file: the rows of contig tid */
 
 static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "Usage: minimod %s ref.fa reads.bam\n", o->view ? "view" : "freq");
@@ -107,7 +116,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
                               "                              minimod's hash table leaves them in (skips the replay of that table) [%s]\n", o->canonical_order ? "yes" : "no");
     if (!o->view) fprintf(fp, "   --gather INT               -K batches that may share one kernel launch (they are staged in GPU memory one behind the\n"
                               "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
-    if (!o->view) fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
+    fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
@@ -247,6 +256,44 @@ static void replay_batch(mm_freq_t *hv, mmh_tie_t *tie, int32_t ticket, const mm
     *seconds += mmh_realtime() - t0;
 }
 
+
+/* ---- workers of `--devices`: rows of other shares, sections of formatted text ---- */
+static int row_key_cmp(const mm_row_t *a, const mm_row_t *b);
+typedef struct { const int *rank; } rowcmp_t;
+static int row_full_cmp(const rowcmp_t *c, const mm_row_t *a, const mm_row_t *b) {   /* mm_freq_finalize's order: contig by name, then the key */
+    if (a->tid != b->tid) return c->rank[a->tid] < c->rank[b->tid] ? -1 : 1;
+    return row_key_cmp(a, b);
+}
+/* rank of every contig name in strcmp order (cmp_key_fast, src/mod.c:59-76); header order among equal names */
+static int *contig_ranks(const mm_bam_hdr_t *hdr) {
+    const int nt = hdr->n_targets;
+    int *order = (int *)malloc(sizeof(int) * (size_t)(nt > 0 ? nt : 1)), *rank = (int *)malloc(sizeof(int) * (size_t)(nt > 0 ? nt : 1));
+    for (int t = 0; t < nt; t++) order[t] = t;
+    for (int a = 1; a < nt; a++) {
+        int x = order[a], b = a - 1;
+        while (b >= 0 && strcmp(hdr->target_name[order[b]], hdr->target_name[x]) > 0) { order[b + 1] = order[b]; b--; }
+        order[b + 1] = x;
+    }
+    for (int r = 0; r < nt; r++) rank[order[r]] = r;
+    free(order);
+    return rank;
+}
+/* two ordered row arrays as one (equal keys added up); returns a malloc'd array, *n_out rows */
+static mm_row_t *merge_rows(const rowcmp_t *c, const mm_row_t *a, int64_t na, const mm_row_t *b, int64_t nb, int64_t *n_out) {
+    mm_row_t *out = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(na + nb > 0 ? na + nb : 1));
+    int64_t i = 0, j = 0, w = 0;
+    while (out && (i < na || j < nb)) {
+        const int k = i >= na ? 1 : (j >= nb ? -1 : row_full_cmp(c, &a[i], &b[j]));
+        if (k == 0) { mm_row_t m = a[i++]; m.n_called += b[j].n_called; m.n_mod += b[j].n_mod; j++; out[w++] = m; }
+        else if (k < 0) out[w++] = a[i++];
+        else out[w++] = b[j++];
+    }
+    *n_out = w;
+    return out;
+}
+/* is (tid, pos) in front of the share's end?  (shares are contiguous in header order) */
+static int before_hi(const wspec_t *ws, int32_t tid, int32_t pos) { return ws->last || tid < ws->hi_tid || (tid == ws->hi_tid && (int64_t)pos < ws->hi_pos); }
+
 /* Everything behind option parsing and the reference load: the batches of one BAM (or of one share of it) through one
  * GPU.  A single run prints its rows; a worker of `--devices` sends them to the parent, which merges and prints. */
 static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
@@ -287,7 +334,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     int wildcard = 0, star_ctx = 0;
     for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
-    int replay = !view && !o.canonical_order && !ws->sharded && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
+    int replay = !view && !o.canonical_order && (!ws->sharded || ws->tied) && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
     if (replay && o.K >= (1 << 21)) {   /* (the rows the replay works from number a batch's reads with 21 bits) */
         MMH_WARNING("%s", "-K of 2097152 or more: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype (the order of minimod's hash table is replayed for smaller batches)");
         replay = 0;
@@ -310,9 +357,6 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
      * hash table and its unstable sort leave them in (tieorder.c): that order is replayed from the calls of every read,
      * which a second handle in view mode delivers for the same batches.  A run whose rows cannot tie (-c m[CG]) needs
      * none of this. */
-    if (!view && !o.canonical_order && ws->sharded && (mods.n_mods > 1 || star_ctx || o.insertions || o.haplotypes) && ws->first)
-        MMH_WARNING("%s", "--devices prints rows that tie on (contig, start) by strand, code, ins_offset, haplotype: the order of minimod's hash table is not replayed across workers");
-
     if (ws->fd < 0) {
         if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
         else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
@@ -398,24 +442,121 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
     free(cur); free(prev);
     double sort_time = 0;
+    if (!view && ws->sharded && ws->fd >= 0) {
+        /* The halo behind a cut inside a contig: the counters this worker's reads left there go to the right-hand neighbour as
+         * ONE slab (mm_freq_slab_export: position-dense, planes x strands x halo words), which adds them to its own
+         * (mm_freq_slab_add); here they are cleared.  The left neighbour's slab is taken in first. */
+        if (ws->slab_in >= 0) {
+            int64_t hd[3] = {0, 0, 0};   /* tid, begin, length */
+            if (read_all(ws->slab_in, hd, sizeof hd) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+            if (hd[2] > 0) {
+                const int64_t nw = mm_freq_slab_words(h, hd[2]);
+                uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nw);
+                if (!buf || read_all(ws->slab_in, buf, sizeof(uint64_t) * (size_t)nw) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                int e = mm_freq_slab_add_host(h, (int32_t)hd[0], hd[1], hd[2], buf);
+                if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+                free(buf);
+            }
+            close(ws->slab_in);
+        }
+        if (ws->slab_out >= 0) {
+            int64_t hd[3] = {0, 0, 0};
+            uint64_t *buf = NULL;
+            int64_t nw = 0;
+            const mm_interval_t *iv = ws->n_iv > 0 ? &ws->iv[ws->n_iv - 1] : NULL;
+            if (iv && iv->halo > 0) {
+                hd[0] = iv->tid; hd[1] = iv->end;
+                hd[2] = iv->end + iv->halo <= (int64_t)hdr->target_len[iv->tid] ? iv->halo : (int64_t)hdr->target_len[iv->tid] - iv->end;
+                nw = mm_freq_slab_words(h, hd[2]);
+                buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nw > 0 ? nw : 1));
+                int e = buf ? mm_freq_slab_export_host(h, (int32_t)hd[0], hd[1], hd[2], buf) : -MM_E_NOMEM;
+                if (!e) e = mm_freq_slab_clear(h, (int32_t)hd[0], hd[1], hd[2], NULL);
+                if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+            }
+            if (write_all(ws->slab_out, hd, sizeof hd) || (nw > 0 && write_all(ws->slab_out, buf, sizeof(uint64_t) * (size_t)nw))) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
+            free(buf);
+            close(ws->slab_out);
+        }
+    }
     if (!view) {
         double ts = mmh_realtime();
         const mm_row_t *rows = NULL;
         int64_t nrows = mm_freq_finalize(h, &rows);
         if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
         sort_time = mmh_realtime() - ts;
-        if (ws->fd >= 0) {   /* a worker: rows and totals go to the parent */
+        if (ws->fd >= 0) {
+            /* A worker of --devices.  Its rows behind its share's end -- what its reads called past the halo, and every row
+             * the side lists hold there (inside insertions, haplotypes without a plane) -- belong to a share further right:
+             * they go to the right-hand neighbour, which adds them to its own (and passes on what lies behind ITS end).  What
+             * is left is this share's part of the output: formatted here, in parallel with the other workers, one section per
+             * contig; the parent only puts the sections in order.  (Tied runs that want the reference's order send rows and
+             * the first-insertion sequence of their keys to the parent instead, which orders and formats.) */
+            int *rank = contig_ranks(hdr);
+            rowcmp_t rc = {rank};
+            mm_row_t *mine = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(nrows > 0 ? nrows : 1));
+            mm_row_t *fwd = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(nrows > 0 ? nrows : 1));
+            int64_t n_mine = 0, n_fwd = 0;
+            for (int64_t i = 0; i < nrows; i++) { if (before_hi(ws, rows[i].tid, rows[i].pos)) mine[n_mine++] = rows[i]; else fwd[n_fwd++] = rows[i]; }
+            if (ws->rows_in >= 0) {   /* what the shares to the left found in front of them */
+                int64_t n_in = 0;
+                if (read_all(ws->rows_in, &n_in, sizeof n_in) != 0 || n_in < 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                mm_row_t *in = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_in > 0 ? n_in : 1));
+                if (n_in && read_all(ws->rows_in, in, sizeof(mm_row_t) * (size_t)n_in) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                close(ws->rows_in);
+                mm_row_t *in_mine = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_in > 0 ? n_in : 1)), *in_fwd = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_in > 0 ? n_in : 1));
+                int64_t a1 = 0, a2 = 0, nm = 0, nf = 0;
+                for (int64_t i = 0; i < n_in; i++) { if (before_hi(ws, in[i].tid, in[i].pos)) in_mine[a1++] = in[i]; else in_fwd[a2++] = in[i]; }
+                mm_row_t *m2 = merge_rows(&rc, mine, n_mine, in_mine, a1, &nm), *f2 = merge_rows(&rc, fwd, n_fwd, in_fwd, a2, &nf);
+                free(mine); free(fwd); free(in); free(in_mine); free(in_fwd);
+                mine = m2; n_mine = nm; fwd = f2; n_fwd = nf;
+            }
+            if (ws->rows_out >= 0) {
+                if (write_all(ws->rows_out, &n_fwd, sizeof n_fwd) || write_all(ws->rows_out, fwd, sizeof(mm_row_t) * (size_t)n_fwd)) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
+                close(ws->rows_out);
+                n_fwd = 0;
+            }
+            if (n_fwd) { /* (the last worker keeps everything: before_hi is always true there) */ }
             wtotals_t tt;
             memset(&tt, 0, sizeof tt);
-            tt.n_rows = nrows; tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
+            tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
             tt.processed_bytes = ld->processed_bytes; tt.processed_bases = ld->processed_bases;
             tt.load_time = load_time; tt.wait_time = process_wait_time; tt.sort_time = sort_time;
-            if (write_all(ws->fd, &tt, sizeof tt) || write_all(ws->fd, rows, sizeof(mm_row_t) * (size_t)nrows)) {
-                MMH_ERROR("%s", "Could not send the rows to the parent process");
-                exit(EXIT_FAILURE);
+            if (ws->tied) {
+                const void *tk = NULL; const uint32_t *th = NULL;
+                int64_t ntk = replay ? mmh_tie_export(tie, &tk, &th) : -1;
+                tt.n_rows = n_mine; tt.n_tie_keys = ntk;
+                if (write_all(ws->fd, &tt, sizeof tt) || write_all(ws->fd, mine, sizeof(mm_row_t) * (size_t)n_mine) ||
+                    (ntk > 0 && (write_all(ws->fd, tk, 16 * (size_t)ntk) || write_all(ws->fd, th, 4 * (size_t)ntk)))) {
+                    MMH_ERROR("%s", "Could not send the rows to the parent process"); exit(EXIT_FAILURE);
+                }
+            } else {
+                FILE *pf = fopen(ws->part_path, "wb");
+                if (!pf) { MMH_ERROR("Cannot open file %s for writing", ws->part_path); exit(EXIT_FAILURE); }
+                const char *codes[MM_MAX_CODES];
+                int n_codes = code_names(h, codes);
+                wsection_t *sec = (wsection_t *)malloc(sizeof(wsection_t) * (size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1));
+                int64_t n_sec = 0;
+                for (int64_t i = 0; i < n_mine;) {   /* rows come contig by contig */
+                    int64_t j = i;
+                    while (j < n_mine && mine[j].tid == mine[i].tid) j++;
+                    if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+                    const int64_t at = (int64_t)ftello(pf);
+                    mmh_print_freq_rows(pf, mm_bam_pool(ld->bam), mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+                    if (mmh_emit_flush() != 0 || fflush(pf) != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+                    sec[n_sec].tid = mine[i].tid; sec[n_sec].pad = 0; sec[n_sec].off = at; sec[n_sec].len = (int64_t)ftello(pf) - at;
+                    n_sec++;
+                    i = j;
+                }
+                if (mmh_emit_finish() != 0 || fclose(pf) != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+                tt.n_sections = n_sec;
+                if (write_all(ws->fd, &tt, sizeof tt) || write_all(ws->fd, sec, sizeof(wsection_t) * (size_t)n_sec)) { MMH_ERROR("%s", "Could not send the sections to the parent process"); exit(EXIT_FAILURE); }
+                free(sec);
             }
             close(ws->fd);
+            free(mine); free(fwd); free(rank);
             mm_freq_destroy(h);
+            if (hv) mm_freq_destroy(hv);
+            mmh_tie_destroy(tie);
             mmh_loader_close(ld);
             return 0;
         }
@@ -443,6 +584,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o.out != stdout) fclose(o.out);
     else fflush(stdout);
+    if (view && ws->fd >= 0) {   /* a view worker of --devices: its rows are in its part file; the parent wants the totals */
+        wtotals_t tt;
+        memset(&tt, 0, sizeof tt);
+        tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
+        tt.processed_bytes = ld->processed_bytes; tt.processed_bases = ld->processed_bases;
+        tt.load_time = load_time; tt.wait_time = process_wait_time;
+        if (write_all(ws->fd, &tt, sizeof tt)) { MMH_ERROR("%s", "Could not send the totals to the parent process"); exit(EXIT_FAILURE); }
+        close(ws->fd);
+        mm_freq_destroy(h);
+        mmh_loader_close(ld);
+        return 0;
+    }
 
     fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
     fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, ld->total_bytes / (float)(1000 * 1000));
@@ -476,8 +629,6 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
  * opens the BAM at the virtual offset the .bai gives for its share, counts into dense planes over its intervals (a halo
  * behind a cut inside a contig) and sends its rows to the parent, which adds up the rows both neighbours have for the
  * positions behind a cut, puts the contigs in output order and prints. */
-typedef struct { const mm_row_t *rows; int64_t n; } rowrun_t;
-
 static int row_key_cmp(const mm_row_t *a, const mm_row_t *b) {   /* within one contig: mm_freq_finalize's order */
     if (a->pos != b->pos) return a->pos < b->pos ? -1 : 1;
     if (a->strand != b->strand) return a->strand < b->strand ? -1 : 1;
@@ -487,10 +638,25 @@ static int row_key_cmp(const mm_row_t *a, const mm_row_t *b) {   /* within one c
     return ha < hb ? -1 : (ha > hb);
 }
 
+static int copy_bytes(FILE *in, int64_t off, int64_t len, FILE *out) {
+    static char buf[1 << 20];
+    if (fseeko(in, (off_t)off, SEEK_SET) != 0) return -1;
+    while (len > 0) {
+        size_t want = len > (int64_t)sizeof buf ? sizeof buf : (size_t)len;
+        size_t got = fread(buf, 1, want, in);
+        if (got == 0) return -1;
+        if (fwrite(buf, 1, got, out) != got) return -1;
+        len -= (int64_t)got;
+    }
+    return 0;
+}
+
 static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, const char *bam_file, double realtime0) {
-    if (o->view) { MMH_ERROR("%s", "--devices is a freq option"); exit(EXIT_FAILURE); }
-    for (int i = 0; i < mods->n_mods; i++)
+    int star_ctx = 0;
+    for (int i = 0; i < mods->n_mods; i++) {
         if (strcmp(mods->code[i], "*") == 0) { MMH_ERROR("%s", "--devices cannot be combined with the wildcard code -c '*' (code indices are per worker)"); exit(EXIT_FAILURE); }
+        if (strcmp(mods->context[i], "*") == 0) star_ctx = 1;
+    }
     int dev[MMH_MAX_DEVICES], nd = 0;
     for (const char *p = o->devices;;) {   /* ordinals separated by commas; one GPU may be listed more than once (a worker each) */
         char *end = NULL;
@@ -522,12 +688,15 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
     }
     off[nt] = total;
     if (total <= 0) { MMH_ERROR("%s", "No contig of the BAM header is in the reference"); exit(EXIT_FAILURE); }
+    /* rows that tie on (contig, start) in the reference's order: the parent replays it from the workers' key sequences */
+    const int tied = !o->view && !o->canonical_order && (mods->n_mods > 1 || star_ctx || o->insertions || o->haplotypes);
     wspec_t *ws = (wspec_t *)calloc((size_t)nd, sizeof(wspec_t));
     for (int r = 0; r < nd; r++) {
         wspec_t *w = &ws[r];
         int64_t lo = r == 0 ? 0 : (total / nd * r) / MMH_SHARE_ALIGN * MMH_SHARE_ALIGN;
         int64_t hi = r == nd - 1 ? total : (total / nd * (r + 1)) / MMH_SHARE_ALIGN * MMH_SHARE_ALIGN;
-        w->sharded = 1; w->first = r == 0; w->last = r == nd - 1; w->fd = -1;
+        w->sharded = 1; w->first = r == 0; w->last = r == nd - 1; w->fd = -1; w->tied = tied;
+        w->slab_in = w->slab_out = w->rows_in = w->rows_out = -1;
         w->lo_tid = -1; w->hi_tid = nt; w->hi_pos = 0;
         for (int t = 0; t < nt; t++) {
             if (!has[t]) continue;
@@ -538,7 +707,6 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
             iv->tid = t; iv->begin = b - off[t]; iv->end = e - off[t]; iv->halo = 0;
             if (w->lo_tid < 0) { w->lo_tid = t; w->lo_pos = iv->begin; }
             w->hi_tid = t; w->hi_pos = iv->end;
-            if (iv->end < (int64_t)hdr->target_len[t]) iv->halo = MMH_SHARE_HALO;   /* the cut is inside the contig */
         }
         if (w->n_iv == 0) { w->lo_tid = nt; w->lo_pos = 0; w->hi_tid = nt; w->hi_pos = 0; w->voffset = UINT64_MAX; }
         else w->voffset = w->first ? 0 : mm_bai_start(bai, w->lo_tid, w->lo_pos);
@@ -556,6 +724,34 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         }
     }
     mm_bai_free(bai);
+    /* halos: dense counters behind a cut that falls inside a contig, as far as the NEXT share's piece of that contig goes (at
+     * most MMH_SHARE_HALO): the slab then lies inside the neighbour's own counters; what a read calls further right is a side row */
+    int live[MMH_MAX_DEVICES], nlive = 0;
+    for (int r = 0; r < nd; r++) if (ws[r].n_iv > 0 || ws[r].last) live[nlive++] = r;
+    for (int k = 0; k + 1 < nlive; k++) {
+        wspec_t *w = &ws[live[k]], *nx = &ws[live[k + 1]];
+        if (w->n_iv == 0 || nx->n_iv == 0) continue;
+        mm_interval_t *iv = &w->iv[w->n_iv - 1];
+        if (iv->end < (int64_t)hdr->target_len[iv->tid] && nx->iv[0].tid == iv->tid && nx->iv[0].begin == iv->end) {
+            int64_t room = nx->iv[0].end - nx->iv[0].begin;
+            iv->halo = room < MMH_SHARE_HALO ? room : MMH_SHARE_HALO;
+        }
+    }
+    /* the workers' own text goes to files next to each other in a scratch directory, put together by the parent */
+    char tmpl[384];
+    const char *td = getenv("TMPDIR");
+    snprintf(tmpl, sizeof tmpl, "%s/minimod_devices_XXXXXX", td && *td ? td : "/tmp");
+    if (!mkdtemp(tmpl)) { MMH_ERROR("Cannot create a scratch directory %s", tmpl); exit(EXIT_FAILURE); }
+    for (int r = 0; r < nd; r++) snprintf(ws[r].part_path, sizeof ws[r].part_path, "%s/part_%03d", tmpl, r);
+    /* neighbour pipes between the workers that have something to do */
+    int slab_pipe[MMH_MAX_DEVICES][2], rows_pipe[MMH_MAX_DEVICES][2];
+    for (int k = 0; k + 1 < nlive; k++) {
+        if (pipe(slab_pipe[k]) != 0 || pipe(rows_pipe[k]) != 0) { MMH_ERROR("%s", "pipe failed"); exit(EXIT_FAILURE); }
+        if (!o->view) {
+            ws[live[k]].slab_out = slab_pipe[k][1]; ws[live[k + 1]].slab_in = slab_pipe[k][0];
+            ws[live[k]].rows_out = rows_pipe[k][1]; ws[live[k + 1]].rows_in = rows_pipe[k][0];
+        }
+    }
     /* the workers: forked before anything in this process has touched HIP */
     pid_t pid[MMH_MAX_DEVICES];
     int rfd[MMH_MAX_DEVICES];
@@ -568,10 +764,20 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         if (pid[r] == 0) {
             close(pp[0]);
             for (int q = 0; q < r; q++) close(rfd[q]);
+            for (int k = 0; k + 1 < nlive; k++) {   /* only this worker's ends of the neighbour pipes stay open */
+                if (slab_pipe[k][1] != ws[r].slab_out) close(slab_pipe[k][1]);
+                if (slab_pipe[k][0] != ws[r].slab_in) close(slab_pipe[k][0]);
+                if (rows_pipe[k][1] != ws[r].rows_out) close(rows_pipe[k][1]);
+                if (rows_pipe[k][0] != ws[r].rows_in) close(rows_pipe[k][0]);
+            }
             fopt_t wo = *o;
             wo.device = dev[r];
             wo.threads = o->threads / nd > 0 ? o->threads / nd : 1;
             ws[r].fd = pp[1];
+            if (o->view) {   /* a view worker prints its share's rows into its part file, no header */
+                wo.out = fopen(ws[r].part_path, "wb");
+                if (!wo.out) { MMH_ERROR("Cannot open file %s for writing", ws[r].part_path); _exit(EXIT_FAILURE); }
+            }
             int rc = run_body(&wo, mods, ref, bam_file, realtime0, &ws[r]);
             fflush(NULL);
             _exit(rc);
@@ -579,18 +785,31 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         close(pp[1]);
         rfd[r] = pp[0];
     }
+    for (int k = 0; k + 1 < nlive; k++) { close(slab_pipe[k][0]); close(slab_pipe[k][1]); close(rows_pipe[k][0]); close(rows_pipe[k][1]); }
     mmh_free_ref(ref);
-    /* the rows of every worker, in rank order */
+    /* what every worker reports, in rank order */
     wtotals_t tot[MMH_MAX_DEVICES];
     mm_row_t *wrows[MMH_MAX_DEVICES];
+    wsection_t *wsec[MMH_MAX_DEVICES];
+    void *wtk[MMH_MAX_DEVICES]; uint32_t *wth[MMH_MAX_DEVICES];
     int failed = 0;
     for (int r = 0; r < nd; r++) {
-        wrows[r] = NULL;
+        wrows[r] = NULL; wsec[r] = NULL; wtk[r] = NULL; wth[r] = NULL;
         memset(&tot[r], 0, sizeof tot[r]);
         if (read_all(rfd[r], &tot[r], sizeof tot[r]) != 0) failed = 1;
         else {
-            wrows[r] = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(tot[r].n_rows > 0 ? tot[r].n_rows : 1));
-            if (!wrows[r] || read_all(rfd[r], wrows[r], sizeof(mm_row_t) * (size_t)tot[r].n_rows) != 0) failed = 1;
+            if (tot[r].n_rows > 0) {
+                wrows[r] = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)tot[r].n_rows);
+                if (!wrows[r] || read_all(rfd[r], wrows[r], sizeof(mm_row_t) * (size_t)tot[r].n_rows) != 0) failed = 1;
+            }
+            if (!failed && tot[r].n_tie_keys > 0) {
+                wtk[r] = malloc(16 * (size_t)tot[r].n_tie_keys); wth[r] = (uint32_t *)malloc(4 * (size_t)tot[r].n_tie_keys);
+                if (!wtk[r] || !wth[r] || read_all(rfd[r], wtk[r], 16 * (size_t)tot[r].n_tie_keys) != 0 || read_all(rfd[r], wth[r], 4 * (size_t)tot[r].n_tie_keys) != 0) failed = 1;
+            }
+            if (!failed && tot[r].n_sections > 0) {
+                wsec[r] = (wsection_t *)malloc(sizeof(wsection_t) * (size_t)tot[r].n_sections);
+                if (!wsec[r] || read_all(rfd[r], wsec[r], sizeof(wsection_t) * (size_t)tot[r].n_sections) != 0) failed = 1;
+            }
         }
         close(rfd[r]);
     }
@@ -599,11 +818,7 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1;
     }
     if (failed) { MMH_ERROR("%s", "A worker of --devices failed"); exit(EXIT_FAILURE); }
-    double ts = mmh_realtime();
-    /* per contig, the workers' runs in rank order (= position order); neighbours overlap only in the halo behind a cut */
-    int64_t n_all = 0;
-    for (int r = 0; r < nd; r++) n_all += tot[r].n_rows;
-    mm_row_t *out_rows = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_all > 0 ? n_all : 1));
+    double ts = mmh_realtime(), sort_time = 0, output_time = 0;
     int *order = (int *)malloc(sizeof(int) * (size_t)(nt > 0 ? nt : 1));
     for (int t = 0; t < nt; t++) order[t] = t;
     for (int a = 1; a < nt; a++) {   /* contigs by name like cmp_key_fast (src/mod.c:59-76); insertion sort keeps header order among equal names */
@@ -611,47 +826,70 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         while (b >= 0 && strcmp(hdr->target_name[order[b]], hdr->target_name[x]) > 0) { order[b + 1] = order[b]; b--; }
         order[b + 1] = x;
     }
-    int64_t n_out = 0;
-    for (int k = 0; k < nt; k++) {
-        const int t = order[k];
-        const int64_t contig_start = n_out;
-        for (int r = 0; r < nd; r++) {
-            /* worker r's rows of contig t are contiguous (its rows come sorted by contig, then position) */
-            int64_t a = 0, n = tot[r].n_rows;
-            while (a < n && wrows[r][a].tid != t) a++;   /* few contigs per worker: a linear look is fine ... */
-            int64_t b = a;
-            while (b < n && wrows[r][b].tid == t) b++;
-            if (a == b) continue;
-            /* merge run [a, b) behind what the contig has so far: only the tail of the output can overlap it */
-            int64_t lo = n_out;
-            while (lo > contig_start && row_key_cmp(&out_rows[lo - 1], &wrows[r][a]) >= 0) lo--;
-            if (lo == n_out) { memcpy(out_rows + n_out, wrows[r] + a, sizeof(mm_row_t) * (size_t)(b - a)); n_out += b - a; continue; }
-            int64_t n_tail = n_out - lo;
-            mm_row_t *tail = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)n_tail);
-            memcpy(tail, out_rows + lo, sizeof(mm_row_t) * (size_t)n_tail);
-            int64_t i = 0, j = a, w = lo;
-            while (i < n_tail || j < b) {
-                int c = i >= n_tail ? 1 : (j >= b ? -1 : row_key_cmp(&tail[i], &wrows[r][j]));
-                if (c == 0) { mm_row_t m = tail[i++]; m.n_called += wrows[r][j].n_called; m.n_mod += wrows[r][j].n_mod; j++; out_rows[w++] = m; }
-                else if (c < 0) out_rows[w++] = tail[i++];
-                else out_rows[w++] = wrows[r][j++];
-            }
-            free(tail);
-            n_out = w;
+    if (o->view) {
+        /* every read is one worker's: the parts in rank order are the rows in file order */
+        mmh_print_view_header(o->out, o->insertions, o->haplotypes);
+        for (int r = 0; r < nd && !failed; r++) {
+            FILE *pf = fopen(ws[r].part_path, "rb");
+            if (!pf) continue;   /* (a worker with nothing to do wrote nothing) */
+            fseeko(pf, 0, SEEK_END);
+            const int64_t len = (int64_t)ftello(pf);
+            if (len > 0 && copy_bytes(pf, 0, len, o->out) != 0) failed = 1;
+            fclose(pf);
         }
+    } else if (!tied) {
+        /* the workers' sections: a contig's rows are its pieces in rank order (= position order; no two workers hold the same key) */
+        mmh_print_freq_header(o->out, o->bedmethyl, o->insertions, o->haplotypes);
+        FILE *pf[MMH_MAX_DEVICES];
+        for (int r = 0; r < nd; r++) pf[r] = tot[r].n_sections > 0 ? fopen(ws[r].part_path, "rb") : NULL;
+        for (int k = 0; k < nt && !failed; k++)
+            for (int r = 0; r < nd && !failed; r++)
+                for (int64_t i = 0; i < tot[r].n_sections; i++)
+                    if (wsec[r][i].tid == order[k] && wsec[r][i].len > 0 && (!pf[r] || copy_bytes(pf[r], wsec[r][i].off, wsec[r][i].len, o->out) != 0)) failed = 1;
+        for (int r = 0; r < nd; r++) if (pf[r]) fclose(pf[r]);
+    } else {
+        /* tied rows in the reference's order: the first-insertion sequence of the whole run is the workers' sequences one after
+         * the other (a worker's reads all lie in front of the next worker's in the file, src/mod.c:743-774); rows: a contig's
+         * pieces in rank order */
+        int64_t n_all = 0;
+        for (int r = 0; r < nd; r++) n_all += tot[r].n_rows;
+        mm_row_t *out_rows = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(n_all > 0 ? n_all : 1));
+        int64_t n_out = 0;
+        for (int k = 0; k < nt; k++)
+            for (int r = 0; r < nd; r++) {
+                int64_t a = 0, n = tot[r].n_rows;
+                while (a < n && wrows[r][a].tid != order[k]) a++;
+                int64_t b = a;
+                while (b < n && wrows[r][b].tid == order[k]) b++;
+                if (b > a) { memcpy(out_rows + n_out, wrows[r] + a, sizeof(mm_row_t) * (size_t)(b - a)); n_out += b - a; }
+            }
+        mmh_tie_t *tie = mmh_tie_create(hdr, o->insertions, o->haplotypes);
+        int ok = tie != NULL;
+        for (int r = 0; r < nd && ok; r++) {
+            if (tot[r].n_tie_keys < 0) ok = 0;
+            else if (tot[r].n_tie_keys > 0 && mmh_tie_import(tie, wtk[r], wth[r], tot[r].n_tie_keys) != 0) ok = 0;
+        }
+        if (!ok || mmh_tie_order_rows(tie, out_rows, n_out) != 0)
+            MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
+        mmh_tie_destroy(tie);
+        sort_time = mmh_realtime() - ts;
+        double to = mmh_realtime();
+        mm_pool_t *pool = mm_pool_create(o->threads);
+        const char *codes[MM_MAX_MODS];
+        for (int i = 0; i < mods->n_mods; i++) codes[i] = mods->code[i];
+        mmh_print_freq_header(o->out, o->bedmethyl, o->insertions, o->haplotypes);
+        mmh_print_freq_rows(o->out, pool, out_rows, n_out, hdr, codes, mods->n_mods, o->bedmethyl, o->insertions, o->haplotypes);
+        if (mmh_emit_finish() != 0) failed = 1;
+        mm_pool_destroy(pool);
+        free(out_rows);
+        output_time = mmh_realtime() - to;
     }
-    for (int r = 0; r < nd; r++) free(wrows[r]);
-    double sort_time = mmh_realtime() - ts;
-    double to = mmh_realtime();
-    mm_pool_t *pool = mm_pool_create(o->threads);
-    const char *codes[MM_MAX_MODS];
-    for (int i = 0; i < mods->n_mods; i++) codes[i] = mods->code[i];
-    mmh_print_freq_header(o->out, o->bedmethyl, o->insertions, o->haplotypes);
-    mmh_print_freq_rows(o->out, pool, out_rows, n_out, hdr, codes, mods->n_mods, o->bedmethyl, o->insertions, o->haplotypes);
-    if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+    if (!tied || o->view) output_time = mmh_realtime() - ts;
+    for (int r = 0; r < nd; r++) { unlink(ws[r].part_path); free(wrows[r]); free(wsec[r]); free(wtk[r]); free(wth[r]); }
+    rmdir(tmpl);
+    if (failed) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o->out != stdout) fclose(o->out);
     else fflush(stdout);
-    double output_time = mmh_realtime() - to;
     wtotals_t s;
     memset(&s, 0, sizeof s);
     for (int r = 0; r < nd; r++) {
@@ -671,13 +909,12 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
     fprintf(stderr, "\n[%s] total processed bases: %.1f M", __func__, s.processed_bases / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] Data loading time: %.3f sec (slowest worker)", __func__, s.load_time);
     fprintf(stderr, "\n[%s] Data processing time: %.3f sec (slowest worker waiting for its GPU)", __func__, s.wait_time);
-    fprintf(stderr, "\n[%s] Data merging time: %.3f sec (rows of the workers put together)", __func__, sort_time);
+    fprintf(stderr, "\n[%s] Data merging time: %.3f sec (%s)", __func__, sort_time, tied ? "the workers' key sequences replayed, rows put in the reference's order" : "nothing to merge: halo slabs and side rows went from neighbour to neighbour");
     fprintf(stderr, "\n[%s] Data sorting time: %.3f sec (slowest worker's finalize)", __func__, s.sort_time);
-    fprintf(stderr, "\n[%s] Data output time: %.3f sec", __func__, output_time);
+    fprintf(stderr, "\n[%s] Data output time: %.3f sec (%s)", __func__, output_time, tied ? "formatted by the parent" : "the workers' sections put in order");
     fprintf(stderr, "\n");
     (void)realtime0;
-    free(out_rows); free(order); free(off); free(has); free(ws);
-    mm_pool_destroy(pool);
+    free(order); free(off); free(has); free(ws);
     mm_bam_close(hb);
     return 0;
 }
@@ -769,7 +1006,13 @@ static int run_main(int argc, char **argv, int view) {
     if (!ref) { MMH_ERROR("Could not to open file %s", ref_file); exit(EXIT_FAILURE); }
     fprintf(stderr, "[%s] Reference genome loaded in %.3f sec\n", __func__, mmh_realtime() - t1);
     if (o.devices && strchr(o.devices, ',')) return run_devices(&o, &mods, ref, bam_file, realtime0);
-    if (o.devices) o.device = atoi(o.devices);
+    if (o.devices) {   /* one ordinal: the same as --device */
+        char *end = NULL;
+        errno = 0;
+        long v = strtol(o.devices, &end, 10);
+        if (end == o.devices || errno || v < 0 || v > 1023 || *end != 0) { MMH_ERROR("--devices takes GPU ordinals separated by commas, e.g. 0,1,2,3. You entered %s", o.devices); exit(EXIT_FAILURE); }
+        o.device = (int)v;
+    }
     wspec_t ws;
     memset(&ws, 0, sizeof ws);
     ws.fd = -1;

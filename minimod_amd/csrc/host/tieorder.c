@@ -197,7 +197,8 @@ struct mmh_tie {
     tkey_t *keys; uint32_t *hash; size_t n, cap;
     /* membership of `keys` (own open addressing on tkey_mix) */
     uint32_t *set; size_t set_cap;
-    int failed;                    /* a read had more MM groups than the rows can number, or memory ran out */
+    int failed;                    /* memory ran out, or more keys than max_keys */
+    size_t max_keys;               /* the sequence is not kept beyond this many keys (host memory: 20 bytes a key + the sets) */
 };
 
 mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotypes) {
@@ -218,6 +219,8 @@ mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotype
         t->rank[idx[r]] = cur;
     }
     free(idx);
+    t->max_keys = (size_t)128 << 20;   /* ~3.5 GB of host memory; MINIMOD_REPLAY_MAX_KEYS sets another bound */
+    { const char *e = getenv("MINIMOD_REPLAY_MAX_KEYS"); if (e && atoll(e) > 0) t->max_keys = (size_t)atoll(e); }
     t->set_cap = (size_t)1 << 16;
     t->set = (uint32_t *)malloc(sizeof(uint32_t) * t->set_cap);
     if (!t->set) { t->failed = 1; return t; }
@@ -257,7 +260,7 @@ static int seq_add(mmh_tie_t *t, const tkey_t *k, uint32_t h) {
         if (!nh) return -1;
         t->hash = nh; t->cap = nc;
     }
-    if (t->n >= 0xFFFFFFF0u) return -1;
+    if (t->n >= 0xFFFFFFF0u || t->n >= t->max_keys) return -1;
     t->keys[t->n] = *k; t->hash[t->n] = h;
     t->set[s] = (uint32_t)t->n;
     t->n++;
@@ -377,6 +380,21 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
         j->out_keys[r] = sk; j->out_hash[r] = sh; j->out_n[r] = (uint32_t)w2;
     }
     free(ord);
+}
+
+/* the first-insertion sequence so far, as opaque 16-byte keys and their hashes (a worker of `--devices` hands its own to the
+ * parent); -1 when the replay has failed */
+int64_t mmh_tie_export(const mmh_tie_t *t, const void **keys, const uint32_t **hash) {
+    if (!t || t->failed) return -1;
+    *keys = t->keys; *hash = t->hash;
+    return (int64_t)t->n;
+}
+/* ... appended to this sequence, in order (keys already in it keep their place) */
+int mmh_tie_import(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n) {
+    if (!t || t->failed) return -1;
+    const tkey_t *k = (const tkey_t *)keys;
+    for (int64_t i = 0; i < n; i++) if (seq_add(t, &k[i], hash[i])) { t->failed = 1; return -1; }
+    return 0;
 }
 
 int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, const mm_view_row_t *rows, int64_t n,

@@ -1,45 +1,63 @@
 // sort_kernels.hip.h -- finalize-side helpers for the updates that do not fit the dense counter planes:
-// they are counted in a device hash table keyed by one 64-bit word (side_insert, freq_kernels.hip.h); at finalize the
-// occupied slots are compacted and ordered by key with an 8-bit LSD radix sort, so the host receives unique, ordered
-// (key, counts) pairs instead of one record per call.
+// they are appended to regional lists as (64-bit key, increment) records (side_insert, freq_kernels.hip.h); a compaction
+// gathers the lists, orders the records by key with an 8-bit LSD radix sort and adds up equal keys, so the host receives
+// unique, ordered (key, counts) pairs instead of one record per call.
 #pragma once
 #include "freq_kernels.hip.h"
 
 namespace mmhip {
 
-__global__ __launch_bounds__(256) void k_side_clear(unsigned long long* __restrict__ tab, unsigned long long cap) {
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * 256u) {
-        tab[2 * i] = kSideEmpty; tab[2 * i + 1] = 0ull;
+// the regions' records -> one (key, value) array pair: region r's first n[r] records go to [off[r], off[r] + n[r])
+__global__ __launch_bounds__(256) void k_side_gather(const unsigned long long* __restrict__ tab, unsigned long long cap_r, const unsigned long long* __restrict__ off,
+                                                     unsigned long long* __restrict__ out_k, unsigned long long* __restrict__ out_v) {
+    const uint32_t r = blockIdx.y;
+    const unsigned long long n = off[r + 1] - off[r];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const ulonglong2 rec = *reinterpret_cast<const ulonglong2*>(tab + 2ull * ((unsigned long long)r * cap_r + i));
+        out_k[off[r] + i] = rec.x; out_v[off[r] + i] = rec.y;
     }
 }
-
-// occupied slots of the table
-__global__ __launch_bounds__(256) void k_side_count(const unsigned long long* __restrict__ tab, unsigned long long cap, unsigned long long* __restrict__ counter) {
-    unsigned long long c = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * 256u)
-        c += tab[2 * i] != kSideEmpty ? 1ull : 0ull;
+// sorted (key, value) pairs -> one pair per key, values added up: (1) the keys' first entries ("heads") counted per tile of
+// 2048, (2) the counts scanned (k_radix_scan), (3) every head writes its key and the sum of its run
+constexpr int kReduceTile = 2048;
+__global__ __launch_bounds__(256) void k_reduce_count(const unsigned long long* __restrict__ k, unsigned long long n, uint32_t* __restrict__ tile_heads) {
+    __shared__ uint32_t part[4];
+    const unsigned long long base = (unsigned long long)blockIdx.x * kReduceTile;
+    uint32_t c = 0;
+    for (int j = threadIdx.x; j < kReduceTile; j += 256) {
+        const unsigned long long i = base + (unsigned long long)j;
+        if (i < n && (i == 0 || k[i] != k[i - 1])) c++;
+    }
     for (int d = 32; d; d >>= 1) c += __shfl_down(c, d, 64);
-    if (lane_id() == 0 && c) atomicAdd(counter, c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_heads[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-
-// occupied slots -> dense (key, value) arrays, in any order (one wave-aggregated reservation per wave)
-__global__ __launch_bounds__(256) void k_side_compact(const unsigned long long* __restrict__ tab,
-                                                      unsigned long long cap, unsigned long long* __restrict__ out_k,
-                                                      unsigned long long* __restrict__ out_v, unsigned long long* __restrict__ counter) {
-    for (unsigned long long i0 = (unsigned long long)blockIdx.x * 256u; i0 < cap; i0 += (unsigned long long)gridDim.x * 256u) {
-        const unsigned long long i = i0 + threadIdx.x;
-        const unsigned long long k = i < cap ? tab[2 * i] : kSideEmpty;
-        const bool have = k != kSideEmpty;
-        const uint64_t m = __ballot(have);
-        if (!m) continue;
-        unsigned long long base = 0;
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (have) {
-            const unsigned long long at = base + (unsigned long long)__popcll(m & lanemask_lt());
-            out_k[at] = k; out_v[at] = tab[2 * i + 1];
+__global__ __launch_bounds__(256) void k_reduce_emit(const unsigned long long* __restrict__ k, const unsigned long long* __restrict__ v, unsigned long long n,
+                                                     const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ out_k, unsigned long long* __restrict__ out_v) {
+    __shared__ uint32_t wsum[4];
+    const unsigned long long base = (unsigned long long)blockIdx.x * kReduceTile;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t run = tile_off[blockIdx.x];
+    for (int j0 = 0; j0 < kReduceTile; j0 += 256) {
+        const unsigned long long i = base + (unsigned long long)(j0 + (int)threadIdx.x);
+        const bool head = i < n && (i == 0 || k[i] != k[i - 1]);
+        const uint64_t b = __ballot(head);
+        if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = run;
+        for (int w = 0; w < wv; w++) before += wsum[w];
+        if (head) {
+            const unsigned long long key = k[i];
+            unsigned long long lo = 0, hi = 0;   // the two 32-bit halves are added on their own (n_called must not carry into n_mod)
+            for (unsigned long long j = i; j < n && k[j] == key; j++) { lo += v[j] & 0xFFFFFFFFull; hi += v[j] >> 32; }
+            // (a count past 2^32 - 1 becomes {n_called 0, n_mod 1}: more modified than called is what mm_freq_finalize reports as MM_E_OVERFLOW)
+            const unsigned long long at = (unsigned long long)before + (unsigned long long)__popcll(b & ((1ull << lane) - 1ull));
+            out_k[at] = key;
+            out_v[at] = lo > 0xFFFFFFFFull ? (1ull << 32) : (lo | (hi << 32));
         }
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
     }
 }
 

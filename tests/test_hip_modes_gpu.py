@@ -203,6 +203,7 @@ for r in range(2):
     engs.append(e)
 words = engs[0].slab_words(halo)
 buf = torch.zeros(words, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()   # (the fill runs on torch's stream, the slab kernels on the handle's own non-blocking one)
 engs[0].slab_export(0, plans[0]["end"], halo, buf.data_ptr())
 engs[0].slab_clear(0, plans[0]["end"], halo)
 crossed = int((buf != 0).sum())

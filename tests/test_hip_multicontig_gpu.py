@@ -226,6 +226,58 @@ def test_cli_devices_shares_of_the_genome_equal_a_single_run(flags, genome, tmp_
         assert b"total processed entries: 1100" in many.stderr and b"devices: %d" % len(devs.split(",")) in many.stderr
 
 
+@pytest.mark.parametrize("flags", [[], ["--haplotypes", "--insertions"], ["-b"]], ids=["tsv", "hap_ins", "bedmethyl"])
+def test_cli_devices_print_tied_rows_in_the_reference_order(flags, genome, tmp_path):
+    """Without --canonical-order a --devices run prints rows that tie on (contig, start) in the order the reference's hash table
+    and sort leave them in, like a single run: every worker replays its own reads' keys, the parent strings the workers'
+    first-insertion sequences together in file order (src/mod.c:743-774) and orders the rows.  Same bytes as one run."""
+    from minimod_amd import synth
+    gen = dict(haplotypes=True, long_insertions=True) if "--haplotypes" in flags else {}
+    bs = _batches(genome, **gen)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    base = [BIN, "freq", "-c", "m[CG],h[CG]", "-m", "0.8,0.7", "-K", "200", "-t", "6"] + flags
+    one = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert one.returncode == 0 and b"Row order replay" in one.stderr, one.stderr.decode()[-2000:]
+    canon = subprocess.run(base + ["--canonical-order", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert canon.returncode == 0 and sorted(canon.stdout.splitlines()) == sorted(one.stdout.splitlines())
+    if "-b" not in flags:
+        assert canon.stdout != one.stdout          # (the two orders do differ on this input: the test means something)
+    for devs in ("0,0", "0,0,0"):
+        many = subprocess.run(base + ["--devices", devs, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert many.returncode == 0, many.stderr.decode()[-3000:]
+        assert len(one.stdout) > 100000 and many.stdout == one.stdout, many.stderr.decode()[-1500:]
+
+
+def test_cli_view_devices_equal_a_single_run(genome, tmp_path):
+    """`minimod view --devices a,b,c`: every read is one worker's (the one its start lies in); the workers' rows one after the
+    other are the single run's rows."""
+    from minimod_amd import synth
+    bs = _batches(genome)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    base = [BIN, "view", "-c", "m[CG],h[CG]", "-K", "200", "-t", "6"]
+    one = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    for devs in ("0,0", "0,0,0"):
+        many = subprocess.run(base + ["--devices", devs, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert many.returncode == 0, many.stderr.decode()[-3000:]
+        assert len(one.stdout) > 100000 and many.stdout == one.stdout
+
+
+def test_cli_devices_rejects_a_malformed_list(genome, tmp_path):
+    from minimod_amd import synth
+    bs = _batches(genome)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    for bad in ("0,,1", "a,b", "0,-1", "0;1"):
+        r = subprocess.run([BIN, "freq", "--devices", bad, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and b"--devices takes GPU ordinals" in r.stderr, (bad, r.stderr.decode()[-500:])
+
+
 def test_cli_devices_needs_the_index(genome, tmp_path):
     from minimod_amd import synth
     bs = _batches(genome)

@@ -43,6 +43,7 @@ for seed in range(first, first + count):
             engs.append(e)
         h = ivs[0][3]
         buf = torch.zeros(engs[0].slab_words(h), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()   # (the fill runs on torch's stream, the slab kernels on the handle's own non-blocking one: not ordered otherwise)
         engs[0].slab_export(0, cut, h, buf.data_ptr()); engs[0].slab_clear(0, cut, h); engs[1].slab_add(0, cut, h, buf.data_ptr())
         got = {}
         for e in engs:
