@@ -91,6 +91,9 @@ def parse_args():
                                                           "`value` is the median repetition, `spread` has min / max")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-path leg (the same batches through mm_freq_submit, PCIe included) and the "
                                                                 "one-launch-per-step leg")
+    ap.add_argument("--e2e-gbases", type=float, default=0.0, help="opt-in, instead of the bench line: the STEADY-STATE end-to-end figure -- this many Gbases of "
+                                                                    "reads (30x of a genome share: 12 = BASELINE configs[3] / 8) as one BGZF BAM, through the product "
+                                                                    "CLI and through the CPU port, start-up included and excluded; prints its own JSON line")
     ap.add_argument("--mode", default="freq", choices=["freq", "view"],
                     help="freq = the headline metric (default); view = the same batches through `minimod view` (SURVEY.md 8f row 1), "
                          "rows ordered and left in HBM; an extra measurement, not the driver's contract line")
@@ -380,13 +383,119 @@ def self_launch(args):
         raise SystemExit(rc)
 
 
+def run_e2e_big(args):
+    """`--e2e-gbases G`: a job long enough that start-up does not matter.  G Gbases of the workload's reads at 30x over G/30
+    Gb of reference, written once as a BGZF BAM (filter fodder included) + FASTA; `minimod freq` (GPU) twice and the CPU port
+    once on the same files, every run a child process; the bedmethyl outputs compared byte for byte.  Nothing here touches
+    the GPU in this process."""
+    from minimod_amd import synth
+    from oracle import oracle as O
+    wl = WORKLOADS[args.config]
+    cores = os.cpu_count() or 1
+    threads = args.e2e_threads if args.e2e_threads > 0 else min(cores, 128)
+    bases_target = args.e2e_gbases * 1e9
+    region = max(1 << 20, int(bases_target / 30) // (1 << 20) * (1 << 20))
+    n_reads = int(bases_target / 15070)
+    plan = single_contig_plan(0, 1, region, HALO)
+    t0 = time.perf_counter()
+    refs = plan_references(plan, args.seed)
+    iv = plan["intervals"][0]
+    jobs = [(f, min(args.batch, n_reads - f)) for f in range(0, n_reads, args.batch)]
+
+    def gen(job):
+        first, n = job
+        return synth.batch(refs[0], first, n, seed=args.seed, contig_len=plan["contigs"][0][1], n_reads_total=n_reads, tid=0,
+                           region_begin=iv["read_begin"], region_len=iv["read_len"], with_order=False, **wl["gen"])
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > int(2.5 * bases_target) else None
+    tmp = tempfile.mkdtemp(prefix="mm_e2e_big_", dir=base)
+    try:
+        bam, fa = os.path.join(tmp, "reads.bam"), os.path.join(tmp, "ref.fa")
+        bases = 0
+        # generated and written in rounds of 64 batches (memory stays bounded), the pieces concatenated
+        with open(bam, "wb") as out:
+            for r0 in range(0, len(jobs), 64):
+                with ThreadPoolExecutor(max_workers=min(32, cores)) as ex:
+                    bs = list(ex.map(gen, jobs[r0:r0 + 64]))
+                bases += int(sum(b["n_bases"] for b in bs))
+                piece = os.path.join(tmp, "piece.bam")
+                synth.write_bam_rounds(piece, plan["contigs"], bs, first_round=r0 == 0, last_round=r0 + 64 >= len(jobs), first_read=r0 * args.batch, threads=min(32, cores))
+                with open(piece, "rb") as f:
+                    shutil.copyfileobj(f, out, 1 << 24)
+                os.remove(piece)
+        synth.write_fasta(fa, plan["contigs"][0][0], refs[0])
+        t_build = time.perf_counter() - t0
+        common = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(threads)]
+        cli = os.path.join(ROOT, "minimod_amd", "bin", "minimod")
+        cpu_cli = O.build_cpu_cli()
+
+        def run(cmd, out_path):
+            t = time.perf_counter()
+            r = subprocess.run(cmd + ["-o", out_path, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.perf_counter() - t
+            if r.returncode != 0:
+                raise SystemExit("end-to-end run failed: %s\n%s" % (" ".join(cmd), r.stderr.decode(errors="replace")[-2000:]))
+            return wall, r.stderr.decode(errors="replace")
+
+        def md5(path):
+            h = hashlib.md5()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            return h.hexdigest()
+        og, oc = os.path.join(tmp, "gpu.bed"), os.path.join(tmp, "cpu.bed")
+        # rows can tie on (contig, start) with several codes / --insertions / --haplotypes: the CPU port prints them in the fixed
+        # order, so the compared GPU run does too; the default run -- the reference's order, replayed on the host -- is timed beside it
+        tied = len(wl["mods"]) > 1 or bool(wl["eng"])
+        runs = [run([cli, "freq"] + (["--canonical-order"] if tied else []) + common, og) for _ in range(2)]
+        wall, err = min(runs, key=lambda x: x[0])
+        st = _stage_timers(err)
+        startup = st.get("reference", 0.0) + st.get("contexts", 0.0)
+        m = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with k_stream_reads\)", err)
+        w_cpu, err_cpu = run([cpu_cli] + common, oc)
+        st_cpu = _stage_timers(err_cpu)
+        res = {"metric": "minimod freq end to end, steady state", "unit": "Mbases/s", "bases": bases, "reads": n_reads, "reference_bases": region,
+               "bam_bytes": os.path.getsize(bam), "threads": threads, "cores": cores, "input_build_s": t_build,
+               "gpu_cli": {"value": bases / wall / 1e6, "value_without_startup": bases / max(wall - startup, 1e-9) / 1e6, "wall_s": wall,
+                           "wall_s_first_run": runs[0][0], "startup_s": startup, "stages_s": st,
+                           "launches": {"launches": int(m.group(1)), "batches": int(m.group(2)), "with_k_stream_reads": int(m.group(3))} if m else None,
+                           "cmd": "minimod freq " + " ".join(common) + " ref.fa reads.bam",
+                           "what": "whole child process (start, HIP initialisation, FASTA load + context kernels, BGZF/BAM decode, batches through "
+                                   "mm_freq_submit, finalize, bedmethyl written); value_without_startup leaves out the reference load and context "
+                                   "kernels (the part that does not grow with the reads)"},
+               "cpu_port": {"kind": "port", "value": bases / w_cpu / 1e6, "value_without_startup": bases / max(w_cpu - st_cpu.get("reference", 0.0) - st_cpu.get("contexts", 0.0), 1e-9) / 1e6,
+                            "wall_s": w_cpu, "stages_s": st_cpu, "cmd": "oracle/_build/freq_cpu " + " ".join(common) + " ref.fa reads.bam"},
+               "parity_vs_cpu": {"byte_identical": md5(og) == md5(oc) and os.path.getsize(og) == os.path.getsize(oc), "bytes": os.path.getsize(og)}}
+        if tied:
+            w_rp, err_rp = run([cli, "freq"] + common, os.path.join(tmp, "gpu_replay.bed"))
+            mr = re.search(r"Row order replay[^:]*: ([0-9.]+) sec", err_rp)
+            mp = re.search(r"Peak RAM: ([0-9.]+) GB", err_rp)
+            mp0 = re.search(r"Peak RAM: ([0-9.]+) GB", err)
+            res["reference_order_replay"] = {"wall_s": w_rp, "value": bases / w_rp / 1e6, "replay_s": float(mr.group(1)) if mr else None,
+                                             "peak_ram_gb": float(mp.group(1)) if mp else None, "peak_ram_gb_canonical": float(mp0.group(1)) if mp0 else None,
+                                             "same_rows_as_canonical": sorted(open(os.path.join(tmp, "gpu_replay.bed"), "rb").read().splitlines()) == sorted(open(og, "rb").read().splitlines())
+                                             if os.path.getsize(og) < (1 << 30) else None,
+                                             "what": "the default run of a tied configuration: a second handle in view mode delivers every call, the host replays the "
+                                                     "reference's hash table and sort (csrc/host/tieorder.c); --canonical-order skips it"}
+        print(json.dumps(res))
+        sys.stdout.flush()
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
+    if args.e2e_gbases > 0:
+        return run_e2e_big(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MM_BENCH_LAUNCH_ONLY"):   # the CPU test of the self-launch: what a rank was started with, nothing else
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world, "rank": rank, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}))
+        return None
     wl = WORKLOADS[args.config]
     if args.config == "C5" and args.reads == 100000:
         args.reads = wl["reads"]

@@ -78,6 +78,7 @@ struct Slot {
     // view mode: regional record buffers filled by the call kernels, then the ordering pipeline's buffers
     unsigned long long* d_vkeys = nullptr; size_t cap_vkeys = 0;
     unsigned long long* d_vvals = nullptr; size_t cap_vvals = 0;
+    unsigned int* d_vseq = nullptr; size_t cap_vseq = 0;     // per record: its place among its read's records, or 0xFFFFFFFF
     unsigned int* d_vcount = nullptr;      // [kViewRegions * kViewCountStride] + [1] selected rows
     unsigned int* h_vcount = nullptr;      // pinned copy
     unsigned int view_cap = 0;             // records per region
@@ -340,7 +341,7 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
     unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates
     const uint32_t nr = (uint32_t)b->n_reads;
     hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
-    hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vcount,
+    hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vcount,
                        s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
     const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
     const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
@@ -404,9 +405,10 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
         if (h->opts.view_cap > 0) want = (size_t)h->opts.view_cap;   // tests: force the overflow path
         if (want > s.view_cap) {
             if ((r = grow(h, (void**)&s.d_vkeys, &s.cap_vkeys, 8 * want * kViewRegions)) ||
-                (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)))
+                (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)) ||
+                (r = grow(h, (void**)&s.d_vseq, &s.cap_vseq, 4 * want * kViewRegions)))
                 return r;
-            s.view_cap = (unsigned int)std::min<size_t>(std::min(s.cap_vkeys, s.cap_vvals) / (8 * kViewRegions), 0xFFFFFFFFu / kViewRegions);
+            s.view_cap = (unsigned int)std::min<size_t>(std::min(std::min(s.cap_vkeys, s.cap_vvals) / 8, s.cap_vseq / 4) / kViewRegions, 0xFFFFFFFFu / kViewRegions);
         }
         // the ordering pass works on at most what the regions can hold
         const size_t cap_total = (size_t)s.view_cap * kViewRegions, nr = (size_t)std::max(b->n_reads, 1);
@@ -417,7 +419,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
             (r = grow(h, (void**)&s.d_vnewoff, &s.cap_vnewoff, 4 * (nr + 1))))
             return r;
         p.view = 1; p.view_cap = s.view_cap; p.view_keys = s.d_vkeys; p.view_vals = s.d_vvals; p.view_count = s.d_vcount;
-        p.view_read_count = s.d_vreadcount;
+        p.view_read_count = s.d_vreadcount; p.view_seq = s.d_vseq;
         HIPCHK(hipMemsetAsync(s.d_vcount, 0, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), st));
         HIPCHK(hipMemsetAsync(s.d_vreadcount, 0, 4 * nr, st));
     }
@@ -740,7 +742,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
                       s.d_plan, s.d_plan_stream, s.d_plan_state,
-                      s.d_vkeys, s.d_vvals, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
+                      s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
@@ -1609,9 +1611,10 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
         size_t want = (size_t)worst + worst / 4 + 1024;
         int r;
         if ((r = grow(h, (void**)&s.d_vkeys, &s.cap_vkeys, 8 * want * kViewRegions)) ||
-            (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)))
+            (r = grow(h, (void**)&s.d_vvals, &s.cap_vvals, 8 * want * kViewRegions)) ||
+            (r = grow(h, (void**)&s.d_vseq, &s.cap_vseq, 4 * want * kViewRegions)))
             return r;
-        s.view_cap = (unsigned int)std::min<size_t>(std::min(s.cap_vkeys, s.cap_vvals) / (8 * kViewRegions), 0xFFFFFFFFu / kViewRegions);
+        s.view_cap = (unsigned int)std::min<size_t>(std::min(std::min(s.cap_vkeys, s.cap_vvals) / 8, s.cap_vseq / 4) / kViewRegions, 0xFFFFFFFFu / kViewRegions);
         mm_batch_t again = s.last_batch;
         if ((r = launch_k1(h, s, &again, st))) return r;
     }

@@ -144,6 +144,8 @@ struct DevParams {
     unsigned long long* view_vals;   // [kViewRegions][view_cap]  code << 56 | ins_offset << 40 | group << 29 | implicit << 28 | fastq read_pos
     unsigned int* view_count;        // [kViewRegions * kViewCountStride]; counts past view_cap mean "grow and run again"
     unsigned int* view_read_count;   // [n_reads] records per read (sizes the per-read segments of the ordering pass)
+    unsigned int* view_seq;          // [kViewRegions][view_cap] the record's place among its read's records when the kernel that made it knows
+                                     // (k_stream_reads: a wavefront makes a read's records in order), else 0xFFFFFFFF
     // the control words (queue, error summary, tile counters) the slot's NEXT launch will use: reset by this launch's
     // last kernel, which saves a host-to-device copy per batch (a slot alternates between two sets)
     unsigned int* ctl_next;
@@ -238,7 +240,33 @@ __device__ __forceinline__ void view_append(const DevParams& p, uint32_t region,
         p.view_keys[at] = ((unsigned long long)prob << 56) | ((unsigned long long)ridx << 28) | (unsigned long long)rel_pos;
         p.view_vals[at] = ((unsigned long long)code << 56) | ((unsigned long long)(ins_off & 0xFFFFu) << 40) |
                           ((unsigned long long)group << 29) | ((unsigned long long)implicit << 28) | (unsigned long long)fq_pos;
+        p.view_seq[at] = 0xFFFFFFFFu;
     }
+}
+// The same from a wavefront that makes ALL records of a read, in the order the reference meets the calls (k_stream_reads): called
+// by every lane (emit: this lane has a record), `seq` = records of the read so far.  A record carries its place in the read, so
+// the ordering pass can put it there without cursor atomics and finds the read's records in call order.  Returns the records made.
+__device__ __forceinline__ uint32_t view_append_seq(const DevParams& p, uint32_t region, uint32_t ridx, bool emit, uint32_t rel_pos, uint32_t fq_pos,
+                                                    uint32_t ins_off, uint32_t code, uint32_t group, uint32_t implicit, uint32_t prob, uint32_t seq) {
+    const uint64_t m = __ballot(emit);
+    if (!m) return 0u;
+    const unsigned int cnt = (unsigned int)__popcll(m);
+    unsigned int base = 0;
+    if (lane_id() == 0) {
+        base = atomicAdd(p.view_count + region * kViewCountStride, cnt);
+        const unsigned int room = base < p.view_cap ? p.view_cap - base : 0u;
+        atomicAdd(p.view_read_count + ridx, cnt < room ? cnt : room);
+    }
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned int rank = (unsigned int)__popcll(m & lanemask_lt());
+    if (emit && base + rank < p.view_cap) {
+        const size_t at = (size_t)region * p.view_cap + base + rank;
+        p.view_keys[at] = ((unsigned long long)prob << 56) | ((unsigned long long)ridx << 28) | (unsigned long long)rel_pos;
+        p.view_vals[at] = ((unsigned long long)code << 56) | ((unsigned long long)(ins_off & 0xFFFFu) << 40) |
+                          ((unsigned long long)group << 29) | ((unsigned long long)implicit << 28) | (unsigned long long)fq_pos;
+        p.view_seq[at] = seq + rank;
+    }
+    return cnt;
 }
 // A wave-uniform address of data that no wave writes during the launch, read through the scalar cache: the value lands in
 // scalar registers (no vector register per load in flight, no readfirstlane) and several loads overlap freely.  The

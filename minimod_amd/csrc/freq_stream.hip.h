@@ -158,6 +158,7 @@ struct KF {
     int32_t pos, rev, ridx_cur;
     int32_t hp, hpi;            // kIns: the read's haplotype tag (-1: haplotypes off), its dense plane (-1: none)
     uint32_t v_region, v_gord;   // view: append region of the wavefront, ordinal of the group at hand
+    uint32_t v_seq;              // view: records of the read so far
     // the group
     int32_t ncg;
     bool dot_group;             // a '.' group: unlisted bases are calls too
@@ -595,7 +596,28 @@ struct KF {
                     if (kStats) st_look++;
                 }
                 call = call && in_ctx;
-                if (call) {
+                if (kView) {
+                    // `minimod view`: a call that passes the tests is a record (add_view_entry, mod.c:931-946: no threshold, the ML byte
+                    // itself; implicit calls carry probability 0, mod.c:1281-1283, :1361-1363).  Every lane takes part in the append:
+                    // the wavefront numbers the read's records in the order it makes them.
+                    const uint32_t refcode = w & 31u;
+                    for (int m = 0; m < ncg; m++) {
+                        const int ci = gcode_at(m);
+                        if (ci < 0) continue;
+                        const uint32_t cinfo = cinfo_at(m);
+                        bool emit = call && (gsite == nullptr || ((cinfo >> 18) & 1u) || refcode == code);
+                        uint32_t prob = 0;
+                        if (expl) {
+                            const uint64_t ml_idx = (kTwinOK && tw) ? (uint64_t)ml_start + kidx + (uint32_t)m * tw
+                                                                     : (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                            if (emit && ml_idx >= ml_len) { err = MM_E_MLIDX; emit = false; }
+                            if (emit) prob = m == 0 ? ml0 : (uint32_t)ml[ml_idx];
+                            if (kStats && emit) st_ml++;
+                        }
+                        v_seq = uniu(v_seq + view_append_seq(p, v_region, (uint32_t)ridx_cur, emit, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci,
+                                                             v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), expl ? 0u : 1u, prob, v_seq));
+                    }
+                } else if (call) {
                     const uint32_t refcode = w & 31u;
                     for (int m = 0; m < ncg; m++) {
                         const int ci = gcode_at(m);
@@ -604,22 +626,14 @@ struct KF {
                         const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
                         if (gsite != nullptr && !(((cinfo >> 18) & 1u) || refcode == code)) continue;   // the base test (mod.c:1163-1164); a dense class has none
                         int is_mod = 0;
-                        if (kView && !expl) {   // mod.c:1281-1283, :1361-1363: implicit calls carry probability 0
-                            view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), 1u, 0u);
-                            continue;
-                        }
                         if (expl) {
                             const uint64_t ml_idx = (kTwinOK && tw) ? (uint64_t)ml_start + kidx + (uint32_t)m * tw
                                                                      : (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
                             if (ml_idx >= ml_len) { err = MM_E_MLIDX; continue; }   // (not `break`: a divergent exit would make m, and all that
-                                                                                     // hangs on it -- the code's table word, its plane, the 64-bit
+                                                                                     // hangs on it -- the code's table word, its slot, the 64-bit
                                                                                      // counter offset -- vector values; the read fails either way)
                             const int mv = m == 0 ? (int)ml0 : (int)ml[ml_idx];
                             if (kStats) st_ml++;
-                            if (kView) {   // mod.c:1194-1196: no threshold, the ML byte itself
-                                view_append(p, v_region, (uint32_t)ridx_cur, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci, v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), 0u, (uint32_t)mv);
-                                continue;
-                            }
                             if (mv >= t_hi) is_mod = 1;
                             else if (mv <= t_lo) is_mod = 0;
                             else continue;
@@ -734,19 +748,29 @@ struct KF {
     __device__ __forceinline__ uint32_t twin_lists(uint32_t a, uint32_t b, uint32_t len) const {
         const uint32_t lane = (uint32_t)lane_id();
         uint32_t bad = 0, commas = 0;
-        for (uint32_t off = 0; off < len; off += 256u) {
-            const uint32_t o = off + 4u * lane;
-            const uint32_t wa = mm_dword(mm, a + len, a + o), wb = mm_dword(mm, b + len, b + o);
-            const uint32_t wp = mm_dword(mm, a + len, a + o - 1u);                 // the same four characters' left neighbours (a >= 1: a header is in front)
-            const uint32_t vm = o >= len ? 0u : (len - o >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * (len - o))) - 1u)));   // bytes inside the list
-            const uint32_t ya = wa ^ 0x2C2C2C2Cu, yp = wp ^ 0x2C2C2C2Cu, yd = wa ^ 0x30303030u;
-            const uint32_t ca = ~(((ya & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ya) & 0x80808080u;   // commas
-            const uint32_t cp = ~(((yp & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yp) & 0x80808080u;   // commas among the left neighbours
-            const uint32_t nd = (((yd & 0x7F7F7F7Fu) + 0x76767676u) | yd) & 0x80808080u;     // not a digit
-            bad |= (wa ^ wb) | ((nd & ~ca) & vm) | (ca & cp & vm);
-            if (o <= len - 1u && len - 1u < o + 4u) bad |= ca & (0x80u << (8u * (len - 1u - o)));   // the last character is a digit
-            if (o == 0u) bad |= (~ca) & 0x80u;                                                    // the first one a comma
-            commas += (uint32_t)__popc(ca & vm);
+        // 1024 characters a trip: the twelve loads of a trip are requested together (a list of a 15 kb read is one trip)
+        for (uint32_t off0 = 0; off0 < len; off0 += 1024u) {
+            uint32_t va[4], vb[4], vp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t o = off0 + 256u * (uint32_t)u + 4u * lane;
+                va[u] = mm_dword(mm, a + len, a + o); vb[u] = mm_dword(mm, b + len, b + o);
+                vp[u] = mm_dword(mm, a + len, a + o - 1u);                              // the same four characters' left neighbours (a >= 1: a header is in front)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t o = off0 + 256u * (uint32_t)u + 4u * lane;
+                const uint32_t wa = va[u], wb = vb[u], wp = vp[u];
+                const uint32_t vm = o >= len ? 0u : (len - o >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * (len - o))) - 1u)));   // bytes inside the list
+                const uint32_t ya = wa ^ 0x2C2C2C2Cu, yp = wp ^ 0x2C2C2C2Cu, yd = wa ^ 0x30303030u;
+                const uint32_t ca = ~(((ya & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ya) & 0x80808080u;   // commas
+                const uint32_t cp = ~(((yp & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yp) & 0x80808080u;   // commas among the left neighbours
+                const uint32_t nd = (((yd & 0x7F7F7F7Fu) + 0x76767676u) | yd) & 0x80808080u;     // not a digit
+                bad |= ((wa ^ wb) & (vm >> 7) * 0xFFu) | ((nd & ~ca) & vm) | (ca & cp & vm);
+                if (o <= len - 1u && len - 1u < o + 4u) bad |= ca & (0x80u << (8u * (len - 1u - o)));   // the last character is a digit
+                if (o == 0u) bad |= (~ca) & 0x80u;                                                    // the first one a comma
+                commas += (uint32_t)__popc(ca & vm);
+            }
         }
         if (__ballot(bad != 0u)) return 0u;
         return lane_valu(wave_incl_scan(commas), 63);
@@ -785,7 +809,7 @@ struct KF {
         const int64_t ctg_len = scalar_load(p.ctg_len + tid_c);
         const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c);
         int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
-        d_n = 0; c_n = 0; rank_ok = 0;
+        d_n = 0; c_n = 0; rank_ok = 0; v_seq = 0;
         if (st == 0) {
             // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, the checks reduced to what a
             // clean record passes outright (anything else is the tile pipeline's to judge op by op) -- and, on the way, the

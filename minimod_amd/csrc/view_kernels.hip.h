@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_view_offsets(const unsigned int* __rest
 
 // regions -> per-read segments
 __global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ rv,
+                                                      const unsigned int* __restrict__ rseq,
                                                       const unsigned int* __restrict__ region_counts, unsigned int cap, uint32_t read_mask,
                                                       const unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
                                                       unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals) {
@@ -72,13 +73,17 @@ __global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* 
         for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
             unsigned long long k = rk[base + i], v = rv[base + i];
             uint32_t read = (uint32_t)(k >> 28) & read_mask;
-            // neighbours in a region mostly belong to one read (a tile appends its records together): one cursor atomic per
-            // distinct read of the wave instead of one per record
-            unsigned int slot = 0;
-            bool pending = true;
+            // a record of k_stream_reads knows its place among its read's records: no cursor, and the read's records arrive in the
+            // order they were made.  The others: neighbours in a region mostly belong to one read (a tile appends its records
+            // together): one cursor atomic per distinct read of the wave instead of one per record
+            const unsigned int sq = rseq[base + i];
+            unsigned int slot = sq != 0xFFFFFFFFu ? offsets[read] + sq : 0u;
+            bool pending = sq == 0xFFFFFFFFu;
             while (pending) {
-                uint32_t first = uniu(read);   // the first still-pending lane's read
-                bool same = read == first;
+                const uint64_t pm = __ballot(pending);
+                if (!pm) break;
+                const uint32_t first = lane_valu(read, __ffsll((unsigned long long)pm) - 1);   // the first still-pending lane's read
+                bool same = pending && read == first;
                 uint64_t m = __ballot(same);
                 unsigned int at = 0;
                 int leader = __ffsll((unsigned long long)m) - 1;
@@ -278,7 +283,17 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
         wave_sync();
         for (uint32_t i = lane; i < n; i += 64) Pw[i] = view_pack(keys[off + i], vals[off + i], i);
         wave_sync();
-        view_bitonic1<64>(Pw, n, lane);
+        // A read whose records arrived in call order (k_stream_reads) with one code a call is sorted already -- by position for a
+        // forward read, backwards for a reverse one: the network is only run when neither holds (keys without the index bits)
+        bool asc = true, desc = true;
+        for (uint32_t i = lane; i + 1u < n; i += 64) { const unsigned long long a = Pw[i] >> 12, b = Pw[i + 1u] >> 12; asc = asc && a < b; desc = desc && a > b; }
+        const bool all_asc = !__ballot(!asc), all_desc = !__ballot(!desc);
+        if (!all_asc && all_desc) {
+            for (uint32_t i = lane; 2u * i + 1u < n; i += 64) { const unsigned long long a = Pw[i], b = Pw[n - 1u - i]; Pw[i] = b; Pw[n - 1u - i] = a; }
+            wave_sync();
+        } else if (!all_asc) {
+            view_bitonic1<64>(Pw, n, lane);
+        }
         uint32_t dropped = view_emit_rows1<64>(Pw, keys + off, vals + off, n, lane, r, reads[r].pos, rows + off, ordinal);
         uint32_t tot = lane_valu(wave_incl_scan(dropped), 63);
         if (lane == 0) {

@@ -229,6 +229,41 @@ def write_bam_parallel(path, contigs, batches, filter_fodder=True, threads=8):
             os.remove(pp)
 
 
+def write_bam_rounds(path, contigs, batches, first_round=True, last_round=True, first_read=0, filter_fodder=True, threads=8):
+    """One ROUND of a BAM written in several rounds (a file too big to hold as batches at once): like write_bam_parallel, with the
+    header only in the first round's first piece and the EOF block only behind the last round's last piece; the rounds' files
+    concatenated are the BAM."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    from .engine import batch_struct
+    L = host_lib()
+    names = (ctypes.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
+    lens = (ctypes.c_int64 * len(contigs))(*[int(l) for _, l in contigs])
+    firsts, acc = [], first_read
+    for b in batches:
+        firsts.append(acc)
+        acc += len(b["reads"])
+    nb = len(batches)
+
+    def piece(i):
+        flags = (0 if (first_round and i == 0) else 1) | (0 if (last_round and i == nb - 1) else 2)
+        pp = "%s.piece%d" % (path, i)
+        w = L.mm_bam_writer_open_piece(pp.encode(), len(contigs), names, lens, flags, firsts[i])
+        if not w:
+            raise IOError("cannot create %s" % pp)
+        bs = batch_struct(batches[i])
+        if L.mm_bam_writer_put_batch(w, ctypes.byref(bs), int(filter_fodder)) or L.mm_bam_writer_close(w):
+            raise IOError("write failed")
+        return pp
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        pieces = list(ex.map(piece, range(nb)))
+    with open(path, "wb") as out:
+        for pp in pieces:
+            with open(pp, "rb") as f:
+                shutil.copyfileobj(f, out, 1 << 24)
+            os.remove(pp)
+
+
 def write_fasta(path, name, seq):
     seq = np.ascontiguousarray(seq)
     if host_lib().mm_write_fasta(path.encode(), name.encode(), seq.ctypes.data, len(seq)):

@@ -116,6 +116,21 @@ def test_bench_other_workloads_run(config):
         assert d["roofline"]["side_list_updates_per_pass"] > 0
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): bench.py starts the two ranks itself as fresh
+    child processes (the parent never touches the GPU) and rank 0's line says n_gpus 2.  (gloo: the two ranks share the one GPU
+    of the test box; with RCCL every rank needs a GPU of its own.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "6000", "--batch", "1024", "--steps", "4",
+                        "--warmup", "1", "--reps", "2", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["final_reduce"]["ranks"] == 2 and d["final_reduce"]["backend"] == "gloo" and d["value"] > 0
+    assert d["config"]["sharding"].startswith("24 contigs")
+
+
 def test_bench_view_results_match_oracle(tmp_path):
     from oracle import oracle as O
     dump = str(tmp_path / "view.npz")

@@ -298,33 +298,40 @@ def test_random_reads_against_the_oracle(seed):
         assert st["stream_done"] == short and st["stream_to_tiles"] == 0 and st["stream_to_fused"] == 0, st
 
 
-def test_full_size_timed_launch_equals_the_oracle(tmp_path):
-    """BASELINE.json's C2 at full size, through exactly what bench.py times: 100 000 ONT-shape reads as 25 device-resident
-    -K 4096 windows gathered into one launch (every read goes through k_stream_reads there, the 100 kb ones too).  The rows
-    the timed engine holds after one pass equal the oracle's over the same batches, row for row."""
+@pytest.mark.parametrize("config", ["C2", "C3", "C5"])
+def test_full_size_timed_launch_equals_the_oracle(config, tmp_path):
+    """BASELINE.json's workloads at full size, through exactly what bench.py times: C2 = 100 000 ONT-shape reads as 25
+    device-resident -K 4096 windows gathered into one launch (every read goes through k_stream_reads there, the 100 kb ones
+    too); C3 = 100 000 HiFi-shape reads, -c m[CG],h[CG] -m 0.8,0.7 (twin groups); C5 = 66 000 reads at 200x on 5 Mb with
+    --haplotypes --insertions (the kIns instantiation, 50 million side rows).  The rows the timed engine holds after one pass
+    equal the oracle's over the same batches, row for row."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
+    wl = bench.WORKLOADS[config]
+    reads = wl.get("reads", 100000)
+    nb = (reads + 4095) // 4096
     dump = str(tmp_path / "timed.npz")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "25", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-extra",
-                        "--dump-timed", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", str(nb), "--warmup", "0", "--reps", "2", "--no-e2e",
+                        "--no-cpu-baseline", "--no-extra", "--dump-timed", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert d["dump_timed"]["batches"] == 25 and d["roofline"]["launches"] == 1
+    assert d["dump_timed"]["batches"] == nb and d["roofline"]["launches"] == 1
     rt = d["config"]["routing"]
-    assert rt["reads"] == 100000 and rt["handed_to_the_fused_kernel"] == 0
+    assert rt["reads"] == reads and rt["handed_to_the_fused_kernel"] == 0 and rt["reads_done_by_k_stream_reads"] >= 0.99 * reads
     got = np.load(dump)["rows"]
-    plan = bench.shard_plan(0, 1)
+    region = wl.get("region", bench.INTERVAL)
+    plan = bench.shard_plan(0, 1, region)
     ref = bench.gen_reference(plan, 0x5EED)
-    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc = O.Oracle([(c, x) for c, x, _ in wl["mods"]], [t for _, _, t in wl["mods"]], ["chrS"], **wl["eng"])
     orc.add_contig("chrS", ref)
-    for bi in range(25):
-        orc.process(bench.gen_batch(ref, plan, 0, 0x5EED, 100000, 4096, bi), threads=os.cpu_count() or 1)
+    for bi in range(nb):
+        orc.process(bench.gen_batch(ref, plan, 0, 0x5EED, reads, 4096, bi, **wl["gen"]), threads=os.cpu_count() or 1)
     want = orc.rows()
     assert len(want) > 500000 and len(got) == len(want)
-    for k in ("pos", "strand", "n_called", "n_mod"):
-        assert (got[k] == want[k]).all(), k
+    for a, b in (("pos", "pos"), ("strand", "strand"), ("code", "code"), ("ins_offset", "ins_off"), ("hp", "hp"), ("n_called", "n_called"), ("n_mod", "n_mod")):
+        assert (got[a] == want[b]).all(), a
 
 
 @pytest.mark.parametrize("flag", [0, 16], ids=["fwd", "rev"])

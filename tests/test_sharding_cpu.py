@@ -212,3 +212,19 @@ def test_world2_genome_sharding_equals_unsharded(tmp_path):
     own0 = _genome_oracle([_genome_reads(0, plans[0], refs_all[0])], refs_all[0])
     assert int(((own0["tid"] == 1) & (own0["pos"] >= (1 << 20))).sum()) > 0      # rank 0 really has calls past the cut
     assert len(want_l) > 1000 and sorted(got) == want_l
+
+
+def test_bench_gpus_flag_launches_the_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (fresh child processes, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 set) and passes rank 0's line on; under an external launcher (WORLD_SIZE set) it does not."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MM_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d == {"launch_only": True, "n_gpus": 4, "rank": 0, "local_rank": 0, "master": "127.0.0.1"}
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env2)
+    assert r.returncode == 0 and json.loads(r.stdout.decode().strip().splitlines()[-1])["n_gpus"] == 2

@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT"; do
   tagc=$(echo $c | tr ' ' '_')
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/p -o k -- python3 $root/bench.py --steps 32 --warmup 0 --no-cpu-baseline --no-e2e --no-extra "$@" > /dev/null 2> $out/err_$tagc.txt
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/p -o k -- python3 $root/bench.py --steps 32 --warmup 0 --reps 1 --no-cpu-baseline --no-e2e --no-extra "$@" > /dev/null 2> $out/err_$tagc.txt
   cp $out/p/k_counter_collection.csv $out/cc_$tagc.csv 2>/dev/null
   rm -rf $out/p
 done
