@@ -1012,6 +1012,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             k.np = std::max(np[c], 1);
             k.dense = (opts->insertions || std::strcmp(opts->mods[first_mod[c]].context, "*") == 0) ? 1 : 0;
             k.site[0] = k.site[1] = nullptr;
+            k.stride = h->ref_kind == 0 ? 2 : 1;   // four-bit reference words: the site words carry the bases too
+            k.pad = 0;
             k.base = words;
             if (k.dense) {
                 k.nsites = plane_len;
@@ -1024,7 +1026,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 uint32_t* tsum = nullptr;
                 const int64_t n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
                 for (int sd = 0; sd < 2; sd++) {
-                    if (dev_alloc(h, (void**)&site[sd], sizeof(uint2) * (size_t)std::max<int64_t>(n_blocks, 1))) return fail(h, "site index alloc failed");
+                    if (dev_alloc(h, (void**)&site[sd], sizeof(uint2) * (size_t)k.stride * (size_t)std::max<int64_t>(n_blocks, 1))) return fail(h, "site index alloc failed");
                     h->d_site_arrays.push_back(site[sd]);
                     if (hipMalloc((void**)&cnt[sd], 4 * (size_t)std::max<int64_t>(n_blocks, 1)) != hipSuccess) return fail(h, "site index alloc failed");
                 }
@@ -1033,12 +1035,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 bool ok = true;
                 if (n_blocks > 0) {
                     const int blocks = (int)std::min<int64_t>((n_blocks + 255) / 256, (int64_t)h->n_cu * 16);
-                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, first_mod[c], site[0], site[1], cnt[0], cnt[1]));
+                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, first_mod[c], (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
                     for (int sd = 0; sd < 2 && ok; sd++) {
                         (void)hipMemsetAsync(tsum + n_tiles, 0, 4, h->stream);
                         hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum);
                         hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, tsum, (unsigned long long)n_tiles + 1ull);
-                        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum, site[sd]);
+                        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum, site[sd], (int)k.stride);
                         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total[sd], tsum + n_tiles, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
                              hipStreamSynchronize(h->stream) == hipSuccess;
                     }
@@ -1054,7 +1056,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                          hipMemcpy(d_g, gq.data(), 8 * gq.size(), hipMemcpyHostToDevice) == hipSuccess;
                     for (int sd = 0; sd < 2 && ok; sd++) {
                         rk[sd].resize(gq.size());
-                        hipLaunchKernelGGL(k_rank_at, dim3((unsigned)((gq.size() + 255) / 256)), dim3(256), 0, h->stream, site[sd], d_g, (int)gq.size(), n_blocks, total[sd], d_o);
+                        hipLaunchKernelGGL(k_rank_at, dim3((unsigned)((gq.size() + 255) / 256)), dim3(256), 0, h->stream, site[sd], (int)k.stride, d_g, (int)gq.size(), n_blocks, total[sd], d_o);
                         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(rk[sd].data(), d_o, 4 * gq.size(), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
                              hipStreamSynchronize(h->stream) == hipSuccess;
                     }

@@ -63,6 +63,9 @@ struct DevClass {
     int64_t nsites;         // sites per (haplotype plane, strand) block: the larger of the two strands' counts
     int32_t np;             // code planes of the class, side by side per site
     int32_t dense;
+    int32_t stride;         // uint2 units per site word: 1, or 2 when the word also carries its 32 positions' bases, two bits each
+                            // (handles with four-bit reference words: k_stream_reads then needs ONE gather per call, not two)
+    int32_t pad;
 };
 __device__ __forceinline__ uint32_t site_rank(uint2 w, uint32_t bit) { return w.y + (uint32_t)__popc(w.x & ((1u << bit) - 1u)); }
 
@@ -290,7 +293,7 @@ __device__ __forceinline__ unsigned long long* counter_word(const DevParams& p, 
     const int c = p.cls_of_mod[dc.req];
     const DevClass k = p.classes[c];
     int64_t r = g;
-    if (!k.dense) { const uint2 w = k.site[rev][g >> 5]; r = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+    if (!k.dense) { const uint2 w = k.site[rev][(g >> 5) * k.stride]; r = (int64_t)site_rank(w, (uint32_t)g & 31u); }
     return p.counters + k.base + (((int64_t)(hpi * 2 + rev) * k.nsites) + p.adj[((int64_t)tid * p.n_classes + c) * 2 + rev] + r) * k.np + dc.slot;
 }
 // value of lane `l` (wave-uniform l) as a wave-uniform scalar
@@ -1152,17 +1155,24 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
 // which positions of the reference-word space are sites of a context class: bit (5 + 2 * mod) / (6 + 2 * mod) of the reference
 // words of the class's first mod (bits 2 / 3 of the four-bit words), 32 positions a word, and how many a block holds
 template <typename RefWord>
-__global__ __launch_bounds__(256) void k_site_bits(const void* __restrict__ refw, int64_t n_blocks, int mod, uint2* __restrict__ fwd,
+__global__ __launch_bounds__(256) void k_site_bits(const void* __restrict__ refw, int64_t n_blocks, int mod, int stride, uint2* __restrict__ fwd,
                                                    uint2* __restrict__ rev, uint32_t* __restrict__ cnt_fwd, uint32_t* __restrict__ cnt_rev) {
     const typename RefLoad<RefWord>::Base rw = RefLoad<RefWord>::from(refw, 0);
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x) {
         uint32_t f = 0, r = 0;
+        unsigned long long bases = 0;   // A C G T = 0 1 2 3 (the words' base bits 0-3 are one-hot; other letters never lie in a match)
         for (int k = 0; k < 32; k++) {
             const uint32_t w = RefLoad<RefWord>::at(rw, b * 32 + k);
             f |= ((w >> (5 + 2 * mod)) & 1u) << k;
             r |= ((w >> (6 + 2 * mod)) & 1u) << k;
+            const uint32_t b2 = (w & 2u) ? 1u : ((w & 4u) ? 2u : ((w & 8u) ? 3u : 0u));
+            bases |= (unsigned long long)b2 << (2 * k);
         }
-        fwd[b].x = f; rev[b].x = r;
+        fwd[b * stride].x = f; rev[b * stride].x = r;
+        if (stride == 2) {
+            fwd[b * 2 + 1] = make_uint2((uint32_t)bases, (uint32_t)(bases >> 32));
+            rev[b * 2 + 1] = make_uint2((uint32_t)bases, (uint32_t)(bases >> 32));
+        }
         cnt_fwd[b] = (uint32_t)__popc(f); cnt_rev[b] = (uint32_t)__popc(r);
     }
 }
@@ -1179,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restri
     __syncthreads();
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ cnt, int64_t n, const uint32_t* __restrict__ tile_offsets, uint2* __restrict__ site) {
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ cnt, int64_t n, const uint32_t* __restrict__ tile_offsets, uint2* __restrict__ site, int stride) {
     __shared__ uint32_t wsum[4];
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1192,17 +1202,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
         __syncthreads();
         uint32_t before = run + incl - c;
         for (int w = 0; w < wv; w++) before += wsum[w];
-        if (i < n) site[i].y = before;
+        if (i < n) site[i * stride].y = before;
         run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
 }
 // rank of a few positions (segment boundaries): out[i] = sites of the strand in front of g[i]
-__global__ void k_rank_at(const uint2* __restrict__ site, const int64_t* __restrict__ g, int n, int64_t n_blocks, uint32_t total, uint32_t* __restrict__ out) {
+__global__ void k_rank_at(const uint2* __restrict__ site, int stride, const int64_t* __restrict__ g, int n, int64_t n_blocks, uint32_t total, uint32_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t b = g[i] >> 5;
-    out[i] = b >= n_blocks ? total : site_rank(site[b], (uint32_t)g[i] & 31u);
+    out[i] = b >= n_blocks ? total : site_rank(site[b * stride], (uint32_t)g[i] & 31u);
 }
 
 // ---------------------------------------------------------------------------------- K2
@@ -1249,7 +1259,7 @@ __device__ __forceinline__ uint32_t site_rows(const K2Params& P, int tid, int64_
             if (c != last_c) {
                 last_c = c;
                 if (k.dense) { is_site = true; rk = g; }
-                else { const uint2 w = k.site[strand][g >> 5]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+                else { const uint2 w = k.site[strand][(g >> 5) * k.stride]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
             }
             if (!is_site) continue;
             const int64_t a = P.adj[((int64_t)tid * P.n_classes + c) * 2 + strand] + rk;
@@ -1318,7 +1328,7 @@ __global__ void k_slab_op(const K2Params P, int op, int tid, int64_t begin, int6
         const int64_t g = P.ref_base[tid] + begin + j;
         bool is_site = true;
         int64_t rk = g;
-        if (!k.dense) { const uint2 w = k.site[strand][g >> 5]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+        if (!k.dense) { const uint2 w = k.site[strand][(g >> 5) * k.stride]; is_site = (w.x >> ((uint32_t)g & 31u)) & 1u; rk = (int64_t)site_rank(w, (uint32_t)g & 31u); }
         unsigned long long* word = cnt + k.base + (((int64_t)(hp * 2 + strand) * k.nsites) + P.adj[((int64_t)tid * P.n_classes + c) * 2 + strand] + rk) * k.np + P.plane_slot[pl];
         if (op == 0) buf[i] = is_site ? *word : 0ull;
         else if (op == 2) { if (is_site) *word = 0ull; }

@@ -584,11 +584,21 @@ struct KF {
                 uint32_t site = (uint32_t)ref_pos;
                 if (call && gsite != nullptr) {
                     const int64_t gp = ref_base_g + (int64_t)(uint32_t)ref_pos;
+                    uint2 sw;
 #ifndef MM_ABL_NOREF
-                    const uint2 sw = gsite[gp >> 5];
-                    w = RefLoad<RefWord>::at(rwb, (int64_t)(uint32_t)ref_pos);
+                    if (std::is_same<RefWord, RefNib>::value) {
+                        // four-bit reference words (one requested mod): the site word carries its 32 positions' bases as well -- ONE
+                        // 16-byte gather answers context, rank and base
+                        const uint4 s4 = *reinterpret_cast<const uint4*>(gsite + 2 * (gp >> 5));
+                        sw = make_uint2(s4.x, s4.y);
+                        const uint32_t bsel = ((uint32_t)gp & 31u) * 2u;
+                        w = 1u << (((bsel < 32u ? s4.z >> bsel : s4.w >> (bsel - 32u))) & 3u);
+                    } else {
+                        sw = gsite[gp >> 5];
+                        w = RefLoad<RefWord>::at(rwb, (int64_t)(uint32_t)ref_pos);
+                    }
 #else
-                    const uint2 sw = make_uint2(0xFFFFFFFFu, (uint32_t)(gp >> 5) * 32u);
+                    sw = make_uint2(0xFFFFFFFFu, (uint32_t)(gp >> 5) * 32u);
                     w = 0xFFFFFFE0u | (code & 31u) | ((uint32_t)ref_pos & 0u);
 #endif
                     in_ctx = (sw.x >> ((uint32_t)gp & 31u)) & 1u;

@@ -3,6 +3,7 @@
 # usage: tools/cli_profile.sh <out dir> [batches of 4096 reads] [extra CLI flags...]
 out=$1; nb=${2:-25}; shift; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
+case "$out" in /*) ;; *) out=$PWD/$out;; esac
 mkdir -p $out /tmp/clip
 cd /tmp && export TMPDIR=/tmp
 python3 - <<PY
