@@ -79,6 +79,7 @@ struct Slot {
     unsigned long long* d_vkeys = nullptr; size_t cap_vkeys = 0;
     unsigned long long* d_vvals = nullptr; size_t cap_vvals = 0;
     unsigned int* d_vseq = nullptr; size_t cap_vseq = 0;     // per record: its place among its read's records, or 0xFFFFFFFF
+    uint32_t* d_vtile = nullptr; size_t cap_vtile = 0;        // tile sums of the offsets scan
     unsigned int* d_vcount = nullptr;      // [kViewRegions * kViewCountStride] + [1] selected rows
     unsigned int* h_vcount = nullptr;      // pinned copy
     unsigned int view_cap = 0;             // records per region
@@ -340,7 +341,16 @@ K2Params k2_params(mm_freq* h) {
 int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st) {
     unsigned int* tail = s.d_vcount + kViewRegions * kViewCountStride;   // [0] rows dropped as duplicates
     const uint32_t nr = (uint32_t)b->n_reads;
-    hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
+    if (nr <= 8192u) {
+        hipLaunchKernelGGL(k_view_offsets, dim3(1), dim3(256), 0, st, s.d_vreadcount, nr, s.d_voff, s.d_vcursor);
+    } else {   // a gathered launch: the scan in tiles
+        const uint32_t nt = (nr + kScanTile - 1) / kScanTile;
+        { int r = grow(h, (void**)&s.d_vtile, &s.cap_vtile, 4 * ((size_t)nt + 2)); if (r) return r; }
+        HIPCHK(hipMemsetAsync(s.d_vtile + nt, 0, 4, st));
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3(nt), dim3(256), 0, st, s.d_vreadcount, (int64_t)nr, s.d_vtile);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st, s.d_vtile, (unsigned long long)nt + 1ull);
+        hipLaunchKernelGGL(k_view_offsets_apply, dim3(nt), dim3(256), 0, st, s.d_vreadcount, nr, s.d_vtile, nt, s.d_voff, s.d_vcursor);
+    }
     hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vcount,
                        s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
     const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
@@ -742,7 +752,7 @@ void mm_freq_destroy(mm_freq_t* h) {
         void* ps[] = {s.d_reads, s.d_cigar, s.d_seq, s.d_mm, s.d_ml, s.d_order, s.d_status, s.d_spill, s.d_ctl, s.d_tq,
                       s.d_gcq, s.d_gcr, s.d_gdir, s.d_gqtot, s.d_gnb, s.d_gqdir, s.d_grdir, s.d_gsum, s.d_gtok, s.d_tiles, s.d_fb,
                       s.d_plan, s.d_plan_stream, s.d_plan_state,
-                      s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
+                      s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vtile, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
         for (void* p : ps) if (p) (void)hipFree(p);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);

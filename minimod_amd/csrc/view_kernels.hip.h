@@ -60,6 +60,30 @@ __global__ __launch_bounds__(256) void k_view_offsets(const unsigned int* __rest
     if (threadIdx.x == 0) offsets[n_reads] = carry;
 }
 
+// the same as a tiled scan for the big (gathered) launches -- k_scan_tile_sums over the counts, k_radix_scan over the tile sums
+// (freq_kernels.hip.h / sort_kernels.hip.h), then this: every read's offset from its tile's, cursors zeroed, the total behind
+// the last read (a single workgroup took 104 us for the 81 920 reads of a 20-batch launch)
+__global__ __launch_bounds__(256) void k_view_offsets_apply(const unsigned int* __restrict__ counts, uint32_t n_reads, const uint32_t* __restrict__ tile_off, uint32_t n_tiles,
+                                                            unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor) {
+    __shared__ uint32_t wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t run = tile_off[blockIdx.x];
+    for (int j0 = 0; j0 < kScanTile; j0 += 256) {
+        const int64_t i = base + j0 + threadIdx.x;
+        const uint32_t c = i < (int64_t)n_reads ? counts[i] : 0u;
+        const uint32_t incl = wave_incl_scan(c);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = run + incl - c;
+        for (int w = 0; w < wv; w++) before += wsum[w];
+        if (i < (int64_t)n_reads) { offsets[i] = before; cursor[i] = 0u; }
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = tile_off[n_tiles];
+}
+
 // regions -> per-read segments
 __global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ rv,
                                                       const unsigned int* __restrict__ rseq,
