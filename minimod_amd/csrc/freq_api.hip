@@ -352,11 +352,11 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
         hipLaunchKernelGGL(k_view_offsets_apply, dim3(nt), dim3(256), 0, st, s.d_vreadcount, nr, s.d_vtile, nt, s.d_voff, s.d_vcursor);
     }
     hipLaunchKernelGGL(k_view_scatter, dim3(std::max(1, h->n_cu / 8), kViewRegions), dim3(256), 0, st, s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vcount,
-                       s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va);
+                       s.view_cap, 0xFFFFFFu, s.d_voff, s.d_vcursor, s.d_ka, s.d_va, b->reads, s.d_vrows, h->opts.view == 2 ? 1u : 0u);
     const uint32_t small_blocks = std::min<uint32_t>((nr + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->n_cu * 4);
     const uint32_t big_blocks = std::min<uint32_t>(nr, (uint32_t)h->n_cu);
     hipLaunchKernelGGL(k_view_sort, dim3(big_blocks + small_blocks), dim3(256), 0, st, s.d_ka, s.d_va, s.d_voff, nr, big_blocks, b->reads,
-                       s.d_vrows, s.d_vkept, tail, h->opts.view == 2 ? 1u : 0u);
+                       s.d_vrows, s.d_vkept, tail, h->opts.view == 2 ? 1u : 0u, s.d_vcursor);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -159,6 +159,8 @@ struct KF {
     int32_t hp, hpi;            // kIns: the read's haplotype tag (-1: haplotypes off), its dense plane (-1: none)
     uint32_t v_region, v_gord;   // view: append region of the wavefront, ordinal of the group at hand
     uint32_t v_seq;              // view: records of the read so far
+    uint32_t v_sorted;           // view: 0x80000000 when the read's records are made in the order of its rows (one requested code in one
+                                 // '?' group: positions rise with the ranks of a forward read and fall with those of a reverse one)
     // the group
     int32_t ncg;
     bool dot_group;             // a '.' group: unlisted bases are calls too
@@ -625,7 +627,7 @@ struct KF {
                             if (kStats && emit) st_ml++;
                         }
                         v_seq = uniu(v_seq + view_append_seq(p, v_region, (uint32_t)ridx_cur, emit, (uint32_t)(ref_pos - pos + 1), rev ? L - 1u - q : q, 0u, (uint32_t)ci,
-                                                             v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), expl ? 0u : 1u, prob, v_seq));
+                                                             v_gord + ((kTwinOK && tw) ? (uint32_t)m : 0u), expl ? 0u : 1u, prob, v_seq | v_sorted));
                     }
                 } else if (call) {
                     const uint32_t refcode = w & 31u;
@@ -819,7 +821,7 @@ struct KF {
         const int64_t ctg_len = scalar_load(p.ctg_len + tid_c);
         const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c);
         int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
-        d_n = 0; c_n = 0; rank_ok = 0; v_seq = 0;
+        d_n = 0; c_n = 0; rank_ok = 0; v_seq = 0; v_sorted = 0;
         if (st == 0) {
             // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, the checks reduced to what a
             // clean record passes outright (anything else is the tile pipeline's to judge op by op) -- and, on the way, the
@@ -946,6 +948,18 @@ struct KF {
             }
             cpat = class_pattern(first_cls);
             wave_sync();
+            if (kView) {
+                uint32_t ncodes = 0, dots = 0;
+                for (uint32_t gi = 0; gi < ngrp; gi++) {
+                    const uint32_t f = uniu(S.g_flags[gi]), c01 = uniu(S.g_c01[gi]), c23 = uniu(S.g_c23[gi]);
+                    if (f & 64u) continue;
+                    dots |= f & 4u;
+                    const uint32_t n = (f >> 12) & 7u;
+                    ncodes += (n > 0u && (c01 & 0xFFFFu) != 0xFFFFu) + (n > 1u && (c01 >> 16) != 0xFFFFu) + (n > 2u && (c23 & 0xFFFFu) != 0xFFFFu) +
+                              (n > 3u && (c23 >> 16) != 0xFFFFu);
+                }
+                v_sorted = (ncodes == 1u && !dots) ? 0x80000000u : 0u;
+            }
         }
         KFT_LAP(1);
         if (st == 0 && ngrp > 0u) {

@@ -6,7 +6,8 @@
 // read.  A read's rows are independent of every other read's, so the ordering is a counting sort by read followed by
 // one small sort per read -- no global sort:
 //   1. k_view_offsets  exclusive scan of the per-read record counts                       (one block)
-//   2. k_view_scatter  every record to its read's segment (one cursor atomic per record, ~100 records per cursor)
+//   2. k_view_scatter  every record to its read's segment (k_stream_reads' records carry their place; the tile kernels' take one
+//                      cursor atomic per read and wave); reads whose records were made in row order get their ROWS here
 //   3. k_view_sort     bitonic sort of every read's segment on (position, code, ins_offset, the order the reference met
 //                      the calls in), later entries of a key marked, rows expanded to the 16-byte form of the C ABI: one
 //                      wavefront per read up to 512 records (LDS), one workgroup per bigger read (LDS up to 2048 records,
@@ -84,12 +85,33 @@ __global__ __launch_bounds__(256) void k_view_offsets_apply(const unsigned int* 
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = tile_off[n_tiles];
 }
 
+// opts.view == 2 (rows for the tie-order replay of the host, csrc/host/tieorder.c): a row also says in which MM group the
+// call was made (its ordinal, at most kViewMaxGroup = 2047, in the top eleven bits of `read`: a batch of such a handle has
+// fewer than 2^21 reads) and whether it was an implicit call of a '.' group (bit 31 of read_pos): with the position in the
+// read as sequenced that is the order the reference met the calls in.  Later entries of a key are KEPT there (the replay
+// wants every call: update_freq_map may meet a key whose first entry was ambiguous, src/mod.c:886-904).
+__device__ __forceinline__ uint32_t view_read_word(uint32_t r, unsigned long long v, uint32_t ordinal) {
+    if (!ordinal) return r;
+    const uint32_t g = (uint32_t)((v >> 29) & 0x7FFull);
+    return r | (g << 21);
+}
+__device__ __forceinline__ uint32_t view_read_pos_word(unsigned long long v, uint32_t ordinal) {
+    const uint32_t q = (uint32_t)(v & 0x0FFFFFFFull);
+    return ordinal ? (q | ((uint32_t)((v >> 28) & 1ull) << 31)) : q;
+}
+
 // regions -> per-read segments
+// A record of k_stream_reads knows its place among its read's records (rseq), and when the read made them in the order of its
+// rows (bit 31 of rseq: one requested code in one '?' group -- positions rise with the calls of a forward read, fall with those
+// of a reverse one, and no key comes twice) the ROW is written here, at its final place: such a read has nothing left for
+// k_view_sort (told so by its cursor word, kViewPresorted).
+constexpr unsigned int kViewPresorted = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ rv,
                                                       const unsigned int* __restrict__ rseq,
                                                       const unsigned int* __restrict__ region_counts, unsigned int cap, uint32_t read_mask,
                                                       const unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
-                                                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals) {
+                                                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
+                                                      const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows, uint32_t ordinal) {
     for (uint32_t region = blockIdx.y; region < kViewRegions; region += gridDim.y) {
         unsigned int n = region_counts[region * kViewCountStride];
         if (n > cap) n = cap;
@@ -97,10 +119,22 @@ __global__ __launch_bounds__(256) void k_view_scatter(const unsigned long long* 
         for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
             unsigned long long k = rk[base + i], v = rv[base + i];
             uint32_t read = (uint32_t)(k >> 28) & read_mask;
-            // a record of k_stream_reads knows its place among its read's records: no cursor, and the read's records arrive in the
-            // order they were made.  The others: neighbours in a region mostly belong to one read (a tile appends its records
-            // together): one cursor atomic per distinct read of the wave instead of one per record
             const unsigned int sq = rseq[base + i];
+            if (sq != 0xFFFFFFFFu && (sq >> 31)) {
+                const unsigned int off = offsets[read], nrec = offsets[read + 1u] - off, at = sq & 0x7FFFFFFFu;
+                const mm_read_t& rd = reads[read];
+                ViewRow o;
+                o.read = view_read_word(read, v, ordinal);
+                o.pos = rd.pos + (int32_t)((uint32_t)k & 0x0FFFFFFFu) - 1;
+                o.read_pos = view_read_pos_word(v, ordinal);
+                o.ins_offset = (uint16_t)((v >> 40) & 0xFFFFull); o.code = (uint8_t)(v >> 56); o.prob = (uint8_t)(k >> 56);
+                if (at < nrec) rows[off + ((rd.flag & 0x10) ? nrec - 1u - at : at)] = o;
+                if (at == 0u) cursor[read] = kViewPresorted;
+                continue;
+            }
+            // The others of k_stream_reads: no cursor, and the read's records arrive in the order they were made.  The tile
+            // kernels': neighbours in a region mostly belong to one read (a tile appends its records
+            // together): one cursor atomic per distinct read of the wave instead of one per record
             unsigned int slot = sq != 0xFFFFFFFFu ? offsets[read] + sq : 0u;
             bool pending = sq == 0xFFFFFFFFu;
             while (pending) {
@@ -152,21 +186,6 @@ __device__ __forceinline__ void view_bitonic(Ptr K, Ptr V, uint32_t n, uint32_t 
             if (kThreads == 64) wave_sync(); else __syncthreads();
         }
     }
-}
-
-// opts.view == 2 (rows for the tie-order replay of the host, csrc/host/tieorder.c): a row also says in which MM group the
-// call was made (its ordinal, at most kViewMaxGroup = 2047, in the top eleven bits of `read`: a batch of such a handle has
-// fewer than 2^21 reads) and whether it was an implicit call of a '.' group (bit 31 of read_pos): with the position in the
-// read as sequenced that is the order the reference met the calls in.  Later entries of a key are KEPT there (the replay
-// wants every call: update_freq_map may meet a key whose first entry was ambiguous, src/mod.c:886-904).
-__device__ __forceinline__ uint32_t view_read_word(uint32_t r, unsigned long long v, uint32_t ordinal) {
-    if (!ordinal) return r;
-    const uint32_t g = (uint32_t)((v >> 29) & 0x7FFull);
-    return r | (g << 21);
-}
-__device__ __forceinline__ uint32_t view_read_pos_word(unsigned long long v, uint32_t ordinal) {
-    const uint32_t q = (uint32_t)(v & 0x0FFFFFFFull);
-    return ordinal ? (q | ((uint32_t)((v >> 28) & 1ull) << 31)) : q;
 }
 
 // sorted records -> rows; a record with the key (position, code, ins_offset) of the one in front is a later entry of that
@@ -265,7 +284,8 @@ __device__ __forceinline__ uint32_t view_emit_rows1(const unsigned long long* P,
 __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals,
                                                    const unsigned int* __restrict__ offsets, uint32_t n_reads, uint32_t n_big_blocks,
                                                    const mm_read_t* __restrict__ reads, ViewRow* __restrict__ rows,
-                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped, uint32_t ordinal) {
+                                                   unsigned int* __restrict__ kept, unsigned int* __restrict__ n_dropped, uint32_t ordinal,
+                                                   const unsigned int* __restrict__ cursor) {
     __shared__ unsigned long long sp[kViewLdsRecs];   // packed sort words: a workgroup's segment, or four waves' slices
     __shared__ uint32_t drop_s;
     static_assert(kViewLdsRecs >= kWavesPerBlock * kViewWaveRecs, "one LDS layout for both kinds of workers");
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
         for (uint32_t r = blockIdx.x; r < n_reads; r += n_big_blocks) {
             const uint32_t off = offsets[r], n = offsets[r + 1] - off;
             if (n <= kViewWaveRecs) continue;   // a wave's job
+            if (cursor[r] == kViewPresorted) { if (threadIdx.x == 0) kept[r] = n; continue; }   // its rows are written (k_view_scatter)
             if (threadIdx.x == 0) drop_s = 0;
             __syncthreads();
             unsigned long long* gk = keys + off;
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(256) void k_view_sort(unsigned long long* __restric
         const uint32_t off = uniu(offsets[r]), n = uniu(offsets[r + 1]) - off;
         if (n == 0) { if (lane == 0) kept[r] = 0; continue; }
         if (n > kViewWaveRecs) continue;        // a workgroup's job
+        if (uniu(cursor[r]) == kViewPresorted) { if (lane == 0) kept[r] = n; continue; }   // its rows are written (k_view_scatter)
         wave_sync();
         for (uint32_t i = lane; i < n; i += 64) Pw[i] = view_pack(keys[off + i], vals[off + i], i);
         wave_sync();
