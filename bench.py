@@ -290,13 +290,39 @@ def _stage_timers(stderr_text):
     return out
 
 
+
+def usable_cores():
+    """CPUs this process can actually use: the affinity mask, cut down to the cgroup's CPU quota if there is one (the GPU boxes
+    show 256 hardware threads and grant 16 CPUs' worth of time: 128 workers there only preempt each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:   # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
 def run_end_to_end(args, wl, host_batches, contig, ref):
     """The END-TO-END leg: the workload's reads as a BGZF BAM + FASTA, through the product CLI (GPU) and through the CPU
     path (oracle behind the same reader and formatter), every run a child process.  Called before this process initialises
     the GPU.  Returns (end_to_end, cpu_baseline_e2e)."""
     from minimod_amd import synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     threads = args.e2e_threads if args.e2e_threads > 0 else min(cores, 128)
     cli = os.path.join(ROOT, "minimod_amd", "bin", "minimod")
     cpu_cli = O.build_cpu_cli()
@@ -391,7 +417,7 @@ def run_e2e_big(args):
     from minimod_amd import synth
     from oracle import oracle as O
     wl = WORKLOADS[args.config]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     threads = args.e2e_threads if args.e2e_threads > 0 else min(cores, 128)
     bases_target = args.e2e_gbases * 1e9
     region = max(1 << 20, int(bases_target / 30) // (1 << 20) * (1 << 20))
@@ -465,6 +491,15 @@ def run_e2e_big(args):
                "cpu_port": {"kind": "port", "value": bases / w_cpu / 1e6, "value_without_startup": bases / max(w_cpu - st_cpu.get("reference", 0.0) - st_cpu.get("contexts", 0.0), 1e-9) / 1e6,
                             "wall_s": w_cpu, "stages_s": st_cpu, "cmd": "oracle/_build/freq_cpu " + " ".join(common) + " ref.fa reads.bam"},
                "parity_vs_cpu": {"byte_identical": md5(og) == md5(oc) and os.path.getsize(og) == os.path.getsize(oc), "bytes": os.path.getsize(og)}}
+        ml = re.search(r"\[loader\] ([^\n]*)", err)
+        if ml:
+            res["gpu_cli"]["loader"] = ml.group(1)
+        # MM_E2E_SWEEP="16,32,64": the same job at other -t (diagnostic: where the host side stops scaling)
+        for t_alt in [int(x) for x in os.environ.get("MM_E2E_SWEEP", "").split(",") if x.strip()]:
+            alt = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(t_alt)]
+            w_alt, err_alt = run([cli, "freq"] + (["--canonical-order"] if tied else []) + alt, os.path.join(tmp, "gpu_alt.bed"))
+            ma = re.search(r"\[loader\] ([^\n]*)", err_alt)
+            res.setdefault("threads_sweep", []).append({"threads": t_alt, "wall_s": w_alt, "stages_s": _stage_timers(err_alt), "loader": ma.group(1) if ma else None})
         if tied:
             w_rp, err_rp = run([cli, "freq"] + common, os.path.join(tmp, "gpu_replay.bed"))
             mr = re.search(r"Row order replay[^:]*: ([0-9.]+) sec", err_rp)
@@ -528,7 +563,7 @@ def main():
                            n_reads_total=n_iv, tid=iv["tid"], region_begin=iv["read_begin"], region_len=iv["read_len"], max_len=args.max_len,
                            with_order=False, **wl["gen"])
 
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(16, usable_cores())) as ex:
         pieces = list(ex.map(gen, jobs))
     whole = synth.concat(pieces)
     # (N = 1: the pieces are the -K batches themselves, each with pools of its own -- what a host caller hands to mm_freq_submit)
@@ -979,7 +1014,7 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
             result["dump"] = {"file": args.dump, "batches": 1}
         if not args.no_cpu_baseline:
             from oracle import oracle as O
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             orc = O.Oracle([("m", "CG")], [0.8], [n for n, _ in plan["contigs"]])
             orc.set_view(True)
             for (n, _), rf in zip(plan["contigs"], ref):
@@ -1004,7 +1039,7 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
 def cpu_baseline(args, wl, host_batches, plan, refs):
     """The oracle (bit-exact CPU restatement) timed on this host's cores over a bounded sample of the same batches."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     orc = O.Oracle([(c, x) for c, x, _ in wl["mods"]], [t for _, _, t in wl["mods"]], [n for n, _ in plan["contigs"]], **wl["eng"])
     for (n, _), rf in zip(plan["contigs"], refs):
         if rf is not None:

@@ -293,7 +293,7 @@ __device__ __forceinline__ unsigned long long* counter_word(const DevParams& p, 
     const int c = p.cls_of_mod[dc.req];
     const DevClass k = p.classes[c];
     int64_t r = g;
-    if (!k.dense) { const uint2 w = k.site[rev][(g >> 5) * k.stride]; r = (int64_t)site_rank(w, (uint32_t)g & 31u); }
+    if (!k.dense) { const uint2 w = (rev ? k.site[1] : k.site[0])[(g >> 5) * k.stride]; r = (int64_t)site_rank(w, (uint32_t)g & 31u); }
     return p.counters + k.base + (((int64_t)(hpi * 2 + rev) * k.nsites) + p.adj[((int64_t)tid * p.n_classes + c) * 2 + rev] + r) * k.np + dc.slot;
 }
 // value of lane `l` (wave-uniform l) as a wave-uniform scalar

@@ -985,7 +985,7 @@ struct KF {
                     const DevClass kd = scalar_load(p.classes + kc);
                     const int64_t adjv = scalar_load(p.adj + ((int64_t)tid * p.n_classes + kc) * 2 + rev);
                     gnp = (uint32_t)kd.np;
-                    gsite = kd.dense ? nullptr : kd.site[rev];
+                    gsite = kd.dense ? nullptr : (rev ? kd.site[1] : kd.site[0]);   // (a select: an index would put the pair into scratch)
                     const int hpl = kIns ? (hpi >= 0 ? hpi : 0) : 0;
                     gcb = has_dense ? p.counters + kd.base + (((int64_t)(hpl * 2 + rev) * kd.nsites) + adjv + (kd.dense ? ref_base : 0)) * kd.np : nullptr;
                 }

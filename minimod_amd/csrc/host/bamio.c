@@ -14,6 +14,8 @@
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
@@ -22,32 +24,69 @@
 #define CHUNK_HEAD ((size_t)4 << 20)
 #define CHUNK_PAYLOAD ((size_t)GROUP_BLOCKS * 65536)
 #define GROUP_CBYTES ((size_t)8 << 20)   /* compressed bytes read per group (a group is the whole blocks among them) */
-#define CHUNKS_AHEAD 4                   /* decoded chunks the producer may run ahead of the consumer */
+#define GROUP_TICKETS 16                 /* workers on one group at a time (several groups are in flight) */
+#define CHUNKS_AHEAD 8                   /* chunks the producer may run ahead of the consumer: framed, their blocks being inflated or done */
 
 /* ------------------------------------------------------------------ worker pool */
+/* A parallel loop over [0, n) is ONE task: the queue gets a few tickets for it (one lock, not one per piece) and the workers
+ * that draw a ticket take pieces of `grain` indices off the task's counter until none is left.  (Queueing every piece by
+ * itself cost 16 us a piece with 128 workers on the queue's lock: 7 ms to hand out the 450 copies of a batch.) */
 typedef struct pool_group {
-    int pending;
+    void (*fn)(void *arg, int64_t lo, int64_t hi);
+    void *arg;
+    int64_t n, grain;
+    int64_t next;        /* first index nobody has taken yet (atomic) */
+    int pending;         /* tickets not yet handed back */
+    int urgent;          /* somebody waits for this loop now (mm_pool_for): its tickets go to the front of the queue, and a worker
+                          * in the middle of a read-ahead ticket runs one of them between two of its pieces */
     pthread_mutex_t mu;
     pthread_cond_t cv;
 } pool_group_t;
-
-typedef struct pool_job {
-    void (*fn)(void *arg, int64_t lo, int64_t hi);
-    void *arg;
-    int64_t lo, hi;
-    pool_group_t *grp;
-} pool_job_t;
 
 #define POOL_QCAP 4096
 struct mm_pool {
     int n_threads;
     pthread_t *th;
-    pool_job_t q[POOL_QCAP];
+    pool_group_t *q[POOL_QCAP];   /* tickets */
     int qhead, qtail, qlen;
     int stop;
+    int n_urgent;                 /* urgent tickets in the queue (atomic) */
     pthread_mutex_t mu;
     pthread_cond_t cv_job, cv_room;
+    /* diagnostics (MM_LOADER_TIMING): nanoseconds the workers spent inside jobs, pieces run, nanoseconds callers spent queueing */
+    unsigned long long busy_ns, jobs, submit_ns;
 };
+
+static unsigned long long pool_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (unsigned long long)t.tv_sec * 1000000000ull + (unsigned long long)t.tv_nsec; }
+
+/* one ticket: pieces off the task's counter until none is left, then the ticket is handed back */
+static void pool_run_ticket(mm_pool_t *p, pool_group_t *g) {
+    const unsigned long long t_j = pool_ns();
+    unsigned long long pieces = 0, nested_ns = 0;
+    for (;;) {
+        const int64_t lo = __atomic_fetch_add(&g->next, g->grain, __ATOMIC_RELAXED);
+        if (lo >= g->n) break;
+        g->fn(g->arg, lo, lo + g->grain < g->n ? lo + g->grain : g->n);
+        pieces++;
+        if (!g->urgent && __atomic_load_n(&p->n_urgent, __ATOMIC_RELAXED) > 0) {
+            pool_group_t *u = NULL;
+            pthread_mutex_lock(&p->mu);
+            if (p->qlen > 0 && p->q[p->qhead]->urgent) {
+                u = p->q[p->qhead];
+                p->qhead = (p->qhead + 1) % POOL_QCAP; p->qlen--;
+                __atomic_fetch_sub(&p->n_urgent, 1, __ATOMIC_RELAXED);
+                pthread_cond_signal(&p->cv_room);
+            }
+            pthread_mutex_unlock(&p->mu);
+            if (u) { const unsigned long long t_n = pool_ns(); pool_run_ticket(p, u); nested_ns += pool_ns() - t_n; }
+        }
+    }
+    __atomic_fetch_add(&p->busy_ns, pool_ns() - t_j - nested_ns, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&p->jobs, pieces, __ATOMIC_RELAXED);
+    pthread_mutex_lock(&g->mu);
+    if (--g->pending == 0) pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+}
 
 static void *pool_worker(void *arg) {
     mm_pool_t *p = (mm_pool_t *)arg;
@@ -55,14 +94,12 @@ static void *pool_worker(void *arg) {
         pthread_mutex_lock(&p->mu);
         while (p->qlen == 0 && !p->stop) pthread_cond_wait(&p->cv_job, &p->mu);
         if (p->qlen == 0 && p->stop) { pthread_mutex_unlock(&p->mu); return NULL; }
-        pool_job_t j = p->q[p->qhead];
+        pool_group_t *g = p->q[p->qhead];
         p->qhead = (p->qhead + 1) % POOL_QCAP; p->qlen--;
+        if (g->urgent) __atomic_fetch_sub(&p->n_urgent, 1, __ATOMIC_RELAXED);
         pthread_cond_signal(&p->cv_room);
         pthread_mutex_unlock(&p->mu);
-        j.fn(j.arg, j.lo, j.hi);
-        pthread_mutex_lock(&j.grp->mu);
-        if (--j.grp->pending == 0) pthread_cond_broadcast(&j.grp->cv);
-        pthread_mutex_unlock(&j.grp->mu);
+        pool_run_ticket(p, g);
     }
 }
 
@@ -99,27 +136,53 @@ void mm_pool_destroy(mm_pool_t *p) {
 }
 
 int mm_pool_threads(const mm_pool_t *p) { return p ? p->n_threads : 1; }
+void mm_pool_stats(const mm_pool_t *p, double *busy_s, unsigned long long *jobs, double *submit_s) {
+    *busy_s = p ? 1e-9 * (double)p->busy_ns : 0.0; *jobs = p ? p->jobs : 0ull; *submit_s = p ? 1e-9 * (double)p->submit_ns : 0.0;
+}
+
+/* the loop over [0, n) queued as at most `max_tickets` tickets; `g` (initialised, nothing pending) counts them down; the caller
+ * waits with group_wait when it needs the results */
+static void pool_submit(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *arg, pool_group_t *g, int max_tickets, int front) {
+    const unsigned long long t_s = pool_ns();
+    const int64_t pieces = (n + grain - 1) / grain;
+    int k = p->n_threads;
+    if (k > max_tickets) k = max_tickets;
+    if ((int64_t)k > pieces) k = (int)pieces;
+    if (k > POOL_QCAP / 2) k = POOL_QCAP / 2;
+    pthread_mutex_lock(&g->mu);
+    g->fn = fn; g->arg = arg; g->n = n; g->grain = grain; g->urgent = front;
+    __atomic_store_n(&g->next, 0, __ATOMIC_RELAXED);
+    g->pending = k;
+    pthread_mutex_unlock(&g->mu);
+    pthread_mutex_lock(&p->mu);
+    while (p->qlen + k > POOL_QCAP) pthread_cond_wait(&p->cv_room, &p->mu);
+    /* front: somebody is waiting for this loop right now (mm_pool_for): its tickets go in front of the read-ahead's */
+    if (front) {
+        for (int i = 0; i < k; i++) { p->qhead = (p->qhead + POOL_QCAP - 1) % POOL_QCAP; p->q[p->qhead] = g; p->qlen++; }
+        __atomic_fetch_add(&p->n_urgent, k, __ATOMIC_RELAXED);
+    }
+    else for (int i = 0; i < k; i++) { p->q[p->qtail] = g; p->qtail = (p->qtail + 1) % POOL_QCAP; p->qlen++; }
+    if (2 * k >= p->n_threads) pthread_cond_broadcast(&p->cv_job);
+    else for (int i = 0; i < k; i++) pthread_cond_signal(&p->cv_job);
+    pthread_mutex_unlock(&p->mu);
+    __atomic_fetch_add(&p->submit_ns, pool_ns() - t_s, __ATOMIC_RELAXED);
+}
+static void group_wait(pool_group_t *g) {
+    pthread_mutex_lock(&g->mu);
+    while (g->pending > 0) pthread_cond_wait(&g->cv, &g->mu);
+    pthread_mutex_unlock(&g->mu);
+}
 
 void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *arg) {
     if (n <= 0) return;
     if (grain < 1) grain = 1;
     if (!p || n <= grain) { fn(arg, 0, n); return; }
     pool_group_t g;
-    g.pending = (int)((n + grain - 1) / grain);
+    memset(&g, 0, sizeof g);
     pthread_mutex_init(&g.mu, NULL);
     pthread_cond_init(&g.cv, NULL);
-    for (int64_t lo = 0; lo < n; lo += grain) {
-        pthread_mutex_lock(&p->mu);
-        while (p->qlen == POOL_QCAP) pthread_cond_wait(&p->cv_room, &p->mu);
-        pool_job_t *j = &p->q[p->qtail];
-        j->fn = fn; j->arg = arg; j->lo = lo; j->hi = lo + grain < n ? lo + grain : n; j->grp = &g;
-        p->qtail = (p->qtail + 1) % POOL_QCAP; p->qlen++;
-        pthread_cond_signal(&p->cv_job);
-        pthread_mutex_unlock(&p->mu);
-    }
-    pthread_mutex_lock(&g.mu);
-    while (g.pending > 0) pthread_cond_wait(&g.cv, &g.mu);
-    pthread_mutex_unlock(&g.mu);
+    pool_submit(p, n, grain, fn, arg, &g, p->n_threads, 1);
+    group_wait(&g);
     pthread_mutex_destroy(&g.mu); pthread_cond_destroy(&g.cv);
 }
 
@@ -138,6 +201,9 @@ typedef struct chunk {
     int n_blk;
     blk_t blk[GROUP_BLOCKS];
     int err, last;       /* last: the file ended with this group */
+    pool_group_t grp;    /* the group's inflate jobs: the producer queues them and frames the next group, the consumer waits for
+                          * them when it takes the chunk (a producer that waited for every group itself kept 64 of 128 workers
+                          * busy for one group at a time, with nothing running while it framed the next) */
     struct chunk *next;
 } chunk_t;
 
@@ -167,6 +233,7 @@ struct mm_bam {
     uint8_t **spills; int n_spills;     /* assembled oversized records */
     uint8_t *cur_spill;                 /* the spill buffer b->p points into, if any */
     int eof, failed;
+    double wait_s;                      /* consumer: seconds spent waiting for decoded chunks */
 };
 
 static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -212,9 +279,16 @@ static chunk_t *chunk_new(void) {
     if (!c) return NULL;
     c->buf = (uint8_t *)malloc(CHUNK_HEAD + CHUNK_PAYLOAD);
     c->cbuf = (uint8_t *)malloc(GROUP_CBYTES + 65536 + 1024);
+    pthread_mutex_init(&c->grp.mu, NULL);
+    pthread_cond_init(&c->grp.cv, NULL);
     return c;
 }
-static void chunk_free(chunk_t *c) { if (c) { free(c->buf); free(c->cbuf); free(c); } }
+static void chunk_free(chunk_t *c) {
+    if (!c) return;
+    group_wait(&c->grp);   /* (a reader closed early: its workers may still be writing into the chunk) */
+    pthread_mutex_destroy(&c->grp.mu); pthread_cond_destroy(&c->grp.cv);
+    free(c->buf); free(c->cbuf); free(c);
+}
 
 /* one BGZF block header at h (avail bytes are there): total block size, or 0 if the header itself is cut off, -1 if bad */
 static long block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) {
@@ -355,9 +429,9 @@ static void *producer_main(void *arg) {
         }
         c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0;
         if (!c->buf || !c->cbuf || (b->map ? read_group_mapped(b, c) : read_group(b, c)) != 0) c->err = 1;
-        else {
-            mm_pool_for(b->pool, c->n_blk, 4, inflate_range, c);
-            for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
+        else if (c->n_blk > 0) {
+            if (b->pool) pool_submit(b->pool, c->n_blk, 2, inflate_range, c, &c->grp, GROUP_TICKETS, 0);
+            else inflate_range(c, 0, c->n_blk);
         }
         int stop = c->err || c->last;
         pthread_mutex_lock(&b->mu);
@@ -373,8 +447,11 @@ static void *producer_main(void *arg) {
 static void hold(mm_bam_t *b, chunk_t *c) { c->next = b->held; b->held = c; }
 
 /* next decoded chunk (blocks until one is ready); NULL at end of file or on error (b->failed) */
+static double mono_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
 static chunk_t *take_chunk(mm_bam_t *b) {
     if (b->eof) return NULL;
+    const double t_in = mono_s();
     pthread_mutex_lock(&b->mu);
     while (!b->ready_head && b->n_ready >= 0) pthread_cond_wait(&b->cv_ready, &b->mu);
     chunk_t *c = b->ready_head;
@@ -387,6 +464,9 @@ static chunk_t *take_chunk(mm_bam_t *b) {
     pthread_mutex_unlock(&b->mu);
     if (!c) { b->failed = 1; b->eof = 1; return NULL; }
     c->next = NULL;
+    group_wait(&c->grp);
+    b->wait_s += mono_s() - t_in;
+    for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
     if (c->err) { b->failed = 1; b->eof = 1; hold(b, c); return NULL; }
     if (c->last) b->eof = 1;
     return c;
@@ -599,6 +679,7 @@ uint64_t mm_bai_start(const mm_bai_t *x, int32_t tid, int64_t pos) {
 }
 
 mm_pool_t *mm_bam_pool(mm_bam_t *b) { return b->pool; }
+double mm_bam_wait_seconds(const mm_bam_t *b) { return b->wait_s; }
 
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b) { return &b->hdr; }
 

@@ -35,6 +35,7 @@ typedef struct mm_pool mm_pool_t;
 mm_pool_t *mm_pool_create(int n_threads);
 void mm_pool_destroy(mm_pool_t *p);
 int mm_pool_threads(const mm_pool_t *p);
+void mm_pool_stats(const mm_pool_t *p, double *busy_s, unsigned long long *jobs, double *submit_s);   /* diagnostics: seconds inside jobs (all workers), jobs run, seconds spent queueing */
 /* fn(arg, lo, hi) over [0, n) in pieces of `grain` items; returns when every piece is done */
 void mm_pool_for(mm_pool_t *p, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *arg);
 
@@ -50,6 +51,7 @@ mm_bai_t *mm_bai_load(const char *bai_path);
 void mm_bai_free(mm_bai_t *x);
 uint64_t mm_bai_start(const mm_bai_t *x, int32_t tid, int64_t pos);   /* UINT64_MAX: nothing at or after (tid, pos) */
 mm_pool_t *mm_bam_pool(mm_bam_t *b);
+double mm_bam_wait_seconds(const mm_bam_t *b);   /* seconds the record reader has waited for decoded data so far */
 /* record views handed out since the last release are no longer needed: their buffers may be reused */
 void mm_bam_release(mm_bam_t *b);
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b);

@@ -6,6 +6,8 @@
  * still being uploaded. */
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
 
 #include "mmhost.h"
 
@@ -33,6 +35,7 @@ typedef struct loader_priv {
     size_t items_cap;
     /* a worker of a sharded run reads only the alignments that START inside its share [lo, hi) of the genome */
     int ranged, first, last, seen, done;
+    double t_frame, t_copy;   /* seconds in step 1 (framing + filters, waits for decoded data included) and step 2 (the copies) */
     int32_t lo_tid, hi_tid;
     int64_t lo_pos, hi_pos;
 } loader_priv_t;
@@ -48,6 +51,7 @@ static void pool_reserve(pool_t *b, size_t bytes) {
     }
     b->n = bytes;
 }
+static double loader_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 mmh_loader_t *mmh_loader_open(const char *bam_path, int threads, int32_t K, int64_t B, int allow_secondary, int skip_supplementary) {
@@ -92,7 +96,9 @@ static int aux2i(const uint8_t *t) {   /* bam_aux2i on the type byte */
 typedef struct { pool_t *P; const item_t *it; } copy_ctx_t;
 
 /* copy records [lo, hi): every byte of the pools between the items (alignment padding) is zeroed by the item behind it */
+static unsigned long long copy_busy_ns;   /* diagnostics: nanoseconds inside copy_range, all workers */
 static void copy_range(void *arg, int64_t lo, int64_t hi) {
+    const double t_c = loader_now();
     const copy_ctx_t *c = (const copy_ctx_t *)arg;
     pool_t *P = c->P;
     for (int64_t i = lo; i < hi; i++) {
@@ -123,6 +129,7 @@ static void copy_range(void *arg, int64_t lo, int64_t hi) {
         rd->tid = it->tid; rd->pos = it->pos; rd->l_qseq = it->l_qseq; rd->n_cigar = it->n_cigar;
         rd->mm_len = it->mm_len; rd->ml_len = it->ml_len; rd->flag = it->flag; rd->hp = it->hp;
     }
+    __atomic_fetch_add(&copy_busy_ns, (unsigned long long)((loader_now() - t_c) * 1e9), __ATOMIC_RELAXED);
 }
 
 int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
@@ -134,6 +141,7 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     size_t o_cigar = 0, o_seq = 0, o_mm = 0, o_ml = 0, o_qname = 0;
     mm_bam_rec_t rec;
     int rc = 1;
+    const double t_1 = loader_now();
     /* ---- step 1: frame + filter, in file order (minimod.c:249-333) */
     while (n < ld->K && proc_bytes < ld->B) {           /* minimod.c:249 */
         if (lp->done) { rc = 0; break; }
@@ -188,6 +196,8 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
         proc_bytes += rec.l_data;
         ld->processed_bases += (uint64_t)rec.l_qseq;
     }
+    const double t_2 = loader_now();
+    lp->t_frame += t_2 - t_1;
     /* ---- step 2: sizes are known: reserve, copy in parallel, zero the tails (every pool ends in >= 64 zero bytes) */
     size_t e_cigar = o_cigar, e_seq = o_seq, e_mm = o_mm, e_ml = o_ml;
     o_cigar = align_up(o_cigar, 16) + 64; o_seq = align_up(o_seq, 16) + 64; o_mm = align_up(o_mm, 16) + 64; o_ml = align_up(o_ml, 4) + 64;
@@ -202,6 +212,7 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     memset(P[P_CIGAR].p + e_cigar, 0, o_cigar - e_cigar); memset(P[P_SEQ].p + e_seq, 0, o_seq - e_seq);
     memset(P[P_MM].p + e_mm, 0, o_mm - e_mm); memset(P[P_ML].p + e_ml, 0, o_ml - e_ml);
     mm_bam_release(ld->bam);
+    lp->t_copy += loader_now() - t_2;
     memset(out, 0, sizeof(*out));
     out->reads = (const mm_read_t *)P[P_READS].p;
     out->cigar = (const uint32_t *)P[P_CIGAR].p; out->seq = P[P_SEQ].p; out->mm = P[P_MM].p; out->ml = P[P_ML].p;
@@ -225,6 +236,14 @@ const char *mmh_loader_qname(const mmh_loader_t *ld, int set, int32_t read) {
 
 void mmh_loader_close(mmh_loader_t *ld) {
     if (!ld) return;
+    if (getenv("MM_LOADER_TIMING")) {
+        double busy = 0, sub = 0; unsigned long long jobs = 0;
+        mm_pool_stats(mm_bam_pool(ld->bam), &busy, &jobs, &sub);
+        fprintf(stderr, "[loader] framing + filters %.3f s (of which waiting for decoded data %.3f s), copies %.3f s, %d threads; "
+                        "pool: %llu jobs, %.3f s inside jobs (%.3f s of them copies), %.3f s queueing\n",
+                PRIV(ld)->t_frame, mm_bam_wait_seconds(ld->bam), PRIV(ld)->t_copy, mm_pool_threads(mm_bam_pool(ld->bam)),
+                jobs, busy, 1e-9 * (double)copy_busy_ns, sub);
+    }
     mm_bam_close(ld->bam);
     loader_priv_t *lp = PRIV(ld);
     for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) free(lp->sets[s][i].p);
