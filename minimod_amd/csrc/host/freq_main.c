@@ -1002,7 +1002,7 @@ static int run_main(int argc, char **argv, int view) {
 
     double t1 = mmh_realtime();
     fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);
-    mmh_ref_t *ref = mmh_load_ref(ref_file);
+    mmh_ref_t *ref = mmh_load_ref_mt(ref_file, o.threads > 0 ? o.threads : 1);
     if (!ref) { MMH_ERROR("Could not to open file %s", ref_file); exit(EXIT_FAILURE); }
     fprintf(stderr, "[%s] Reference genome loaded in %.3f sec\n", __func__, mmh_realtime() - t1);
     if (o.devices && strchr(o.devices, ',')) return run_devices(&o, &mods, ref, bam_file, realtime0);

@@ -48,6 +48,7 @@ typedef struct mmh_ref {
     int64_t *len;
 } mmh_ref_t;
 mmh_ref_t *mmh_load_ref(const char *path);      /* load_ref: names up to the first whitespace, raw letters */
+mmh_ref_t *mmh_load_ref_mt(const char *path, int threads);   /* ... a plain file in parallel passes over its mapping; threads <= 0: the stream parser */
 int mmh_ref_find(const mmh_ref_t *r, const char *name);   /* last duplicate wins like kh_put (src/ref.c:81-82) */
 void mmh_free_ref(mmh_ref_t *r);
 

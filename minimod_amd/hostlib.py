@@ -63,9 +63,12 @@ def parse_num(s):
     return int(_lib().mmh_parse_num(s.encode()))
 
 
-def load_ref(path):
+def load_ref(path, threads=1):
+    """threads >= 1: a plain file through the mapped parser with that many workers; 0: the stream parser (what .gz files get)"""
     L = _lib()
-    r = L.mmh_load_ref(path.encode())
+    L.mmh_load_ref_mt.restype = ctypes.POINTER(mmh_ref_t)
+    L.mmh_load_ref_mt.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    r = L.mmh_load_ref_mt(path.encode(), int(threads))
     if not r:
         raise IOError("cannot open %s" % path)
     out = []

@@ -91,6 +91,37 @@ def test_fasta_loader(tmp_path):
     assert hostlib.load_ref(str(pz)) == got
 
 
+def test_fasta_parsers_agree(tmp_path):
+    """The mapped parser (plain files, parallel passes) against the stream parser (what a .gz gets) on text that tries the rules:
+    junk before the first record, '>' inside a line and after a carriage return, blanks inside sequence lines, a header the file
+    ends in, empty records, a name of more than 1023 characters, records bigger than a piece and than a find chunk."""
+    import numpy as np
+    from minimod_amd import hostlib
+    rng = np.random.default_rng(7)
+    big = "\n".join("".join("ACGTNacgtn"[int(x)] for x in rng.integers(0, 10, 61)) for _ in range(200000))   # 12 MB
+    cases = {
+        "plain": ">a\nAC\nGT\n>b desc\nTT\n",
+        "junk_first": "xx\nyy >no\n>a\nAC>GT\n\r>notarecord\nGG\n",
+        "blanks": ">a\tz\nA C\tG\r\n \n\nT\n>b\r\nAA\n",
+        "header_at_eof": ">a\nAC\n>b",
+        "header_only_eof_nl": ">a\nAC\n>b\n",
+        "empty_records": ">a\n>b\n>c\nA\n>d\n",
+        "no_records": "ACGT\nACGT\n",
+        "empty_file_ish": "\n\n",
+        "long_name": ">" + "n" * 3000 + " d\nACGT\n",
+        "no_final_newline": ">a\nACGT",
+        "big": ">big one\n" + big + "\n>tail\nAC\n" + big[:100000],
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(text.encode())
+        want = hostlib.load_ref(str(p), threads=0)
+        for t in (1, 3, 8):
+            assert hostlib.load_ref(str(p), threads=t) == want, (name, t)
+    assert hostlib.load_ref(str(tmp_path / "plain.fa")) == [("a", b"ACGT"), ("b", b"TT")]
+    assert [(n, len(s)) for n, s in hostlib.load_ref(str(tmp_path / "big.fa"), threads=4)] == [("big", 200000 * 61), ("tail", 2 + 100000 - big[:100000].count("\n"))]
+
+
 def _same_batch(a, b):
     ra, rb = a["reads"], b["reads"]
     assert len(ra) == len(rb)
