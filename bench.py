@@ -472,8 +472,12 @@ def run_e2e_big(args):
         # rows can tie on (contig, start) with several codes / --insertions / --haplotypes: the CPU port prints them in the fixed
         # order, so the compared GPU run does too; the default run -- the reference's order, replayed on the host -- is timed beside it
         tied = len(wl["mods"]) > 1 or bool(wl["eng"])
-        runs = [run([cli, "freq"] + (["--canonical-order"] if tied else []) + common, og) for _ in range(2)]
+        gpu_flags = os.environ.get("MM_E2E_CLI_FLAGS", "").split()   # e.g. --gpu-inflate (the GPU CLI's runs only)
+        runs = [run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, og) for _ in range(2)]
         wall, err = min(runs, key=lambda x: x[0])
+        if os.environ.get("MM_E2E_STDERR"):   # the CLI's own log of the timed run (its lines carry the time since start)
+            with open(os.environ["MM_E2E_STDERR"], "w") as f:
+                f.write(err)
         st = _stage_timers(err)
         startup = st.get("reference", 0.0) + st.get("contexts", 0.0)
         m = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with k_stream_reads\)", err)
@@ -484,7 +488,7 @@ def run_e2e_big(args):
                "gpu_cli": {"value": bases / wall / 1e6, "value_without_startup": bases / max(wall - startup, 1e-9) / 1e6, "wall_s": wall,
                            "wall_s_first_run": runs[0][0], "startup_s": startup, "stages_s": st,
                            "launches": {"launches": int(m.group(1)), "batches": int(m.group(2)), "with_k_stream_reads": int(m.group(3))} if m else None,
-                           "cmd": "minimod freq " + " ".join(common) + " ref.fa reads.bam",
+                           "cmd": "minimod freq " + " ".join(gpu_flags + common) + " ref.fa reads.bam",
                            "what": "whole child process (start, HIP initialisation, FASTA load + context kernels, BGZF/BAM decode, batches through "
                                    "mm_freq_submit, finalize, bedmethyl written); value_without_startup leaves out the reference load and context "
                                    "kernels (the part that does not grow with the reads)"},

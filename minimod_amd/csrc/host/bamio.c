@@ -21,6 +21,9 @@
 #include <zlib.h>
 
 #define GROUP_BLOCKS 256
+#define GPU_GROUP_BLOCKS 1024           /* with a device inflater (mm_bam_set_backend) a group is one launch: it wants thousands of
+                                         * blocks in flight, three or four launches of this size */
+#define GPU_GROUP_CBYTES ((size_t)40 << 20)
 #define CHUNK_HEAD ((size_t)4 << 20)
 #define CHUNK_PAYLOAD ((size_t)GROUP_BLOCKS * 65536)
 #define GROUP_CBYTES ((size_t)8 << 20)   /* compressed bytes read per group (a group is the whole blocks among them) */
@@ -199,7 +202,10 @@ typedef struct chunk {
     uint8_t *cbuf;       /* compressed bytes of the group */
     size_t len;          /* decoded bytes at buf + CHUNK_HEAD */
     int n_blk;
-    blk_t blk[GROUP_BLOCKS];
+    blk_t blk[GPU_GROUP_BLOCKS];
+    int gpu_slot;        /* >= 0: the group was given to the device inflater's slot (the consumer waits for the launch) */
+    int pinned;          /* buf comes from the backend's allocator */
+    size_t cap_blocks;
     int err, last;       /* last: the file ended with this group */
     pool_group_t grp;    /* the group's inflate jobs: the producer queues them and frames the next group, the consumer waits for
                           * them when it takes the chunk (a producer that waited for every group itself kept 64 of 128 workers
@@ -274,10 +280,95 @@ static void inflate_range(void *arg, int64_t lo, int64_t hi) {
     for (int64_t i = lo; i < hi; i++) c->blk[i].err = inflate_block(&c->blk[i]);
 }
 
+/* ------------------------------------------------------------------ device inflater (bamio.h: mm_bgzf_backend_t) */
+static const mm_bgzf_backend_t *g_be = NULL;
+static pthread_mutex_t g_be_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_be_busy[16];
+static unsigned long long g_be_groups, g_be_blocks, g_be_fallback_blocks;   /* diagnostics */
+
+void mm_bam_set_backend(const mm_bgzf_backend_t *be) {
+    pthread_mutex_lock(&g_be_mu);
+    g_be = be;
+    memset(g_be_busy, 0, sizeof g_be_busy);
+    pthread_mutex_unlock(&g_be_mu);
+}
+void mm_bam_backend_stats(unsigned long long out[3]) { out[0] = g_be_groups; out[1] = g_be_blocks; out[2] = g_be_fallback_blocks; }
+
+static int be_take_slot(void) {
+    int got = -1;
+    pthread_mutex_lock(&g_be_mu);
+    if (g_be) for (int i = 0; i < g_be->slots && i < 16; i++) if (!g_be_busy[i]) { g_be_busy[i] = 1; got = i; break; }
+    pthread_mutex_unlock(&g_be_mu);
+    return got;
+}
+static void be_release_slot(int slot) {
+    pthread_mutex_lock(&g_be_mu);
+    if (slot >= 0 && slot < 16) g_be_busy[slot] = 0;
+    pthread_mutex_unlock(&g_be_mu);
+}
+
+typedef struct { chunk_t *c; uint8_t *staging; const uint32_t *c_off; } stage_ctx_t;
+static void stage_range(void *arg, int64_t lo, int64_t hi) {
+    stage_ctx_t *s = (stage_ctx_t *)arg;
+    for (int64_t i = lo; i < hi; i++) memcpy(s->staging + s->c_off[i], s->c->blk[i].cdata, s->c->blk[i].clen);
+}
+
+/* the group's blocks to the device: payloads one behind the other into the slot's staging (copied by the pool), the block
+ * records, the launch.  0 = on its way, -1 = not taken (the host pool inflates the group as usual) */
+static int be_submit_group(mm_pool_t *pool, chunk_t *c) {
+    const mm_bgzf_backend_t *be = g_be;
+    if (!be || !c->pinned || c->n_blk <= 0 || c->n_blk > be->max_blocks || c->len > be->max_obytes || verify_zlib > 0) return -1;
+    const int slot = be_take_slot();
+    if (slot < 0) return -1;
+    uint32_t *rec = (uint32_t *)be->blocks(be->ctx, slot);
+    uint8_t *staging = be->staging(be->ctx, slot);
+    size_t cb = 0;
+    for (int i = 0; i < c->n_blk; i++) {
+        const blk_t *k = &c->blk[i];
+        rec[5 * i + 0] = (uint32_t)cb; rec[5 * i + 1] = k->clen; rec[5 * i + 2] = (uint32_t)(k->out - (c->buf + CHUNK_HEAD));
+        rec[5 * i + 3] = k->isize; rec[5 * i + 4] = k->crc;
+        cb += k->clen;
+    }
+    if (cb > be->max_cbytes) { be_release_slot(slot); return -1; }
+    {
+        /* (the offsets live in the records: every fifth word) */
+        uint32_t *offs = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)c->n_blk);
+        if (!offs) { be_release_slot(slot); return -1; }
+        for (int i = 0; i < c->n_blk; i++) offs[i] = rec[5 * i];
+        stage_ctx_t sc = {c, staging, offs};
+        mm_pool_for(pool, c->n_blk, 16, stage_range, &sc);
+        free(offs);
+    }
+    if (be->submit(be->ctx, slot, c->n_blk, cb, c->len, c->buf + CHUNK_HEAD) != 0) { be_release_slot(slot); return -1; }
+    c->gpu_slot = slot;
+    __atomic_fetch_add(&g_be_groups, 1ull, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_be_blocks, (unsigned long long)c->n_blk, __ATOMIC_RELAXED);
+    return 0;
+}
+
+static int inflate_block(blk_t *b);
+/* the launch's end: a block the device refused (or a failed launch) is inflated here, by the host's decoder -- what counts as an
+ * error stays what it is without a device */
+static void be_finish_group(chunk_t *c) {
+    const mm_bgzf_backend_t *be = g_be;
+    const int32_t *st = NULL;
+    int r = be ? be->wait(be->ctx, c->gpu_slot, &st) : -1;
+    for (int i = 0; i < c->n_blk; i++)
+        if (r != 0 || !st || st[i] != 0) { c->blk[i].err = inflate_block(&c->blk[i]); __atomic_fetch_add(&g_be_fallback_blocks, 1ull, __ATOMIC_RELAXED); }
+    be_release_slot(c->gpu_slot);
+    c->gpu_slot = -1;
+}
+
 static chunk_t *chunk_new(void) {
     chunk_t *c = (chunk_t *)calloc(1, sizeof(*c));
     if (!c) return NULL;
-    c->buf = (uint8_t *)malloc(CHUNK_HEAD + CHUNK_PAYLOAD);
+    c->gpu_slot = -1;
+    if (g_be && g_be->host_alloc) {   /* a device inflater: groups of GPU_GROUP_BLOCKS, decoded into pinned memory */
+        c->buf = (uint8_t *)g_be->host_alloc(CHUNK_HEAD + (size_t)GPU_GROUP_BLOCKS * 65536);
+        c->pinned = c->buf != NULL;
+        c->cap_blocks = GPU_GROUP_BLOCKS;
+    }
+    if (!c->buf) { c->buf = (uint8_t *)malloc(CHUNK_HEAD + CHUNK_PAYLOAD); c->pinned = 0; c->cap_blocks = GROUP_BLOCKS; }
     c->cbuf = (uint8_t *)malloc(GROUP_CBYTES + 65536 + 1024);
     pthread_mutex_init(&c->grp.mu, NULL);
     pthread_cond_init(&c->grp.cv, NULL);
@@ -286,8 +377,10 @@ static chunk_t *chunk_new(void) {
 static void chunk_free(chunk_t *c) {
     if (!c) return;
     group_wait(&c->grp);   /* (a reader closed early: its workers may still be writing into the chunk) */
+    if (c->gpu_slot >= 0 && g_be) { const int32_t *st; (void)g_be->wait(g_be->ctx, c->gpu_slot, &st); be_release_slot(c->gpu_slot); }
     pthread_mutex_destroy(&c->grp.mu); pthread_cond_destroy(&c->grp.cv);
-    free(c->buf); free(c->cbuf); free(c);
+    if (c->pinned && g_be && g_be->host_free) g_be->host_free(c->buf); else if (!c->pinned) free(c->buf);
+    free(c->cbuf); free(c);
 }
 
 /* one BGZF block header at h (avail bytes are there): total block size, or 0 if the header itself is cut off, -1 if bad */
@@ -315,7 +408,8 @@ static long block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) {
 static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
     size_t out = 0, cbytes = 0;
     int n = 0;
-    while (n < GROUP_BLOCKS && cbytes < GROUP_CBYTES && b->map_pos < b->map_len) {
+    const size_t max_blk = c->cap_blocks, max_cb = c->cap_blocks > GROUP_BLOCKS ? GPU_GROUP_CBYTES : GROUP_CBYTES;
+    while ((size_t)n < max_blk && cbytes < max_cb && b->map_pos < b->map_len) {
         const uint8_t *h = b->map + b->map_pos;
         uint32_t xlen = 0;
         long total = block_total(h, b->map_len - b->map_pos, &xlen);
@@ -427,10 +521,11 @@ static void *producer_main(void *arg) {
             pthread_mutex_unlock(&b->mu);
             return NULL;
         }
-        c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0;
+        c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0; c->gpu_slot = -1;
         if (!c->buf || !c->cbuf || (b->map ? read_group_mapped(b, c) : read_group(b, c)) != 0) c->err = 1;
         else if (c->n_blk > 0) {
-            if (b->pool) pool_submit(b->pool, c->n_blk, 2, inflate_range, c, &c->grp, GROUP_TICKETS, 0);
+            if (b->map && be_submit_group(b->pool, c) == 0) { /* the device has it */ }
+            else if (b->pool) pool_submit(b->pool, c->n_blk, 2, inflate_range, c, &c->grp, GROUP_TICKETS, 0);
             else inflate_range(c, 0, c->n_blk);
         }
         int stop = c->err || c->last;
@@ -465,6 +560,7 @@ static chunk_t *take_chunk(mm_bam_t *b) {
     if (!c) { b->failed = 1; b->eof = 1; return NULL; }
     c->next = NULL;
     group_wait(&c->grp);
+    if (c->gpu_slot >= 0) be_finish_group(c);
     b->wait_s += mono_s() - t_in;
     for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
     if (c->err) { b->failed = 1; b->eof = 1; hold(b, c); return NULL; }

@@ -31,6 +31,24 @@ typedef struct mm_bam_rec {
 typedef struct mm_bam mm_bam_t;
 
 /* worker pool shared by the reader (block inflate) and the loader (parallel copy into the flattened pools) */
+/* A device-side BGZF inflater the reader may hand whole groups of blocks to (include/minimod_bgzf.h has one; this library does
+ * not link it: the program that does fills the table in).  Groups the backend has no free slot for -- and blocks it refuses --
+ * are inflated by the host pool as without it. */
+typedef struct mm_bgzf_backend {
+    void *ctx;
+    int slots, max_blocks;            /* launches in flight; blocks, payload bytes, decoded bytes per launch */
+    size_t max_cbytes, max_obytes;
+    void *(*host_alloc)(size_t);      /* pinned host memory for the decoded groups */
+    void (*host_free)(void *);
+    uint8_t *(*staging)(void *ctx, int slot);
+    void *(*blocks)(void *ctx, int slot);   /* records of five uint32: payload offset, payload length, output offset, ISIZE, CRC32 */
+    int (*submit)(void *ctx, int slot, int n_blocks, size_t cbytes, size_t obytes, uint8_t *out_host);
+    int (*wait)(void *ctx, int slot, const int32_t **status);
+} mm_bgzf_backend_t;
+void mm_bam_set_backend(const mm_bgzf_backend_t *be);   /* process-wide; NULL: host inflate only.  Before the readers are opened;
+                                                         * the table must outlive them */
+void mm_bam_backend_stats(unsigned long long out[3]);   /* groups and blocks given to the device, blocks inflated again on the host */
+
 typedef struct mm_pool mm_pool_t;
 mm_pool_t *mm_pool_create(int n_threads);
 void mm_pool_destroy(mm_pool_t *p);

@@ -11,6 +11,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include "minimod_bgzf.h"
 #include "mmhost.h"
 
 static struct option long_options[] = {
@@ -35,6 +36,7 @@ static struct option long_options[] = {
     {"devices", required_argument, 0, 0},          /* 18 (new: one worker process per listed GPU, the genome cut into shares) */
     {"canonical-order", no_argument, 0, 0},        /* 19 (new: rows that tie on (contig, start) in a fixed order instead of the reference's hash order) */
     {"gather", required_argument, 0, 0},           /* 20 (new: -K batches that may share one kernel launch) */
+    {"gpu-inflate", no_argument, 0, 0},            /* 21 (new: BGZF blocks inflated on the device, next to the host pool) */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -56,11 +58,12 @@ static struct option view_long_options[] = {
     {"skip-supplementary", no_argument, 0, 0},
     {"device", required_argument, 0, 0},
     {"devices", required_argument, 0, 0},
+    {"gpu-inflate", no_argument, 0, 0},
     {0, 0, 0, 0}};
 
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device, view, canonical_order, gather;
+    int progress_interval, device, view, canonical_order, gather, gpu_inflate;
     const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
@@ -116,7 +119,38 @@ static void print_help(FILE *fp, const fopt_t *o) {
                               "                              minimod's hash table leaves them in (skips the replay of that table) [%s]\n", o->canonical_order ? "yes" : "no");
     if (!o->view) fprintf(fp, "   --gather INT               -K batches that may share one kernel launch (they are staged in GPU memory one behind the\n"
                               "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
+    fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
+                "                              -t host threads; blocks the device refuses are the host decoder's) [%s]\n", o->gpu_inflate ? "yes" : "no");
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
+}
+
+/* --gpu-inflate: the device inflater of include/minimod_bgzf.h behind the reader's backend table (bamio.h) */
+static uint8_t *bz_staging(void *ctx, int slot) { return mm_bgzf_staging((mm_bgzf_t *)ctx, slot); }
+static void *bz_blocks(void *ctx, int slot) { return mm_bgzf_blocks((mm_bgzf_t *)ctx, slot); }
+static int bz_submit(void *ctx, int slot, int n, size_t cb, size_t ob, uint8_t *out) { return mm_bgzf_submit((mm_bgzf_t *)ctx, slot, n, cb, ob, out); }
+static int bz_wait(void *ctx, int slot, const int32_t **st) { return mm_bgzf_wait((mm_bgzf_t *)ctx, slot, st); }
+static mm_bgzf_backend_t bz_backend;
+static mm_bgzf_t *bz_start(int device) {
+    char err[256];
+    const int slots = 4;
+    mm_bgzf_t *bz = mm_bgzf_create(device, slots, 1024, ((size_t)41 << 20), ((size_t)64 << 20), err, sizeof err);
+    if (!bz) { MMH_WARNING("--gpu-inflate: %s; the host threads inflate alone", err); return NULL; }
+    bz_backend.ctx = bz; bz_backend.slots = slots; bz_backend.max_blocks = 1024;
+    bz_backend.max_cbytes = (size_t)41 << 20; bz_backend.max_obytes = (size_t)64 << 20;
+    bz_backend.host_alloc = mm_bgzf_host_alloc; bz_backend.host_free = mm_bgzf_host_free;
+    bz_backend.staging = bz_staging; bz_backend.blocks = bz_blocks; bz_backend.submit = bz_submit; bz_backend.wait = bz_wait;
+    mm_bam_set_backend(&bz_backend);
+    mmh_loader_set_allocator(mm_bgzf_host_alloc, mm_bgzf_host_free);   /* (the batches leave by DMA as well) */
+    return bz;
+}
+static void bz_stop(mm_bgzf_t *bz) {
+    if (!bz) return;
+    unsigned long long st[3];
+    mm_bam_backend_stats(st);
+    fprintf(stderr, "[gpu-inflate] %llu groups (%llu blocks) inflated on the device, %llu blocks again on the host\n", st[0], st[1], st[2]);
+    mm_bam_set_backend(NULL);
+    mmh_loader_set_allocator(NULL, NULL);
+    mm_bgzf_destroy(bz);
 }
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
@@ -308,6 +342,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         close(ws->fd);
         return 0;
     }
+    mm_bgzf_t *bz = o.gpu_inflate ? bz_start(o.device) : NULL;
     mmh_loader_t *ld = ws->sharded
         ? mmh_loader_open_share(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
                                 ws->hi_tid, ws->hi_pos, ws->first, ws->last)
@@ -362,7 +397,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
     }
 
-    double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0;
+    double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0, submit_time = 0;
     int more = 1, counter = 0, set = 0;
     int32_t pending_ticket = -1, pending_vticket = -1;
     const uint8_t *klass_of_code[MM_MAX_CODES];
@@ -403,7 +438,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (!view) retire_group(h, prev, hdr, &process_wait_time);
         if (n > 0) {
             if (wildcard) { intern_batch_codes(h, &batch); if (replay) intern_batch_codes(hv, &batch); }
+            const double t_sub = mmh_realtime();
             int32_t tk = mm_freq_submit(h, &batch);
+            submit_time += mmh_realtime() - t_sub;
             if (tk < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(tk)); exit(EXIT_FAILURE); }
             pending_batch = batch;
             if (view) pending_ticket = tk;
@@ -557,7 +594,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             mm_freq_destroy(h);
             if (hv) mm_freq_destroy(hv);
             mmh_tie_destroy(tie);
-            mmh_loader_close(ld);
+            mmh_loader_close(ld); bz_stop(bz);
             return 0;
         }
         mm_row_t *ordered = NULL;
@@ -593,7 +630,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (write_all(ws->fd, &tt, sizeof tt)) { MMH_ERROR("%s", "Could not send the totals to the parent process"); exit(EXIT_FAILURE); }
         close(ws->fd);
         mm_freq_destroy(h);
-        mmh_loader_close(ld);
+        mmh_loader_close(ld); bz_stop(bz);
         return 0;
     }
 
@@ -605,6 +642,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fprintf(stderr, "\n[%s] total processed bytes: %.1f M", __func__, ld->processed_bytes / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] total processed bases: %.1f M", __func__, ld->processed_bases / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] Data loading time: %.3f sec", __func__, load_time);
+    fprintf(stderr, "\n[%s] Batch hand-over time: %.3f sec (mm_freq_submit: host -> device copies queued, launches)", __func__, submit_time);
     fprintf(stderr, "\n[%s] Data processing time: %.3f sec (waiting for the GPU; the rest overlaps loading)", __func__, process_wait_time);
     fprintf(stderr, "\n[%s] Data merging time: %.3f sec", __func__, 0.0);
     fprintf(stderr, "\n[%s] Data sorting time: %.3f sec", __func__, sort_time);
@@ -618,7 +656,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mm_freq_destroy(h);
     if (hv) mm_freq_destroy(hv);
     mmh_tie_destroy(tie);
-    mmh_loader_close(ld);
+    mmh_loader_close(ld); bz_stop(bz);
     return 0;
 }
 
@@ -969,6 +1007,7 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "device") == 0) { o.device = atoi(optarg);
         } else if (c == 0 && strcmp(lname, "devices") == 0) { o.devices = optarg;
         } else if (c == 0 && strcmp(lname, "canonical-order") == 0) { o.canonical_order = 1;
+        } else if (c == 0 && strcmp(lname, "gpu-inflate") == 0) { o.gpu_inflate = 1;
         } else if (c == 0 && strcmp(lname, "gather") == 0) {
             o.gather = atoi(optarg);
             if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }

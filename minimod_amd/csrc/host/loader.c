@@ -14,7 +14,7 @@
 enum { P_READS = 0, P_CIGAR, P_SEQ, P_MM, P_ML, P_QOFF, P_QNAME };   /* the last two stay on the host (view prints read names) */
 #define NPOOL 7
 
-typedef struct { uint8_t *p; size_t n, cap; } pool_t;
+typedef struct { uint8_t *p; size_t n, cap; int foreign; } pool_t;   /* foreign: from the caller's allocator */
 
 
 /* one accepted record: where its parts lie in the reader's buffers and where they go in the pools */
@@ -41,16 +41,33 @@ typedef struct loader_priv {
 } loader_priv_t;
 #define PRIV(ld) ((loader_priv_t *)(ld)->priv)
 
-static void pool_reserve(pool_t *b, size_t bytes) {
+/* The device-bound pools (records, CIGARs, sequences, MM, ML) may come from an allocator of the caller's: pinned memory makes
+ * mm_freq_submit's host -> device copies DMA transfers instead of the runtime's staged copies (mmh_loader_set_allocator). */
+static void *(*pool_alloc_fn)(size_t) = NULL;
+static void (*pool_free_fn)(void *) = NULL;
+void mmh_loader_set_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *)) { pool_alloc_fn = alloc_fn; pool_free_fn = free_fn; }
+
+static void pool_release(pool_t *b) {
+    if (b->p) { if (b->foreign) pool_free_fn(b->p); else free(b->p); }
+    b->p = NULL; b->cap = 0; b->foreign = 0;
+}
+static void pool_reserve_kind(pool_t *b, size_t bytes, int device_bound) {
     if (bytes > b->cap) {
         size_t nc = b->cap ? b->cap : ((size_t)1 << 22);
         while (nc < bytes) nc *= 2;
-        free(b->p);                       /* contents are rebuilt for every batch */
-        b->p = (uint8_t *)malloc(nc);
+        pool_release(b);                  /* contents are rebuilt for every batch */
+        if (device_bound && pool_alloc_fn && pool_free_fn) {
+            /* pinning costs by the byte and the pools of a run settle at the size of its biggest batch: no doubling, a quarter more */
+            nc = bytes + bytes / 4 + ((size_t)1 << 20);
+            b->p = (uint8_t *)pool_alloc_fn(nc);
+            b->foreign = b->p != NULL;
+        }
+        if (!b->p) { b->p = (uint8_t *)malloc(nc); b->foreign = 0; }
         b->cap = nc;
     }
     b->n = bytes;
 }
+static void pool_reserve(pool_t *b, size_t bytes) { pool_reserve_kind(b, bytes, 0); }
 static double loader_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -201,8 +218,8 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     /* ---- step 2: sizes are known: reserve, copy in parallel, zero the tails (every pool ends in >= 64 zero bytes) */
     size_t e_cigar = o_cigar, e_seq = o_seq, e_mm = o_mm, e_ml = o_ml;
     o_cigar = align_up(o_cigar, 16) + 64; o_seq = align_up(o_seq, 16) + 64; o_mm = align_up(o_mm, 16) + 64; o_ml = align_up(o_ml, 4) + 64;
-    pool_reserve(&P[P_READS], sizeof(mm_read_t) * (size_t)(n > 0 ? n : 1));
-    pool_reserve(&P[P_CIGAR], o_cigar); pool_reserve(&P[P_SEQ], o_seq); pool_reserve(&P[P_MM], o_mm); pool_reserve(&P[P_ML], o_ml);
+    pool_reserve_kind(&P[P_READS], sizeof(mm_read_t) * (size_t)(n > 0 ? n : 1), 1);
+    pool_reserve_kind(&P[P_CIGAR], o_cigar, 1); pool_reserve_kind(&P[P_SEQ], o_seq, 1); pool_reserve_kind(&P[P_MM], o_mm, 1); pool_reserve_kind(&P[P_ML], o_ml, 1);
     pool_reserve(&P[P_QOFF], 8 * (size_t)(n > 0 ? n : 1)); pool_reserve(&P[P_QNAME], o_qname + 1);
     copy_ctx_t cc = {P, lp->items};
     mm_pool_t *pool = mm_bam_pool(ld->bam);
@@ -246,7 +263,7 @@ void mmh_loader_close(mmh_loader_t *ld) {
     }
     mm_bam_close(ld->bam);
     loader_priv_t *lp = PRIV(ld);
-    for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) free(lp->sets[s][i].p);
+    for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) pool_release(&lp->sets[s][i]);
     free(lp->items);
     free(lp);
     free(ld);

@@ -73,6 +73,9 @@ mmh_loader_t *mmh_loader_open_share(const char *bam_path, int threads, int32_t K
  * Returns the number of accepted reads, or -1 on a read error.  *more = 0 when the reference's loop would stop
  * (src/freq_main.c:410). */
 int32_t mmh_loader_next(mmh_loader_t *ld, int pool_set, mm_batch_t *out, int *more);
+/* process-wide, before the loaders are opened: where the batches' device-bound arrays come from (pinned memory: the copies of
+ * mm_freq_submit become DMA transfers); NULL, NULL = malloc */
+void mmh_loader_set_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *));
 /* read name of read `read` of the batch last loaded into `pool_set` */
 const char *mmh_loader_qname(const mmh_loader_t *ld, int pool_set, int32_t read);
 void mmh_loader_close(mmh_loader_t *ld);

@@ -1,0 +1,152 @@
+"""Device-side BGZF inflate (include/minimod_bgzf.h, csrc/bgzf_kernels.hip.h) against zlib: the reference's BAM files block by
+block, synthetic streams of every DEFLATE block type and shape, the CRC32 check, and what a damaged block's status says."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def inf():
+    from minimod_amd import bgzf
+    h = bgzf.Inflater(slots=2, max_blocks=4096, max_cbytes=64 << 20, max_obytes=192 << 20)
+    yield h
+    h.close()
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def make_block(data, **kw):
+    return (raw_deflate(data, **kw), len(data), zlib.crc32(data) & 0xFFFFFFFF)
+
+
+def check(inf, blocks, want):
+    got, status = inf.inflate(blocks)
+    assert status.tolist() == [0] * len(blocks), status.tolist()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "block %d differs (first at %d of %d)" % (i, next(k for k in range(min(len(g), len(w))) if g[k] != w[k]) if len(g) == len(w) else -1, len(w))
+
+
+def test_reference_bams_block_by_block(inf):
+    from minimod_amd import bgzf
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "data", "*.bam")))
+    assert files
+    for f in files:
+        blocks = bgzf.split_bgzf(open(f, "rb").read())
+        want = [zlib.decompress(p, -15) for p, _, _ in blocks]
+        for k in range(0, len(blocks), 4096):
+            check(inf, blocks[k:k + 4096], want[k:k + 4096])
+
+
+def test_every_block_type_and_shape(inf):
+    rng = np.random.default_rng(11)
+    datas = [b"", b"A", b"AB" * 32000 + b"x", bytes(rng.integers(0, 256, 65280, dtype=np.uint8)),
+             bytes(rng.integers(0, 4, 65000, dtype=np.uint8)), b"\x00" * 65280, bytes(range(256)) * 255,
+             bytes(rng.choice(np.frombuffer(b"ACGT,;0123456789", dtype=np.uint8), 60000)),
+             b"".join(bytes([int(x)]) * int(n) for x, n in zip(rng.integers(0, 256, 3000), rng.integers(1, 40, 3000)))[:65280]]
+    blocks, want = [], []
+    for d in datas:
+        for kw in (dict(level=6), dict(level=1), dict(level=9), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY),
+                   dict(level=6, strategy=zlib.Z_RLE), dict(level=9, wbits=-9)):
+            blocks.append(make_block(d, **kw)); want.append(d)
+    # several DEFLATE blocks in one BGZF block (sync flushes in between), a stored block in the middle
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [bytes(rng.integers(0, 50, 9000, dtype=np.uint8)) for _ in range(5)]
+    raw = b"".join(c.compress(p) + c.flush(zlib.Z_SYNC_FLUSH if i != 2 else zlib.Z_FULL_FLUSH) for i, p in enumerate(parts)) + c.flush()
+    whole = b"".join(parts)
+    blocks.append((raw, len(whole), zlib.crc32(whole))); want.append(whole)
+    check(inf, blocks, want)
+
+
+def test_long_codes_and_far_matches(inf):
+    """Skewed symbol statistics give codes longer than the first-level tables (11 / 8 bits); matches at the window's far end."""
+    rng = np.random.default_rng(5)
+    p = 1.0 / (1.6 ** np.arange(256)); p /= p.sum()
+    skew = bytes(rng.choice(256, 65000, p=p).astype(np.uint8))
+    far = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    far = far + bytes(rng.integers(0, 256, 2700, dtype=np.uint8)) + far[:32000]
+    blocks = [make_block(skew, level=9), make_block(far[:65280], level=9), make_block(skew[:1000] * 60, level=9)]
+    check(inf, blocks, [skew, far[:65280], (skew[:1000] * 60)])
+
+
+def test_damaged_blocks_are_reported_not_decoded(inf):
+    rng = np.random.default_rng(3)
+    good = bytes(rng.integers(0, 16, 40000, dtype=np.uint8))
+    payload, isize, crc = make_block(good)
+    flipped = bytearray(payload); flipped[len(flipped) // 2] ^= 0x10
+    blocks = [(payload, isize, crc), (payload, isize, crc ^ 1), (payload, isize - 1, crc), (payload[:len(payload) // 2], isize, crc),
+              (bytes(flipped), isize, crc), (bytes(rng.integers(0, 256, 500, dtype=np.uint8)), 4000, 0), (payload, isize, crc)]
+    got, status = inf.inflate(blocks)
+    assert status[0] == 0 and status[6] == 0 and got[0] == good and got[6] == good
+    assert status[1] == 9                      # CRC mismatch
+    assert all(int(s) != 0 for s in status[1:6])
+
+
+def test_two_slots_in_flight_and_a_file_sized_launch(inf):
+    """A C2-shape BAM's blocks, thousands per launch, two launches in flight; every decoded byte against zlib."""
+    from minimod_amd import bgzf, synth
+    import tempfile
+    ref = synth.reference(3, 4 << 20)
+    bs = [synth.batch(ref, i * 2048, 2048, seed=9, n_reads_total=4096, with_order=False) for i in range(2)]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "s.bam")
+        synth.write_bam_parallel(path, [("chrS", len(ref))], bs, threads=4)
+        blocks = bgzf.split_bgzf(open(path, "rb").read())
+    want = [zlib.decompress(p, -15) for p, _, _ in blocks]
+    half = len(blocks) // 2
+    groups = [blocks[:half], blocks[half:]]
+    sizes = [inf.fill(s, g) for s, g in enumerate(groups)]
+    for s, (n, c, o) in enumerate(sizes):
+        inf.submit(s, n, c, o)
+    k = 0
+    for s, (n, c, o) in enumerate(sizes):
+        st = inf.wait(s, n)
+        assert not st.any()
+        out, br = inf.out_buffer(s), inf.blocks(s)
+        for i in range(n):
+            a = int(br[i]["o_off"])
+            assert bytes(out[a:a + int(br[i]["isize"])]) == want[k], (s, i)
+            k += 1
+        t = inf.times(s)
+        assert t and t["inflate_ms"] > 0
+    assert k == len(blocks)
+
+
+def test_cli_with_gpu_inflate_writes_the_same_bytes(tmp_path):
+    """`minimod freq --gpu-inflate`: a reference golden (a file smaller than one group) and a synthetic BAM of several groups,
+    byte for byte what the host pool alone gives; the log says how many groups the device took."""
+    import subprocess
+    from minimod_amd import synth
+    root = os.path.dirname(HERE)
+    cli = os.path.join(root, "minimod_amd", "bin", "minimod")
+    data = os.path.join(HERE, "golden", "data")
+    ref = synth.reference(3, 8 << 20)
+    bs = [synth.batch(ref, i * 2048, 2048, seed=4, n_reads_total=8192, with_order=False) for i in range(4)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam_parallel(bam, [("chrS", len(ref))], bs, threads=4)
+    synth.write_fasta(fa, "chrS", ref)
+    cases = [(os.path.join(data, "example-ont.bam"), os.path.join(data, "hg38_chr22.fa") if os.path.exists(os.path.join(data, "hg38_chr22.fa")) else None),
+             (bam, fa)]
+    for b, f in cases:
+        if f is None:
+            continue
+        outs = []
+        for flags in ([], ["--gpu-inflate"]):
+            out = str(tmp_path / ("o%d.bed" % len(outs)))
+            r = subprocess.run([cli, "freq", "-b", "-c", "m[CG]", "-t", "4", "-o", out] + flags + [f, b], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs.append((open(out, "rb").read(), r.stderr.decode()))
+        assert outs[0][0] == outs[1][0]
+        assert "[gpu-inflate]" in outs[1][1]
+        if b == bam:
+            import re
+            m = re.search(r"\[gpu-inflate\] (\d+) groups \((\d+) blocks\) inflated on the device, (\d+) blocks again on the host", outs[1][1])
+            assert m and int(m.group(1)) >= 1 and int(m.group(3)) == 0, outs[1][1][-500:]

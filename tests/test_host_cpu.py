@@ -28,6 +28,19 @@ def test_abi_exports_every_declared_symbol():
     assert [n for n in engine.READ_DTYPE.names] == [n for n in pybam.READ_DTYPE.names]
 
 
+def test_bgzf_abi_symbols_exported():
+    """Every function include/minimod_bgzf.h declares is exported by the device library (no calls: there is no GPU here)."""
+    import ctypes, re
+    from minimod_amd import bgzf, build
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "minimod_bgzf.h")).read()
+    declared = set(re.findall(r"\b(mm_bgzf_[a-z_]+)\s*\(", hdr))
+    assert declared == set(bgzf.EXPORTS)
+    L = ctypes.CDLL(build.lib_path())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert bgzf.BLOCK_DTYPE.itemsize == 20
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
