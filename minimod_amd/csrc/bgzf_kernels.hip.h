@@ -17,7 +17,7 @@
 //     CRC per lane, the slices' registers combined by multiplying with x^(8 * bytes behind the slice) modulo the polynomial.
 // Measured: 11.0 GB/s of decoded bytes per MI355X on a C2-shape BAM.  Literals are decoded in bursts (a
 // candidate symbol at every bit offset of a 64-bit window from one 64-lane table lookup, the scalar unit walks the chain); a
-// match still costs the scalar path's ~240 ns (sixty instructions with a dozen branches, two dependent lookups), and a BAM's
+// match still costs the scalar path's ~0.8 us (two dependent lookups, sixty instructions with a dozen branches each, a ring copy), and a BAM's
 // blocks are half matches: a correct, tested first form, not yet the fast one.
 // Anything the decoder does not like (a malformed stream, a size or CRC mismatch) is a status word per block: the host's own
 // decoder (csrc/host/inflate_fast.c, then zlib) has the last word on such a block, so error behaviour stays what it was.
