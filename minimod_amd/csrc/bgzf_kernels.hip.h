@@ -349,6 +349,24 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
             b.bitpos = (uint64_t)uni(t.bit_lo) | ((uint64_t)uni(t.bit_hi) << 32);
             st = (int)uni((uint32_t)t.st);
             if (st != S_OK) return st;
+            // a match's bytes: out[at + i] = out[at - dist + i mod dist], all lanes at once, from the ring when the source is that near
+            auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) {
+                const uint32_t s0 = at - dist;
+                if (s0 + kNear < at) {
+                    // a far source: flushed bytes, in global memory -- behind a fence if they were flushed since the last one
+                    // (agent-scope loads: from L2, where the stores are -- a line of the vector cache may be older than they)
+                    const uint32_t src_end = s0 + (len < dist ? len : dist);
+                    if (src_end > fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
+                }
+                lds_sync();   // (the bytes in front of the match are other lanes' stores)
+                for (uint32_t i = (uint32_t)l; i < len; i += 64u) {
+                    const uint32_t p = s0 + (dist >= len ? i : i % dist);
+                    uint8_t v;
+                    if (p + kNear >= at) v = S.ring[p & (kRing - 1u)];
+                    else v = __hip_atomic_load(out + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S.ring[(at + i) & (kRing - 1u)] = v;
+                }
+            };
             // ---- the block's symbols
             uint32_t burst_wait = 0;
             for (;;) {
@@ -361,33 +379,76 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 }
                 uint32_t bits = b.peek32();
                 if (burst_wait == 0u) {
-                    // A BURST of literals: every lane looks up the symbol that would start at ITS bit offset behind the reader's
-                    // position (64 candidate symbols from one table lookup); the scalar unit then only walks the chain from
-                    // symbol to symbol -- one v_readlane a literal instead of sixty instructions -- until a symbol that is not a
-                    // first-level literal, or the 64 bits end.  The chain's lanes store their bytes side by side.
+                    // A BURST of symbols: every lane decodes the TOKEN that would start at ITS bit offset behind the reader's
+                    // position -- a literal, or a length with its extra bits, its distance code and that code's extra bits (64
+                    // candidate tokens from two table lookups; a lane has 64 bits of the stream from its offset on, a token is at
+                    // most 37) -- and the scalar unit only walks the chain from token to token: a literal is a select (its
+                    // place in the output), a match is copied at once (the literals in front of it stored first), until a token
+                    // that needs the plain path (end of block, a code longer than the first-level tables) or the 64 offsets end.
                     const uint32_t bp = (uint32_t)(b.bitpos - 8ull * (uint64_t)b.wpos) + (uint32_t)l;   // (peek32 has placed the window)
-                    const uint32_t i0 = bp >> 5, i1 = i0 + 1u;
-                    const uint32_t a0 = (uint32_t)__shfl((int)b.va, (int)(i0 & 63u)), b0 = (uint32_t)__shfl((int)b.vb, (int)(i0 & 63u));
-                    const uint32_t a1 = (uint32_t)__shfl((int)b.va, (int)(i1 & 63u)), b1 = (uint32_t)__shfl((int)b.vb, (int)(i1 & 63u));
-                    const uint64_t w64 = (uint64_t)(i0 < 64u ? a0 : b0) | ((uint64_t)(i1 < 64u ? a1 : b1) << 32);
-                    const uint32_t ev = S.ll[(uint32_t)(w64 >> (bp & 31u)) & ((1u << kLL) - 1u)];
-                    const uint64_t litmask = __ballot((ev & 0xF0u) == 0u && (ev & 15u) != 0u);
-                    uint32_t pos = 0, cnt = 0;
-                    uint64_t chain = 0;
-                    while (pos < 64u && ((litmask >> pos) & 1ull)) {
-                        chain |= 1ull << pos;
-                        cnt++;
-                        pos += (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)pos) & 15u;
+                    const uint32_t i0 = bp >> 5, sh = bp & 31u;
+                    uint32_t wd[3];
+#pragma unroll
+                    for (uint32_t k = 0; k < 3u; k++) {
+                        const uint32_t idx = i0 + k;
+                        const uint32_t xa = (uint32_t)__shfl((int)b.va, (int)(idx & 63u)), xb = (uint32_t)__shfl((int)b.vb, (int)(idx & 63u));
+                        wd[k] = idx < 64u ? xa : xb;
                     }
-                    if (cnt) {
-                        if (o + cnt > isize) return S_OVERRUN_OUT;
-                        if ((chain >> l) & 1ull) S.ring[(o + (uint32_t)__popcll(chain & ((1ull << l) - 1ull))) & (kRing - 1u)] = (uint8_t)(ev >> 16);
-                        o = uni(o + cnt);
+                    uint64_t bits64 = (((uint64_t)wd[1] << 32) | (uint64_t)wd[0]) >> sh;
+                    if (sh) bits64 |= (uint64_t)wd[2] << (64u - sh);
+                    const uint32_t e1 = S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)];
+                    const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
+                    uint32_t t_type = 2u, t_bits = 0u, t_val = 0u, t_dist = 0u;   // 0 literal (val = byte), 1 match (val = length), 2 the plain path's
+                    if (l1 != 0u && k1 == (uint32_t)K_LIT) { t_type = 0u; t_bits = l1; t_val = e1 >> 16; }
+                    else if (l1 != 0u && k1 == (uint32_t)K_LEN) {
+                        const uint32_t xl = (e1 >> 8) & 31u;
+                        const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
+                        const uint32_t used = l1 + xl;
+                        const uint32_t dbits = (uint32_t)(bits64 >> used);
+                        const uint32_t d = S.dt[dbits & ((1u << kD) - 1u)];
+                        const uint32_t dl = d & 15u;
+                        if (dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST) {
+                            const uint32_t xd = (d >> 8) & 31u;
+                            t_dist = (d >> 16) + ((dbits >> dl) & ((1u << xd) - 1u));
+                            t_type = 1u; t_bits = used + dl + xd; t_val = mlen;
+                        }
+                    }
+                    const uint32_t t_head = t_type | (t_bits << 8);
+                    uint32_t pos = 0, oo = o, outoff = 0;
+                    uint64_t pend = 0;   // literal lanes of the chain whose bytes are not in the ring yet
+                    int fail = S_OK;
+                    while (pos < 64u) {
+                        const uint32_t th = (uint32_t)__builtin_amdgcn_readlane((int)t_head, (int)pos);
+                        const uint32_t ty = th & 255u;
+                        if (ty == 2u) break;
+                        if (ty == 0u) {
+                            if (oo >= isize) { fail = S_OVERRUN_OUT; break; }
+                            outoff = (uint32_t)l == pos ? oo : outoff;
+                            pend |= 1ull << pos;
+                            oo++;
+                        } else {
+                            const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)t_val, (int)pos);
+                            const uint32_t md = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, (int)pos);
+                            if (md > oo) { fail = S_BAD_DISTANCE; break; }
+                            if (oo + mlen > isize) { fail = S_OVERRUN_OUT; break; }
+                            if (pend) { if ((pend >> l) & 1ull) S.ring[outoff & (kRing - 1u)] = (uint8_t)t_val; pend = 0; }
+                            if (oo - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                            copy_match(oo, mlen, md);
+                            oo += mlen;
+                        }
+                        pos += th >> 8;
+                    }
+                    if (pend && ((pend >> l) & 1ull)) S.ring[outoff & (kRing - 1u)] = (uint8_t)t_val;
+                    if (fail != S_OK) return fail;
+                    if (pos) {
+                        guard += pos;
+                        o = uni(oo);
                         b.bitpos += (uint64_t)pos;
-                        guard += cnt;
-                        if (pos >= 64u) continue;          // the window was all literals: another burst
-                        bits = b.peek32();                 // behind the literals: a length, the end of the block, a long code
-                    } else burst_wait = 3u;                // (no literal here: a few symbols the plain way first)
+                        f = uni(f); fenced = uni(fenced);
+                        if (pos >= 64u) continue;          // every offset of the window belonged to a token: another burst
+                        b.settle();
+                        bits = b.peek32();                 // the token the chain stopped at
+                    } else burst_wait = 3u;                // (nothing for a burst here: a few symbols the plain way first)
                 } else burst_wait--;
                 uint32_t e = uni(S.ll[bits & ((1u << kLL) - 1u)]);
                 if ((e & 15u) == 0u) { e = decode_long(b, S.cl_ll, false); if ((e & 15u) == 0u) return S_BAD_SYMBOL; }
@@ -414,21 +475,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 b.bitpos += (d & 15u) + xd;
                 if (dist > o) return S_BAD_DISTANCE;
                 if (o + len > isize) return S_OVERRUN_OUT;
-                const uint32_t s0 = o - dist;
-                if (s0 + kNear < o) {
-                    // a far source: flushed bytes, in global memory -- behind a fence if they were flushed since the last one
-                    // (agent-scope loads: from L2, where the stores are -- a line of the vector cache may be older than they)
-                    const uint32_t src_end = s0 + (len < dist ? len : dist);
-                    if (src_end > fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
-                }
-                lds_sync();   // (the literals in front of the match are lane 0's stores)
-                for (uint32_t i = (uint32_t)l; i < len; i += 64u) {
-                    const uint32_t p = s0 + (dist >= len ? i : i % dist);
-                    uint8_t v;
-                    if (p + kNear >= o) v = S.ring[p & (kRing - 1u)];
-                    else v = __hip_atomic_load(out + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    S.ring[(o + i) & (kRing - 1u)] = v;
-                }
+                copy_match(o, len, dist);
                 o = uni(o + len);
                 b.settle();
             }
