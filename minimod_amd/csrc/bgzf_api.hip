@@ -54,8 +54,12 @@ mm_bgzf_t* mm_bgzf_create(int32_t device, int32_t slots, int32_t max_blocks, siz
     BCHK(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount;
     h->slots.resize((size_t)slots);
+    // the lowest stream priority there is: the inflate's workgroups run for milliseconds, and what shares the device with them
+    // (the freq path's launches and copies) should get the CUs they leave first
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (BSlot& s : h->slots) {
-        BCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        BCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_least));
         for (auto& e : s.ev) BCHK(hipEventCreate(&e));
         BCHK(hipHostMalloc((void**)&s.h_c, max_cbytes + 64, hipHostMallocDefault));
         BCHK(hipHostMalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)max_blocks, hipHostMallocDefault));
