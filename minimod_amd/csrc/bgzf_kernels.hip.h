@@ -27,7 +27,7 @@
 
 namespace mmbgzf {
 
-constexpr int kLL = 11, kD = 8;                 // first-level table bits
+constexpr int kLL = 10, kD = 8;                 // first-level table bits
 constexpr int kWaves = 4;                       // wavefronts per workgroup
 constexpr size_t kPad = 1024;                   // readable bytes behind a launch's compressed bytes
 enum { S_OK = 0, S_BAD_BLOCK_TYPE = 1, S_BAD_STORED = 2, S_BAD_CODE_LENGTHS = 3, S_BAD_SYMBOL = 4, S_BAD_DISTANCE = 5, S_OVERRUN_OUT = 6,
