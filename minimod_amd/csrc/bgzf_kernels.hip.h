@@ -61,7 +61,7 @@ struct WaveLds {
     CodeLds cl_ll, cl_d;
     uint8_t lens[320];    // litlen lengths, then distance lengths
     uint32_t clt[128];    // the code-length code's table
-    uint8_t ring[4096];   // the block's latest output (kRing)
+    uint8_t ring[2048];   // the block's latest output (kRing)
 };
 
 __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
@@ -297,7 +297,7 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
 // source lies that near (nearly all of them) is an LDS copy; every kFlush bytes the ring's older half goes to global memory in
 // whole dwords.  Only a match that reaches further back reads global memory -- bytes flushed long before -- after a release
 // fence if they were flushed since the last one.
-constexpr uint32_t kRing = 4096, kFlush = 2048, kNear = kRing - 320;   // a match is at most 258 bytes: positions >= o - kNear are in the ring
+constexpr uint32_t kRing = 2048, kFlush = 1024, kNear = kRing - 320;   // a match is at most 258 bytes: positions >= o - kNear are in the ring
 __device__ __forceinline__ void ring_flush(uint8_t* out, const uint8_t* ring, uint32_t from, uint32_t upto) {   // from: a multiple of 4
     for (uint32_t i = from + 4u * (uint32_t)lane(); i < upto; i += 256u) {
         uint32_t w;
