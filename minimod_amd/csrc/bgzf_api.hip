@@ -116,7 +116,7 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
     SCHK(hipMemcpyAsync(s.d_c, s.h_c, cbytes, hipMemcpyHostToDevice, s.stream));
     SCHK(hipMemcpyAsync(s.d_blocks, s.h_blocks, sizeof(Block) * (size_t)n_blocks, hipMemcpyHostToDevice, s.stream));
     SCHK(hipEventRecord(s.ev[1], s.stream));
-    const int wgs = std::max(1, std::min(h->n_cu * 4, (n_blocks + kWaves - 1) / kWaves));   // (three workgroups of 45 KB of LDS fit a CU)
+    const int wgs = std::max(1, std::min(h->n_cu * 4, (n_blocks + kWaves - 1) / kWaves));   // (four workgroups of 37 KB of LDS fit a CU)
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(wgs), dim3(64 * kWaves), 0, s.stream, s.d_c, s.d_blocks, n_blocks, s.d_out, s.d_status);
     SCHK(hipEventRecord(s.ev[2], s.stream));
     hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(h->n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, s.stream, s.d_out, s.d_blocks, n_blocks, s.d_status);

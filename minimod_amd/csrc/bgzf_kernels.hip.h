@@ -6,19 +6,21 @@
 //   * the bit reader is SCALAR: the block's compressed bytes stand in two vector registers as a 512-byte window (lane l holds
 //     dword l), and the next 64 bits at any bit position are two v_readlane away -- no memory trip per symbol;
 //   * the Huffman tables (RFC 1951) are built by the wavefront in its slice of LDS: codes numbered with ballots (a symbol's code
-//     is its length's first code plus the number of symbols of that length in front of it), a first-level table of 11 bits for
+//     is its length's first code plus the number of symbols of that length in front of it), a first-level table of 10 bits for
 //     literals / lengths and 8 for distances filled by the lanes, longer codes decoded canonically (first code and count per
 //     length: the rare path);
-//   * a symbol is one LDS lookup; the block's latest 4 KB of output stand in an LDS ring: a literal is a byte store of lane 0
-//     there, a match is copied by all lanes at once, out[o + i] = out[o - dist + i mod dist], from the ring when its source is
-//     that near (else from global memory, behind a release fence if those bytes were flushed since the last one); the ring's
-//     older half goes to global memory in whole dwords every 2 KB;
+//   * tokens are decoded in BURSTS: every lane decodes the token (literal, or length + distance with their extra bits) that would
+//     start at its own bit offset behind the reader's position, and the scalar unit only walks the chain from token to token;
+//     what a burst cannot take (end of block, long codes) goes through the plain path, one LDS lookup a symbol;
+//   * the block's latest 2 KB of output stand in an LDS ring: a literal is a byte store there, a match is copied by all lanes at
+//     once, out[o + i] = out[o - dist + i mod dist], from the ring when its source is that near (else from global memory, behind
+//     a release fence if those bytes were flushed since the last one); the ring's older half goes to global memory in whole
+//     dwords every 1 KB;
 //   * the CRC32 of the decoded bytes (the gzip trailer covers them) is a kernel of its own: 64 slices a block, a table-driven
 //     CRC per lane, the slices' registers combined by multiplying with x^(8 * bytes behind the slice) modulo the polynomial.
-// Measured: 11.0 GB/s of decoded bytes per MI355X on a C2-shape BAM.  Literals are decoded in bursts (a
-// candidate symbol at every bit offset of a 64-bit window from one 64-lane table lookup, the scalar unit walks the chain); a
-// match still costs the scalar path's ~0.8 us (two dependent lookups, sixty instructions with a dozen branches each, a ring copy), and a BAM's
-// blocks are half matches: a correct, tested first form, not yet the fast one.
+// Measured: 24 GB/s of decoded bytes per MI355X on a C2-shape BAM in a launch of 7 000 blocks (the scalar
+// symbol loop alone: 9.6; literals in bursts 11.0; whole tokens in bursts 16.7; smaller tables and ring for 16 wavefronts per CU
+// 24.2).  Issue-bound by then: about a hundred instructions a token.
 // Anything the decoder does not like (a malformed stream, a size or CRC mismatch) is a status word per block: the host's own
 // decoder (csrc/host/inflate_fast.c, then zlib) has the last word on such a block, so error behaviour stays what it was.
 #pragma once
