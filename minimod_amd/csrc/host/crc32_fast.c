@@ -74,10 +74,11 @@ static uint32_t crc32_pclmul(uint32_t crc, const uint8_t *buf, size_t len) {
     return (uint32_t)_mm_extract_epi32(x1, 1);
 }
 
-static int have_pclmul(void) {
+static int have_pclmul(void) {   /* (every thread that finds -1 stores the same answer: relaxed atomics keep it race-free) */
     static int known = -1;
-    if (known < 0) known = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
-    return known;
+    int k = __atomic_load_n(&known, __ATOMIC_RELAXED);
+    if (k < 0) { k = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"); __atomic_store_n(&known, k, __ATOMIC_RELAXED); }
+    return k;
 }
 #endif
 

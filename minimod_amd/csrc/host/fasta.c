@@ -111,7 +111,7 @@ static void fa_copy_range(void *arg, int64_t lo, int64_t hi) {
             const uint8_t *le = nl ? nl : e;
             const size_t L = (size_t)(le - s);
             if (!memchr(s, '\r', L) && !memchr(s, ' ', L) && !memchr(s, '\t', L)) { memcpy(o, s, L); o += L; }
-            else for (const uint8_t *q = s; q < le; q++) { *o = *q; o += fa_keep[*q]; }
+            else for (const uint8_t *q = s; q < le; q++) if (fa_keep[*q]) *o++ = *q;
             s = nl ? nl + 1 : e;
         }
     }
