@@ -412,11 +412,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
      * wait costs nothing); copied[set] = the ticket whose host -> device copy last read from that pool set */
     group_t *cur = (group_t *)calloc(1, sizeof(group_t)), *prev = (group_t *)calloc(1, sizeof(group_t));
     cur->ticket = prev->ticket = -1;
-    int32_t copied[2] = {-1, -1};
+    int32_t copied[MMH_POOL_SETS];
+    for (int i = 0; i < MMH_POOL_SETS; i++) copied[i] = -1;
     double prog_t = mmh_realtime();
     while (more) {
         double tl = mmh_realtime();
-        if (copied[set] >= 0) {   /* the batch read into this pool set two iterations ago must have left host memory */
+        if (copied[set] >= 0) {   /* the batch read into this pool set MMH_POOL_SETS iterations ago must have left host memory */
             int e = mm_freq_host_done(h, copied[set]);
             if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
             copied[set] = -1;
@@ -428,7 +429,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (view && pending_ticket >= 0) {
-            retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+            retire_batch(h, pending_ticket, &pending_batch, ld, (set + MMH_POOL_SETS - 1) % MMH_POOL_SETS, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
             pending_ticket = -1;
         }
         if (replay && pending_vticket >= 0) {
@@ -469,12 +470,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             MMH_WARNING("%s", "90% of the reads are skipped. Possible causes: unmapped bam, zero sequence lengths, or missing MM, ML tags (not performed base modification aware basecalling). Refer https://github.com/warp9seq/minimod for more information.");
         if (skipped == ld->total_reads)
             MMH_ERROR("%s", "All reads are skipped. Quitting. Possible causes: unmapped bam, zero sequence lengths, or missing MM, ML tags (not performed base modification aware basecalling). Refer https://github.com/warp9seq/minimod for more information.");
-        set ^= 1;
+        set = (set + 1) % MMH_POOL_SETS;
         if (o.debug_break == counter) break;
         counter++;
     }
     if (view && pending_ticket >= 0)
-        retire_batch(h, pending_ticket, &pending_batch, ld, set ^ 1, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+        retire_batch(h, pending_ticket, &pending_batch, ld, (set + MMH_POOL_SETS - 1) % MMH_POOL_SETS, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
     if (replay && pending_vticket >= 0) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
     free(cur); free(prev);

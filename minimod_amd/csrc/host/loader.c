@@ -30,7 +30,7 @@ typedef struct {
 
 /* per-loader state: two pool sets and the item array (two loaders in one process do not share anything) */
 typedef struct loader_priv {
-    pool_t sets[2][NPOOL];
+    pool_t sets[MMH_POOL_SETS][NPOOL];
     item_t *items;
     size_t items_cap;
     /* a worker of a sharded run reads only the alignments that START inside its share [lo, hi) of the genome */
@@ -151,7 +151,7 @@ static void copy_range(void *arg, int64_t lo, int64_t hi) {
 
 int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
     loader_priv_t *lp = PRIV(ld);
-    pool_t *P = lp->sets[set & 1];
+    pool_t *P = lp->sets[(unsigned)set % MMH_POOL_SETS];
     int32_t n = 0, total = 0;
     int64_t total_bytes = 0, proc_bytes = 0;
     uint32_t max_cig = 0, max_l = 0;
@@ -245,7 +245,7 @@ int32_t mmh_loader_next(mmh_loader_t *ld, int set, mm_batch_t *out, int *more) {
 }
 
 const char *mmh_loader_qname(const mmh_loader_t *ld, int set, int32_t read) {
-    const pool_t *P = PRIV(ld)->sets[set & 1];
+    const pool_t *P = PRIV(ld)->sets[(unsigned)set % MMH_POOL_SETS];
     uint64_t qo;
     memcpy(&qo, P[P_QOFF].p + 8 * (size_t)read, sizeof qo);
     return (const char *)P[P_QNAME].p + qo;
@@ -263,7 +263,7 @@ void mmh_loader_close(mmh_loader_t *ld) {
     }
     mm_bam_close(ld->bam);
     loader_priv_t *lp = PRIV(ld);
-    for (int s = 0; s < 2; s++) for (int i = 0; i < NPOOL; i++) pool_release(&lp->sets[s][i]);
+    for (int s = 0; s < MMH_POOL_SETS; s++) for (int i = 0; i < NPOOL; i++) pool_release(&lp->sets[s][i]);
     free(lp->items);
     free(lp);
     free(ld);

@@ -72,6 +72,7 @@ mmh_loader_t *mmh_loader_open_share(const char *bam_path, int threads, int32_t K
 /* Fills `out` with the next batch (pointers into the loader's pools, valid until the next call with the same pool set).
  * Returns the number of accepted reads, or -1 on a read error.  *more = 0 when the reference's loop would stop
  * (src/freq_main.c:410). */
+#define MMH_POOL_SETS 2   /* pool sets of a loader: the caller fills set k + 1 while the batches of sets k and k - 1 are still leaving for the device */
 int32_t mmh_loader_next(mmh_loader_t *ld, int pool_set, mm_batch_t *out, int *more);
 /* process-wide, before the loaders are opened: where the batches' device-bound arrays come from (pinned memory: the copies of
  * mm_freq_submit become DMA transfers); NULL, NULL = malloc */
