@@ -90,6 +90,43 @@ def test_damaged_blocks_are_reported_not_decoded(inf):
     assert all(int(s) != 0 for s in status[1:6])
 
 
+def test_damaged_streams_never_decode_to_something_else(inf):
+    """3 000 damaged deflate streams in one launch (bit flips, truncations, spliced and random bytes): every block comes back
+    with a status; status 0 means the bytes are exactly what zlib makes of the same stream."""
+    rng = np.random.default_rng(17)
+    bases = [bytes(rng.integers(0, 256, 20000, dtype=np.uint8)), bytes(rng.integers(0, 8, 30000, dtype=np.uint8)),
+             (b"ACGT,12,3;" * 3000), bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 40000)), b"\x00" * 5000]
+    good = [raw_deflate(d, level=lv, strategy=st) for d in bases for lv, st in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY))]
+    sizes = [len(d) for d in bases for _ in range(4)]
+    blocks = []
+    for k in range(3000):
+        i = int(rng.integers(0, len(good)))
+        p = bytearray(good[i])
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))): p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1: p = p[:int(rng.integers(1, len(p)))]
+        elif kind == 2:
+            j = int(rng.integers(0, len(good))); a = int(rng.integers(0, len(p))); p = p[:a] + bytearray(good[j][int(rng.integers(0, len(good[j]))):])
+        elif kind == 3: p = bytearray(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes())
+        else: p[:int(rng.integers(1, 12))] = rng.integers(0, 256, 1, dtype=np.uint8).tobytes() * 1   # header bits
+        p = bytes(p[:65000])
+        isize = sizes[i] if rng.random() < 0.8 else int(rng.integers(0, 65536))
+        try:
+            ref = zlib.decompressobj(-15).decompress(p, 70000)
+        except zlib.error:
+            ref = None
+        crc = zlib.crc32(ref) if ref is not None and rng.random() < 0.9 else int(rng.integers(0, 1 << 32))
+        blocks.append((p, isize, crc, ref))
+    got, status = inf.inflate([(p, isize, crc) for p, isize, crc, _ in blocks])
+    n_ok = 0
+    for (p, isize, crc, ref), g, st in zip(blocks, got, status):
+        if st == 0:
+            n_ok += 1
+            assert ref is not None and len(ref) >= isize and g == ref[:isize] and zlib.crc32(g) == crc
+    assert 0 < n_ok < len(blocks)
+
+
 def test_two_slots_in_flight_and_a_file_sized_launch(inf):
     """A C2-shape BAM's blocks, thousands per launch, two launches in flight; every decoded byte against zlib."""
     from minimod_amd import bgzf, synth
