@@ -8,12 +8,13 @@
 // small tables in LDS that are built ONCE per read (round 3; rounds 1-2 slid two windows along the read instead):
 //
 //   CIGAR table     one pass over the CIGAR (get_aln walks it before anything else, mod.c:776-881) gives the totals, the checks
-//                   AND, for a segment of 1024 ops, a checkpoint every FOUR ops: query / reference positions consumed in
-//                   front of it, in stored order.  A call finds its checkpoint with an 8-step search in LDS, loads the
+//                   AND, for a segment of 512 ops, a checkpoint every FOUR ops: query / reference positions consumed in
+//                   front of it, in stored order.  A call finds its checkpoint with a 7-step search in LDS, loads the
 //                   checkpoint's four ops (16 bytes the pass has just read) and walks them.  A reverse read needs no mirrored
 //                   walk: get_aln's back-to-front walk with mirrored coordinates (mod.c:813-815, :855-858) is the ordinary
-//                   projection of BAM position q shifted by L - q_total (SURVEY.md section 8a').  Reads of up to 1024 ops --
-//                   18 kb of ONT read -- read their CIGAR from memory once; longer ones move the table a segment at a time.
+//                   projection of BAM position q shifted by L - q_total (SURVEY.md section 8a').  Reads of up to 512 ops -- every
+//                   HiFi read, 9 kb of ONT read -- hold their whole CIGAR in the table; longer ones move it a segment at a time
+//                   (the pass holds a segment's ops in registers: 1024 ops were sixteen registers and forty more spills).
 //   directory       the read's base class counted per 32-base block (popcount + one wave scan per 64 blocks), a segment of 512
 //                   blocks (16 kb of read) at a time, walked from the read's END for a reverse read (whose MM counts bases of
 //                   the original orientation); every lane finds its block with a 9-step search and selects the base inside it.
@@ -58,7 +59,13 @@ constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at mo
 #define MM_STREAM_WAVES 6
 #endif
 constexpr uint32_t kSegBlocks = MM_STREAM_SEG_BLOCKS;   // directory segment: 32-base blocks (a multiple of 64)
-constexpr uint32_t kSegOps = 1024;          // CIGAR segment: ops
+#ifndef MM_SEG_OPS
+#define MM_SEG_OPS 512   // (1024: the pass over a segment holds sixteen registers of ops and the kernel spills 51 registers instead of
+                         // 10 -- C2 36.6 against 35.1 us per batch, C3 30.5 against 29.2; 256: an ONT read's 1 000 ops are four
+                         // dependent trips instead of two, C2 39.3)
+#endif
+constexpr uint32_t kSegOps = MM_SEG_OPS;    // CIGAR segment: ops
+constexpr int kSegVec = (int)(kSegOps / 256u);   // ... as 16-byte words per lane
 constexpr uint32_t kSegCk = kSegOps / 4;    // ... and its checkpoints, one per four ops
 constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
 constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
@@ -377,10 +384,10 @@ struct KF {
 
     // ------------------------------------------------------------------ CIGAR -> checkpoint table
     // the ops of segment [o0, o0 + 1024) as the lanes hold them: lane's word u = stored ops o0 + 256u + 4 lane .. + 3
-    __device__ __forceinline__ void load_seg(uint4 (&cv)[4], uint32_t o0) const {
+    __device__ __forceinline__ void load_seg(uint4 (&cv)[kSegVec], uint32_t o0) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kSegVec; u++) {
             const uint32_t i = o0 + 256u * (uint32_t)u + 4u * lane;
             cv[u] = i < ncig ? *reinterpret_cast<const uint4*>(cg + i) : make_uint4(0, 0, 0, 0);
         }
@@ -403,14 +410,14 @@ struct KF {
     // Segment o0 of the CIGAR from the words the lanes hold: its totals (tq / tr) and, with `build`, its checkpoint table.
     // from_end = false: (qa, ra) are the positions consumed in front of op o0; true: through the segment's last op (a reverse
     // read's tokens walk the CIGAR from its end): the table is then written relative to the segment's start and moved.
-    __device__ __forceinline__ void seg_pass(const uint4 (&cv)[4], uint32_t o0, uint32_t qa, uint32_t ra, bool from_end, bool build,
+    __device__ __forceinline__ void seg_pass(const uint4 (&cv)[kSegVec], uint32_t o0, uint32_t qa, uint32_t ra, bool from_end, bool build,
                                              uint32_t& okops, uint32_t& lenor, uint32_t& tq_out, uint32_t& tr_out) {
         const uint32_t lane = (uint32_t)lane_id();
         uint32_t tq = 0, tr = 0;
         if (!build) {
             uint32_t a = 0, b = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kSegVec; u++) {
                 uint32_t au, bu;
                 word_sums(cv[u], o0 + 256u * (uint32_t)u + 4u * lane, au, bu, okops, lenor);
                 a += au; b += bu;
@@ -420,7 +427,7 @@ struct KF {
             const uint32_t q0 = from_end ? 0u : qa, r0 = from_end ? 0u : ra;
             wave_sync();
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kSegVec; u++) {
                 if (o0 + 256u * (uint32_t)u < ncig) {
                     const uint32_t i = o0 + 256u * (uint32_t)u + 4u * lane;
                     uint32_t a, b;
@@ -436,7 +443,7 @@ struct KF {
                 qb = qa - tq; rb = ra - tr;
                 wave_sync();
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < kSegVec; u++) {
                     const uint32_t c = 64u * (uint32_t)u + lane;
                     if (c < nck) { S.cq[c] += qb; S.cr[c] += rb; }
                 }
@@ -463,7 +470,7 @@ struct KF {
                 o0 = c_o0 - kSegOps; from_end = true; qa = Q_lo; ra = R_lo;
             }
             if (o0 >= ncig) { err = MM_E_QOVER; break; }   // (cannot happen: the totals are this table's own sums)
-            uint4 cv[4];
+            uint4 cv[kSegVec];
             uint32_t okops = 0xFFFFFFFFu, lenor = 0, tq, tr;
             load_seg(cv, o0);
             seg_pass(cv, o0, qa, ra, from_end, true, okops, lenor, tq, tr);
@@ -809,9 +816,9 @@ struct KF {
         sq = reinterpret_cast<const uint4*>(p.seq + rd.seq_off);
         cg = p.cigar + rd.cigar_off;
         nblk = (L + 31u) >> 5;
-        // Everything that only needs the record is requested before anything is waited for: the CIGAR (its first 1024 ops),
+        // Everything that only needs the record is requested before anything is waited for: the CIGAR (its first segment),
         // the first characters of the MM string (the first group's header and the start of its list), the contig's entries
-        uint4 cv[4];
+        uint4 cv[kSegVec];
         load_seg(cv, 0u);
         staged_at = 0xFFFFFFFFu; skip0 = 0;
         fetch_chunk(0u);
