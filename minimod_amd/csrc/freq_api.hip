@@ -105,7 +105,7 @@ struct Slot {
 struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
-    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6;
+    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6, stream_blocks_per_cu_dot = 6;
     bool stream_dot = false; // a read with a '.' group has been seen: k_stream_reads' '.'-capable instantiation from now on
     bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
     int ref_kind = 1;   // reference words: 0 four bits a base (one mod, RefNib), 1 16-bit (up to 5 mods), 2 32-bit
@@ -529,13 +529,14 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
             if (ga < 1) ga = 1;
             if (stream) {
                 h->n_stream_launches++;
-                const int gf = h->n_cu * h->stream_blocks_per_cu;
+                int gf = h->n_cu * h->stream_blocks_per_cu;
                 // which instantiation: the lean one until a read with a '.' group has shown up (the flag of the slot's last
                 // launch is looked at here: a file's reads carry one flag or the other), stream_mode 3 = the '.'-capable one at once
                 for (auto& sl : h->slots) if (sl.h_ctl && sl.h_ctl[132] != 0u) h->stream_dot = true;   // (any slot's finished launch)
                 s.h_ctl[132] = 0u;
                 tp.host_dot_flag = s.h_ctl + 132;
                 const bool kd = h->stream_dot || h->opts.stream_mode == 3;
+                if (kd && !(p.insertions || p.haplotypes)) gf = h->n_cu * h->stream_blocks_per_cu_dot;
 #define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true, false>), dim3(gf), dim3(256), 0, st, tp); \
                                            else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
                 MM_REF_DISPATCH(h,
@@ -818,11 +819,15 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         int nf = 0;
         MM_REF_DISPATCH(h,
             if (!plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, false, false, true>), 256, 0);
-            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, true, false, false>), 256, 0));
-        if (getenv("MM_DEBUG_OCC")) std::fprintf(stderr, "[minimod_hip] k_stream_reads: %d workgroups per CU\n", nf);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, false, false, false>), 256, 0));
+        int nfd = 0;   // the '.'-capable instantiation keeps more registers and one wavefront per SIMD fewer
+        MM_REF_DISPATCH(h, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nfd, (k_stream_reads<RW, false, true, false, false>), 256, 0));
+        if (getenv("MM_DEBUG_OCC")) std::fprintf(stderr, "[minimod_hip] k_stream_reads: %d workgroups per CU (%d with '.' groups)\n", nf, nfd);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
+        h->stream_blocks_per_cu_dot = nfd > 0 ? std::min(nfd, 8) : 4;
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
+        h->stream_blocks_per_cu_dot = std::min(h->stream_blocks_per_cu_dot, MM_STREAM_GRID_BLOCKS);
 #endif
         h->use_tiles = opts->force_fused == 0;
     }
