@@ -180,7 +180,9 @@ __device__ __forceinline__ bool side_key(int64_t rpos, int rev, int code, uint32
 constexpr uint32_t kSideRegions = 64;
 constexpr uint32_t kSideCurStride = 32;   // cursors 128 bytes apart
 __device__ __forceinline__ int side_insert(unsigned long long* tab, unsigned long long cap_r, unsigned int* cur, unsigned long long key, unsigned long long inc) {
-    const uint32_t region = ((uint32_t)blockIdx.x * 4u + ((uint32_t)threadIdx.x >> 6)) & (kSideRegions - 1u);
+    // (readfirstlane: the region is the wavefront's, and as a scalar the cursor's and the list's addresses are scalar too -- as
+    // per-lane pointers the compiler made them at the kernel's start and kept them in scratch: three scratch loads per insert)
+    const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)blockIdx.x * 4u + ((uint32_t)threadIdx.x >> 6)) & (kSideRegions - 1u)));
     const uint64_t m = __ballot(1);
     const int leader = __ffsll((unsigned long long)m) - 1;
     unsigned int base = 0;
