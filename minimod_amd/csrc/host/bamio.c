@@ -814,13 +814,15 @@ void mm_bam_close(mm_bam_t *b) {
         pthread_mutex_unlock(&b->mu);
         pthread_join(b->producer, NULL);
     }
+    /* the chunks first: a reader closed early (the header's reader of mm_bam_open_pool_at) has groups in flight whose workers
+     * read the mapping -- chunk_free waits for them */
+    chunk_t *lists[3] = {b->ready_head, b->free_list, b->held};
+    for (int k = 0; k < 3; k++) for (chunk_t *c = lists[k]; c;) { chunk_t *n = c->next; chunk_free(c); c = n; }
+    chunk_free(b->cur);
     if (b->map) munmap((void *)b->map, b->map_len);
     if (b->fp) fclose(b->fp);
     for (int32_t i = 0; i < b->hdr.n_targets; i++) free(b->hdr.target_name ? b->hdr.target_name[i] : NULL);
     free(b->hdr.target_name); free(b->hdr.target_len);
-    chunk_t *lists[3] = {b->ready_head, b->free_list, b->held};
-    for (int k = 0; k < 3; k++) for (chunk_t *c = lists[k]; c;) { chunk_t *n = c->next; chunk_free(c); c = n; }
-    chunk_free(b->cur);
     for (int i = 0; i < b->n_spills; i++) free(b->spills[i]);
     free(b->spills); free(b->carry);
     if (b->own_pool) mm_pool_destroy(b->pool);

@@ -854,7 +854,11 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
     }
     for (int r = 0; r < nd; r++) {
         int st = 0;
-        if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1;
+        if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            if (WIFSIGNALED(st)) fprintf(stderr, "[%s] worker %d (device %d) was ended by signal %d\n", __func__, r, dev[r], WTERMSIG(st));
+            else if (WIFEXITED(st)) fprintf(stderr, "[%s] worker %d (device %d) exited with status %d\n", __func__, r, dev[r], WEXITSTATUS(st));
+            failed = 1;
+        }
     }
     if (failed) { MMH_ERROR("%s", "A worker of --devices failed"); exit(EXIT_FAILURE); }
     double ts = mmh_realtime(), sort_time = 0, output_time = 0;

@@ -187,3 +187,26 @@ def test_cli_with_gpu_inflate_writes_the_same_bytes(tmp_path):
             import re
             m = re.search(r"\[gpu-inflate\] (\d+) groups \((\d+) blocks\) inflated on the device, (\d+) blocks again on the host", outs[1][1])
             assert m and int(m.group(1)) >= 1 and int(m.group(3)) == 0, outs[1][1][-500:]
+
+
+def test_view_and_devices_with_gpu_inflate(tmp_path):
+    """`minimod view --gpu-inflate` and `minimod freq --devices 0,0 --gpu-inflate` (two workers on one GPU, an inflater each)
+    write what they write without the flag."""
+    import subprocess
+    from minimod_amd import synth
+    root = os.path.dirname(HERE)
+    cli = os.path.join(root, "minimod_amd", "bin", "minimod")
+    ref = synth.reference(5, 4 << 20)
+    bs = [synth.batch(ref, i * 1024, 1024, seed=6, n_reads_total=3072, with_order=False) for i in range(3)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs, index=True)
+    synth.write_fasta(fa, "chrS", ref)
+    assert os.path.exists(bam + ".bai")
+    for cmd in (["view", "-c", "m[CG]", "-t", "4"], ["freq", "-b", "-c", "m[CG]", "-t", "4", "--devices", "0,0"]):
+        outs = []
+        for flags in ([], ["--gpu-inflate"]):
+            out = str(tmp_path / ("o%d.txt" % len(outs)))
+            r = subprocess.run([cli] + cmd + flags + ["-o", out, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1] and len(outs[0]) > 1000, cmd

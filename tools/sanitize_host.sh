@@ -25,6 +25,14 @@ for mode in address,undefined thread; do
         ASAN_OPTIONS=detect_leaks=1 "$ibin" 20000 > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): inflate_check"; exit 1; }
         if grep -q "ERROR: \|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): inflate_check"; exit 1; fi
     fi
+    sbin="$out/share_check_${mode%%,*}"
+    gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu99 -I"$H" -I"$here/../include" -o "$sbin" "$here/share_check.c" "$H/loader.c" "$H/bamio.c" "$H/inflate_fast.c" "$H/crc32_fast.c" -lz -lpthread
+    for f in "$@"; do
+        if [ -f "$f.bai" ]; then
+            ASAN_OPTIONS=detect_leaks=1 "$sbin" "$f" 1048576 > "$out/last.log" 2>&1 || { cat "$out/last.log"; echo "FAILED ($mode): share_check $f"; exit 1; }
+            if grep -q "ERROR: \|WARNING: ThreadSanitizer\|runtime error" "$out/last.log"; then cat "$out/last.log"; echo "REPORT ($mode): share_check"; exit 1; fi
+        fi
+    done
     fbin="$out/fasta_check_${mode%%,*}"
     gcc -O1 -g -fsanitize=$mode -fno-omit-frame-pointer -std=gnu99 -I"$H" -I"$here/../include" -o "$fbin" "$here/fasta_check.c" "$H/fasta.c" "$H/bamio.c" "$H/inflate_fast.c" "$H/crc32_fast.c" -lz -lpthread
     printf '>a d\nAC GT\r\n\n>b\nTT>x\n>c\n>d\nA' > "$out/t1.fa"; printf 'junk\n>a\nACGT\n>b' > "$out/t2.fa"
