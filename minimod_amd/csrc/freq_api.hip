@@ -408,6 +408,7 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
     if (r) return r;
     p.spill = s.d_spill; p.spill_cig = spill_cig; p.spill_blk = spill_blk;
     p.status = s.d_status;
+    HIPCHK(hipMemsetAsync(s.d_status, 0, sizeof(int32_t) * (size_t)std::max(b->n_reads, 1), st));   // (-1 = handed to the fused kernel: the tile kernels read it)
     if (h->opts.view) {
         // every explicit row consumes one ML byte, so the ML pool bounds them; implicit rows ('.' groups) are not bounded
         // by anything cheap: mm_view_fetch grows the buffer and runs the batch again when a region overflows

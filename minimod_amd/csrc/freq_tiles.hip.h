@@ -51,6 +51,8 @@ struct TileRec {  // 32 bytes
 };
 static_assert(sizeof(TileRec) == 32, "TileRec must be 32 bytes");
 
+constexpr int kStatusHandedOver = -1;   // DevParams.status of a read the tile kernels leave to the fused kernel
+
 struct TileParams {
     DevParams d;              // batch, reference, counters, options
     uint32_t* g_cq;           // [n_cigar_words] query offset at the start of each op (indexed like the cigar pool)
@@ -457,6 +459,16 @@ struct KA {
         if (lane < 8) reinterpret_cast<uint32_t*>(tiles_base + idx)[lane] = v;
     }
 
+    // The read is the fused kernel's: on the fallback list ONCE (its CIGAR item, its MM item and, for a long read, several parts
+    // may all come to that conclusion), and status -1 tells k_sum_tiles / k_call_tiles that its tiles are nobody's.
+    __device__ void hand_over(int ridx) {
+        if (lane_id() == 0 && atomicCAS(reinterpret_cast<int*>(p.status + ridx), 0, kStatusHandedOver) == 0) {
+            const unsigned int k = atomicAdd(P.fb_count, 1u);
+            P.fb_list[k] = ridx;
+            if (P.host_fb_flag) *P.host_fb_flag = 1u;
+        }
+    }
+
     // ---------------- item kind 0: CIGAR prefix arrays -> global (mod.c:776-881 as scans)
     // A long read's scan is cut into `nparts` chunks of ops, one wave each: a chunk first SUMS the op lengths in
     // front of it (cheap: no scans, no stores) to get its carries, then scans only its own ops.
@@ -475,6 +487,7 @@ struct KA {
             const int64_t ctg_len = scalar_load(p.ctg_len + tid);
             uint32_t* const qdir = P.g_qdir + (rd.seq_off >> 7) + 2u * (uint32_t)ridx;
             uint32_t carry_q = 0, carry_r = 0;
+            bool over = false;   // an op reaches past the sequence's end
             const uint32_t op_lo = (uint32_t)(((uint64_t)ncig * part) / nparts) & ~63u;   // chunk starts on a 64-op boundary
             const uint32_t op_hi = part + 1u >= nparts ? ncig : ((uint32_t)(((uint64_t)ncig * (part + 1u)) / nparts) & ~63u);
             {   // carries of the chunk: sums over ops [0, op_lo)
@@ -525,11 +538,11 @@ struct KA {
                     rs = carry_r + rs - rinc;
                     bool aligned = act && ((0x181u >> op) & 1u) && len > 0;
                     if (aligned) {
-                        if ((uint64_t)qs + len > L) err = err ? err : MM_E_QOVER;
+                        if ((uint64_t)qs + len > L) over = true;
                         int64_t r0 = (int64_t)pos + rs;
                         if (r0 < 0 || r0 + (int64_t)len > ctg_len) err = err ? err : MM_E_REFPOS;
                     }
-                    if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > L) err = err ? err : MM_E_QOVER;
+                    if (p.insertions && act && op == 1u && len > 0 && (uint64_t)qs + len > L) over = true;
                     if ((uint64_t)carry_r + rtot >= (1u << 28)) err = err ? err : MM_E_REFPOS;
                     if (act) { P.g_cq[cig_off + i] = qs; P.g_cr[cig_off + i] = (rs & 0x0FFFFFFFu) | (op << 28); }
                     {   // coarse directory: the op that holds every read position that is a multiple of 256.  Most ops
@@ -554,8 +567,9 @@ struct KA {
             if (lane == 0 && part + 1u >= nparts) P.g_qtot[ridx] = carry_q;
             // a CIGAR that consumes more than the sequence has: whether that is an error depends on where the excess lies and on
             // the strand (get_aln only looks at aligned bases, in the order it walks them, mod.c:813-860): the fused kernel judges
-            if (part + 1u >= nparts && carry_q > L) err = err ? err : MM_E_QOVER;
+            if (part + 1u >= nparts && carry_q > L) over = true;
             result = any_err();
+            if (result == 0 && __ballot(over)) hand_over(ridx);
         }
         return result;
     }
@@ -720,7 +734,7 @@ struct KA {
         const uint32_t mm_abs0 = (uint32_t)rd.mm_off;   // the MM pool of a batch is below 4 GiB (checked at submit)
         if (have_ref && irregular) {
             err = 0;
-            if (lane == 0) { unsigned int k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = ridx; if (P.host_fb_flag) *P.host_fb_flag = 1u; }
+            hand_over(ridx);
         }
         // pass 2: the tile records of all groups in one sweep, a lane per record (no text is read here)
         if (have_ref && !irregular) {
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(256) void k_sum_tiles(const TileParams P) {
             }
             e = lane_val(e, 0);
             const uint32_t ridx = uniu(rtiles[ti].ridx);
-            if (lane == 0) { p.status[ridx] = e; report_error(p, ridx, e); }
+            if (lane == 0 && p.status[ridx] != kStatusHandedOver) { p.status[ridx] = e; report_error(p, ridx, e); }   // (a handed-over read's errors are the fused kernel's to name)
         }
         if (lane == 0) rsum[ti] = make_uint2(ntok | (dy & 0x70000u), rsum_v);
     }
@@ -1497,7 +1511,7 @@ __global__ __launch_bounds__(256, kPlain ? 7 : 5) void k_call_tiles(const TilePa
         t.flags = src[4]; t.index = ti; t.gord = src[7]; t.region = region;
         uint32_t gc01 = src[5], gc23 = src[6];
         // a group nobody asked for only has its last listed rank checked (mod.c:1116): the last tile of its list does that
-        if ((t.flags & 1u) && (!(t.flags & 64u) || (t.flags & 130u) == 128u)) {
+        if ((t.flags & 1u) && (!(t.flags & 64u) || (t.flags & 130u) == 128u) && scalar_load(p.status + t.ridx) != kStatusHandedOver) {
             int e = uni(k.run(t, gc01, gc23, P.g_sum + (size_t)region * P.tile_cap));
             if (e != 0 && lane_id() == 0) {
                 p.status[t.ridx] = e;

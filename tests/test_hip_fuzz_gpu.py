@@ -18,7 +18,10 @@ COUNT = int(os.environ.get("MM_FUZZ_SEEDS", "50"))
 
 @pytest.fixture(scope="module")
 def campaigns():
-    procs = {c: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", c + ".py"), str(FIRST), str(COUNT)], stdout=subprocess.PIPE,
+    # (the error campaign gets four times the seeds: a corrupted record of the kind that shows a deviation -- a reverse read whose
+    # leading clip overshoots the sequence -- comes once in sixty batches; it is the quickest of the six)
+    procs = {c: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", c + ".py"), str(FIRST if c != "fuzz_errors" else 400),
+                                  str(COUNT if c != "fuzz_errors" else 4 * COUNT)], stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, cwd=ROOT) for c in CAMPAIGNS}
     out = {}
     for c, p in procs.items():
@@ -39,7 +42,7 @@ def test_random_campaign_agrees_with_the_oracle(name, campaigns):
     last = txt.strip().splitlines()[-1]
     m = re.search(r"seeds (\d+)\.\.(\d+) done in \d+ s, (\d+) problems", last)
     assert m, txt[-3000:]
-    assert int(m.group(2)) - int(m.group(1)) + 1 == COUNT and int(m.group(3)) == 0, txt[-3000:]
+    assert int(m.group(2)) - int(m.group(1)) + 1 == (COUNT if name != "fuzz_errors" else 4 * COUNT) and int(m.group(3)) == 0, txt[-3000:]
     if name == "fuzz_errors":   # the malformed-input deviations DESIGN.md section 7 used to list are closed
         k = re.search(r"(\d+) known deviations", last)
         assert k and int(k.group(1)) == 0, last
