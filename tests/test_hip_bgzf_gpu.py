@@ -127,6 +127,25 @@ def test_damaged_streams_never_decode_to_something_else(inf):
     assert 0 < n_ok < len(blocks)
 
 
+def test_valid_streams_no_compressor_writes(inf):
+    """tools/fuzz_inflate.py's generator, bounded: 512 valid DEFLATE streams made token by token (random complete Huffman codes up
+    to 15 bits, code-length runs across the literal/distance boundary, one or no distance code, end-of-block-only blocks, every
+    match length and distance).  zlib agrees with the generator on every one of them (checked here as well); the device returns
+    those bytes -- a refusal (status != 0) would only send the block to the host decoder, but none is expected."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import fuzz_inflate
+    streams = []
+    for seed in range(900, 908):
+        s, rejects = fuzz_inflate.make(seed, 64)
+        assert rejects == 0
+        streams += s
+    assert all(zlib.decompress(raw, -15) == want for raw, want in streams)
+    got, status = inf.inflate([(raw, len(want), zlib.crc32(want) & 0xFFFFFFFF) for raw, want in streams])
+    assert status.tolist() == [0] * len(streams), [(i, int(s)) for i, s in enumerate(status) if s][:10]
+    assert all(g == want for g, (_, want) in zip(got, streams))
+
+
 def test_two_slots_in_flight_and_a_file_sized_launch(inf):
     """A C2-shape BAM's blocks, thousands per launch, two launches in flight; every decoded byte against zlib."""
     from minimod_amd import bgzf, synth
