@@ -498,6 +498,8 @@ def run_e2e_big(args):
         ml = re.search(r"\[loader\] ([^\n]*)", err)
         if ml:
             res["gpu_cli"]["loader"] = ml.group(1)
+        mz = re.search(r"\[gpu-inflate\] ([^\n]*)", err)   # (the CLI's default for a BAM of 3 GiB or more per GPU; --no-gpu-inflate: host threads alone)
+        res["gpu_cli"]["gpu_inflate"] = mz.group(1) if mz else None
         # MM_E2E_SWEEP="16,32,64": the same job at other -t (diagnostic: where the host side stops scaling)
         for t_alt in [int(x) for x in os.environ.get("MM_E2E_SWEEP", "").split(",") if x.strip()]:
             alt = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(t_alt)]

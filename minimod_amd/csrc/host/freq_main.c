@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/wait.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "minimod_bgzf.h"
@@ -37,6 +38,7 @@ static struct option long_options[] = {
     {"canonical-order", no_argument, 0, 0},        /* 19 (new: rows that tie on (contig, start) in a fixed order instead of the reference's hash order) */
     {"gather", required_argument, 0, 0},           /* 20 (new: -K batches that may share one kernel launch) */
     {"gpu-inflate", no_argument, 0, 0},            /* 21 (new: BGZF blocks inflated on the device, next to the host pool) */
+    {"no-gpu-inflate", no_argument, 0, 0},         /* 22 */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -59,6 +61,7 @@ static struct option view_long_options[] = {
     {"device", required_argument, 0, 0},
     {"devices", required_argument, 0, 0},
     {"gpu-inflate", no_argument, 0, 0},
+    {"no-gpu-inflate", no_argument, 0, 0},
     {0, 0, 0, 0}};
 
 typedef struct {
@@ -120,7 +123,8 @@ static void print_help(FILE *fp, const fopt_t *o) {
     if (!o->view) fprintf(fp, "   --gather INT               -K batches that may share one kernel launch (they are staged in GPU memory one behind the\n"
                               "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
     fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
-                "                              -t host threads; blocks the device refuses are the host decoder's) [%s]\n", o->gpu_inflate ? "yes" : "no");
+                "   --no-gpu-inflate           -t host threads; blocks the device refuses are the host decoder's) [%s]\n",
+            o->gpu_inflate < 0 ? "for a BAM file of 3 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -330,6 +334,13 @@ static int before_hi(const wspec_t *ws, int32_t tid, int32_t pos) { return ws->l
 
 /* Everything behind option parsing and the reference load: the batches of one BAM (or of one share of it) through one
  * GPU.  A single run prints its rows; a worker of `--devices` sends them to the parent, which merges and prints. */
+/* MM_TIMELINE=1: where the process is, in seconds since its start (start-up and teardown are not in the stage timers) */
+static void tl_mark(double realtime0, const char *what) {
+    static int on = -1;
+    if (on < 0) on = getenv("MM_TIMELINE") != NULL;
+    if (on) fprintf(stderr, "[timeline] %.3f %s\n", mmh_realtime() - realtime0, what);
+}
+
 static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
     const fopt_t o = *op;
     const mmh_mods_t mods = *modsp;
@@ -343,6 +354,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         return 0;
     }
     mm_bgzf_t *bz = o.gpu_inflate ? bz_start(o.device) : NULL;
+    tl_mark(realtime0, "run_body (after bz_start)");
     mmh_loader_t *ld = ws->sharded
         ? mmh_loader_open_share(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
                                 ws->hi_tid, ws->hi_pos, ws->first, ws->last)
@@ -350,6 +362,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!ld) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
     const mm_bam_hdr_t *hdr = mm_bam_header(ld->bam);
 
+    tl_mark(realtime0, "loader open");
     double t2 = mmh_realtime();
     fprintf(stderr, "[%s] Loading contexts in reference\n", __func__);
     mm_contig_t *ctg = (mm_contig_t *)calloc((size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1), sizeof(mm_contig_t));
@@ -367,6 +380,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fo.coalesce = view ? 0 : (o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather);
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
+    tl_mark(realtime0, "mm_freq_create done");
     int wildcard = 0, star_ctx = 0;
     for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
     int replay = !view && !o.canonical_order && (!ws->sharded || ws->tied) && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
@@ -516,6 +530,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             close(ws->slab_out);
         }
     }
+    tl_mark(realtime0, "last batch handed over");
     if (!view) {
         double ts = mmh_realtime();
         const mm_row_t *rows = NULL;
@@ -635,6 +650,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         return 0;
     }
 
+    tl_mark(realtime0, "output written");
     fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
     fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, ld->total_bytes / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(ld->total_reads - ld->processed_reads));
@@ -654,10 +670,15 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         fprintf(stderr, "\n[%s] GPU launches: %lu for %lu batches (%lu with k_stream_reads)", __func__, (unsigned long)lc[0], (unsigned long)lc[2], (unsigned long)lc[1]);
     }
     fprintf(stderr, "\n");
+    tl_mark(realtime0, "teardown starts");
     mm_freq_destroy(h);
     if (hv) mm_freq_destroy(hv);
+    tl_mark(realtime0, "handles destroyed");
     mmh_tie_destroy(tie);
-    mmh_loader_close(ld); bz_stop(bz);
+    mmh_loader_close(ld);
+    tl_mark(realtime0, "loader closed");
+    bz_stop(bz);
+    tl_mark(realtime0, "teardown done");
     return 0;
 }
 
@@ -971,7 +992,7 @@ static int run_main(int argc, char **argv, int view) {
     fopt_t o;
     memset(&o, 0, sizeof(o));
     o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    o.view = view; o.gather = 32;
+    o.view = view; o.gather = 32; o.gpu_inflate = -1;
     while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
         const char *lname = c == 0 ? lopts[longindex].name : "";
         if (c == 'B') {
@@ -1013,6 +1034,7 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "devices") == 0) { o.devices = optarg;
         } else if (c == 0 && strcmp(lname, "canonical-order") == 0) { o.canonical_order = 1;
         } else if (c == 0 && strcmp(lname, "gpu-inflate") == 0) { o.gpu_inflate = 1;
+        } else if (c == 0 && strcmp(lname, "no-gpu-inflate") == 0) { o.gpu_inflate = 0;
         } else if (c == 0 && strcmp(lname, "gather") == 0) {
             o.gather = atoi(optarg);
             if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }
@@ -1044,6 +1066,15 @@ static int run_main(int argc, char **argv, int view) {
     const char *ref_file = argv[optind], *bam_file = argv[optind + 1];
     if (access(bam_file, F_OK) == -1) { MMH_ERROR("BAM file %s does not exist", bam_file); exit(EXIT_FAILURE); }
 
+    tl_mark(realtime0, "options parsed");
+    if (o.gpu_inflate < 0) {
+        /* The device inflater costs about 0.3 s of pinned allocations and their release, and wins that back once the host threads
+         * would be inflating for longer: measured break-even between a 1 GB and a 5 GB file. */
+        struct stat sb;
+        int n_dev = 1;
+        if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
+        o.gpu_inflate = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)3 << 30);
+    }
     double t1 = mmh_realtime();
     fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);
     mmh_ref_t *ref = mmh_load_ref_mt(ref_file, o.threads > 0 ? o.threads : 1);

@@ -178,7 +178,8 @@ def test_two_slots_in_flight_and_a_file_sized_launch(inf):
 
 def test_cli_with_gpu_inflate_writes_the_same_bytes(tmp_path):
     """`minimod freq --gpu-inflate`: a reference golden (a file smaller than one group) and a synthetic BAM of several groups,
-    byte for byte what the host pool alone gives; the log says how many groups the device took."""
+    byte for byte what the host pool alone gives (the default for files this small, and `--no-gpu-inflate`); the log says how
+    many groups the device took."""
     import subprocess
     from minimod_amd import synth
     root = os.path.dirname(HERE)
@@ -195,13 +196,15 @@ def test_cli_with_gpu_inflate_writes_the_same_bytes(tmp_path):
         if f is None:
             continue
         outs = []
-        for flags in ([], ["--gpu-inflate"]):
+        for flags in ([], ["--gpu-inflate"], ["--no-gpu-inflate"]):
             out = str(tmp_path / ("o%d.bed" % len(outs)))
             r = subprocess.run([cli, "freq", "-b", "-c", "m[CG]", "-t", "4", "-o", out] + flags + [f, b], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             outs.append((open(out, "rb").read(), r.stderr.decode()))
-        assert outs[0][0] == outs[1][0]
+        assert outs[0][0] == outs[1][0] == outs[2][0]
         assert "[gpu-inflate]" in outs[1][1]
+        # without a flag the file's size decides (3 GiB per GPU): these are the host threads' alone
+        assert "[gpu-inflate]" not in outs[0][1] and "[gpu-inflate]" not in outs[2][1]
         if b == bam:
             import re
             m = re.search(r"\[gpu-inflate\] (\d+) groups \((\d+) blocks\) inflated on the device, (\d+) blocks again on the host", outs[1][1])
