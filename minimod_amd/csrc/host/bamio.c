@@ -685,6 +685,83 @@ static int read_header(mm_bam_t *b) {
     return 0;
 }
 
+/* The header alone, with plain file reads and the host decoder (no reader, no threads): what a caller wants to know of the file
+ * before its readers exist (the CLI sets up the device while the inflater's pinned buffers are being made).  0 ok, -1 not a BAM
+ * file / cut off inside its header. */
+static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr) {   /* 0 done, 1 more bytes needed, -1 bad */
+    if (n < 12) return 1;
+    if (memcmp(p, "BAM\1", 4) != 0) return -1;
+    size_t pos = 8 + (size_t)rd_u32(p + 4);
+    if (n < pos + 4) return 1;
+    const int32_t n_ref = (int32_t)rd_u32(p + pos);
+    pos += 4;
+    if (n_ref < 0) return -1;
+    size_t q = pos;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (n < q + 4) return 1;
+        const size_t l_name = rd_u32(p + q);
+        if (n < q + 8 + l_name) return 1;
+        q += 8 + l_name;
+    }
+    hdr->target_name = (char **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char *));
+    hdr->target_len = (uint32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint32_t));
+    if (!hdr->target_name || !hdr->target_len) return -1;
+    hdr->n_targets = n_ref;
+    for (int32_t i = 0; i < n_ref; i++) {
+        const size_t l_name = rd_u32(p + pos);
+        hdr->target_name[i] = (char *)malloc(l_name + 1);
+        if (!hdr->target_name[i]) return -1;
+        memcpy(hdr->target_name[i], p + pos + 4, l_name);
+        hdr->target_name[i][l_name] = 0;
+        hdr->target_len[i] = rd_u32(p + pos + 4 + l_name);
+        pos += 8 + l_name;
+    }
+    return 0;
+}
+void mm_bam_hdr_free(mm_bam_hdr_t *hdr) {
+    if (!hdr) return;
+    for (int32_t i = 0; i < hdr->n_targets; i++) free(hdr->target_name ? hdr->target_name[i] : NULL);
+    free(hdr->target_name); free(hdr->target_len);
+    memset(hdr, 0, sizeof *hdr);
+}
+int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr) {
+    memset(hdr, 0, sizeof *hdr);
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return -1;
+    uint8_t *raw = (uint8_t *)malloc(65536 + 64), *dec = NULL;
+    size_t n_dec = 0, cap = 0;
+    int rc = raw ? 1 : -1;
+    while (rc == 1) {
+        /* one more block */
+        uint32_t xlen = 0;
+        if (fread(raw, 1, 12, fp) != 12) { rc = -1; break; }
+        const size_t xl = rd_u16(raw + 10);
+        if (xl < 6 || fread(raw + 12, 1, xl, fp) != xl) { rc = -1; break; }
+        const long total = block_total(raw, 12 + xl, &xlen);
+        if (total <= 0 || total > 65536 || fread(raw + 12 + xl, 1, (size_t)total - 12 - xl, fp) != (size_t)total - 12 - xl) { rc = -1; break; }
+        blk_t k;
+        memset(&k, 0, sizeof k);
+        k.cdata = raw + 12 + xlen;
+        k.clen = (uint32_t)((size_t)total - xlen - 12 - 8);
+        k.isize = rd_u32(raw + total - 4);
+        k.crc = rd_u32(raw + total - 8);
+        if (k.isize > 65536) { rc = -1; break; }
+        if (n_dec + k.isize > cap) {
+            cap = (n_dec + k.isize) * 2 + 65536;
+            uint8_t *g = (uint8_t *)realloc(dec, cap);
+            if (!g) { rc = -1; break; }
+            dec = g;
+        }
+        k.out = dec + n_dec;
+        if (inflate_block(&k) != 0) { rc = -1; break; }
+        n_dec += k.isize;
+        rc = header_from_bytes(dec, n_dec, hdr);
+    }
+    free(raw); free(dec); fclose(fp);
+    if (rc != 0) { mm_bam_hdr_free(hdr); return -1; }
+    return 0;
+}
+
 mm_bam_t *mm_bam_open_pool(const char *path, mm_pool_t *pool) {
     mm_bam_t *b = reader_start(path, pool, 0);
     if (!b) return NULL;

@@ -73,6 +73,9 @@ double mm_bam_wait_seconds(const mm_bam_t *b);   /* seconds the record reader ha
 /* record views handed out since the last release are no longer needed: their buffers may be reused */
 void mm_bam_release(mm_bam_t *b);
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b);
+/* the header alone, read with plain file reads on the calling thread (no reader is made): 0 ok (mm_bam_hdr_free it), -1 not a BAM file */
+int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr);
+void mm_bam_hdr_free(mm_bam_hdr_t *hdr);
 /* 1 = record read, 0 = end of file, <0 = error */
 int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *rec);
 void mm_bam_close(mm_bam_t *b);

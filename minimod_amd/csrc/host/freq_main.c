@@ -6,6 +6,7 @@
  * src/view_main.c:142-160); freq prints once at the end. */
 #include <errno.h>
 #include <getopt.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/wait.h>
@@ -134,19 +135,24 @@ static void *bz_blocks(void *ctx, int slot) { return mm_bgzf_blocks((mm_bgzf_t *
 static int bz_submit(void *ctx, int slot, int n, size_t cb, size_t ob, uint8_t *out) { return mm_bgzf_submit((mm_bgzf_t *)ctx, slot, n, cb, ob, out); }
 static int bz_wait(void *ctx, int slot, const int32_t **st) { return mm_bgzf_wait((mm_bgzf_t *)ctx, slot, st); }
 static mm_bgzf_backend_t bz_backend;
-static mm_bgzf_t *bz_start(int device) {
+#define BZ_SLOTS 4
+static mm_bgzf_t *bz_create(int device) {   /* (any thread: nothing here is seen by the readers yet) */
     char err[256];
-    const int slots = 4;
-    mm_bgzf_t *bz = mm_bgzf_create(device, slots, 1024, ((size_t)41 << 20), ((size_t)64 << 20), err, sizeof err);
-    if (!bz) { MMH_WARNING("--gpu-inflate: %s; the host threads inflate alone", err); return NULL; }
-    bz_backend.ctx = bz; bz_backend.slots = slots; bz_backend.max_blocks = 1024;
+    mm_bgzf_t *bz = mm_bgzf_create(device, BZ_SLOTS, 1024, ((size_t)41 << 20), ((size_t)64 << 20), err, sizeof err);
+    if (!bz) MMH_WARNING("--gpu-inflate: %s; the host threads inflate alone", err);
+    return bz;
+}
+static void bz_attach(mm_bgzf_t *bz) {      /* before the readers are opened */
+    if (!bz) return;
+    bz_backend.ctx = bz; bz_backend.slots = BZ_SLOTS; bz_backend.max_blocks = 1024;
     bz_backend.max_cbytes = (size_t)41 << 20; bz_backend.max_obytes = (size_t)64 << 20;
     bz_backend.host_alloc = mm_bgzf_host_alloc; bz_backend.host_free = mm_bgzf_host_free;
     bz_backend.staging = bz_staging; bz_backend.blocks = bz_blocks; bz_backend.submit = bz_submit; bz_backend.wait = bz_wait;
     mm_bam_set_backend(&bz_backend);
     mmh_loader_set_allocator(mm_bgzf_host_alloc, mm_bgzf_host_free);   /* (the batches leave by DMA as well) */
-    return bz;
 }
+typedef struct { int device; mm_bgzf_t *bz; } bz_job_t;
+static void *bz_create_main(void *arg) { bz_job_t *j = (bz_job_t *)arg; j->bz = bz_create(j->device); return NULL; }
 static void bz_stop(mm_bgzf_t *bz) {
     if (!bz) return;
     unsigned long long st[3];
@@ -334,6 +340,15 @@ static int before_hi(const wspec_t *ws, int32_t tid, int32_t pos) { return ws->l
 
 /* Everything behind option parsing and the reference load: the batches of one BAM (or of one share of it) through one
  * GPU.  A single run prints its rows; a worker of `--devices` sends them to the parent, which merges and prints. */
+static mmh_loader_t *open_loader(const fopt_t *o, const char *bam_file, const wspec_t *ws) {
+    mmh_loader_t *ld = ws->sharded
+        ? mmh_loader_open_share(bam_file, o->threads, o->K, o->B, o->allow_secondary, o->skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
+                                ws->hi_tid, ws->hi_pos, ws->first, ws->last)
+        : mmh_loader_open(bam_file, o->threads, o->K, o->B, o->allow_secondary, o->skip_supplementary);
+    if (!ld) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
+    return ld;
+}
+
 /* MM_TIMELINE=1: where the process is, in seconds since its start (start-up and teardown are not in the stage timers) */
 static void tl_mark(double realtime0, const char *what) {
     static int on = -1;
@@ -353,16 +368,28 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         close(ws->fd);
         return 0;
     }
-    mm_bgzf_t *bz = o.gpu_inflate ? bz_start(o.device) : NULL;
-    tl_mark(realtime0, "run_body (after bz_start)");
-    mmh_loader_t *ld = ws->sharded
-        ? mmh_loader_open_share(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos,
-                                ws->hi_tid, ws->hi_pos, ws->first, ws->last)
-        : mmh_loader_open(bam_file, o.threads, o.K, o.B, o.allow_secondary, o.skip_supplementary);
-    if (!ld) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
-    const mm_bam_hdr_t *hdr = mm_bam_header(ld->bam);
+    /* With the device inflater the readers can only be opened once its pinned buffers exist (0.2 s): they are made on a thread of
+     * their own while this one sets up the freq handle (reference to HBM, context kernels, counter planes), for which the file's
+     * header is read ahead of the readers.  Without it: the readers first, they decode ahead while the handle is set up. */
+    mm_bgzf_t *bz = NULL;
+    mmh_loader_t *ld = NULL;
+    const mm_bam_hdr_t *hdr = NULL;
+    mm_bam_hdr_t hdr0;
+    memset(&hdr0, 0, sizeof hdr0);
+    bz_job_t bzj = {o.device, NULL};
+    pthread_t bz_thread;
+    int bz_running = 0;
+    if (o.gpu_inflate && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
+        bz_running = 1;
+        hdr = &hdr0;
+    } else {
+        if (o.gpu_inflate) { bz = bz_create(o.device); bz_attach(bz); }
+        tl_mark(realtime0, "run_body (inflater made)");
+        ld = open_loader(&o, bam_file, ws);
+        hdr = mm_bam_header(ld->bam);
+        tl_mark(realtime0, "loader open");
+    }
 
-    tl_mark(realtime0, "loader open");
     double t2 = mmh_realtime();
     fprintf(stderr, "[%s] Loading contexts in reference\n", __func__);
     mm_contig_t *ctg = (mm_contig_t *)calloc((size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1), sizeof(mm_contig_t));
@@ -401,6 +428,16 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     free(ctg);
     mmh_free_ref(ref);   /* the reference now lives in HBM */
     fprintf(stderr, "[%s] Reference contexts loaded in %.3f sec\n", __func__, mmh_realtime() - t2);
+    if (bz_running) {
+        pthread_join(bz_thread, NULL);
+        bz = bzj.bz;
+        bz_attach(bz);
+        tl_mark(realtime0, "inflater made (beside the handle)");
+        ld = open_loader(&o, bam_file, ws);
+        hdr = mm_bam_header(ld->bam);
+        if (hdr->n_targets != hdr0.n_targets) { MMH_ERROR("%s changed while it was being read", bam_file); exit(EXIT_FAILURE); }
+        tl_mark(realtime0, "loader open");
+    }
     /* (replay, above) Rows can tie on (contig, start) when several codes are counted, both strands can be called on one
      * position (`*` contexts), insertion offsets or haplotypes are keys.  The reference prints such rows in the order its
      * hash table and its unstable sort leave them in (tieorder.c): that order is replayed from the calls of every read,
@@ -678,6 +715,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mmh_loader_close(ld);
     tl_mark(realtime0, "loader closed");
     bz_stop(bz);
+    mm_bam_hdr_free(&hdr0);
     tl_mark(realtime0, "teardown done");
     return 0;
 }

@@ -573,3 +573,60 @@ def test_bai_linear_index_and_positioned_reader(tmp_path):
             assert (got[k] == want[k]).all()
     assert L.mm_bai_start(bai, 3, 0) == 2 ** 64 - 1
     L.mm_bai_free(bai)
+
+
+def test_peek_header_reads_what_the_reader_reads(tmp_path):
+    """mm_bam_peek_header (bamio.h): the header alone with plain file reads -- every golden BAM, a synthetic one whose header
+    spans several BGZF blocks (3 000 contigs with long names), and files that are not BAM or end inside the header."""
+    import ctypes, glob, gzip, struct
+    from minimod_amd.build import lib_path
+    from oracle import pybam
+    L = ctypes.CDLL(lib_path("libminimod_host.so"))
+
+    class Hdr(ctypes.Structure):
+        _fields_ = [("n_targets", ctypes.c_int32), ("target_name", ctypes.POINTER(ctypes.c_char_p)), ("target_len", ctypes.POINTER(ctypes.c_uint32))]
+    L.mm_bam_peek_header.argtypes = [ctypes.c_char_p, ctypes.POINTER(Hdr)]
+    L.mm_bam_hdr_free.argtypes = [ctypes.POINTER(Hdr)]
+
+    def peek(path):
+        h = Hdr()
+        if L.mm_bam_peek_header(str(path).encode(), ctypes.byref(h)) != 0:
+            return None
+        out = ([h.target_name[i].decode() for i in range(h.n_targets)], [int(h.target_len[i]) for i in range(h.n_targets)])
+        L.mm_bam_hdr_free(ctypes.byref(h))
+        return out
+
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "data", "*.bam")))
+    assert files
+    for f in files:
+        want = pybam.BamFile(f)
+        assert peek(f) == (want.target_name, want.target_len), f
+    # a header of several blocks: Python's gzip writes ONE member, so the BGZF framing is made here (blocks of 60 000 bytes)
+    names = ["contig_%05d_%s" % (i, "x" * (i % 90)) for i in range(3000)]
+    text = b"@HD\tVN:1.6\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (n.encode(), 1000 + i) for i, n in enumerate(names))
+    raw = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(names))
+    raw += b"".join(struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", 1000 + i) for i, n in enumerate(names))
+    import zlib
+
+    def bgzf(data):
+        out = b""
+        for k in range(0, len(data), 60000):
+            d = data[k:k + 60000]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            p = c.compress(d) + c.flush()
+            out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(p) + 25) + p + struct.pack("<II", zlib.crc32(d), len(d))
+        return out
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    big = tmp_path / "big_header.bam"
+    big.write_bytes(bgzf(raw) + eof)
+    assert len(raw) > 3 * 60000
+    assert peek(big) == (names, [1000 + i for i in range(len(names))])
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(bgzf(raw[:100000]) + eof)
+    assert peek(cut) is None
+    notbam = tmp_path / "x.bam"
+    notbam.write_bytes(bgzf(b"SAM\1" + raw[4:]))
+    assert peek(notbam) is None
+    notbam.write_bytes(b"hello, world" * 10)
+    assert peek(notbam) is None
+    assert peek(tmp_path / "missing.bam") is None
