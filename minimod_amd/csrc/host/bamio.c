@@ -207,6 +207,7 @@ typedef struct chunk {
     int pinned;          /* buf comes from the backend's allocator */
     size_t cap_blocks;
     int err, last;       /* last: the file ended with this group */
+    int tail_err;        /* the file is damaged right behind this group's last block (a bad header, a block cut off by the file's end) */
     pool_group_t grp;    /* the group's inflate jobs: the producer queues them and frames the next group, the consumer waits for
                           * them when it takes the chunk (a producer that waited for every group itself kept 64 of 128 workers
                           * busy for one group at a time, with nothing running while it framed the next) */
@@ -239,6 +240,7 @@ struct mm_bam {
     uint8_t **spills; int n_spills;     /* assembled oversized records */
     uint8_t *cur_spill;                 /* the spill buffer b->p points into, if any */
     int eof, failed;
+    int fail_next;                      /* the chunk handed out last ends in front of a damaged block: the next request fails */
     double wait_s;                      /* consumer: seconds spent waiting for decoded chunks */
 };
 
@@ -413,13 +415,18 @@ static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
         const uint8_t *h = b->map + b->map_pos;
         uint32_t xlen = 0;
         long total = block_total(h, b->map_len - b->map_pos, &xlen);
-        if (total <= 0 || (size_t)total > b->map_len - b->map_pos) return -1;   /* bad header, or the file ends inside a block */
+        /* a bad header, or the file ends inside a block: the blocks in front of it are good data, the error is the reader's when it
+         * gets there (as with htslib, and whatever the group's size) */
+        if (total <= 0 || (size_t)total > b->map_len - b->map_pos || rd_u32(h + total - 4) > 65536) {
+            if (n == 0) return -1;
+            c->tail_err = 1;
+            break;
+        }
         blk_t *k = &c->blk[n];
         k->cdata = h + 12 + xlen;
         k->clen = (uint32_t)((size_t)total - xlen - 12 - 8);
         k->isize = rd_u32(h + total - 4);
         k->crc = rd_u32(h + total - 8);
-        if (k->isize > 65536) return -1;
         k->out = c->buf + CHUNK_HEAD + out;
         k->err = 0;
         out += k->isize;
@@ -428,7 +435,7 @@ static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
         n++;
     }
     c->n_blk = n; c->len = out;
-    c->last = b->map_pos >= b->map_len;
+    c->last = c->tail_err || b->map_pos >= b->map_len;
     return 0;
 }
 
@@ -521,7 +528,7 @@ static void *producer_main(void *arg) {
             pthread_mutex_unlock(&b->mu);
             return NULL;
         }
-        c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0; c->gpu_slot = -1;
+        c->next = NULL; c->err = 0; c->last = 0; c->len = 0; c->n_blk = 0; c->gpu_slot = -1; c->tail_err = 0;
         if (!c->buf || !c->cbuf || (b->map ? read_group_mapped(b, c) : read_group(b, c)) != 0) c->err = 1;
         else if (c->n_blk > 0) {
             if (b->map && be_submit_group(b->pool, c) == 0) { /* the device has it */ }
@@ -545,6 +552,7 @@ static void hold(mm_bam_t *b, chunk_t *c) { c->next = b->held; b->held = c; }
 static double mono_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static chunk_t *take_chunk(mm_bam_t *b) {
+    if (b->fail_next) { b->fail_next = 0; b->failed = 1; b->eof = 1; return NULL; }
     if (b->eof) return NULL;
     const double t_in = mono_s();
     pthread_mutex_lock(&b->mu);
@@ -562,8 +570,18 @@ static chunk_t *take_chunk(mm_bam_t *b) {
     group_wait(&c->grp);
     if (c->gpu_slot >= 0) be_finish_group(c);
     b->wait_s += mono_s() - t_in;
-    for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) c->err = 1;
-    if (c->err) { b->failed = 1; b->eof = 1; hold(b, c); return NULL; }
+    /* a damaged block: the blocks in front of it are handed out, the request after them fails (groups are 256 or 1024 blocks: a
+     * group failed as a whole lost up to that many good blocks, and which ones depended on the group's size) */
+    int first_bad = -1;
+    for (int i = 0; i < c->n_blk; i++) if (c->blk[i].err) { first_bad = i; break; }
+    if (c->err || first_bad == 0) { b->failed = 1; b->eof = 1; hold(b, c); return NULL; }
+    if (first_bad > 0) {
+        c->len = (size_t)(c->blk[first_bad].out - (c->buf + CHUNK_HEAD));
+        c->n_blk = first_bad;
+        b->fail_next = 1;
+        return c;
+    }
+    if (c->tail_err) { b->fail_next = 1; return c; }
     if (c->last) b->eof = 1;
     return c;
 }

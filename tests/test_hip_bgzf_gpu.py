@@ -232,3 +232,48 @@ def test_view_and_devices_with_gpu_inflate(tmp_path):
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             outs.append(open(out, "rb").read())
         assert outs[0] == outs[1] and len(outs[0]) > 1000, cmd
+
+
+def test_cli_damaged_bam_fails_alike_with_and_without_the_device(tmp_path):
+    """A BAM with one damaged BGZF block (a flipped CRC32 trailer; a flipped bit in the deflate payload; a block cut off by the
+    file's end): the device refuses the block, the host decoder judges it -- `minimod freq --gpu-inflate` ends with the same exit
+    code and the same last message as `--no-gpu-inflate`, and writes no rows for it."""
+    import subprocess
+    from minimod_amd import bgzf, synth
+    root = os.path.dirname(HERE)
+    cli = os.path.join(root, "minimod_amd", "bin", "minimod")
+    ref = synth.reference(13, 4 << 20)
+    bs = [synth.batch(ref, i * 1500, 1500, seed=8, n_reads_total=4500, with_order=False) for i in range(3)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    raw = open(bam, "rb").read()
+    # block boundaries (offset, total size) from the BSIZE fields
+    pos, blocks = 0, []
+    while pos < len(raw):
+        total = int.from_bytes(raw[pos + 16:pos + 18], "little") + 1
+        blocks.append((pos, total))
+        pos += total
+    assert len(blocks) > 1200          # more than one group of 1024 blocks
+    victims = [len(blocks) // 3, 1024 + 50]
+    cases = {}
+    for name, k in (("crc", victims[0]), ("payload", victims[1])):
+        off, total = blocks[k]
+        bad = bytearray(raw)
+        if name == "crc":
+            bad[off + total - 8] ^= 0x01
+        else:
+            bad[off + 18 + (total - 26) // 2] ^= 0x08
+        cases[name] = bytes(bad)
+    off, total = blocks[len(blocks) // 2]
+    cases["cut"] = raw[:off + total // 2]
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".bam"))
+        open(p, "wb").write(data)
+        res = []
+        for flag in ("--no-gpu-inflate", "--gpu-inflate"):
+            out = str(tmp_path / (name + flag + ".bed"))
+            r = subprocess.run([cli, "freq", "-b", "-c", "m[CG]", "-t", "4", flag, "-o", out, fa, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            msgs = [l for l in r.stderr.decode(errors="replace").splitlines() if "ERROR" in l or "error" in l]
+            res.append((r.returncode, msgs[-1] if msgs else ""))
+        assert res[0][0] != 0 and res[0] == res[1], (name, res)

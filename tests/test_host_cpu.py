@@ -630,3 +630,30 @@ def test_peek_header_reads_what_the_reader_reads(tmp_path):
     notbam.write_bytes(b"hello, world" * 10)
     assert peek(notbam) is None
     assert peek(tmp_path / "missing.bam") is None
+
+
+def test_loader_hands_out_the_reads_in_front_of_a_damaged_block(tmp_path):
+    """A damaged block fails the file when the reader gets THERE (htslib's behaviour): the blocks in front of it in the same group
+    are good data.  Here: the reads decoded before the error are a prefix of the intact file's, the same whether the damage is
+    a CRC, or the file's end inside a block -- and there are some."""
+    from minimod_amd import hostlib, synth
+    ref = synth.reference(9, 1 << 20)
+    p = str(tmp_path / "t.bam")
+    synth.write_bam(p, [("chrS", len(ref))], [synth.batch(ref, 0, 400, seed=5, n_reads_total=400)])
+    raw = open(p, "rb").read()
+    blocks = _bgzf_blocks(raw)
+    assert 8 < len(blocks) < 250            # one group
+    want = [int(x) for b in hostlib.load_batches(p, K=16, B=10 ** 9, threads=3) for x in b["reads"]["pos"]]
+    assert len(want) == 400
+    k = len(blocks) * 2 // 3
+    off, total, _ = blocks[k]
+    bad = bytearray(raw); bad[off + total - 8] ^= 0x01
+    files = {"crc": bytes(bad), "cut": raw[:off + total // 2]}
+    for name, data in files.items():
+        q = str(tmp_path / (name + ".bam"))
+        open(q, "wb").write(data)
+        got = []
+        with pytest.raises(IOError):
+            for b in hostlib.load_batches(q, K=16, B=10 ** 9, threads=3):
+                got += [int(x) for x in b["reads"]["pos"]]
+        assert 100 < len(got) < 400 and got == want[:len(got)], (name, len(got))
