@@ -462,7 +462,7 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
             continue;
         }
         const uint8_t *h = c->cbuf + pos;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { if (n == 0) return -1; c->tail_err = 1; break; }
         uint32_t xlen = rd_u16(h + 10);
         size_t total = 0;
         if (have - pos >= 12 + (size_t)xlen) {
@@ -470,13 +470,12 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
             int bsize = -1;
             while (x + 4 <= xe) {
                 uint32_t sl = rd_u16(x + 2);
-                if (x + 4 + sl > xe) return -1;   /* a subfield that runs past XLEN */
+                if (x + 4 + sl > xe) { bsize = -2; break; }   /* a subfield that runs past XLEN */
                 if (x[0] == 'B' && x[1] == 'C' && sl == 2) bsize = rd_u16(x + 4);
                 x += 4 + sl;
             }
-            if (bsize < 0) return -1;
+            if (bsize < 0 || (size_t)bsize + 1 < 12 + (size_t)xlen + 8) { if (n == 0) return -1; c->tail_err = 1; break; }
             total = (size_t)bsize + 1;
-            if (total < 12 + (size_t)xlen + 8) return -1;
         }
         if (total == 0 || have - pos < total) {   /* the block is cut off by the end of what was read */
             if (n > 0) break;                      /* it starts the next group */
@@ -492,7 +491,7 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
         k->clen = (uint32_t)(total - xlen - 12 - 8);
         k->isize = rd_u32(h + total - 4);
         k->crc = rd_u32(h + total - 8);
-        if (k->isize > 65536) return -1;
+        if (k->isize > 65536) { if (n == 0) return -1; c->tail_err = 1; break; }
         k->out = c->buf + CHUNK_HEAD + out;
         k->err = 0;
         out += k->isize;
@@ -500,6 +499,10 @@ static int read_group(mm_bam_t *b, chunk_t *c) {
         n++;
     }
     size_t rest = have - pos;
+    if (c->tail_err) {   /* (a damaged header behind good blocks: they are handed out, the reader fails when it gets here -- as in read_group_mapped) */
+        c->n_blk = n; c->len = out; c->last = 1;
+        return 0;
+    }
     if (rest) {
         if (file_end && n == 0) return -1;   /* trailing bytes that are not a block */
         if (rest > b->carry_cap) { b->carry = (uint8_t *)realloc(b->carry, rest); b->carry_cap = rest; }

@@ -648,12 +648,20 @@ def test_loader_hands_out_the_reads_in_front_of_a_damaged_block(tmp_path):
     k = len(blocks) * 2 // 3
     off, total, _ = blocks[k]
     bad = bytearray(raw); bad[off + total - 8] ^= 0x01
-    files = {"crc": bytes(bad), "cut": raw[:off + total // 2]}
+    magic = bytearray(raw); magic[off + 1] ^= 0x10
+    files = {"crc": bytes(bad), "cut": raw[:off + total // 2], "magic": bytes(magic)}
     for name, data in files.items():
         q = str(tmp_path / (name + ".bam"))
         open(q, "wb").write(data)
-        got = []
-        with pytest.raises(IOError):
-            for b in hostlib.load_batches(q, K=16, B=10 ** 9, threads=3):
-                got += [int(x) for x in b["reads"]["pos"]]
-        assert 100 < len(got) < 400 and got == want[:len(got)], (name, len(got))
+        for env in ({}, {"MM_BAM_NO_MMAP": "1"}):       # mapped file and fread path
+            old = {k_: os.environ.get(k_) for k_ in env}
+            os.environ.update(env)
+            try:
+                got = []
+                with pytest.raises(IOError):
+                    for b in hostlib.load_batches(q, K=16, B=10 ** 9, threads=3):
+                        got += [int(x) for x in b["reads"]["pos"]]
+                assert 100 < len(got) < 400 and got == want[:len(got)], (name, env, len(got))
+            finally:
+                for k_, v in old.items():
+                    os.environ.pop(k_, None) if v is None else os.environ.__setitem__(k_, v)
