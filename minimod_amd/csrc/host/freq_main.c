@@ -125,7 +125,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
                               "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
     fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
                 "   --no-gpu-inflate           -t host threads; blocks the device refuses are the host decoder's) [%s]\n",
-            o->gpu_inflate < 0 ? "for a BAM file of 3 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
+            o->gpu_inflate < 0 ? "for a BAM file of 4 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -1107,11 +1107,11 @@ static int run_main(int argc, char **argv, int view) {
     tl_mark(realtime0, "options parsed");
     if (o.gpu_inflate < 0) {
         /* The device inflater costs about 0.3 s of pinned allocations and their release, and wins that back once the host threads
-         * would be inflating for longer: measured break-even between a 1 GB and a 5 GB file. */
+         * would be inflating for longer: a wash up to 3.4 GiB, 0.2 - 0.6 s faster at 5.1 GiB. */
         struct stat sb;
         int n_dev = 1;
         if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
-        o.gpu_inflate = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)3 << 30);
+        o.gpu_inflate = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)4 << 30);
     }
     double t1 = mmh_realtime();
     fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);

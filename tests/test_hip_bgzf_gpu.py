@@ -203,7 +203,7 @@ def test_cli_with_gpu_inflate_writes_the_same_bytes(tmp_path):
             outs.append((open(out, "rb").read(), r.stderr.decode()))
         assert outs[0][0] == outs[1][0] == outs[2][0]
         assert "[gpu-inflate]" in outs[1][1]
-        # without a flag the file's size decides (3 GiB per GPU): these are the host threads' alone
+        # without a flag the file's size decides (4 GiB per GPU): these are the host threads' alone
         assert "[gpu-inflate]" not in outs[0][1] and "[gpu-inflate]" not in outs[2][1]
         if b == bam:
             import re
