@@ -379,7 +379,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     bz_job_t bzj = {o.device, NULL};
     pthread_t bz_thread;
     int bz_running = 0;
-    if (o.gpu_inflate && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
+    struct stat bst;   /* (a pipe's bytes can be read once: no header read-ahead there -- and no device inflate, which wants the file mapped) */
+    const int regular = stat(bam_file, &bst) == 0 && S_ISREG(bst.st_mode);
+    if (o.gpu_inflate && regular && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
         bz_running = 1;
         hdr = &hdr0;
     } else {

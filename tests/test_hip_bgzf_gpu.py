@@ -277,3 +277,31 @@ def test_cli_damaged_bam_fails_alike_with_and_without_the_device(tmp_path):
             msgs = [l for l in r.stderr.decode(errors="replace").splitlines() if "ERROR" in l or "error" in l]
             res.append((r.returncode, msgs[-1] if msgs else ""))
         assert res[0][0] != 0 and res[0] == res[1], (name, res)
+
+
+def test_cli_reads_a_pipe_with_gpu_inflate_asked_for(tmp_path):
+    """The BAM through a named pipe with `--gpu-inflate`: a pipe's bytes can be read once (no header read-ahead) and cannot be
+    mapped (the host threads inflate alone) -- the rows are the file's."""
+    import subprocess
+    import threading
+    from minimod_amd import synth
+    root = os.path.dirname(HERE)
+    cli = os.path.join(root, "minimod_amd", "bin", "minimod")
+    ref = synth.reference(5, 2 << 20)
+    bam, fa, pipe = str(tmp_path / "s.bam"), str(tmp_path / "s.fa"), str(tmp_path / "p.bam")
+    synth.write_bam(bam, [("chrS", len(ref))], [synth.batch(ref, 0, 800, seed=6, n_reads_total=800, with_order=False)])
+    synth.write_fasta(fa, "chrS", ref)
+    a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    r = subprocess.run([cli, "freq", "-b", "-c", "m[CG]", "-t", "4", "-o", a, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    os.mkfifo(pipe)
+
+    def feed():
+        with open(pipe, "wb") as w:
+            w.write(open(bam, "rb").read())
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    r = subprocess.run([cli, "freq", "-b", "-c", "m[CG]", "-t", "4", "--gpu-inflate", "-o", b, fa, pipe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    t.join(timeout=10)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert open(a, "rb").read() == open(b, "rb").read() and os.path.getsize(a) > 1000
