@@ -46,6 +46,13 @@ int32_t mm_bgzf_wait(mm_bgzf_t *h, int32_t slot, const int32_t **status);   /* s
 /* device milliseconds of the slot's last launch: [0] host -> device copies, [1] inflate kernel, [2] CRC kernel, [3] device -> host */
 int32_t mm_bgzf_times(mm_bgzf_t *h, int32_t slot, float ms[4]);
 
+/* The same two kernels on blocks that already lie in DEVICE memory, the decoded bytes left there (include/minimod_ingest.h builds on
+ * it): d_c = the payloads (at least 1024 readable bytes behind the last one), d_blocks = n_blocks records, d_out / d_status = where the
+ * decoded bytes and the status words go, stream = a hipStream_t, between_event = a hipEvent_t recorded between the inflate and the
+ * CRC kernel (or NULL).  Asynchronous.  0 or -4 (a HIP failure). */
+int32_t mm_bgzf_inflate_device(int32_t device, void *stream, const uint8_t *d_c, const mm_bgzf_block_t *d_blocks, int32_t n_blocks,
+                               uint8_t *d_out, int32_t *d_status, void *between_event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,10 @@ int32_t mm_freq_read_record(mm_freq_t *h, int32_t ticket, int32_t index, mm_read
  * that does not continue the group).  A per-read error of a group is reported with the read's index counted from the
  * group's first read. */
 int32_t mm_freq_submit_device(mm_freq_t *h, const mm_batch_t *dev_batch, void *hip_stream);
+/* The same for a batch that is a launch by itself (a whole group of -K batches flattened on the device, include/minimod_ingest.h):
+ * launched at once whatever opts.coalesce says, and sized by `bases` (the sum of its reads' l_qseq; 0 = not known) where
+ * mm_freq_submit_device has to guess a resident window's bases from its read count. */
+int32_t mm_freq_submit_device_now(mm_freq_t *h, const mm_batch_t *dev_batch, void *hip_stream, uint64_t bases);
 /* submits that went into the ticket's launch (1 without coalescing) */
 int32_t mm_freq_ticket_batches(mm_freq_t *h, int32_t ticket);
 

@@ -42,13 +42,15 @@ def build_hip(force=False, verbose=False):
                  os.path.join(CSRC, "sort_kernels.hip.h"),
                  os.path.join(INCLUDE, "minimod_hip.h")]
     bgzf_srcs = [os.path.join(CSRC, "bgzf_api.hip"), os.path.join(CSRC, "bgzf_kernels.hip.h"), os.path.join(INCLUDE, "minimod_bgzf.h")]
+    ingest_srcs = [os.path.join(CSRC, "ingest_api.hip"), os.path.join(CSRC, "ingest_kernels.hip.h"), os.path.join(INCLUDE, "minimod_ingest.h"),
+                   os.path.join(INCLUDE, "minimod_bgzf.h"), os.path.join(INCLUDE, "minimod_hip.h")]
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     defs = os.environ.get("MM_HIP_DEFS", "").split()   # build-time experiments: -DMM_TILE_CHARS=... etc.
     objs = []
     relink = force or not os.path.exists(out)
-    for srcs in (freq_srcs, bgzf_srcs):
+    for srcs in (freq_srcs, bgzf_srcs, ingest_srcs):
         obj = os.path.join(objdir, os.path.basename(srcs[0]) + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))
         if force or _stale(obj, srcs):
             cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-I", INCLUDE, "-o", obj, srcs[0]] + defs

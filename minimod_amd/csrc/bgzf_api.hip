@@ -130,6 +130,24 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
     return 0;
 }
 
+int32_t mm_bgzf_inflate_device(int32_t device, void* stream, const uint8_t* d_c, const mm_bgzf_block_t* d_blocks, int32_t n_blocks, uint8_t* d_out, int32_t* d_status,
+                               void* between_event) {
+    static int n_cu_of[64];   // (0: not asked yet)
+    if (device < 0 || device >= 64 || n_blocks < 0) return -1;
+    if (!n_cu_of[device]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -4;
+        n_cu_of[device] = prop.multiProcessorCount;
+    }
+    const int n_cu = n_cu_of[device];
+    hipStream_t st = (hipStream_t)stream;
+    if (n_blocks) hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::max(1, std::min(n_cu * 4, (n_blocks + kWaves - 1) / kWaves))), dim3(64 * kWaves), 0, st, d_c,
+                                     reinterpret_cast<const Block*>(d_blocks), n_blocks, d_out, d_status);
+    if (between_event && hipEventRecord((hipEvent_t)between_event, st) != hipSuccess) return -4;
+    if (n_blocks) hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, st, d_out, reinterpret_cast<const Block*>(d_blocks), n_blocks, d_status);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 int32_t mm_bgzf_wait(mm_bgzf_t* h, int32_t slot, const int32_t** status) {
     if (!h || slot < 0 || (size_t)slot >= h->slots.size()) return -1;
     BSlot& s = h->slots[(size_t)slot];

@@ -268,6 +268,7 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
         while (r.st == S_OK && n < total) {
             b.settle(); n = (int)uni((uint32_t)n); prev = uni(prev); guard = uni(guard);
             if (++guard > 400u) { r.st = S_BAD_CODE_LENGTHS; break; }
+            if (b.bitpos > 8ull * (uint64_t)b.c_len + 64ull) { r.st = S_OVERRUN_IN; break; }   // (a cut-off stream reads as zeros behind its end: never further than this)
             const uint32_t bits = b.peek32();
             const uint32_t e = uni(S.clt[bits & 127u]);
             const uint32_t el = e & 15u;
@@ -374,6 +375,10 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
             for (;;) {
                 b.settle(); o = uni(o); f = uni(f); fenced = uni(fenced); guard = uni(guard); burst_wait = uni(burst_wait);
                 if (++guard > guard_max) return S_OVERRUN_IN;
+                // a stream that ends in the middle of a symbol reads as zeros from there on, and a code of zeros may well be a literal
+                // or a match: without this the loop would run on to ISIZE, up to 120 KB behind the payload (the window's loads are
+                // real loads).  With it the reader stays within a round's bits (64 + a token) of the payload's end.
+                if (b.bitpos > 8ull * (uint64_t)c_len + 64ull) return S_OVERRUN_IN;
                 if (o - f >= kFlush + 256u) {   // the ring's older part to global memory
                     lds_sync();
                     ring_flush(out, S.ring, f, f + kFlush);

@@ -1195,6 +1195,24 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     return r ? r : si;
 }
 
+int32_t mm_freq_submit_device_now(mm_freq_t* h, const mm_batch_t* b, void* hip_stream, uint64_t bases) {
+    if (!h || !b || b->n_reads < 0 || b->n_reads >= (1 << 24) || b->n_mm_bytes >= 0xFFFFF000ull) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->opts.view == 2 && b->n_reads >= (1 << 21)) return -MM_E_ARG;
+    { int rs = side_room(h); if (rs) return rs; }
+    h->n_submits++; h->n_reads_submitted += (uint64_t)b->n_reads;
+    { int r = flush_pending(h); if (r) return r; }
+    int si = acquire_slot(h);
+    if (h->sticky_err) return -h->sticky_err;
+    Slot& s = h->slots[si];
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s.stream;
+    int r = upload_codes(h, st);
+    if (r) return r;
+    r = launch_k1(h, s, b, st, bases);
+    s.members = 1;
+    return r ? r : si;
+}
+
 int32_t mm_freq_ticket_batches(mm_freq_t* h, int32_t ticket) {
     if (!h || ticket < 0 || ticket >= kSlots) return -MM_E_ARG;
     return ticket == h->pending_slot ? h->pending_members : h->slots[ticket].members;

@@ -277,6 +277,14 @@ static int inflate_block(blk_t *b) {
     return 0;
 }
 
+int mm_bgzf_inflate_host(const uint8_t *cdata, uint32_t clen, uint32_t isize, uint32_t crc, uint8_t *out) {
+    blk_t b;
+    memset(&b, 0, sizeof b);
+    b.cdata = cdata; b.clen = clen; b.isize = isize; b.crc = crc; b.out = out;
+    if (verify_zlib < 0) { const char *ev = getenv("MM_BAM_VERIFY_ZLIB"); verify_zlib = ev && atoi(ev) != 0; }
+    return inflate_block(&b);
+}
+
 static void inflate_range(void *arg, int64_t lo, int64_t hi) {
     chunk_t *c = (chunk_t *)arg;
     for (int64_t i = lo; i < hi; i++) c->blk[i].err = inflate_block(&c->blk[i]);
@@ -405,6 +413,8 @@ static long block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) {
     *xlen_out = xlen;
     return total;
 }
+
+long mm_bgzf_block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out) { return block_total(h, avail, xlen_out); }
 
 /* the same group layout over the mapped file: no copy of the compressed bytes at all */
 static int read_group_mapped(mm_bam_t *b, chunk_t *c) {
@@ -709,7 +719,7 @@ static int read_header(mm_bam_t *b) {
 /* The header alone, with plain file reads and the host decoder (no reader, no threads): what a caller wants to know of the file
  * before its readers exist (the CLI sets up the device while the inflater's pinned buffers are being made).  0 ok, -1 not a BAM
  * file / cut off inside its header. */
-static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr) {   /* 0 done, 1 more bytes needed, -1 bad */
+static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr, uint64_t *hdr_bytes) {   /* 0 done, 1 more bytes needed, -1 bad */
     if (n < 12) return 1;
     if (memcmp(p, "BAM\1", 4) != 0) return -1;
     size_t pos = 8 + (size_t)rd_u32(p + 4);
@@ -724,6 +734,7 @@ static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr) {   
         if (n < q + 8 + l_name) return 1;
         q += 8 + l_name;
     }
+    if (hdr_bytes) *hdr_bytes = (uint64_t)q;   /* the first record's offset in the decoded stream */
     hdr->target_name = (char **)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char *));
     hdr->target_len = (uint32_t *)calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(uint32_t));
     if (!hdr->target_name || !hdr->target_len) return -1;
@@ -745,7 +756,8 @@ void mm_bam_hdr_free(mm_bam_hdr_t *hdr) {
     free(hdr->target_name); free(hdr->target_len);
     memset(hdr, 0, sizeof *hdr);
 }
-int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr) {
+int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr) { return mm_bam_peek_header2(path, hdr, NULL); }
+int mm_bam_peek_header2(const char *path, mm_bam_hdr_t *hdr, uint64_t *hdr_bytes) {
     memset(hdr, 0, sizeof *hdr);
     FILE *fp = fopen(path, "rb");
     if (!fp) return -1;
@@ -776,7 +788,7 @@ int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr) {
         k.out = dec + n_dec;
         if (inflate_block(&k) != 0) { rc = -1; break; }
         n_dec += k.isize;
-        rc = header_from_bytes(dec, n_dec, hdr);
+        rc = header_from_bytes(dec, n_dec, hdr, hdr_bytes);
     }
     free(raw); free(dec); fclose(fp);
     if (rc != 0) { mm_bam_hdr_free(hdr); return -1; }

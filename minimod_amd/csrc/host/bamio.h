@@ -75,7 +75,14 @@ void mm_bam_release(mm_bam_t *b);
 const mm_bam_hdr_t *mm_bam_header(const mm_bam_t *b);
 /* the header alone, read with plain file reads on the calling thread (no reader is made): 0 ok (mm_bam_hdr_free it), -1 not a BAM file */
 int mm_bam_peek_header(const char *path, mm_bam_hdr_t *hdr);
+int mm_bam_peek_header2(const char *path, mm_bam_hdr_t *hdr, uint64_t *hdr_bytes);   /* ... and where the first record begins in the decoded stream */
 void mm_bam_hdr_free(mm_bam_hdr_t *hdr);
+/* one BGZF block header at h (avail bytes are there): the block's total size, 0 if the header itself is cut off, -1 if it is no
+ * BGZF header; *xlen_out = its extra field's length (the deflate payload begins at h + 12 + xlen, the CRC32 / ISIZE trailer is the
+ * block's last 8 bytes) */
+long mm_bgzf_block_total(const uint8_t *h, size_t avail, uint32_t *xlen_out);
+/* one block's payload through the host's decoders (the own one, then zlib), CRC32 checked: 0 ok, -1 a damaged block */
+int mm_bgzf_inflate_host(const uint8_t *cdata, uint32_t clen, uint32_t isize, uint32_t crc, uint8_t *out);
 /* 1 = record read, 0 = end of file, <0 = error */
 int mm_bam_next(mm_bam_t *b, mm_bam_rec_t *rec);
 void mm_bam_close(mm_bam_t *b);

@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include "minimod_bgzf.h"
+#include "minimod_ingest.h"
 #include "mmhost.h"
 
 static struct option long_options[] = {
@@ -40,6 +41,8 @@ static struct option long_options[] = {
     {"gather", required_argument, 0, 0},           /* 20 (new: -K batches that may share one kernel launch) */
     {"gpu-inflate", no_argument, 0, 0},            /* 21 (new: BGZF blocks inflated on the device, next to the host pool) */
     {"no-gpu-inflate", no_argument, 0, 0},         /* 22 */
+    {"gpu-ingest", no_argument, 0, 0},             /* 23 (new: the decoded BAM stays in GPU memory: inflate, record framing and load_db's flattening on the device) */
+    {"no-gpu-ingest", no_argument, 0, 0},          /* 24 */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -67,7 +70,7 @@ static struct option view_long_options[] = {
 
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device, view, canonical_order, gather, gpu_inflate;
+    int progress_interval, device, view, canonical_order, gather, gpu_inflate, gpu_ingest;
     const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
@@ -126,6 +129,10 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
                 "   --no-gpu-inflate           -t host threads; blocks the device refuses are the host decoder's) [%s]\n",
             o->gpu_inflate < 0 ? "for a BAM file of 4 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
+    if (!o->view) fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
+                              "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
+                              "                              replay minimod's row order, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
+                      o->gpu_ingest < 0 ? "for a BAM file of 1 GiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -161,6 +168,15 @@ static void bz_stop(mm_bgzf_t *bz) {
     mm_bam_set_backend(NULL);
     mmh_loader_set_allocator(NULL, NULL);
     mm_bgzf_destroy(bz);
+}
+
+/* --gpu-ingest: the device loader's buffers (pinned staging, device memory) are made beside the freq handle's set-up */
+typedef struct { const char *path; mm_pool_t *pool; mmh_devloader_opts_t o; mmh_devloader_t *dl; char err[256]; } dl_job_t;
+static void *dl_open_main(void *arg) { dl_job_t *j = (dl_job_t *)arg; j->dl = mmh_devloader_open(j->path, j->pool, &j->o, j->err, sizeof j->err); return NULL; }
+static void close_loaders(mmh_loader_t *ld, mmh_devloader_t *dl, mm_pool_t *own_pool) {
+    if (ld) mmh_loader_close(ld);
+    if (dl) mmh_devloader_close(dl);
+    if (own_pool) mm_pool_destroy(own_pool);
 }
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
@@ -371,8 +387,15 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     /* With the device inflater the readers can only be opened once its pinned buffers exist (0.2 s): they are made on a thread of
      * their own while this one sets up the freq handle (reference to HBM, context kernels, counter planes), for which the file's
      * header is read ahead of the readers.  Without it: the readers first, they decode ahead while the handle is set up. */
+    int wildcard = 0, star_ctx = 0;
+    for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
+    int replay = !view && !o.canonical_order && (!ws->sharded || ws->tied) && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
     mm_bgzf_t *bz = NULL;
     mmh_loader_t *ld = NULL;
+    mmh_devloader_t *dl = NULL;   /* --gpu-ingest: the decoded BAM stays on the device (devloader.c) */
+    mm_pool_t *pool = NULL;       /* the workers that format the rows (the host loader's, or one of this function's own) */
+    dl_job_t dlj;
+    memset(&dlj, 0, sizeof dlj);
     const mm_bam_hdr_t *hdr = NULL;
     mm_bam_hdr_t hdr0;
     memset(&hdr0, 0, sizeof hdr0);
@@ -381,7 +404,26 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     int bz_running = 0;
     struct stat bst;   /* (a pipe's bytes can be read once: no header read-ahead there -- and no device inflate, which wants the file mapped) */
     const int regular = stat(bam_file, &bst) == 0 && S_ISREG(bst.st_mode);
-    if (o.gpu_inflate && regular && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
+    uint64_t hdr_bytes = 0;
+    /* the device loader takes the runs whose rows cannot tie (the headline run, -c m[CG]): the tie-order replay and the wildcard
+     * code table work from host batches */
+    const int use_dev = o.gpu_ingest && !view && !replay && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
+    if (use_dev) {
+        hdr = &hdr0;
+        pool = mm_pool_create(o.threads);
+        if (!pool) { MMH_ERROR("%s", "Could not start the worker threads"); exit(EXIT_FAILURE); }
+        mmh_devloader_opts_t *d = &dlj.o;
+        d->device = o.device; d->n_targets = hdr0.n_targets; d->allow_secondary = o.allow_secondary; d->skip_supplementary = o.skip_supplementary;
+        d->header_bytes = hdr_bytes;
+        if (ws->sharded) {
+            d->ranged = 1; d->first = ws->first; d->last = ws->last; d->lo_tid = ws->lo_tid; d->lo_pos = ws->lo_pos; d->hi_tid = ws->hi_tid; d->hi_pos = ws->hi_pos;
+            if (ws->voffset == UINT64_MAX) d->range_done_before_start = 1; else d->voffset = ws->voffset;
+        }
+        dlj.path = bam_file; dlj.pool = pool;
+        /* its pinned staging and device buffers are made on a thread of their own while this one sets up the freq handle */
+        if (pthread_create(&bz_thread, NULL, dl_open_main, &dlj) == 0) bz_running = 2;
+        else dl_open_main(&dlj);
+    } else if (o.gpu_inflate && regular && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
         bz_running = 1;
         hdr = &hdr0;
     } else {
@@ -410,9 +452,6 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     tl_mark(realtime0, "mm_freq_create done");
-    int wildcard = 0, star_ctx = 0;
-    for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
-    int replay = !view && !o.canonical_order && (!ws->sharded || ws->tied) && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
     if (replay && o.K >= (1 << 21)) {   /* (the rows the replay works from number a batch's reads with 21 bits) */
         MMH_WARNING("%s", "-K of 2097152 or more: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype (the order of minimod's hash table is replayed for smaller batches)");
         replay = 0;
@@ -430,7 +469,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     free(ctg);
     mmh_free_ref(ref);   /* the reference now lives in HBM */
     fprintf(stderr, "[%s] Reference contexts loaded in %.3f sec\n", __func__, mmh_realtime() - t2);
-    if (bz_running) {
+    if (use_dev) {
+        if (bz_running == 2) pthread_join(bz_thread, NULL);
+        dl = dlj.dl;
+        if (!dl) { MMH_ERROR("The device-side BAM reader could not be set up: %s (try --no-gpu-ingest)", dlj.err); exit(EXIT_FAILURE); }
+        tl_mark(realtime0, "device loader open (beside the handle)");
+    } else if (bz_running) {
         pthread_join(bz_thread, NULL);
         bz = bzj.bz;
         bz_attach(bz);
@@ -450,6 +494,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
     }
 
+    if (!use_dev) pool = mm_bam_pool(ld->bam);
     double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0, submit_time = 0;
     int more = 1, counter = 0, set = 0;
     int32_t pending_ticket = -1, pending_vticket = -1;
@@ -468,7 +513,76 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     int32_t copied[MMH_POOL_SETS];
     for (int i = 0; i < MMH_POOL_SETS; i++) copied[i] = -1;
     double prog_t = mmh_realtime();
-    while (more) {
+    if (use_dev) {
+        /* load(N + 1) beside process(N), as in the reference's pipeline (src/freq_main.c:404-474) -- only that "load" here is the
+         * device decoding the next batch while its freq kernels work on this one; the host moves compressed bytes.  Two batches'
+         * tickets are kept open (their arenas stay theirs until they have been waited for), a third arena is being filled. */
+        int32_t tk[2] = {-1, -1};
+        int ar[2] = {-1, -1};
+        void *stream = mmh_devloader_stream(dl);
+        more = 1;
+        while (more) {
+            double tl = mmh_realtime();
+            mmh_devbatch_t db;
+            int32_t n = mmh_devloader_next(dl, &db, &more);
+            if (n < 0) {
+                const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
+                if (st->err > 1) MMH_ERROR("The device-side BAM reader gave up: %s (try --no-gpu-ingest)", mm_ingest_strerror(st->err));
+                else MMH_ERROR("%s", "Truncated or corrupt BAM file");
+                exit(EXIT_FAILURE);
+            }
+            load_time += mmh_realtime() - tl;
+            fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bases) loaded\n", __func__, mmh_realtime() - realtime0,
+                    mmh_cputime() / (mmh_realtime() - realtime0), n, db.processed_bytes / (1000.0 * 1000.0));
+            for (int k = 0; k < 2 && tk[0] >= 0; k++) {   /* the older ticket; both when nothing follows */
+                double tw = mmh_realtime();
+                int32_t bad = -1;
+                int e = mm_freq_wait(h, tk[0], &bad);
+                process_wait_time += mmh_realtime() - tw;
+                if (e) {
+                    mm_read_t rec;
+                    const int have = bad >= 0 && mm_freq_read_record(h, tk[0], bad, &rec) == 0;
+                    die_read_record(e, bad, have ? &rec : NULL, hdr);   /* (the read's index in the device's batch: -K does not cut those) */
+                }
+                mmh_devloader_release(dl, ar[0]);
+                tk[0] = tk[1]; ar[0] = ar[1]; tk[1] = -1; ar[1] = -1;
+                if (more) break;
+            }
+            if (n > 0) {
+                const double t_sub = mmh_realtime();
+                int32_t t = mm_freq_submit_device_now(h, &db.batch, stream, db.bases);
+                submit_time += mmh_realtime() - t_sub;
+                if (t < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(t)); exit(EXIT_FAILURE); }
+                if (tk[0] < 0) { tk[0] = t; ar[0] = db.arena; } else { tk[1] = t; ar[1] = db.arena; }
+            }
+            if (o.progress_interval <= 0 || mmh_realtime() - prog_t > o.progress_interval) {
+                fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bytes) processed\t%d Entries (%.1fM bytes) skipped\n", __func__,
+                        mmh_realtime() - realtime0, mmh_cputime() / (mmh_realtime() - realtime0), n, db.total_bytes / (1000.0 * 1000.0),
+                        (int)(db.total_reads - (uint64_t)n), (db.total_bytes - db.processed_bytes) / (1000.0 * 1000.0));
+                prog_t = mmh_realtime();
+            }
+            const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
+            uint64_t skipped = st->total_reads - st->processed_reads;
+            if (skipped > 0.9 * st->total_reads)
+                MMH_WARNING("%s", "90% of the reads are skipped. Possible causes: unmapped bam, zero sequence lengths, or missing MM, ML tags (not performed base modification aware basecalling). Refer https://github.com/warp9seq/minimod for more information.");
+            if (skipped == st->total_reads)
+                MMH_ERROR("%s", "All reads are skipped. Quitting. Possible causes: unmapped bam, zero sequence lengths, or missing MM, ML tags (not performed base modification aware basecalling). Refer https://github.com/warp9seq/minimod for more information.");
+        }
+        for (int k = 0; k < 2; k++) {
+            if (tk[k] < 0) continue;
+            double tw = mmh_realtime();
+            int32_t bad = -1;
+            int e = mm_freq_wait(h, tk[k], &bad);
+            process_wait_time += mmh_realtime() - tw;
+            if (e) {
+                mm_read_t rec;
+                const int have = bad >= 0 && mm_freq_read_record(h, tk[k], bad, &rec) == 0;
+                die_read_record(e, bad, have ? &rec : NULL, hdr);
+            }
+            mmh_devloader_release(dl, ar[k]);
+        }
+    }
+    while (more && !use_dev) {
         double tl = mmh_realtime();
         if (copied[set] >= 0) {   /* the batch read into this pool set MMH_POOL_SETS iterations ago must have left host memory */
             int e = mm_freq_host_done(h, copied[set]);
@@ -532,6 +646,15 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (replay && pending_vticket >= 0) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
     free(cur); free(prev);
+    struct { uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases; } T;
+    if (use_dev) {
+        const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
+        T.total_reads = st->total_reads; T.total_bytes = st->total_bytes; T.processed_reads = st->processed_reads; T.processed_bytes = st->processed_bytes; T.processed_bases = st->processed_bases;
+        fprintf(stderr, "[gpu-ingest] %lu groups of BGZF blocks framed and flattened on the device (%lu blocks walked again from their true entry, %lu decoded by the host), "
+                        "%.3f s waiting for staged groups, %.3f s staging\n", (unsigned long)st->groups, (unsigned long)st->slow_blocks, (unsigned long)st->patched_blocks, st->wait_seconds, st->stage_seconds);
+    } else {
+        T.total_reads = ld->total_reads; T.total_bytes = ld->total_bytes; T.processed_reads = ld->processed_reads; T.processed_bytes = ld->processed_bytes; T.processed_bases = ld->processed_bases;
+    }
     double sort_time = 0;
     if (!view && ws->sharded && ws->fd >= 0) {
         /* The halo behind a cut inside a contig: the counters this worker's reads left there go to the right-hand neighbour as
@@ -610,8 +733,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             if (n_fwd) { /* (the last worker keeps everything: before_hi is always true there) */ }
             wtotals_t tt;
             memset(&tt, 0, sizeof tt);
-            tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
-            tt.processed_bytes = ld->processed_bytes; tt.processed_bases = ld->processed_bases;
+            tt.total_reads = T.total_reads; tt.total_bytes = T.total_bytes; tt.processed_reads = T.processed_reads;
+            tt.processed_bytes = T.processed_bytes; tt.processed_bases = T.processed_bases;
             tt.load_time = load_time; tt.wait_time = process_wait_time; tt.sort_time = sort_time;
             if (ws->tied) {
                 const void *tk = NULL; const uint32_t *th = NULL;
@@ -633,7 +756,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     while (j < n_mine && mine[j].tid == mine[i].tid) j++;
                     if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     const int64_t at = (int64_t)ftello(pf);
-                    mmh_print_freq_rows(pf, mm_bam_pool(ld->bam), mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+                    mmh_print_freq_rows(pf, pool, mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
                     if (mmh_emit_flush() != 0 || fflush(pf) != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     sec[n_sec].tid = mine[i].tid; sec[n_sec].pad = 0; sec[n_sec].off = at; sec[n_sec].len = (int64_t)ftello(pf) - at;
                     n_sec++;
@@ -649,7 +772,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             mm_freq_destroy(h);
             if (hv) mm_freq_destroy(hv);
             mmh_tie_destroy(tie);
-            mmh_loader_close(ld); bz_stop(bz);
+            close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
             return 0;
         }
         mm_row_t *ordered = NULL;
@@ -667,7 +790,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         double to = mmh_realtime();
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
-        mmh_print_freq_rows(o.out, mm_bam_pool(ld->bam), rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+        mmh_print_freq_rows(o.out, pool, rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
         free(ordered);
@@ -679,24 +802,24 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (view && ws->fd >= 0) {   /* a view worker of --devices: its rows are in its part file; the parent wants the totals */
         wtotals_t tt;
         memset(&tt, 0, sizeof tt);
-        tt.total_reads = ld->total_reads; tt.total_bytes = ld->total_bytes; tt.processed_reads = ld->processed_reads;
-        tt.processed_bytes = ld->processed_bytes; tt.processed_bases = ld->processed_bases;
+        tt.total_reads = T.total_reads; tt.total_bytes = T.total_bytes; tt.processed_reads = T.processed_reads;
+        tt.processed_bytes = T.processed_bytes; tt.processed_bases = T.processed_bases;
         tt.load_time = load_time; tt.wait_time = process_wait_time;
         if (write_all(ws->fd, &tt, sizeof tt)) { MMH_ERROR("%s", "Could not send the totals to the parent process"); exit(EXIT_FAILURE); }
         close(ws->fd);
         mm_freq_destroy(h);
-        mmh_loader_close(ld); bz_stop(bz);
+        close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
         return 0;
     }
 
     tl_mark(realtime0, "output written");
-    fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
-    fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, ld->total_bytes / (float)(1000 * 1000));
-    fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(ld->total_reads - ld->processed_reads));
-    fprintf(stderr, "\n[%s] total skipped bytes: %.1f M", __func__, (ld->total_bytes - ld->processed_bytes) / (float)(1000 * 1000));
-    fprintf(stderr, "\n[%s] total processed entries: %ld", __func__, (long)ld->processed_reads);
-    fprintf(stderr, "\n[%s] total processed bytes: %.1f M", __func__, ld->processed_bytes / (float)(1000 * 1000));
-    fprintf(stderr, "\n[%s] total processed bases: %.1f M", __func__, ld->processed_bases / (float)(1000 * 1000));
+    fprintf(stderr, "[%s] total entries: %ld", __func__, (long)T.total_reads);
+    fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, T.total_bytes / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(T.total_reads - T.processed_reads));
+    fprintf(stderr, "\n[%s] total skipped bytes: %.1f M", __func__, (T.total_bytes - T.processed_bytes) / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total processed entries: %ld", __func__, (long)T.processed_reads);
+    fprintf(stderr, "\n[%s] total processed bytes: %.1f M", __func__, T.processed_bytes / (float)(1000 * 1000));
+    fprintf(stderr, "\n[%s] total processed bases: %.1f M", __func__, T.processed_bases / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] Data loading time: %.3f sec", __func__, load_time);
     fprintf(stderr, "\n[%s] Batch hand-over time: %.3f sec (mm_freq_submit: host -> device copies queued, launches)", __func__, submit_time);
     fprintf(stderr, "\n[%s] Data processing time: %.3f sec (waiting for the GPU; the rest overlaps loading)", __func__, process_wait_time);
@@ -714,7 +837,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (hv) mm_freq_destroy(hv);
     tl_mark(realtime0, "handles destroyed");
     mmh_tie_destroy(tie);
-    mmh_loader_close(ld);
+    close_loaders(ld, dl, use_dev ? pool : NULL);
     tl_mark(realtime0, "loader closed");
     bz_stop(bz);
     mm_bam_hdr_free(&hdr0);
@@ -1032,7 +1155,7 @@ static int run_main(int argc, char **argv, int view) {
     fopt_t o;
     memset(&o, 0, sizeof(o));
     o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    o.view = view; o.gather = 32; o.gpu_inflate = -1;
+    o.view = view; o.gather = 32; o.gpu_inflate = -1; o.gpu_ingest = -1;
     while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
         const char *lname = c == 0 ? lopts[longindex].name : "";
         if (c == 'B') {
@@ -1075,6 +1198,8 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "canonical-order") == 0) { o.canonical_order = 1;
         } else if (c == 0 && strcmp(lname, "gpu-inflate") == 0) { o.gpu_inflate = 1;
         } else if (c == 0 && strcmp(lname, "no-gpu-inflate") == 0) { o.gpu_inflate = 0;
+        } else if (c == 0 && strcmp(lname, "gpu-ingest") == 0) { o.gpu_ingest = 1;
+        } else if (c == 0 && strcmp(lname, "no-gpu-ingest") == 0) { o.gpu_ingest = 0;
         } else if (c == 0 && strcmp(lname, "gather") == 0) {
             o.gather = atoi(optarg);
             if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }
@@ -1114,6 +1239,12 @@ static int run_main(int argc, char **argv, int view) {
         int n_dev = 1;
         if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
         o.gpu_inflate = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)4 << 30);
+    }
+    if (o.gpu_ingest < 0) {
+        struct stat sb;
+        int n_dev = 1;
+        if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
+        o.gpu_ingest = !view && stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)1 << 30);
     }
     double t1 = mmh_realtime();
     fprintf(stderr, "[%s] Loading reference genome %s\n", __func__, ref_file);

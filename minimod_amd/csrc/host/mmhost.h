@@ -81,6 +81,40 @@ void mmh_loader_set_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *)
 const char *mmh_loader_qname(const mmh_loader_t *ld, int pool_set, int32_t read);
 void mmh_loader_close(mmh_loader_t *ld);
 
+/* ---- load_db with the decoded BAM kept in GPU memory (devloader.c on include/minimod_ingest.h) ---- */
+typedef struct mmh_devloader mmh_devloader_t;
+typedef struct mmh_devloader_opts {
+    int device, n_targets, allow_secondary, skip_supplementary;
+    uint64_t header_bytes;          /* where the first record begins in the decoded stream (mm_bam_peek_header2) */
+    uint64_t voffset;               /* not 0: start at this virtual offset of a .bai instead (a worker of a sharded run) */
+    int ranged, first, last, range_done_before_start;
+    int32_t lo_tid, hi_tid; int64_t lo_pos, hi_pos;
+    uint64_t target_bases;          /* a batch is handed out once it holds this many bases (0 = 600 M: what fills an MI355X several times over) */
+    /* sizes, 0 = the library's defaults (tests make them small) */
+    int group_slots, max_blocks, arenas;
+    uint64_t max_cbytes, arena_bytes, head_room;
+} mmh_devloader_opts_t;
+typedef struct mmh_devbatch {
+    mm_batch_t batch;               /* DEVICE pointers: for mm_freq_submit_device_now on mmh_devloader_stream() */
+    int arena;                      /* give it back with mmh_devloader_release once the batch's ticket has been waited for */
+    uint64_t bases;
+    uint64_t total_reads, total_bytes, processed_bytes;   /* of the records this batch was made from (db_t counters, src/minimod.h:147-150) */
+} mmh_devbatch_t;
+typedef struct mmh_devloader_stats {
+    uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;   /* core_t counters, src/minimod.h:190-194 */
+    uint64_t groups, slow_blocks, patched_blocks;
+    double wait_seconds, stage_seconds;
+    int err;                        /* MM_INGEST_E_* of a failed run */
+} mmh_devloader_stats_t;
+mmh_devloader_t *mmh_devloader_open(const char *bam_path, mm_pool_t *pool, const mmh_devloader_opts_t *o, char *err, size_t err_len);
+/* the next batch: the number of reads (0: none were accepted), -1 on a damaged file; *more = 0 behind the last one */
+int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more);
+void mmh_devloader_release(mmh_devloader_t *dl, int arena);
+void *mmh_devloader_stream(mmh_devloader_t *dl);
+int mmh_devloader_fetch(mmh_devloader_t *dl, void *dst_host, const void *src_dev, size_t n);   /* device bytes of a batch to the host (0 ok) */
+const mmh_devloader_stats_t *mmh_devloader_stats(mmh_devloader_t *dl);
+void mmh_devloader_close(mmh_devloader_t *dl);
+
 /* ---- output ---- */
 /* Rows are formatted on `pool` (NULL: on the calling thread) and written by a writer thread in row order; the text of
  * the rows is complete when a print call returns, the write may still be under way: call mmh_emit_flush() before

@@ -158,3 +158,102 @@ def inflate_raw(data, out_len):
     out = ctypes.create_string_buffer(out_len + 16)
     r = L.mm_inflate_raw(bytes(data), len(data), out, out_len)
     return out.raw[:out_len] if r == 0 else None
+
+
+class mmh_devloader_opts_t(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("n_targets", ctypes.c_int), ("allow_secondary", ctypes.c_int), ("skip_supplementary", ctypes.c_int),
+                ("header_bytes", ctypes.c_uint64), ("voffset", ctypes.c_uint64),
+                ("ranged", ctypes.c_int), ("first", ctypes.c_int), ("last", ctypes.c_int), ("range_done_before_start", ctypes.c_int),
+                ("lo_tid", ctypes.c_int32), ("hi_tid", ctypes.c_int32), ("lo_pos", ctypes.c_int64), ("hi_pos", ctypes.c_int64),
+                ("target_bases", ctypes.c_uint64),
+                ("group_slots", ctypes.c_int), ("max_blocks", ctypes.c_int), ("arenas", ctypes.c_int),
+                ("max_cbytes", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64), ("head_room", ctypes.c_uint64)]
+
+
+class mmh_devbatch_t(ctypes.Structure):
+    _fields_ = [("batch", mm_batch_t), ("arena", ctypes.c_int), ("bases", ctypes.c_uint64),
+                ("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_bytes", ctypes.c_uint64)]
+
+
+class mmh_devloader_stats_t(ctypes.Structure):
+    _fields_ = [("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_reads", ctypes.c_uint64),
+                ("processed_bytes", ctypes.c_uint64), ("processed_bases", ctypes.c_uint64),
+                ("groups", ctypes.c_uint64), ("slow_blocks", ctypes.c_uint64), ("patched_blocks", ctypes.c_uint64),
+                ("wait_seconds", ctypes.c_double), ("stage_seconds", ctypes.c_double), ("err", ctypes.c_int)]
+
+
+def peek_header(path):
+    """(contig names, lengths, offset of the first record in the decoded stream) through mm_bam_peek_header2"""
+    L = _lib()
+    L.mm_bam_peek_header2.argtypes = [ctypes.c_char_p, ctypes.POINTER(mm_bam_hdr_t), ctypes.POINTER(ctypes.c_uint64)]
+    L.mm_bam_hdr_free.argtypes = [ctypes.POINTER(mm_bam_hdr_t)]
+    hdr = mm_bam_hdr_t()
+    hb = ctypes.c_uint64(0)
+    if L.mm_bam_peek_header2(path.encode(), ctypes.byref(hdr), ctypes.byref(hb)) != 0:
+        raise IOError("not a BAM file: %s" % path)
+    names = [hdr.target_name[i].decode() for i in range(hdr.n_targets)]
+    lens = [int(hdr.target_len[i]) for i in range(hdr.n_targets)]
+    L.mm_bam_hdr_free(ctypes.byref(hdr))
+    return names, lens, int(hb.value)
+
+
+def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementary=False, target_bases=0, device=0, sizes=None, share=None, voffset=0):
+    """Yield (numpy batch dict, per-batch totals) made by the DEVICE loader (devloader.c on include/minimod_ingest.h), copied back to
+    the host for comparison with load_batches().  sizes: dict of the small test geometries (group_slots, max_blocks, arenas,
+    max_cbytes, arena_bytes, head_room).  share: (lo_tid, lo_pos, hi_tid, hi_pos, first, last).  The last item yielded is the
+    stats structure."""
+    L = _lib()
+    L.mm_pool_create.restype = ctypes.c_void_p
+    L.mm_pool_create.argtypes = [ctypes.c_int]
+    L.mm_pool_destroy.argtypes = [ctypes.c_void_p]
+    L.mmh_devloader_open.restype = ctypes.c_void_p
+    L.mmh_devloader_open.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(mmh_devloader_opts_t), ctypes.c_char_p, ctypes.c_size_t]
+    L.mmh_devloader_next.restype = ctypes.c_int32
+    L.mmh_devloader_next.argtypes = [ctypes.c_void_p, ctypes.POINTER(mmh_devbatch_t), ctypes.POINTER(ctypes.c_int)]
+    L.mmh_devloader_release.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.mmh_devloader_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.mmh_devloader_stats.restype = ctypes.POINTER(mmh_devloader_stats_t)
+    L.mmh_devloader_stats.argtypes = [ctypes.c_void_p]
+    L.mmh_devloader_close.argtypes = [ctypes.c_void_p]
+    names, lens, hb = peek_header(path)
+    o = mmh_devloader_opts_t()
+    o.device = device; o.n_targets = len(names); o.allow_secondary = int(allow_secondary); o.skip_supplementary = int(skip_supplementary)
+    o.header_bytes = hb; o.voffset = voffset; o.target_bases = target_bases
+    if share:
+        o.ranged = 1
+        o.lo_tid, o.lo_pos, o.hi_tid, o.hi_pos, o.first, o.last = share
+    for k, v in (sizes or {}).items():
+        setattr(o, k, v)
+    pool = L.mm_pool_create(threads)
+    err = ctypes.create_string_buffer(512)
+    dl = L.mmh_devloader_open(path.encode(), pool, ctypes.byref(o), err, 512)
+    if not dl:
+        L.mm_pool_destroy(pool)
+        raise IOError("device loader: " + err.value.decode())
+    more = ctypes.c_int(1)
+    try:
+        while more.value:
+            db = mmh_devbatch_t()
+            n = L.mmh_devloader_next(dl, ctypes.byref(db), ctypes.byref(more))
+            if n < 0:
+                raise IOError("corrupt BAM %s (device loader, error %d)" % (path, L.mmh_devloader_stats(dl).contents.err))
+            b = db.batch
+
+            def fetch(ptr, count, dt):
+                out = np.zeros(count, dtype=dt)
+                if count and L.mmh_devloader_fetch(dl, out.ctypes.data, ptr, out.nbytes) != 0:
+                    raise IOError("device -> host copy failed")
+                return out
+            if n > 0:
+                d = {"reads": fetch(b.reads, b.n_reads, READ_DTYPE), "cigar": fetch(b.cigar, b.n_cigar_words, "<u4"),
+                     "seq": fetch(b.seq, b.n_seq_bytes, np.uint8), "mm": fetch(b.mm, b.n_mm_bytes, np.uint8),
+                     "ml": fetch(b.ml, b.n_ml_bytes, np.uint8), "max_n_cigar": b.max_n_cigar, "max_l_qseq": b.max_l_qseq}
+                L.mmh_devloader_release(dl, db.arena)
+            else:
+                d = None
+            yield d, {"bases": int(db.bases), "total_reads": int(db.total_reads), "total_bytes": int(db.total_bytes), "processed_bytes": int(db.processed_bytes)}
+        st = L.mmh_devloader_stats(dl).contents
+        yield None, {k: getattr(st, k) for k, _ in mmh_devloader_stats_t._fields_}
+    finally:
+        L.mmh_devloader_close(dl)
+        L.mm_pool_destroy(pool)

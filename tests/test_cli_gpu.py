@@ -213,3 +213,57 @@ def test_cli_view_hard_clip_exits_like_reference(fastas):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     if r.returncode != 0:
         assert r.returncode == 1 and b"Hard clipping" in r.stderr
+
+
+# ---- --gpu-ingest: the decoded BAM stays in GPU memory (include/minimod_ingest.h, csrc/host/devloader.c)
+INGEST_CASES = [c for c in GOLDEN_CASES if c[4]]   # the runs whose rows cannot tie: the device loader's (the others fall back to the host threads)
+
+
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", INGEST_CASES, ids=["ingest-" + c[0] for c in INGEST_CASES])
+def test_cli_gpu_ingest_matches_reference_golden(exp, bam, ctg, kw, exact, fastas):
+    cmd = [BIN, "freq", "--gpu-ingest"] + _args(kw) + (["-b"] if exp.endswith("bedmethyl") else []) + [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"[gpu-ingest]" in r.stderr
+    assert r.stdout.decode() == open(os.path.join(GOLDEN, "expected", exp)).read()
+    # the totals the reference prints are the host loader's
+    r0 = subprocess.run([c for c in cmd if c != "--gpu-ingest"] + ["--no-gpu-ingest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    pick = lambda err: [l.split("] ", 1)[1] for l in err.decode().splitlines() if "] total " in l]
+    assert pick(r.stderr) == pick(r0.stderr) and len(pick(r.stderr)) == 7
+
+
+def test_cli_gpu_ingest_falls_back_where_it_must(fastas):
+    """runs that replay the reference's tie order, and view, read with the host threads whatever the flag says"""
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    r = subprocess.run([BIN, "freq", "--gpu-ingest", "-c", "m,h", "-m", "0.8,0.8", fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"[gpu-ingest]" not in r.stderr and r.stdout.decode() == open(os.path.join(GOLDEN, "expected", "test8.tsv")).read()
+
+
+def test_cli_gpu_ingest_on_synthetic_bam(tmp_path):
+    """the synthetic ONT-shape file of test_cli_on_synthetic_bam_matches_oracle (filter fodder, records that straddle BGZF blocks and
+    groups): the same bytes with the device loader, with small groups forced through the environment, and a hard-clipped read
+    reported as the host path reports it"""
+    from minimod_amd import synth
+    from oracle import oracle as O
+    ref = synth.reference(13, 4 << 20)
+    bs = [synth.batch(ref, i * 350, 350, seed=3, n_reads_total=1400) for i in range(4)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+    orc.add_contig("chrS", ref)
+    for b in bs:
+        orc.process(b, threads=4)
+    want = O.format_rows(orc.rows(), ["chrS"], orc.code_names(), bedmethyl=True)
+    for env in ({}, {"MM_INGEST_MAX_BLOCKS": "16", "MM_INGEST_TARGET_BASES": "3000000"}):
+        r = subprocess.run([BIN, "freq", "--gpu-ingest", "-b", "-c", "m[CG]", "-m", "0.8", "-t", "4", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout.decode() == want
+        assert b"total processed entries: 1400" in r.stderr and b"[gpu-ingest]" in r.stderr
+    # a truncated file fails the run, as it does with the host reader
+    cut = str(tmp_path / "cut.bam")
+    raw = open(bam, "rb").read()
+    open(cut, "wb").write(raw[:len(raw) * 2 // 3])
+    r = subprocess.run([BIN, "freq", "--gpu-ingest", "-b", fa, cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Truncated or corrupt BAM file" in r.stderr

@@ -1,0 +1,124 @@
+"""Device-side BAM ingestion (include/minimod_ingest.h, csrc/ingest_kernels.hip.h, csrc/host/devloader.c) against the host loader
+(csrc/host/loader.c, itself checked against the independent Python reader in tests/test_host_cpu.py): the SAME flattened batch --
+read records, the four pools byte for byte, the totals load_db keeps (reference src/minimod.c:235-333) -- for every bundled BAM
+and every filter flag, with group and arena sizes small enough that records straddle groups, batches close early and a group has
+to be run again into a fresh arena."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+BAMS = sorted(glob.glob(os.path.join(HERE, "golden", "data", "*.bam")))
+
+
+def host_batch(path, **flt):
+    """the whole file as ONE batch of the host loader"""
+    from minimod_amd import hostlib
+    got = list(hostlib.load_batches(path, K=1 << 30, B=1 << 60, threads=2, **flt))
+    assert len(got) == 1
+    return got[0]
+
+
+def device_batches(path, sizes=None, target_bases=1 << 62, **flt):
+    from minimod_amd import hostlib
+    items = list(hostlib.load_batches_device(path, threads=2, sizes=sizes, target_bases=target_bases, **flt))
+    stats = items[-1][1]
+    return [b for b, _ in items[:-1] if b is not None], [t for _, t in items[:-1]], stats
+
+
+def concat(batches):
+    """several batches as the one batch the host loader makes of the same reads: pools one behind the other, offsets moved"""
+    if len(batches) == 1:
+        return batches[0]
+    out = {k: [] for k in ("reads", "cigar", "seq", "mm", "ml")}
+    o_c = o_s = o_m = o_l = 0
+    for b in batches:
+        r = b["reads"].copy()
+        r["cigar_off"] += o_c // 4; r["seq_off"] += o_s; r["mm_off"] += o_m; r["ml_off"] += o_l
+        out["reads"].append(r)
+        # a batch's pool = its items (each padded to its alignment) + 64 bytes of zero slack
+        for k, o in (("cigar", None), ("seq", None), ("mm", None), ("ml", None)):
+            a = b[k].view(np.uint8) if k == "cigar" else b[k]
+            out[k].append(a[:len(a) - 64])
+        o_c += len(b["cigar"]) * 4 - 64; o_s += len(b["seq"]) - 64; o_m += len(b["mm"]) - 64; o_l += len(b["ml"]) - 64
+    z = np.zeros(64, dtype=np.uint8)
+    return {"reads": np.concatenate(out["reads"]), "cigar": np.concatenate(out["cigar"] + [z]).view("<u4"), "seq": np.concatenate(out["seq"] + [z]),
+            "mm": np.concatenate(out["mm"] + [z]), "ml": np.concatenate(out["ml"] + [z]),
+            "max_n_cigar": max(b["max_n_cigar"] for b in batches), "max_l_qseq": max(b["max_l_qseq"] for b in batches)}
+
+
+def same_batch(dev, host):
+    assert len(dev["reads"]) == len(host["reads"])
+    for f in host["reads"].dtype.names:
+        assert np.array_equal(dev["reads"][f], host["reads"][f]), f
+    for k in ("cigar", "seq", "mm", "ml"):
+        assert len(dev[k]) == len(host[k]), (k, len(dev[k]), len(host[k]))
+        assert np.array_equal(dev[k], host[k]), k
+    assert dev["max_n_cigar"] == host["max_n_cigar"] and dev["max_l_qseq"] == host["max_l_qseq"]
+
+
+@pytest.mark.parametrize("path", BAMS, ids=[os.path.basename(p) for p in BAMS])
+@pytest.mark.parametrize("flt", [dict(), dict(allow_secondary=True), dict(skip_supplementary=True), dict(allow_secondary=True, skip_supplementary=True)],
+                         ids=["default", "secondary", "no-supp", "both"])
+def test_device_batch_equals_the_host_loaders(path, flt):
+    want = host_batch(path, **flt)
+    got, totals, st = device_batches(path, **flt)
+    assert st["err"] == 0
+    if len(want["reads"]) == 0:
+        assert not got
+        return
+    assert len(got) == 1
+    same_batch(got[0], want)
+    assert st["processed_reads"] == len(want["reads"]) and st["processed_bases"] == int(want["reads"]["l_qseq"].sum())
+
+
+# tiny groups (8 blocks), a head room of 64 KB, arenas that hold a few hundred KB: tails in every group, batches closing on the
+# arena's size, groups run again into the next arena -- the batches put end to end must still be the host loader's one batch
+SMALL = dict(group_slots=3, max_blocks=8, arenas=3, max_cbytes=1 << 20, arena_bytes=(8 * 65536 + (64 << 10)) * 2, head_room=64 << 10)
+
+
+@pytest.mark.parametrize("path", BAMS, ids=[os.path.basename(p) for p in BAMS])
+def test_small_groups_and_arenas(path):
+    want = host_batch(path)
+    got, totals, st = device_batches(path, sizes=SMALL)
+    assert st["err"] == 0 and (st["groups"] > 1 or os.path.getsize(path) < 600000)
+    if len(want["reads"]) == 0:
+        assert not got
+        return
+    same_batch(concat(got), want)
+
+
+def test_batches_close_on_the_base_target():
+    path = os.path.join(HERE, "golden", "data", "example-ont.bam")
+    want = host_batch(path)
+    got, totals, st = device_batches(path, sizes=dict(group_slots=4, max_blocks=4, arenas=3, max_cbytes=1 << 20, arena_bytes=64 << 20, head_room=1 << 20), target_bases=100000)
+    assert len(got) > 2
+    same_batch(concat(got), want)
+    assert sum(t["bases"] for t in totals if t["bases"]) == int(want["reads"]["l_qseq"].sum())
+
+
+def test_totals_are_the_host_loaders():
+    """total / processed entries and bytes (core_t counters, src/minimod.h:190-194) of a file with secondary alignments"""
+    import ctypes
+    from minimod_amd import hostlib
+    path = os.path.join(HERE, "golden", "data", "dna_5mCG_5hmCG_mm_with_secondary_chr22.bam")
+    L = hostlib._lib()
+
+    class loader_t(ctypes.Structure):
+        _fields_ = [("bam", ctypes.c_void_p), ("allow_secondary", ctypes.c_int), ("skip_supplementary", ctypes.c_int), ("K", ctypes.c_int32), ("B", ctypes.c_int64),
+                    ("last_total_reads", ctypes.c_int32), ("last_total_bytes", ctypes.c_int64), ("last_processed_bytes", ctypes.c_int64),
+                    ("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_reads", ctypes.c_uint64), ("processed_bytes", ctypes.c_uint64),
+                    ("processed_bases", ctypes.c_uint64), ("priv", ctypes.c_void_p)]
+    for flt in (dict(), dict(allow_secondary=True)):
+        ld = L.mmh_loader_open(path.encode(), 2, 1 << 30, 1 << 60, int(flt.get("allow_secondary", False)), 0)
+        from minimod_amd.engine import mm_batch_t
+        b = mm_batch_t(); more = ctypes.c_int(1)
+        assert L.mmh_loader_next(ld, 0, ctypes.byref(b), ctypes.byref(more)) >= 0
+        h = loader_t.from_address(ld)
+        want = (h.total_reads, h.total_bytes, h.processed_reads, h.processed_bytes, h.processed_bases)
+        L.mmh_loader_close(ld)
+        _, _, st = device_batches(path, **flt)
+        assert (st["total_reads"], st["total_bytes"], st["processed_reads"], st["processed_bytes"], st["processed_bases"]) == want

@@ -41,6 +41,25 @@ def test_bgzf_abi_symbols_exported():
     assert bgzf.BLOCK_DTYPE.itemsize == 20
 
 
+def test_ingest_abi_symbols_exported():
+    """Every function include/minimod_ingest.h declares is exported by the device library, and the host library's device loader
+    (csrc/host/devloader.c) is there (no calls: there is no GPU here)."""
+    import ctypes, re
+    from minimod_amd import build
+    from minimod_amd.synth import host_lib
+    hdr = open(os.path.join(ROOT, "include", "minimod_ingest.h")).read()
+    declared = set(re.findall(r"\b(mm_ingest_[a-z_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert len(declared) >= 15
+    L = ctypes.CDLL(build.lib_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    H = host_lib()
+    for name in ("mmh_devloader_open", "mmh_devloader_next", "mmh_devloader_release", "mmh_devloader_stream", "mmh_devloader_fetch", "mmh_devloader_stats", "mmh_devloader_close",
+                 "mm_bam_peek_header2", "mm_bgzf_block_total", "mm_bgzf_inflate_host"):
+        assert hasattr(H, name), name
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
