@@ -500,6 +500,20 @@ def run_e2e_big(args):
             res["gpu_cli"]["loader"] = ml.group(1)
         mz = re.search(r"\[gpu-inflate\] ([^\n]*)", err)   # (the CLI's default for a BAM of 3 GiB or more per GPU; --no-gpu-inflate: host threads alone)
         res["gpu_cli"]["gpu_inflate"] = mz.group(1) if mz else None
+        mi = re.search(r"\[gpu-ingest\] ([^\n]*)", err)   # (the default for a tie-free run on a BAM of 1 GiB or more per GPU: the decoded stream stays on the device)
+        res["gpu_cli"]["gpu_ingest"] = mi.group(1) if mi else None
+        # MM_E2E_VARIANTS="host:--no-gpu-ingest --no-gpu-inflate;inflate:--no-gpu-ingest --gpu-inflate": the same files through the GPU CLI
+        # with other flags (two runs each, the faster one kept; MM_E2E_STDERR gets ".<name>" appended for the CLI's log)
+        for spec in [x for x in os.environ.get("MM_E2E_VARIANTS", "").split(";") if x.strip()]:
+            name, _, fl = spec.partition(":")
+            ov = os.path.join(tmp, "gpu_var.bed")
+            vruns = [run([cli, "freq"] + fl.split() + (["--canonical-order"] if tied else []) + common, ov) for _ in range(2)]
+            vw, verr = min(vruns, key=lambda x: x[0])
+            if os.environ.get("MM_E2E_STDERR"):
+                with open(os.environ["MM_E2E_STDERR"] + "." + name.strip(), "w") as f:
+                    f.write(verr)
+            res.setdefault("variants", {})[name.strip()] = {"flags": fl.strip(), "wall_s": vw, "wall_s_first_run": vruns[0][0], "value": bases / vw / 1e6, "stages_s": _stage_timers(verr),
+                                                            "byte_identical_to_cpu": md5(ov) == md5(oc)}
         # MM_E2E_SWEEP="16,32,64": the same job at other -t (diagnostic: where the host side stops scaling)
         for t_alt in [int(x) for x in os.environ.get("MM_E2E_SWEEP", "").split(",") if x.strip()]:
             alt = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(t_alt)]
