@@ -29,7 +29,7 @@
 
 namespace mmbgzf {
 
-constexpr int kLL = 10, kD = 8;                 // first-level table bits
+constexpr int kLL = 10, kD = 7;                 // first-level table bits (round 4: 7 for distances -- the wavefront's LDS is 7.6 KB: five workgroups a CU)
 constexpr int kWaves = 4;                       // wavefronts per workgroup
 constexpr size_t kPad = 1024;                   // readable bytes behind a launch's compressed bytes
 enum { S_OK = 0, S_BAD_BLOCK_TYPE = 1, S_BAD_STORED = 2, S_BAD_CODE_LENGTHS = 3, S_BAD_SYMBOL = 4, S_BAD_DISTANCE = 5, S_OVERRUN_OUT = 6,
@@ -53,19 +53,25 @@ struct Block {            // one BGZF block of a launch
     uint32_t crc;         // CRC32 of the trailer
 };
 
-struct CodeLds {          // one Huffman code: first-level table + the canonical description for longer codes
+struct CodeLds {          // one Huffman code: the canonical description for codes longer than its first-level table
     uint16_t cnt[16];     // codes per length
     uint16_t sorted[320]; // symbols by (length, symbol)
 };
+struct CodeLdsD {         // the same for the distance code (30 symbols)
+    uint16_t cnt[16];
+    uint16_t sorted[32];
+};
 struct WaveLds {
-    uint32_t ll[1 << kLL];
+    uint32_t ll[1 << kLL];   // (its first 128 words are the code-length code's table while a block's code lengths are read)
     uint32_t dt[1 << kD];
-    CodeLds cl_ll, cl_d;
+    CodeLds cl_ll;
+    CodeLdsD cl_d;
     uint8_t lens[320];    // litlen lengths, then distance lengths
-    uint32_t clt[128];    // the code-length code's table
     uint8_t ring[2048];   // the block's latest output (kRing)
 };
 
+typedef uint32_t u32_unal __attribute__((aligned(1)));
+typedef uint16_t u16_unal __attribute__((aligned(1)));
 __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -97,6 +103,10 @@ struct Bits {
     __device__ __forceinline__ uint32_t dword_at(uint32_t wi) const {   // wi < 128, uniform
         return wi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)va, (int)wi) : (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)(wi - 64u));
     }
+    __device__ __forceinline__ uint32_t dword_sel(uint32_t wi) const {  // the same without a branch: both halves read, one kept
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)(wi & 63u)), y = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)(wi & 63u));
+        return wi < 64u ? x : y;
+    }
     // the next 32 bits (the stream's later bits in the higher positions)
     __device__ __forceinline__ uint32_t peek32() {
         const uint32_t byte = (uint32_t)(bitpos >> 3);
@@ -119,7 +129,8 @@ struct Bits {
 
 // ---- one Huffman code from its lengths lens[0..n) (in LDS): table `tab` of `root` bits, canonical description `cd`.
 // Returns false for a code zlib refuses too (over-subscribed, or incomplete with more than one code).
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_dist, int root, uint32_t* tab, CodeLds& cd) {
+template <typename CD>
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_dist, int root, uint32_t* tab, CD& cd) {
     const int l = lane();
     // codes per length, the first code of every length, each symbol's place among the symbols of its length
     uint32_t cnt[16];
@@ -185,7 +196,8 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_d
 
 // a symbol of a code whose first-level entry says "longer than the table": canonical decoding, one bit at a time (the stream's
 // bits are a code's most significant first).  Returns the entry (length 0: no such code).
-__device__ __forceinline__ uint32_t decode_long(Bits& b, const CodeLds& cd, bool is_dist) {
+template <typename CD>
+__device__ __forceinline__ uint32_t decode_long(Bits& b, const CD& cd, bool is_dist) {
     const uint32_t bits = b.peek32();
     uint32_t code = 0, first = 0, index = 0;
     for (int len = 1; len <= 15; len++) {
@@ -249,14 +261,14 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
 #pragma unroll
             for (int k = 1; k < 8; k++) { left = (left << 1) - (int)cnt[k]; code = (code + cnt[k - 1]) << 1; first[k] = code; }
             if (left != 0 && r.st == S_OK) r.st = S_BAD_CODE_LENGTHS;   // the code-length code must be complete
-            S.clt[l] = 0u; S.clt[64 + l] = 0u;
+            S.ll[l] = 0u; S.ll[64 + l] = 0u;
             lds_sync();
             if (l < 19 && cl_len) {
                 uint32_t fk = 0;
 #pragma unroll
                 for (int k = 1; k < 8; k++) if (cl_len == (uint32_t)k) fk = first[k];
                 const uint32_t c = rev_bits(fk + rank, (int)cl_len);
-                for (uint32_t i = c; i < 128u; i += 1u << cl_len) S.clt[i] = ent(cl_len, 0, 0, (uint32_t)l);
+                for (uint32_t i = c; i < 128u; i += 1u << cl_len) S.ll[i] = ent(cl_len, 0, 0, (uint32_t)l);
             }
             lds_sync();
         }
@@ -270,7 +282,7 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
             if (++guard > 400u) { r.st = S_BAD_CODE_LENGTHS; break; }
             if (b.bitpos > 8ull * (uint64_t)b.c_len + 64ull) { r.st = S_OVERRUN_IN; break; }   // (a cut-off stream reads as zeros behind its end: never further than this)
             const uint32_t bits = b.peek32();
-            const uint32_t e = uni(S.clt[bits & 127u]);
+            const uint32_t e = uni(S.ll[bits & 127u]);
             const uint32_t el = e & 15u;
             if (!el) { r.st = S_BAD_CODE_LENGTHS; break; }
             b.bitpos += el;
@@ -370,121 +382,193 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     S.ring[(at + i) & (kRing - 1u)] = v;
                 }
             };
-            // ---- the block's symbols
-            uint32_t burst_wait = 0;
+            // ---- the block's symbols, a WINDOW of 64 bit offsets at a time (round 4; round 3 walked the chain of tokens one by one on the
+            // scalar unit and copied every match, three bytes or three hundred, with all 64 lanes behind a wave barrier: ~90
+            // instructions a token, and a BAM's packed sequence is literals in runs of two or three between matches of three or four
+            // bytes -- 13 600 tokens a block).
+            //   1. every lane decodes the TOKEN that would start at ITS bit offset behind the reader's position: a literal, or a length
+            //      with its extra bits, its distance code and that code's extra bits (the window's five dwords are scalars; a lane's 64
+            //      bits are two v_alignbit away; two table lookups for 64 candidate tokens);
+            //   2. pointer doubling over "the token behind this one" (four rounds, three ds_bpermute each: sixteen tokens) gives every offset the set of
+            //      offsets on ITS chain, where that chain leaves the window (or meets something the plain path must take) and how many
+            //      bytes it produces -- so the chain from the reader's position is a readlane away, and every token on it knows where its
+            //      output goes;
+            //   3. the tokens of the chain write their bytes TOGETHER: a literal its byte, a match its (up to sixteen) bytes from the ring
+            //      or, further back, from global memory -- as long as no match reads what this step writes (distance >= bytes in front of
+            //      it in the step + its length).  A match that does (a run: distance < length), or a long one, ends the step and is
+            //      copied the old way, all lanes on one match; the same tables serve the rest of the window.
+            bool eob = false;
             for (;;) {
-                b.settle(); o = uni(o); f = uni(f); fenced = uni(fenced); guard = uni(guard); burst_wait = uni(burst_wait);
+                b.settle(); o = uni(o); f = uni(f); fenced = uni(fenced); guard = uni(guard);
                 if (++guard > guard_max) return S_OVERRUN_IN;
                 // a stream that ends in the middle of a symbol reads as zeros from there on, and a code of zeros may well be a literal
                 // or a match: without this the loop would run on to ISIZE, up to 120 KB behind the payload (the window's loads are
-                // real loads).  With it the reader stays within a round's bits (64 + a token) of the payload's end.
+                // real loads).  With it the reader stays within a window's bits (64 + a token) of the payload's end.
                 if (b.bitpos > 8ull * (uint64_t)c_len + 64ull) return S_OVERRUN_IN;
-                if (o - f >= kFlush + 256u) {   // the ring's older part to global memory
-                    lds_sync();
-                    ring_flush(out, S.ring, f, f + kFlush);
-                    f += kFlush;
+                (void)b.peek32();                                  // places the window: the position's byte lies in its first 256
+                const uint64_t base = b.bitpos;
+                const uint32_t rel = (uint32_t)(base - 8ull * (uint64_t)b.wpos);
+                const uint32_t i0 = rel >> 5, sh = rel & 31u;
+                const uint32_t w0 = b.dword_sel(i0), w1 = b.dword_sel(i0 + 1u), w2 = b.dword_sel(i0 + 2u), w3 = b.dword_sel(i0 + 3u), w4 = b.dword_sel(i0 + 4u);
+                const uint32_t sb = sh + (uint32_t)l, kq = sb >> 5, rq = sb & 31u;
+                const uint32_t a0 = kq == 0u ? w0 : (kq == 1u ? w1 : w2), a1 = kq == 0u ? w1 : (kq == 1u ? w2 : w3), a2 = kq == 0u ? w2 : (kq == 1u ? w3 : w4);
+                const uint64_t bits64 = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, rq) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, rq) << 32);
+                const uint32_t e1 = S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)];
+                const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
+                uint32_t t_type = 2u, t_bits = 0u, t_val = 0u, t_dist = 0u, t_out = 0u;   // 0 literal (val = byte), 1 match (val = length), 2 the plain path's
+                if (l1 != 0u && k1 == (uint32_t)K_LIT) { t_type = 0u; t_bits = l1; t_val = e1 >> 16; t_out = 1u; }
+                else if (l1 != 0u && k1 == (uint32_t)K_LEN) {
+                    const uint32_t xl = (e1 >> 8) & 31u;
+                    const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
+                    const uint32_t used = l1 + xl;
+                    const uint32_t dbits = (uint32_t)(bits64 >> used);
+                    const uint32_t d = S.dt[dbits & ((1u << kD) - 1u)];
+                    const uint32_t dl = d & 15u;
+                    if (dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST) {
+                        const uint32_t xd = (d >> 8) & 31u;
+                        t_dist = (d >> 16) + ((dbits >> dl) & ((1u << xd) - 1u));
+                        t_type = 1u; t_bits = used + dl + xd; t_val = mlen; t_out = mlen;
+                    }
                 }
-                uint32_t bits = b.peek32();
-                if (burst_wait == 0u) {
-                    // A BURST of symbols: every lane decodes the TOKEN that would start at ITS bit offset behind the reader's
-                    // position -- a literal, or a length with its extra bits, its distance code and that code's extra bits (64
-                    // candidate tokens from two table lookups; a lane has 64 bits of the stream from its offset on, a token is at
-                    // most 37) -- and the scalar unit only walks the chain from token to token: a literal is a select (its
-                    // place in the output), a match is copied at once (the literals in front of it stored first), until a token
-                    // that needs the plain path (end of block, a code longer than the first-level tables) or the 64 offsets end.
-                    const uint32_t bp = (uint32_t)(b.bitpos - 8ull * (uint64_t)b.wpos) + (uint32_t)l;   // (peek32 has placed the window)
-                    const uint32_t i0 = bp >> 5, sh = bp & 31u;
-                    uint32_t wd[3];
+                const bool tok = t_type != 2u;
+                // the chain behind every offset: next offset (>= 64: out of the window; itself: the plain path's) | bytes produced << 8; the offsets on it
+                uint32_t nxs = (tok ? (uint32_t)l + t_bits : (uint32_t)l) | (t_out << 8);
+                uint32_t r_lo = tok && l < 32 ? 1u << l : 0u, r_hi = tok && l >= 32 ? 1u << (l - 32) : 0u;
 #pragma unroll
-                    for (uint32_t k = 0; k < 3u; k++) {
-                        const uint32_t idx = i0 + k;
-                        const uint32_t xa = (uint32_t)__shfl((int)b.va, (int)(idx & 63u)), xb = (uint32_t)__shfl((int)b.vb, (int)(idx & 63u));
-                        wd[k] = idx < 64u ? xa : xb;
-                    }
-                    uint64_t bits64 = (((uint64_t)wd[1] << 32) | (uint64_t)wd[0]) >> sh;
-                    if (sh) bits64 |= (uint64_t)wd[2] << (64u - sh);
-                    const uint32_t e1 = S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)];
-                    const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
-                    uint32_t t_type = 2u, t_bits = 0u, t_val = 0u, t_dist = 0u;   // 0 literal (val = byte), 1 match (val = length), 2 the plain path's
-                    if (l1 != 0u && k1 == (uint32_t)K_LIT) { t_type = 0u; t_bits = l1; t_val = e1 >> 16; }
-                    else if (l1 != 0u && k1 == (uint32_t)K_LEN) {
-                        const uint32_t xl = (e1 >> 8) & 31u;
-                        const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
-                        const uint32_t used = l1 + xl;
-                        const uint32_t dbits = (uint32_t)(bits64 >> used);
-                        const uint32_t d = S.dt[dbits & ((1u << kD) - 1u)];
-                        const uint32_t dl = d & 15u;
-                        if (dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST) {
-                            const uint32_t xd = (d >> 8) & 31u;
-                            t_dist = (d >> 16) + ((dbits >> dl) & ((1u << xd) - 1u));
-                            t_type = 1u; t_bits = used + dl + xd; t_val = mlen;
-                        }
-                    }
-                    const uint32_t t_head = t_type | (t_bits << 8);
-                    uint32_t pos = 0, oo = o, outoff = 0;
-                    uint64_t pend = 0;   // literal lanes of the chain whose bytes are not in the ring yet
-                    int fail = S_OK;
-                    while (pos < 64u) {
-                        const uint32_t th = (uint32_t)__builtin_amdgcn_readlane((int)t_head, (int)pos);
-                        const uint32_t ty = th & 255u;
-                        if (ty == 2u) break;
-                        if (ty == 0u) {
-                            if (oo >= isize) { fail = S_OVERRUN_OUT; break; }
-                            outoff = (uint32_t)l == pos ? oo : outoff;
-                            pend |= 1ull << pos;
-                            oo++;
-                        } else {
-                            const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)t_val, (int)pos);
-                            const uint32_t md = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, (int)pos);
-                            if (md > oo) { fail = S_BAD_DISTANCE; break; }
-                            if (oo + mlen > isize) { fail = S_OVERRUN_OUT; break; }
-                            if (pend) { if ((pend >> l) & 1ull) S.ring[outoff & (kRing - 1u)] = (uint8_t)t_val; pend = 0; }
-                            if (oo - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
-                            copy_match(oo, mlen, md);
-                            oo += mlen;
-                        }
-                        pos += th >> 8;
-                    }
-                    if (pend && ((pend >> l) & 1ull)) S.ring[outoff & (kRing - 1u)] = (uint8_t)t_val;
-                    if (fail != S_OK) return fail;
-                    if (pos) {
-                        guard += pos;
-                        o = uni(oo);
-                        b.bitpos += (uint64_t)pos;
-                        f = uni(f); fenced = uni(fenced);
-                        if (pos >= 64u) continue;          // every offset of the window belonged to a token: another burst
-                        b.settle();
-                        bits = b.peek32();                 // the token the chain stopped at
-                    } else burst_wait = 3u;                // (nothing for a burst here: a few symbols the plain way first)
-                } else burst_wait--;
-                uint32_t e = uni(S.ll[bits & ((1u << kLL) - 1u)]);
-                if ((e & 15u) == 0u) { e = decode_long(b, S.cl_ll, false); if ((e & 15u) == 0u) return S_BAD_SYMBOL; }
-                const uint32_t kind = (e >> 4) & 15u;
-                if (kind == K_LIT) {
-                    b.bitpos += e & 15u;
-                    if (o >= isize) return S_OVERRUN_OUT;
-                    if (l == 0) S.ring[o & (kRing - 1u)] = (uint8_t)(e >> 16);
-                    o++;
-                    continue;
+                for (int step = 0; step < 4; step++) {
+                    const int tgt = (int)(nxs & 63u);
+                    const uint32_t an = (uint32_t)__shfl((int)nxs, tgt), a_lo = (uint32_t)__shfl((int)r_lo, tgt), a_hi = (uint32_t)__shfl((int)r_hi, tgt);
+                    if ((nxs & 255u) < 64u) { r_lo |= a_lo; r_hi |= a_hi; nxs = (an & 255u) | (((nxs >> 8) + (an >> 8)) << 8); }
                 }
-                if (kind == K_EOB) { b.bitpos += e & 15u; break; }
-                // a match: length (extra bits behind the code), distance code, its extra bits
-                bits >>= e & 15u;
-                const uint32_t xl = (e >> 8) & 31u;
-                const uint32_t len = (e >> 16) + (bits & ((1u << xl) - 1u));
-                b.bitpos += (e & 15u) + xl;
-                bits = b.peek32();
-                uint32_t d = uni(S.dt[bits & ((1u << kD) - 1u)]);
-                if ((d & 15u) == 0u) { d = decode_long(b, S.cl_d, true); if ((d & 15u) == 0u) return S_BAD_DISTANCE; }
-                bits >>= d & 15u;
-                const uint32_t xd = (d >> 8) & 31u;
-                const uint32_t dist = (d >> 16) + (bits & ((1u << xd) - 1u));
-                b.bitpos += (d & 15u) + xd;
-                if (dist > o) return S_BAD_DISTANCE;
-                if (o + len > isize) return S_OVERRUN_OUT;
-                copy_match(o, len, dist);
-                o = uni(o + len);
-                b.settle();
+                const uint64_t tok_mask = __ballot(tok);
+                uint32_t pos = 0;
+                for (;;) {
+                    o = uni(o); f = uni(f); fenced = uni(fenced); guard = uni(guard); pos = uni(pos);
+                    if (++guard > guard_max) return S_OVERRUN_IN;
+                    if (o - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                    if ((tok_mask >> pos) & 1ull) {
+                        const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)r_lo, (int)pos), m_hi = (uint32_t)__builtin_amdgcn_readlane((int)r_hi, (int)pos);
+                        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)nxs, (int)pos);
+                        const uint32_t stop = pp & 255u, s_tot = pp >> 8;
+                        const bool on_chain = (l < 32 ? (m_lo >> l) : (m_hi >> (l - 32))) & 1u;
+                        if (stop >= 64u || !((tok_mask >> stop) & 1ull)) {
+                            // (the chain has been followed to its end: every token on it knows the bytes in front of it)
+                            const uint32_t off = s_tot - (nxs >> 8);                       // bytes the chain produces in front of this token
+                            const bool dep = on_chain && t_type == 1u && (t_dist < off + t_val || t_val > 16u);
+                            const bool cut = on_chain && off + t_out > 256u;   // (a step writes at most 256 + 16 bytes: the ring's near sources stay whole)
+                            const uint64_t db = __ballot(dep), sbm = db | __ballot(cut);
+                            const uint32_t first = sbm ? (uint32_t)__builtin_ctzll(sbm) : 64u;
+                            const bool first_dep = sbm && ((db >> (first & 63u)) & 1ull);
+                            const bool in_step = on_chain && (uint32_t)l < first;
+                            const uint32_t n_step = sbm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(first & 63u)) : s_tot;
+                            if (o + n_step > isize) return S_OVERRUN_OUT;
+                            const bool is_m = in_step && t_type == 1u;
+                            const uint32_t at = o + off;
+                            if (__ballot(is_m && t_dist > at)) return S_BAD_DISTANCE;
+                            const bool far = is_m && t_dist > kNear;
+                            // a far source: flushed bytes, in global memory -- behind a fence if they were flushed since the last one
+                            if (__ballot(far && at - t_dist + t_val > fenced)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
+                            lds_sync();   // (the bytes in front of the step are other lanes' stores)
+                            const uint32_t my_n = in_step ? t_out : 0u;
+                            // four bytes a trip (a BAM's matches are mostly three or four bytes): one unaligned LDS read, one or two writes
+                            for (uint32_t i = 0; __ballot(i < my_n); i += 4u) {
+                                if (i < my_n) {
+                                    const uint32_t n4 = min(4u, my_n - i);
+                                    uint32_t v = t_val;
+                                    if (t_type == 1u) {
+                                        const uint32_t sp = at - t_dist + i;
+                                        if (far) {
+                                            uint32_t q0 = __hip_atomic_load(out + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q1 = 0, q2 = 0, q3 = 0;
+                                            if (n4 > 1u) q1 = __hip_atomic_load(out + sp + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            if (n4 > 2u) q2 = __hip_atomic_load(out + sp + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            if (n4 > 3u) q3 = __hip_atomic_load(out + sp + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            v = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+                                        } else {
+                                            const uint32_t rs = sp & (kRing - 1u);
+                                            if (rs <= kRing - 4u) v = *reinterpret_cast<const u32_unal*>(S.ring + rs);
+                                            else v = (uint32_t)S.ring[rs] | ((uint32_t)S.ring[(rs + 1u) & (kRing - 1u)] << 8) | ((uint32_t)S.ring[(rs + 2u) & (kRing - 1u)] << 16) | ((uint32_t)S.ring[(rs + 3u) & (kRing - 1u)] << 24);
+                                        }
+                                    }
+                                    const uint32_t rd = (at + i) & (kRing - 1u);
+                                    if (rd <= kRing - 4u) {
+                                        if (n4 == 4u) *reinterpret_cast<u32_unal*>(S.ring + rd) = v;
+                                        else {
+                                            if (n4 & 2u) { *reinterpret_cast<u16_unal*>(S.ring + rd) = (uint16_t)v; }
+                                            if (n4 & 1u) S.ring[rd + (n4 & 2u)] = (uint8_t)(v >> (8u * (n4 & 2u)));
+                                        }
+                                    } else {
+                                        for (uint32_t k = 0; k < n4; k++) S.ring[(rd + k) & (kRing - 1u)] = (uint8_t)(v >> (8u * k));
+                                    }
+                                }
+                            }
+                            o += n_step;
+                            guard += (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+                            if (!sbm) { pos = stop; }
+                            else if (!first_dep) { pos = first; }   // (the step was cut short: the next one begins here)
+                            else {
+                                // the match that reads what the step wrote (or a long one): all lanes on it
+                                const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)t_val, (int)first), md = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, (int)first);
+                                if (md > o) return S_BAD_DISTANCE;
+                                if (o + mlen > isize) return S_OVERRUN_OUT;
+                                if (o - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                                copy_match(o, mlen, md);
+                                o = uni(o + mlen);
+                                pos = first + (uint32_t)__builtin_amdgcn_readlane((int)t_bits, (int)first);
+                            }
+                        } else {
+                            // more than sixteen tokens in what is left of the window (codes of three bits and less): one token, the old way
+                            const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)t_type, (int)pos);
+                            if (ty == 0u) {
+                                if (o >= isize) return S_OVERRUN_OUT;
+                                if ((uint32_t)l == pos) S.ring[o & (kRing - 1u)] = (uint8_t)t_val;
+                                o++;
+                            } else {
+                                const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)t_val, (int)pos), md = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, (int)pos);
+                                if (md > o) return S_BAD_DISTANCE;
+                                if (o + mlen > isize) return S_OVERRUN_OUT;
+                                copy_match(o, mlen, md);
+                                o = uni(o + mlen);
+                            }
+                            pos += (uint32_t)__builtin_amdgcn_readlane((int)t_bits, (int)pos);
+                        }
+                        if (pos >= 64u) { b.bitpos = base + (uint64_t)pos; break; }
+                        continue;
+                    }
+                    // one token of the plain path at base + pos: the end of the block, a code longer than the first-level tables
+                    b.bitpos = base + (uint64_t)pos;
+                    uint32_t bits = b.peek32();
+                    uint32_t e = uni(S.ll[bits & ((1u << kLL) - 1u)]);
+                    if ((e & 15u) == 0u) { e = decode_long(b, S.cl_ll, false); if ((e & 15u) == 0u) return S_BAD_SYMBOL; }
+                    const uint32_t kind = (e >> 4) & 15u;
+                    if (kind == K_LIT) {
+                        b.bitpos += e & 15u;
+                        if (o >= isize) return S_OVERRUN_OUT;
+                        if (l == 0) S.ring[o & (kRing - 1u)] = (uint8_t)(e >> 16);
+                        o++;
+                    } else if (kind == K_EOB) { b.bitpos += e & 15u; eob = true; break; }
+                    else {
+                        // a match: length (extra bits behind the code), distance code, its extra bits
+                        bits >>= e & 15u;
+                        const uint32_t xl = (e >> 8) & 31u;
+                        const uint32_t len = (e >> 16) + (bits & ((1u << xl) - 1u));
+                        b.bitpos += (e & 15u) + xl;
+                        bits = b.peek32();
+                        uint32_t d = uni(S.dt[bits & ((1u << kD) - 1u)]);
+                        if ((d & 15u) == 0u) { d = decode_long(b, S.cl_d, true); if ((d & 15u) == 0u) return S_BAD_DISTANCE; }
+                        bits >>= d & 15u;
+                        const uint32_t xd = (d >> 8) & 31u;
+                        const uint32_t dist = (d >> 16) + (bits & ((1u << xd) - 1u));
+                        b.bitpos += (d & 15u) + xd;
+                        if (dist > o) return S_BAD_DISTANCE;
+                        if (o + len > isize) return S_OVERRUN_OUT;
+                        copy_match(o, len, dist);
+                        o = uni(o + len);
+                    }
+                    b.settle();
+                    if (b.bitpos - base >= 64ull) break;          // the window is used up
+                    pos = (uint32_t)(b.bitpos - base);
+                }
+                if (eob) break;
             }
             if (b.overrun()) return S_OVERRUN_IN;
         }

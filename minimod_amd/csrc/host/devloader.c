@@ -277,6 +277,7 @@ int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more) 
         }
         dl->first_group = 0;
         dl->groups++; dl->slow_blocks += r.n_slow_blocks;
+        { float ms[4]; if (mm_ingest_times(dl->ing, slot, ms) == 0) for (int k = 0; k < 4; k++) dl->st.stage_ms[k] += ms[k]; }
         dl->cur = r;
         b_total_reads += r.total_reads; b_total_bytes += r.total_bytes; b_proc_bytes += r.processed_bytes;
         dl->st.total_reads += r.total_reads; dl->st.total_bytes += r.total_bytes; dl->st.processed_bytes += r.processed_bytes;

@@ -651,7 +651,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
         T.total_reads = st->total_reads; T.total_bytes = st->total_bytes; T.processed_reads = st->processed_reads; T.processed_bytes = st->processed_bytes; T.processed_bases = st->processed_bases;
         fprintf(stderr, "[gpu-ingest] %lu groups of BGZF blocks framed and flattened on the device (%lu blocks walked again from their true entry, %lu decoded by the host), "
-                        "%.3f s waiting for staged groups, %.3f s staging\n", (unsigned long)st->groups, (unsigned long)st->slow_blocks, (unsigned long)st->patched_blocks, st->wait_seconds, st->stage_seconds);
+                        "%.3f s waiting for staged groups, %.3f s staging; device ms summed over the groups: copies %.0f, inflate %.0f, CRC32 %.0f, frame + flatten %.0f\n", (unsigned long)st->groups, (unsigned long)st->slow_blocks, (unsigned long)st->patched_blocks, st->wait_seconds, st->stage_seconds,
+                st->stage_ms[0], st->stage_ms[1], st->stage_ms[2], st->stage_ms[3]);
     } else {
         T.total_reads = ld->total_reads; T.total_bytes = ld->total_bytes; T.processed_reads = ld->processed_reads; T.processed_bytes = ld->processed_bytes; T.processed_bases = ld->processed_bases;
     }

@@ -104,6 +104,7 @@ typedef struct mmh_devloader_stats {
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;   /* core_t counters, src/minimod.h:190-194 */
     uint64_t groups, slow_blocks, patched_blocks;
     double wait_seconds, stage_seconds;
+    double stage_ms[4];             /* device milliseconds summed over the groups: host -> device copies, inflate, CRC32, frame + flatten (they overlap between groups) */
     int err;                        /* MM_INGEST_E_* of a failed run */
 } mmh_devloader_stats_t;
 mmh_devloader_t *mmh_devloader_open(const char *bam_path, mm_pool_t *pool, const mmh_devloader_opts_t *o, char *err, size_t err_len);

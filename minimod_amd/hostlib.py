@@ -179,7 +179,7 @@ class mmh_devloader_stats_t(ctypes.Structure):
     _fields_ = [("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_reads", ctypes.c_uint64),
                 ("processed_bytes", ctypes.c_uint64), ("processed_bases", ctypes.c_uint64),
                 ("groups", ctypes.c_uint64), ("slow_blocks", ctypes.c_uint64), ("patched_blocks", ctypes.c_uint64),
-                ("wait_seconds", ctypes.c_double), ("stage_seconds", ctypes.c_double), ("err", ctypes.c_int)]
+                ("wait_seconds", ctypes.c_double), ("stage_seconds", ctypes.c_double), ("stage_ms", ctypes.c_double * 4), ("err", ctypes.c_int)]
 
 
 def peek_header(path):
@@ -253,7 +253,7 @@ def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementa
                 d = None
             yield d, {"bases": int(db.bases), "total_reads": int(db.total_reads), "total_bytes": int(db.total_bytes), "processed_bytes": int(db.processed_bytes)}
         st = L.mmh_devloader_stats(dl).contents
-        yield None, {k: getattr(st, k) for k, _ in mmh_devloader_stats_t._fields_}
+        yield None, {k: (list(getattr(st, k)) if k == "stage_ms" else getattr(st, k)) for k, _ in mmh_devloader_stats_t._fields_}
     finally:
         L.mmh_devloader_close(dl)
         L.mm_pool_destroy(pool)

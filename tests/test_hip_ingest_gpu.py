@@ -75,9 +75,9 @@ def test_device_batch_equals_the_host_loaders(path, flt):
     assert st["processed_reads"] == len(want["reads"]) and st["processed_bases"] == int(want["reads"]["l_qseq"].sum())
 
 
-# tiny groups (8 blocks), a head room of 64 KB, arenas that hold a few hundred KB: tails in every group, batches closing on the
+# tiny groups (8 blocks), a head room of 512 KB, arenas that hold a few hundred KB: tails in every group, batches closing on the
 # arena's size, groups run again into the next arena -- the batches put end to end must still be the host loader's one batch
-SMALL = dict(group_slots=3, max_blocks=8, arenas=3, max_cbytes=1 << 20, arena_bytes=(8 * 65536 + (64 << 10)) * 2, head_room=64 << 10)
+SMALL = dict(group_slots=3, max_blocks=8, arenas=3, max_cbytes=1 << 20, arena_bytes=(8 * 65536 + (512 << 10)) * 2, head_room=512 << 10)
 
 
 @pytest.mark.parametrize("path", BAMS, ids=[os.path.basename(p) for p in BAMS])
