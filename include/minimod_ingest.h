@@ -43,7 +43,7 @@ typedef struct mm_ingest_opts {
     int32_t arenas;               /* 0 = 3 */
     int32_t rsvd;
     uint64_t max_cbytes;          /* staging bytes per group; 0 = 48 MiB */
-    uint64_t arena_bytes;         /* decoded bytes a batch may be made of (sizes the pools); 0 = 2 GiB */
+    uint64_t arena_bytes;         /* decoded bytes a batch may be made of (sizes the pools); 0 = 1 GiB */
     uint64_t head_room;           /* longest record tail that can be carried; 0 = 32 MiB */
     /* a worker of a sharded run (csrc/host/loader.c mmh_loader_open_share): only alignments that START inside the share */
     int32_t ranged, first, last;

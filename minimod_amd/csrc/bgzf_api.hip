@@ -116,7 +116,7 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
     SCHK(hipMemcpyAsync(s.d_c, s.h_c, cbytes, hipMemcpyHostToDevice, s.stream));
     SCHK(hipMemcpyAsync(s.d_blocks, s.h_blocks, sizeof(Block) * (size_t)n_blocks, hipMemcpyHostToDevice, s.stream));
     SCHK(hipEventRecord(s.ev[1], s.stream));
-    const int wgs = std::max(1, std::min(h->n_cu * 5, (n_blocks + kWaves - 1) / kWaves));   // (five workgroups of 30 KB of LDS fit a CU)
+    const int wgs = std::max(1, std::min(h->n_cu * 4, (n_blocks + kWaves - 1) / kWaves));   // (four workgroups of 32 KB of LDS fit a CU)
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(wgs), dim3(64 * kWaves), 0, s.stream, s.d_c, s.d_blocks, n_blocks, s.d_out, s.d_status);
     SCHK(hipEventRecord(s.ev[2], s.stream));
     hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(h->n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, s.stream, s.d_out, s.d_blocks, n_blocks, s.d_status);
@@ -141,7 +141,7 @@ int32_t mm_bgzf_inflate_device(int32_t device, void* stream, const uint8_t* d_c,
     }
     const int n_cu = n_cu_of[device];
     hipStream_t st = (hipStream_t)stream;
-    if (n_blocks) hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::max(1, std::min(n_cu * 5, (n_blocks + kWaves - 1) / kWaves))), dim3(64 * kWaves), 0, st, d_c,
+    if (n_blocks) hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::max(1, std::min(n_cu * 4, (n_blocks + kWaves - 1) / kWaves))), dim3(64 * kWaves), 0, st, d_c,
                                      reinterpret_cast<const Block*>(d_blocks), n_blocks, d_out, d_status);
     if (between_event && hipEventRecord((hipEvent_t)between_event, st) != hipSuccess) return -4;
     if (n_blocks) hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, st, d_out, reinterpret_cast<const Block*>(d_blocks), n_blocks, d_status);

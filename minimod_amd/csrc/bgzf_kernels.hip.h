@@ -29,7 +29,10 @@
 
 namespace mmbgzf {
 
-constexpr int kLL = 10, kD = 7;                 // first-level table bits (round 4: 7 for distances -- the wavefront's LDS is 7.6 KB: five workgroups a CU)
+constexpr int kLL = 10, kD = 8;                 // first-level table bits.  The wavefront's LDS is 8.1 KB: FOUR workgroups a CU (32.3 KB each), on purpose --
+                                                // five (7.6 KB a wavefront with kD = 7) decoded 5 % faster alone, but a workgroup holds its CU's LDS and registers for
+                                                // ~9 ms, and with five of them nothing else fits: the record framing behind the inflate and k_stream_reads (22.5 KB of
+                                                // LDS, 72 registers) waited for workgroups to retire
 constexpr int kWaves = 4;                       // wavefronts per workgroup
 constexpr size_t kPad = 1024;                   // readable bytes behind a launch's compressed bytes
 enum { S_OK = 0, S_BAD_BLOCK_TYPE = 1, S_BAD_STORED = 2, S_BAD_CODE_LENGTHS = 3, S_BAD_SYMBOL = 4, S_BAD_DISTANCE = 5, S_OVERRUN_OUT = 6,

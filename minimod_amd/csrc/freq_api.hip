@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -794,6 +795,9 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return fail(h, "hipGetDeviceProperties failed");
     h->n_cu = prop.multiProcessorCount;
+    const bool tl_on = std::getenv("MM_TIMELINE") != nullptr;
+    auto tl_now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double tl_a = tl_now();
     // four bits a position need a context made of A C G T (or `*`): only then does no other reference letter ever sit in a match
     auto plain_context = [&]() {
         const char* c = opts->mods[0].context;
@@ -975,6 +979,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         (void)hipMemcpy(h->d_seg_len, h->seg_len.data(), tb, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_cnt_base, h->cnt_base.data(), tb, hipMemcpyHostToDevice);
     }
+    const double tl_b = tl_now();
     // K0 per contig through a staging buffer
     {
         int64_t maxlen = 0;
@@ -998,6 +1003,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             (void)hipFree(d_raw);
         }
     }
+    const double tl_c = tl_now();
     // ---- context classes: mods with one context string share a class (their counters lie side by side per site); every position
     // is a site of a DENSE class: the context `*`, and any class under --insertions, where no context is looked at (mod.c:1167-1172)
     {
@@ -1103,11 +1109,14 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         (void)hipMemset(h->d_slab_flag, 0, 4);
         h->codes_dirty = !h->codes.empty();
     }
+    const double tl_d = tl_now();
     if (dev_alloc(h, (void**)&h->d_counters, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)))
         return fail(h, "counter plane alloc failed");
     if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)) != hipSuccess)
         return fail(h, "counter memset failed");
     if (hipDeviceSynchronize() != hipSuccess) return fail(h, "device sync failed");
+    if (tl_on) std::fprintf(stderr, "[timeline] mm_freq_create: tables + allocations %.3f s, reference upload + context kernels %.3f s, site index %.3f s, counters %.3f s (the runtime's start lies in front of these)\n",
+                            tl_b - tl_a, tl_c - tl_b, tl_d - tl_c, tl_now() - tl_d);
     return h;
 }
 

@@ -177,7 +177,9 @@ mmh_devloader_t *mmh_devloader_open(const char *bam_path, mm_pool_t *pool, const
         if (e1 && atoi(e1) > 0) { io.max_blocks = atoi(e1); if (!io.max_cbytes) io.max_cbytes = (uint64_t)io.max_blocks * 66000 + 65536; }
         if (e2 && atoll(e2) > 0) dl->target_bases = (uint64_t)atoll(e2);
     }
+    const double t_create = dl_now();
     dl->ing = mm_ingest_create(&io, err, err_len);
+    if (getenv("MM_TIMELINE")) fprintf(stderr, "[timeline] mm_ingest_create took %.3f s\n", dl_now() - t_create);
     if (!dl->ing) { close(dl->fd); free(dl); return NULL; }
     dl->n_slots = mm_ingest_group_slots(dl->ing);
     dl->n_arenas = io.arenas > 0 ? io.arenas : 3;
@@ -289,7 +291,7 @@ int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more) 
             if (g.err || r.tail_len) { dl->failed = 1; dl->st.err = MM_INGEST_E_RECORD; }   /* a damaged block behind the group, or the file ends inside a record */
             break;
         }
-        if (r.batch_bases >= dl->target_bases || r.seq_bytes + r.cigar_bytes + r.mm_bytes > mm_ingest_arena_bytes(dl->ing) / 3) break;
+        if (r.batch_bases >= dl->target_bases || r.seq_bytes > mm_ingest_arena_bytes(dl->ing) / 3 || r.cigar_bytes > mm_ingest_arena_bytes(dl->ing) / 6 || r.mm_bytes > mm_ingest_arena_bytes(dl->ing) / 6) break;   /* (two thirds of a pool: the next group still fits) */
     }
     if (dl->finished && !dl->quit) { pthread_mutex_lock(&dl->mu); dl->quit = 1; pthread_cond_broadcast(&dl->cv_free); pthread_mutex_unlock(&dl->mu); }
     int32_t n = 0;

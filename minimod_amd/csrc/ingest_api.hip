@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "ingest_kernels.hip.h"
@@ -78,7 +80,7 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     if (h->o.max_blocks <= 0) h->o.max_blocks = 2048;
     if (h->o.arenas <= 0) h->o.arenas = 3;
     if (h->o.max_cbytes == 0) h->o.max_cbytes = (uint64_t)48 << 20;
-    if (h->o.arena_bytes == 0) h->o.arena_bytes = (uint64_t)2 << 30;
+    if (h->o.arena_bytes == 0) h->o.arena_bytes = (uint64_t)1 << 30;
     if (h->o.head_room == 0) h->o.head_room = (uint64_t)32 << 20;
     h->o.head_room = (h->o.head_room + 255) & ~(uint64_t)255;
     const uint64_t max_ob = (uint64_t)h->o.max_blocks * 65536ull;
@@ -90,6 +92,9 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     }
     h->device = h->o.device; h->H = (uint32_t)h->o.head_room; h->max_obytes = (uint32_t)max_ob;
     h->max_records = (uint32_t)((h->o.head_room + max_ob) / 48);
+    const bool tl = std::getenv("MM_TIMELINE") != nullptr;
+    auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double t0 = now();
     ICHK(hipSetDevice(h->device));
     hipDeviceProp_t prop;
     ICHK(hipGetDeviceProperties(&prop, h->device));
@@ -102,10 +107,13 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     ICHK(hipMalloc((void**)&h->d_cursor, 2 * sizeof(Cursor)));
     ICHK(hipMemset(h->d_cursor, 0, 2 * sizeof(Cursor)));
     for (int k = 0; k < 2; k++) ICHK(hipMalloc((void**)&h->d_tail[k], h->H));
+    const double t1 = now();
     h->slots.resize((size_t)h->o.group_slots);
     const size_t nb1 = (size_t)h->o.max_blocks + 1;
     for (GSlot& s : h->slots) {
         // the lowest priority: the inflate's workgroups run for milliseconds; the chain's and the freq path's kernels get the CUs they leave first
+        // (a stream with a CU mask that keeps the inflate off a few CUs -- hipExtStreamCreateWithCUMask -- hung the first launch on this
+        // pool's boxes: not used.  Instead the inflate's workgroups are sized so that four of them leave room on every CU, below.)
         ICHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_least));
         for (auto& e : s.ev) ICHK(hipEventCreate(&e));
         ICHK(hipEventCreate(&s.ev_f0)); ICHK(hipEventCreate(&s.ev_done));
@@ -126,19 +134,22 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
         ICHK(hipMalloc((void**)&s.d_desc, sizeof(Desc) * (size_t)h->max_records));
         ICHK(hipMalloc((void**)&s.d_result, sizeof(Result)));
     }
+    const double t2 = now();
     h->arenas.resize((size_t)h->o.arenas);
     for (Arena& a : h->arenas) {
-        // a batch is made of at most arena_bytes of decoded stream; no pool can take more than that (+ its padding), and a BAM's
-        // records are mostly sequence (a nibble a base) and qualities (not kept): the pools get fixed shares of it, a group that does
-        // not fit is answered with MM_INGEST_E_ARENA (the caller closes the batch and runs the group again into an empty arena)
+        // a batch is made of about arena_bytes of decoded stream, and a BAM's records are mostly sequence (a nibble a base) and
+        // qualities (not kept): the pools get fixed shares of that -- sequence a half, CIGARs and MM text a quarter each, ML an eighth
+        // (what is allocated is also what the process's end has to unmap) -- and a group that does not fit is answered with
+        // MM_INGEST_E_ARENA: the caller closes the batch and runs the group again into an empty arena
         const uint64_t D = h->o.arena_bytes;
         a.cap_reads = D / 512 + 4096;
-        a.cap_cigar = D / 2 + (1 << 20); a.cap_seq = D / 2 + (1 << 20); a.cap_mm = std::min<uint64_t>(D / 2 + (1 << 20), 0xFFFFF000ull); a.cap_ml = D / 4 + (1 << 20);
+        a.cap_cigar = D / 4 + (1 << 20); a.cap_seq = D / 2 + (1 << 20); a.cap_mm = std::min<uint64_t>(D / 4 + (1 << 20), 0xFFFFF000ull); a.cap_ml = D / 8 + (1 << 20);
         ICHK(hipMalloc((void**)&a.reads, sizeof(mm_read_t) * a.cap_reads));
         ICHK(hipMalloc((void**)&a.cigar, a.cap_cigar)); ICHK(hipMalloc((void**)&a.seq, a.cap_seq));
         ICHK(hipMalloc((void**)&a.mm, a.cap_mm)); ICHK(hipMalloc((void**)&a.ml, a.cap_ml));
     }
     ICHK(hipDeviceSynchronize());
+    if (tl) std::fprintf(stderr, "[timeline] mm_ingest_create: runtime + streams %.3f s, group slots %.3f s, arenas %.3f s\n", t1 - t0, t2 - t1, now() - t2);
     return h;
 }
 
@@ -232,7 +243,7 @@ int32_t mm_ingest_flatten(mm_ingest_t* h, int32_t slot, int32_t arena, int32_t n
     hipLaunchKernelGGL(k_frame_chain, dim3(1), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_frame_fill, dim3((unsigned)((s.n_blocks + 1 + 255) / 256)), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_rec_parse, dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, st, P);
+    hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(kScanThreads), 0, st, P);
     hipLaunchKernelGGL(k_rec_copy, dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, P);
     RCHK(hipGetLastError());
     RCHK(hipMemcpyAsync(s.h_result, s.d_result, sizeof(Result), hipMemcpyDeviceToHost, st));

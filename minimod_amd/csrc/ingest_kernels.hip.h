@@ -375,23 +375,27 @@ __global__ __launch_bounds__(256) void k_rec_parse(Params P) {
     }
 }
 
-// ---- exclusive sums over a workgroup of 1024 threads
-__device__ __forceinline__ uint64_t wg_scan(uint64_t v, uint64_t* sh /*[17]*/, uint64_t* total) {
+// ---- exclusive sums over a workgroup of kScanThreads threads.  (Four wavefronts that need few registers: the kernel runs beside the
+// inflate's workgroups, which hold a CU's LDS and most of its registers for milliseconds -- a workgroup of 1024 threads and 112
+// registers waited for a whole CU to drain, 3.8 ms a group.)
+constexpr int kScanThreads = 256, kScanWaves = kScanThreads / 64;
+__device__ __forceinline__ uint64_t wg_scan(uint64_t v, uint64_t* sh /*[kScanWaves + 1]*/, uint64_t* total) {
     const int l = lane(), w = (int)(threadIdx.x >> 6);
     uint64_t x = v;
     for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d, 64); if (l >= d) x += y; }
     __syncthreads();
     if (l == 63) sh[w] = x;
     __syncthreads();
-    if (threadIdx.x == 0) { uint64_t run = 0; for (int k = 0; k < 16; k++) { const uint64_t t = sh[k]; sh[k] = run; run += t; } sh[16] = run; }
-    __syncthreads();
-    *total = sh[16];
-    return sh[w] + x - v;
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < kScanWaves; k++) { const uint64_t t = sh[k]; if (k < w) before += t; all += t; }
+    *total = all;
+    return before + x - v;
 }
 
 // ---- which records count, which are accepted, where they go: one workgroup
-__global__ __launch_bounds__(1024) void k_rec_scan(Params P) {
-    __shared__ uint64_t sh[17];
+__global__ __launch_bounds__(kScanThreads, 4) void k_rec_scan(Params P) {
+    __shared__ uint64_t sh[kScanWaves + 1];
     const uint32_t n_rec = P.result->n_records;
     Carry co = *P.carry_out;               // (k_frame_chain's; done / seen and a record's error are added here)
     Cursor cu;
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_rec_scan(Params P) {
     uint32_t seen = (uint32_t)co.seen, done = (uint32_t)co.done;
     uint32_t mx_c = cu.max_n_cigar, mx_l = cu.max_l_qseq;
     bool full = false;
-    for (uint32_t base = 0; base < n_use; base += 1024u) {
+    for (uint32_t base = 0; base < n_use; base += (uint32_t)kScanThreads) {
         const uint32_t i = base + threadIdx.x;
         Desc d;
         d.flags = 0; d.l_data = 0; d.l_qseq = 0; d.n_cigar_lname = 0; d.mm_len = d.ml_len = 0; d.mm_src = d.ml_src = 0;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_rec_scan(Params P) {
         __syncthreads();
         if (lane() == 0) { sh[threadIdx.x >> 6] = ((uint64_t)c2 << 32) | l2; }
         __syncthreads();
-        for (int k = 0; k < 16; k++) { mx_c = max(mx_c, (uint32_t)(sh[k] >> 32)); mx_l = max(mx_l, (uint32_t)sh[k]); }
+        for (int k = 0; k < kScanWaves; k++) { mx_c = max(mx_c, (uint32_t)(sh[k] >> 32)); mx_l = max(mx_l, (uint32_t)sh[k]); }
         __syncthreads();
         cu.n_reads += t_n; cu.cigar_bytes += t_c; cu.seq_bytes += t_s; cu.mm_bytes += t_m; cu.ml_bytes += t_l; cu.bases += t_b;
         n_acc += (uint32_t)t_n;
