@@ -84,6 +84,7 @@ def parse_args():
                                                                "instead of the 24-contig genome")
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5", "DOT"], help="BASELINE.json workload: C2 = the headline (default); DOT (not a BASELINE config): C2's reads "
                                                                                      "with the MM '.' flag (every unlisted C an implicit call)")
+    ap.add_argument("--stream-slices", type=int, default=0, help="mm_freq_opts_t.stream_slices: 0 one position slice of a launch per XCD (default), 1 costliest first over the whole launch")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
     ap.add_argument("--cpu-t1-batches", type=int, default=2, help="batches in the BAM the `-t 1` CPU run reads")
@@ -618,7 +619,7 @@ def main():
     else:
         eng = minimod_amd.FreqEngine(wl["mods"], contig, device=local_rank,
                                      intervals=[(iv["tid"], iv["begin"], iv["end"], iv["halo"]) for iv in plan["intervals"]],
-                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce, stream_mode=1 if args.no_stream else 0,
+                                     side_capacity=(96 << 20) if wl["eng"].get("insertions") else 0, split_bases=args.split_bases, force_fused=args.force_fused, coalesce=args.coalesce, stream_mode=1 if args.no_stream else 0, stream_slices=args.stream_slices,
                                      **wl["eng"])
     # ---- make the reads resident in HBM (torch owns the memory: plumbing only): ONE read set -- the pools of all batches
     # end to end, as a decoder writing into device memory would leave them -- and a step's batch is a window of -K reads of

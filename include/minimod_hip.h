@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4
+#define MM_ABI_VERSION 5
 #define MM_MAX_MODS 13    /* requested -c entries (2 context bits each + 5 base bits in one 32-bit ref word) */
 #define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
 #define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
@@ -111,7 +111,8 @@ typedef struct mm_freq_opts {
     int32_t split_bases;     /* device planning: reads longer than this are cut into parts of about this many bases (0 = default) */
     int32_t coalesce;        /* up to this many consecutive submits share one launch: for mm_freq_submit_device consecutive windows of
                               * one resident read set, for mm_freq_submit host batches staged one behind the other in device memory
-                              * (see both); 0 or 1 = every submit is its own launch */
+                              * (see both).  0 = the library's default (32: a -K batch fills a fraction of an MI355X, and a caller that
+                              * sets nothing should not get a launch per batch); 1 = every submit is its own launch.  (ABI 4: 0 meant 1.) */
     int32_t stream_mode;     /* which reads take the streaming kernel (k_stream_reads: a whole read in one wavefront) instead of the
                               * tile pipeline, in plain runs (freq or view; no --insertions, no --haplotypes).  0 (default): by the
                               * size of the launch -- none in a launch of fewer than about 15 000 reads (a single -K 4096 batch:
@@ -122,6 +123,10 @@ typedef struct mm_freq_opts {
                               * pipeline -- and the '.'-capable one from the next launch on: a file's reads carry one flag or the other).
                               * (A reserved field before: same layout.) */
     int32_t gather_mb;       /* mm_freq_submit with coalesce > 1: MiB of staging a launch may gather (0 = 1024) */
+    int32_t stream_slices;   /* k_stream_reads in launches of 8192 reads and more: 0 (default) one POSITION slice of the launch per XCD, each
+                              * worked through in file order (the slice's site words, bases and counters stay in that XCD's L2); 1 the
+                              * launch's reads costliest first whatever their place (rounds 2 and 3) */
+    int32_t rsvd_opts;
     mm_mod_t mods[MM_MAX_MODS];
 } mm_freq_opts_t;
 

@@ -514,9 +514,14 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
                     HIPCHK(hipMemsetAsync(s.d_plan_state, 0, sizeof(PlanState), st));
                 }
                 const int pb = std::max(1, std::min(64, (b->n_reads + kPlanReadsPerBlock - 1) / kPlanReadsPerBlock));
+                // sliced hand-out (one position slice per XCD, freq_tiles.hip.h stream_bucket): launches of thousands of reads
+                uint32_t long_cut = 0u;   // (the launch's mean read length; 0 = not sliced)
+                if (stream && b->n_reads >= 8192 && h->opts.stream_slices != 1)
+                    long_cut = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((bases_hint ? bases_hint : 12000ull * (uint64_t)b->n_reads) / (uint64_t)b->n_reads, 256), 0x00FFFFFFu);
                 hipLaunchKernelGGL(k_plan_items, dim3(pb), dim3(kPlanThreads), 0, st, b->reads, b->n_reads, split, s.d_plan, ctl + 6,
                                    s.d_plan_state, ++s.plan_serial, p.err_summary, p.host_flag, stream ? stream_max : 0u, s.d_plan_stream, ctl + 7,
-                                   all_stream ? s.h_ctl + 131 : nullptr);
+                                   all_stream ? s.h_ctl + 131 : nullptr, long_cut);
+                tp.stream_slices = long_cut ? s.d_plan_state->slices : nullptr;
                 p.order = s.d_plan;
                 p.n_items = (int32_t)std::min<size_t>(max_items, (size_t)0x7FFFFFFF);   // an upper bound: sizes the grid
                 tp.plan_count = ctl + 6;
@@ -790,6 +795,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (opts->device < 0 || opts->device >= ndev) return fail(nullptr, "bad device ordinal");
     mm_freq* h = new mm_freq();
     h->opts = *opts;
+    if (h->opts.coalesce <= 0) h->opts.coalesce = 32;   // the library's default (ABI 5); 1 = every submit its own launch
     h->device = opts->device;
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, "hipSetDevice failed");
     hipDeviceProp_t prop;

@@ -1089,14 +1089,39 @@ __global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)
     const int g = uni((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
     const bool dynamic = n_waves >= (int)kTileRegions;
     k.v_region = (uint32_t)g % kViewRegions;
-    for (int r = g; r < n;) {
-        const int r_cur = r;
-        if (dynamic) {
-            unsigned int c = 0;
-            if (lane_id() == 0) c = atomicAdd(P.stream_queue + (unsigned int)(g % (int)kTileRegions) * kQueueStride, 1u);
-            r = n_waves + (int)(uniu(c) * kTileRegions) + g % (int)kTileRegions;
+    // a SLICED launch (freq_tiles.hip.h, stream_bucket): this workgroup's XCD works through its own position slice front to back
+    // (eight interleaved queues per slice), then through the slices behind it; otherwise items costliest first, a wave's first item
+    // fixed, the following ones handed out by 64 padded counters (as in k_scan_reads)
+    const bool sliced = P.stream_slices != nullptr && dynamic;
+    const uint32_t xcc = sliced ? (uniu(__builtin_amdgcn_s_getreg((3 << 11) | 20)) & (kStreamSlices - 1u)) : 0u;    // HW_REG_XCC_ID, bits 3:0
+    const uint32_t sub = (((uint32_t)blockIdx.x >> 3) * (uint32_t)kWavesPerBlock + (threadIdx.x >> 6)) & 7u;   // (workgroups b and b + 8 share an XCD: its wavefronts spread over the slice's eight queues)
+    uint32_t hop = 0;
+    int lo = 0, hi = 0;
+    if (sliced) { lo = (int)scalar_load(P.stream_slices + xcc); hi = (int)scalar_load(P.stream_slices + xcc + 1u); }
+    for (int r = g;;) {
+        int r_cur;
+        if (sliced) {
+            bool got = false;
+            while (hop < kStreamSlices) {
+                const uint32_t sl = (xcc + hop) & (kStreamSlices - 1u);
+                unsigned int c = 0;
+                if (lane_id() == 0) c = atomicAdd(P.stream_queue + (sl * 8u + sub) * kQueueStride, 1u);
+                r_cur = lo + (int)(uniu(c) * 8u + sub);
+                if (r_cur < hi) { got = true; break; }
+                hop++;
+                if (hop < kStreamSlices) { const uint32_t s2 = (xcc + hop) & (kStreamSlices - 1u); lo = (int)scalar_load(P.stream_slices + s2); hi = (int)scalar_load(P.stream_slices + s2 + 1u); }
+            }
+            if (!got) break;
         } else {
-            r += n_waves;
+            if (r >= n) break;
+            r_cur = r;
+            if (dynamic) {
+                unsigned int c = 0;
+                if (lane_id() == 0) c = atomicAdd(P.stream_queue + (unsigned int)(g % (int)kTileRegions) * kQueueStride, 1u);
+                r = n_waves + (int)(uniu(c) * kTileRegions) + g % (int)kTileRegions;
+            } else {
+                r += n_waves;
+            }
         }
         const int ridx = uni((int)scalar_load(P.stream_items + r_cur));
         const int st = uni(k.run(ridx));

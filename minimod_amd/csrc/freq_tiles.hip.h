@@ -82,6 +82,7 @@ struct TileParams {
     // the static first round, and where it appends the reads it leaves to the tile pipeline (which runs after it)
     const int32_t* stream_items;
     const unsigned int* stream_count;
+    const unsigned int* stream_slices;   // sliced launches (k_plan_items with long_cut): first item of every position slice, [8] = the items; else null
     unsigned int* stream_queue;       // [kTileRegions * kQueueStride]
     int32_t* tile_items;              // == d.order, writable
     unsigned int* tile_plan_count;    // == plan_count, writable
@@ -243,9 +244,27 @@ __device__ __forceinline__ uint32_t plan_bucket(uint32_t L, uint32_t w) {
 // Stream items: costliest first like the tile items.  (Tried: four length classes and, inside a class, the reads of one 64th of
 // the batch together, so that wavefronts running side by side meet the same reference words in L2 -- C2 58.4 against 56.9 us
 // per batch, L2-miss traffic 185 against 192 MB per batch: not kept.)
-__device__ __forceinline__ uint32_t stream_bucket(uint32_t L, uint32_t i, uint32_t n) {
-    (void)i; (void)n;
-    return plan_bucket(L, 1u);
+//
+// Round 4, SLICED launches (mean_len != 0: gathered launches of thousands of reads): the chip has eight XCDs with an L2 of 4 MB
+// each, and reads come in coordinate order.  The launch's reads are cut into eight POSITION slices (read index * 8 / n), and
+// k_stream_reads hands slice x to the workgroups on XCD x (s_getreg XCC_ID), which work through it front to back and then help
+// with the slices behind it.  Inside a slice, 32 buckets in three zones:
+//   0 - 7    the long reads (more than twice the launch's mean length), costliest first: a 200 kb read lasts as long as the launch;
+//   8 - 27   everything within a factor of two of the mean, in FILE ORDER: at any moment an XCD's wavefronts sit on a few hundred
+//            consecutive reads -- a few hundred kilobases of reference whose site words, bases and counters stay in that XCD's L2
+//            for all thirty reads over a site, instead of every L2 seeing every position once per read;
+//   28 - 31  the short reads (less than half the mean), costliest first: what a launch ends with decides how long its last
+//            wavefront runs alone (file order to the end: C2 41.6 against 32.0 us per batch).
+constexpr uint32_t kStreamSlices = 8, kSliceBuckets = kPlanBuckets / kStreamSlices;
+__device__ __forceinline__ uint32_t stream_bucket(uint32_t L, uint32_t i, uint32_t n, uint32_t mean_len) {
+    if (mean_len == 0u) return plan_bucket(L, 1u);
+    const uint32_t sl = min(kStreamSlices - 1u, (uint32_t)(((uint64_t)i * kStreamSlices) / n));
+    const uint32_t lo = (uint32_t)(((uint64_t)sl * n + kStreamSlices - 1u) / kStreamSlices), hi = (uint32_t)(((uint64_t)(sl + 1u) * n + kStreamSlices - 1u) / kStreamSlices);
+    uint32_t cls;
+    if (L > 2u * mean_len) cls = 7u - min(7u, L / (2u * mean_len) - 1u);
+    else if (2u * L < mean_len) cls = 31u - min(3u, (8u * L) / mean_len);
+    else cls = 8u + min(19u, (uint32_t)(((uint64_t)(i - lo) * 20u) / max(hi - lo, 1u)));
+    return sl * kSliceBuckets + cls;
 }
 // State the planning workgroups share (one per slot, zeroed once at creation; every launch leaves it zeroed again).
 // Two lists are planned at once: class 0 = the tile pipeline's items (parts), class 1 = reads for k_stream_reads.
@@ -254,6 +273,7 @@ struct PlanState {
     unsigned int cursor[2 * kPlanBuckets];   // first free item of every bucket (each class counts from 0: two item arrays)
     unsigned int done;                       // workgroups that have added their histogram
     unsigned int ready;                      // the launch serial, once the cursors are valid
+    unsigned int slices[kStreamSlices + 4];  // sliced launches: first stream item of every slice, [kStreamSlices] = their number
 };
 constexpr int kPlanThreads = 256;
 constexpr int kPlanReadsPerBlock = 512;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
                                                              unsigned int* __restrict__ n_items_out, PlanState* __restrict__ st, unsigned int serial,
                                                              unsigned int* __restrict__ err_summary, unsigned int* __restrict__ host_flag,
                                                              uint32_t stream_max, int32_t* __restrict__ items_stream,
-                                                             unsigned int* __restrict__ n_stream_out, unsigned int* __restrict__ host_tile_flag) {
+                                                             unsigned int* __restrict__ n_stream_out, unsigned int* __restrict__ host_tile_flag, uint32_t mean_len) {
     __shared__ uint32_t hist[2 * kPlanBuckets];
     __shared__ uint32_t base[2 * kPlanBuckets];
     __shared__ uint32_t wsum[2][kPlanThreads / 64];
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             if (i < hi) {
                 const bool stream = stream_max != 0u && L[u] <= stream_max;
                 const uint32_t w = stream ? 1u : plan_parts(L[u], split);
-                atomicAdd(&hist[stream ? kPlanBuckets + stream_bucket(L[u], (uint32_t)i, (uint32_t)n) : plan_bucket(L[u], w)], w);
+                atomicAdd(&hist[stream ? kPlanBuckets + stream_bucket(L[u], (uint32_t)i, (uint32_t)n, mean_len) : plan_bucket(L[u], w)], w);
             }
         }
     }
@@ -309,6 +329,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             uint32_t before = incl[c] - v[c];
             for (int w = 0; w < (t >> 6); w++) before += wsum[c][w];
             atomicExch(&st->cursor[c * kPlanBuckets + t], before);
+            if (c == 1 && (t % (int)kSliceBuckets) == 0) st->slices[t / (int)kSliceBuckets] = before;
+            if (c == 1 && t == kPlanThreads - 1) st->slices[kStreamSlices] = before + v[c];
             if (t == kPlanThreads - 1) {
                 if (c == 0) {
                     *n_items_out = before + v[c];
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_items(const mm_read_t* __
             const int i = i0 + kPlanThreads * u + t;
             if (i < hi) {
                 const bool stream = stream_max != 0u && L[u] <= stream_max;
-                const uint32_t w = stream ? 1u : plan_parts(L[u], split), b = stream ? kPlanBuckets + stream_bucket(L[u], (uint32_t)i, (uint32_t)n) : plan_bucket(L[u], w);
+                const uint32_t w = stream ? 1u : plan_parts(L[u], split), b = stream ? kPlanBuckets + stream_bucket(L[u], (uint32_t)i, (uint32_t)n, mean_len) : plan_bucket(L[u], w);
                 const uint32_t at = base[b] + atomicAdd(&hist[b], w);
                 if (stream) items_stream[at] = (int32_t)i;
                 else for (uint32_t j = 0; j < w; j++) items[at + j] = (int32_t)((uint32_t)i | (j << 24) | ((w - 1u) << 28));

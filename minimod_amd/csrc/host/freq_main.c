@@ -452,7 +452,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fo.view = view;
     /* process_db is called per -K batch (src/minimod.c:344-350); the library stages consecutive batches in GPU memory and
      * launches them together.  view prints a batch's rows when the batch is retired, so its batches stay their own launches. */
-    fo.coalesce = view ? 0 : (o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather);
+    fo.coalesce = view ? 1 : (o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather);
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     tl_mark(realtime0, "mm_freq_create done");
@@ -465,7 +465,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (replay) {
         mm_freq_opts_t fv = fo;
         fv.view = 2;
-        fv.coalesce = 0;   /* its rows are fetched batch by batch */
+        fv.coalesce = 1;   /* its rows are fetched batch by batch */
         hv = mm_freq_create(&fv, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
         tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
         if (!hv || !tie) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }

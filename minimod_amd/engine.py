@@ -10,7 +10,7 @@ import numpy as np
 
 from .build import build_hip, lib_path
 
-MM_ABI_VERSION = 4
+MM_ABI_VERSION = 5
 MM_MAX_MODS = 13
 MM_CODE_LEN = 16
 
@@ -47,7 +47,7 @@ class mm_freq_opts_t(ctypes.Structure):
                 ("side_capacity", ctypes.c_int64), ("n_wild_planes", ctypes.c_int32), ("view", ctypes.c_int32),
                 ("force_fused", ctypes.c_int32), ("view_cap", ctypes.c_int32), ("finalize_by_runs", ctypes.c_int32),
                 ("split_bases", ctypes.c_int32), ("coalesce", ctypes.c_int32), ("stream_mode", ctypes.c_int32),
-                ("gather_mb", ctypes.c_int32), ("mods", mm_mod_t * MM_MAX_MODS)]
+                ("gather_mb", ctypes.c_int32), ("stream_slices", ctypes.c_int32), ("rsvd_opts", ctypes.c_int32), ("mods", mm_mod_t * MM_MAX_MODS)]
 
 
 class mm_contig_t(ctypes.Structure):
@@ -222,7 +222,7 @@ class FreqEngine(object):
 
     def __init__(self, mods, contigs, insertions=False, haplotypes=False, device=0, intervals=None,
                  n_hp_planes=0, side_capacity=0, n_wild_planes=0, view=False, force_fused=False, view_cap=0,
-                 finalize_by_runs=False, split_bases=0, coalesce=0, stream_mode=0, gather_mb=0):
+                 finalize_by_runs=False, split_bases=0, coalesce=1, stream_mode=0, gather_mb=0, stream_slices=0):
         L = load_library()
         if not (1 <= len(mods) <= MM_MAX_MODS):
             raise MinimodHipError(36, "1..%d modification codes supported" % MM_MAX_MODS)
@@ -232,7 +232,8 @@ class FreqEngine(object):
         o.n_hp_planes, o.side_capacity, o.n_wild_planes = int(n_hp_planes), int(side_capacity), int(n_wild_planes)
         o.view = int(view)
         o.force_fused, o.view_cap, o.finalize_by_runs = int(force_fused), int(view_cap), int(finalize_by_runs)
-        o.split_bases, o.coalesce, o.gather_mb = int(split_bases), int(coalesce), int(gather_mb)
+        o.split_bases, o.coalesce, o.gather_mb = int(split_bases), int(coalesce), int(gather_mb)   # (coalesce: 1 = every submit its own launch, this class's default; 0 = the library's 32)
+        o.stream_slices = int(stream_slices)
         o.stream_mode = int(stream_mode)   # 0 by launch size, 1 never, 2 always (reads up to split_bases), 3 always + '.' groups from the first launch
         for i, (code, ctx, th) in enumerate(mods):
             o.mods[i].code = code.encode()

@@ -33,7 +33,7 @@ for kw_name, kw in (("plain", {}), ("ins_hap", dict(insertions=True, haplotypes=
     orc = O.Oracle(mods, th, ["chrS"], **kw); orc.add_contig("chrS", ref)
     for b in bs: orc.process(b, threads=8)
     want = orc.rows()
-    for name, coalesce, mb in (("off", 0, 0), ("groups_of_3", 3, 0), ("one_group", 16, 0), ("small_staging", 16, 8)):
+    for name, coalesce, mb in (("off", 1, 0), ("groups_of_3", 3, 0), ("one_group", 16, 0), ("small_staging", 16, 8)):
         eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(mods, th)], [("chrS", len(ref), ref)], coalesce=coalesce, gather_mb=mb, stream_mode=STREAM_MODE, **kw)
         tickets = []
         for b in bs:

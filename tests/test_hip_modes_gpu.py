@@ -272,7 +272,7 @@ for b in bs: orc.process(b, threads=8)
 want = orc.rows()
 key = lambda r, io: list(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
 out = {}
-for name, coalesce, order in (("off", 0, range(7)), ("groups_of_3", 3, range(7)), ("one_group", 16, range(7)), ("broken_runs", 4, [0, 1, 3, 4, 5, 2, 6])):
+for name, coalesce, order in (("off", 1, range(7)), ("groups_of_3", 3, range(7)), ("one_group", 16, range(7)), ("broken_runs", 4, [0, 1, 3, 4, 5, 2, 6])):
     eng = minimod_amd.FreqEngine([("m", "CG", 0.8), ("h", "CG", 0.7)], [("chrS", len(ref), ref)], coalesce=coalesce, stream_mode=STREAM_MODE)
     tickets = [eng.submit_device(window(i)) for i in order]
     sizes = {}
