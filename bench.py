@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5", "DOT"], help="BASELINE.json workload: C2 = the headline (default); DOT (not a BASELINE config): C2's reads "
                                                                                      "with the MM '.' flag (every unlisted C an implicit call)")
     ap.add_argument("--stream-slices", type=int, default=0, help="mm_freq_opts_t.stream_slices: 0 one position slice of a launch per XCD (default), 1 costliest first over the whole launch")
+    ap.add_argument("--no-config-fracs", action="store_true", help="skip the short runs of the other BASELINE workloads (C3, C5, view) whose roofline fractions the default line carries as `config_fracs`")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg and its CPU counterpart")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of the end-to-end runs (0 = all host cores, at most 128)")
     ap.add_argument("--cpu-t1-batches", type=int, default=2, help="batches in the BAM the `-t 1` CPU run reads")
@@ -595,6 +596,22 @@ def main():
     n_batches = len(host_batches)
     t_gen = time.time() - t0
 
+    # ---- the other BASELINE workloads' roofline fractions: each a child process of its own (this same script, no CPU legs), started
+    # before this process has touched the GPU
+    config_fracs = None
+    if world == 1 and args.mode == "freq" and args.config == "C2" and not args.no_extra and not args.no_config_fracs and torch.cuda.device_count() > 0:
+        config_fracs = {}
+        for name, extra, st in (("C3", ["--config", "C3"], 20), ("C5", ["--config", "C5"], 17), ("view", ["--mode", "view"], 20)):
+            t_c = time.time()
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + ["--steps", str(st), "--warmup", "5", "--reps", "3", "--no-e2e", "--no-cpu-baseline", "--no-extra"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                rf = d["roofline"]
+                config_fracs[name] = {"frac": rf["frac"], "achieved": rf["achieved"], "traffic": rf.get("traffic"), "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                                      "kernel_ms_per_batch": rf.get("kernel_ms_per_batch"), "steps": st, "workload": d["config"]["workload"], "wall_s": time.time() - t_c}
+            except Exception as e:   # (a leg that fails leaves its reason, never a number)
+                config_fracs[name] = {"frac": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     # ---- the end-to-end leg runs in child processes, before this process has touched the GPU
     e2e = cpu_e2e = None
     if world == 1 and args.mode == "freq" and not args.no_e2e:
@@ -794,22 +811,7 @@ def main():
         achieved = abytes / (float(np.sum(kms)) * 1e-3) / 1e9
         # HBM traffic per batch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) of this same command, which cannot
         # run inside it: the figure is read from the committed profile and labelled as such
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config.lower())
-        if os.path.exists(tpath):
-            try:
-                from minimod_amd.build import source_hash
-                tj = json.load(open(tpath))
-                if tj.get("source_hash") == source_hash():
-                    traffic = tj.get("hbm_bytes_per_batch") * args.steps / len(kms)   # per launch, like `achieved`
-                    traffic_src = ("profiles/%s: bytes per batch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (not measured "
-                                   "in this run; made from these very kernel sources: source_hash %s), times this run's batches per launch"
-                                   % (os.path.basename(tpath), tj.get("source_hash")))
-                else:
-                    traffic_src = ("profiles/%s was measured on other kernel sources (its source_hash %s, now %s): no traffic figure"
-                                   % (os.path.basename(tpath), tj.get("source_hash"), source_hash()))
-            except Exception:
-                traffic = None
+        traffic, traffic_src = committed_traffic(args.config.lower(), args.steps / len(kms))   # per launch, like `achieved`
         reads_all = np.concatenate([hb["reads"]["l_qseq"] for hb in host_batches])
         result = {
             "metric": "minimod freq Mbases/sec", "value": total_bases / elapsed / 1e6, "unit": "Mbases/s",
@@ -861,6 +863,8 @@ def main():
             result.update(legs)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, refs)
+        if config_fracs:
+            result["config_fracs"] = config_fracs
         if e2e:
             result["end_to_end"] = e2e
             result["cpu_baseline_e2e"] = cpu_e2e
@@ -881,6 +885,25 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def committed_traffic(name, batches_per_unit):
+    """HBM bytes per `batches_per_unit` batches from profiles/traffic_<name>.json -- rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) of this
+    same command, which cannot run inside it (tools/traffic.sh) -- or None when the file was measured on other kernel sources."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        from minimod_amd.build import source_hash
+        tj = json.load(open(tpath))
+        if tj.get("source_hash") == source_hash():
+            return (tj.get("hbm_bytes_per_batch") * batches_per_unit,
+                    "profiles/%s: bytes per batch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (not measured in this run; made from "
+                    "these very kernel sources: source_hash %s), times this run's batches per launch" % (os.path.basename(tpath), tj.get("source_hash")))
+        return None, ("profiles/%s was measured on other kernel sources (its source_hash %s, now %s): no traffic figure"
+                      % (os.path.basename(tpath), tj.get("source_hash"), source_hash()))
+    except Exception:
+        return None, None
 
 
 def extra_legs(args, wl, contig, plan, host_batches, dev_batches, batch_bases, alg_bytes, stream, local_rank):
@@ -1016,6 +1039,7 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
     if rank == 0:
         mean_ms = float(np.mean(kms))
         step_ms = elapsed / args.steps * 1e3
+        v_traffic, v_traffic_src = committed_traffic("view", 1.0)   # per step, like this line's `achieved`
         result = {
             "metric": "minimod view Mbases/sec", "value": total_bases / elapsed / 1e6, "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
@@ -1024,7 +1048,7 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
                                    "ordered rows left in HBM" % (args.reads, args.batch),
                        "rows_per_step": rows / args.steps, "sharding": "interval per GPU, no exchange" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": (abytes / args.steps) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (abytes / args.steps) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": (abytes / args.steps) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": v_traffic, "traffic_source": v_traffic_src,
                          "kernel": "whole step = k_scan_reads + k_sum_tiles + k_call_tiles<view> + k_view_offsets + k_view_scatter + "
                                    "k_view_sort + k_view_sort_big, wall clock per step; HIP events around the same launches: kernel_ms_mean",
                          "kernel_ms_mean": mean_ms, "algorithmic_bytes_per_launch": abytes / args.steps},

@@ -244,6 +244,9 @@ typedef struct {
     const mm_batch_t *batch;
     const mmh_loader_t *ld;
     int pool_set;
+    const mm_read_t *reads;          /* mmh_print_view_rows_of: the launch's read records and names (batch / ld not used then) */
+    const uint64_t *name_off;
+    const char *names;
     const mm_bam_hdr_t *hdr;
     const char *const *codes;
     int n_codes, insertions, haplotypes;
@@ -259,8 +262,8 @@ static void view_piece(const void *vctx, int64_t lo, int64_t hi, mbuf_t *out) {
         const mm_view_row_t *r = &c->rows[i];
         if (r->read != last_read) {
             last_read = r->read;
-            rd = &c->batch->reads[r->read];
-            qname = mmh_loader_qname(c->ld, c->pool_set, (int32_t)r->read);
+            rd = c->reads ? &c->reads[r->read] : &c->batch->reads[r->read];
+            qname = c->reads ? c->names + c->name_off[r->read] : mmh_loader_qname(c->ld, c->pool_set, (int32_t)r->read);
             qlen = strlen(qname);
             contig = (rd->tid >= 0 && rd->tid < c->hdr->n_targets) ? c->hdr->target_name[rd->tid] : "*";
             clen = strlen(contig);
@@ -286,6 +289,14 @@ static void view_piece(const void *vctx, int64_t lo, int64_t hi, mbuf_t *out) {
 void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, const mmh_loader_t *ld, int pool_set,
                          const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes) {
     pthread_once(&view_once, view_init);
-    view_ctx_t c = {rows, batch, ld, pool_set, hdr, codes, n_codes, insertions, haplotypes};
+    view_ctx_t c = {rows, batch, ld, pool_set, NULL, NULL, NULL, hdr, codes, n_codes, insertions, haplotypes};
+    emit_rows(fp, pool, n, view_piece, &c);
+}
+/* the same for the rows of a gathered launch: `reads` are the records of every batch that went into it, one behind the other (a row
+ * names its read by its index in the launch), names[name_off[i]] read i's name */
+void mmh_print_view_rows_of(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_read_t *reads, const uint64_t *name_off, const char *names,
+                            const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes) {
+    pthread_once(&view_once, view_init);
+    view_ctx_t c = {rows, NULL, NULL, 0, reads, name_off, names, hdr, codes, n_codes, insertions, haplotypes};
     emit_rows(fp, pool, n, view_piece, &c);
 }

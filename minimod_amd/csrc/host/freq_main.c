@@ -66,6 +66,7 @@ static struct option view_long_options[] = {
     {"devices", required_argument, 0, 0},
     {"gpu-inflate", no_argument, 0, 0},
     {"no-gpu-inflate", no_argument, 0, 0},
+    {"gather", required_argument, 0, 0},
     {0, 0, 0, 0}};
 
 typedef struct {
@@ -124,8 +125,8 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "   --device INT               GPU to use [%d]\n", o->device);
     if (!o->view) fprintf(fp, "   --canonical-order          rows of one (contig, start) by strand, code, ins_offset, haplotype instead of the order\n"
                               "                              minimod's hash table leaves them in (skips the replay of that table) [%s]\n", o->canonical_order ? "yes" : "no");
-    if (!o->view) fprintf(fp, "   --gather INT               -K batches that may share one kernel launch (they are staged in GPU memory one behind the\n"
-                              "                              other and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
+    fprintf(fp, "   --gather INT               -K batches that may share one kernel launch at most (they are staged in GPU memory one behind the\n"
+                "                              other, 1 GiB of them, and processed together; 1: every batch is its own launch) [%d]\n", o->gather);
     fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
                 "   --no-gpu-inflate           -t host threads; blocks the device refuses are the host decoder's) [%s]\n",
             o->gpu_inflate < 0 ? "for a BAM file of 4 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
@@ -235,34 +236,11 @@ static void intern_batch_codes(mm_freq_t *h, const mm_batch_t *b) {
     }
 }
 
-/* merge_db's place in the pipeline: wait for the batch; freq has nothing to merge, view prints the batch's rows
- * (print_view_output, src/mod.c:560-626).  `pool_set` is the loader pool set the batch was read into. */
 static int code_names(mm_freq_t *h, const char **codes) {
     int n = mm_freq_n_codes(h);
     if (n > MM_MAX_CODES) n = MM_MAX_CODES;
     for (int i = 0; i < n; i++) codes[i] = mm_freq_code_name(h, i);
     return n;
-}
-
-static void retire_batch(mm_freq_t *h, int32_t ticket, const mm_batch_t *b, const mmh_loader_t *ld, int pool_set, const mm_bam_hdr_t *hdr, const fopt_t *o,
-                         mm_pool_t *pool, double *wait_time, double *output_time) {
-    double tw = mmh_realtime();
-    int32_t bad = -1;
-    if (!o->view) {
-        int e = mm_freq_wait(h, ticket, &bad);
-        *wait_time += mmh_realtime() - tw;
-        if (e) die_read_error(e, bad, b, hdr);
-        return;
-    }
-    const mm_view_row_t *rows = NULL;
-    int64_t n = mm_view_fetch(h, ticket, &rows, &bad);
-    *wait_time += mmh_realtime() - tw;
-    if (n < 0) die_read_error((int)-n, bad, b, hdr);
-    double to = mmh_realtime();
-    const char *codes[MM_MAX_CODES];
-    int n_codes = code_names(h, codes);
-    mmh_print_view_rows(o->out, pool, rows, n, b, ld, pool_set, hdr, codes, n_codes, o->insertions, o->haplotypes);
-    *output_time += mmh_realtime() - to;
 }
 
 static int write_all(int fd, const void *buf, size_t n) {
@@ -286,8 +264,43 @@ static int read_all(int fd, void *buf, size_t n) {
 }
 
 /* freq: the -K batches that share a ticket (mm_freq_submit gathers up to opts.coalesce of them into one launch) */
-#define MMH_MAX_GATHER 256
-typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; } group_t;
+#define MMH_MAX_GATHER 2048
+/* view (and the replay handle of a tied freq run): what the rows of a gathered launch are printed from -- the read records and the
+ * read names of every batch that went into it, one behind the other (a row names its read by its index in the launch) */
+typedef struct { mm_read_t *reads; size_t n, cap; char *names; size_t names_len, names_cap; uint64_t *name_off; size_t off_cap; } journal_t;
+typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; journal_t j; } group_t;
+static void journal_reset(journal_t *j) { j->n = 0; j->names_len = 0; }
+static void journal_free(journal_t *j) { free(j->reads); free(j->names); free(j->name_off); memset(j, 0, sizeof *j); }
+static int journal_add(journal_t *j, const mm_batch_t *b, const mmh_loader_t *ld, int pool_set) {
+    const size_t n = (size_t)b->n_reads;
+    if (j->n + n > j->cap) {
+        size_t nc = j->cap ? j->cap : 8192;
+        while (nc < j->n + n) nc *= 2;
+        mm_read_t *r = (mm_read_t *)realloc(j->reads, nc * sizeof(mm_read_t));
+        uint64_t *o = (uint64_t *)realloc(j->name_off, nc * sizeof(uint64_t));
+        if (r) j->reads = r;
+        if (o) j->name_off = o;
+        if (!r || !o) return -1;
+        j->cap = nc;
+    }
+    memcpy(j->reads + j->n, b->reads, n * sizeof(mm_read_t));
+    for (size_t i = 0; i < n; i++) {
+        const char *q = mmh_loader_qname(ld, pool_set, (int32_t)i);
+        const size_t l = strlen(q) + 1;
+        if (j->names_len + l > j->names_cap) {
+            size_t nc = j->names_cap ? j->names_cap * 2 : ((size_t)1 << 20);
+            while (nc < j->names_len + l) nc *= 2;
+            char *g = (char *)realloc(j->names, nc);
+            if (!g) return -1;
+            j->names = g; j->names_cap = nc;
+        }
+        memcpy(j->names + j->names_len, q, l);
+        j->name_off[j->n + i] = j->names_len;
+        j->names_len += l;
+    }
+    j->n += n;
+    return 0;
+}
 
 /* wait for a group's launch; a failing read is named by its index in its own -K batch, like the reference does */
 static void retire_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr, double *wait_time) {
@@ -304,6 +317,28 @@ static void retire_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr, doub
         die_read_record(e, in_batch, have ? &rec : NULL, hdr);
     }
     g->ticket = -1; g->n = 0;
+}
+
+/* view: wait for a group's launch, order its rows on the device, print them (print_view_output per db_t, src/mod.c:560-626: the
+ * batches' rows one after the other are the launch's rows in read order) */
+static void retire_view_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr, const fopt_t *o, mm_pool_t *pool, double *wait_time, double *output_time) {
+    if (g->ticket < 0) return;
+    double tw = mmh_realtime();
+    int32_t bad = -1;
+    const mm_view_row_t *rows = NULL;
+    int64_t n = mm_view_fetch(h, g->ticket, &rows, &bad);
+    *wait_time += mmh_realtime() - tw;
+    if (n < 0) {
+        int32_t in_batch = bad;
+        for (int m = 0; m < g->n && in_batch >= g->n_reads[m]; m++) in_batch -= g->n_reads[m];
+        die_read_record((int)-n, in_batch, (bad >= 0 && (size_t)bad < g->j.n) ? &g->j.reads[bad] : NULL, hdr);
+    }
+    double to = mmh_realtime();
+    const char *codes[MM_MAX_CODES];
+    int n_codes = code_names(h, codes);
+    mmh_print_view_rows_of(o->out, pool, rows, n, g->j.reads, g->j.name_off, g->j.names, hdr, codes, n_codes, o->insertions, o->haplotypes);
+    *output_time += mmh_realtime() - to;
+    g->ticket = -1; g->n = 0; journal_reset(&g->j);
 }
 
 /* a replay run's second handle: the batch's calls (view rows with group ordinals) go into the tie-order replay */
@@ -451,8 +486,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mmh_fill_opts(&mods, o.insertions, o.haplotypes, o.device, &fo);
     fo.view = view;
     /* process_db is called per -K batch (src/minimod.c:344-350); the library stages consecutive batches in GPU memory and
-     * launches them together.  view prints a batch's rows when the batch is retired, so its batches stay their own launches. */
-    fo.coalesce = view ? 1 : (o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather);
+     * launches them together.  view prints a launch's rows when the launch is retired. */
+    fo.coalesce = o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather;   /* (view as well since round 4: a launch's rows are printed from the group's journal) */
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     tl_mark(realtime0, "mm_freq_create done");
@@ -501,7 +536,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!use_dev) pool = mm_bam_pool(ld->bam);
     double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0, submit_time = 0;
     int more = 1, counter = 0, set = 0;
-    int32_t pending_ticket = -1, pending_vticket = -1;
+    int32_t pending_vticket = -1;
     const uint8_t *klass_of_code[MM_MAX_CODES];
     for (int i = 0; i < MM_MAX_CODES; i++) {   /* a wildcard run counts every code under the one `*` entry */
         int req = i < mods.n_mods ? i : 0;
@@ -599,10 +634,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bases) loaded\n", __func__, mmh_realtime() - realtime0,
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
-        if (view && pending_ticket >= 0) {
-            retire_batch(h, pending_ticket, &pending_batch, ld, (set + MMH_POOL_SETS - 1) % MMH_POOL_SETS, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
-            pending_ticket = -1;
-        }
+        if (view) retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time);
         if (replay && pending_vticket >= 0) {
             replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
             pending_vticket = -1;
@@ -615,14 +647,15 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             submit_time += mmh_realtime() - t_sub;
             if (tk < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(tk)); exit(EXIT_FAILURE); }
             pending_batch = batch;
-            if (view) pending_ticket = tk;
-            else {
+            {
                 if (tk != cur->ticket) {   /* a new group: the one before it has been launched */
-                    retire_group(h, prev, hdr, &process_wait_time);
+                    if (view) retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time);
+                    else retire_group(h, prev, hdr, &process_wait_time);
                     group_t *t = prev; prev = cur; cur = t;
-                    cur->ticket = tk; cur->n = 0;
+                    cur->ticket = tk; cur->n = 0; journal_reset(&cur->j);
                 }
                 if (cur->n < MMH_MAX_GATHER) cur->n_reads[cur->n++] = n;
+                if (view && journal_add(&cur->j, &batch, ld, set) != 0) { MMH_ERROR("%s", "Out of memory"); exit(EXIT_FAILURE); }
                 copied[set] = tk;
             }
             if (replay) {
@@ -645,10 +678,10 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (o.debug_break == counter) break;
         counter++;
     }
-    if (view && pending_ticket >= 0)
-        retire_batch(h, pending_ticket, &pending_batch, ld, (set + MMH_POOL_SETS - 1) % MMH_POOL_SETS, hdr, &o, mm_bam_pool(ld->bam), &process_wait_time, &output_time);
+    if (view) { retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time); retire_view_group(h, cur, hdr, &o, pool, &process_wait_time, &output_time); }
     if (replay && pending_vticket >= 0) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
+    journal_free(&cur->j); journal_free(&prev->j);
     free(cur); free(prev);
     struct { uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases; } T;
     if (use_dev) {
@@ -1164,7 +1197,7 @@ static int run_main(int argc, char **argv, int view) {
     fopt_t o;
     memset(&o, 0, sizeof(o));
     o.K = 512; o.B = 20 * 1000 * 1000; o.threads = 8; o.debug_break = -1; o.out = stdout;   /* init_opt, src/minimod.c:485-513 */
-    o.view = view; o.gather = 32; o.gpu_inflate = -1; o.gpu_ingest = -1;
+    o.view = view; o.gather = MMH_MAX_GATHER; o.gpu_inflate = -1; o.gpu_ingest = -1;   /* (--gather: as many batches as the staging takes -- a launch is sized by its bases, not by -K) */
     while ((c = getopt_long(argc, argv, optstring, lopts, &longindex)) >= 0) {
         const char *lname = c == 0 ? lopts[longindex].name : "";
         if (c == 'B') {

@@ -128,6 +128,8 @@ void mmh_print_freq_rows(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_
 void mmh_print_view_header(FILE *fp, int insertions, int haplotypes);
 void mmh_print_view_rows(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_batch_t *batch, const mmh_loader_t *ld, int pool_set,
                          const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes);
+void mmh_print_view_rows_of(FILE *fp, mm_pool_t *pool, const mm_view_row_t *rows, int64_t n, const mm_read_t *reads, const uint64_t *name_off, const char *names,
+                            const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes, int insertions, int haplotypes);   /* ... of a gathered launch */
 int mmh_emit_flush(void);
 int mmh_emit_finish(void);   /* flush, then stop the writer thread and free the recycled buffers */
 

@@ -164,7 +164,8 @@ def test_cli_batches_reach_the_streaming_kernel(tmp_path):
     m = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with k_stream_reads\)", err)
     assert m, err[-1500:]
     launches, batches, streamed = (int(x) for x in m.groups())
-    assert batches >= 19 and launches <= (batches + 31) // 32 + 1 and streamed >= 1, (launches, batches, streamed)
+    # -K 512 does not make the launches small: the batches are gathered by what the staging takes (1 GiB), and every launch streams
+    assert batches >= 19 and launches == 1 and streamed == launches, (launches, batches, streamed)
     orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
     orc.add_contig("chrS", ref)
     for b in bs:
@@ -175,6 +176,14 @@ def test_cli_batches_reach_the_streaming_kernel(tmp_path):
     assert r1.returncode == 0 and r1.stdout == r.stdout
     m1 = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with", r1.stderr.decode())
     assert m1 and int(m1.group(1)) == int(m1.group(2))
+    # `minimod view` gathers as well (round 4): its launches stream, its rows are those of one launch per batch
+    vcmd = [BIN, "view", "-c", "m[CG]", "-t", "8", "-B", "100M"]
+    v = subprocess.run(vcmd + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert v.returncode == 0, v.stderr.decode()[-2000:]
+    mv = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with k_stream_reads\)", v.stderr.decode())
+    assert mv and int(mv.group(1)) <= 2 and int(mv.group(3)) == int(mv.group(1)), v.stderr.decode()[-800:]
+    v1 = subprocess.run(vcmd + ["--gather", "1", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert v1.returncode == 0 and v1.stdout == v.stdout and len(v.stdout) > 1000000
 
 
 def test_cli_names_a_failing_read_of_a_gathered_group(tmp_path):

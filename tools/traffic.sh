@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $out/pmc_${name}_$c
 done
 alg=$(python3 -c "
-import json; d=json.loads(open('$out/bench_$name.json').read().strip().splitlines()[-1]); print(d['roofline']['algorithmic_bytes_per_launch'] / d['roofline']['batches_per_launch'])")
+import json; d=json.loads(open('$out/bench_$name.json').read().strip().splitlines()[-1]); r=d['roofline']; print(r['algorithmic_bytes_per_launch'] / r.get('batches_per_launch', 1.0))")
 python3 $root/tools/pmc_traffic.py $out/${name}_pmc_FETCH_SIZE.csv $out/${name}_pmc_WRITE_SIZE.csv $steps $alg "$name: bench.py $*" > $out/traffic_$name.json 2> $out/traffic_$name.err
 python3 -c "
 import json; d=json.load(open('$out/traffic_$name.json')); print('$name', 'bytes/batch %.1f MB' % (d['hbm_bytes_per_batch']/1e6), 'algorithmic %.1f MB' % (d['algorithmic_bytes_per_batch']/1e6), 'ratio %.2f' % d['ratio'])"
