@@ -525,9 +525,10 @@ def run_e2e_big(args):
         if tied:
             w_rp, err_rp = run([cli, "freq"] + common, os.path.join(tmp, "gpu_replay.bed"))
             mr = re.search(r"Row order replay[^:]*: ([0-9.]+) sec", err_rp)
+            mrf = re.search(r"Row order replay[^:]*: [0-9.]+ sec \(([0-9.]+) of them waiting", err_rp)
             mp = re.search(r"Peak RAM: ([0-9.]+) GB", err_rp)
             mp0 = re.search(r"Peak RAM: ([0-9.]+) GB", err)
-            res["reference_order_replay"] = {"wall_s": w_rp, "value": bases / w_rp / 1e6, "replay_s": float(mr.group(1)) if mr else None,
+            res["reference_order_replay"] = {"wall_s": w_rp, "value": bases / w_rp / 1e6, "replay_s": float(mr.group(1)) if mr else None, "replay_waiting_for_gpu_s": float(mrf.group(1)) if mrf else None, "stages_s": _stage_timers(err_rp),
                                              "peak_ram_gb": float(mp.group(1)) if mp else None, "peak_ram_gb_canonical": float(mp0.group(1)) if mp0 else None,
                                              "same_rows_as_canonical": sorted(open(os.path.join(tmp, "gpu_replay.bed"), "rb").read().splitlines()) == sorted(open(og, "rb").read().splitlines())
                                              if os.path.getsize(og) < (1 << 30) else None,

@@ -1259,7 +1259,7 @@ static int32_t submit_host_gathered(mm_freq* h, const mm_batch_t* hb) {
         const bool fits = h->pending_host && !h->codes_dirty && h->pending_members < h->opts.coalesce &&
                           sizeof(mm_read_t) * (s.fill_reads + (size_t)hb->n_reads) <= s.cap_reads && 4 * (s.fill_cigar + hb->n_cigar_words) <= s.cap_cigar &&
                           s.fill_seq + hb->n_seq_bytes <= s.cap_seq && s.fill_mm + hb->n_mm_bytes <= s.cap_mm && s.fill_ml + hb->n_ml_bytes <= s.cap_ml &&
-                          s.fill_mm + hb->n_mm_bytes < 0xFFFFF000ull && s.fill_reads + (size_t)hb->n_reads < ((size_t)1 << 24);
+                          s.fill_mm + hb->n_mm_bytes < 0xFFFFF000ull && s.fill_reads + (size_t)hb->n_reads < ((size_t)1 << (h->opts.view == 2 ? 21 : 24));   // (view == 2: the rows number a launch's reads with 21 bits)
         if (!fits) { int r = flush_pending(h); if (r) return r; }
     }
     if (h->pending_slot < 0) {

@@ -186,9 +186,6 @@ static void close_loaders(mmh_loader_t *ld, mmh_devloader_t *dl, mm_pool_t *own_
 
 /* the reference's message for a per-read device status (src/mod.c line in brackets), then exit(1) like it does */
 static void die_read_record(int code, int32_t read, const mm_read_t *rd, const mm_bam_hdr_t *hdr);
-static void die_read_error(int code, int32_t read, const mm_batch_t *b, const mm_bam_hdr_t *hdr) {
-    die_read_record(code, read, (read >= 0 && read < b->n_reads) ? &b->reads[read] : NULL, hdr);
-}
 /* `read`: the read's index in its -K batch (what the reference prints); rd: its record, or NULL */
 static void die_read_record(int code, int32_t read, const mm_read_t *rd, const mm_bam_hdr_t *hdr) {
     (void)mmh_emit_flush();   /* rows of earlier batches reach the output as they did with stdio */
@@ -267,10 +264,35 @@ static int read_all(int fd, void *buf, size_t n) {
 #define MMH_MAX_GATHER 2048
 /* view (and the replay handle of a tied freq run): what the rows of a gathered launch are printed from -- the read records and the
  * read names of every batch that went into it, one behind the other (a row names its read by its index in the launch) */
-typedef struct { mm_read_t *reads; size_t n, cap; char *names; size_t names_len, names_cap; uint64_t *name_off; size_t off_cap; } journal_t;
+typedef struct { mm_read_t *reads; size_t n, cap; char *names; size_t names_len, names_cap; uint64_t *name_off; size_t off_cap;
+                 uint8_t *mm; size_t mm_len, mm_cap; } journal_t;   /* (mm: the replay's journal keeps the MM text instead of the names) */
 typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; journal_t j; } group_t;
-static void journal_reset(journal_t *j) { j->n = 0; j->names_len = 0; }
-static void journal_free(journal_t *j) { free(j->reads); free(j->names); free(j->name_off); memset(j, 0, sizeof *j); }
+static void journal_reset(journal_t *j) { j->n = 0; j->names_len = 0; j->mm_len = 0; }
+static void journal_free(journal_t *j) { free(j->reads); free(j->names); free(j->name_off); free(j->mm); memset(j, 0, sizeof *j); }
+/* the replay's journal: read records with their MM text (tieorder.c looks at a read's group headers), offsets moved behind the text so far */
+static int journal_add_mm(journal_t *j, const mm_batch_t *b) {
+    const size_t n = (size_t)b->n_reads;
+    if (j->n + n > j->cap) {
+        size_t nc = j->cap ? j->cap : 8192;
+        while (nc < j->n + n) nc *= 2;
+        mm_read_t *r = (mm_read_t *)realloc(j->reads, nc * sizeof(mm_read_t));
+        if (!r) return -1;
+        j->reads = r; j->cap = nc;
+    }
+    if (j->mm_len + b->n_mm_bytes > j->mm_cap) {
+        size_t nc = j->mm_cap ? j->mm_cap : ((size_t)1 << 22);
+        while (nc < j->mm_len + b->n_mm_bytes) nc *= 2;
+        uint8_t *g = (uint8_t *)realloc(j->mm, nc);
+        if (!g) return -1;
+        j->mm = g; j->mm_cap = nc;
+    }
+    memcpy(j->mm + j->mm_len, b->mm, b->n_mm_bytes);
+    memcpy(j->reads + j->n, b->reads, n * sizeof(mm_read_t));
+    for (size_t i = 0; i < n; i++) j->reads[j->n + i].mm_off += j->mm_len;
+    j->mm_len += b->n_mm_bytes;
+    j->n += n;
+    return 0;
+}
 static int journal_add(journal_t *j, const mm_batch_t *b, const mmh_loader_t *ld, int pool_set) {
     const size_t n = (size_t)b->n_reads;
     if (j->n + n > j->cap) {
@@ -341,18 +363,30 @@ static void retire_view_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr,
     g->ticket = -1; g->n = 0; journal_reset(&g->j);
 }
 
-/* a replay run's second handle: the batch's calls (view rows with group ordinals) go into the tie-order replay */
-static void replay_batch(mm_freq_t *hv, mmh_tie_t *tie, int32_t ticket, const mm_batch_t *b, const mm_bam_hdr_t *hdr, mm_pool_t *pool,
+static double replay_fetch_seconds;   /* of the replay's seconds: waiting for the second handle's launches and their rows */
+/* a replay run's second handle: a launch's calls (view rows with group ordinals) go into the tie-order replay, from the group's
+ * journal (the records and MM text of the batches that went into the launch) */
+static void replay_group(mm_freq_t *hv, mmh_tie_t *tie, group_t *g, const mm_bam_hdr_t *hdr, mm_pool_t *pool,
                          const uint8_t *const *klass_of_code, double *seconds) {
+    if (g->ticket < 0) return;
     double t0 = mmh_realtime();
     int32_t bad = -1;
     const mm_view_row_t *rows = NULL;
-    int64_t n = mm_view_fetch(hv, ticket, &rows, &bad);
-    if (n < 0) die_read_error((int)-n, bad, b, hdr);
+    int64_t n = mm_view_fetch(hv, g->ticket, &rows, &bad);
+    replay_fetch_seconds += mmh_realtime() - t0;
+    if (n < 0) {
+        int32_t in_batch = bad;
+        for (int m = 0; m < g->n && in_batch >= g->n_reads[m]; m++) in_batch -= g->n_reads[m];
+        die_read_record((int)-n, in_batch, (bad >= 0 && (size_t)bad < g->j.n) ? &g->j.reads[bad] : NULL, hdr);
+    }
     const char *codes[MM_MAX_CODES];
     int n_codes = code_names(hv, codes);
-    (void)mmh_tie_add_batch(tie, pool, b, rows, n, klass_of_code, codes, n_codes);   /* a failed replay is reported once, at the end */
+    mm_batch_t jb;
+    memset(&jb, 0, sizeof jb);
+    jb.reads = g->j.reads; jb.mm = g->j.mm; jb.n_reads = (int32_t)g->j.n; jb.n_mm_bytes = g->j.mm_len;
+    (void)mmh_tie_add_batch(tie, pool, &jb, rows, n, klass_of_code, codes, n_codes);   /* a failed replay is reported once, at the end */
     *seconds += mmh_realtime() - t0;
+    g->ticket = -1; g->n = 0; journal_reset(&g->j);
 }
 
 
@@ -500,7 +534,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (replay) {
         mm_freq_opts_t fv = fo;
         fv.view = 2;
-        fv.coalesce = 1;   /* its rows are fetched batch by batch */
+        /* (gathered like the first handle's since round 4: its launches stream, a launch's rows are replayed from the group's journal) */
         hv = mm_freq_create(&fv, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
         tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
         if (!hv || !tie) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
@@ -536,19 +570,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!use_dev) pool = mm_bam_pool(ld->bam);
     double load_time = 0, process_wait_time = 0, output_time = 0, replay_time = 0, submit_time = 0;
     int more = 1, counter = 0, set = 0;
-    int32_t pending_vticket = -1;
     const uint8_t *klass_of_code[MM_MAX_CODES];
     for (int i = 0; i < MM_MAX_CODES; i++) {   /* a wildcard run counts every code under the one `*` entry */
         int req = i < mods.n_mods ? i : 0;
         if (wildcard) for (int m2 = 0; m2 < mods.n_mods; m2++) if (strcmp(mods.code[m2], "*") == 0) req = m2;
         klass_of_code[i] = fo.mods[req].klass;
     }
-    mm_batch_t pending_batch, batch;
-    memset(&pending_batch, 0, sizeof pending_batch);
+    mm_batch_t batch;
     /* freq: `cur` = the group being gathered, `prev` = the one launched last (waited for one iteration later, so that the
      * wait costs nothing); copied[set] = the ticket whose host -> device copy last read from that pool set */
     group_t *cur = (group_t *)calloc(1, sizeof(group_t)), *prev = (group_t *)calloc(1, sizeof(group_t));
-    cur->ticket = prev->ticket = -1;
+    group_t *vcur = (group_t *)calloc(1, sizeof(group_t)), *vprev = (group_t *)calloc(1, sizeof(group_t));   /* the replay handle's groups */
+    cur->ticket = prev->ticket = vcur->ticket = vprev->ticket = -1;
     int32_t copied[MMH_POOL_SETS];
     for (int i = 0; i < MMH_POOL_SETS; i++) copied[i] = -1;
     double prog_t = mmh_realtime();
@@ -635,10 +668,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (view) retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time);
-        if (replay && pending_vticket >= 0) {
-            replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
-            pending_vticket = -1;
-        }
+        if (replay) replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
         if (!view) retire_group(h, prev, hdr, &process_wait_time);
         if (n > 0) {
             if (wildcard) { intern_batch_codes(h, &batch); if (replay) intern_batch_codes(hv, &batch); }
@@ -646,7 +676,6 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             int32_t tk = mm_freq_submit(h, &batch);
             submit_time += mmh_realtime() - t_sub;
             if (tk < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(tk)); exit(EXIT_FAILURE); }
-            pending_batch = batch;
             {
                 if (tk != cur->ticket) {   /* a new group: the one before it has been launched */
                     if (view) retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time);
@@ -659,8 +688,17 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 copied[set] = tk;
             }
             if (replay) {
-                pending_vticket = mm_freq_submit(hv, &batch);
-                if (pending_vticket < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(pending_vticket)); exit(EXIT_FAILURE); }
+                const int32_t vt = mm_freq_submit(hv, &batch);
+                if (vt < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(vt)); exit(EXIT_FAILURE); }
+                if (vt != vcur->ticket) {
+                    replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
+                    group_t *t = vprev; vprev = vcur; vcur = t;
+                    vcur->ticket = vt; vcur->n = 0; journal_reset(&vcur->j);
+                }
+                if (vcur->n < MMH_MAX_GATHER) vcur->n_reads[vcur->n++] = n;
+                if (journal_add_mm(&vcur->j, &batch) != 0) { MMH_ERROR("%s", "Out of memory"); exit(EXIT_FAILURE); }
+                /* (both handles copy out of the same pool set: the one checked below is the first's, whose copies were queued first ... */
+                if (mm_freq_host_done(hv, vt) != 0) { MMH_ERROR("%s", "GPU path failed"); exit(EXIT_FAILURE); }   /* ... so this one is waited for here) */
             }
         }
         if (o.progress_interval <= 0 || mmh_realtime() - prog_t > o.progress_interval) {
@@ -679,10 +717,10 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         counter++;
     }
     if (view) { retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time); retire_view_group(h, cur, hdr, &o, pool, &process_wait_time, &output_time); }
-    if (replay && pending_vticket >= 0) replay_batch(hv, tie, pending_vticket, &pending_batch, hdr, mm_bam_pool(ld->bam), klass_of_code, &replay_time);
+    if (replay) { replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time); replay_group(hv, tie, vcur, hdr, pool, klass_of_code, &replay_time); }
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
-    journal_free(&cur->j); journal_free(&prev->j);
-    free(cur); free(prev);
+    journal_free(&cur->j); journal_free(&prev->j); journal_free(&vcur->j); journal_free(&vprev->j);
+    free(cur); free(prev); free(vcur); free(vprev);
     struct { uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases; } T;
     if (use_dev) {
         const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
@@ -833,7 +871,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         output_time += mmh_realtime() - to;
         free(ordered);
     }
-    if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort): %.3f sec\n", __func__, replay_time);
+    if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort): %.3f sec (%.3f of them waiting for the calls of the second handle's launches)\n", __func__, replay_time, replay_fetch_seconds);
     if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o.out != stdout) fclose(o.out);
     else fflush(stdout);

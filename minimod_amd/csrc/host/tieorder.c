@@ -20,6 +20,7 @@
  * The COUNTS never come from here: they are the GPU's.  This file only decides in which order the GPU's rows are printed.
  * Input per batch: the calls of every read as `minimod view` rows with group ordinal and implicit flag (mm_freq_opts_t.view
  * == 2), from a second handle that sees the same batches. */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -91,6 +92,8 @@ static int ktab_grow(ktab_t *t, uint32_t want, const uint32_t *hash) {
     uint8_t *old = t->used;
     const uint32_t mask = nb - 1;
     for (uint32_t j = 0; j < t->n_buckets; j++) {
+        /* (the walk is in bucket order, its targets are anywhere: the bucket sixteen ahead says where its element will go) */
+        if (j + 16 < t->n_buckets && old[j + 16]) { const uint32_t pf = hash[t->id[j + 16]] & mask; __builtin_prefetch(&nused[pf], 1); __builtin_prefetch(&t->id[pf], 1); }
         if (!old[j]) continue;
         uint32_t key = t->id[j];
         old[j] = 0;
@@ -189,16 +192,30 @@ static int intro_sort(const cmpctx_t *c, size_t n, uint32_t *a) {
 }
 
 /* ---------------------------------------------------------------- the replay */
+/* Round 4: the first-insertion ORDER of the keys is kept as a stamp per key -- (serial number of the read in the file) << 24 | place
+ * of the key among the read's own -- in 256 tables of their own lock each, so that the reads of a batch are replayed AND entered by
+ * the worker pool side by side (a key met again keeps the smaller stamp); the sequence itself is made once, at the end, by a
+ * radix sort on the stamps.  Round 3 entered every key of every read into one table on one thread: 60 M probes for 3 Gbases of
+ * HiFi reads with two codes, 2.2 s of a 2.9 s run. */
+#define TS_SHARDS 256
+typedef struct {
+    pthread_mutex_t mu;
+    tkey_t *keys; uint32_t *hash; uint64_t *stamp; size_t n, cap;
+    uint32_t *slot; size_t slot_cap;   /* open addressing on tkey_mix's low bits; 0xFFFFFFFF = free */
+    char pad[64];
+} tshard_t;
 struct mmh_tie {
     const mm_bam_hdr_t *hdr;
     int insertions, haplotypes;
     int32_t *rank;                 /* contig tid -> rank of its name in strcmp order */
-    /* first-insertion sequence of the core table */
+    tshard_t *shard;               /* [TS_SHARDS] */
+    uint64_t reads_seen;           /* serial number of the next batch's first read */
+    size_t n_keys;                 /* keys in all (atomic) */
+    /* first-insertion sequence of the core table, made from the stamps when somebody asks for it (seq_build) */
     tkey_t *keys; uint32_t *hash; size_t n, cap;
-    /* membership of `keys` (own open addressing on tkey_mix) */
-    uint32_t *set; size_t set_cap;
+    int seq_valid;
     int failed;                    /* memory ran out, or more keys than max_keys */
-    size_t max_keys;               /* the sequence is not kept beyond this many keys (host memory: 20 bytes a key + the sets) */
+    size_t max_keys;               /* the sequence is not kept beyond this many keys (host memory: 28 bytes a key + the tables) */
 };
 
 mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotypes) {
@@ -221,49 +238,90 @@ mmh_tie_t *mmh_tie_create(const mm_bam_hdr_t *hdr, int insertions, int haplotype
     free(idx);
     t->max_keys = (size_t)128 << 20;   /* ~3.5 GB of host memory; MINIMOD_REPLAY_MAX_KEYS sets another bound */
     { const char *e = getenv("MINIMOD_REPLAY_MAX_KEYS"); if (e && atoll(e) > 0) t->max_keys = (size_t)atoll(e); }
-    t->set_cap = (size_t)1 << 16;
-    t->set = (uint32_t *)malloc(sizeof(uint32_t) * t->set_cap);
-    if (!t->set) { t->failed = 1; return t; }
-    memset(t->set, 0xFF, sizeof(uint32_t) * t->set_cap);
+    t->shard = (tshard_t *)calloc(TS_SHARDS, sizeof(tshard_t));
+    if (!t->shard) { t->failed = 1; return t; }
+    for (int i = 0; i < TS_SHARDS; i++) pthread_mutex_init(&t->shard[i].mu, NULL);
     return t;
 }
 
 void mmh_tie_destroy(mmh_tie_t *t) {
     if (!t) return;
-    free(t->rank); free(t->keys); free(t->hash); free(t->set); free(t);
+    if (t->shard) for (int i = 0; i < TS_SHARDS; i++) { tshard_t *s = &t->shard[i]; pthread_mutex_destroy(&s->mu); free(s->keys); free(s->hash); free(s->stamp); free(s->slot); }
+    free(t->shard); free(t->rank); free(t->keys); free(t->hash); free(t);
 }
 
-static int seq_add(mmh_tie_t *t, const tkey_t *k, uint32_t h) {
-    if ((t->n + 1) * 10 > t->set_cap * 6) {   /* grow the membership set */
-        size_t nc = t->set_cap * 2;
+/* enter key k (reference hash h) with its stamp; a key already there keeps the smaller one.  Any thread.  0 or -1 */
+static int stamp_add(mmh_tie_t *t, const tkey_t *k, uint32_t h, uint64_t stamp) {
+    const uint64_t mix = tkey_mix(k);
+    tshard_t *s = &t->shard[(mix >> 56) & (TS_SHARDS - 1)];
+    int rc = 0;
+    pthread_mutex_lock(&s->mu);
+    if ((s->n + 1) * 10 > s->slot_cap * 6) {   /* grow the slots */
+        const size_t nc = s->slot_cap ? s->slot_cap * 2 : 1024;
         uint32_t *ns = (uint32_t *)malloc(sizeof(uint32_t) * nc);
-        if (!ns) return -1;
+        if (!ns) { pthread_mutex_unlock(&s->mu); return -1; }
         memset(ns, 0xFF, sizeof(uint32_t) * nc);
-        for (size_t i = 0; i < t->n; i++) {
-            size_t s = (size_t)tkey_mix(&t->keys[i]) & (nc - 1);
-            while (ns[s] != 0xFFFFFFFFu) s = (s + 1) & (nc - 1);
-            ns[s] = (uint32_t)i;
+        for (size_t i = 0; i < s->n; i++) {
+            size_t q = (size_t)tkey_mix(&s->keys[i]) & (nc - 1);
+            while (ns[q] != 0xFFFFFFFFu) q = (q + 1) & (nc - 1);
+            ns[q] = (uint32_t)i;
         }
-        free(t->set); t->set = ns; t->set_cap = nc;
+        free(s->slot); s->slot = ns; s->slot_cap = nc;
     }
-    size_t s = (size_t)tkey_mix(k) & (t->set_cap - 1);
-    while (t->set[s] != 0xFFFFFFFFu) {
-        if (tkey_eq(&t->keys[t->set[s]], k)) return 0;
-        s = (s + 1) & (t->set_cap - 1);
+    size_t q = (size_t)mix & (s->slot_cap - 1);
+    while (s->slot[q] != 0xFFFFFFFFu) {
+        const uint32_t i = s->slot[q];
+        if (tkey_eq(&s->keys[i], k)) { if (stamp < s->stamp[i]) s->stamp[i] = stamp; pthread_mutex_unlock(&s->mu); return 0; }
+        q = (q + 1) & (s->slot_cap - 1);
     }
-    if (t->n == t->cap) {
-        size_t nc = t->cap ? t->cap * 2 : (size_t)1 << 16;
-        tkey_t *nk = (tkey_t *)realloc(t->keys, sizeof(tkey_t) * nc);
-        if (!nk) return -1;
-        t->keys = nk;
-        uint32_t *nh = (uint32_t *)realloc(t->hash, sizeof(uint32_t) * nc);
-        if (!nh) return -1;
-        t->hash = nh; t->cap = nc;
+    if (s->n == s->cap) {
+        const size_t nc = s->cap ? s->cap * 2 : 512;
+        tkey_t *nk = (tkey_t *)realloc(s->keys, sizeof(tkey_t) * nc);
+        if (nk) s->keys = nk;
+        uint32_t *nh = (uint32_t *)realloc(s->hash, sizeof(uint32_t) * nc);
+        if (nh) s->hash = nh;
+        uint64_t *nst = (uint64_t *)realloc(s->stamp, sizeof(uint64_t) * nc);
+        if (nst) s->stamp = nst;
+        if (!nk || !nh || !nst) rc = -1; else s->cap = nc;
     }
-    if (t->n >= 0xFFFFFFF0u || t->n >= t->max_keys) return -1;
-    t->keys[t->n] = *k; t->hash[t->n] = h;
-    t->set[s] = (uint32_t)t->n;
-    t->n++;
+    if (!rc) {
+        const size_t all = __atomic_add_fetch(&t->n_keys, 1, __ATOMIC_RELAXED);
+        if (all >= 0xFFFFFFF0u || all > t->max_keys) rc = -1;
+        else { s->keys[s->n] = *k; s->hash[s->n] = h; s->stamp[s->n] = stamp; s->slot[q] = (uint32_t)s->n; s->n++; }
+    }
+    pthread_mutex_unlock(&s->mu);
+    if (!rc) t->seq_valid = 0;
+    return rc;
+}
+
+/* the first-insertion sequence from the stamps: every table's keys, ordered by stamp (LSD radix sort, 11 bits a pass) */
+static int seq_build(mmh_tie_t *t) {
+    if (t->seq_valid) return 0;
+    size_t n = 0;
+    for (int i = 0; i < TS_SHARDS; i++) n += t->shard[i].n;
+    free(t->keys); free(t->hash); t->keys = NULL; t->hash = NULL; t->n = t->cap = 0;
+    typedef struct { uint64_t stamp; uint32_t shard, idx; } ent_t;
+    ent_t *a = (ent_t *)malloc(sizeof(ent_t) * (n ? n : 1)), *b = (ent_t *)malloc(sizeof(ent_t) * (n ? n : 1));
+    t->keys = (tkey_t *)malloc(sizeof(tkey_t) * (n ? n : 1)); t->hash = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    if (!a || !b || !t->keys || !t->hash) { free(a); free(b); return -1; }
+    size_t w = 0;
+    uint64_t top = 0;
+    for (uint32_t sh = 0; sh < TS_SHARDS; sh++)
+        for (size_t i = 0; i < t->shard[sh].n; i++) { a[w].stamp = t->shard[sh].stamp[i]; a[w].shard = sh; a[w].idx = (uint32_t)i; if (a[w].stamp > top) top = a[w].stamp; w++; }
+    size_t *cnt = (size_t *)malloc(sizeof(size_t) * 2048);
+    if (!cnt) { free(a); free(b); return -1; }
+    for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 11) {
+        memset(cnt, 0, sizeof(size_t) * 2048);
+        for (size_t i = 0; i < n; i++) cnt[(a[i].stamp >> shift) & 2047]++;
+        size_t run = 0;
+        for (int d = 0; d < 2048; d++) { const size_t c = cnt[d]; cnt[d] = run; run += c; }
+        for (size_t i = 0; i < n; i++) b[cnt[(a[i].stamp >> shift) & 2047]++] = a[i];
+        ent_t *tmp = a; a = b; b = tmp;
+    }
+    for (size_t i = 0; i < n; i++) { t->keys[i] = t->shard[a[i].shard].keys[a[i].idx]; t->hash[i] = t->shard[a[i].shard].hash[a[i].idx]; }
+    free(a); free(b); free(cnt);
+    t->n = t->cap = n;
+    t->seq_valid = 1;
     return 0;
 }
 
@@ -275,7 +333,7 @@ typedef struct {
     const int64_t *first;          /* first row of every read (n_reads + 1 entries) */
     const uint8_t *const *klass;   /* per code: the 256-entry threshold class table of the mod it counts for */
     const char *const *codes; int n_codes;
-    tkey_t **out_keys; uint32_t **out_hash; uint32_t *out_n;
+    uint64_t serial0;              /* serial number of the batch's first read */
     int failed;
 } readjob_t;
 
@@ -323,7 +381,6 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
     callord_t *ord = NULL; size_t ord_cap = 0;
     for (int64_t r = lo; r < hi; r++) {
         const int64_t a = j->first[r], b = j->first[r + 1];
-        j->out_keys[r] = NULL; j->out_hash[r] = NULL; j->out_n[r] = 0;
         if (a == b) continue;
         const mm_read_t *rd = &j->batch->reads[r];
         const char *mm = (const char *)j->batch->mm + rd->mm_off;
@@ -367,25 +424,22 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
                 if (pr == 1) nk++;
             }
         }
-        /* slot order of the read's table = the order merge_freq_maps offers its keys to the core table */
-        tkey_t *sk = (tkey_t *)malloc(sizeof(tkey_t) * (nk ? nk : 1));
-        uint32_t *sh = (uint32_t *)malloc(sizeof(uint32_t) * (nk ? nk : 1));
+        /* slot order of the read's table = the order merge_freq_maps offers its keys to the core table (src/mod.c:743-774: reads in
+         * file order): the key in the w-th occupied slot of read number `serial` gets the stamp serial << 24 | w */
+        (void)nk;
         size_t w2 = 0;
-        if (sk && sh) {
-            for (uint32_t s = 0; s < tab.n_buckets; s++) if (tab.used[s]) { sk[w2] = keys[tab.id[s]]; sh[w2] = hash[tab.id[s]]; w2++; }
-        } else {
-            j->failed = 1;
-        }
+        for (uint32_t s = 0; s < tab.n_buckets; s++)
+            if (tab.used[s]) { if (stamp_add(t, &keys[tab.id[s]], hash[tab.id[s]], ((j->serial0 + (uint64_t)r) << 24) | (uint64_t)(w2 & 0xFFFFFFu))) j->failed = 1; w2++; }
         free(keys); free(hash); ktab_free(&tab);
-        j->out_keys[r] = sk; j->out_hash[r] = sh; j->out_n[r] = (uint32_t)w2;
     }
     free(ord);
 }
 
 /* the first-insertion sequence so far, as opaque 16-byte keys and their hashes (a worker of `--devices` hands its own to the
  * parent); -1 when the replay has failed */
-int64_t mmh_tie_export(const mmh_tie_t *t, const void **keys, const uint32_t **hash) {
-    if (!t || t->failed) return -1;
+int64_t mmh_tie_export(const mmh_tie_t *tc, const void **keys, const uint32_t **hash) {
+    mmh_tie_t *t = (mmh_tie_t *)tc;
+    if (!t || t->failed || seq_build(t) != 0) return -1;
     *keys = t->keys; *hash = t->hash;
     return (int64_t)t->n;
 }
@@ -393,7 +447,9 @@ int64_t mmh_tie_export(const mmh_tie_t *t, const void **keys, const uint32_t **h
 int mmh_tie_import(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n) {
     if (!t || t->failed) return -1;
     const tkey_t *k = (const tkey_t *)keys;
-    for (int64_t i = 0; i < n; i++) if (seq_add(t, &k[i], hash[i])) { t->failed = 1; return -1; }
+    /* (a worker's sequence counts as the keys of so many reads of one key each: its order is kept, and it lies behind everything entered before) */
+    for (int64_t i = 0; i < n; i++) if (stamp_add(t, &k[i], hash[i], (t->reads_seen + (uint64_t)i) << 24)) { t->failed = 1; return -1; }
+    t->reads_seen += (uint64_t)n;
     return 0;
 }
 
@@ -402,10 +458,7 @@ int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, co
     if (!t || t->failed) return -1;
     const int32_t nr = batch->n_reads;
     int64_t *first = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nr + 1));
-    tkey_t **ok = (tkey_t **)calloc((size_t)nr + 1, sizeof(tkey_t *));
-    uint32_t **oh = (uint32_t **)calloc((size_t)nr + 1, sizeof(uint32_t *));
-    uint32_t *on = (uint32_t *)calloc((size_t)nr + 1, sizeof(uint32_t));
-    if (!first || !ok || !oh || !on) { free(first); free(ok); free(oh); free(on); t->failed = 1; return -1; }
+    if (!first) { t->failed = 1; return -1; }
     int64_t i = 0;
     for (int32_t r = 0; r <= nr; r++) {   /* rows come sorted by read */
         while (i < n && (int32_t)(rows[i].read & 0x1FFFFFu) < r) i++;
@@ -415,15 +468,13 @@ int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, co
     readjob_t job;
     memset(&job, 0, sizeof job);
     job.t = t; job.batch = batch; job.rows = rows; job.first = first; job.klass = klass_of_code; job.codes = codes; job.n_codes = n_codes;
-    job.out_keys = ok; job.out_hash = oh; job.out_n = on;
+    job.serial0 = t->reads_seen;
+    /* every read replays its own table and enters its keys with their stamps: merge_freq_maps' order (reads in batch order, every
+     * read's keys in its table's slot order) is in the stamps, not in who gets there first */
     mm_pool_for(pool, nr, 16, read_range, &job);
+    t->reads_seen += (uint64_t)nr;
     if (job.failed) t->failed = 1;
-    /* merge_freq_maps: reads in batch order, every read's keys in its table's slot order */
-    for (int32_t r = 0; r < nr && !t->failed; r++)
-        for (uint32_t k = 0; k < on[r]; k++)
-            if (seq_add(t, &ok[r][k], oh[r][k])) { t->failed = 1; break; }
-    for (int32_t r = 0; r < nr; r++) { free(ok[r]); free(oh[r]); }
-    free(first); free(ok); free(oh); free(on);
+    free(first);
     return t->failed ? -1 : 0;
 }
 
@@ -432,11 +483,15 @@ int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, co
 int mmh_tie_order_rows(mmh_tie_t *t, mm_row_t *rows, int64_t n) {
     if (!t || t->failed) return -1;
     if (n == 0) return 0;
+    if (seq_build(t) != 0) return -1;
     if ((size_t)n != t->n) return -1;   /* the replay saw another set of keys than the counters hold: do not guess */
     /* the core table: keys in first-insertion order */
     ktab_t core;
     memset(&core, 0, sizeof core);
-    for (size_t i = 0; i < t->n; i++) if (ktab_put(&core, (uint32_t)i, t->hash, t->keys) != 1) { ktab_free(&core); return -1; }
+    for (size_t i = 0; i < t->n; i++) {
+        if (i + 12 < t->n && core.n_buckets) { const uint32_t pf = t->hash[i + 12] & (core.n_buckets - 1); __builtin_prefetch(&core.used[pf], 1); __builtin_prefetch(&core.id[pf], 1); }
+        if (ktab_put(&core, (uint32_t)i, t->hash, t->keys) != 1) { ktab_free(&core); return -1; }
+    }
     uint32_t *arr = (uint32_t *)malloc(sizeof(uint32_t) * t->n);
     if (!arr) { ktab_free(&core); return -1; }
     size_t w = 0;
