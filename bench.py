@@ -82,7 +82,7 @@ def parse_args():
     ap.add_argument("--split-bases", type=int, default=0, help="experiment: part size of the device planning (0 = library default)")
     ap.add_argument("--single-contig", action="store_true", help="N > 1: one long contig cut into one interval per rank (round 1's layout) "
                                                                "instead of the 24-contig genome")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5", "DOT"], help="BASELINE.json workload: C2 = the headline (default); DOT (not a BASELINE config): C2's reads "
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "DOT"], help="BASELINE.json workload: C2 = the headline (default); DOT (not a BASELINE config): C2's reads "
                                                                                      "with the MM '.' flag (every unlisted C an implicit call)")
     ap.add_argument("--stream-slices", type=int, default=0, help="mm_freq_opts_t.stream_slices: 0 one position slice of a launch per XCD (default), 1 costliest first over the whole launch")
     ap.add_argument("--no-config-fracs", action="store_true", help="skip the short runs of the other BASELINE workloads (C3, C5, view) whose roofline fractions the default line carries as `config_fracs`")
@@ -249,6 +249,13 @@ def plan_reads(plan, refs, rank, seed, reads, max_len=0.0, **gen):
 WORKLOADS = {
     "C2": dict(gen=dict(), mods=[("m", "CG", 0.8)], eng=dict(), cli=["-c", "m[CG]", "-m", "0.8"],
                what="C2: %(reads)d ONT-shape reads (~15 kb) per GPU on a %(mb).1f Mb interval, -c m[CG] -m 0.8, -K %(batch)d, batches resident in HBM"),
+    # BASELINE.json configs[3]: 30x of a human-sized genome over 8 GPUs = 370 MiB (388 M positions) of reference and 775 000 ONT-shape
+    # reads (11.7 Gbases) PER GPU, 24 contigs with hg38's length ratios whatever N (at N = 8 the whole genome), contiguous shares cut at
+    # 64 kb-aligned positions, halo slabs exchanged once behind the last step.  (The reads are made by the C generator, csrc/host/synth.c,
+    # on the host's cores: ~20 s and ~10 GB of host memory per rank.)
+    "C4": dict(gen=dict(), mods=[("m", "CG", 0.8)], eng=dict(), cli=["-c", "m[CG]", "-m", "0.8"], region=370 << 20, reads=775000, genome=True,
+               what="C4: %(reads)d ONT-shape reads (~15 kb, 30x) per GPU on a %(mb).1f Mb share of a 24-contig genome with hg38's length ratios, "
+                    "-c m[CG] -m 0.8, -K %(batch)d, batches resident in HBM"),
     "C3": dict(gen=dict(shape=1), mods=[("m", "CG", 0.8), ("h", "CG", 0.7)], eng=dict(), cli=["-c", "m[CG],h[CG]", "-m", "0.8,0.7"],
                what="C3: %(reads)d PacBio-HiFi-shape reads (~15 kb, MM '?' flag) per GPU on a %(mb).1f Mb interval, -c m[CG],h[CG] -m 0.8,0.7, "
                     "-K %(batch)d, batches resident in HBM"),
@@ -555,7 +562,7 @@ def main():
             print(json.dumps({"launch_only": True, "n_gpus": world, "rank": rank, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}))
         return None
     wl = WORKLOADS[args.config]
-    if args.config == "C5" and args.reads == 100000:
+    if "reads" in wl and args.reads == 100000:   # (C5, C4: the workload's own number of reads per GPU)
         args.reads = wl["reads"]
     import torch                      # importing torch does not initialise the GPU
     import torch.distributed as dist
@@ -565,10 +572,12 @@ def main():
 
     # N = 1: one contig (C2 as BASELINE.json states it).  N > 1: the 24-contig genome, one contiguous share per rank.
     region = wl.get("region", INTERVAL) if args.region_mb <= 0 else int(args.region_mb * (1 << 20)) // (1 << 20) * (1 << 20)
-    if world == 1 or args.single_contig:
+    if (world == 1 and not wl.get("genome")) or args.single_contig:
         plan = single_contig_plan(rank, world, region, HALO)
     else:
         plan = genome_plan(rank, world, genome_layout(world, region), HALO)
+    if wl.get("genome") and world == 1:
+        args.no_e2e = True   # (the end-to-end legs write the whole read set as a BAM: --e2e-gbases is the tool for that size)
     t0 = time.time()
     refs = plan_references(plan, args.seed)
     names = [n for n, _ in plan["contigs"]]
@@ -795,8 +804,14 @@ def main():
         tb = torch.tensor([bases], dtype=torch.int64, device=rdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = int(tb.item())
+        # every rank's own figures (its bases, the seconds of its median repetition), for the line's per_rank
+        mine = torch.tensor([float(bases), float(sorted(r["elapsed"] for r in reps)[len(reps) // 2])], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": k, "bases": int(v[0].item()), "seconds": float(v[1].item()), "Mbases_per_s": float(v[0].item()) / max(float(v[1].item()), 1e-12) / 1e6} for k, v in enumerate(allr)]
     else:
         total_bases = bases
+        per_rank = None
     mid = int(np.argsort(el)[len(el) // 2])      # the median repetition (the upper one of an even count)
     elapsed, kms, abytes = el[mid], reps[mid]["kms"], reps[mid]["abytes"]
 
@@ -821,7 +836,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["what"] % dict(reads=args.reads, mb=region / 1e6, batch=args.batch),
                        "reads_per_gpu": args.reads, "batch_reads": args.batch, "mean_read_len": int(np.mean(reads_all)),
-                       "sharding": "single GPU, one contig" if world == 1 else
+                       "sharding": "single GPU, one contig" if (world == 1 and not wl.get("genome")) else
                                    ("one long contig, one interval per GPU + halo slab to the right neighbour" if args.single_contig else
                                     "24 contigs with hg38's length ratios, %.1f Mb in all, cut into one contiguous share per GPU at 64 kb-aligned "
                                     "positions; a halo slab goes to the right neighbour where a cut falls inside a contig (this rank: %d intervals, "
@@ -856,7 +871,8 @@ def main():
             result["phase_cycles_timed"] = [int(x) for x in timed_phases]
         if world > 1:
             result["final_reduce"] = {"ms": reduce_s * 1e3, "value_incl": total_bases / (elapsed + reduce_s) / 1e6, "unit": "Mbases/s",
-                                      "ranks": world, "slab_bytes": slab_words * 8, "backend": args.backend,
+                                      "ranks": world, "ranks_seen": dist.get_world_size(), "slab_bytes": slab_words * 8, "backend": args.backend,
+                                      "per_rank": per_rank, "sends": int(plan["send"] is not None), "receives": int(plan["recv"] is not None),
                                       "note": "halo slabs (%d positions x planes x 8 B) to the right neighbour wherever a cut falls inside a "
                                               "contig, once per job after the last step; timed on its own, max over ranks; value_incl = "
                                               "throughput if these K steps were the whole job" % slab_len}

@@ -129,6 +129,24 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["final_reduce"]["ranks"] == 2 and d["final_reduce"]["backend"] == "gloo" and d["value"] > 0
     assert d["config"]["sharding"].startswith("24 contigs")
+    fr = d["final_reduce"]
+    assert fr["ranks_seen"] == 2 and len(fr["per_rank"]) == 2 and all(p["bases"] > 0 and p["Mbases_per_s"] > 0 for p in fr["per_rank"])
+    assert sum(p["bases"] for p in fr["per_rank"]) > 0 and fr["slab_bytes"] > 0
+
+
+def test_bench_config_c4_line():
+    """`--config C4` (BASELINE.json configs[3]) scaled down: the 24-contig genome with hg38's length ratios at N = 1 as well, and
+    with two ranks (gloo, sharing the GPU) the halo slab between them; the line names the workload."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--config", "C4", "--reads", "6000", "--region-mb", "24", "--batch", "1024", "--steps", "4", "--warmup", "1", "--reps", "2", "--no-cpu-baseline", "--no-extra"]
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        d = json.loads([l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == n and d["config"]["workload"].startswith("C4:") and "24-contig genome" in d["config"]["workload"]
+        assert d["config"]["sharding"].startswith("24 contigs") and d["value"] > 0
+        if n == 2:
+            assert d["final_reduce"]["ranks"] == 2 and len(d["final_reduce"]["per_rank"]) == 2
 
 
 def test_bench_view_results_match_oracle(tmp_path):

@@ -228,3 +228,27 @@ def test_bench_gpus_flag_launches_the_ranks_without_a_launcher():
     env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env2)
     assert r.returncode == 0 and json.loads(r.stdout.decode().strip().splitlines()[-1])["n_gpus"] == 2
+
+
+def test_config_c4_is_the_human_genome_at_eight_gpus():
+    """bench.py --config C4 (BASELINE.json configs[3]): 370 MiB of reference and 775 000 reads per GPU; at eight GPUs the 24 contigs
+    add up to a human genome and every rank's share is an eighth of it, cut at 64 kb-aligned positions."""
+    import bench
+    wl = bench.WORKLOADS["C4"]
+    assert wl["reads"] == 775000 and wl["region"] == 370 << 20 and wl.get("genome")
+    for world in (1, 2, 8):
+        contigs = bench.genome_layout(world, wl["region"])
+        assert len(contigs) == 24 and [n for n, _ in contigs][:3] == ["chr1", "chr2", "chr3"]
+        total = sum(l for _, l in contigs)
+        assert abs(total - world * wl["region"]) < 24 << 20
+        if world == 8:
+            assert 3.0e9 < total < 3.2e9
+        owned = 0
+        for r in range(world):
+            plan = bench.genome_plan(r, world, contigs, bench.HALO)
+            mine = sum(iv["end"] - iv["begin"] for iv in plan["intervals"])
+            owned += mine
+            assert abs(mine - total / world) <= bench.CUT_ALIGN
+        assert owned == total
+    what = wl["what"] % dict(reads=wl["reads"], mb=wl["region"] / 1e6, batch=4096)
+    assert what.startswith("C4: 775000 ONT-shape reads") and "388.0 Mb" in what
