@@ -46,6 +46,10 @@ int32_t mm_bgzf_wait(mm_bgzf_t *h, int32_t slot, const int32_t **status);   /* s
 /* device milliseconds of the slot's last launch: [0] host -> device copies, [1] inflate kernel, [2] CRC kernel, [3] device -> host */
 int32_t mm_bgzf_times(mm_bgzf_t *h, int32_t slot, float ms[4]);
 
+/* sha256 (16 hex digits) over the sources this library was built from -- every .hip / .hip.h under csrc and every header under include, minimod_amd/build.py
+ * library_source_hash() -- or "unstamped": build() recompiles a shipped library that was made from other sources, smoke() checks */
+const char *mm_build_source_hash(void);
+
 /* The same two kernels on blocks that already lie in DEVICE memory, the decoded bytes left there (include/minimod_ingest.h builds on
  * it): d_c = the payloads (at least 1024 readable bytes behind the last one), d_blocks = n_blocks records, d_out / d_status = where the
  * decoded bytes and the status words go, stream = a hipStream_t, between_event = a hipEvent_t recorded between the inflate and the

@@ -268,6 +268,15 @@ int32_t mm_freq_slab_clear(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len
 int32_t mm_freq_slab_export_host(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *dst_host);
 int32_t mm_freq_slab_add_host(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *src_host);
 
+/* ... and from GPU to GPU between two processes (round 4; north_star: "reduce of boundary counter slabs over xGMI"): export packs the
+ * slab into a device buffer the handle keeps (until its next export or its end) and writes that buffer's HIP IPC handle -- 64 bytes
+ * the caller passes to the other process by whatever means it has; add opens the handle there, copies device to device (a peer copy
+ * when the two processes own different GPUs) and adds.  0, or -MM_E_HIP when this platform gives or takes no IPC handle (the callers
+ * then fall back to the host-memory pair above). */
+#define MM_IPC_HANDLE_BYTES 64
+int32_t mm_freq_slab_export_ipc(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, void *handle_out);
+int32_t mm_freq_slab_add_ipc(mm_freq_t *h, int32_t tid, int64_t begin, int64_t len, const void *handle);
+
 /* Measurement hook (bench.py): device time of a ticket's hot-path kernels in milliseconds (HIP events recorded on the
  * launch stream around them). */
 float mm_freq_last_kernel_ms(mm_freq_t *h, int32_t ticket);

@@ -8,7 +8,7 @@ from . import build
 
 BLOCK_DTYPE = np.dtype([("c_off", "<u4"), ("c_len", "<u4"), ("o_off", "<u4"), ("isize", "<u4"), ("crc", "<u4")])
 EXPORTS = ["mm_bgzf_create", "mm_bgzf_destroy", "mm_bgzf_host_alloc", "mm_bgzf_host_free", "mm_bgzf_staging", "mm_bgzf_blocks",
-           "mm_bgzf_submit", "mm_bgzf_wait", "mm_bgzf_times", "mm_bgzf_inflate_device"]
+           "mm_bgzf_submit", "mm_bgzf_wait", "mm_bgzf_times", "mm_bgzf_inflate_device"]   # (+ mm_build_source_hash: not an mm_bgzf_ name)
 _L = None
 
 

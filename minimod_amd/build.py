@@ -21,10 +21,37 @@ def source_hash():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(f for f in glob.glob(os.path.join(CSRC, "*.hip*")) if not os.path.basename(f).startswith("bgzf_")) + [os.path.join(INCLUDE, "minimod_hip.h")]:
+    for f in sorted(f for f in glob.glob(os.path.join(CSRC, "*.hip*")) if not os.path.basename(f).startswith(("bgzf_", "ingest_"))) + [os.path.join(INCLUDE, "minimod_hip.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def _hash_files(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_source_hash():
+    """sha256 over EVERY source of the device library (csrc/*.hip*, include/*.h): what the built library carries
+    (mm_build_source_hash) and what build() / smoke() compare it with -- a shipped .so made from other sources is rebuilt, not reused."""
+    import glob
+    return _hash_files(sorted(glob.glob(os.path.join(CSRC, "*.hip*")) + glob.glob(os.path.join(INCLUDE, "*.h"))))
+
+
+def built_library_hash(path=None):
+    """the hash the library at `path` was built from (None: it does not say, or cannot be loaded)"""
+    import ctypes
+    try:
+        L = ctypes.CDLL(path or lib_path())
+        L.mm_build_source_hash.restype = ctypes.c_char_p
+        return L.mm_build_source_hash().decode()
+    except (OSError, AttributeError):
+        return None
 
 
 def _stale(target, sources):
@@ -50,16 +77,26 @@ def build_hip(force=False, verbose=False):
     defs = os.environ.get("MM_HIP_DEFS", "").split()   # build-time experiments: -DMM_TILE_CHARS=... etc.
     objs = []
     relink = force or not os.path.exists(out)
+    full = library_source_hash()
     for srcs in (freq_srcs, bgzf_srcs, ingest_srcs):
         obj = os.path.join(objdir, os.path.basename(srcs[0]) + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))
-        if force or _stale(obj, srcs):
+        # an object is reused only when it was made from these very bytes (its sources' hash is kept beside it): time stamps say
+        # nothing after a checkout or a copy to another machine
+        want = _hash_files(srcs) + ("+" + full if srcs is bgzf_srcs else "")   # (the small translation unit carries the whole library's hash)
+        side = obj + ".srchash"
+        have = open(side).read().strip() if os.path.exists(side) and os.path.exists(obj) else None
+        if force or have != want:
             cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-I", INCLUDE, "-o", obj, srcs[0]] + defs
+            if srcs is bgzf_srcs:
+                cmd.append('-DMM_SOURCE_HASH="%s"' % full)
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            with open(side, "w") as f:
+                f.write(want)
             relink = True
         objs.append(obj)
-    if relink or _stale(out, objs):
+    if relink or _stale(out, objs) or built_library_hash(out) != full:
         cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
         if verbose:
             print(" ".join(cmd))

@@ -129,6 +129,7 @@ struct mm_freq {
     DevClass* d_classes = nullptr; int32_t* d_cls_of_mod = nullptr; int64_t* d_adj = nullptr;
     std::vector<void*> d_site_arrays;
     unsigned int* d_slab_flag = nullptr;
+    void* d_ipc_slab = nullptr;   // the slab another process reads through an IPC handle (mm_freq_slab_export_ipc): kept until the next one or the end
     DevMod* d_mods = nullptr;
     DevCode* d_codes = nullptr;
     std::vector<DevCode> codes;
@@ -154,7 +155,7 @@ struct mm_freq {
     int64_t device_bytes = 0;
     // an error of a batch whose ticket was never waited for (its slot was recycled), or of a deferred launch that failed:
     // reported by the next submit / wait / finalize instead of being lost
-    int sticky_err = 0, sticky_read = -1;
+    int sticky_err = 0, sticky_read = -1, sticky_ticket = -1;   // (sticky_ticket: the slot whose batch sticky_read counts in; -1: none)
     // a group of consecutive windows of one resident read set, gathered but not launched yet (opts.coalesce)
     int pending_slot = -1, pending_members = 0;
     mm_batch_t pending_batch;
@@ -677,7 +678,7 @@ int drain(mm_freq* h) {
         if (s.busy) {   // never waited for: its reads' errors still count
             int32_t bad = -1;
             int e = slot_status(h, s, &bad);
-            if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; }
+            if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; h->sticky_ticket = (int)(&s - h->slots); }
             s.busy = false;
         }
     }
@@ -704,7 +705,7 @@ int acquire_slot(mm_freq* h) {
         if (!e && finish_deferred(h, s) < 0) e = MM_E_HIP;
         int32_t bad = -1;
         if (!e) e = slot_status(h, s, &bad);
-        if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; }
+        if (e && !h->sticky_err) { h->sticky_err = e; h->sticky_read = bad; h->sticky_ticket = i; }
         s.busy = false;
     } else if (finish_deferred(h, s) < 0 && !h->sticky_err) {
         h->sticky_err = MM_E_HIP;
@@ -749,6 +750,7 @@ const char* mm_strerror(int32_t code) {
 void mm_freq_destroy(mm_freq_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->d_ipc_slab) (void)hipFree(h->d_ipc_slab);
     (void)flush_pending(h);
     (void)hipDeviceSynchronize();
     for (auto& s : h->slots) {
@@ -992,7 +994,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         for (int t = 0; t < n_contigs; t++) if (h->ref_base[t] >= 0) maxlen = std::max(maxlen, h->ctg_len[t]);
         uint8_t* d_raw = nullptr;
         if (maxlen > 0) {
-            if (hipMalloc((void**)&d_raw, (size_t)maxlen) != hipSuccess) return fail(h, "staging alloc failed");
+            if (hipMalloc((void**)&d_raw, (size_t)maxlen + 64) != hipSuccess) return fail(h, "staging alloc failed");   // (k_build_refnibs loads whole 16-byte pieces)
             for (int t = 0; t < n_contigs; t++) {
                 if (h->ref_base[t] < 0 || h->ctg_len[t] == 0) continue;
                 int64_t len = h->ctg_len[t];
@@ -1002,8 +1004,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                                                          (uint32_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
                 else if (h->ref_kind == 1) hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
                                                               (uint16_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
-                else hipLaunchKernelGGL(k_build_refnibs, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
+                else if (std::strlen(opts->mods[0].context) <= 4)
+                    hipLaunchKernelGGL(k_build_refnibs<4>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
+                                       (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
+                else hipLaunchKernelGGL(k_build_refnibs<15>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
+                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);
                 if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "context kernel failed"); }
             }
             (void)hipFree(d_raw);
@@ -1368,7 +1373,9 @@ int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     Slot& s = h->slots[ticket];
     if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP;
     if (ticket == h->pending_slot) (void)flush_pending(h);   // a failed launch is the sticky error reported next
-    if (h->sticky_err) { if (bad_read) *bad_read = h->sticky_read; return h->sticky_err; }
+    // (an error of ANOTHER ticket's batch -- found when its slot was recycled or the device was drained -- is reported here too, but the
+    // read it names is no read of this ticket's batch: the caller gets the code and -1)
+    if (h->sticky_err) { if (bad_read) *bad_read = h->sticky_ticket == ticket ? h->sticky_read : -1; return h->sticky_err; }
     if (!s.busy) return MM_OK;
     if (hipEventSynchronize(s.ev_wait) != hipSuccess) return MM_E_HIP;
     s.busy = false;
@@ -1418,7 +1425,7 @@ void mm_freq_reset_counters(mm_freq_t* h) {
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
     (void)side_table_clear(h);
     (void)hipDeviceSynchronize();
-    h->sticky_err = 0; h->sticky_read = -1;
+    h->sticky_err = 0; h->sticky_read = -1; h->sticky_ticket = -1;
 }
 
 int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
@@ -1750,6 +1757,43 @@ int32_t mm_freq_slab_add_host(mm_freq_t* h, int32_t tid, int64_t begin, int64_t 
     int r = hipMemcpy(d, src_host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -MM_E_HIP;
     if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
     (void)hipFree(d);
+    return r;
+}
+
+// The same between two PROCESSES that each own a GPU (the workers of `minimod freq --devices`): the slab is packed into a device
+// buffer of its own, whose IPC handle goes to the neighbour (64 bytes through a socket); the neighbour opens it, copies device to
+// device -- over xGMI when the two are different GPUs -- and adds.  Nothing of the slab passes through host memory.
+static_assert(sizeof(hipIpcMemHandle_t) == MM_IPC_HANDLE_BYTES, "the ABI's handle size is HIP's");
+int32_t mm_freq_slab_export_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, void* handle_out) {
+    if (!h || !handle_out || len < 0) return -MM_E_ARG;
+    const size_t bytes = 8 * (size_t)mm_freq_slab_words(h, len);
+    if (bytes == 0) return -MM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->d_ipc_slab) { (void)hipFree(h->d_ipc_slab); h->d_ipc_slab = nullptr; }
+    if (hipMalloc(&h->d_ipc_slab, bytes) != hipSuccess) return -MM_E_NOMEM;
+    int r = slab_op(h, 0, tid, begin, len, h->d_ipc_slab, nullptr);
+    if (r) return r;
+    HIPCHK(hipDeviceSynchronize());   // the neighbour reads it from another process: complete, and written back
+    hipIpcMemHandle_t hd;
+    if (hipIpcGetMemHandle(&hd, h->d_ipc_slab) != hipSuccess) { (void)hipGetLastError(); return -MM_E_HIP; }
+    std::memcpy(handle_out, &hd, sizeof hd);
+    return 0;
+}
+int32_t mm_freq_slab_add_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* handle) {
+    if (!h || !handle || len < 0) return -MM_E_ARG;
+    const size_t bytes = 8 * (size_t)mm_freq_slab_words(h, len);
+    if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    hipIpcMemHandle_t hd;
+    std::memcpy(&hd, handle, sizeof hd);
+    void* theirs = nullptr;
+    if (hipIpcOpenMemHandle(&theirs, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -MM_E_HIP; }
+    void* d = nullptr;
+    int r = hipMalloc(&d, bytes) == hipSuccess ? 0 : -MM_E_NOMEM;
+    if (!r && hipMemcpy(d, theirs, bytes, hipMemcpyDeviceToDevice) != hipSuccess) r = -MM_E_HIP;
+    (void)hipIpcCloseMemHandle(theirs);
+    if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
+    if (d) (void)hipFree(d);
     return r;
 }
 

@@ -405,13 +405,74 @@ __device__ __forceinline__ uint32_t ref_nibble(uint32_t w) {
     const uint32_t b = w & 31u;
     return (b == 2u ? 1u : (b == 4u ? 2u : (b == 8u ? 3u : 0u))) | (((w >> 5) & 3u) << 2);
 }
+// Round 4: SIXTEEN positions a thread (round 3: one byte of output a thread, every letter fetched with byte loads once per window
+// that covers it: 485 us for 50 Mb, 0.02 of the HBM roofline).  A thread loads the 48 raw letters around its 16 positions with
+// three 16-byte loads (a context is at most 15 letters: the windows that cover its positions begin at most 15 in front of them),
+// normalises them once, and works on 48-bit masks: bit k of eq_j = "letter k is the context's j-th"; a window matches where all
+// its eq_j, shifted by j, are set; a position lies in a match if one begins at it or up to L - 1 in front of it.  Eight bytes out.
+// kLmax: the longest context the instantiation takes (4: CG, CHG, CHH, A ... -- the letters further than three from the thread's
+// positions are not looked at; 15: any)
+template <int kLmax>
 __global__ __launch_bounds__(256) void k_build_refnibs(const uint8_t* __restrict__ raw, int64_t len, uint8_t* __restrict__ out,
                                                        const DevMod* __restrict__ mods) {
-    const int64_t nbytes = (len + 1) >> 1;   // (a contig starts on an even position of the array: its first byte is its own)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t lo = ref_nibble(ref_word_bits(raw, len, 2 * i, mods, 1));
-        const uint32_t hi = 2 * i + 1 < len ? ref_nibble(ref_word_bits(raw, len, 2 * i + 1, mods, 1)) : 0u;
-        out[i] = (uint8_t)(lo | (hi << 4));
+    const DevMod& m = mods[0];
+    const int L = m.ctx_is_star ? 0 : min(m.ctx_len, kLmax);
+    const int64_t n_chunks = (len + 15) >> 4;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = c << 4;
+        // letters [p0 - 16, p0 + 32): three aligned 16-byte loads (the staging buffer is allocated with 64 spare bytes; outside the
+        // contig a letter is 0, which matches nothing and is no base)
+        uint32_t w[12];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int64_t a = p0 + 16 * (q - 1);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a < len) v = *reinterpret_cast<const uint4*>(raw + a);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        uint64_t in_f = 0, in_r = 0;
+        uint32_t base2 = 0;   // two bits a position: A C G T = 0 1 2 3 (any other letter 0)
+        uint64_t st_f = ~0ull, st_r = ~0ull;
+        for (int j = 0; j < L; j++) {
+            const uint32_t cf = (uint32_t)(uint8_t)m.ctx_fwd[j], cr = (uint32_t)(uint8_t)m.ctx_rev[j];
+            uint64_t ef = 0, er = 0;
+#pragma unroll
+            for (int k = 16 - (kLmax - 1); k < 32 + (kLmax - 1); k++) {
+                const int64_t pos = p0 - 16 + k;
+                uint32_t ch = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (ch >= 'a' && ch <= 'z') ch -= 32u;
+                if (ch == 'U') ch = 'T';
+                if (pos >= len) ch = 0;
+                ef |= (uint64_t)(ch == cf) << k; er |= (uint64_t)(ch == cr) << k;
+            }
+            st_f &= ef >> j; st_r &= er >> j;
+        }
+        if (L > 0) {
+            // a window that begins at letter k must end inside the contig: k + L <= len - (p0 - 16)
+            const int64_t room = len - (p0 - 16) - L;          // last letter index a window may begin at
+            const uint64_t ok = room < 0 ? 0ull : (room >= 63 ? ~0ull : ((2ull << room) - 1ull));
+            st_f &= ok; st_r &= ok;
+            for (int k = 0; k < L; k++) { in_f |= st_f << k; in_r |= st_r << k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t ch = (w[4 + (k >> 2)] >> (8 * (k & 3))) & 255u;
+            if (ch >= 'a' && ch <= 'z') ch -= 32u;
+            const uint32_t b = ch == 'C' ? 1u : (ch == 'G' ? 2u : ((ch == 'T' || ch == 'U') ? 3u : 0u));
+            base2 |= b << (2 * k);
+        }
+        uint32_t o[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t nib = (base2 >> (2 * k)) & 3u;
+            if (m.ctx_is_star) nib |= 12u;
+            else nib |= (uint32_t)((in_f >> (16 + k)) & 1ull) << 2 | (uint32_t)((in_r >> (16 + k)) & 1ull) << 3;
+            if (p0 + k >= len) nib = 0u;
+            o[k >> 3] |= nib << (4 * (k & 7));
+        }
+        const int64_t ob = p0 >> 1, nbytes = (len + 1) >> 1;
+        if (ob + 8 <= nbytes) *reinterpret_cast<uint2*>(out + ob) = make_uint2(o[0], o[1]);
+        else for (int k = 0; ob + k < nbytes; k++) out[ob + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
     }
 }
 // a contig's words: from(refw, ref_base) once per read, at(base, position) per call -> the word in the 16 / 32-bit layout

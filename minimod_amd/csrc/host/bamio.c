@@ -204,7 +204,8 @@ typedef struct chunk {
     int n_blk;
     blk_t blk[GPU_GROUP_BLOCKS];
     int gpu_slot;        /* >= 0: the group was given to the device inflater's slot (the consumer waits for the launch) */
-    int pinned;          /* buf comes from the backend's allocator */
+    int pinned;          /* buf comes from the backend's allocator ... */
+    void (*buf_free)(void *);   /* ... and goes back through this (kept with the chunk: the backend may be gone by then) */
     size_t cap_blocks;
     int err, last;       /* last: the file ended with this group */
     int tail_err;        /* the file is damaged right behind this group's last block (a bad header, a block cut off by the file's end) */
@@ -359,12 +360,25 @@ static int be_submit_group(mm_pool_t *pool, chunk_t *c) {
 static int inflate_block(blk_t *b);
 /* the launch's end: a block the device refused (or a failed launch) is inflated here, by the host's decoder -- what counts as an
  * error stays what it is without a device */
-static void be_finish_group(chunk_t *c) {
+static void inflate_range(void *arg, int64_t lo, int64_t hi);
+static void be_finish_group(chunk_t *c, mm_pool_t *pool) {
     const mm_bgzf_backend_t *be = g_be;
     const int32_t *st = NULL;
     int r = be ? be->wait(be->ctx, c->gpu_slot, &st) : -1;
+    if (r != 0 || !st) {
+        /* the launch itself failed (a HIP error): the whole group through the pool, and no further group to a device that has
+         * stopped answering -- one warning instead of a file read on one thread */
+        mm_pool_for(pool, c->n_blk, 2, inflate_range, c);
+        __atomic_fetch_add(&g_be_fallback_blocks, (unsigned long long)c->n_blk, __ATOMIC_RELAXED);
+        be_release_slot(c->gpu_slot);
+        pthread_mutex_lock(&g_be_mu);
+        if (g_be) { g_be = NULL; fprintf(stderr, "[bamio] the device inflater failed: the host threads inflate alone from here on\n"); }
+        pthread_mutex_unlock(&g_be_mu);
+        c->gpu_slot = -1;
+        return;
+    }
     for (int i = 0; i < c->n_blk; i++)
-        if (r != 0 || !st || st[i] != 0) { c->blk[i].err = inflate_block(&c->blk[i]); __atomic_fetch_add(&g_be_fallback_blocks, 1ull, __ATOMIC_RELAXED); }
+        if (st[i] != 0) { c->blk[i].err = inflate_block(&c->blk[i]); __atomic_fetch_add(&g_be_fallback_blocks, 1ull, __ATOMIC_RELAXED); }
     be_release_slot(c->gpu_slot);
     c->gpu_slot = -1;
 }
@@ -373,10 +387,16 @@ static chunk_t *chunk_new(void) {
     chunk_t *c = (chunk_t *)calloc(1, sizeof(*c));
     if (!c) return NULL;
     c->gpu_slot = -1;
-    if (g_be && g_be->host_alloc) {   /* a device inflater: groups of GPU_GROUP_BLOCKS, decoded into pinned memory */
-        c->buf = (uint8_t *)g_be->host_alloc(CHUNK_HEAD + (size_t)GPU_GROUP_BLOCKS * 65536);
-        c->pinned = c->buf != NULL;
-        c->cap_blocks = GPU_GROUP_BLOCKS;
+    {   /* a device inflater: groups of GPU_GROUP_BLOCKS, decoded into pinned memory */
+        pthread_mutex_lock(&g_be_mu);
+        const mm_bgzf_backend_t *be = g_be;
+        pthread_mutex_unlock(&g_be_mu);
+        if (be && be->host_alloc) {
+            c->buf = (uint8_t *)be->host_alloc(CHUNK_HEAD + (size_t)GPU_GROUP_BLOCKS * 65536);
+            c->pinned = c->buf != NULL;
+            c->buf_free = be->host_free;
+            c->cap_blocks = GPU_GROUP_BLOCKS;
+        }
     }
     if (!c->buf) { c->buf = (uint8_t *)malloc(CHUNK_HEAD + CHUNK_PAYLOAD); c->pinned = 0; c->cap_blocks = GROUP_BLOCKS; }
     c->cbuf = (uint8_t *)malloc(GROUP_CBYTES + 65536 + 1024);
@@ -389,7 +409,7 @@ static void chunk_free(chunk_t *c) {
     group_wait(&c->grp);   /* (a reader closed early: its workers may still be writing into the chunk) */
     if (c->gpu_slot >= 0 && g_be) { const int32_t *st; (void)g_be->wait(g_be->ctx, c->gpu_slot, &st); be_release_slot(c->gpu_slot); }
     pthread_mutex_destroy(&c->grp.mu); pthread_cond_destroy(&c->grp.cv);
-    if (c->pinned && g_be && g_be->host_free) g_be->host_free(c->buf); else if (!c->pinned) free(c->buf);
+    if (c->pinned) { if (c->buf_free) c->buf_free(c->buf); } else free(c->buf);
     free(c->cbuf); free(c);
 }
 
@@ -581,7 +601,7 @@ static chunk_t *take_chunk(mm_bam_t *b) {
     if (!c) { b->failed = 1; b->eof = 1; return NULL; }
     c->next = NULL;
     group_wait(&c->grp);
-    if (c->gpu_slot >= 0) be_finish_group(c);
+    if (c->gpu_slot >= 0) be_finish_group(c, b->pool);
     b->wait_s += mono_s() - t_in;
     /* a damaged block: the blocks in front of it are handed out, the request after them fails (groups are 256 or 1024 blocks: a
      * group failed as a whole lost up to that many good blocks, and which ones depended on the group's size) */
@@ -722,6 +742,7 @@ static int read_header(mm_bam_t *b) {
 static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr, uint64_t *hdr_bytes) {   /* 0 done, 1 more bytes needed, -1 bad */
     if (n < 12) return 1;
     if (memcmp(p, "BAM\1", 4) != 0) return -1;
+    if (rd_u32(p + 4) > (1u << 30)) return -1;   /* (a header text of a gigabyte: not a header) */
     size_t pos = 8 + (size_t)rd_u32(p + 4);
     if (n < pos + 4) return 1;
     const int32_t n_ref = (int32_t)rd_u32(p + pos);
@@ -731,6 +752,7 @@ static int header_from_bytes(const uint8_t *p, size_t n, mm_bam_hdr_t *hdr, uint
     for (int32_t i = 0; i < n_ref; i++) {
         if (n < q + 4) return 1;
         const size_t l_name = rd_u32(p + q);
+        if (l_name > (1u << 20)) return -1;
         if (n < q + 8 + l_name) return 1;
         q += 8 + l_name;
     }

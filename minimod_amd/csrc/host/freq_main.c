@@ -9,6 +9,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
 #include <sys/wait.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -554,7 +555,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         tl_mark(realtime0, "inflater made (beside the handle)");
         ld = open_loader(&o, bam_file, ws);
         hdr = mm_bam_header(ld->bam);
-        if (hdr->n_targets != hdr0.n_targets) { MMH_ERROR("%s changed while it was being read", bam_file); exit(EXIT_FAILURE); }
+        {   /* the handle was built from the header read ahead: it must be the reader's, contig by contig */
+            int same = hdr->n_targets == hdr0.n_targets;
+            for (int t = 0; same && t < hdr->n_targets; t++) same = hdr->target_len[t] == hdr0.target_len[t] && strcmp(hdr->target_name[t], hdr0.target_name[t]) == 0;
+            if (!same) { MMH_ERROR("%s changed while it was being read", bam_file); exit(EXIT_FAILURE); }
+        }
         tl_mark(realtime0, "loader open");
     }
     /* (replay, above) Rows can tie on (contig, start) when several codes are counted, both strands can be called on one
@@ -736,35 +741,59 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         /* The halo behind a cut inside a contig: the counters this worker's reads left there go to the right-hand neighbour as
          * ONE slab (mm_freq_slab_export: position-dense, planes x strands x halo words), which adds them to its own
          * (mm_freq_slab_add); here they are cleared.  The left neighbour's slab is taken in first. */
+        /* Transport (round 4): the slab goes from GPU to GPU -- the sender packs it into a device buffer and sends that buffer's HIP
+         * IPC handle (64 bytes) over the socket between the two workers; the receiver opens it, copies device to device (xGMI between two
+         * GPUs of a node) and answers with one byte, after which the sender may let go of the buffer.  Where the platform gives or takes
+         * no handle (answer 0) the slab goes through host memory and the socket as before. */
         if (ws->slab_in >= 0) {
-            int64_t hd[3] = {0, 0, 0};   /* tid, begin, length */
+            int64_t hd[4] = {0, 0, 0, 0};   /* tid, begin, length, 1 = an IPC handle follows / 0 = the words follow */
             if (read_all(ws->slab_in, hd, sizeof hd) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
             if (hd[2] > 0) {
-                const int64_t nw = mm_freq_slab_words(h, hd[2]);
-                uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nw);
-                if (!buf || read_all(ws->slab_in, buf, sizeof(uint64_t) * (size_t)nw) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
-                int e = mm_freq_slab_add_host(h, (int32_t)hd[0], hd[1], hd[2], buf);
-                if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
-                free(buf);
+                int took = 0;
+                if (hd[3] == 1) {
+                    unsigned char ih[MM_IPC_HANDLE_BYTES];
+                    if (read_all(ws->slab_in, ih, sizeof ih) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                    took = mm_freq_slab_add_ipc(h, (int32_t)hd[0], hd[1], hd[2], ih) == 0;
+                    const unsigned char ack = took ? 1 : 0;
+                    if (write_all(ws->slab_in, &ack, 1) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                    if (took) fprintf(stderr, "[%s] halo slab of %ld positions taken from the left neighbour's GPU through a HIP IPC handle (device to device)\n", __func__, (long)hd[2]);
+                }
+                if (!took) {
+                    const int64_t nw = mm_freq_slab_words(h, hd[2]);
+                    uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nw);
+                    if (!buf || read_all(ws->slab_in, buf, sizeof(uint64_t) * (size_t)nw) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
+                    int e = mm_freq_slab_add_host(h, (int32_t)hd[0], hd[1], hd[2], buf);
+                    if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+                    free(buf);
+                }
             }
             close(ws->slab_in);
         }
         if (ws->slab_out >= 0) {
-            int64_t hd[3] = {0, 0, 0};
-            uint64_t *buf = NULL;
-            int64_t nw = 0;
+            int64_t hd[4] = {0, 0, 0, 0};
             const mm_interval_t *iv = ws->n_iv > 0 ? &ws->iv[ws->n_iv - 1] : NULL;
+            int sent = 0;
             if (iv && iv->halo > 0) {
                 hd[0] = iv->tid; hd[1] = iv->end;
                 hd[2] = iv->end + iv->halo <= (int64_t)hdr->target_len[iv->tid] ? iv->halo : (int64_t)hdr->target_len[iv->tid] - iv->end;
-                nw = mm_freq_slab_words(h, hd[2]);
-                buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nw > 0 ? nw : 1));
-                int e = buf ? mm_freq_slab_export_host(h, (int32_t)hd[0], hd[1], hd[2], buf) : -MM_E_NOMEM;
-                if (!e) e = mm_freq_slab_clear(h, (int32_t)hd[0], hd[1], hd[2], NULL);
+                unsigned char ih[MM_IPC_HANDLE_BYTES];
+                if (!getenv("MM_NO_IPC_SLABS") && mm_freq_slab_export_ipc(h, (int32_t)hd[0], hd[1], hd[2], ih) == 0) {
+                    hd[3] = 1;
+                    unsigned char ack = 0;
+                    if (write_all(ws->slab_out, hd, sizeof hd) || write_all(ws->slab_out, ih, sizeof ih) || read_all(ws->slab_out, &ack, 1)) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
+                    sent = ack == 1;   /* (0: the neighbour could not open the handle and waits for the words now) */
+                } else if (write_all(ws->slab_out, hd, sizeof hd)) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
+                if (!sent) {
+                    const int64_t nw = mm_freq_slab_words(h, hd[2]);
+                    uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nw > 0 ? nw : 1));
+                    int e = buf ? mm_freq_slab_export_host(h, (int32_t)hd[0], hd[1], hd[2], buf) : -MM_E_NOMEM;
+                    if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+                    if (write_all(ws->slab_out, buf, sizeof(uint64_t) * (size_t)nw)) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
+                    free(buf);
+                }
+                int e = mm_freq_slab_clear(h, (int32_t)hd[0], hd[1], hd[2], NULL);
                 if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
-            }
-            if (write_all(ws->slab_out, hd, sizeof hd) || (nw > 0 && write_all(ws->slab_out, buf, sizeof(uint64_t) * (size_t)nw))) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
-            free(buf);
+            } else if (write_all(ws->slab_out, hd, sizeof hd)) { MMH_ERROR("%s", "A worker of --devices lost its right neighbour"); exit(EXIT_FAILURE); }
             close(ws->slab_out);
         }
     }
@@ -849,6 +878,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             if (hv) mm_freq_destroy(hv);
             mmh_tie_destroy(tie);
             close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
+            mm_bam_hdr_free(&hdr0);
             return 0;
         }
         mm_row_t *ordered = NULL;
@@ -885,6 +915,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         close(ws->fd);
         mm_freq_destroy(h);
         close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
+        mm_bam_hdr_free(&hdr0);
         return 0;
     }
 
@@ -1049,7 +1080,8 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
     /* neighbour pipes between the workers that have something to do */
     int slab_pipe[MMH_MAX_DEVICES][2], rows_pipe[MMH_MAX_DEVICES][2];
     for (int k = 0; k + 1 < nlive; k++) {
-        if (pipe(slab_pipe[k]) != 0 || pipe(rows_pipe[k]) != 0) { MMH_ERROR("%s", "pipe failed"); exit(EXIT_FAILURE); }
+        /* (the slab's channel runs both ways -- the receiver answers -- so it is a socket pair: [1] the left worker's end, [0] the right one's) */
+        if (socketpair(AF_UNIX, SOCK_STREAM, 0, slab_pipe[k]) != 0 || pipe(rows_pipe[k]) != 0) { MMH_ERROR("%s", "pipe failed"); exit(EXIT_FAILURE); }
         if (!o->view) {
             ws[live[k]].slab_out = slab_pipe[k][1]; ws[live[k + 1]].slab_in = slab_pipe[k][0];
             ws[live[k]].rows_out = rows_pipe[k][1]; ws[live[k + 1]].rows_in = rows_pipe[k][0];

@@ -62,7 +62,7 @@ class mm_interval_t(ctypes.Structure):
 
 EXPORTS = ["mm_freq_plan_batch", "mm_freq_ticket_batches", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device", "mm_freq_submit_device_now",
            "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
-           "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear", "mm_freq_slab_export_host", "mm_freq_slab_add_host",
+           "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear", "mm_freq_slab_export_host", "mm_freq_slab_add_host", "mm_freq_slab_export_ipc", "mm_freq_slab_add_ipc",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_launch_counts", "mm_freq_reset_counters", "mm_freq_destroy"]
 
 _lib = None

@@ -224,6 +224,11 @@ def test_cli_devices_shares_of_the_genome_equal_a_single_run(flags, genome, tmp_
         assert many.returncode == 0, many.stderr.decode()[-3000:]
         assert len(one.stdout) > 100000 and many.stdout == one.stdout
         assert b"total processed entries: 1100" in many.stderr and b"devices: %d" % len(devs.split(",")) in many.stderr
+        # the halo slabs go from GPU to GPU through HIP IPC handles (two workers on one GPU exercise it too); through host memory
+        # and the socket when that is switched off: the same bytes either way
+        assert b"through a HIP IPC handle" in many.stderr, many.stderr.decode()[-1500:]
+    old = subprocess.run(base + ["--devices", "0,0", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MM_NO_IPC_SLABS="1"))
+    assert old.returncode == 0 and old.stdout == one.stdout and b"through a HIP IPC handle" not in old.stderr
 
 
 @pytest.mark.parametrize("flags", [[], ["--haplotypes", "--insertions"], ["-b"]], ids=["tsv", "hap_ins", "bedmethyl"])
