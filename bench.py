@@ -367,7 +367,7 @@ def run_end_to_end(args, wl, host_batches, contig, ref):
             return h.hexdigest(), os.path.getsize(path)
         cmd_bam = [bam]
         out_gpu, out_cpu, out_cpu1 = os.path.join(tmp, "gpu.bed"), os.path.join(tmp, "cpu.bed"), os.path.join(tmp, "cpu1.bed")
-        gpu_cmd = [cli, "freq"] + common + ["-t", str(threads)]
+        gpu_cmd = [cli, "freq"] + os.environ.get("MM_E2E_CLI_FLAGS", "").split() + common + ["-t", str(threads)]
         walls = []
         for _ in range(2):      # the first run also pages the file in and brings the HIP runtime up cold
             w, err_gpu = run(gpu_cmd, out_gpu)

@@ -49,6 +49,9 @@ int32_t mm_bgzf_times(mm_bgzf_t *h, int32_t slot, float ms[4]);
 /* sha256 (16 hex digits) over the sources this library was built from -- every .hip / .hip.h under csrc and every header under include, minimod_amd/build.py
  * library_source_hash() -- or "unstamped": build() recompiles a shipped library that was made from other sources, smoke() checks */
 const char *mm_build_source_hash(void);
+/* brings the HIP runtime up on `device` (its first call takes ~0.2 s): a caller with something else to do meanwhile -- reading the
+ * reference, say -- makes it on a thread of its own.  NOT in a process that is going to fork workers.  0 or -4 */
+int32_t mm_hip_warm(int32_t device);
 
 /* The same two kernels on blocks that already lie in DEVICE memory, the decoded bytes left there (include/minimod_ingest.h builds on
  * it): d_c = the payloads (at least 1024 readable bytes behind the last one), d_blocks = n_blocks records, d_out / d_status = where the

@@ -78,24 +78,36 @@ def build_hip(force=False, verbose=False):
     objs = []
     relink = force or not os.path.exists(out)
     full = library_source_hash()
-    for srcs in (freq_srcs, bgzf_srcs, ingest_srcs):
-        obj = os.path.join(objdir, os.path.basename(srcs[0]) + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))
-        # an object is reused only when it was made from these very bytes (its sources' hash is kept beside it): time stamps say
+    freq_srcs = freq_srcs + [os.path.join(CSRC, "freq_kinds.h")]
+    dispatch_srcs = [os.path.join(CSRC, "freq_dispatch.cpp"), os.path.join(INCLUDE, "minimod_hip.h")]
+    # (translation unit, its sources, extra flags): the freq / view path once per reference-word kind (csrc/freq_kinds.h), the public
+    # names that forward to them, the BGZF inflate, the ingestion
+    units = [("freq_api_k%d" % k, freq_srcs, ["-DMM_KIND=%d" % k]) for k in (0, 1, 2)] + \
+            [("freq_dispatch", dispatch_srcs, []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, [])]
+    todo = []
+    for name, srcs, extra in units:
+        obj = os.path.join(objdir, name + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))
+        # an object is reused only when it was made from these very bytes and flags (their hash is kept beside it): time stamps say
         # nothing after a checkout or a copy to another machine
-        want = _hash_files(srcs) + ("+" + full if srcs is bgzf_srcs else "")   # (the small translation unit carries the whole library's hash)
+        want = _hash_files(srcs) + "+" + "+".join(extra + defs)
         side = obj + ".srchash"
         have = open(side).read().strip() if os.path.exists(side) and os.path.exists(obj) else None
         if force or have != want:
-            cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-I", INCLUDE, "-o", obj, srcs[0]] + defs
-            if srcs is bgzf_srcs:
-                cmd.append('-DMM_SOURCE_HASH="%s"' % full)
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-            with open(side, "w") as f:
-                f.write(want)
-            relink = True
+            cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-I", INCLUDE, "-o", obj, srcs[0]] + extra + defs
+            todo.append((cmd, side, want))
         objs.append(obj)
+    # the three copies of the freq path take half a minute each: side by side
+    procs = []
+    for cmd, side, want in todo:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((subprocess.Popen(cmd), cmd, side, want))
+    for pr, cmd, side, want in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        with open(side, "w") as f:
+            f.write(want)
+        relink = True
     if relink or _stale(out, objs) or built_library_hash(out) != full:
         cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
         if verbose:

@@ -134,6 +134,7 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
 #define MM_SOURCE_HASH "unstamped"
 #endif
 const char* mm_build_source_hash(void) { return MM_SOURCE_HASH; }
+int32_t mm_hip_warm(int32_t device) { return (hipSetDevice(device) == hipSuccess && hipFree(nullptr) == hipSuccess) ? 0 : -4; }
 
 int32_t mm_bgzf_inflate_device(int32_t device, void* stream, const uint8_t* d_c, const mm_bgzf_block_t* d_blocks, int32_t n_blocks, uint8_t* d_out, int32_t* d_status,
                                void* between_event) {

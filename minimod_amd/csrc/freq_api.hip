@@ -7,6 +7,7 @@
 //   mm_freq_wait     per-read errors                                  (the ERROR()+exit paths of src/mod.c)
 //   mm_freq_finalize K2 + side list + ordering                        (print_freq_output src/mod.c:644-728)
 // There is no CPU fallback: every entry point needs a HIP device and fails with MM_E_HIP otherwise.
+#include "freq_kinds.h"   // (first: this copy's names)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -364,10 +365,18 @@ int enqueue_view_ordering(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t 
 }
 
 // the reference word type of a handle: RW inside the statement
+#if defined(MM_KIND) && MM_KIND == 0   // this copy's kind only (freq_kinds.h): the other kinds' instantiations are in the other copies
+#define MM_REF_DISPATCH(h, ...) do { using RW = RefNib; __VA_ARGS__; } while (0)
+#elif defined(MM_KIND) && MM_KIND == 1
+#define MM_REF_DISPATCH(h, ...) do { using RW = uint16_t; __VA_ARGS__; } while (0)
+#elif defined(MM_KIND) && MM_KIND == 2
+#define MM_REF_DISPATCH(h, ...) do { using RW = uint32_t; __VA_ARGS__; } while (0)
+#else
 #define MM_REF_DISPATCH(h, ...) do { \
         if ((h)->ref_kind == 2) { using RW = uint32_t; __VA_ARGS__; } \
         else if ((h)->ref_kind == 1) { using RW = uint16_t; __VA_ARGS__; } \
         else { using RW = RefNib; __VA_ARGS__; } } while (0)
+#endif
 
 void launch_tile_kernels(mm_freq* h, const TileParams& tp, int ga, int gs, int gc, hipStream_t st) {
     const DevParams& p = tp.d;
@@ -814,6 +823,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         return true;
     };
     h->ref_kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 && plain_context() ? 0 : 1);
+#ifdef MM_KIND
+    if (h->ref_kind != MM_KIND) return fail(h, "the handle's reference-word kind is another copy's (freq_dispatch.cpp picks the copy by the same rule)");
+#endif
+    const double tl_a0 = tl_now();
+    double tl_a1 = tl_a0;
     {
         int nb = 0;
         hipError_t e = hipSuccess;
@@ -838,6 +852,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         if (getenv("MM_DEBUG_OCC")) std::fprintf(stderr, "[minimod_hip] k_stream_reads: %d workgroups per CU (%d with '.' groups)\n", nf, nfd);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
         h->stream_blocks_per_cu_dot = nfd > 0 ? std::min(nfd, 8) : 4;
+        tl_a1 = tl_now();
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
         h->stream_blocks_per_cu_dot = std::min(h->stream_blocks_per_cu_dot, MM_STREAM_GRID_BLOCKS);
@@ -1126,6 +1141,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(h->n_counter_words, 1)) != hipSuccess)
         return fail(h, "counter memset failed");
     if (hipDeviceSynchronize() != hipSuccess) return fail(h, "device sync failed");
+    if (tl_on) std::fprintf(stderr, "[timeline] mm_freq_create: occupancy queries (the code object is loaded here) %.3f s\n", tl_a1 - tl_a0);
     if (tl_on) std::fprintf(stderr, "[timeline] mm_freq_create: tables + allocations %.3f s, reference upload + context kernels %.3f s, site index %.3f s, counters %.3f s (the runtime's start lies in front of these)\n",
                             tl_b - tl_a, tl_c - tl_b, tl_d - tl_c, tl_now() - tl_d);
     return h;
