@@ -1,0 +1,59 @@
+#!/bin/bash
+# Round 4's measurements on the GPU box, in the order they depend on each other: the HBM traffic of every workload's timed launch
+# first (PMC passes; the files go to profiles/ so that the bench lines behind them carry roofline.traffic), then the driver's
+# line (with config_fracs, the end-to-end legs, the CPU legs), per-kernel times, the inflate kernel alone.
+# usage: tools/r4_final.sh <tag>
+tag=${1:-r4p}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd $root
+timeout 300 tools/traffic.sh $tag c2 16
+timeout 300 tools/traffic.sh $tag c3 16 --config C3
+timeout 300 tools/traffic.sh $tag c5 16 --config C5
+timeout 300 tools/traffic.sh $tag view 16 --mode view
+cp $out/traffic_c2.json $out/traffic_c3.json $out/traffic_c5.json $out/traffic_view.json $root/profiles/ 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+B="python3 $root/bench.py"
+Q="--no-cpu-baseline --no-e2e --no-extra --reps 1"
+( time timeout 900 $B --steps 20 --warmup 5 > $out/freq_bench.json 2> $out/freq_bench.err ) 2> $out/freq_bench.time
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks -o freq -- $B --steps 20 --warmup 5 $Q > /dev/null 2>&1
+cp $out/ks/freq_kernel_stats.csv $out/freq_kernel_stats.csv 2>/dev/null
+for cfg in C3 C5; do
+  st=20; [ $cfg = C5 ] && st=17
+  timeout 900 $B --config $cfg --steps $st --warmup 5 --no-e2e > $out/${cfg}_bench.json 2> $out/${cfg}_bench.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$cfg -o $cfg -- $B --config $cfg --steps $st --warmup 5 $Q > /dev/null 2>&1
+  cp $out/ks_$cfg/${cfg}_kernel_stats.csv $out/${cfg}_kernel_stats.csv 2>/dev/null
+done
+timeout 300 $B --mode view --steps 20 --warmup 5 > $out/view_bench.json 2> $out/view_bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_view -o view -- $B --mode view --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+cp $out/ks_view/view_kernel_stats.csv $out/view_kernel_stats.csv 2>/dev/null
+# the CLI with the device loader under the kernel trace (a 1.5-Gbase file: every kernel of the ingestion and of the freq path by name)
+python3 - <<PY
+import os, sys, subprocess
+sys.path.insert(0, "$root")
+from minimod_amd import synth
+ref = synth.reference(3, 48 << 20)
+bs = [synth.batch(ref, i * 4096, 4096, seed=9, n_reads_total=49152, with_order=False) for i in range(12)]
+os.makedirs("/tmp/r4cli", exist_ok=True)
+synth.write_bam_parallel("/tmp/r4cli/s.bam", [("chrS", len(ref))], bs, threads=8)
+synth.write_fasta("/tmp/r4cli/s.fa", "chrS", ref)
+PY
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $out/ks_cli -o cli -- $root/minimod_amd/bin/minimod freq -b -c "m[CG]" -t 16 --gpu-ingest -o /tmp/r4cli/o.bed /tmp/r4cli/s.fa /tmp/r4cli/s.bam > $out/cli_ingest.log 2>&1
+cp $out/ks_cli/cli_kernel_stats.csv $out/cli_ingest_kernel_stats.csv 2>/dev/null
+cp $out/ks_cli/cli_memory_copy_stats.csv $out/cli_ingest_memory_copy_stats.csv 2>/dev/null
+rm -rf $out/ks $out/ks_C3 $out/ks_C5 $out/ks_view $out/ks_cli /tmp/r4cli
+cd $root
+python3 tools/inflate_bench.py 16384 4096 > $out/inflate_bench.txt 2>&1
+python3 tools/inflate_bench.py 8192 2048 >> $out/inflate_bench.txt 2>&1
+for f in $out/*_bench*.json; do echo "== $f"; python3 -c "
+import json,sys
+try:
+    d=json.loads(open('$f').read().strip().splitlines()[-1]); r=d['roofline']
+    print(d['config']['workload'][:60], '| value %.0f ms/step %.4f frac %.4f traffic %s' % (d['value'], d['ms_per_step'], r['frac'], r.get('traffic')))
+    for k in ('config_fracs',):
+        if k in d: print('   ', k, json.dumps(d[k])[:900])
+    if 'end_to_end' in d: print('    e2e', d['end_to_end']['wall_s'], d['end_to_end']['stages_s'], 'cpu', d['cpu_baseline_e2e']['t_all']['wall_s'])
+except Exception as e: print('unreadable', e)
+"; done
+cat $out/freq_bench.time $out/inflate_bench.txt; head -6 $out/cli_ingest_kernel_stats.csv | cut -c1-150; cat $out/cli_ingest_memory_copy_stats.csv 2>/dev/null | cut -c1-150
