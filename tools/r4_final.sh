@@ -39,9 +39,11 @@ os.makedirs("/tmp/r4cli", exist_ok=True)
 synth.write_bam_parallel("/tmp/r4cli/s.bam", [("chrS", len(ref))], bs, threads=8)
 synth.write_fasta("/tmp/r4cli/s.fa", "chrS", ref)
 PY
+export MM_FULL_TEARDOWN=1   # (the CLI leaves with _exit() otherwise: the profiler would never write its files)
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $out/ks_cli -o cli -- $root/minimod_amd/bin/minimod freq -b -c "m[CG]" -t 16 --gpu-ingest -o /tmp/r4cli/o.bed /tmp/r4cli/s.fa /tmp/r4cli/s.bam > $out/cli_ingest.log 2>&1
 cp $out/ks_cli/cli_kernel_stats.csv $out/cli_ingest_kernel_stats.csv 2>/dev/null
 cp $out/ks_cli/cli_memory_copy_stats.csv $out/cli_ingest_memory_copy_stats.csv 2>/dev/null
+unset MM_FULL_TEARDOWN
 rm -rf $out/ks $out/ks_C3 $out/ks_C5 $out/ks_view $out/ks_cli /tmp/r4cli
 cd $root
 python3 tools/inflate_bench.py 16384 4096 > $out/inflate_bench.txt 2>&1
