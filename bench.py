@@ -96,6 +96,9 @@ def parse_args():
     ap.add_argument("--e2e-gbases", type=float, default=0.0, help="opt-in, instead of the bench line: the STEADY-STATE end-to-end figure -- this many Gbases of "
                                                                     "reads (30x of a genome share: 12 = BASELINE configs[3] / 8) as one BGZF BAM, through the product "
                                                                     "CLI and through the CPU port, start-up included and excluded; prints its own JSON line")
+    ap.add_argument("--e2e-devices", default="", help="with --e2e-gbases: also run the same job as `minimod freq --devices LIST` (one worker process per listed GPU, "
+                    "e.g. 0,1,2,3 on a node, 0,0 to run two workers on the one GPU of a box): wall, every worker's loading / waiting / finalize time, the parent's merge and output "
+                    "time, bytes compared with the single run's")
     ap.add_argument("--mode", default="freq", choices=["freq", "view"],
                     help="freq = the headline metric (default); view = the same batches through `minimod view` (SURVEY.md 8f row 1), "
                          "rows ordered and left in HBM; an extra measurement, not the driver's contract line")
@@ -445,7 +448,7 @@ def run_e2e_big(args):
     tmp = tempfile.mkdtemp(prefix="mm_e2e_big_", dir=base)
     try:
         bam, fa = os.path.join(tmp, "reads.bam"), os.path.join(tmp, "ref.fa")
-        bases = 0
+        bases, bai_parts = 0, []
         # generated and written in rounds of 64 batches (memory stays bounded), the pieces concatenated
         with open(bam, "wb") as out:
             for r0 in range(0, len(jobs), 64):
@@ -453,10 +456,14 @@ def run_e2e_big(args):
                     bs = list(ex.map(gen, jobs[r0:r0 + 64]))
                 bases += int(sum(b["n_bases"] for b in bs))
                 piece = os.path.join(tmp, "piece.bam")
-                synth.write_bam_rounds(piece, plan["contigs"], bs, first_round=r0 == 0, last_round=r0 + 64 >= len(jobs), first_read=r0 * args.batch, threads=min(32, cores))
+                pr = synth.write_bam_rounds(piece, plan["contigs"], bs, first_round=r0 == 0, last_round=r0 + 64 >= len(jobs), first_read=r0 * args.batch, threads=min(32, cores),
+                                            index=bool(args.e2e_devices))
+                bai_parts += [(x, out.tell() + at) for x, at in pr]
                 with open(piece, "rb") as f:
                     shutil.copyfileobj(f, out, 1 << 24)
                 os.remove(piece)
+        if args.e2e_devices:   # the workers of a --devices run open the file where the index says their share begins
+            synth.merge_bai(bam + ".bai", bai_parts)
         synth.write_fasta(fa, plan["contigs"][0][0], refs[0])
         t_build = time.perf_counter() - t0
         common = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(threads)]
@@ -523,6 +530,26 @@ def run_e2e_big(args):
                     f.write(verr)
             res.setdefault("variants", {})[name.strip()] = {"flags": fl.strip(), "wall_s": vw, "wall_s_first_run": vruns[0][0], "value": bases / vw / 1e6, "stages_s": _stage_timers(verr),
                                                             "byte_identical_to_cpu": md5(ov) == md5(oc)}
+        if args.e2e_devices:
+            # one BAM, N worker processes (csrc/host/freq_main.c run_devices: shares cut at 64 kb-aligned positions, every worker reads its share
+            # through the index, counts on its GPU, hands its halo slab to the right-hand neighbour, formats its own section)
+            od = os.path.join(tmp, "gpu_devices.bed")
+            druns = [run([cli, "freq", "--devices", args.e2e_devices] + gpu_flags + (["--canonical-order"] if tied else []) + common, od) for _ in range(2)]
+            dw, derr = min(druns, key=lambda x: x[0])
+            if os.environ.get("MM_E2E_STDERR"):
+                with open(os.environ["MM_E2E_STDERR"] + ".devices", "w") as f:
+                    f.write(derr)
+            workers = [{"worker": int(m.group(1)), "device": int(m.group(2)), "reads": int(m.group(3)), "mbases": float(m.group(4)), "load_s": float(m.group(5)),
+                        "waiting_for_gpu_s": float(m.group(6)), "finalize_s": float(m.group(7))}
+                       for m in re.finditer(r"worker (\d+) \(device (\d+)\): (\d+) entries, ([0-9.]+) Mbases, loading ([0-9.]+) sec, waiting for the GPU ([0-9.]+) sec, finalize ([0-9.]+) sec", derr)]
+            sd = _stage_timers(derr)
+            res["devices_run"] = {"devices": args.e2e_devices, "n_workers": len(args.e2e_devices.split(",")), "wall_s": dw, "wall_s_first_run": druns[0][0], "value": bases / dw / 1e6,
+                                  "workers": workers, "parent_merge_s": sd.get("merge"), "parent_output_s": sd.get("output"), "stages_s": sd,
+                                  "slabs_through_hip_ipc": len(re.findall(r"through a HIP IPC handle", derr)),
+                                  "byte_identical_to_single_run": md5(od) == md5(og) and os.path.getsize(od) == os.path.getsize(og),
+                                  "cmd": "minimod freq --devices %s " % args.e2e_devices + " ".join(gpu_flags + common) + " ref.fa reads.bam",
+                                  "what": "the same files through `minimod freq --devices`: the parent never touches a GPU, forks one worker per listed device; workers listed on "
+                                          "the same device share it (a one-GPU box shows the path and its costs, not scaling)"}
         # MM_E2E_SWEEP="16,32,64": the same job at other -t (diagnostic: where the host side stops scaling)
         for t_alt in [int(x) for x in os.environ.get("MM_E2E_SWEEP", "").split(",") if x.strip()]:
             alt = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M", "-t", str(t_alt)]

@@ -77,14 +77,22 @@ constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // the bound behind a table's last 
 constexpr uint32_t kStreamMaxLen = 1u << 20; // an op this long (a 1 Mb intron) is the tile pipeline's: shorter ones cannot wrap a segment's sums
 constexpr uint32_t kNoPend = 0xFFFFFFFFu;
 
-struct StreamLds {
+// kDotLds: the instantiation does '.' groups (their two arrays are the 516 bytes the member bits below take in the others, which
+// have to fit seven workgroups into a CU's 160 KB)
+template <bool kDotLds>
+struct StreamLdsT {
     uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
     uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
-    uint32_t dw[kSegBlocks + 1];            // class members in front of each block of the segment (traversal order), then the running total
+    // the directory segment (traversal order): which of a block's 32 bases are class members (bit n = base n of the block, BAM
+    // order), and the members in front of every FOURTH block, then the running total.  A call finds its four blocks with a 7-step
+    // search, takes their bits with one 16-byte read and selects its base there -- round 3 kept a count per block and fetched the
+    // block's 16 bytes of sequence from memory a second time (the whole read, once more, long after the L2 had let go of it)
+    alignas(16) uint32_t dm[kSegBlocks];
+    uint32_t cw[kSegBlocks / 4 + 1];
     uint32_t cq[kSegCk + 1];                // query positions consumed in front of every fourth op of the segment (stored order), then 0xFFFFFFFF
     uint32_t cr[kSegCk];                    // ... reference positions
-    uint32_t gap_p[65];                     // '.' groups: first element (gap bases, then the token) of each token of the batch; [n] = all
-    uint32_t gap_r[64];                     //             first rank of the gap in front of each token
+    uint32_t gap_p[kDotLds ? 65 : 1];                     // '.' groups: first element (gap bases, then the token) of each token of the batch; [n] = all
+    uint32_t gap_r[kDotLds ? 64 : 1];                     //             first rank of the gap in front of each token
     char hdr[16];
     int16_t g_code[16];
     // what the header pass leaves for the groups: where the group starts and its list begins, flags (bit 6 no requested code,
@@ -126,6 +134,39 @@ __device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, ui
     if (pat == 0u) c -= 32u - min(32u, L - b * 32u);   // the padding behind the read's last base is none of C, G, T, N either
     return c;
 }
+// the eight match bits of a word (bit 4n+3 = nibble n) side by side: bit n = nibble n
+__device__ __forceinline__ uint32_t match_byte(uint32_t m) {
+    uint32_t x = m >> 3;
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    return (x | (x >> 12)) & 0xFFu;
+}
+// which of block b's 32 bases are members of the class: bit n = base n (a byte holds base 2i in its HIGH nibble: neighbours swap).
+// (Tried: the four words' match bits shifted into each other's gaps, no bit moved to its base's place -- 30 instructions fewer per
+// block, eight blocks a lane per read -- and the selection in a call's round paying for it: C2 36.5 against 35.5 us per batch.  What a
+// round's chain of dependent steps costs counts for more than what the passes over the whole read cost.)
+__device__ __forceinline__ uint32_t stream_block_mask(uint4 v, uint32_t pat, uint32_t b, uint32_t L) {
+    uint32_t m0, m1, m2, m3;
+    block_bits(v, pat, m0, m1, m2, m3);
+    const uint32_t nib = match_byte(m0) | (match_byte(m1) << 8) | (match_byte(m2) << 16) | (match_byte(m3) << 24);
+    uint32_t mk = ((nib & 0x55555555u) << 1) | ((nib >> 1) & 0x55555555u);
+    const uint32_t valid = min(32u, L - b * 32u);
+    if (pat == 0u && valid < 32u) mk &= (1u << valid) - 1u;   // the padding behind the read's last base is none of C, G, T, N either
+    return mk;
+}
+// position of the k-th set bit of m (k counts from 0 and is below popcount(m))
+__device__ __forceinline__ uint32_t select_bit(uint32_t m, uint32_t k) {
+    uint32_t n = 0, c = __popc(m & 0xFFFFu);
+    bool ge = k >= c;
+    k -= ge ? c : 0u; n += ge ? 16u : 0u; m = ge ? m >> 16 : m;
+    c = __popc(m & 0xFFu); ge = k >= c;
+    k -= ge ? c : 0u; n += ge ? 8u : 0u; m = ge ? m >> 8 : m;
+    c = __popc(m & 0xFu); ge = k >= c;
+    k -= ge ? c : 0u; n += ge ? 4u : 0u; m = ge ? m >> 4 : m;
+    c = __popc(m & 3u); ge = k >= c;
+    k -= ge ? c : 0u; n += ge ? 2u : 0u; m = ge ? m >> 2 : m;
+    return n + (k >= (m & 1u) ? 1u : 0u);
+}
 // all ones when bit `op` of `mask` is set, else 0 (one signed bit-field extract: which ops consume the read / the reference)
 __device__ __forceinline__ uint32_t op_mask(uint32_t mask, uint32_t op) { return (uint32_t)__builtin_amdgcn_sbfe((int)mask, op, 1u); }
 // number of set bits below the lowest clear one (64 when all are set)
@@ -155,6 +196,7 @@ struct KF {
     static_assert(!(kIns && (kDot || kView)), "the --insertions / --haplotypes instantiation is freq with '?' groups");
     const TileParams& P;
     const DevParams& p;
+    using StreamLds = StreamLdsT<kDot>;
     StreamLds& S;
     const uint32_t* ptab;
     uint32_t st_look, st_ml, st_dense, st_side;
@@ -332,15 +374,17 @@ struct KF {
                 if (h + 64u * (uint32_t)r < nb) {
                     const uint32_t t = t0 + h + 64u * (uint32_t)r + lane;
                     const bool valid = t < nblk;
-                    uint32_t cnt = stream_block_count(vv[r], cpat, rev ? nblk - 1u - t : t, L);
-                    cnt = valid ? cnt : 0u;
+                    const uint32_t mk = valid ? stream_block_mask(vv[r], cpat, rev ? nblk - 1u - t : t, L) : 0u;
+                    const uint32_t cnt = __popc(mk);
                     const uint32_t incl = wave_incl_scan(cnt);
-                    if (valid) S.dw[h + 64u * (uint32_t)r + lane] = run + incl - cnt;
+                    const uint32_t at = h + 64u * (uint32_t)r + lane;
+                    S.dm[at] = mk;                                        // (zero behind the read's last block: a group of four is whole)
+                    if (valid && (at & 3u) == 0u) S.cw[at >> 2] = run + incl - cnt;
                     run = uniu(run + lane_valu(incl, 63));
                 }
             }
         }
-        if (lane == 0u) S.dw[nb] = run;
+        if (lane == 0u) S.cw[(nb + 3u) >> 2] = run;
         d_t0 = t0; d_n = nb; S_lo = s0; S_hi = run;
         wave_sync();
     }
@@ -356,34 +400,6 @@ struct KF {
             for (int u = 0; u < 8; u++) { const uint32_t b = b0 + 64u * (uint32_t)u + lane; if (b < nblk) sum += stream_block_count(vv[u], cpat, b, L); }
         }
         return lane_valu(wave_incl_scan(sum), 63);
-    }
-    // k-th (from the block's start) member of the class among the 32 bases of block blk -> read position and base code
-    __device__ __forceinline__ uint32_t select_in_block(uint4 v, uint32_t blk, uint32_t k, uint32_t& code) const {
-        // match bits per word in BAM's nibble order (counts do not care), masked to the read's bases for the "other" class
-        uint32_t m0, m1, m2, m3;
-        block_bits(v, cpat, m0, m1, m2, m3);
-        if (cpat == 0u) {
-            const int valid = (int)min(32u, L - blk * 32u);
-            // base_order maps base n to nibble n; its inverse is itself
-            m0 &= base_order(valid_bits(valid)); m1 &= base_order(valid_bits(valid - 8));
-            m2 &= base_order(valid_bits(valid - 16)); m3 &= base_order(valid_bits(valid - 24));
-        }
-        const uint32_t s1 = __popc(m0), s2 = s1 + __popc(m1), s3 = s2 + __popc(m2);
-        const uint32_t word = (k >= s1 ? 1u : 0u) + (k >= s2 ? 1u : 0u) + (k >= s3 ? 1u : 0u);
-        k -= word == 0u ? 0u : (word == 1u ? s1 : (word == 2u ? s2 : s3));
-        const uint32_t raw = word == 0u ? v.x : (word == 1u ? v.y : (word == 2u ? v.z : v.w));
-        uint32_t mk = base_order(word == 0u ? m0 : (word == 1u ? m1 : (word == 2u ? m2 : m3)));   // bit 4n+3 <-> base n of the word
-        const uint32_t wv = base_order(raw);
-        uint32_t n = 0, cn = __popc(mk & 0xFFFFu);
-        bool ge = k >= cn;
-        k -= ge ? cn : 0u; n += ge ? 4u : 0u; mk = ge ? mk >> 16 : mk;
-        cn = __popc(mk & 0xFFu);
-        ge = k >= cn;
-        k -= ge ? cn : 0u; n += ge ? 2u : 0u; mk = ge ? mk >> 8 : mk;
-        cn = __popc(mk & 0xFu);
-        n += k >= cn ? 1u : 0u;
-        code = (wv >> (4u * n)) & 15u;
-        return blk * 32u + word * 8u + n;
     }
 
     // ------------------------------------------------------------------ CIGAR -> checkpoint table
@@ -538,19 +554,26 @@ struct KF {
         KFT_LAP(3);
         uint32_t n_done = 0;
         if (n1 > 0u) {
-            // rank -> block: largest j with dw[j] <= rho (dw[0] = S_lo <= rho_0)
+            // rank -> four blocks: largest g with cw[g] <= rho (cw[0] = S_lo <= rho_0) -> the block among them by its members' counts
             const bool act = lane < n1;
-            const uint32_t j = act ? search_le<kSegBlocks>(S.dw, rho, d_n) : 0u;
-            const uint32_t s_t = S.dw[j], c_b = S.dw[j + 1u] - s_t;
+            const uint32_t g4 = act ? search_le<kSegBlocks / 4>(S.cw, rho, (d_n + 3u) >> 2) : 0u;
+            const uint4 mb = *reinterpret_cast<const uint4*>(S.dm + 4u * g4);
+            const uint32_t rg = rho - S.cw[g4];
+            const uint32_t e1 = __popc(mb.x), e2 = e1 + __popc(mb.y), e3 = e2 + __popc(mb.z);
+            const uint32_t wb = (rg >= e1 ? 1u : 0u) + (rg >= e2 ? 1u : 0u) + (rg >= e3 ? 1u : 0u);
+            const uint32_t mk = wb == 0u ? mb.x : (wb == 1u ? mb.y : (wb == 2u ? mb.z : mb.w));
+            const uint32_t j = 4u * g4 + wb;
+            const uint32_t r_in = rg - (wb == 0u ? 0u : (wb == 1u ? e1 : (wb == 2u ? e2 : e3))), c_b = __popc(mk);
             const uint32_t t = d_t0 + j, blk = rev ? nblk - 1u - t : t;
-            const uint32_t kk = rev ? c_b - 1u - (rho - s_t) : rho - s_t;
-#ifndef MM_ABL_NOGATHER
-            const uint4 sv = act ? sq[blk] : make_uint4(0, 0, 0, 0);
-#else
-            const uint4 sv = make_uint4(0x22222222u ^ blk, 0x44444444u, 0x22224444u, 0x42424242u);
-#endif
-            uint32_t code = 0;
-            const uint32_t q = act ? select_in_block(sv, blk, kk, code) : 0u;
+            const uint32_t kk = rev ? c_b - 1u - r_in : r_in;
+            // the base inside the block from the segment's member bits; its code is the class's own (C 2, G 4, T 8, N 15) -- only the
+            // fifth class (A and the ambiguity codes) has to look at the read's bases again
+            const uint32_t q = act ? blk * 32u + select_bit(mk, kk) : 0u;
+            uint32_t code = cpat & 15u;
+            if (cpat == 0u) {
+                const uint32_t raw = act ? reinterpret_cast<const uint32_t*>(sq)[q >> 3] : 0u;
+                code = (base_order(raw) >> (4u * (q & 7u))) & 15u;
+            }
             // BAM position -> query position of the CIGAR: get_aln walks a reverse read's ops back to front from position 0 of
             // the original orientation (mod.c:813-860), so its aligned part lies at BAM positions [L - q_total, L); positions
             // outside the CIGAR's query length have no call
@@ -1071,7 +1094,7 @@ struct KF {
 // kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
 template <typename RefWord, bool kStats, bool kDot, bool kView, bool kIns>
 __global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)) void k_stream_reads(const TileParams P) {
-    __shared__ StreamLds lds[kWavesPerBlock];
+    __shared__ StreamLdsT<kDot> lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
     __syncthreads();

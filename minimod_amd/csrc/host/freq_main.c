@@ -943,7 +943,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     /* Everything the run had to say has been written and flushed.  What is left -- freeing device memory, unpinning buffers, joining
      * threads, and behind main() the HIP runtime's own exit handlers -- took 0.2 s of a 1.4 s run (12 Gbases), and the process's death
      * does it all anyway: main() leaves with _exit() unless MM_FULL_TEARDOWN is set (leak checks, sanitizers). */
-    if (!getenv("MM_FULL_TEARDOWN") && !ws->sharded) { bz_report(bz); tl_mark(realtime0, "teardown left to the process's exit"); return 0; }
+    if (!getenv("MM_FULL_TEARDOWN")) { bz_report(bz); tl_mark(realtime0, "teardown left to the process's exit"); return 0; }   /* (a --devices worker too: it leaves with _exit()) */
     tl_mark(realtime0, "teardown starts");
     mm_freq_destroy(h);
     if (hv) mm_freq_destroy(hv);
@@ -1240,6 +1240,9 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         if (tot[r].sort_time > s.sort_time) s.sort_time = tot[r].sort_time;
     }
     fprintf(stderr, "[%s] devices: %d (one worker process each, shares of %.1f Mb)", __func__, nd, total / (double)nd / 1e6);
+    for (int r = 0; r < nd; r++)
+        fprintf(stderr, "\n[%s] worker %d (device %d): %ld entries, %.1f Mbases, loading %.3f sec, waiting for the GPU %.3f sec, finalize %.3f sec", __func__, r, dev[r],
+                (long)tot[r].processed_reads, tot[r].processed_bases / 1e6, tot[r].load_time, tot[r].wait_time, tot[r].sort_time);
     fprintf(stderr, "\n[%s] total entries: %ld", __func__, (long)s.total_reads);
     fprintf(stderr, "\n[%s] total bytes: %.1f M", __func__, s.total_bytes / (float)(1000 * 1000));
     fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(s.total_reads - s.processed_reads));

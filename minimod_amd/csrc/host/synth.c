@@ -451,7 +451,7 @@ static void bai_add(mm_bam_writer_t *bw, int32_t tid, int64_t beg, int64_t end, 
         memset(r->lin + r->cap_lin, 0, (nc - r->cap_lin) * sizeof(uint64_t));
         r->cap_lin = nc;
     }
-    for (size_t w = (size_t)(beg >> 14); w < w1; w++) if (r->lin[w] == 0) r->lin[w] = v0;
+    for (size_t w = (size_t)(beg >> 14); w < w1; w++) if (r->lin[w] == 0) r->lin[w] = v0 + 1;   /* kept + 1: 0 is "not set", and a piece without a header has a record AT 0 */
     if (w1 > r->n_lin) r->n_lin = w1;
 }
 static int chunk_cmp(const void *a, const void *b) {
@@ -481,6 +481,7 @@ static int bai_write(mm_bam_writer_t *bw, const char *path) {
         int32_t n_intv = (int32_t)r->n_lin;
         fwrite(&n_intv, 4, 1, fp);
         for (size_t w = 1; w < r->n_lin; w++) if (r->lin[w] == 0) r->lin[w] = r->lin[w - 1];   /* windows nothing overlaps, as samtools fills them */
+        for (size_t w = 0; w < r->n_lin; w++) if (r->lin[w]) r->lin[w]--;
         if (n_intv) fwrite(r->lin, 8, (size_t)n_intv, fp);
     }
     fwrite(&bw->n_no_coor, 8, 1, fp);

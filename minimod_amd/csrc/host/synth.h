@@ -46,7 +46,7 @@ int mm_batch_make_order(mm_host_batch_t *b);
 typedef struct mm_bam_writer mm_bam_writer_t;
 mm_bam_writer_t *mm_bam_writer_open(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens);
 /* a big file written in pieces on several threads and concatenated (BGZF members concatenate) */
-enum { MM_BAMW_NO_HEADER = 1, MM_BAMW_NO_EOF = 2, MM_BAMW_INDEX = 4 /* also write <path>.bai (whole files only, not pieces) */ };
+enum { MM_BAMW_NO_HEADER = 1, MM_BAMW_NO_EOF = 2, MM_BAMW_INDEX = 4 /* also write <path>.bai; a piece's index holds offsets inside the piece (synth.py merge_bai shifts and joins them) */ };
 mm_bam_writer_t *mm_bam_writer_open_piece(const char *path, int32_t n_contigs, const char *const *names, const int64_t *lens,
                                           int flags, uint64_t first_serial);
 int mm_bam_writer_put_batch(mm_bam_writer_t *bw, const mm_batch_t *b, int with_filter_fodder);

@@ -229,10 +229,68 @@ def write_bam_parallel(path, contigs, batches, filter_fodder=True, threads=8):
             os.remove(pp)
 
 
-def write_bam_rounds(path, contigs, batches, first_round=True, last_round=True, first_read=0, filter_fodder=True, threads=8):
+def read_bai(path):
+    """A .bai as [(bins, lin)] per reference + n_no_coor: bins = {bin: [(beg, end), ...]}, lin = the linear index (SAM spec 5.2)."""
+    import struct
+    d = open(path, "rb").read()
+    if d[:4] != b"BAI\1":
+        raise ValueError("not a .bai: %s" % path)
+    n_ref, = struct.unpack_from("<i", d, 4)
+    o, refs = 8, []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", d, o); o += 4
+        bins = {}
+        for _ in range(n_bin):
+            b_, n_chunk = struct.unpack_from("<Ii", d, o); o += 8
+            v = struct.unpack_from("<%dQ" % (2 * n_chunk), d, o); o += 16 * n_chunk
+            bins[b_] = [(v[2 * i], v[2 * i + 1]) for i in range(n_chunk)]
+        n_intv, = struct.unpack_from("<i", d, o); o += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, d, o)); o += 8 * n_intv
+        refs.append((bins, lin))
+    n_no_coor = struct.unpack_from("<Q", d, o)[0] if o + 8 <= len(d) else 0
+    return refs, n_no_coor
+
+
+def merge_bai(out_path, parts):
+    """The index of a BAM that is pieces one behind the other: parts = [(piece's .bai as read_bai gives it, the piece's first byte in
+    the whole file)] in file order (every piece begins a BGZF block, so a virtual offset moves by first_byte << 16).  Chunks of a bin
+    that continue each other across a joint are joined; a 16 kb window takes the first piece's entry that has one."""
+    import struct
+    n_ref = len(parts[0][0][0])
+    out = [b"BAI\1", struct.pack("<i", n_ref)]
+    no_coor = sum(p[0][1] for p in parts)
+    for t in range(n_ref):
+        bins, lin = {}, []
+        for (refs, _), base in parts:
+            sh = base << 16
+            pb, pl = refs[t]
+            for b_, chunks in pb.items():
+                dst = bins.setdefault(b_, [])
+                for beg, end in chunks:
+                    if dst and dst[-1][1] == beg + sh:
+                        dst[-1] = (dst[-1][0], end + sh)
+                    else:
+                        dst.append((beg + sh, end + sh))
+            # a piece's windows: [0, first record's window) are 0 = nothing there; inside, the writer has filled every window.  The
+            # first piece that reaches a window decides it (records are sorted over the pieces: no later piece has an earlier record there)
+            if len(pl) > len(lin):
+                lin.extend((v + sh) if (v or base) else 0 for v in pl[len(lin):])
+        out.append(struct.pack("<i", len(bins)))
+        for b_ in sorted(bins):
+            ch = bins[b_]
+            out.append(struct.pack("<Ii", b_, len(ch)))
+            out.append(struct.pack("<%dQ" % (2 * len(ch)), *[x for c in ch for x in c]))
+        out.append(struct.pack("<i", len(lin)))
+        out.append(struct.pack("<%dQ" % len(lin), *lin))
+    out.append(struct.pack("<Q", no_coor))
+    with open(out_path, "wb") as f:
+        f.write(b"".join(out))
+
+
+def write_bam_rounds(path, contigs, batches, first_round=True, last_round=True, first_read=0, filter_fodder=True, threads=8, index=False):
     """One ROUND of a BAM written in several rounds (a file too big to hold as batches at once): like write_bam_parallel, with the
     header only in the first round's first piece and the EOF block only behind the last round's last piece; the rounds' files
-    concatenated are the BAM."""
+    concatenated are the BAM.  index=True: returns [(piece's index, piece's first byte inside this round's file)] for merge_bai."""
     import shutil
     from concurrent.futures import ThreadPoolExecutor
     from .engine import batch_struct
@@ -246,7 +304,7 @@ def write_bam_rounds(path, contigs, batches, first_round=True, last_round=True, 
     nb = len(batches)
 
     def piece(i):
-        flags = (0 if (first_round and i == 0) else 1) | (0 if (last_round and i == nb - 1) else 2)
+        flags = (0 if (first_round and i == 0) else 1) | (0 if (last_round and i == nb - 1) else 2) | (4 if index else 0)
         pp = "%s.piece%d" % (path, i)
         w = L.mm_bam_writer_open_piece(pp.encode(), len(contigs), names, lens, flags, firsts[i])
         if not w:
@@ -257,11 +315,17 @@ def write_bam_rounds(path, contigs, batches, first_round=True, last_round=True, 
         return pp
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
         pieces = list(ex.map(piece, range(nb)))
+    parts, at = [], 0
     with open(path, "wb") as out:
         for pp in pieces:
+            if index:
+                parts.append((read_bai(pp + ".bai"), at))
+                os.remove(pp + ".bai")
+                at += os.path.getsize(pp)
             with open(pp, "rb") as f:
                 shutil.copyfileobj(f, out, 1 << 24)
             os.remove(pp)
+    return parts
 
 
 def write_fasta(path, name, seq):

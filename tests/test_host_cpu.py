@@ -546,17 +546,32 @@ def test_own_inflate_matches_zlib_on_every_block_type_and_rejects_damage():
             p += bsize
 
 
-def test_bai_linear_index_and_positioned_reader(tmp_path):
+@pytest.mark.parametrize("pieces", [False, True], ids=["whole", "pieces"])
+def test_bai_linear_index_and_positioned_reader(tmp_path, pieces):
     """The writer's .bai (SAM specification 5.2) and the reader's use of it: for a set of (contig, position) starts, opening
     the BAM at mm_bai_start()'s virtual offset and skipping the records in front of the start gives exactly the records an
-    unpositioned read of the file gives from there on."""
+    unpositioned read of the file gives from there on.  pieces: the file written in rounds of pieces (bench.py --e2e-gbases), its
+    index the pieces' indices shifted and joined (synth.merge_bai)."""
     import ctypes
     from minimod_amd import hostlib, synth
     names, lens = ["chr1", "chr2", "chr10"], [1 << 20, 3 << 19, 1 << 19]
     refs = [synth.reference(100 + i, L) for i, L in enumerate(lens)]
     bs = synth.multi_contig(refs, [300, 400, 150], 256, seed=5, median_len=4000.0, max_len=30000.0)
     p = str(tmp_path / "i.bam")
-    synth.write_bam(p, list(zip(names, lens)), bs, index=True)
+    if not pieces:
+        synth.write_bam(p, list(zip(names, lens)), bs, index=True)
+    else:
+        parts, base, first = [], 0, 0
+        with open(p, "wb") as out:
+            for r0 in range(0, len(bs), 2):
+                rp = str(tmp_path / "round.bam")
+                pr = synth.write_bam_rounds(rp, list(zip(names, lens)), bs[r0:r0 + 2], first_round=r0 == 0, last_round=r0 + 2 >= len(bs), first_read=first, threads=2, index=True)
+                parts += [(x, base + at) for x, at in pr]
+                base += os.path.getsize(rp)
+                first += sum(len(b["reads"]) for b in bs[r0:r0 + 2])
+                out.write(open(rp, "rb").read())
+        assert len(parts) == len(bs) and len(bs) > 2
+        synth.merge_bai(p + ".bai", parts)
     L = hostlib._lib()
     L.mm_bai_load.restype = ctypes.c_void_p
     L.mm_bai_load.argtypes = [ctypes.c_char_p]
