@@ -295,7 +295,7 @@ def _stage_timers(stderr_text):
                      ("merge", r"Data merging time: ([0-9.]+)"), ("sort", r"Data sorting time: ([0-9.]+)"),
                      ("output", r"Data output time: ([0-9.]+)"), ("reference", r"Reference genome loaded in ([0-9.]+)"),
                      ("reference", r"Reference loading time: ([0-9.]+)"), ("contexts", r"Reference contexts loaded in ([0-9.]+)"),
-                     ("contexts", r"Reference contexts time: ([0-9.]+)")):
+                     ("contexts", r"Reference contexts time: ([0-9.]+)"), ("gpu_runtime", r"GPU runtime ready [0-9.]+ sec after the process began \(waited ([0-9.]+)")):
         m = re.search(pat, stderr_text)
         if m:
             out[key] = float(m.group(1))
@@ -495,7 +495,7 @@ def run_e2e_big(args):
             with open(os.environ["MM_E2E_STDERR"], "w") as f:
                 f.write(err)
         st = _stage_timers(err)
-        startup = st.get("reference", 0.0) + st.get("contexts", 0.0)
+        startup = st.get("reference", 0.0) + st.get("contexts", 0.0) + st.get("gpu_runtime", 0.0)
         m = re.search(r"GPU launches: (\d+) for (\d+) batches \((\d+) with k_stream_reads\)", err)
         w_cpu, err_cpu = run([cpu_cli] + common, oc)
         st_cpu = _stage_timers(err_cpu)

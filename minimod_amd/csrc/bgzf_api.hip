@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "bgzf_kernels.hip.h"
@@ -134,7 +135,28 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
 #define MM_SOURCE_HASH "unstamped"
 #endif
 const char* mm_build_source_hash(void) { return MM_SOURCE_HASH; }
-int32_t mm_hip_warm(int32_t device) { return (hipSetDevice(device) == hipSuccess && hipFree(nullptr) == hipSuccess) ? 0 : -4; }
+// The runtime's start AND what it puts off until first use -- a queue, a copy engine, this library's code object: one stream, one
+// four-byte copy, one empty launch.  Once per device; later callers wait for the first and return.
+__global__ void k_warm(int* p) { if (p && threadIdx.x == 12345u) *p = 0; }
+int32_t mm_hip_warm(int32_t device) {
+    static std::mutex mu;
+    static int done[64];
+    std::lock_guard<std::mutex> g(mu);
+    if (device >= 0 && device < 64 && done[device]) return done[device] > 0 ? 0 : -4;
+    bool ok = hipSetDevice(device) == hipSuccess && hipFree(nullptr) == hipSuccess;
+    if (ok) {
+        hipStream_t st = nullptr;
+        int* d = nullptr;
+        int v = 0;
+        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&d, 64) == hipSuccess &&
+             hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st) == hipSuccess;
+        if (ok) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st, d); ok = hipStreamSynchronize(st) == hipSuccess; }
+        if (d) (void)hipFree(d);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    if (device >= 0 && device < 64) done[device] = ok ? 1 : -1;
+    return ok ? 0 : -4;
+}
 
 int32_t mm_bgzf_inflate_device(int32_t device, void* stream, const uint8_t* d_c, const mm_bgzf_block_t* d_blocks, int32_t n_blocks, uint8_t* d_out, int32_t* d_status,
                                void* between_event) {

@@ -134,7 +134,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
     if (!o->view) fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
                               "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
                               "                              replay minimod's row order, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
-                      o->gpu_ingest < 0 ? "for a BAM file of 128 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
+                      o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -509,6 +509,13 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         tl_mark(realtime0, "loader open");
     }
 
+    /* The HIP runtime's start (begun on a thread of its own when the process began, or here in a --devices worker) is not the
+     * reference's work: waited for and reported by itself, in front of the stage the reference calls "contexts" (src/freq_main.c:470-482) */
+    {
+        const double tw = mmh_realtime();
+        if (mm_hip_warm(o.device) != 0) { MMH_ERROR("GPU %d is not usable (no CPU fallback in this build)", o.device); exit(EXIT_FAILURE); }
+        fprintf(stderr, "[%s] GPU runtime ready %.3f sec after the process began (waited %.3f sec for it here)\n", __func__, mmh_realtime() - realtime0, mmh_realtime() - tw);
+    }
     double t2 = mmh_realtime();
     fprintf(stderr, "[%s] Loading contexts in reference\n", __func__);
     mm_contig_t *ctg = (mm_contig_t *)calloc((size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1), sizeof(mm_contig_t));
@@ -1360,7 +1367,7 @@ static int run_main(int argc, char **argv, int view) {
         struct stat sb;
         int n_dev = 1;
         if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
-        o.gpu_ingest = !view && stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)128 << 20);   /* (measured: 0.52 against 0.78 s for a 656 MB file; the reference's test files, a megabyte or two, stay with the host threads) */
+        o.gpu_ingest = !view && stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)512 << 20);   /* (tools/ingest_threshold.sh: the device reader's own start -- 192 MiB of pinned staging, 3 GiB of pools, their release at exit -- is 0.1 - 0.3 s by box; the host threads win below ~0.5 GiB, lose from ~1 GiB, between them it depends on the box) */
     }
     /* the HIP runtime's start (~0.2 s) beside the reference's load -- unless this process is going to fork workers (--devices a,b,...:
      * the parent must not have touched HIP) */
