@@ -107,7 +107,7 @@ struct Slot {
 struct mm_freq {
     mm_freq_opts_t opts;
     int device = 0;
-    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6, stream_blocks_per_cu_dot = 6;
+    int n_cu = 0, blocks_per_cu = 1, scan_blocks_per_cu = 8, call_blocks_per_cu = 4, stream_blocks_per_cu = 6, stream_blocks_per_cu_dot = 6, stream_blocks_per_cu_dot_ins = 6;
     bool stream_dot = false; // a read with a '.' group has been seen: k_stream_reads' '.'-capable instantiation from now on
     bool use_tiles = true;   // opts.force_fused: the fused one-wave-per-read kernel for every read
     int ref_kind = 1;   // reference words: 0 four bits a base (one mod, RefNib), 1 16-bit (up to 5 mods), 2 32-bit
@@ -553,13 +553,15 @@ int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t
                 s.h_ctl[132] = 0u;
                 tp.host_dot_flag = s.h_ctl + 132;
                 const bool kd = h->stream_dot || h->opts.stream_mode == 3;
-                if (kd && !(p.insertions || p.haplotypes)) gf = h->n_cu * h->stream_blocks_per_cu_dot;
+                if (kd) gf = h->n_cu * ((p.insertions || p.haplotypes) ? h->stream_blocks_per_cu_dot_ins : h->stream_blocks_per_cu_dot);
 #define MM_LAUNCH_STREAM(T, ST, DT) do { if (p.view) hipLaunchKernelGGL((k_stream_reads<T, ST, DT, true, false>), dim3(gf), dim3(256), 0, st, tp); \
                                            else hipLaunchKernelGGL((k_stream_reads<T, ST, DT, false, false>), dim3(gf), dim3(256), 0, st, tp); } while (0)
                 MM_REF_DISPATCH(h,
-                    if (p.insertions || p.haplotypes) {   // '?' groups only: reads with '.' groups go on to the tile pipeline
-                        if (p.stats) hipLaunchKernelGGL((k_stream_reads<RW, true, false, false, true>), dim3(gf), dim3(256), 0, st, tp);
-                        else hipLaunchKernelGGL((k_stream_reads<RW, false, false, false, true>), dim3(gf), dim3(256), 0, st, tp);
+                    if (p.insertions || p.haplotypes) {   // (round 4: '.' groups too -- only a reverse read of more than 512 ops under --insertions goes on to the tile pipeline)
+                        if (p.stats) { if (kd) hipLaunchKernelGGL((k_stream_reads<RW, true, true, false, true>), dim3(gf), dim3(256), 0, st, tp);
+                                       else hipLaunchKernelGGL((k_stream_reads<RW, true, false, false, true>), dim3(gf), dim3(256), 0, st, tp); }
+                        else { if (kd) hipLaunchKernelGGL((k_stream_reads<RW, false, true, false, true>), dim3(gf), dim3(256), 0, st, tp);
+                               else hipLaunchKernelGGL((k_stream_reads<RW, false, false, false, true>), dim3(gf), dim3(256), 0, st, tp); }
                     }
                     else if (p.stats) { if (kd) MM_LAUNCH_STREAM(RW, true, true); else MM_LAUNCH_STREAM(RW, true, false); }
                     else { if (kd) MM_LAUNCH_STREAM(RW, false, true); else MM_LAUNCH_STREAM(RW, false, false); });
@@ -848,10 +850,13 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             if (!plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, false, false, true>), 256, 0);
             else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (k_stream_reads<RW, false, false, false, false>), 256, 0));
         int nfd = 0;   // the '.'-capable instantiation keeps more registers and one wavefront per SIMD fewer
-        MM_REF_DISPATCH(h, (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nfd, (k_stream_reads<RW, false, true, false, false>), 256, 0));
+        MM_REF_DISPATCH(h,
+            if (!plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nfd, (k_stream_reads<RW, false, true, false, true>), 256, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nfd, (k_stream_reads<RW, false, true, false, false>), 256, 0));
         if (getenv("MM_DEBUG_OCC")) std::fprintf(stderr, "[minimod_hip] k_stream_reads: %d workgroups per CU (%d with '.' groups)\n", nf, nfd);
         h->stream_blocks_per_cu = nf > 0 ? std::min(nf, 8) : 4;
         h->stream_blocks_per_cu_dot = nfd > 0 ? std::min(nfd, 8) : 4;
+        h->stream_blocks_per_cu_dot_ins = h->stream_blocks_per_cu_dot;   // (one of the two is this handle's: `plain` says which)
         tl_a1 = tl_now();
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);

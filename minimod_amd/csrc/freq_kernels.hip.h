@@ -412,6 +412,68 @@ __device__ __forceinline__ uint32_t ref_nibble(uint32_t w) {
 // its eq_j, shifted by j, are set; a position lies in a match if one begins at it or up to L - 1 in front of it.  Eight bytes out.
 // kLmax: the longest context the instantiation takes (4: CG, CHG, CHH, A ... -- the letters further than three from the thread's
 // positions are not looked at; 15: any)
+// bit 8k+7 of the result: byte k of x equals the letter
+__device__ __forceinline__ uint32_t bytes_eq(uint32_t x, uint32_t letter) {
+    const uint32_t y = x ^ (letter * 0x01010101u);
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+// Contexts of up to four letters, a chunk whose 48 letters all lie inside the contig (every chunk but a contig's first and its last
+// two): four letters an instruction.  Letters are folded to upper case by clearing bit 5 (only a lower-case letter can become a
+// letter that way) and U becomes T; e_j = "the letter is the context's j-th" as a flag in bit 7 of the letter's byte; a window
+// begins where all e_j, moved j letters down, are set (v_alignbyte moves letters across the dwords); a position lies in a match
+// where a window begins at it or up to L - 1 letters in front of it.
+__device__ __forceinline__ uint2 refnibs_chunk_fast(const uint32_t (&w)[12], const DevMod& m, int L) {
+    uint32_t f[6];   // letters [p0 - 4, p0 + 20): dwords 3 .. 8 of the 48
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+        const uint32_t u = w[3 + d] & 0xDFDFDFDFu;
+        f[d] = u ^ (bytes_eq(u, 'U') >> 7);   // 'U' ^ 1 = 'T'
+    }
+    uint32_t inf[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u}, inr[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    if (!m.ctx_is_star) {
+        uint32_t sf[5], sr[5];   // windows beginning at the letters of dwords 0 .. 4 of f (the last one's would need letters this thread has not got)
+#pragma unroll
+        for (int d = 0; d < 5; d++) { sf[d] = 0x80808080u; sr[d] = 0x80808080u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < L) {
+                const uint32_t cf = (uint32_t)(uint8_t)m.ctx_fwd[j], cr = (uint32_t)(uint8_t)m.ctx_rev[j];
+                uint32_t ef[6], er[6];
+#pragma unroll
+                for (int d = 0; d < 6; d++) { ef[d] = bytes_eq(f[d], cf); er[d] = bytes_eq(f[d], cr); }
+#pragma unroll
+                for (int d = 0; d < 5; d++) {
+                    sf[d] &= j == 0 ? ef[d] : __builtin_amdgcn_alignbyte(ef[d + 1], ef[d], (uint32_t)j);
+                    sr[d] &= j == 0 ? er[d] : __builtin_amdgcn_alignbyte(er[d + 1], er[d], (uint32_t)j);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {   // the thread's positions are dwords 1 .. 4 of f
+            uint32_t a = sf[d + 1], b2 = sr[d + 1];
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                if (k < L) {
+                    a |= __builtin_amdgcn_alignbyte(sf[d + 1], sf[d], (uint32_t)(4 - k));
+                    b2 |= __builtin_amdgcn_alignbyte(sr[d + 1], sr[d], (uint32_t)(4 - k));
+                }
+            }
+            inf[d] = a; inr[d] = b2;
+        }
+    }
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t eC = bytes_eq(f[d + 1], 'C'), eG = bytes_eq(f[d + 1], 'G'), eT = bytes_eq(f[d + 1], 'T');
+        // a nibble in the low half of every byte: base (A C G T = 0 1 2 3, any other letter 0), forward match, reverse match
+        uint32_t x = ((eC | eT) >> 7) | ((eG | eT) >> 6) | (inf[d] >> 5) | (inr[d] >> 4);
+        x = (x | (x >> 4)) & 0x00FF00FFu;
+        x = (x | (x >> 8)) & 0xFFFFu;
+        o[d >> 1] |= x << (16 * (d & 1));
+    }
+    return make_uint2(o[0], o[1]);
+}
+
 template <int kLmax>
 __global__ __launch_bounds__(256) void k_build_refnibs(const uint8_t* __restrict__ raw, int64_t len, uint8_t* __restrict__ out,
                                                        const DevMod* __restrict__ mods) {
@@ -420,6 +482,16 @@ __global__ __launch_bounds__(256) void k_build_refnibs(const uint8_t* __restrict
     const int64_t n_chunks = (len + 15) >> 4;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p0 = c << 4;
+        if (kLmax <= 4 && p0 >= 16 && p0 + 32 <= len) {
+            uint32_t w[12];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(raw + p0 + 16 * (q - 1));
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+            *reinterpret_cast<uint2*>(out + (p0 >> 1)) = refnibs_chunk_fast(w, m, L);
+            continue;
+        }
         // letters [p0 - 16, p0 + 32): three aligned 16-byte loads (the staging buffer is allocated with 64 spare bytes; outside the
         // contig a letter is 0, which matches nothing and is no base)
         uint32_t w[12];

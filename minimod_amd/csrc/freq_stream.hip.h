@@ -193,7 +193,7 @@ __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key,
 // kIns: --insertions and / or --haplotypes (freq, '?' groups)
 template <typename RefWord, bool kStats, bool kDot, bool kView, bool kIns>
 struct KF {
-    static_assert(!(kIns && (kDot || kView)), "the --insertions / --haplotypes instantiation is freq with '?' groups");
+    static_assert(!(kIns && kView), "the --insertions / --haplotypes instantiations are freq");
     const TileParams& P;
     const DevParams& p;
     using StreamLds = StreamLdsT<kDot>;
@@ -258,6 +258,11 @@ struct KF {
     __device__ KF(const TileParams& tp, StreamLds& s, const uint32_t* tab)
         : P(tp), p(tp.d), S(s), ptab(tab), st_look(0), st_ml(0), st_dense(0), st_side(0), err(0), saw_dot(false) {}
 
+    // --insertions with '.' groups: an implicit call on a base that is not aligned takes its anchor from the MIRRORED read position
+    // (the reference indexes ins[] with the BAM position there and everything else with the original one, mod.c:1234, :1314):
+    // a reverse read's implicit calls look a second op up, anywhere in the CIGAR.  With the whole CIGAR in the table (up to kSegOps
+    // ops) that is one more search; a longer reverse read stays with the tile pipeline, which keeps every op's sums in memory.
+    __device__ __forceinline__ bool dot_ins_far() const { return p.insertions && rev && ncig > kSegOps; }
     __device__ __forceinline__ int gcode_at(int m) const { return (int)(int16_t)(((m < 2 ? gc01 : gc23) >> (16 * (m & 1))) & 0xFFFFu); }
     __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
 
@@ -279,58 +284,89 @@ struct KF {
     }
     __device__ __forceinline__ void parse_chunk(bool keep) {
         const int lane = lane_id();
-        constexpr int kSub = (int)(kStreamChunk / 64);
         if (staged_at != cpos) stage_chunk(cpos);
         fetch_chunk(cpos + kStreamChunk);   // the next chunk is requested before this one is parsed
         const uint32_t skip = skip0;         // the group's first chunk starts at its header: the list begins `skip` characters in
         skip0 = 0;
         const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(S.mmw);
-        uint32_t x[kSub];
-#pragma unroll
-        for (int sc = 0; sc < kSub; sc++) x[sc] = mb8[64 * sc + lane];
+        // Round 4: FOUR characters a lane (its dword of the chunk) and ONE scan a chunk -- rounds 2 and 3 took a character a lane, a
+        // quarter of the chunk at a time, four scans one behind the other: 29 % of the kernel's time on C2 (profiles/r4q_phases.txt).
+        const uint32_t w = S.mmw[lane];
         const uint32_t x4 = mb8[kStreamChunk + (lane & 15)];
-        // delimiter bitmaps of the sub-chunk at hand and of the one behind it only (all five at once cost eighteen scalar
-        // registers the kernel does not have)
-        const uint64_t D_look = __ballot(lane < 16 && (x4 == ',' || x4 == ';')) | ~0xFFFFull;
-        uint64_t Sm_cur = __ballot(x[0] == ';');
-        uint64_t D_cur = Sm_cur | __ballot(x[0] == ',');
-        if (skip) D_cur |= 1ull << (skip - 1u);   // the list's first character follows the header as if it followed a delimiter
-        uint64_t pd = prev_delim ? 1ull : 0ull;    // is the character in front of the sub-chunk a delimiter
-        uint64_t D_last = 0;                        // the last sub-chunk's bitmap, for the look-ahead
-        const uint32_t qtail = qhead + qn;
-        uint32_t nends = 0, rsum_v = 0;
-        uint64_t bad = 0;
-        bool cl = false, open_tail = false;
+        const uint32_t yc = w ^ 0x2C2C2C2Cu, ys = w ^ 0x3B3B3B3Bu, yd = w ^ 0x30303030u;
+        const uint32_t cm = ~(((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc) & 0x80808080u;   // commas (bit 8j+7: character j of the dword)
+        const uint32_t sm = ~(((ys & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ys) & 0x80808080u;   // semicolons
+        const uint32_t ndm = (((yd & 0x7F7F7F7Fu) + 0x76767676u) | yd) & 0x80808080u;    // not a digit
+        const uint32_t dlm = cm | sm;
+        const uint32_t xd = dlm >> 7;
+        uint32_t d4 = (xd | (xd >> 7) | (xd >> 14) | (xd >> 21)) & 0xFu;                 // the dword's delimiters: bit j
+        const uint32_t L16 = (uint32_t)__ballot(lane < 16 && (x4 == ',' || x4 == ';')) & 0xFFFFu;   // ... those of the 16 characters behind the chunk
+        // where the group ends (its ';') and where this chunk's own tokens begin
+        const uint64_t semis = __ballot(sm != 0u);
+        uint32_t hi = kStreamChunk;
+        bool cl = false;
+        if (semis) {
+            const int ls = __ffsll((unsigned long long)semis) - 1;
+            hi = 4u * (uint32_t)ls + ((uint32_t)__ffs((int)lane_valu(sm, ls)) - 1u) / 8u;
+            cl = true;
+        }
+        if (skip && (uint32_t)lane == (skip - 1u) >> 2) d4 |= 1u << ((skip - 1u) & 3u);   // the list's first character follows the header as if it followed a delimiter
+        uint32_t lo = 0;
+        if (skip) lo = skip;
+        else if (!prev_delim) {   // the token that began in the chunk before is that chunk's
+            const uint64_t dels = __ballot(d4 != 0u);
+            lo = kStreamChunk;
+            if (dels) { const int ld = __ffsll((unsigned long long)dels) - 1; lo = 4u * (uint32_t)ld + (uint32_t)__ffs((int)lane_valu(d4, ld)) - 1u; }
+        }
+        // the lane's window: bit 0 = the character in front of the dword, bits 1..4 the dword's, bits 5..16 the twelve behind it
+        const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d4, 0x130, 0xF, 0xF, true);   // wave_shl:1 -- lane i takes lane i + 1's
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, 0x130, 0xF, 0xF, true);
+        const uint32_t a3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a2, 0x130, 0xF, 0xF, true);
+        uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d4, 0x138, 0xF, 0xF, true) >> 3;       // wave_shr:1 -- the lane in front's last character
+        if (lane == 0) pv = prev_delim ? 1u : 0u;
+        uint32_t W = d4 | (a1 << 4) | (a2 << 8) | (a3 << 12);
+        if (lane >= 61) W |= (L16 << (4u * (64u - (uint32_t)lane))) & 0xFFFFu;
+        W = (W << 1) | pv;
+        const uint32_t base = 4u * (uint32_t)lane;
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, ends = 0, badv = 0;
 #pragma unroll
-        for (int sc = 0; sc < kSub; sc++) {
-            if (cl) break;
-            uint64_t Sm_next = 0, D_next = D_look;
-            if (sc + 1 < kSub) { Sm_next = __ballot(x[sc + 1 < kSub ? sc + 1 : 0] == ';'); D_next = Sm_next | __ballot(x[sc + 1 < kSub ? sc + 1 : 0] == ','); }
-            int lo = 0, hi = 64;
-            if (Sm_cur) { hi = __ffsll((unsigned long long)Sm_cur) - 1; cl = true; }
-            if (sc == 0 && !prev_delim) lo = D_cur ? __ffsll((unsigned long long)D_cur) - 1 : 64;
-            if (sc == 0 && skip) lo = (int)skip;
-            const uint32_t w = window32((D_cur << 1) | pd, (D_next << 1) | (D_cur >> 63), lane);
-            const bool own = (uint32_t)(lane - lo) < (uint32_t)(hi - lo) && lo < hi;
-            const bool start = own && (w & 3u) == 1u;
-            const bool end = own && (w & 6u) == 4u;
-            uint32_t e = (uint32_t)__ffs((int)(w >> 1)) - 1u;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t wj = W >> j;   // bit 0 the character in front, bit 1 this one, bit 2 the next
+            const bool own = base + (uint32_t)j - lo < hi - lo && lo < hi;
+            const bool start = own && (wj & 3u) == 1u;
+            const bool end = own && (wj & 6u) == 4u;
+            uint32_t e = (uint32_t)__ffs((int)(wj >> 1)) - 1u;
             e = e < 10u ? e : 10u;
-            const uint32_t dv = x[sc] - (uint32_t)'0';
+            const uint32_t dv = ((w >> (8 * j)) & 0xFFu) - (uint32_t)'0';
             uint32_t c = ptab[(e << 4) | (dv & 15u)];
             c = own ? c : 0u;
             c += start ? 1u : 0u;
-            const uint32_t run = wave_incl_scan(c);
-            const uint64_t eb = __ballot(end);
-            if (keep && end) S.tok[(qtail + nends + (uint32_t)__popcll(eb & lanemask_lt())) & (kStreamRing - 1u)] = Rcarry + rsum_v + run - 1u;
-            bad |= __ballot(own && !(w & 2u) && dv > 9u) | __ballot(start && e >= 10u);
-            rsum_v += lane_valu(run, 63);
-            nends += (uint32_t)__popcll(eb);
-            if (sc == kSub - 1 && !cl) open_tail = ((D_cur >> 63) == 0) && ((D_look & 1ull) == 0);
-            D_last = D_cur;
-            pd = D_cur >> 63; D_cur = D_next; Sm_cur = Sm_next;
+            if (j == 0) c0 = c; else if (j == 1) c1 = c; else if (j == 2) c2 = c; else c3 = c;
+            ends |= end ? 1u << j : 0u;
+            badv |= (own && ((ndm & ~dlm) >> (8 * j + 7) & 1u)) || (start && e >= 10u) ? 1u : 0u;
         }
-        (void)D_last;
+        const uint32_t p0 = c0, p1 = p0 + c1, p2 = p1 + c2, p3 = p2 + c3;
+        const uint32_t run = wave_incl_scan(p3);
+        const uint32_t rsum0 = lane_valu(run, 63);
+        const uint64_t E1 = __ballot(ends != 0u), E2 = __ballot((ends & (ends - 1u)) != 0u);   // lanes with a token's end, with two (four characters hold no more)
+        const uint32_t nends = (uint32_t)__popcll(E1) + (uint32_t)__popcll(E2);
+        const uint32_t qtail = qhead + qn;
+        if (keep && ends) {
+            const uint32_t at = qtail + (uint32_t)__popcll(E1 & lanemask_lt()) + (uint32_t)__popcll(E2 & lanemask_lt());
+            const uint32_t front = Rcarry + run - p3 - 1u;
+            const uint32_t j1 = (uint32_t)__ffs((int)ends) - 1u;
+            S.tok[at & (kStreamRing - 1u)] = front + (j1 == 0u ? p0 : (j1 == 1u ? p1 : (j1 == 2u ? p2 : p3)));
+            const uint32_t rest = ends & (ends - 1u);
+            if (rest) {
+                const uint32_t j2 = (uint32_t)__ffs((int)rest) - 1u;   // 2 or 3
+                S.tok[(at + 1u) & (kStreamRing - 1u)] = front + (j2 == 2u ? p2 : p3);
+            }
+        }
+        uint64_t bad = __ballot(badv != 0u);
+        uint32_t rsum_v = rsum0;
+        // the chunk's last character inside a token that goes on behind it
+        const bool open_tail = !cl && ((lane_valu(W, 63) >> 4) & 3u) == 0u;   // (bit 4: the chunk's last character, bit 5: the first one behind it)
+        const uint64_t D_look = (uint64_t)L16 | ~0xFFFFull;
         uint32_t ntok = nends;
         if (open_tail) {
             const int k = __ffsll((unsigned long long)D_look) - 1;   // 1..16
@@ -344,7 +380,7 @@ struct KF {
             ntok = nends + 1u;
         }
         if (bad) bad_text = true;
-        prev_delim = lane_valu(x[kSub - 1], 63) == (uint32_t)',';
+        prev_delim = (lane_valu(w, 63) >> 24) == (uint32_t)',';
         closed = cl;
         // (the cursors are wave-uniform by construction; saying so keeps them and the arithmetic on them in scalar registers)
         if (keep) qn = uniu(qn + ntok);
@@ -607,10 +643,35 @@ struct KF {
                 uint32_t ins_off = 0;
                 if (kIns && p.insertions && fin && op == 1u) {
                     // a base inside an insertion: a call on the reference base left of it, with its 1-based offset truncated like
-                    // make_key's uint16 (mod.c:428, :864-874); listed calls only here (kIns has no '.' groups)
+                    // make_key's uint16 (mod.c:428, :864-874)
                     ins_off = (e + 1u) & 0xFFFFu;
                     ref_pos = pos + (int32_t)b_s - 1;
                     call = ref_pos >= 0;
+                }
+                if (kIns && kDot && p.insertions && rev && !expl) {
+                    // ... but an IMPLICIT call of a reverse read that is not on an aligned base (inside an insertion, or in a soft
+                    // clip) takes the anchor of the base at the mirrored position, if that one lies inside an insertion, and no call
+                    // else; its offset stays its own (0 in a clip).  The whole CIGAR is in the table here (dot_ins_far).
+                    const bool odd = fin && !((0x181u >> op) & 1u);
+                    if (__ballot(odd)) {
+                        const uint32_t q2 = L - 1u - q, qi2 = q2 - q_shift;
+                        const bool in2 = odd && qi2 < q_total;
+                        const uint32_t ck2 = in2 ? search_le<kSegCk>(S.cq, qi2, c_n) : 0u;
+                        const uint32_t a20 = S.cq[ck2], b20 = S.cr[ck2];
+                        const uint4 ov2 = in2 ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck2) : make_uint4(0, 0, 0, 0);
+                        const uint32_t p0 = ov2.x & 15u, p1 = ov2.y & 15u, p2 = ov2.z & 15u, p3 = ov2.w & 15u;
+                        const uint32_t m0 = ov2.x >> 4, m1 = ov2.y >> 4, m2 = ov2.z >> 4;
+                        const uint32_t a21 = a20 + (m0 & op_mask(0x193u, p0)), a22 = a21 + (m1 & op_mask(0x193u, p1)), a23 = a22 + (m2 & op_mask(0x193u, p2));
+                        const uint32_t b21 = b20 + (m0 & op_mask(0x18Du, p0)), b22 = b21 + (m1 & op_mask(0x18Du, p1)), b23 = b22 + (m2 & op_mask(0x18Du, p2));
+                        const uint32_t k2 = (qi2 >= a21 ? 1u : 0u) + (qi2 >= a22 ? 1u : 0u) + (qi2 >= a23 ? 1u : 0u);
+                        const uint32_t op2 = k2 == 0u ? p0 : (k2 == 1u ? p1 : (k2 == 2u ? p2 : p3));
+                        const uint32_t bs2 = k2 == 0u ? b20 : (k2 == 1u ? b21 : (k2 == 2u ? b22 : b23));
+                        if (odd) {
+                            ref_pos = pos + (int32_t)bs2 - 1;
+                            call = in2 && op2 == 1u && ref_pos >= 0;
+                            ins_off = op == 1u ? ins_off : 0u;
+                        }
+                    }
                 }
                 uint32_t w = 0;
                 // Is the position a site of the group's context class, and which one: the class's site word (32 positions: which are
@@ -911,7 +972,10 @@ struct KF {
                     gflags = uniu(S.memo_flags[slot]); c01 = uniu(S.memo_c01[slot]); c23 = uniu(S.memo_c23[slot]);
                     if (lane < 4u) ci_w = S.memo_ci[slot][lane];
                     lstart = mpos + hlen;
-                    if (kIns && (gflags & 4u)) st = 1;   // ('.' groups under --insertions / --haplotypes: the tile pipeline's)
+                    if (kIns && (gflags & 4u)) {   // a '.' group under --insertions / --haplotypes (round 4)
+                        if (!kDot) { st = 1; saw_dot = true; }
+                        else if (dot_ins_far()) st = 1;
+                    }
                 } else {
                     GroupHdr g = hp_.parse_header_ch(ch, mlen, mpos);
                     lstart = g.lstart;
@@ -920,6 +984,7 @@ struct KF {
                     else {
                         if (g.modbase == 'N') st = 1;   // the tile pipeline has the direct groups
                         if (!kDot && g.flag == '.') { st = 1; saw_dot = true; }   // ... and, for this instantiation, the implicit calls
+                        if (kDot && kIns && g.flag == '.' && dot_ins_far()) st = 1;
                         hp_.err = 0;
                         hp_.lookup_codes(g);
                         if (__ballot(hp_.err != 0)) st = 1;
@@ -1153,7 +1218,7 @@ __global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)
             const unsigned int at = atomicAdd(P.tile_plan_count, 1u);
             P.tile_items[at] = ridx;
             if (P.host_tile_flag) *P.host_tile_flag = 1u;
-            if (!kDot && !kIns && k.saw_dot && P.host_dot_flag) *P.host_dot_flag = 1u;
+            if (!kDot && k.saw_dot && P.host_dot_flag) *P.host_dot_flag = 1u;
         }
         if (st == 2 && lane_id() == 0) {   // an input error somewhere in the read: the fused kernel names it
             const unsigned int at = atomicAdd(P.fb_count, 1u);

@@ -31,6 +31,11 @@ cases = {
   "dot_hp_ins": dict(gen=dict(n=150, dot_fraction=1.0, haplotypes=True, long_insertions=True, max_len=20000.0), c=[("m","C")], th=[0.7],
                      kw=dict(insertions=True, haplotypes=True)),
   "star_ctx_single": dict(gen=dict(n=200, single_code=True), c=[("m","*")], th=[0.9], kw={}),
+  # round 4: '.' groups under --insertions / --haplotypes in k_stream_reads -- HiFi-shape reads (their whole CIGAR is in the
+  # kernel's table: reverse reads take the mirrored anchor of mod.c:1234, :1314 there), and --haplotypes alone on ONT shapes
+  "hifi_dot_hp_ins": dict(gen=dict(n=300, shape=1, dot_fraction=1.0, haplotypes=True, long_insertions=True), c=[("m","C")], th=[0.7],
+                          kw=dict(insertions=True, haplotypes=True)),
+  "dot_hp_only": dict(gen=dict(n=150, dot_fraction=1.0, haplotypes=True, max_len=20000.0), c=[("m","CG")], th=[0.8], kw=dict(haplotypes=True)),
   "dot_long": dict(gen=dict(n=60, dot_fraction=1.0), c=[("m","C")], th=[0.8], kw={}),   # view: tens of thousands of rows per read
   # BASELINE.json configs[2]: multi-mod -c m[CG],h[CG] -m 0.8,0.7 on PacBio-HiFi-shape reads with the MM '?' flag
   "hifi_q_multimod": dict(gen=dict(n=600, shape=1, dot_fraction=0.0), c=[("m","CG"),("h","CG")], th=[0.8,0.7], kw={}),
@@ -39,12 +44,15 @@ for name, cs in cases.items():
     g = dict(cs["gen"]); n = g.pop("n")
     b = synth.batch(ref, 0, n, seed=77, n_reads_total=n, **g)
     eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], force_fused=FUSED, stream_mode=STREAM_MODE, **cs["kw"])
+    eng.stats_enable(True)
     eng.process(b)
+    st = eng.stats_get()
     got = eng.finalize(); eng.close()
     orc = O.Oracle(cs["c"], cs["th"], ["chrS"], **cs["kw"]); orc.add_contig("chrS", ref); orc.process(b, threads=8)
     want = orc.rows()
     key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
-    out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max())}
+    out[name] = {"rows": int(len(want)), "equal": key(got, "ins_offset") == key(want, "ins_off"), "max_l": int(b["reads"]["l_qseq"].max()),
+                 "to_tiles": st["stream_to_tiles"], "streamed": st["stream_done"], "rev_long": int(((b["reads"]["flag"] & 16) != 0).sum())}
     # the same batch through view mode: rows in print_view_output order, element for element
     eng = minimod_amd.FreqEngine([(c, x, t) for (c, x), t in zip(cs["c"], cs["th"])], [("chrS", len(ref), ref)], view=True, force_fused=FUSED, stream_mode=STREAM_MODE, **cs["kw"])
     v = eng.view(b); eng.close()
@@ -61,7 +69,12 @@ def test_synthetic_shapes_match_oracle(fused, stream_mode):
     r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, fused, stream_mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long", "hifi_q_multimod"}
+    assert set(res) == {"ont_long", "hifi_dot", "dot_hp_ins", "star_ctx_single", "dot_long", "hifi_q_multimod", "hifi_dot_hp_ins", "dot_hp_only"}
+    if fused == 0 and stream_mode == 3:   # the '.'-capable instantiations from the first launch on
+        assert res["hifi_dot_hp_ins"]["to_tiles"] == 0 and res["hifi_dot_hp_ins"]["streamed"] == 300, res["hifi_dot_hp_ins"]
+        assert res["dot_hp_only"]["to_tiles"] == 0, res["dot_hp_only"]
+        # ONT-shape reads under --insertions: the forward ones stream, the reverse ones of more than 512 ops are the tile pipeline's
+        assert 0 < res["dot_hp_ins"]["streamed"] and res["dot_hp_ins"]["to_tiles"] <= res["dot_hp_ins"]["rev_long"], res["dot_hp_ins"]
     for name, v in res.items():
         assert v["rows"] > 1000, (name, v)
         assert v["equal"], (name, v)
