@@ -99,6 +99,12 @@ struct StreamLdsT {
     // 12-14 codes per token), the codes and their packed table entries
     uint32_t g_mpos[kStreamGroups], g_lstart[kStreamGroups], g_flags[kStreamGroups], g_c01[kStreamGroups], g_c23[kStreamGroups];
     uint32_t g_end[kStreamGroups];   // the group's ';' (or the string's end)
+    // side-list appends (round 4): the wavefront reserves kSideChunk records of its region at a time and hands them out itself --
+    // one atomic with a return value per chunk instead of one per round and code (the lanes of the round waited for it: a trip to the
+    // memory side in the middle of every round of a --insertions run).  [at, end) is what is left of the chunk, kf a key of the chunk:
+    // what is left when the next chunk is taken, or when the kernel ends, is filled with (kf, increment 0) -- the lists' readers
+    // take every record below the cursor.  In LDS because the appends sit in divergent code (only the lanes with an update run them).
+    uint32_t sres_at, sres_end, sres_klo, sres_khi;
     uint32_t g_ci[kStreamGroups][4];
     // the headers this wave resolved last, by group ordinal: the reads of a file nearly all carry the same ones, and a header
     // whose characters are those of the memo needs neither the checks nor the code table again
@@ -534,13 +540,35 @@ struct KF {
     }
 
     __device__ __forceinline__ void side_append(int32_t spos, uint32_t ins_off, int is_mod, int code) {
-        // (the rare path: what it needs of the read is fetched again rather than kept in registers)
-        const int tid = p.reads[ridx_cur].tid;
-        const int64_t ref_base = p.ref_base[tid];
+        const int tid = tid_cur;
+        const int64_t ref_base = ref_base_g;   // (round 3 fetched both again here, two dependent loads a round: rare then, every round of a --insertions run)
         const int hpk = kIns ? hp : -1;
         unsigned long long key;
         if (side_key(ref_base + spos, rev, code, ins_off, hpk, key)) {
-            if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL;
+            if (!kIns) { if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL; return; }
+            // (the lanes that are here together: those of the round with a side update that has a 64-bit key)
+            const uint64_t m = __ballot(1);
+            const uint32_t cnt = (uint32_t)__popcll(m), mine = (uint32_t)__popcll(m & lanemask_lt());
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            const uint32_t region = uniu(((uint32_t)blockIdx.x * 4u + ((uint32_t)threadIdx.x >> 6)) & (kSideRegions - 1u));
+            unsigned long long* const list = p.stab + 2ull * (unsigned long long)region * p.smask;
+            wave_sync();   // (what the leader of the lanes that were here last wrote: a fence, no instruction -- the lanes here are not all of the wave's)
+            uint32_t at = S.sres_at;
+            const uint32_t end = S.sres_end;
+            if (end - at < cnt) {
+                const unsigned long long kf = ((unsigned long long)S.sres_khi << 32) | S.sres_klo;
+                for (uint32_t i = at + mine; i < end; i += cnt)
+                    if ((unsigned long long)i < p.smask) { ulonglong2 z; z.x = kf; z.y = 0ull; *reinterpret_cast<ulonglong2*>(list + 2ull * i) = z; }
+                unsigned int base = 0;
+                if (lane_id() == leader) base = atomicAdd(p.scur + region * kSideCurStride, kSideChunk);
+                at = (uint32_t)__shfl((int)base, leader, 64);
+                if (lane_id() == leader) { S.sres_end = at + kSideChunk; S.sres_klo = (uint32_t)key; S.sres_khi = (uint32_t)(key >> 32); }
+            }
+            const unsigned long long idx = (unsigned long long)at + mine;
+            if (idx >= p.smask) err = MM_E_SIDEFULL;
+            else { ulonglong2 rec; rec.x = key; rec.y = is_mod ? 0x100000001ull : 1ull; *reinterpret_cast<ulonglong2*>(list + 2ull * idx) = rec; }
+            if (lane_id() == leader) S.sres_at = at + cnt;
+            wave_sync();
             return;
         }
         uint64_t m = __ballot(1);
@@ -557,6 +585,19 @@ struct KF {
         } else {
             err = MM_E_SIDEFULL;
         }
+    }
+
+    static constexpr uint32_t kSideChunk = 256;
+    // the unused records of the wavefront's last chunk (the kernel's end; wave-uniform)
+    __device__ __forceinline__ void side_fill_rest() {
+        wave_sync();
+        const uint32_t at = S.sres_at, end = S.sres_end;
+        if (at == end) return;
+        const unsigned long long kf = ((unsigned long long)S.sres_khi << 32) | S.sres_klo;
+        const uint32_t region = uniu(((uint32_t)blockIdx.x * 4u + ((uint32_t)threadIdx.x >> 6)) & (kSideRegions - 1u));
+        unsigned long long* const list = p.stab + 2ull * (unsigned long long)region * p.smask;
+        for (uint32_t i = at + (uint32_t)lane_id(); i < end; i += 64u)
+            if ((unsigned long long)i < p.smask) { ulonglong2 z; z.x = kf; z.y = 0ull; *reinterpret_cast<ulonglong2*>(list + 2ull * i) = z; }
     }
 
     __device__ __forceinline__ void flush_pending() {
@@ -1166,6 +1207,7 @@ __global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)
     KF<RefWord, kStats, kDot, kView, kIns> k(P, lds[threadIdx.x >> 6], ptab);
     const DevParams& p = P.d;
     if (lane_id() < (int)kStreamMemo) lds[threadIdx.x >> 6].memo_len[lane_id()] = 0u;   // no header remembered yet
+    if (lane_id() == 0) { lds[threadIdx.x >> 6].sres_at = 0u; lds[threadIdx.x >> 6].sres_end = 0u; }   // no side-list chunk yet
     if (P.reset_in_stream && blockIdx.x == 0) {   // the other control set (this launch uses its own until it ends)
         if (p.ctl_next && threadIdx.x < kCtlWords) p.ctl_next[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;
         if (p.queue_next && threadIdx.x < 192) p.queue_next[threadIdx.x * kQueueStride] = 0u;
@@ -1226,6 +1268,7 @@ __global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)
             if (P.host_fb_flag) *P.host_fb_flag = 1u;
         }
     }
+    if (kIns) k.side_fill_rest();
     if (kStats && p.stats) k.flush_stats((uint32_t)g & (kStatSlots - 1));
 #ifdef MM_STREAM_TIMING
     if (p.stats && lane_id() == 0) for (int i = 0; i < 9; i++) atomicAdd(p.stats + 7 + i, k.ftacc[i]);
