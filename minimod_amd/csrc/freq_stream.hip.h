@@ -59,6 +59,9 @@ constexpr uint32_t kStreamRing = 256;       // token ring, a power of two: at mo
 #define MM_STREAM_WAVES 7       // wavefronts per SIMD the kernel is built for: 72 registers (measured with 512-op CIGAR segments: C2 33.3 us
                                 // per batch against 34.8 at 6 / 80 registers and 37.8 at 5 / 96; view 0.140 against 0.134)
 #endif
+#ifndef MM_STREAM_WAVES_INS
+#define MM_STREAM_WAVES_INS 7   // ... the --insertions / --haplotypes one
+#endif
 #ifndef MM_STREAM_WAVES_DOT
 #define MM_STREAM_WAVES_DOT 6   // ... the '.'-capable instantiation: at 72 registers it spills 55 of them (C2 with '.' flags 179 against 172 us)
 #endif
@@ -1199,7 +1202,7 @@ struct KF {
 
 // kStats: the tally pass (work counts per wave, routing counts); the timed launches run the instantiation without them
 template <typename RefWord, bool kStats, bool kDot, bool kView, bool kIns>
-__global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : MM_STREAM_WAVES)) void k_stream_reads(const TileParams P) {
+__global__ __launch_bounds__(256, (kDot ? MM_STREAM_WAVES_DOT : (kIns ? MM_STREAM_WAVES_INS : MM_STREAM_WAVES))) void k_stream_reads(const TileParams P) {
     __shared__ StreamLdsT<kDot> lds[kWavesPerBlock];
     __shared__ uint32_t ptab[kSumTabWords];
     fill_sum_table(ptab);
