@@ -530,7 +530,17 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     fo.view = view;
     /* process_db is called per -K batch (src/minimod.c:344-350); the library stages consecutive batches in GPU memory and
      * launches them together.  view prints a launch's rows when the launch is retired. */
-    fo.coalesce = o.gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : o.gather;   /* (view as well since round 4: a launch's rows are printed from the group's journal) */
+    int gather = o.gather;
+    if (replay && gather == MMH_MAX_GATHER) {
+        /* a run that replays the reference's row order keeps a launch's batches and its calls on the host until the launch has been
+         * replayed: launches of about 24 000 reads (still streamed) instead of as many as the staging takes -- the replay of one
+         * launch then runs beside the loading of the next ones, and 1.3 GB less is held (3 Gbases of HiFi reads, two codes: 1.96 ->
+         * 1.76 s, tools/c3_replay_sweep.sh).  (The replay on a thread of its own, beside the submits, was slower: 1.86 s -- the
+         * loop is bound by the 16 cores the loader and the replay share, not by who waits for whom.) */
+        int g = (24576 + (o.K > 0 ? o.K : 512) - 1) / (o.K > 0 ? o.K : 512);
+        gather = g < 6 ? 6 : (g > MMH_MAX_GATHER ? MMH_MAX_GATHER : g);
+    }
+    fo.coalesce = gather > MMH_MAX_GATHER ? MMH_MAX_GATHER : gather;   /* (view as well since round 4: a launch's rows are printed from the group's journal) */
     mm_freq_t *h = mm_freq_create(&fo, hdr->n_targets, ctg, ws->sharded ? ws->n_iv : 0, ws->sharded ? ws->iv : NULL, err, sizeof err);
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     tl_mark(realtime0, "mm_freq_create done");
@@ -894,7 +904,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             double tr = mmh_realtime();
             ordered = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
             if (ordered) memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
-            if (!ordered || mmh_tie_order_rows(tie, ordered, nrows) != 0) {
+            if (!ordered || mmh_tie_order_rows_mt(tie, pool, ordered, nrows) != 0) {
                 MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
                 free(ordered); ordered = NULL;
             } else rows = ordered;

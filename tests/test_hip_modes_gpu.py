@@ -421,3 +421,18 @@ def test_library_first_then_torch_share_one_hip_runtime():
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     x, n_rows, n_hip = r.stdout.decode().strip().splitlines()[-1].split()
     assert int(x) == 28 and int(n_rows) > 0 and int(n_hip) == 1
+
+
+def test_bench_e2e_devices_leg():
+    """`bench.py --e2e-gbases G --e2e-devices 0,0`: the steady-state end-to-end job (one BAM written in pieces, its index merged from the
+    pieces') through `minimod freq` once as a single run and once as two --devices workers sharing the box's GPU -- same bytes, and
+    the line says what every worker spent where."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e-gbases", "0.06", "--e2e-devices", "0,0", "--batch", "1024"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["parity_vs_cpu"]["byte_identical"] and d["reads"] > 3000
+    dv = d["devices_run"]
+    assert dv["n_workers"] == 2 and dv["byte_identical_to_single_run"] and len(dv["workers"]) == 2
+    assert sum(w["reads"] for w in dv["workers"]) == d["reads"] and all(w["device"] == 0 for w in dv["workers"])
+    assert dv["parent_merge_s"] is not None and dv["wall_s"] > 0

@@ -27,6 +27,8 @@ def _lib():
                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
     L.mmh_tie_order_rows.restype = ctypes.c_int
     L.mmh_tie_order_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    L.mmh_tie_order_rows_mt.restype = ctypes.c_int
+    L.mmh_tie_order_rows_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     L.mmh_tie_destroy.argtypes = [ctypes.c_void_p]
     L.mm_pool_create.restype = ctypes.c_void_p
     L.mm_pool_create.argtypes = [ctypes.c_int]
@@ -85,7 +87,7 @@ def replay_order(bam_path, contigs, c="m", m=None, insertions=False, haplotypes=
     out = np.zeros(len(want_rows), dtype=ROW_DTYPE)
     out["tid"], out["pos"], out["strand"], out["code"] = want_rows["tid"], want_rows["pos"], want_rows["strand"], want_rows["code"]
     out["ins_offset"], out["hp"], out["n_called"], out["n_mod"] = want_rows["ins_off"], want_rows["hp"], want_rows["n_called"], want_rows["n_mod"]
-    assert L.mmh_tie_order_rows(tie, out.ctypes.data, len(out)) == 0
+    assert L.mmh_tie_order_rows_mt(tie, pool, out.ctypes.data, len(out)) == 0   # (the worker pool helps where the walk is not the reference's own)
     L.mmh_tie_destroy(tie)
     L.mm_pool_destroy(pool)
     res = np.zeros(len(out), dtype=O.ROW_DTYPE)
