@@ -142,9 +142,10 @@ static int ktab_grow(ktab_t *t, uint32_t want, const uint32_t *hash) {
      * bucket of the OLD table) still holds an element not yet moved, the two swap and the evicted one goes next */
     uint8_t *old = t->used;
     const uint32_t mask = nb - 1;
+    const int big = t->n_buckets >= 8192;   /* (a read's own table is in the cache anyway) */
     for (uint32_t j = 0; j < t->n_buckets; j++) {
         /* (the walk is in bucket order, its targets are anywhere: the bucket sixteen ahead says where its element will go) */
-        if (j + 16 < t->n_buckets && old[j + 16]) { const uint32_t pf = hash[t->id[j + 16]] & mask; __builtin_prefetch(&nused[pf], 1); __builtin_prefetch(&t->id[pf], 1); }
+        if (big && j + 16 < t->n_buckets && old[j + 16]) { const uint32_t pf = hash[t->id[j + 16]] & mask; __builtin_prefetch(&nused[pf], 1); __builtin_prefetch(&t->id[pf], 1); }
         if (!old[j]) continue;
         uint32_t key = t->id[j];
         old[j] = 0;
@@ -169,7 +170,9 @@ static int ktab_put(ktab_t *t, uint32_t key, const uint32_t *hash, const tkey_t 
     const uint32_t mask = t->n_buckets - 1;
     uint32_t i = hash[key] & mask, step = 0;
     const uint32_t last = i;
-    while (t->used[i] && !tkey_eq(&keys[t->id[i]], &keys[key])) {
+    const uint32_t hk = hash[key];
+    /* (an occupied slot's key is first told apart by its hash -- equal keys have equal hashes -- and only then fetched) */
+    while (t->used[i] && !(hash[t->id[i]] == hk && tkey_eq(&keys[t->id[i]], &keys[key]))) {
         i = (i + (++step)) & mask;
         if (i == last) return -1;   /* cannot happen below the load bound */
     }
