@@ -375,35 +375,73 @@ static int stamp_add_locked(mmh_tie_t *t, tshard_t *s, uint64_t mix, const tkey_
 }
 
 /* the first-insertion sequence from the stamps: every table's keys, ordered by stamp (LSD radix sort, 11 bits a pass) */
-static int seq_build(mmh_tie_t *t) {
+typedef struct { uint64_t stamp; uint32_t shard, idx; } ent_t;
+#define SQ_PARTS 64   /* pieces of the array a radix pass is counted and scattered in (any number of threads take them) */
+typedef struct { mmh_tie_t *t; ent_t *a, *b; size_t n; const size_t *off; int shift; size_t *cnt; /* [SQ_PARTS][2048] */ uint64_t top[TS_SHARDS]; } seqjob_t;
+static void seq_gather(void *arg, int64_t lo, int64_t hi) {   /* a table's stamps behind those of the tables in front of it */
+    seqjob_t *q = (seqjob_t *)arg;
+    for (int64_t sh = lo; sh < hi; sh++) {
+        const tshard_t *s = &q->t->shard[sh];
+        ent_t *a = q->a + q->off[sh];
+        uint64_t top = 0;
+        for (size_t i = 0; i < s->n; i++) { a[i].stamp = s->stamp[i]; a[i].shard = (uint32_t)sh; a[i].idx = (uint32_t)i; if (s->stamp[i] > top) top = s->stamp[i]; }
+        q->top[sh] = top;
+    }
+}
+static void seq_count(void *arg, int64_t lo, int64_t hi) {
+    seqjob_t *q = (seqjob_t *)arg;
+    for (int64_t p = lo; p < hi; p++) {
+        size_t *c = q->cnt + (size_t)p * 2048;
+        memset(c, 0, sizeof(size_t) * 2048);
+        const size_t i0 = q->n * (size_t)p / SQ_PARTS, i1 = q->n * (size_t)(p + 1) / SQ_PARTS;
+        for (size_t i = i0; i < i1; i++) c[(q->a[i].stamp >> q->shift) & 2047]++;
+    }
+}
+static void seq_scatter(void *arg, int64_t lo, int64_t hi) {   /* (cnt holds every piece's first place per digit: the pass stays stable) */
+    seqjob_t *q = (seqjob_t *)arg;
+    for (int64_t p = lo; p < hi; p++) {
+        size_t *c = q->cnt + (size_t)p * 2048;
+        const size_t i0 = q->n * (size_t)p / SQ_PARTS, i1 = q->n * (size_t)(p + 1) / SQ_PARTS;
+        for (size_t i = i0; i < i1; i++) q->b[c[(q->a[i].stamp >> q->shift) & 2047]++] = q->a[i];
+    }
+}
+static void seq_emit(void *arg, int64_t lo, int64_t hi) {
+    seqjob_t *q = (seqjob_t *)arg;
+    mmh_tie_t *t = q->t;
+    for (int64_t i = lo; i < hi; i++) { t->keys[i] = t->shard[q->a[i].shard].keys[q->a[i].idx]; t->hash[i] = t->shard[q->a[i].shard].hash[q->a[i].idx]; }
+}
+/* the first-insertion sequence from the stamps: every table's keys, ordered by stamp (LSD radix sort, 11 bits a pass; `pool` may be NULL) */
+static int seq_build_mt(mmh_tie_t *t, mm_pool_t *pool) {
     if (t->seq_valid) return 0;
-    size_t n = 0;
-    for (int i = 0; i < TS_SHARDS; i++) n += t->shard[i].n;
+    size_t n = 0, off[TS_SHARDS + 1];
+    for (int i = 0; i < TS_SHARDS; i++) { off[i] = n; n += t->shard[i].n; }
+    off[TS_SHARDS] = n;
     free(t->keys); free(t->hash); t->keys = NULL; t->hash = NULL; t->n = t->cap = 0;
-    typedef struct { uint64_t stamp; uint32_t shard, idx; } ent_t;
     ent_t *a = (ent_t *)malloc(sizeof(ent_t) * (n ? n : 1)), *b = (ent_t *)malloc(sizeof(ent_t) * (n ? n : 1));
     t->keys = (tkey_t *)malloc(sizeof(tkey_t) * (n ? n : 1)); t->hash = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
-    if (!a || !b || !t->keys || !t->hash) { free(a); free(b); return -1; }
-    size_t w = 0;
+    seqjob_t *q = (seqjob_t *)calloc(1, sizeof(seqjob_t));
+    size_t *cnt = (size_t *)malloc(sizeof(size_t) * 2048 * SQ_PARTS);
+    if (!a || !b || !t->keys || !t->hash || !q || !cnt) { free(a); free(b); free(q); free(cnt); return -1; }
+    q->t = t; q->a = a; q->b = b; q->n = n; q->off = off; q->cnt = cnt;
+    mm_pool_for(pool, TS_SHARDS, 4, seq_gather, q);
     uint64_t top = 0;
-    for (uint32_t sh = 0; sh < TS_SHARDS; sh++)
-        for (size_t i = 0; i < t->shard[sh].n; i++) { a[w].stamp = t->shard[sh].stamp[i]; a[w].shard = sh; a[w].idx = (uint32_t)i; if (a[w].stamp > top) top = a[w].stamp; w++; }
-    size_t *cnt = (size_t *)malloc(sizeof(size_t) * 2048);
-    if (!cnt) { free(a); free(b); return -1; }
+    for (int i = 0; i < TS_SHARDS; i++) if (q->top[i] > top) top = q->top[i];
     for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 11) {
-        memset(cnt, 0, sizeof(size_t) * 2048);
-        for (size_t i = 0; i < n; i++) cnt[(a[i].stamp >> shift) & 2047]++;
+        q->shift = shift;
+        mm_pool_for(pool, SQ_PARTS, 1, seq_count, q);
         size_t run = 0;
-        for (int d = 0; d < 2048; d++) { const size_t c = cnt[d]; cnt[d] = run; run += c; }
-        for (size_t i = 0; i < n; i++) b[cnt[(a[i].stamp >> shift) & 2047]++] = a[i];
-        ent_t *tmp = a; a = b; b = tmp;
+        for (int d = 0; d < 2048; d++)
+            for (int p = 0; p < SQ_PARTS; p++) { const size_t c = cnt[(size_t)p * 2048 + d]; cnt[(size_t)p * 2048 + d] = run; run += c; }
+        mm_pool_for(pool, SQ_PARTS, 1, seq_scatter, q);
+        ent_t *tmp = q->a; q->a = q->b; q->b = tmp;
     }
-    for (size_t i = 0; i < n; i++) { t->keys[i] = t->shard[a[i].shard].keys[a[i].idx]; t->hash[i] = t->shard[a[i].shard].hash[a[i].idx]; }
-    free(a); free(b); free(cnt);
+    mm_pool_for(pool, (int64_t)n, 65536, seq_emit, q);
+    free(q->a); free(q->b); free(q); free(cnt);
     t->n = t->cap = n;
     t->seq_valid = 1;
     return 0;
 }
+static int seq_build(mmh_tie_t *t) { return seq_build_mt(t, NULL); }
 
 /* per read: its keys in the slot order of its own table */
 typedef struct {
@@ -706,7 +744,7 @@ int mmh_tie_order_rows_mt(mmh_tie_t *t, mm_pool_t *pool, mm_row_t *rows, int64_t
     const int timing = getenv("MM_TIE_TIMING") != NULL;
     double tp[5] = {0, 0, 0, 0, 0};
     tp[0] = mmh_realtime();
-    if (seq_build(t) != 0) return -1;
+    if (seq_build_mt(t, pool) != 0) return -1;
     tp[1] = mmh_realtime();
     if ((size_t)n != t->n) return -1;   /* the replay saw another set of keys than the counters hold: do not guess */
     /* the core table: keys in first-insertion order */
