@@ -91,6 +91,14 @@ static inline uint32_t key_hash_from(uint32_t hc, const tkey_t *k, const char *c
     h = (h << 5) - h + (uint32_t)'\t'; h = x31_dec(h, k->hp);
     return h;
 }
+/* a fixed piece of the string as h -> h * mul + add (mul = 31^length, add = the piece's own sum): "\t+\tm\t" between the position and the
+ * insertion offset is one multiply-add per call, and so is the usual end "0\t-1" */
+typedef struct { uint32_t mul, add; } x31_piece_t;
+static inline x31_piece_t x31_piece(const char *p, size_t n) {
+    x31_piece_t q = {1u, 0u};
+    for (size_t i = 0; i < n; i++) { q.add = (q.add << 5) - q.add + (uint32_t)(unsigned char)p[i]; q.mul *= 31u; }
+    return q;
+}
 /* ... of "contig \t"; *plain = 0 when the string's first byte is NUL (khash's function stops there: the general routine does those) */
 static inline uint32_t x31_prefix(const char *contig, size_t clen, int *plain) {
     *plain = clen > 0 && contig[0] != 0;
@@ -534,6 +542,10 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
     mmh_tie_t *t = j->t;
     tscratch_t *ts = &g_ts;
     callord_t *ord = ts->ord, *tmp_ord = ts->tmp_ord; size_t ord_cap = ts->ord_cap, tmp_cap = ts->tmp_cap;
+    x31_piece_t mid[2][64];          /* "\t<strand>\t<code>\t" of the codes met in this range */
+    uint8_t mid_have[2][64];
+    memset(mid_have, 0, sizeof mid_have);
+    const x31_piece_t tail0 = x31_piece("0\t-1", 4);
     trec_t *recs = ts->recs; size_t n_recs = 0, recs_cap = ts->recs_cap;   /* the keys of this range's reads with their stamps */
     for (int64_t r = lo; r < hi; r++) {
         const int64_t a = j->first[r], b = j->first[r + 1];
@@ -575,6 +587,7 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
         const size_t clen = strlen(contig);
         int plain = 0;
         const uint32_t hc = x31_prefix(contig, clen, &plain);
+        const int strand = (rd->flag & 0x10) ? 1 : 0;
         size_t nk = 0;
         for (size_t i = 0; i < n; i++) {
             const mm_view_row_t *w = &j->rows[a + ord[i].row];
@@ -586,7 +599,22 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
                 k.tid = rd->tid; k.pos = w->pos; k.ins = t->insertions ? w->ins_offset : 0; k.code = (int16_t)w->code;
                 k.strand = (rd->flag & 0x10) ? 1 : 0;
                 k.hp = (int16_t)(t->haplotypes ? (v == 0 ? (int)rd->hp : -1) : -1);
-                keys[nk] = k; hash[nk] = plain ? key_hash_from(hc, &k, code, colen) : key_hash(&k, contig, clen, code, colen);
+                keys[nk] = k;
+                if (plain && w->code < 64) {
+                    if (!mid_have[strand][w->code]) {
+                        char tmpc[MM_CODE_LEN + 4];
+                        size_t tl = 0;
+                        tmpc[tl++] = '\t'; tmpc[tl++] = strand ? '-' : '+'; tmpc[tl++] = '\t';
+                        memcpy(tmpc + tl, code, colen < MM_CODE_LEN ? colen : MM_CODE_LEN - 1); tl += colen < MM_CODE_LEN ? colen : MM_CODE_LEN - 1;
+                        tmpc[tl++] = '\t';
+                        mid[strand][w->code] = x31_piece(tmpc, tl); mid_have[strand][w->code] = 1;
+                    }
+                    uint32_t h = x31_dec(hc, k.pos);
+                    h = h * mid[strand][w->code].mul + mid[strand][w->code].add;
+                    if (k.ins == 0 && k.hp == -1) h = h * tail0.mul + tail0.add;
+                    else { h = x31_dec(h, k.ins); h = (h << 5) - h + (uint32_t)'\t'; h = x31_dec(h, k.hp); }
+                    hash[nk] = h;
+                } else hash[nk] = plain ? key_hash_from(hc, &k, code, colen) : key_hash(&k, contig, clen, code, colen);
                 int pr = ktab_put(&tab, (uint32_t)nk, hash, keys);
                 if (pr < 0) j->failed = 1;
                 if (pr == 1) nk++;
