@@ -86,8 +86,7 @@ template <bool kDotLds>
 struct StreamLdsT {
     uint32_t mmw[kStreamChunk / 4 + 4];     // the chunk's characters
     uint32_t tok[kStreamRing];              // ranks of parsed tokens not yet called
-    // the directory segment (traversal order): which of a block's 32 bases are class members (bit n = base n of the block, BAM
-    // order), and the members in front of every FOURTH block, then the running total.  A call finds its four blocks with a 7-step
+    // the directory segment (traversal order): which of a block's 32 bases are class members (stream_block_mask's word), and the members in front of every FOURTH block, then the running total.  A call finds its four blocks with a 7-step
     // search, takes their bits with one 16-byte read and selects its base there -- round 3 kept a count per block and fetched the
     // block's 16 bytes of sequence from memory a second time (the whole read, once more, long after the L2 had let go of it)
     alignas(16) uint32_t dm[kSegBlocks];
@@ -143,38 +142,35 @@ __device__ __forceinline__ uint32_t stream_block_count(uint4 v, uint32_t pat, ui
     if (pat == 0u) c -= 32u - min(32u, L - b * 32u);   // the padding behind the read's last base is none of C, G, T, N either
     return c;
 }
-// the eight match bits of a word (bit 4n+3 = nibble n) side by side: bit n = nibble n
-__device__ __forceinline__ uint32_t match_byte(uint32_t m) {
-    uint32_t x = m >> 3;
-    x = (x | (x >> 3)) & 0x03030303u;
-    x = (x | (x >> 6)) & 0x000F000Fu;
-    return (x | (x >> 12)) & 0xFFu;
-}
-// which of block b's 32 bases are members of the class: bit n = base n (a byte holds base 2i in its HIGH nibble: neighbours swap).
-// (Tried: the four words' match bits shifted into each other's gaps, no bit moved to its base's place -- 30 instructions fewer per
-// block, eight blocks a lane per read -- and the selection in a call's round paying for it: C2 36.5 against 35.5 us per batch.  What a
-// round's chain of dependent steps costs counts for more than what the passes over the whole read cost.)
+// Which of block b's 32 bases are members of the class, as ONE word: bit 4n + i = nibble n of the block's word i -- the four words'
+// match bits, which sit at 4n + 3, shifted into each other's gaps.  No bit is moved to its base's place here: eight blocks a lane are made
+// per read and only a few of them are ever asked (select_bit does the sorting out, for one block).  (With the freq units still built with
+// machine LICM -- scratch spills in the rounds -- the dearer selection made this form 2.7 % SLOWER than bits compacted to base order with
+// 31 instructions a block; without the spills it is 220 vector instructions a read fewer and 2.1 % faster: the unit is the bound.)
 __device__ __forceinline__ uint32_t stream_block_mask(uint4 v, uint32_t pat, uint32_t b, uint32_t L) {
     uint32_t m0, m1, m2, m3;
     block_bits(v, pat, m0, m1, m2, m3);
-    const uint32_t nib = match_byte(m0) | (match_byte(m1) << 8) | (match_byte(m2) << 16) | (match_byte(m3) << 24);
-    uint32_t mk = ((nib & 0x55555555u) << 1) | ((nib >> 1) & 0x55555555u);
-    const uint32_t valid = min(32u, L - b * 32u);
-    if (pat == 0u && valid < 32u) mk &= (1u << valid) - 1u;   // the padding behind the read's last base is none of C, G, T, N either
-    return mk;
+    if (pat == 0u) {   // the padding behind the read's last base is none of C, G, T, N either
+        const int valid = (int)min(32u, L - b * 32u);
+        m0 &= base_order(valid_bits(valid)); m1 &= base_order(valid_bits(valid - 8));
+        m2 &= base_order(valid_bits(valid - 16)); m3 &= base_order(valid_bits(valid - 24));
+    }
+    return (m0 >> 3) | (m1 >> 2) | (m2 >> 1) | m3;
 }
-// position of the k-th set bit of m (k counts from 0 and is below popcount(m))
-__device__ __forceinline__ uint32_t select_bit(uint32_t m, uint32_t k) {
-    uint32_t n = 0, c = __popc(m & 0xFFFFu);
-    bool ge = k >= c;
-    k -= ge ? c : 0u; n += ge ? 16u : 0u; m = ge ? m >> 16 : m;
-    c = __popc(m & 0xFFu); ge = k >= c;
-    k -= ge ? c : 0u; n += ge ? 8u : 0u; m = ge ? m >> 8 : m;
-    c = __popc(m & 0xFu); ge = k >= c;
-    k -= ge ? c : 0u; n += ge ? 4u : 0u; m = ge ? m >> 4 : m;
-    c = __popc(m & 3u); ge = k >= c;
-    k -= ge ? c : 0u; n += ge ? 2u : 0u; m = ge ? m >> 2 : m;
-    return n + (k >= (m & 1u) ? 1u : 0u);
+// the k-th member (k counts from 0 and is below the popcount) of such a word, in the order of the bases -> base 0 .. 31 of the block
+__device__ __forceinline__ uint32_t select_bit(uint32_t c, uint32_t k) {
+    const uint32_t s1 = __popc(c & 0x11111111u), s2 = s1 + __popc(c & 0x22222222u), s3 = s2 + __popc(c & 0x44444444u);
+    const uint32_t word = (k >= s1 ? 1u : 0u) + (k >= s2 ? 1u : 0u) + (k >= s3 ? 1u : 0u);
+    k -= word == 0u ? 0u : (word == 1u ? s1 : (word == 2u ? s2 : s3));
+    uint32_t mk = base_order((c >> word) & 0x11111111u);   // bit 4n <-> base n of the word (a byte holds base 2i in its HIGH nibble)
+    uint32_t n = 0, cn = __popc(mk & 0xFFFFu);
+    bool ge = k >= cn;
+    k -= ge ? cn : 0u; n += ge ? 4u : 0u; mk = ge ? mk >> 16 : mk;
+    cn = __popc(mk & 0xFFu);
+    ge = k >= cn;
+    k -= ge ? cn : 0u; n += ge ? 2u : 0u; mk = ge ? mk >> 8 : mk;
+    n += k >= (mk & 1u) ? 1u : 0u;
+    return word * 8u + n;
 }
 // all ones when bit `op` of `mask` is set, else 0 (one signed bit-field extract: which ops consume the read / the reference)
 __device__ __forceinline__ uint32_t op_mask(uint32_t mask, uint32_t op) { return (uint32_t)__builtin_amdgcn_sbfe((int)mask, op, 1u); }
@@ -191,6 +187,18 @@ __device__ __forceinline__ uint32_t search_le(const uint32_t* arr, uint32_t key,
     for (uint32_t m = N; m > 1u; m -= m >> 1) {
         const uint32_t half = m >> 1;
         const uint32_t at = min(lo + half, n);
+        lo = arr[at] <= key ? at : lo;
+    }
+    return lo;
+}
+// ... over a table whose entries behind the last one in use, up to N - 1, all hold the bound (the table's maker fills them): no probe
+// has to be kept inside the part in use, which is one vector instruction a step less, fourteen a call
+template <uint32_t N>
+__device__ __forceinline__ uint32_t search_le_padded(const uint32_t* arr, uint32_t key) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t m = N; m > 1u; m -= m >> 1) {
+        const uint32_t at = lo + (m >> 1);
         lo = arr[at] <= key ? at : lo;
     }
     return lo;
@@ -430,6 +438,7 @@ struct KF {
             }
         }
         if (lane == 0u) S.cw[(nb + 3u) >> 2] = run;
+        for (uint32_t c = ((nb + 3u) >> 2) + 1u + lane; c <= kSegBlocks / 4; c += 64u) S.cw[c] = kStreamInf;   // (search_le_padded)
         d_t0 = t0; d_n = nb; S_lo = s0; S_hi = run;
         wave_sync();
     }
@@ -513,7 +522,8 @@ struct KF {
                     if (c < nck) { S.cq[c] += qb; S.cr[c] += rb; }
                 }
             }
-            if (lane == 0u) S.cq[nck] = kStreamInf;
+            for (uint32_t c = nck + lane; c < kSegCk; c += 64u) S.cq[c] = kStreamInf;   // (the bound, up to the table's end: search_le_padded)
+            if (lane == 0u) S.cq[kSegCk] = kStreamInf;
             c_o0 = o0; c_n = nck; Q_lo = qb; Q_hi = qb + tq; R_lo = rb; R_hi = rb + tr;
             wave_sync();
         }
@@ -636,7 +646,7 @@ struct KF {
         if (n1 > 0u) {
             // rank -> four blocks: largest g with cw[g] <= rho (cw[0] = S_lo <= rho_0) -> the block among them by its members' counts
             const bool act = lane < n1;
-            const uint32_t g4 = act ? search_le<kSegBlocks / 4>(S.cw, rho, (d_n + 3u) >> 2) : 0u;
+            const uint32_t g4 = act ? search_le_padded<kSegBlocks / 4>(S.cw, rho) : 0u;
             const uint4 mb = *reinterpret_cast<const uint4*>(S.dm + 4u * g4);
             const uint32_t rg = rho - S.cw[g4];
             const uint32_t e1 = __popc(mb.x), e2 = e1 + __popc(mb.y), e3 = e2 + __popc(mb.z);
@@ -669,7 +679,7 @@ struct KF {
             const bool fin = lane < n_done && live;
             if (__ballot(fin)) {
                 // query position -> checkpoint (largest c with cq[c] <= qi) -> op: the checkpoint's four ops are walked
-                const uint32_t ck = fin ? search_le<kSegCk>(S.cq, qi, c_n) : 0u;
+                const uint32_t ck = fin ? search_le_padded<kSegCk>(S.cq, qi) : 0u;
                 const uint32_t a0 = S.cq[ck], b0 = S.cr[ck];
                 const uint4 ov = fin ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck) : make_uint4(0, 0, 0, 0);
                 const uint32_t o0 = ov.x & 15u, o1 = ov.y & 15u, o2 = ov.z & 15u, o3 = ov.w & 15u;
@@ -700,7 +710,7 @@ struct KF {
                     if (__ballot(odd)) {
                         const uint32_t q2 = L - 1u - q, qi2 = q2 - q_shift;
                         const bool in2 = odd && qi2 < q_total;
-                        const uint32_t ck2 = in2 ? search_le<kSegCk>(S.cq, qi2, c_n) : 0u;
+                        const uint32_t ck2 = in2 ? search_le_padded<kSegCk>(S.cq, qi2) : 0u;
                         const uint32_t a20 = S.cq[ck2], b20 = S.cr[ck2];
                         const uint4 ov2 = in2 ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck2) : make_uint4(0, 0, 0, 0);
                         const uint32_t p0 = ov2.x & 15u, p1 = ov2.y & 15u, p2 = ov2.z & 15u, p3 = ov2.w & 15u;
