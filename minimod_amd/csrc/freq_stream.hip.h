@@ -638,8 +638,12 @@ struct KF {
         const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
         // the directory segment that holds the round's first rank (ranks rise inside a group; a new group starts over)
+#ifdef MM_ABL_NODIR   // (diagnostic: a directory that claims every block holds 8 members, never built)
+        if (d_n == 0u) { d_t0 = 0; d_n = nblk < kSegBlocks ? nblk : kSegBlocks; S_lo = 0; S_hi = 0x7FFFFFFFu; }
+#else
         if (d_n == 0u || rho_0 < S_lo) build_dir(0u, 0u);
         while (rho_0 >= S_hi && d_t0 + d_n < nblk) build_dir(d_t0 + d_n, S_hi);
+#endif
         const uint32_t n1 = leading_ones(__ballot(lv && rho < S_hi));   // ranks whose block is in the segment
         KFT_LAP(3);
         uint32_t n_done = 0;
@@ -677,7 +681,11 @@ struct KF {
             if (__ballot(err != 0)) n_done = 0;
             KFT_LAP(5);
             const bool fin = lane < n_done && live;
+#ifdef MM_ABL_NOFINISH
+            if (false) {
+#else
             if (__ballot(fin)) {
+#endif
                 // query position -> checkpoint (largest c with cq[c] <= qi) -> op: the checkpoint's four ops are walked
                 const uint32_t ck = fin ? search_le_padded<kSegCk>(S.cq, qi) : 0u;
                 const uint32_t a0 = S.cq[ck], b0 = S.cr[ck];
@@ -893,7 +901,11 @@ struct KF {
                 rank = S.tok[(qhead + e_done + lane) & (kStreamRing - 1u)];
                 kidx = kdone + e_done + lane;
             }
+#ifdef MM_ABL_NOROUNDS   // (diagnostic builds, with tools/valu.sh: what the rounds cost -- their results are of course wrong)
+            const uint32_t nd = cnt;
+#else
             const uint32_t nd = round_core(rank, cnt, is_tok, kidx);
+#endif
             const uint64_t eb = __ballot(err != 0);
             if (nd == 0u || eb) { st = 2; break; }
             if (tail) r0 = uniu(r0 + nd);
