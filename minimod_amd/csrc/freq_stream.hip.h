@@ -286,6 +286,12 @@ struct KF {
     // ------------------------------------------------------------------ text -> ranks
     __device__ __forceinline__ void fetch_chunk(uint32_t c) {
         const uint32_t lane = (uint32_t)lane_id();
+        if (c + kStreamChunk + 16u <= mlen) {   // (every chunk but the text's last: nothing to replace behind the end, mm_dword's seven instructions a load)
+            __builtin_memcpy(&nx_w0, mm + c + 4u * lane, 4);
+            nx_w1 = 0u;
+            if (lane < 4u) __builtin_memcpy(&nx_w1, mm + c + kStreamChunk + 4u * lane, 4);
+            return;
+        }
         nx_w0 = mm_dword(mm, mlen, c + 4u * lane);
         nx_w1 = lane < 4u ? mm_dword(mm, mlen, c + kStreamChunk + 4u * lane) : 0u;
     }
@@ -617,7 +623,9 @@ struct KF {
         if (pend != kNoPend) {
             // (the first code's slot is wave-uniform: the lane keeps one word, not an address and an increment)
             const uint32_t slot = ((ci0 >> 23) & 127u) - 1u;
-            atomicAdd(gcb + ((uint64_t)(pend >> 1) * gnp + slot), (pend & 1u) ? 0x100000001ull : 1ull);
+            // (one code a class -- the usual run -- needs no 64-bit multiply for the counter's place: that instruction issues at a quarter of the rate)
+            const uint64_t at = gnp == 1u ? (uint64_t)(pend >> 1) + slot : (uint64_t)(pend >> 1) * gnp + slot;
+            atomicAdd(gcb + at, (pend & 1u) ? 0x100000001ull : 1ull);
         }
         pend = kNoPend;
     }
@@ -634,7 +642,8 @@ struct KF {
         const uint32_t rho_0 = lane_valu(rho, 0);
         KFT_LAP(2);
         // the round's ML bytes are requested before anything else is waited for
-        const uint64_t mi0 = (uint64_t)ml_start + (uint64_t)kidx * ((kTwinOK && tw) ? 1u : (uint32_t)ncg);
+        // (32 bits: a BAM record is shorter than 2^29 bytes, so a read's groups have fewer than 2^28 tokens in all; times four codes: below 2^30)
+        const uint32_t mi0 = ml_start + kidx * ((kTwinOK && tw) ? 1u : (uint32_t)ncg);
         const uint32_t ml0 = (lv && expl && mi0 < ml_len) ? ml[mi0] : 0u;
         flush_pending();   // the round before's updates, behind this round's loads
         // the directory segment that holds the round's first rank (ranks rise inside a group; a new group starts over)
@@ -777,8 +786,7 @@ struct KF {
                         bool emit = call && (gsite == nullptr || ((cinfo >> 18) & 1u) || refcode == code);
                         uint32_t prob = 0;
                         if (expl) {
-                            const uint64_t ml_idx = (kTwinOK && tw) ? (uint64_t)ml_start + kidx + (uint32_t)m * tw
-                                                                     : (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                            const uint32_t ml_idx = (kTwinOK && tw) ? ml_start + kidx + (uint32_t)m * tw : ml_start + kidx * (uint32_t)ncg + (uint32_t)m;
                             if (emit && ml_idx >= ml_len) { err = MM_E_MLIDX; emit = false; }
                             if (emit) prob = m == 0 ? ml0 : (uint32_t)ml[ml_idx];
                             if (kStats && emit) st_ml++;
@@ -796,8 +804,7 @@ struct KF {
                         if (gsite != nullptr && !(((cinfo >> 18) & 1u) || refcode == code)) continue;   // the base test (mod.c:1163-1164); a dense class has none
                         int is_mod = 0;
                         if (expl) {
-                            const uint64_t ml_idx = (kTwinOK && tw) ? (uint64_t)ml_start + kidx + (uint32_t)m * tw
-                                                                     : (uint64_t)ml_start + (uint64_t)kidx * (uint32_t)ncg + (uint32_t)m;
+                            const uint32_t ml_idx = (kTwinOK && tw) ? ml_start + kidx + (uint32_t)m * tw : ml_start + kidx * (uint32_t)ncg + (uint32_t)m;
                             if (ml_idx >= ml_len) { err = MM_E_MLIDX; continue; }   // (not `break`: a divergent exit would make m, and all that
                                                                                      // hangs on it -- the code's table word, its slot, the 64-bit
                                                                                      // counter offset -- vector values; the read fails either way)
@@ -927,8 +934,13 @@ struct KF {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t o = off0 + 256u * (uint32_t)u + 4u * lane;
-                va[u] = mm_dword(mm, a + len, a + o); vb[u] = mm_dword(mm, b + len, b + o);
-                vp[u] = mm_dword(mm, a + len, a + o - 1u);                              // the same four characters' left neighbours (a >= 1: a header is in front)
+                // (plain loads: what lies behind a list's end -- the text goes on, or the pool's 64 bytes of slack -- is masked out by `vm` below;
+                // mm_dword's own replacing of those bytes was seven instructions a load, twelve loads a trip)
+                va[u] = 0u; vb[u] = 0u; vp[u] = 0u;
+                if (o < len) {
+                    __builtin_memcpy(&va[u], mm + a + o, 4); __builtin_memcpy(&vb[u], mm + b + o, 4);
+                    __builtin_memcpy(&vp[u], mm + a + o - 1u, 4);                       // the same four characters' left neighbours (a >= 1: a header is in front)
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -939,7 +951,7 @@ struct KF {
                 const uint32_t ca = ~(((ya & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ya) & 0x80808080u;   // commas
                 const uint32_t cp = ~(((yp & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yp) & 0x80808080u;   // commas among the left neighbours
                 const uint32_t nd = (((yd & 0x7F7F7F7Fu) + 0x76767676u) | yd) & 0x80808080u;     // not a digit
-                bad |= ((wa ^ wb) & (vm >> 7) * 0xFFu) | ((nd & ~ca) & vm) | (ca & cp & vm);
+                bad |= ((wa ^ wb) & (vm | (vm - (vm >> 7)))) | ((nd & ~ca) & vm) | (ca & cp & vm);   // (0x80 -> 0xFF a byte without a multiply)
                 if (o <= len - 1u && len - 1u < o + 4u) bad |= ca & (0x80u << (8u * (len - 1u - o)));   // the last character is a digit
                 if (o == 0u) bad |= (~ca) & 0x80u;                                                    // the first one a comma
                 commas += (uint32_t)__popc(ca & vm);
