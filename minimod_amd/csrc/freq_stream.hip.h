@@ -422,26 +422,27 @@ struct KF {
         uint32_t run = s0;
         wave_sync();
         for (uint32_t h = 0; h < nb; h += 256u) {
+            // a lane takes FOUR CONSECUTIVE blocks (64 bytes of sequence): their bits go out as one 16-byte LDS write, the count in front of
+            // them is the lane's entry of `cw`, and one scan over the lanes' totals serves 256 blocks (a block a lane, 64 blocks a row, was a
+            // scan a row: four of them)
             uint4 vv[4];
+            const uint32_t at = h + 4u * lane, tb = t0 + at;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t t = t0 + h + 64u * (uint32_t)r + lane;
-                vv[r] = (h + 64u * (uint32_t)r < nb && t < nblk) ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
+                const uint32_t t = tb + (uint32_t)r;
+                vv[r] = at + (uint32_t)r < nb ? sq[rev ? nblk - 1u - t : t] : make_uint4(0, 0, 0, 0);
             }
+            uint32_t mk[4], total = 0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                if (h + 64u * (uint32_t)r < nb) {
-                    const uint32_t t = t0 + h + 64u * (uint32_t)r + lane;
-                    const bool valid = t < nblk;
-                    const uint32_t mk = valid ? stream_block_mask(vv[r], cpat, rev ? nblk - 1u - t : t, L) : 0u;
-                    const uint32_t cnt = __popc(mk);
-                    const uint32_t incl = wave_incl_scan(cnt);
-                    const uint32_t at = h + 64u * (uint32_t)r + lane;
-                    S.dm[at] = mk;                                        // (zero behind the read's last block: a group of four is whole)
-                    if (valid && (at & 3u) == 0u) S.cw[at >> 2] = run + incl - cnt;
-                    run = uniu(run + lane_valu(incl, 63));
-                }
+                const uint32_t t = tb + (uint32_t)r;
+                mk[r] = at + (uint32_t)r < nb ? stream_block_mask(vv[r], cpat, rev ? nblk - 1u - t : t, L) : 0u;   // (zero behind the read's last block: a group of four is whole)
+                total += __popc(mk[r]);
             }
+            const uint32_t incl = wave_incl_scan(total);
+            *reinterpret_cast<uint4*>(&S.dm[at]) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+            if (at < nb) S.cw[at >> 2] = run + incl - total;
+            run = uniu(run + lane_valu(incl, 63));
         }
         if (lane == 0u) S.cw[(nb + 3u) >> 2] = run;
         for (uint32_t c = ((nb + 3u) >> 2) + 1u + lane; c <= kSegBlocks / 4; c += 64u) S.cw[c] = kStreamInf;   // (search_le_padded)
