@@ -247,6 +247,10 @@ struct KF {
     int64_t ref_base_g;         // the contig's first position in the reference-word space
     bool has_dense;             // the contig has dense counters in this handle
     int32_t tid_cur;
+    // kIns: the part of a side update's key that is the READ's -- contig base << 28 | strand << 27 | haplotype -- when every key of the
+    // read fits the 64-bit form (side_key's range checks made once per read, not per update); side_fast says so
+    unsigned long long side_kbase;
+    bool side_fast;
     uint32_t ml_start;
     // TWIN groups (run()): two one-code `?` lists over the same tokens, done in one pass.  tw = 0: an ordinary group, the ML byte
     // of token k's code m is ml[ml_start + k * ncg + m]; tw = the list's tokens: ml[ml_start + k + m * tw] (the second list's
@@ -564,7 +568,9 @@ struct KF {
         const int64_t ref_base = ref_base_g;   // (round 3 fetched both again here, two dependent loads a round: rare then, every round of a --insertions run)
         const int hpk = kIns ? hp : -1;
         unsigned long long key;
-        if (side_key(ref_base + spos, rev, code, ins_off, hpk, key)) {
+        const bool keyed = (kIns && side_fast) ? (key = side_kbase + ((unsigned long long)(uint32_t)spos << 28) + (((uint32_t)code << 21) | ((ins_off & 0xFFFFu) << 5)), true)
+                                               : side_key(ref_base + spos, rev, code, ins_off, hpk, key);
+        if (keyed) {
             if (!kIns) { if (side_insert(p.stab, p.smask, p.scur, key, is_mod ? 0x100000001ull : 1ull)) err = MM_E_SIDEFULL; return; }
             // (the lanes that are here together: those of the round with a side update that has a 64-bit key)
             const uint64_t m = __ballot(1);
@@ -585,7 +591,7 @@ struct KF {
                 if (lane_id() == leader) { S.sres_end = at + kSideChunk; S.sres_klo = (uint32_t)key; S.sres_khi = (uint32_t)(key >> 32); }
             }
             const unsigned long long idx = (unsigned long long)at + mine;
-            if (idx >= p.smask) err = MM_E_SIDEFULL;
+            if ((uint32_t)idx >= (uint32_t)p.smask) err = MM_E_SIDEFULL;   // (a region holds fewer than 2^32 records)
             else { ulonglong2 rec; rec.x = key; rec.y = is_mod ? 0x100000001ull : 1ull; *reinterpret_cast<ulonglong2*>(list + 2ull * idx) = rec; }
             if (lane_id() == leader) S.sres_at = at + cnt;
             wave_sync();
@@ -607,7 +613,10 @@ struct KF {
         }
     }
 
-    static constexpr uint32_t kSideChunk = 256;
+#ifndef MM_SIDE_CHUNK
+#define MM_SIDE_CHUNK 256
+#endif
+    static constexpr uint32_t kSideChunk = MM_SIDE_CHUNK;
     // the unused records of the wavefront's last chunk (the kernel's end; wave-uniform)
     __device__ __forceinline__ void side_fill_rest() {
         wave_sync();
@@ -1144,6 +1153,10 @@ struct KF {
             seg_lo32 = (uint32_t)seg_begin; seg_len32 = (uint32_t)seg_len;
             rwb = RefLoad<RefWord>::from(p.refw, ref_base);
             ref_base_g = ref_base; has_dense = seg_len > 0; tid_cur = tid;
+            if (kIns) {
+                side_fast = ref_base >= 0 && ref_base + ctg_len < (1ll << 35) && hp <= 29;
+                side_kbase = ((unsigned long long)ref_base << 28) | ((unsigned long long)(rev & 1) << 27) | (hp < 0 ? 31ull : (unsigned long long)hp);
+            }
             gcb = nullptr; gsite = nullptr; gnp = 1;
             ml_start = 0;
             uint32_t unw_last = 0;   // 1 + the largest last rank of the groups nobody asked for (0: none)
