@@ -699,3 +699,27 @@ def test_loader_hands_out_the_reads_in_front_of_a_damaged_block(tmp_path):
             finally:
                 for k_, v in old.items():
                     os.environ.pop(k_, None) if v is None else os.environ.__setitem__(k_, v)
+
+
+def test_stream_kernel_fits_its_waves():
+    """The built code objects' metadata (tools/resources.py): the lean and kIns instantiations of k_stream_reads keep the 72 VGPRs
+    and the LDS that seven wavefronts a SIMD allow, the `.`-capable ones the 80 of six (DESIGN §4's kernel table quotes these)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mm_resources", os.path.join(root, "tools", "resources.py"))
+    res = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(res)
+    seen = 0
+    for k in (0, 1, 2):
+        obj = os.path.join(root, "minimod_amd", "lib", "obj", "freq_api_k%d.o" % k)
+        if not os.path.exists(obj):
+            pytest.skip("no freq objects beside the library (a library built elsewhere)")
+        for name, f in res.kernels(obj):
+            if "k_stream_reads" not in name:
+                continue
+            seen += 1
+            lean = f["group_segment_fixed_size"] <= 22592
+            assert f["vgpr_count"] <= (72 if lean else 80), (name, f)
+            assert f["group_segment_fixed_size"] * (7 if lean else 6) <= 160 * 1024, (name, f)
+    assert seen == 36
