@@ -143,6 +143,9 @@ int mmh_tie_add_batch(mmh_tie_t *t, mm_pool_t *pool, const mm_batch_t *batch, co
 /* mm_freq_finalize's rows, reordered in place into the order print_freq_output prints; -1 = no replay possible (rows untouched) */
 int mmh_tie_order_rows(mmh_tie_t *t, mm_row_t *rows, int64_t n);
 int mmh_tie_order_rows_mt(mmh_tie_t *t, mm_pool_t *pool, mm_row_t *rows, int64_t n);
+/* the core table and the sort alone, from every distinct key's reference hash and comparator key in first-insertion order (the checker of
+ * the device-side replay; what a --devices parent runs) */
+int mmh_tie_order_plain(const uint32_t *hash, const int64_t *sortkey, int64_t n, int put_after_last, uint32_t *slot_order, uint32_t *final);
 /* the first-insertion sequence of the keys so far (opaque 16-byte keys + hashes), and the same appended to another replay: the
  * workers of `--devices` replay their own reads, the parent strings the sequences together in file order */
 int64_t mmh_tie_export(const mmh_tie_t *t, const void **keys, const uint32_t **hash);

@@ -170,21 +170,30 @@ static int ktab_grow(ktab_t *t, uint32_t want, const uint32_t *hash) {
     return 0;
 }
 
-/* put: returns 1 when the key was new.  `same(ctx, a, b)` compares key ids. */
+/* put: returns 1 when the key was new.  update_freq_map looks the key up first (kh_get) and calls kh_put only for a key that is not there
+ * (src/mod.c:885-893): a key met AGAIN at the growth bound does not grow the read's table -- the next new key does. */
 static int ktab_put(ktab_t *t, uint32_t key, const uint32_t *hash, const tkey_t *keys) {
-    if (t->n_occupied >= t->upper) {
-        if (ktab_grow(t, t->n_buckets > (t->size << 1) ? t->n_buckets - 1 : t->n_buckets + 1, hash)) return -1;
-    }
-    const uint32_t mask = t->n_buckets - 1;
-    uint32_t i = hash[key] & mask, step = 0;
-    const uint32_t last = i;
     const uint32_t hk = hash[key];
-    /* (an occupied slot's key is first told apart by its hash -- equal keys have equal hashes -- and only then fetched) */
-    while (t->used[i] && !(hash[t->id[i]] == hk && tkey_eq(&keys[t->id[i]], &keys[key]))) {
-        i = (i + (++step)) & mask;
-        if (i == last) return -1;   /* cannot happen below the load bound */
+    if (t->n_buckets) {
+        const uint32_t mask = t->n_buckets - 1;
+        uint32_t i = hk & mask, step = 0;
+        const uint32_t last = i;
+        /* (an occupied slot's key is first told apart by its hash -- equal keys have equal hashes -- and only then fetched) */
+        while (t->used[i]) {
+            if (hash[t->id[i]] == hk && tkey_eq(&keys[t->id[i]], &keys[key])) return 0;
+            i = (i + (++step)) & mask;
+            if (i == last) return -1;   /* cannot happen below the load bound */
+        }
+        if (t->n_occupied < t->upper) { t->used[i] = 1; t->id[i] = key; t->size++; t->n_occupied++; return 1; }
     }
-    if (t->used[i]) return 0;
+    if (ktab_grow(t, t->n_buckets > (t->size << 1) ? t->n_buckets - 1 : t->n_buckets + 1, hash)) return -1;
+    const uint32_t mask = t->n_buckets - 1;
+    uint32_t i = hk & mask, step = 0;
+    const uint32_t last = i;
+    while (t->used[i]) {
+        i = (i + (++step)) & mask;
+        if (i == last) return -1;
+    }
     t->used[i] = 1; t->id[i] = key; t->size++; t->n_occupied++;
     return 1;
 }
@@ -268,6 +277,33 @@ static int intro_sort(size_t n, sel_t *a) {
     }
 }
 
+/* The core table and the sort by themselves, from the reference hash and the comparator's key of every distinct key in first-insertion
+ * order: the checker of the device-side replay (csrc/tie_kernels.hip.h, which computes the same two permutations with parallel
+ * kernels) and what a `--devices` parent runs.  put_after_last: some kh_put followed the last NEW key's (merge_freq_maps offers every
+ * key of every read, src/mod.c:756: a put of a key that is already there still grows a table that has reached its bound,
+ * khash.h kh_put).  slot_order (may be NULL): ids in the core table's slot order; final: ids in the order print_freq_output prints. */
+int mmh_tie_order_plain(const uint32_t *hash, const int64_t *sortkey, int64_t n, int put_after_last, uint32_t *slot_order, uint32_t *final) {
+    if (n <= 0) return 0;
+    if (n >= 0xFFFFFFF0ll) return -1;
+    ktab_t core;
+    memset(&core, 0, sizeof core);
+    for (int64_t i = 0; i < n; i++) {
+        if (i + 12 < n && core.n_buckets) { const uint32_t pf = hash[i + 12] & (core.n_buckets - 1); __builtin_prefetch(&core.used[pf], 1); __builtin_prefetch(&core.id[pf], 1); }
+        if (ktab_put_new(&core, (uint32_t)i, hash) != 1) { ktab_free(&core); return -1; }
+    }
+    if (put_after_last && core.n_occupied >= core.upper && ktab_grow(&core, core.n_buckets + 1, hash)) { ktab_free(&core); return -1; }
+    sel_t *arr = (sel_t *)malloc(sizeof(sel_t) * (size_t)n);
+    if (!arr) { ktab_free(&core); return -1; }
+    size_t w = 0;
+    for (uint32_t s = 0; s < core.n_buckets; s++)
+        if (core.used[s]) { arr[w].key = sortkey[core.id[s]]; arr[w].id = core.id[s]; arr[w].pad = 0; if (slot_order) slot_order[w] = core.id[s]; w++; }
+    ktab_free(&core);
+    if (intro_sort(w, arr)) { free(arr); return -1; }
+    for (size_t i = 0; i < w; i++) final[i] = arr[i].id;
+    free(arr);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- the replay */
 /* Round 4: the first-insertion ORDER of the keys is kept as a stamp per key -- (serial number of the read in the file) << 24 | place
  * of the key among the read's own -- in 256 tables of their own lock each, so that the reads of a batch are replayed AND entered by
@@ -292,6 +328,8 @@ struct mmh_tie {
     int32_t *rank;                 /* contig tid -> rank of its name in strcmp order */
     tshard_t *shard;               /* [TS_SHARDS] */
     uint64_t reads_seen;           /* serial number of the next batch's first read */
+    uint64_t last_put;             /* the largest stamp any put carried, new key or not (atomic max): does a put follow the last new key's? */
+    uint64_t top_stamp;            /* the last new key's stamp (seq_build) */
     size_t n_keys;                 /* keys in all (atomic) */
     /* first-insertion sequence of the core table, made from the stamps when somebody asks for it (seq_build) */
     tkey_t *keys; uint32_t *hash; size_t n, cap;
@@ -434,6 +472,7 @@ static int seq_build_mt(mmh_tie_t *t, mm_pool_t *pool) {
     mm_pool_for(pool, TS_SHARDS, 4, seq_gather, q);
     uint64_t top = 0;
     for (int i = 0; i < TS_SHARDS; i++) if (q->top[i] > top) top = q->top[i];
+    t->top_stamp = top;
     for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 11) {
         q->shift = shift;
         mm_pool_for(pool, SQ_PARTS, 1, seq_count, q);
@@ -636,6 +675,11 @@ static void read_range(void *arg, int64_t lo, int64_t hi) {
                 q->k = keys[tab.id[s]]; q->hash = hash[tab.id[s]]; q->pad = 0; q->stamp = ((j->serial0 + (uint64_t)r) << 24) | (uint64_t)(w2 & 0xFFFFFFu);
                 w2++;
             }
+        if (w2) {   /* the read's last put (merge_freq_maps offers every key of the read to the core table, new there or not) */
+            const uint64_t lp = ((j->serial0 + (uint64_t)r) << 24) | (uint64_t)((w2 - 1) & 0xFFFFFFu);
+            uint64_t cur = __atomic_load_n(&t->last_put, __ATOMIC_RELAXED);
+            while (lp > cur && !__atomic_compare_exchange_n(&t->last_put, &cur, lp, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
         ktab_free(&tab);
     }
     ts->tmp_ord = tmp_ord; ts->tmp_cap = tmp_cap;
@@ -698,6 +742,7 @@ int mmh_tie_import(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t
     const tkey_t *k = (const tkey_t *)keys;
     /* (a worker's sequence counts as the keys of so many reads of one key each: its order is kept, and it lies behind everything entered before) */
     for (int64_t i = 0; i < n; i++) if (stamp_add(t, &k[i], hash[i], (t->reads_seen + (uint64_t)i) << 24)) { t->failed = 1; return -1; }
+    if (n > 0 && ((t->reads_seen + (uint64_t)n - 1) << 24) > t->last_put) t->last_put = (t->reads_seen + (uint64_t)n - 1) << 24;
     t->reads_seen += (uint64_t)n;
     return 0;
 }
@@ -782,6 +827,8 @@ int mmh_tie_order_rows_mt(mmh_tie_t *t, mm_pool_t *pool, mm_row_t *rows, int64_t
         if (i + 12 < t->n && core.n_buckets) { const uint32_t pf = t->hash[i + 12] & (core.n_buckets - 1); __builtin_prefetch(&core.used[pf], 1); __builtin_prefetch(&core.id[pf], 1); }
         if (ktab_put_new(&core, (uint32_t)i, t->hash) != 1) { ktab_free(&core); return -1; }
     }
+    /* a put behind the last new key's finds the table at its bound and grows it (khash.h kh_put looks at the bound before it looks for the key) */
+    if (t->last_put > t->top_stamp && core.n_occupied >= core.upper && ktab_grow(&core, core.n_buckets + 1, t->hash)) { ktab_free(&core); return -1; }
     sel_t *arr = (sel_t *)malloc(sizeof(sel_t) * t->n);
     if (!arr) { ktab_free(&core); return -1; }
     size_t w = 0;

@@ -1,0 +1,123 @@
+"""The device-side replay of the reference's row order (csrc/tie_kernels.hip.h, include/minimod_tie.h) against its serial restatement
+(csrc/host/tieorder.c, which the CPU suite pins against the reference's goldens): the core hash table's slot order and the order
+ks_introsort leaves, for key sequences of every size class -- around khash's growth bounds, with and without a put behind the last new
+key, hashes of real key strings (X31 of make_key's text, src/mod.c:428-439) and random ones, few and many ties."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from minimod_amd import build as B
+
+pytestmark = pytest.mark.gpu
+
+
+def _libs():
+    H = ctypes.CDLL(os.path.join(B.LIBDIR, "libminimod_host.so"))
+    H.mmh_tie_order_plain.restype = ctypes.c_int
+    H.mmh_tie_order_plain.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    D = ctypes.CDLL(B.lib_path())
+    D.mm_tie_order_plain.restype = ctypes.c_int32
+    D.mm_tie_order_plain.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    D.mm_tie_last_stats.argtypes = [ctypes.c_void_p]
+    return H, D
+
+
+def _both(h, sk, pal):
+    H, D = _libs()
+    n = len(h)
+    h = np.ascontiguousarray(h, np.uint32)
+    sk = np.ascontiguousarray(sk, np.int64)
+    hs, hf, ds, df = (np.zeros(max(n, 1), np.uint32) for _ in range(4))
+    assert H.mmh_tie_order_plain(h.ctypes.data, sk.ctypes.data, n, pal, hs.ctypes.data, hf.ctypes.data) == 0
+    assert D.mm_tie_order_plain(0, h.ctypes.data, sk.ctypes.data, n, pal, ds.ctypes.data, df.ctypes.data) == 0
+    st = np.zeros(8, np.uint64)
+    D.mm_tie_last_stats(st.ctypes.data)
+    return hs[:n], hf[:n], ds[:n], df[:n], st
+
+
+def _x31(s):
+    h = s[0]
+    for c in s[1:]:
+        h = (h * 31 + c) & 0xFFFFFFFF
+    return h
+
+
+def _upper(c):
+    return int(c * 0.77 + 0.5)
+
+
+BOUNDS = [_upper(4 << k) for k in range(0, 15)]   # 3, 6, 12, 25, 49, 99, ... 50463
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 12, 13, 16, 17, 18, 25, 26, 49, 99, 100, 197, 394, 1000, 1577, 1578, 2048, 2049, 2050, 5000, 12616, 12617, 50463, 70001])
+def test_core_table_and_sort_at_every_size_class(n):
+    rng = np.random.default_rng(n)
+    h = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    sk = rng.integers(0, max(2, n // 3), n).astype(np.int64)
+    for pal in (0, 1):
+        hs, hf, ds, df, _ = _both(h, sk, pal)
+        assert (hs == ds).all(), (n, pal, "slot order")
+        assert (hf == df).all(), (n, pal, "printed order")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_sizes_and_tie_shapes(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 400000))
+    h = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    shape = seed % 3
+    if shape == 0:
+        sk = rng.integers(0, max(2, n // 2), n).astype(np.int64)            # pairs, as a two-code run has them
+    elif shape == 1:
+        sk = rng.integers(0, 7, n).astype(np.int64) << 32 | rng.integers(0, max(2, n // 8), n).astype(np.int64)   # several contigs, long runs
+    else:
+        sk = rng.permutation(n).astype(np.int64)                            # no ties at all
+    for pal in (0, 1):
+        hs, hf, ds, df, _ = _both(h, sk, pal)
+        assert (hs == ds).all() and (hf == df).all(), (n, pal, shape)
+
+
+def test_hashes_of_real_key_strings():
+    """X31 of 'chr1\\t<pos>\\t<strand>\\tm|h\\t0\\t-1' over neighbouring positions: the hashes differ in their low digits' weights only, the
+    probe paths are long and crowded -- what a two-code run hands the table."""
+    rng = np.random.default_rng(7)
+    pos = np.sort(rng.choice(5_000_000, 60000, replace=False))
+    keys = []
+    for p in pos:
+        st = "+-"[int(rng.integers(2))]
+        for code in ("m", "h"):
+            keys.append(("chr1\t%d\t%s\t%s\t0\t-1" % (p, st, code)).encode())
+    n = len(keys)
+    perm = np.argsort(np.arange(n) // 2 + rng.integers(0, 600, n), kind="stable")   # first met by overlapping reads, not in position order
+    h = np.array([_x31(keys[i]) for i in perm], dtype=np.uint32)
+    sk = np.array([int(keys[i].split(b"\t")[1]) for i in perm], dtype=np.int64)
+    for pal in (0, 1):
+        hs, hf, ds, df, st = _both(h, sk, pal)
+        assert (hs == ds).all() and (hf == df).all()
+    assert st[2] <= 4 * st[1], "a growth should settle in a few passes: %s" % st
+
+
+def test_equal_hashes_and_one_site():
+    """every key on one probe path (equal hashes), every row on one (contig, start): the longest chains and the longest ties"""
+    n = 3000
+    h = np.full(n, 0x1234567, np.uint32)
+    sk = np.zeros(n, np.int64)
+    hs, hf, ds, df, _ = _both(h, sk, 0)
+    assert (hs == ds).all() and (hf == df).all()
+    h2 = (np.arange(n) % 5).astype(np.uint32)
+    hs, hf, ds, df, _ = _both(h2, sk, 1)
+    assert (hs == ds).all() and (hf == df).all()
+
+
+def test_three_million_keys_and_its_cost():
+    """the size of a 3-Gbase two-code run (C3): exact, and the device's time for it on record"""
+    rng = np.random.default_rng(99)
+    n = 3_100_000
+    h = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    sk = np.sort(rng.integers(0, n // 2, n)).astype(np.int64)[rng.permutation(n)]
+    hs, hf, ds, df, st = _both(h, sk, 0)
+    assert (hs == ds).all() and (hf == df).all()
+    print("3.1 M keys: %d launches, %d growths in %d passes, %d placement rounds, %d sort levels, %d segments finished by a thread, %.1f ms on the device"
+          % (st[0], st[1], st[2], st[3], st[4], st[5], st[6] / 1000.0))
