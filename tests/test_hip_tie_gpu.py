@@ -121,3 +121,99 @@ def test_three_million_keys_and_its_cost():
     assert (hs == ds).all() and (hf == df).all()
     print("3.1 M keys: %d launches, %d growths in %d passes, %d placement rounds, %d sort levels, %d segments finished by a thread, %.1f ms on the device"
           % (st[0], st[1], st[2], st[3], st[4], st[5], st[6] / 1000.0))
+
+
+# ---- the whole replay (T1 - T4) against the reference's own golden files -------------------------------------------------------------
+import json
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REPLAY_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
+import minimod_amd
+from minimod_amd import engine as E, tie as T
+from oracle import oracle as O
+from oracle import pybam
+from tests.cases import GOLDEN, GOLDEN_CASES
+
+def pseudo(name):
+    return dict([O.pseudo_reference(os.path.join(GOLDEN, "pseudo_%%s.npz" %% name))])
+
+def device_replay(bam_path, contigs, c="m", m=None, insertions=False, haplotypes=False, K=512, bedmethyl=False, one_launch=False):
+    mods = O.parse_mod_codes(c)
+    th = O.parse_mod_threshes(m, len(mods))
+    eng = hv = tie = None
+    wild = [i for i, (cc, _x) in enumerate(mods) if cc == "*"]
+    keep = []
+    batches = [b for (_bam, b, _st) in pybam.load_batches(bam_path, K=K, B=20 * 1000 * 1000) if len(b["reads"])]
+    bam = next(iter(pybam.load_batches(bam_path, K=K, B=20 * 1000 * 1000)))[0]
+    if one_launch:
+        batches = [pybam.concat_batches(batches)] if hasattr(pybam, "concat_batches") else batches
+    ctg = [(n, l, contigs.get(n)) for n, l in zip(bam.target_name, bam.target_len)]
+    mm = [(cc, x, t) for (cc, x), t in zip(mods, th)]
+    eng = minimod_amd.FreqEngine(mm, ctg, insertions=insertions, haplotypes=haplotypes, stream_mode=2)
+    hv = minimod_amd.FreqEngine(mm, ctg, insertions=insertions, haplotypes=haplotypes, stream_mode=2, view=2, coalesce=1)
+    tie = T.TieReplay(list(bam.target_name), list(bam.target_len), insertions, haplotypes)
+    for b in batches:
+        eng.process(b)
+        if hv.wildcard:
+            hv.intern_codes_from(b)
+        dev = {k: torch.from_numpy(b[k].view(np.uint8).reshape(-1).copy()).cuda() for k in ("reads", "cigar", "seq", "mm", "ml")}
+        torch.cuda.synchronize()
+        db = dict(reads=dev["reads"].data_ptr(), cigar=dev["cigar"].data_ptr(), seq=dev["seq"].data_ptr(), mm=dev["mm"].data_ptr(), ml=dev["ml"].data_ptr(),
+                  n_reads=len(b["reads"]), n_cigar_words=len(b["cigar"]), n_seq_bytes=len(b["seq"]), n_mm_bytes=len(b["mm"]), n_ml_bytes=len(b["ml"]),
+                  max_n_cigar=int(b["reads"]["n_cigar"].max()), max_l_qseq=int(b["reads"]["l_qseq"].max()))
+        t = hv.submit_device(db)
+        ptr, n = hv.fetch_view(t, device=True)
+        codes = hv.code_names()
+        luts = [E.klass_lut(th[wild[0] if wild else min(i, len(th) - 1)]) for i in range(len(codes))]
+        tie.set_codes(codes, luts)
+        rc = tie.add_launch(E.batch_struct(db, device=True), ptr, n)
+        assert rc == 0, (rc, tie.failed())
+        keep.append(dev)
+    rows = eng.finalize()
+    perm = tie.order_rows(rows)
+    assert perm is not None, tie.failed()
+    st = tie.stats()
+    rows = rows[perm]
+    res = np.zeros(len(rows), dtype=O.ROW_DTYPE)
+    res["tid"], res["pos"], res["strand"], res["code"] = rows["tid"], rows["pos"], rows["strand"], rows["code"]
+    res["ins_off"], res["hp"], res["n_called"], res["n_mod"] = rows["ins_offset"], rows["hp"], rows["n_called"], rows["n_mod"]
+    text = O.format_rows(res, eng.names, eng.code_names(), insertions=insertions, haplotypes=haplotypes, bedmethyl=bedmethyl)
+    eng.close(); hv.close(); tie.close()
+    return text, [int(x) for x in st]
+
+out = {}
+refs = {}
+for exp, bamf, ctg, kw, exact in GOLDEN_CASES:
+    if exp == "test16.tsv":
+        continue
+    if ctg not in refs:
+        refs[ctg] = pseudo(ctg)
+    kw = dict(kw)
+    kw.setdefault("bedmethyl", exp.endswith(".bedmethyl"))
+    for K in (512, 7):
+        kk = dict(kw); kk["K"] = kw.get("K", K)
+        got, st = device_replay(os.path.join(GOLDEN, "data", bamf), refs[ctg], **kk)
+        want = open(os.path.join(GOLDEN, "expected", exp)).read()
+        out["%%s:K%%d" %% (exp, K)] = [got == want, len(got), len(want), st]
+print(json.dumps(out))
+'''
+
+
+def test_device_replay_reproduces_the_reference_goldens_byte_for_byte():
+    """every freq golden of the reference (test/test.sh:116-232) through the device-side replay: counts from a freq handle, calls from a
+    view=2 handle on DEVICE-resident batches, T1 - T4 on the device, rows printed in the order it returns -- the bytes are the golden's
+    (test16 aside: SURVEY section 8c), for -K 512 and -K 7 (a read's stamp must not depend on the batch it came in)"""
+    r = subprocess.run([sys.executable, "-c", REPLAY_WORKER % dict(root=ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    bad = {k: v for k, v in res.items() if not v[0]}
+    assert not bad, bad
+    assert len(res) == 22
