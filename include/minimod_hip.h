@@ -208,6 +208,11 @@ int32_t mm_freq_host_done(mm_freq_t *h, int32_t ticket);
 /* the record of read `index` of the ticket's (gathered) batch as the device holds it: tid, pos, l_qseq, ... as submitted,
  * pool offsets those of the staging area.  For error messages (the reference prints contig and position).  0 or MM_E_*. */
 int32_t mm_freq_read_record(mm_freq_t *h, int32_t ticket, int32_t index, mm_read_t *out);
+/* the ticket's (gathered) batch as the device holds it -- DEVICE pointers: the staging area's for mm_freq_submit, the caller's own for
+ * mm_freq_submit_device*; valid until the ticket's slot is used again (four launches later).  What the device-side replay of the
+ * reference's row order reads a launch's read records and MM text from (include/minimod_tie.h).  Launches a gathered group that is
+ * still open.  0 or MM_E_*. */
+int32_t mm_freq_ticket_batch(mm_freq_t *h, int32_t ticket, mm_batch_t *out);
 
 /* Process one batch already RESIDENT in device memory (all mm_batch_t pointers are device pointers) on the given
  * HIP stream (hipStream_t as void*, NULL = the handle's own stream).  Returns a ticket >= 0 or -MM_E_*.  The batch

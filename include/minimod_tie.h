@@ -51,10 +51,12 @@ int32_t mm_tie_add_launch(mm_tie_t *t, const mm_batch_t *dev_batch, const void *
  * Returns 0, or -MM_E_* when the replay cannot be made for this input (a key without a stamp, a haplotype above 61, a read with more
  * than 2^18 calls...: mm_tie_failed says which); the caller then prints the canonical order, as it does when the host replay gives up. */
 int32_t mm_tie_order_rows(mm_tie_t *t, const mm_row_t *rows, int64_t n, uint32_t *perm);
-/* the rows' first-insertion sequence instead (a worker of `--devices` hands it to the parent, which strings the workers' sequences
- * together): seq[i] = index of the i-th key entered, hash[i] = the reference's hash of that key, *put_after_last = whether any put
- * followed the last new key's */
-int32_t mm_tie_sequence(mm_tie_t *t, const mm_row_t *rows, int64_t n, uint32_t *seq, uint32_t *hash, int32_t *put_after_last);
+/* Every key stamped so far in the order of its first insertion (a worker of `--devices` hands its own to the parent, which strings the
+ * workers' sequences together: a key in a halo may have no row in this worker's output and still come first): keys[i] = the i-th key
+ * entered as a row without counts, hash[i] = the reference's hash of its string, *put_after_last = whether any put followed the last
+ * new key's.  mm_tie_sequence_size: how many there are; mm_tie_sequence returns that count (cap must hold it). */
+int64_t mm_tie_sequence_size(const mm_tie_t *t);
+int64_t mm_tie_sequence(mm_tie_t *t, mm_row_t *keys, uint32_t *hash, int64_t cap, int32_t *put_after_last);
 uint32_t mm_tie_failed(const mm_tie_t *t);   /* 0, or why the replay gave up (bit set, csrc/tie_kernels.hip.h TIE_F_*) */
 int64_t mm_tie_device_bytes(const mm_tie_t *t);
 void mm_tie_destroy(mm_tie_t *t);

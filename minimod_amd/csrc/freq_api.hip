@@ -1389,6 +1389,13 @@ int32_t mm_freq_read_record(mm_freq_t* h, int32_t ticket, int32_t index, mm_read
     return MM_OK;
 }
 
+int32_t mm_freq_ticket_batch(mm_freq_t* h, int32_t ticket, mm_batch_t* out) {
+    if (!h || !out || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
+    if (ticket == h->pending_slot) { if (hipSetDevice(h->device) != hipSuccess) return MM_E_HIP; (void)flush_pending(h); }
+    *out = h->slots[ticket].last_batch;
+    return out->reads ? MM_OK : MM_E_ARG;
+}
+
 int32_t mm_freq_wait(mm_freq_t* h, int32_t ticket, int32_t* bad_read) {
     if (!h || ticket < 0 || ticket >= kSlots) return MM_E_ARG;
     Slot& s = h->slots[ticket];

@@ -13,6 +13,7 @@
     int32_t mm_freq_submit_k##K(mm_freq_t*, const mm_batch_t*); \
     int32_t mm_freq_host_done_k##K(mm_freq_t*, int32_t); \
     int32_t mm_freq_read_record_k##K(mm_freq_t*, int32_t, int32_t, mm_read_t*); \
+    int32_t mm_freq_ticket_batch_k##K(mm_freq_t*, int32_t, mm_batch_t*); \
     int32_t mm_freq_submit_device_k##K(mm_freq_t*, const mm_batch_t*, void*); \
     int32_t mm_freq_submit_device_now_k##K(mm_freq_t*, const mm_batch_t*, void*, uint64_t); \
     int32_t mm_freq_ticket_batches_k##K(mm_freq_t*, int32_t); \
@@ -88,6 +89,8 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* b) { MM_FWD(h, -MM_E_ARG,
 int32_t mm_freq_host_done(mm_freq_t* h, int32_t ticket) { MM_FWD(h, MM_E_ARG, C2); }
 #define C3(K) mm_freq_read_record_k##K(h->impl, ticket, index, out)
 int32_t mm_freq_read_record(mm_freq_t* h, int32_t ticket, int32_t index, mm_read_t* out) { MM_FWD(h, MM_E_ARG, C3); }
+#define C3b(K) mm_freq_ticket_batch_k##K(h->impl, ticket, out)
+int32_t mm_freq_ticket_batch(mm_freq_t* h, int32_t ticket, mm_batch_t* out) { MM_FWD(h, MM_E_ARG, C3b); }
 #define C4(K) mm_freq_submit_device_k##K(h->impl, b, st)
 int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* st) { MM_FWD(h, -MM_E_ARG, C4); }
 #define C5(K) mm_freq_submit_device_now_k##K(h->impl, b, st, bases)

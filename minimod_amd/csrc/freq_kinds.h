@@ -18,6 +18,7 @@
 #define mm_freq_submit MM_K(mm_freq_submit)
 #define mm_freq_host_done MM_K(mm_freq_host_done)
 #define mm_freq_read_record MM_K(mm_freq_read_record)
+#define mm_freq_ticket_batch MM_K(mm_freq_ticket_batch)
 #define mm_freq_submit_device MM_K(mm_freq_submit_device)
 #define mm_freq_submit_device_now MM_K(mm_freq_submit_device_now)
 #define mm_freq_ticket_batches MM_K(mm_freq_ticket_batches)

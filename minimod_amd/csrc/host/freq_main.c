@@ -16,6 +16,7 @@
 
 #include "minimod_bgzf.h"
 #include "minimod_ingest.h"
+#include "minimod_tie.h"
 #include "mmhost.h"
 
 static struct option long_options[] = {
@@ -44,6 +45,7 @@ static struct option long_options[] = {
     {"no-gpu-inflate", no_argument, 0, 0},         /* 22 */
     {"gpu-ingest", no_argument, 0, 0},             /* 23 (new: the decoded BAM stays in GPU memory: inflate, record framing and load_db's flattening on the device) */
     {"no-gpu-ingest", no_argument, 0, 0},          /* 24 */
+    {"host-replay", no_argument, 0, 0},            /* 25 (new: minimod's row order replayed by the host's serial restatement instead of on the device) */
     {0, 0, 0, 0}};
 
 /* view takes neither -b nor -m (src/view_main.c:46-63); long options are matched by name below */
@@ -72,7 +74,7 @@ static struct option view_long_options[] = {
 
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
-    int progress_interval, device, view, canonical_order, gather, gpu_inflate, gpu_ingest;
+    int progress_interval, device, view, canonical_order, gather, gpu_inflate, gpu_ingest, host_replay;
     const char *codes, *threshes, *out_path, *devices;
     FILE *out;
 } fopt_t;
@@ -97,6 +99,7 @@ typedef struct {                           /* what a worker reports besides its 
     int64_t n_rows;                        /* rows sent to the parent (tied runs), else 0 */
     int64_t n_sections;                    /* sections of its part file (one per contig it has rows on), sent as wsection_t */
     int64_t n_tie_keys;                    /* tied runs: keys of its first-insertion sequence, sent behind the rows */
+    int64_t tie_put_after;                 /* ... and whether any put followed the sequence's last new key */
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;
     double load_time, wait_time, sort_time;
 } wtotals_t;
@@ -131,9 +134,11 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "   --gpu-inflate              inflate the BAM's BGZF blocks on the GPU as well (groups of 1024 blocks per launch, next to the\n"
                 "   --no-gpu-inflate           -t host threads; blocks the device refuses are the host decoder's) [%s]\n",
             o->gpu_inflate < 0 ? "for a BAM file of 4 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
+    if (!o->view) fprintf(fp, "   --host-replay              replay minimod's row order (rows that tie on contig and start) with the host's serial restatement of its\n"
+                              "                              hash table and sort instead of the device's parallel one (the checker; reads with the host threads) [%s]\n", o->host_replay ? "yes" : "no");
     if (!o->view) fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
                               "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
-                              "                              replay minimod's row order, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
+                              "                              --host-replay, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
                       o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
@@ -392,6 +397,44 @@ static void replay_group(mm_freq_t *hv, mmh_tie_t *tie, group_t *g, const mm_bam
 }
 
 
+/* The same on the device (round 5): the launch's rows stay in GPU memory (mm_view_fetch_device), the batch is the one the second handle
+ * launched (mm_freq_ticket_batch: the staging area's for host batches, the arena's for the device reader's), and k_tie_reads stamps
+ * every key (include/minimod_tie.h).  A replay that gives up is reported once, at the end. */
+static void tie_codes(mm_tie_t *dtie, mm_freq_t *hv, const uint8_t *const *klass_of_code, int *have) {
+    const char *codes[MM_MAX_CODES];
+    const int n_codes = code_names(hv, codes);
+    if (n_codes == *have) return;
+    (void)mm_tie_set_codes(dtie, n_codes, codes, klass_of_code);
+    *have = n_codes;
+}
+static void replay_ticket_dev(mm_freq_t *hv, mm_tie_t *dtie, int32_t ticket, const int32_t *n_reads, int n_batches, const mm_bam_hdr_t *hdr,
+                              const uint8_t *const *klass_of_code, int *have_codes, double *seconds) {
+    if (ticket < 0) return;
+    double t0 = mmh_realtime();
+    int32_t bad = -1;
+    const void *rows = NULL;
+    int64_t n = mm_view_fetch_device(hv, ticket, &rows, &bad);
+    replay_fetch_seconds += mmh_realtime() - t0;
+    if (n < 0) {
+        mm_read_t rec;
+        const int have = bad >= 0 && mm_freq_read_record(hv, ticket, bad, &rec) == 0;
+        int32_t in_batch = bad;
+        for (int m = 0; m < n_batches && in_batch >= n_reads[m]; m++) in_batch -= n_reads[m];
+        die_read_record((int)-n, in_batch, have ? &rec : NULL, hdr);
+    }
+    mm_batch_t db;
+    if (mm_freq_ticket_batch(hv, ticket, &db) == 0) {
+        tie_codes(dtie, hv, klass_of_code, have_codes);
+        (void)mm_tie_add_launch(dtie, &db, rows, n, NULL);
+    }
+    *seconds += mmh_realtime() - t0;
+}
+static void replay_group_dev(mm_freq_t *hv, mm_tie_t *dtie, group_t *g, const mm_bam_hdr_t *hdr, const uint8_t *const *klass_of_code, int *have_codes, double *seconds) {
+    if (g->ticket < 0) return;
+    replay_ticket_dev(hv, dtie, g->ticket, g->n_reads, g->n, hdr, klass_of_code, have_codes, seconds);
+    g->ticket = -1; g->n = 0; journal_reset(&g->j);
+}
+
 /* ---- workers of `--devices`: rows of other shares, sections of formatted text ---- */
 static int row_key_cmp(const mm_row_t *a, const mm_row_t *b);
 typedef struct { const int *rank; } rowcmp_t;
@@ -465,6 +508,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     int wildcard = 0, star_ctx = 0;
     for (int i = 0; i < mods.n_mods; i++) { if (strcmp(mods.code[i], "*") == 0) wildcard = 1; if (strcmp(mods.context[i], "*") == 0) star_ctx = 1; }
     int replay = !view && !o.canonical_order && (!ws->sharded || ws->tied) && (mods.n_mods > 1 || wildcard || star_ctx || o.insertions || o.haplotypes);
+    /* Round 5: the replay runs on the DEVICE (include/minimod_tie.h: a read's own table, the first-insertion stamps, the core table and the
+     * sort as parallel kernels) from the second handle's rows left in GPU memory -- nothing of it crosses PCIe but the final permutation,
+     * and a tied run reads its BAM with the device-side reader like any other.  --host-replay (or MINIMOD_HOST_REPLAY=1) keeps round 4's
+     * path: the serial restatement in tieorder.c, which is the device's checker. */
+    const int dev_replay = replay && !o.host_replay && !getenv("MINIMOD_HOST_REPLAY");
     mm_bgzf_t *bz = NULL;
     mmh_loader_t *ld = NULL;
     mmh_devloader_t *dl = NULL;   /* --gpu-ingest: the decoded BAM stays on the device (devloader.c) */
@@ -482,7 +530,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     uint64_t hdr_bytes = 0;
     /* the device loader takes the runs whose rows cannot tie (the headline run, -c m[CG]): the tie-order replay and the wildcard
      * code table work from host batches */
-    const int use_dev = o.gpu_ingest && !view && !replay && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
+    const int use_dev = o.gpu_ingest && !view && (!replay || dev_replay) && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
     if (use_dev) {
         hdr = &hdr0;
         pool = mm_pool_create(o.threads);
@@ -531,7 +579,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     /* process_db is called per -K batch (src/minimod.c:344-350); the library stages consecutive batches in GPU memory and
      * launches them together.  view prints a launch's rows when the launch is retired. */
     int gather = o.gather;
-    if (replay && gather == MMH_MAX_GATHER) {
+    if (replay && !dev_replay && gather == MMH_MAX_GATHER) {
         /* a run that replays the reference's row order keeps a launch's batches and its calls on the host until the launch has been
          * replayed: launches of about 24 000 reads (still streamed) instead of as many as the staging takes -- the replay of one
          * launch then runs beside the loading of the next ones, and 1.3 GB less is held (3 Gbases of HiFi reads, two codes: 1.96 ->
@@ -550,13 +598,26 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     }
     mm_freq_t *hv = NULL;      /* the second handle of a replay run: the same batches in view mode (rows with group ordinals) */
     mmh_tie_t *tie = NULL;
+    mm_tie_t *dtie = NULL;     /* the device-side replay (dev_replay) */
+    int dtie_codes = -1;       /* code strings it has been given */
     if (replay) {
         mm_freq_opts_t fv = fo;
         fv.view = 2;
         /* (gathered like the first handle's since round 4: its launches stream, a launch's rows are replayed from the group's journal) */
         hv = mm_freq_create(&fv, hdr->n_targets, ctg, 0, NULL, err, sizeof err);
-        tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
-        if (!hv || !tie) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
+        if (dev_replay) {
+            mm_tie_opts_t to;
+            memset(&to, 0, sizeof to);
+            to.abi_version = MM_TIE_ABI_VERSION; to.device = o.device; to.insertions = o.insertions; to.haplotypes = o.haplotypes; to.n_contigs = hdr->n_targets;
+            int64_t *tl = (int64_t *)malloc(sizeof(int64_t) * (size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1));
+            for (int t = 0; t < hdr->n_targets; t++) tl[t] = (int64_t)hdr->target_len[t];
+            char terr[256];
+            terr[0] = 0;
+            dtie = hv ? mm_tie_create(&to, (const char *const *)hdr->target_name, tl, terr, sizeof terr) : NULL;
+            free(tl);
+            if (hv && !dtie) { MMH_ERROR("Assertion failed. %s", terr); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
+        } else tie = mmh_tie_create(hdr, o.insertions, o.haplotypes);
+        if (!hv || (!tie && !dtie)) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     }
     free(ctg);
     mmh_free_ref(ref);   /* the reference now lives in HBM */
@@ -612,7 +673,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         /* load(N + 1) beside process(N), as in the reference's pipeline (src/freq_main.c:404-474) -- only that "load" here is the
          * device decoding the next batch while its freq kernels work on this one; the host moves compressed bytes.  Two batches'
          * tickets are kept open (their arenas stay theirs until they have been waited for), a third arena is being filled. */
-        int32_t tk[2] = {-1, -1};
+        int32_t tk[2] = {-1, -1}, tv[2] = {-1, -1};   /* (tv: the same batch's ticket of the replay's second handle) */
+        int32_t tvn[2] = {0, 0};
         int ar[2] = {-1, -1};
         void *stream = mmh_devloader_stream(dl);
         more = 1;
@@ -639,8 +701,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     const int have = bad >= 0 && mm_freq_read_record(h, tk[0], bad, &rec) == 0;
                     die_read_record(e, bad, have ? &rec : NULL, hdr);   /* (the read's index in the device's batch: -K does not cut those) */
                 }
+                if (dev_replay) replay_ticket_dev(hv, dtie, tv[0], &tvn[0], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
                 mmh_devloader_release(dl, ar[0]);
-                tk[0] = tk[1]; ar[0] = ar[1]; tk[1] = -1; ar[1] = -1;
+                tk[0] = tk[1]; ar[0] = ar[1]; tv[0] = tv[1]; tvn[0] = tvn[1]; tk[1] = -1; ar[1] = -1; tv[1] = -1;
                 if (more) break;
             }
             if (n > 0) {
@@ -648,7 +711,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 int32_t t = mm_freq_submit_device_now(h, &db.batch, stream, db.bases);
                 submit_time += mmh_realtime() - t_sub;
                 if (t < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(t)); exit(EXIT_FAILURE); }
-                if (tk[0] < 0) { tk[0] = t; ar[0] = db.arena; } else { tk[1] = t; ar[1] = db.arena; }
+                int32_t t2 = -1;
+                if (dev_replay) {   /* the same batch through the second handle, right behind the first on the reader's stream */
+                    t2 = mm_freq_submit_device_now(hv, &db.batch, stream, db.bases);
+                    if (t2 < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(t2)); exit(EXIT_FAILURE); }
+                }
+                if (tk[0] < 0) { tk[0] = t; ar[0] = db.arena; tv[0] = t2; tvn[0] = n; } else { tk[1] = t; ar[1] = db.arena; tv[1] = t2; tvn[1] = n; }
             }
             if (o.progress_interval <= 0 || mmh_realtime() - prog_t > o.progress_interval) {
                 fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bytes) processed\t%d Entries (%.1fM bytes) skipped\n", __func__,
@@ -674,6 +742,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 const int have = bad >= 0 && mm_freq_read_record(h, tk[k], bad, &rec) == 0;
                 die_read_record(e, bad, have ? &rec : NULL, hdr);
             }
+            if (dev_replay) replay_ticket_dev(hv, dtie, tv[k], &tvn[k], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
             mmh_devloader_release(dl, ar[k]);
         }
     }
@@ -691,7 +760,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
         /* the previous batch's pool set is about to be reused two iterations from now: retire it first */
         if (view) retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time);
-        if (replay) replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
+        if (dev_replay) replay_group_dev(hv, dtie, vprev, hdr, klass_of_code, &dtie_codes, &replay_time);
+        else if (replay) replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
         if (!view) retire_group(h, prev, hdr, &process_wait_time);
         if (n > 0) {
             if (wildcard) { intern_batch_codes(h, &batch); if (replay) intern_batch_codes(hv, &batch); }
@@ -714,12 +784,13 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 const int32_t vt = mm_freq_submit(hv, &batch);
                 if (vt < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(vt)); exit(EXIT_FAILURE); }
                 if (vt != vcur->ticket) {
-                    replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
+                    if (dev_replay) replay_group_dev(hv, dtie, vprev, hdr, klass_of_code, &dtie_codes, &replay_time);
+                    else replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time);
                     group_t *t = vprev; vprev = vcur; vcur = t;
                     vcur->ticket = vt; vcur->n = 0; journal_reset(&vcur->j);
                 }
                 if (vcur->n < MMH_MAX_GATHER) vcur->n_reads[vcur->n++] = n;
-                if (journal_add_mm(&vcur->j, &batch) != 0) { MMH_ERROR("%s", "Out of memory"); exit(EXIT_FAILURE); }
+                if (!dev_replay && journal_add_mm(&vcur->j, &batch) != 0) { MMH_ERROR("%s", "Out of memory"); exit(EXIT_FAILURE); }
                 /* (both handles copy out of the same pool set: the one checked below is the first's, whose copies were queued first ... */
                 if (mm_freq_host_done(hv, vt) != 0) { MMH_ERROR("%s", "GPU path failed"); exit(EXIT_FAILURE); }   /* ... so this one is waited for here) */
             }
@@ -740,7 +811,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         counter++;
     }
     if (view) { retire_view_group(h, prev, hdr, &o, pool, &process_wait_time, &output_time); retire_view_group(h, cur, hdr, &o, pool, &process_wait_time, &output_time); }
-    if (replay) { replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time); replay_group(hv, tie, vcur, hdr, pool, klass_of_code, &replay_time); }
+    if (dev_replay) { replay_group_dev(hv, dtie, vprev, hdr, klass_of_code, &dtie_codes, &replay_time); replay_group_dev(hv, dtie, vcur, hdr, klass_of_code, &dtie_codes, &replay_time); }
+    else if (replay) { replay_group(hv, tie, vprev, hdr, pool, klass_of_code, &replay_time); replay_group(hv, tie, vcur, hdr, pool, klass_of_code, &replay_time); }
     if (!view) { retire_group(h, prev, hdr, &process_wait_time); retire_group(h, cur, hdr, &process_wait_time); }
     journal_free(&cur->j); journal_free(&prev->j); journal_free(&vcur->j); journal_free(&vprev->j);
     free(cur); free(prev); free(vcur); free(vprev);
@@ -861,12 +933,24 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             tt.load_time = load_time; tt.wait_time = process_wait_time; tt.sort_time = sort_time;
             if (ws->tied) {
                 const void *tk = NULL; const uint32_t *th = NULL;
-                int64_t ntk = replay ? mmh_tie_export(tie, &tk, &th) : -1;
-                tt.n_rows = n_mine; tt.n_tie_keys = ntk;
+                int64_t ntk = -1;
+                int pal = 0;
+                void *dk = NULL; uint32_t *dh = NULL;
+                if (dev_replay) {   /* the sequence from the device: every key this worker's reads entered, in the order they did, as keys the parent's table takes */
+                    const int64_t nk = mm_tie_sequence_size(dtie);
+                    mm_row_t *kr = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(nk > 0 ? nk : 1));
+                    dk = malloc(16 * (size_t)(nk > 0 ? nk : 1)); dh = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nk > 0 ? nk : 1));
+                    int32_t pl = 0;
+                    if (nk >= 0 && kr && dk && dh && mm_tie_sequence(dtie, kr, dh, nk, &pl) == nk) { mmh_tie_keys_from_rows(kr, NULL, nk, dk); tk = dk; th = dh; ntk = nk; pal = pl; }
+                    else MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
+                    free(kr);
+                } else if (replay) ntk = mmh_tie_export2(tie, &tk, &th, &pal);
+                tt.n_rows = n_mine; tt.n_tie_keys = ntk; tt.tie_put_after = pal;
                 if (write_all(ws->fd, &tt, sizeof tt) || write_all(ws->fd, mine, sizeof(mm_row_t) * (size_t)n_mine) ||
                     (ntk > 0 && (write_all(ws->fd, tk, 16 * (size_t)ntk) || write_all(ws->fd, th, 4 * (size_t)ntk)))) {
                     MMH_ERROR("%s", "Could not send the rows to the parent process"); exit(EXIT_FAILURE);
                 }
+                free(dk); free(dh);
             } else {
                 FILE *pf = fopen(ws->part_path, "wb");
                 if (!pf) { MMH_ERROR("Cannot open file %s for writing", ws->part_path); exit(EXIT_FAILURE); }
@@ -894,7 +978,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             free(mine); free(fwd); free(rank);
             mm_freq_destroy(h);
             if (hv) mm_freq_destroy(hv);
-            mmh_tie_destroy(tie);
+            mmh_tie_destroy(tie); mm_tie_destroy(dtie);
             close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
             mm_bam_hdr_free(&hdr0);
             return 0;
@@ -903,8 +987,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (replay && nrows > 0) {   /* the same rows, in the order the reference's table and sort leave them in */
             double tr = mmh_realtime();
             ordered = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
-            if (ordered) memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
-            if (!ordered || mmh_tie_order_rows_mt(tie, pool, ordered, nrows) != 0) {
+            int ord_rc = -1;
+            if (ordered && dev_replay) {
+                uint32_t *perm = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nrows);
+                ord_rc = perm ? mm_tie_order_rows(dtie, rows, nrows, perm) : -1;
+                if (ord_rc == 0) for (int64_t i = 0; i < nrows; i++) ordered[i] = rows[perm[i]];
+                else MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
+                free(perm);
+            } else if (ordered) {
+                memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
+                ord_rc = mmh_tie_order_rows_mt(tie, pool, ordered, nrows);
+            }
+            if (!ordered || ord_rc != 0) {
                 MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
                 free(ordered); ordered = NULL;
             } else rows = ordered;
@@ -919,7 +1013,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         output_time += mmh_realtime() - to;
         free(ordered);
     }
-    if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort): %.3f sec (%.3f of them waiting for the calls of the second handle's launches)\n", __func__, replay_time, replay_fetch_seconds);
+    if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort, %s): %.3f sec (%.3f of them waiting for the calls of the second handle's launches)\n", __func__, dev_replay ? "on the device" : "on the host", replay_time, replay_fetch_seconds);
     if (mmh_emit_finish() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
     if (o.out != stdout) fclose(o.out);
     else fflush(stdout);
@@ -965,7 +1059,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mm_freq_destroy(h);
     if (hv) mm_freq_destroy(hv);
     tl_mark(realtime0, "handles destroyed");
-    mmh_tie_destroy(tie);
+    mmh_tie_destroy(tie); mm_tie_destroy(dtie);
     close_loaders(ld, dl, use_dev ? pool : NULL);
     tl_mark(realtime0, "loader closed");
     bz_stop(bz);
@@ -1224,7 +1318,7 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
         int ok = tie != NULL;
         for (int r = 0; r < nd && ok; r++) {
             if (tot[r].n_tie_keys < 0) ok = 0;
-            else if (tot[r].n_tie_keys > 0 && mmh_tie_import(tie, wtk[r], wth[r], tot[r].n_tie_keys) != 0) ok = 0;
+            else if (tot[r].n_tie_keys > 0 && mmh_tie_import2(tie, wtk[r], wth[r], tot[r].n_tie_keys, (int)tot[r].tie_put_after) != 0) ok = 0;
         }
         if (!ok || mmh_tie_order_rows(tie, out_rows, n_out) != 0)
             MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
@@ -1333,6 +1427,7 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "no-gpu-inflate") == 0) { o.gpu_inflate = 0;
         } else if (c == 0 && strcmp(lname, "gpu-ingest") == 0) { o.gpu_ingest = 1;
         } else if (c == 0 && strcmp(lname, "no-gpu-ingest") == 0) { o.gpu_ingest = 0;
+        } else if (c == 0 && strcmp(lname, "host-replay") == 0) { o.host_replay = 1;
         } else if (c == 0 && strcmp(lname, "gather") == 0) {
             o.gather = atoi(optarg);
             if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }

@@ -150,6 +150,9 @@ int mmh_tie_order_plain(const uint32_t *hash, const int64_t *sortkey, int64_t n,
  * workers of `--devices` replay their own reads, the parent strings the sequences together in file order */
 int64_t mmh_tie_export(const mmh_tie_t *t, const void **keys, const uint32_t **hash);
 int mmh_tie_import(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n);
+int64_t mmh_tie_export2(const mmh_tie_t *t, const void **keys, const uint32_t **hash, int *put_after_last);
+int mmh_tie_import2(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n, int put_after_last);
+void mmh_tie_keys_from_rows(const mm_row_t *rows, const uint32_t *seq, int64_t n, void *keys16);
 void mmh_tie_destroy(mmh_tie_t *t);
 
 int mmh_freq_main(int argc, char **argv);

@@ -736,7 +736,28 @@ int64_t mmh_tie_export(const mmh_tie_t *tc, const void **keys, const uint32_t **
     *keys = t->keys; *hash = t->hash;
     return (int64_t)t->n;
 }
+/* ... and whether any put followed the last new key's (a worker's reads may end on keys met before) */
+int64_t mmh_tie_export2(const mmh_tie_t *tc, const void **keys, const uint32_t **hash, int *put_after_last) {
+    const int64_t n = mmh_tie_export(tc, keys, hash);
+    if (put_after_last) *put_after_last = n >= 0 && tc->last_put > tc->top_stamp;
+    return n;
+}
+/* the same sequence from rows and the order they were first entered in (the device-side replay's mm_tie_sequence): opaque 16-byte keys */
+void mmh_tie_keys_from_rows(const mm_row_t *rows, const uint32_t *seq, int64_t n, void *keys16) {
+    tkey_t *k = (tkey_t *)keys16;
+    for (int64_t i = 0; i < n; i++) {
+        const mm_row_t *r = &rows[seq ? seq[i] : (uint32_t)i];
+        memset(&k[i], 0, sizeof k[i]);
+        k[i].tid = r->tid; k[i].pos = r->pos; k[i].ins = r->ins_offset; k[i].code = r->code; k[i].hp = r->hp; k[i].strand = r->strand;
+    }
+}
 /* ... appended to this sequence, in order (keys already in it keep their place) */
+int mmh_tie_import2(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n, int put_after_last) {
+    const uint64_t first = t ? t->reads_seen : 0;
+    const int rc = mmh_tie_import(t, keys, hash, n);
+    if (rc == 0 && put_after_last && n > 0) { const uint64_t lp = ((first + (uint64_t)n - 1) << 24) | 1u; if (lp > t->last_put) t->last_put = lp; }
+    return rc;
+}
 int mmh_tie_import(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_t n) {
     if (!t || t->failed) return -1;
     const tkey_t *k = (const tkey_t *)keys;

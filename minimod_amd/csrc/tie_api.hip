@@ -481,20 +481,42 @@ int32_t mm_tie_order_rows(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t
     return r;
 }
 
-int32_t mm_tie_sequence(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t* seq, uint32_t* hash, int32_t* put_after_last) {
-    if (!t || n < 0 || (n > 0 && (!rows || !seq || !hash))) return -MM_E_ARG;
+int64_t mm_tie_sequence_size(const mm_tie_t* t) { return t ? (int64_t)t->distinct : -MM_E_ARG; }
+
+int64_t mm_tie_sequence(mm_tie_t* t, mm_row_t* keys, uint32_t* hash, int64_t cap, int32_t* put_after_last) {
+    if (!t || cap < 0 || (cap > 0 && (!keys || !hash))) return -MM_E_ARG;
     if (t->failed) return -MM_E_NOCODE;
     if (put_after_last) *put_after_last = 0;
+    const uint64_t n = t->distinct;
     if (n == 0) return 0;
+    if ((uint64_t)cap < n) return -MM_E_ARG;
     if (hipSetDevice(t->o.device) != hipSuccess) return -MM_E_HIP;
+    hipStream_t st = t->st;
     Bufs B;
-    RowSeq q;
-    int r = rows_sequence(t, B, rows, (uint64_t)n, &q);
-    if (r) return r;
-    if (hipMemcpyAsync(seq, q.order, 4 * (size_t)n, hipMemcpyDeviceToHost, t->st) != hipSuccess || hipMemcpyAsync(hash, q.hash_r, 4 * (size_t)n, hipMemcpyDeviceToHost, t->st) != hipSuccess ||
-        hipStreamSynchronize(t->st) != hipSuccess) return -MM_E_HIP;
-    if (put_after_last) *put_after_last = q.put_after_last;
-    return 0;
+    u64* f = B.get<u64>(t->gcap);
+    u64* tiles = B.get<u64>(t->gcap / kScanTile + 4);
+    u64* ck = B.get<u64>(n);
+    u64* cs[2] = {B.get<u64>(n), B.get<u64>(n)};
+    uint32_t* idx[2] = {B.get<uint32_t>(n), B.get<uint32_t>(n)};
+    mm_row_t* d_rows = B.get<mm_row_t>(n);
+    uint32_t* d_hash = B.get<uint32_t>(n);
+    const uint32_t nblk = blocks(n, kSortTile);
+    uint32_t* hist = B.get<uint32_t>((size_t)256 * nblk + 8);
+    u64* d_or = B.get<u64>(2);
+    if (!f || !tiles || !ck || !cs[0] || !cs[1] || !idx[0] || !idx[1] || !d_rows || !d_hash || !hist || !d_or) return -MM_E_NOMEM;
+    LAUNCH(k_stamp_flags, blocks(t->gcap), 256, st, (const u64*)t->d_gkey, (u64)t->gcap, f);
+    scan64(f, t->gcap, tiles, st);
+    LAUNCH(k_stamp_gather, blocks(t->gcap), 256, st, (const u64*)t->d_gkey, (const u64*)t->d_gstamp, (u64)t->gcap, (const u64*)f, ck, cs[0]);
+    LAUNCH(k_iota32, blocks(n), 256, st, idx[0], (u64)n);
+    const int w = radix_sort(cs[0], idx[0], cs[1], idx[1], n, hist, d_or, &t->h_words[3], st);
+    if (w < 0) return -MM_E_HIP;
+    LAUNCH(k_key_decode, blocks(n), 256, st, tables_of(t), (const u64*)ck, (const uint32_t*)idx[w], (u64)n, d_rows, d_hash);
+    uint64_t top = 0, lastput = 0;
+    if (hipMemcpyAsync(keys, d_rows, sizeof(mm_row_t) * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hash, d_hash, 4 * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&top, cs[w] + (n - 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&lastput, t->d_words, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
+    if (put_after_last) *put_after_last = lastput > top ? 1 : 0;
+    return (int64_t)n;
 }
 
 uint32_t mm_tie_failed(const mm_tie_t* t) { return t ? t->failed : 0u; }

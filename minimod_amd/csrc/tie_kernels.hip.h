@@ -690,6 +690,45 @@ __global__ __launch_bounds__(256) void k_stamp_count(const u64* __restrict__ gk,
     const u64 b = __ballot(have);
     if (lane() == 0 && b) atomicAdd(count, (u64)__popcll(b));
 }
+// X31 of make_key's string for a key (src/mod.c:428-439)
+__device__ inline uint32_t key_x31(const TieTables& T, int32_t tid, int32_t pos, uint32_t strand, uint32_t code, uint32_t ins, int hp) {
+    const uint2 md = T.mid[(strand & 1u) * 64u + code];
+    uint32_t h = x31_dec(T.ctg_hash[tid], (long long)pos);
+    h = h * md.x + md.y;
+    h = x31_dec(h, (long long)ins);
+    h = x31_c(h, (uint32_t)'\t');
+    return x31_dec(h, (long long)hp);
+}
+// every key the table holds, in the order of their first insertion: entries -> (flags, scan) -> compact -> (sort by stamp) -> decoded
+__global__ __launch_bounds__(256) void k_stamp_flags(const u64* __restrict__ gk, u64 cap, u64* __restrict__ f) {
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (j < cap) f[j] = gk[j] != kNone64 ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void k_stamp_gather(const u64* __restrict__ gk, const u64* __restrict__ gs, u64 cap, const u64* __restrict__ incl, u64* __restrict__ out_k, u64* __restrict__ out_s) {
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (j >= cap) return;
+    const u64 k = gk[j];
+    if (k == kNone64) return;
+    const u64 at = incl[j] - 1ull;
+    out_k[at] = k; out_s[at] = gs[j];
+}
+__global__ __launch_bounds__(256) void k_key_decode(TieTables T, const u64* __restrict__ keys, const uint32_t* __restrict__ idx, u64 n, mm_row_t* __restrict__ out, uint32_t* __restrict__ hash) {
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const u64 key = keys[idx[j]];
+    const u64 gpos = key >> 29;
+    int lo = 0, hi = T.n_contigs - 1;   // the last contig whose first position is not behind gpos
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.ctg_base[mid] <= gpos) lo = mid; else hi = mid - 1; }
+    mm_row_t r;
+    r.tid = lo; r.pos = (int32_t)(gpos - T.ctg_base[lo]);
+    r.strand = (uint8_t)((key >> 28) & 1ull); r.rsvd = 0;
+    r.code = (int16_t)((key >> 22) & 63ull);
+    r.ins_offset = (uint16_t)((key >> 6) & 0xFFFFull);
+    r.hp = (int16_t)((int)(key & 63ull) - 1);
+    r.n_called = 0; r.n_mod = 0;
+    out[j] = r;
+    hash[j] = key_x31(T, r.tid, r.pos, r.strand, (uint32_t)r.code, r.ins_offset, (int)r.hp);
+}
 // per output row (any order): its stamp, the reference's hash of its key, what the comparator looks at
 __global__ __launch_bounds__(256) void k_tie_rows(TieTables T, const mm_row_t* __restrict__ rows, u64 n, const u64* __restrict__ gkey, const u64* __restrict__ gstamp, u64 gmask,
                                                   u64* __restrict__ stamp, uint32_t* __restrict__ hash, long long* __restrict__ sortkey, uint32_t* __restrict__ fail) {
@@ -707,12 +746,7 @@ __global__ __launch_bounds__(256) void k_tie_rows(TieTables T, const mm_row_t* _
     }
     if (st == kNone64) atomicOr(fail, (uint32_t)TIE_F_MISSING);
     stamp[j] = st;
-    const uint2 md = T.mid[(uint32_t)(w.strand & 1u) * 64u + (uint32_t)w.code];
-    uint32_t h = x31_dec(T.ctg_hash[w.tid], (long long)w.pos);
-    h = h * md.x + md.y;
-    h = x31_dec(h, (long long)w.ins_offset);
-    h = x31_c(h, (uint32_t)'\t');
-    hash[j] = x31_dec(h, (long long)w.hp);
+    hash[j] = key_x31(T, w.tid, w.pos, w.strand, (uint32_t)w.code, w.ins_offset, (int)w.hp);
     sortkey[j] = ((long long)T.ctg_rank[w.tid] << 32) + (long long)w.pos;
 }
 __global__ __launch_bounds__(256) void k_gather64(const long long* __restrict__ src, const uint32_t* __restrict__ idx, u64 n, long long* __restrict__ out) {

@@ -61,7 +61,7 @@ class mm_interval_t(ctypes.Structure):
 
 
 EXPORTS = ["mm_freq_plan_batch", "mm_freq_ticket_batches", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device", "mm_freq_submit_device_now",
-           "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
+           "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_freq_ticket_batch", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear", "mm_freq_slab_export_host", "mm_freq_slab_add_host", "mm_freq_slab_export_ipc", "mm_freq_slab_add_ipc",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_launch_counts", "mm_freq_reset_counters", "mm_freq_destroy"]
 
@@ -126,6 +126,8 @@ def load_library(build=True):
     L.mm_freq_host_done.argtypes = [vp, i32]
     L.mm_freq_read_record.restype = i32
     L.mm_freq_read_record.argtypes = [vp, i32, i32, vp]
+    L.mm_freq_ticket_batch.restype = i32
+    L.mm_freq_ticket_batch.argtypes = [vp, i32, ctypes.POINTER(mm_batch_t)]
     for f in ("mm_view_fetch", "mm_view_fetch_device"):
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i32)]
@@ -327,6 +329,14 @@ class FreqEngine(object):
         if e:
             raise MinimodHipError(e, "mm_freq_read_record: " + self.L.mm_strerror(e).decode())
         return out[0]
+
+    def ticket_batch(self, ticket):
+        """the ticket's batch as the device holds it (an mm_batch_t of device pointers)"""
+        b = mm_batch_t()
+        e = self.L.mm_freq_ticket_batch(self.h, ticket, ctypes.byref(b))
+        if e:
+            raise MinimodHipError(e, "mm_freq_ticket_batch: " + self.L.mm_strerror(e).decode())
+        return b
 
     def process(self, batch, order=None):
         self.wait(self.submit(batch, order))

@@ -27,8 +27,10 @@ def _lib():
         L.mm_tie_add_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.mm_tie_order_rows.restype = ctypes.c_int32
         L.mm_tie_order_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
-        L.mm_tie_sequence.restype = ctypes.c_int32
-        L.mm_tie_sequence.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mm_tie_sequence_size.restype = ctypes.c_int64
+        L.mm_tie_sequence_size.argtypes = [ctypes.c_void_p]
+        L.mm_tie_sequence.restype = ctypes.c_int64
+        L.mm_tie_sequence.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.mm_tie_failed.restype = ctypes.c_uint32
         L.mm_tie_failed.argtypes = [ctypes.c_void_p]
         L.mm_tie_device_bytes.restype = ctypes.c_int64
@@ -73,13 +75,16 @@ class TieReplay(object):
         r = self.L.mm_tie_order_rows(self.h, rows.ctypes.data, len(rows), perm.ctypes.data)
         return perm[:len(rows)] if r == 0 else None
 
-    def sequence(self, rows):
-        rows = np.ascontiguousarray(rows)
-        seq = np.zeros(max(1, len(rows)), np.uint32)
-        hsh = np.zeros(max(1, len(rows)), np.uint32)
+    def sequence(self):
+        """every key stamped so far in first-insertion order: (keys as ROW_DTYPE rows without counts, hashes, put_after_last) or None"""
+        n = int(self.L.mm_tie_sequence_size(self.h))
+        if n < 0:
+            return None
+        keys = np.zeros(max(1, n), E.ROW_DTYPE)
+        hsh = np.zeros(max(1, n), np.uint32)
         pal = ctypes.c_int32(0)
-        r = self.L.mm_tie_sequence(self.h, rows.ctypes.data, len(rows), seq.ctypes.data, hsh.ctypes.data, ctypes.byref(pal))
-        return (seq[:len(rows)], hsh[:len(rows)], int(pal.value)) if r == 0 else None
+        r = self.L.mm_tie_sequence(self.h, keys.ctypes.data, hsh.ctypes.data, n, ctypes.byref(pal))
+        return (keys[:n], hsh[:n], int(pal.value)) if r == n else None
 
     def failed(self):
         return int(self.L.mm_tie_failed(self.h))

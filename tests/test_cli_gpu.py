@@ -232,11 +232,30 @@ def test_cli_gpu_ingest_matches_reference_golden(exp, bam, ctg, kw, exact, fasta
     assert pick(r.stderr) == pick(r0.stderr) and len(pick(r.stderr)) == 7
 
 
-def test_cli_gpu_ingest_falls_back_where_it_must(fastas):
-    """runs that replay the reference's tie order, and view, read with the host threads whatever the flag says"""
-    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
-    r = subprocess.run([BIN, "freq", "--gpu-ingest", "-c", "m,h", "-m", "0.8,0.8", fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert r.returncode == 0 and b"[gpu-ingest]" not in r.stderr and r.stdout.decode() == open(os.path.join(GOLDEN, "expected", "test8.tsv")).read()
+TIED_CASES = [c for c in GOLDEN_CASES if not c[4] and c[0] not in CLI_SORTED_ONLY]   # test5a, 5b, 5c, 8, 12: rows tie, the reference's order is replayed
+
+
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", TIED_CASES, ids=["tied-" + c[0] for c in TIED_CASES])
+def test_cli_tied_runs_replay_on_the_device_and_take_the_device_reader(exp, bam, ctg, kw, exact, fastas):
+    """Round 5: the reference's tie order comes from the device-side replay (include/minimod_tie.h) by default -- with
+    the host threads reading, with the device-side reader (--gpu-ingest no longer falls back for tied runs), and for small groups of BGZF
+    blocks (several launches, tails carried over); --host-replay is round 4's serial restatement, the checker: the same bytes."""
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    base = [BIN, "freq"] + _args(kw)
+    tail = [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    for extra, env, marks in (([], {}, [b"on the device"]),
+                              (["--gpu-ingest"], {}, [b"on the device", b"[gpu-ingest]"]),
+                              (["--gpu-ingest"], {"MM_INGEST_MAX_BLOCKS": "8", "MM_INGEST_TARGET_BASES": "200000"}, [b"on the device", b"[gpu-ingest]"]),
+                              (["--host-replay"], {}, [b"on the host"]),
+                              (["--gpu-ingest", "--host-replay"], {}, [b"on the host"]),
+                              (["-K", "3"], {"MINIMOD_HOST_REPLAY": "1"}, [b"on the host"])):
+        r = subprocess.run(base + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        for m in marks:
+            assert m in r.stderr, (extra, m, r.stderr.decode()[-1500:])
+        if b"on the host" in marks[0]:
+            assert b"[gpu-ingest]" not in r.stderr   # the host replay works from host batches
+        assert r.stdout.decode() == want, (exp, extra, env)
 
 
 def test_cli_gpu_ingest_on_synthetic_bam(tmp_path):

@@ -60,6 +60,24 @@ def test_ingest_abi_symbols_exported():
         assert hasattr(H, name), name
 
 
+def test_tie_abi_symbols_exported():
+    """Every function include/minimod_tie.h declares is exported by the device library (no calls: there is no GPU here), and the host
+    library has the serial checker beside it."""
+    import ctypes, re
+    from minimod_amd import build
+    from minimod_amd.synth import host_lib
+    hdr = open(os.path.join(ROOT, "include", "minimod_tie.h")).read()
+    declared = set(re.findall(r"\b(mm_(?:tie|fmt)_[a-z_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert len(declared) >= 10
+    L = ctypes.CDLL(build.lib_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    H = host_lib()
+    for name in ("mmh_tie_order_plain", "mmh_tie_add_batch", "mmh_tie_order_rows_mt", "mmh_tie_export", "mmh_tie_import"):
+        assert hasattr(H, name), name
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
