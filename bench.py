@@ -569,8 +569,15 @@ def run_e2e_big(args):
                                              "peak_ram_gb": float(mp.group(1)) if mp else None, "peak_ram_gb_canonical": float(mp0.group(1)) if mp0 else None,
                                              "same_rows_as_canonical": sorted(open(os.path.join(tmp, "gpu_replay.bed"), "rb").read().splitlines()) == sorted(open(og, "rb").read().splitlines())
                                              if os.path.getsize(og) < (1 << 30) else None,
-                                             "what": "the default run of a tied configuration: a second handle in view mode delivers every call, the host replays the "
-                                                     "reference's hash table and sort (csrc/host/tieorder.c); --canonical-order skips it"}
+                                             "replay_on": "device" if "on the device" in err_rp else "host",
+                                             "gpu_ingest": bool(re.search(r"\[gpu-ingest\] ", err_rp)),
+                                             "what": "the default run of a tied configuration: a second handle in view mode leaves every call in GPU memory, the device replays the "
+                                                     "reference's per-read tables, core hash table and sort (csrc/tie_kernels.hip.h); --canonical-order skips it"}
+            # round 4's path, the serial restatement on the host (csrc/host/tieorder.c): the checker -- same bytes -- and the time it took
+            w_hr, err_hr = min((run([cli, "freq", "--host-replay"] + gpu_flags + common, os.path.join(tmp, "gpu_host_replay.bed")) for _ in range(2)), key=lambda x: x[0])
+            mh = re.search(r"Row order replay[^:]*: ([0-9.]+) sec", err_hr)
+            res["reference_order_replay"]["host_replay"] = {"wall_s": w_hr, "replay_s": float(mh.group(1)) if mh else None,
+                                                            "byte_identical_to_device_replay": md5(os.path.join(tmp, "gpu_host_replay.bed")) == md5(os.path.join(tmp, "gpu_replay.bed"))}
         print(json.dumps(res))
         sys.stdout.flush()
         return res

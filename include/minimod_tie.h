@@ -69,6 +69,27 @@ int32_t mm_tie_order_plain(int32_t device, const uint32_t *hash, const int64_t *
  * rounds in all, [4] sort levels, [5] segments finished by one thread, [6] milliseconds on the device */
 int32_t mm_tie_last_stats(uint64_t out[8]);
 
+/* ---- the row text on the device (second half): print_freq_output's fprintf per row, src/mod.c:666-719 ----
+ * One handle per output format.  mm_fmt_rows takes rows in printing order (host memory), makes their text on the device -- every
+ * "%d" and the "%f" of the frequency by integer arithmetic, csrc/fmt_core.h, checked against snprintf in the CPU suite -- and hands back
+ * the bytes in pinned host memory the handle owns (valid until its next call).  The header line (print_freq_header) is the caller's.
+ * A caller with more rows than it wants text for at once calls it piece by piece. */
+typedef struct mm_fmt_opts {
+    int32_t abi_version;     /* MM_TIE_ABI_VERSION */
+    int32_t device;
+    int32_t bedmethyl;       /* opt.bedmethyl_out: the bedMethyl columns, freq = n_mod * 100 / n_called (src/mod.c:671-690) */
+    int32_t insertions;      /* TSV only: the ins_offset column */
+    int32_t haplotypes;      /* TSV only: the haplotype column (`*` for -1) */
+    int32_t n_contigs;
+    int32_t n_codes;
+    int32_t rsvd;
+} mm_fmt_opts_t;
+typedef struct mm_fmt mm_fmt_t;
+mm_fmt_t *mm_fmt_create(const mm_fmt_opts_t *opts, const char *const *contig_names, const char *const *codes, char *err, size_t err_len);
+int64_t mm_fmt_rows(mm_fmt_t *f, const mm_row_t *rows, int64_t n, const char **text);   /* bytes of text, or -MM_E_* */
+float mm_fmt_last_kernel_ms(const mm_fmt_t *f);   /* device time of the last call's kernels (length, scan, write) */
+void mm_fmt_destroy(mm_fmt_t *f);
+
 #ifdef __cplusplus
 }
 #endif

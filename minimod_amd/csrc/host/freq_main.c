@@ -247,6 +247,48 @@ static int code_names(mm_freq_t *h, const char **codes) {
     return n;
 }
 
+/* print_freq_output's rows as text (src/mod.c:666-719).  Round 5: outputs of 65 536 rows and more are formatted ON THE DEVICE
+ * (include/minimod_tie.h mm_fmt_rows: every "%d" and the "%f" by integer arithmetic in a kernel, a piece of two million rows at a time;
+ * the host moves rows in and text out and writes it); smaller ones by the worker pool (emit.c), which needs no launch.  MINIMOD_FMT=device
+ * / host decides it by hand (the tests run both on the reference's goldens: the bytes are the same). */
+static double fmt_device_ms; static int64_t fmt_device_rows;
+static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes,
+                                int bedmethyl, int insertions, int haplotypes, int device) {
+    const char *e = getenv("MINIMOD_FMT");
+    const int use = e ? strcmp(e, "device") == 0 : n >= 65536;
+    if (use && n > 0) {
+        static mm_fmt_t *f; static int f_key = -1;
+        const int key = (bedmethyl ? 1 : 0) | (insertions ? 2 : 0) | (haplotypes ? 4 : 0) | (n_codes << 3);
+        if (f && f_key != key) { mm_fmt_destroy(f); f = NULL; }
+        if (!f) {
+            mm_fmt_opts_t fo;
+            memset(&fo, 0, sizeof fo);
+            fo.abi_version = MM_TIE_ABI_VERSION; fo.device = device; fo.bedmethyl = bedmethyl; fo.insertions = insertions; fo.haplotypes = haplotypes;
+            fo.n_contigs = hdr->n_targets; fo.n_codes = n_codes;
+            char ferr[256];
+            f = mm_fmt_create(&fo, (const char *const *)hdr->target_name, codes, ferr, sizeof ferr);
+            f_key = key;
+            if (!f) MMH_WARNING("the device-side row formatter could not be set up (%s): the host threads format", ferr);
+        }
+        if (f) {
+            if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+            const int64_t piece = (int64_t)2 << 20;
+            int ok = 1;
+            for (int64_t i = 0; i < n && ok; i += piece) {
+                const int64_t m = n - i < piece ? n - i : piece;
+                const char *text = NULL;
+                const int64_t nb = mm_fmt_rows(f, rows + i, m, &text);
+                if (nb < 0) { ok = 0; if (i == 0) break; MMH_ERROR("the device-side row formatter failed: %s", mm_strerror((int32_t)nb)); exit(EXIT_FAILURE); }
+                if (nb > 0 && fwrite(text, 1, (size_t)nb, fp) != (size_t)nb) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+                fmt_device_ms += mm_fmt_last_kernel_ms(f); fmt_device_rows += m;
+            }
+            if (ok) return;
+            MMH_WARNING("%s", "the device-side row formatter failed on its first piece: the host threads format");
+        }
+    }
+    mmh_print_freq_rows(fp, pool, rows, n, hdr, codes, n_codes, bedmethyl, insertions, haplotypes);
+}
+
 static int write_all(int fd, const void *buf, size_t n) {
     const char *p = (const char *)buf;
     while (n) {
@@ -963,7 +1005,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     while (j < n_mine && mine[j].tid == mine[i].tid) j++;
                     if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     const int64_t at = (int64_t)ftello(pf);
-                    mmh_print_freq_rows(pf, pool, mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+                    print_freq_rows_any(pf, pool, mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
                     if (mmh_emit_flush() != 0 || fflush(pf) != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     sec[n_sec].tid = mine[i].tid; sec[n_sec].pad = 0; sec[n_sec].off = at; sec[n_sec].len = (int64_t)ftello(pf) - at;
                     n_sec++;
@@ -1008,9 +1050,10 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         double to = mmh_realtime();
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
-        mmh_print_freq_rows(o.out, pool, rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes);
+        print_freq_rows_any(o.out, pool, rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
+        if (fmt_device_rows) fprintf(stderr, "[%s] %ld rows formatted on the device (k_fmt_len + scan + k_fmt_write: %.3f ms)\n", __func__, (long)fmt_device_rows, fmt_device_ms);
         free(ordered);
     }
     if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort, %s): %.3f sec (%.3f of them waiting for the calls of the second handle's launches)\n", __func__, dev_replay ? "on the device" : "on the host", replay_time, replay_fetch_seconds);

@@ -570,3 +570,5 @@ int32_t mm_tie_order_plain(int32_t device, const uint32_t* hash, const int64_t* 
 int32_t mm_tie_last_stats(uint64_t out[8]) { memcpy(out, g_stats, sizeof g_stats); return 0; }
 
 }  // extern "C"
+
+#include "fmt_api.hip.h"

@@ -12,6 +12,11 @@ class mm_tie_opts_t(ctypes.Structure):
                 ("n_contigs", ctypes.c_int32), ("rsvd", ctypes.c_int32)]
 
 
+class mm_fmt_opts_t(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("bedmethyl", ctypes.c_int32), ("insertions", ctypes.c_int32),
+                ("haplotypes", ctypes.c_int32), ("n_contigs", ctypes.c_int32), ("n_codes", ctypes.c_int32), ("rsvd", ctypes.c_int32)]
+
+
 MM_TIE_ABI_VERSION = 1
 _bound = [False]
 
@@ -39,6 +44,13 @@ def _lib():
         L.mm_tie_order_plain.restype = ctypes.c_int32
         L.mm_tie_order_plain.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.mm_tie_last_stats.argtypes = [ctypes.c_void_p]
+        L.mm_fmt_create.restype = ctypes.c_void_p
+        L.mm_fmt_create.argtypes = [ctypes.POINTER(mm_fmt_opts_t), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        L.mm_fmt_rows.restype = ctypes.c_int64
+        L.mm_fmt_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+        L.mm_fmt_last_kernel_ms.restype = ctypes.c_float
+        L.mm_fmt_last_kernel_ms.argtypes = [ctypes.c_void_p]
+        L.mm_fmt_destroy.argtypes = [ctypes.c_void_p]
         _bound[0] = True
     return L
 
@@ -104,3 +116,33 @@ class TieReplay(object):
             self.close()
         except Exception:
             pass
+
+
+class RowFormatter(object):
+    """print_freq_output's row text made on the device (mm_fmt_rows)."""
+
+    def __init__(self, names, codes, bedmethyl=False, insertions=False, haplotypes=False, device=0):
+        self.L = _lib()
+        o = mm_fmt_opts_t(MM_TIE_ABI_VERSION, int(device), int(bedmethyl), int(insertions), int(haplotypes), len(names), len(codes), 0)
+        cn = (ctypes.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        cc = (ctypes.c_char_p * max(1, len(codes)))(*[c.encode() for c in codes])
+        err = ctypes.create_string_buffer(512)
+        self.h = self.L.mm_fmt_create(ctypes.byref(o), cn, cc, err, 512)
+        if not self.h:
+            raise RuntimeError("mm_fmt_create: " + err.value.decode())
+
+    def format(self, rows):
+        rows = np.ascontiguousarray(rows)
+        p = ctypes.c_void_p()
+        n = self.L.mm_fmt_rows(self.h, rows.ctypes.data, len(rows), ctypes.byref(p))
+        if n < 0:
+            raise RuntimeError("mm_fmt_rows: %d" % n)
+        return ctypes.string_at(p.value, n) if n else b""
+
+    def kernel_ms(self):
+        return float(self.L.mm_fmt_last_kernel_ms(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.mm_fmt_destroy(self.h)
+            self.h = None

@@ -72,6 +72,21 @@ def test_cli_matches_reference_golden(exp, bam, ctg, kw, exact, fastas, tmp_path
         assert b"Row order replay" not in r2.stderr and b"Row order replay" in r.stderr
 
 
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", GOLDEN_CASES, ids=["devfmt-" + c[0] for c in GOLDEN_CASES])
+def test_cli_device_formatter_matches_reference_golden(exp, bam, ctg, kw, exact, fastas):
+    """the same goldens with the rows' text made on the device (MINIMOD_FMT=device: the default from 65 536 rows on; mm_fmt_rows,
+    SURVEY 8(f) row 3): byte for byte, the tie order replayed on the device in front of it"""
+    cmd = [BIN, "freq"] + _args(kw) + (["-b"] if exp.endswith("bedmethyl") else []) + [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MINIMOD_FMT="device"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"rows formatted on the device" in r.stderr
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    if exp in CLI_SORTED_ONLY:
+        assert sorted(r.stdout.decode().splitlines()) == sorted(want.splitlines())
+    else:
+        assert r.stdout.decode() == want
+
+
 def test_cli_tie_order_does_not_depend_on_batching(fastas):
     """The replayed order is a function of the reads in file order only (reference invariance): the
     same bytes for -K 1, -K 7 and -K 4096 with different thread counts, on the goldens that tie."""

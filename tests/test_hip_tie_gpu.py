@@ -217,3 +217,51 @@ def test_device_replay_reproduces_the_reference_goldens_byte_for_byte():
     bad = {k: v for k, v in res.items() if not v[0]}
     assert not bad, bad
     assert len(res) == 22
+
+
+# ---- the row text made on the device (mm_fmt_rows) ------------------------------------------------------------------------------------
+def _py_rows_text(rows, names, codes, bedmethyl, insertions, haplotypes):
+    out = []
+    for r in rows:
+        nc, nm, pos = int(r["n_called"]), int(r["n_mod"]), int(r["pos"])
+        st = "-" if r["strand"] else "+"
+        if bedmethyl:
+            out.append("%s\t%d\t%d\t%s\t%d\t%s\t%d\t%d\t255,0,0\t%d\t%f\n" % (names[r["tid"]], pos, pos + 1, codes[r["code"]], nc, st, pos, pos + 1, nc, float(nm) * 100 / nc))
+        else:
+            line = "%s\t%d\t%d\t%s\t%d\t%d\t%f\t%s" % (names[r["tid"]], pos, pos, st, nc, nm, float(nm) / nc, codes[r["code"]])
+            if insertions:
+                line += "\t%d" % int(r["ins_offset"])
+            if haplotypes:
+                line += "\t*" if r["hp"] < 0 else "\t%d" % int(r["hp"])
+            out.append(line + "\n")
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("fmt", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1)], ids=["tsv", "bedmethyl", "ins", "hp", "ins_hp"])
+def test_device_formatter_writes_the_reference_text(fmt):
+    """random rows over the whole range of counts, positions, contig and code names: the device's bytes are those of the reference's
+    fprintf formats (src/mod.c:685, :703-715; Python's %f rounds as glibc's does), row lengths included (the rows are packed)"""
+    from minimod_amd import engine as E, tie as T
+    bed, ins, hp = fmt
+    rng = np.random.default_rng(17 + bed + 2 * ins + 4 * hp)
+    n = 120000
+    names = ["chr1", "chr10_KI270825v1_alt", "chrX", "c"]
+    codes = ["m", "h", "76792", "hm", "a"]
+    rows = np.zeros(n, E.ROW_DTYPE)
+    rows["tid"] = rng.integers(0, len(names), n)
+    rows["pos"] = (rng.integers(0, 1 << 31, n) >> rng.integers(0, 31, n)).astype(np.int32)
+    rows["strand"] = rng.integers(0, 2, n)
+    rows["ins_offset"] = (rng.integers(0, 65536, n) >> rng.integers(0, 16, n)).astype(np.uint16)
+    rows["code"] = rng.integers(0, len(codes), n)
+    rows["hp"] = rng.integers(-1, 5, n)
+    nc = (rng.integers(1, 1 << 32, n, dtype=np.uint64) >> rng.integers(0, 31, n).astype(np.uint64)).astype(np.uint64)
+    nc[nc == 0] = 1
+    rows["n_called"] = nc.astype(np.uint32)
+    rows["n_mod"] = (rng.random(n) * (nc + 1)).astype(np.uint64).clip(0, nc).astype(np.uint32)
+    rows["n_mod"][:1000] = 0
+    rows["n_mod"][1000:2000] = rows["n_called"][1000:2000]
+    f = T.RowFormatter(names, codes, bedmethyl=bool(bed), insertions=bool(ins), haplotypes=bool(hp))
+    got = f.format(rows)
+    assert got == _py_rows_text(rows, names, codes, bed, ins, hp)
+    assert f.format(rows[:1]) == _py_rows_text(rows[:1], names, codes, bed, ins, hp) and f.format(rows[:0]) == b""
+    f.close()
