@@ -51,6 +51,8 @@ int32_t mm_tie_add_launch(mm_tie_t *t, const mm_batch_t *dev_batch, const void *
  * Returns 0, or -MM_E_* when the replay cannot be made for this input (a key without a stamp, a haplotype above 61, a read with more
  * than 2^18 calls...: mm_tie_failed says which); the caller then prints the canonical order, as it does when the host replay gives up. */
 int32_t mm_tie_order_rows(mm_tie_t *t, const mm_row_t *rows, int64_t n, uint32_t *perm);
+/* ... and / or the rows themselves in that order (either of perm, ordered may be NULL; `ordered` must not alias `rows`) */
+int32_t mm_tie_order_rows2(mm_tie_t *t, const mm_row_t *rows, int64_t n, uint32_t *perm, mm_row_t *ordered);
 /* Every key stamped so far in the order of its first insertion (a worker of `--devices` hands its own to the parent, which strings the
  * workers' sequences together: a key in a halo may have no row in this worker's output and still come first): keys[i] = the i-th key
  * entered as a row without counts, hash[i] = the reference's hash of its string, *put_after_last = whether any put followed the last
@@ -72,7 +74,8 @@ int32_t mm_tie_last_stats(uint64_t out[8]);
 /* ---- the row text on the device (second half): print_freq_output's fprintf per row, src/mod.c:666-719 ----
  * One handle per output format.  mm_fmt_rows takes rows in printing order (host memory), makes their text on the device -- every
  * "%d" and the "%f" of the frequency by integer arithmetic, csrc/fmt_core.h, checked against snprintf in the CPU suite -- and hands back
- * the bytes in pinned host memory the handle owns (valid until its next call).  The header line (print_freq_header) is the caller's.
+ * the bytes in host memory the handle owns -- two buffers taken in turn: a call's text stays valid until the call after the next one, so a
+ * caller can write one piece while the next is made.  The header line (print_freq_header) is the caller's.
  * A caller with more rows than it wants text for at once calls it piece by piece. */
 typedef struct mm_fmt_opts {
     int32_t abi_version;     /* MM_TIE_ABI_VERSION */

@@ -48,7 +48,7 @@ struct mm_fmt {
     char* d_names = nullptr; uint32_t *d_name_off = nullptr, *d_name_len = nullptr; char* d_codes = nullptr; uint32_t* d_code_len = nullptr;
     mm_row_t* d_rows = nullptr; u64* d_len = nullptr; u64* d_tiles = nullptr; size_t cap_rows = 0;
     char* d_text = nullptr; size_t cap_text = 0;
-    char* h_text = nullptr; size_t cap_htext = 0;   // pinned
+    char* h_text[2] = {nullptr, nullptr}; size_t cap_htext[2] = {0, 0}; int turn = 0;   // two host buffers taken in turn (plain memory: pinning 100 MB costs more than the copy)
     float last_ms = 0.f;
 };
 
@@ -120,19 +120,22 @@ int64_t mm_fmt_rows(mm_fmt_t* f, const mm_row_t* rows, int64_t n, const char** t
         if (hipMalloc((void**)&f->d_text, cap) != hipSuccess) return -MM_E_NOMEM;
         f->cap_text = cap;
     }
-    if (total + 64 > f->cap_htext) {
-        if (f->h_text) (void)hipHostFree(f->h_text);
-        f->h_text = nullptr; f->cap_htext = 0;
+    const int tn = f->turn;
+    f->turn ^= 1;
+    if (total + 64 > f->cap_htext[tn]) {
+        free(f->h_text[tn]);
+        f->h_text[tn] = nullptr; f->cap_htext[tn] = 0;
         const size_t cap = (size_t)total + (size_t)total / 8 + 4096;
-        if (hipHostMalloc((void**)&f->h_text, cap, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
-        f->cap_htext = cap;
+        f->h_text[tn] = (char*)malloc(cap);
+        if (!f->h_text[tn]) return -MM_E_NOMEM;
+        f->cap_htext[tn] = cap;
     }
     hipLaunchKernelGGL(k_fmt_write, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, (const mm_row_t*)f->d_rows, (u64)n, (const u64*)f->d_len, f->d_text);
     (void)hipEventRecord(e1, st);
-    if (hipMemcpyAsync(f->h_text, f->d_text, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
+    if (hipMemcpyAsync(f->h_text[tn], f->d_text, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
     (void)hipEventElapsedTime(&f->last_ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *text = f->h_text;
+    *text = f->h_text[tn];
     return (int64_t)total;
 }
 
@@ -144,7 +147,7 @@ void mm_fmt_destroy(mm_fmt_t* f) {
     if (f->st) (void)hipStreamSynchronize(f->st);
     void* ps[] = {f->d_names, f->d_name_off, f->d_name_len, f->d_codes, f->d_code_len, f->d_rows, f->d_len, f->d_tiles, f->d_text};
     for (void* p : ps) if (p) (void)hipFree(p);
-    if (f->h_text) (void)hipHostFree(f->h_text);
+    free(f->h_text[0]); free(f->h_text[1]);
     if (f->st) (void)hipStreamDestroy(f->st);
     delete f;
 }

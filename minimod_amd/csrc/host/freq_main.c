@@ -252,6 +252,8 @@ static int code_names(mm_freq_t *h, const char **codes) {
  * the host moves rows in and text out and writes it); smaller ones by the worker pool (emit.c), which needs no launch.  MINIMOD_FMT=device
  * / host decides it by hand (the tests run both on the reference's goldens: the bytes are the same). */
 static double fmt_device_ms; static int64_t fmt_device_rows;
+typedef struct { FILE *fp; const char *p; size_t n; int err; } fmt_wjob_t;
+static void *fmt_write_main(void *arg) { fmt_wjob_t *j = (fmt_wjob_t *)arg; if (j->n && fwrite(j->p, 1, j->n, j->fp) != j->n) j->err = 1; return NULL; }
 static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes,
                                 int bedmethyl, int insertions, int haplotypes, int device) {
     const char *e = getenv("MINIMOD_FMT");
@@ -272,16 +274,24 @@ static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows,
         }
         if (f) {
             if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
-            const int64_t piece = (int64_t)2 << 20;
-            int ok = 1;
+            /* a piece's text is written by a thread of its own while the device makes the next piece's (the handle's two buffers take turns) */
+            const int64_t piece = (int64_t)1 << 20;
+            int ok = 1, writing = 0;
+            pthread_t wt;
+            fmt_wjob_t job;
+            memset(&job, 0, sizeof job);
             for (int64_t i = 0; i < n && ok; i += piece) {
                 const int64_t m = n - i < piece ? n - i : piece;
                 const char *text = NULL;
                 const int64_t nb = mm_fmt_rows(f, rows + i, m, &text);
                 if (nb < 0) { ok = 0; if (i == 0) break; MMH_ERROR("the device-side row formatter failed: %s", mm_strerror((int32_t)nb)); exit(EXIT_FAILURE); }
-                if (nb > 0 && fwrite(text, 1, (size_t)nb, fp) != (size_t)nb) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
+                if (writing) { pthread_join(wt, NULL); writing = 0; if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
+                job.fp = fp; job.p = text; job.n = (size_t)nb; job.err = 0;
+                if (i + piece < n && pthread_create(&wt, NULL, fmt_write_main, &job) == 0) writing = 1;
+                else { (void)fmt_write_main(&job); if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
                 fmt_device_ms += mm_fmt_last_kernel_ms(f); fmt_device_rows += m;
             }
+            if (writing) { pthread_join(wt, NULL); if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
             if (ok) return;
             MMH_WARNING("%s", "the device-side row formatter failed on its first piece: the host threads format");
         }
@@ -1031,11 +1041,14 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             ordered = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
             int ord_rc = -1;
             if (ordered && dev_replay) {
-                uint32_t *perm = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nrows);
-                ord_rc = perm ? mm_tie_order_rows(dtie, rows, nrows, perm) : -1;
-                if (ord_rc == 0) for (int64_t i = 0; i < nrows; i++) ordered[i] = rows[perm[i]];
-                else MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
-                free(perm);
+                ord_rc = mm_tie_order_rows2(dtie, rows, nrows, NULL, ordered);
+                if (ord_rc != 0) MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
+                else {
+                    uint64_t ts[8];
+                    (void)mm_tie_last_stats(ts);
+                    fprintf(stderr, "[%s] tie order on the device: %ld rows, %lu kernel launches, %lu growths of the core table in %lu passes, %lu placement rounds, %lu sort levels, %.1f ms\n", __func__, (long)nrows,
+                            (unsigned long)ts[0], (unsigned long)ts[1], (unsigned long)ts[2], (unsigned long)ts[3], (unsigned long)ts[4], ts[6] / 1000.0);
+                }
             } else if (ordered) {
                 memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
                 ord_rc = mmh_tie_order_rows_mt(tie, pool, ordered, nrows);

@@ -295,7 +295,7 @@ int ensure_stamps(mm_tie* t, uint64_t incoming) {
 }
 
 // the rows' stamps, hashes and comparator keys; order[] = row indices by stamp.  Device arrays in B.
-struct RowSeq { uint32_t* order; uint32_t* hash_r; long long* sortkey_r; int put_after_last; };
+struct RowSeq { uint32_t* order; uint32_t* hash_r; long long* sortkey_r; int put_after_last; mm_row_t* d_rows; };
 int rows_sequence(mm_tie* t, Bufs& B, const mm_row_t* rows, uint64_t n, RowSeq* out) {
     hipStream_t st = t->st;
     mm_row_t* d_rows = B.get<mm_row_t>(n);
@@ -324,7 +324,7 @@ int rows_sequence(mm_tie* t, Bufs& B, const mm_row_t* rows, uint64_t n, RowSeq* 
     uint64_t top = 0, lastput = 0;
     if (hipMemcpyAsync(&top, stamp[w] + (n - 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&lastput, t->d_words, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
-    out->order = idx[w]; out->hash_r = hash_r; out->sortkey_r = sortkey_r; out->put_after_last = lastput > top ? 1 : 0;
+    out->order = idx[w]; out->hash_r = hash_r; out->sortkey_r = sortkey_r; out->put_after_last = lastput > top ? 1 : 0; out->d_rows = d_rows;
     return 0;
 }
 }  // namespace
@@ -453,8 +453,10 @@ int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view
     return 0;
 }
 
-int32_t mm_tie_order_rows(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t* perm) {
-    if (!t || n < 0 || (n > 0 && (!rows || !perm))) return -MM_E_ARG;
+int32_t mm_tie_order_rows(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t* perm) { return mm_tie_order_rows2(t, rows, n, perm, nullptr); }
+
+int32_t mm_tie_order_rows2(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t* perm, mm_row_t* ordered) {
+    if (!t || n < 0 || (n > 0 && (!rows || (!perm && !ordered)))) return -MM_E_ARG;
     if (t->failed) return -MM_E_NOCODE;
     if (n == 0) return 0;
     if (hipSetDevice(t->o.device) != hipSuccess) return -MM_E_HIP;
@@ -471,7 +473,15 @@ int32_t mm_tie_order_rows(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t
     if (!r) r = core_and_sort(q.hash_r, q.sortkey_r, (uint64_t)n, q.put_after_last, nullptr, d_final, t->st);
     if (!r) {
         LAUNCH(k_gather32, blocks((uint64_t)n), 256, t->st, (const uint32_t*)q.order, (const uint32_t*)d_final, (u64)n, d_perm);
-        if (hipMemcpyAsync(perm, d_perm, 4 * (size_t)n, hipMemcpyDeviceToHost, t->st) != hipSuccess) r = -MM_E_HIP;
+        if (perm && hipMemcpyAsync(perm, d_perm, 4 * (size_t)n, hipMemcpyDeviceToHost, t->st) != hipSuccess) r = -MM_E_HIP;
+        if (!r && ordered) {   // the rows themselves in that order (they are on the device already)
+            mm_row_t* d_ord = B.get<mm_row_t>((size_t)n);
+            if (!d_ord) r = -MM_E_NOMEM;
+            else {
+                LAUNCH(k_gather_rows, blocks((uint64_t)n), 256, t->st, (const mm_row_t*)q.d_rows, (const uint32_t*)d_perm, (u64)n, d_ord);
+                if (hipMemcpyAsync(ordered, d_ord, sizeof(mm_row_t) * (size_t)n, hipMemcpyDeviceToHost, t->st) != hipSuccess) r = -MM_E_HIP;
+            }
+        }
     }
     (void)hipEventRecord(e1, t->st);
     if (hipStreamSynchronize(t->st) != hipSuccess) r = r ? r : -MM_E_HIP;

@@ -753,6 +753,10 @@ __global__ __launch_bounds__(256) void k_gather64(const long long* __restrict__ 
     const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
 }
+__global__ __launch_bounds__(256) void k_gather_rows(const mm_row_t* __restrict__ src, const uint32_t* __restrict__ idx, u64 n, mm_row_t* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
 __global__ __launch_bounds__(256) void k_or_diff(const u64* __restrict__ keys, u64 n, u64* __restrict__ out) {   // which bits differ anywhere (passes of the sort that can be left out)
     const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
     u64 v = i < n ? (keys[i] ^ keys[0]) : 0ull;

@@ -32,6 +32,8 @@ def _lib():
         L.mm_tie_add_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.mm_tie_order_rows.restype = ctypes.c_int32
         L.mm_tie_order_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        L.mm_tie_order_rows2.restype = ctypes.c_int32
+        L.mm_tie_order_rows2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         L.mm_tie_sequence_size.restype = ctypes.c_int64
         L.mm_tie_sequence_size.argtypes = [ctypes.c_void_p]
         L.mm_tie_sequence.restype = ctypes.c_int64
