@@ -21,7 +21,7 @@ def source_hash():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(f for f in glob.glob(os.path.join(CSRC, "*.hip*")) if not os.path.basename(f).startswith(("bgzf_", "ingest_", "tie_", "fmt_"))) + [os.path.join(INCLUDE, "minimod_hip.h")]:
+    for f in sorted(f for f in glob.glob(os.path.join(CSRC, "*.hip*")) if not os.path.basename(f).startswith(("bgzf_", "ingest_", "tie_", "fmt_", "summary_"))) + [os.path.join(INCLUDE, "minimod_hip.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -89,7 +89,7 @@ def build_hip(force=False, verbose=False):
     # 33.9 us per batch, C3 -2.3 %, C5 -2.2 %, tools/ab.sh)
     freq_flags = ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]
     units = [("freq_api_k%d" % k, freq_srcs, ["-DMM_KIND=%d" % k] + freq_flags) for k in (0, 1, 2)] + \
-            [("freq_dispatch", dispatch_srcs, []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, []), ("tie_api", tie_srcs + [os.path.join(CSRC, "fmt_api.hip.h"), os.path.join(CSRC, "fmt_core.h")], [])]
+            [("freq_dispatch", dispatch_srcs, []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, []), ("tie_api", tie_srcs + [os.path.join(CSRC, "fmt_api.hip.h"), os.path.join(CSRC, "fmt_core.h"), os.path.join(CSRC, "summary_api.hip.h"), os.path.join(INCLUDE, "minimod_summary.h")], [])]
     todo = []
     for name, srcs, extra in units:
         obj = os.path.join(objdir, name + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))

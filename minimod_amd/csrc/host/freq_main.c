@@ -45,6 +45,7 @@ static struct option long_options[] = {
     {"no-gpu-inflate", no_argument, 0, 0},         /* 22 */
     {"gpu-ingest", no_argument, 0, 0},             /* 23 (new: the decoded BAM stays in GPU memory: inflate, record framing and load_db's flattening on the device) */
     {"no-gpu-ingest", no_argument, 0, 0},          /* 24 */
+    {"region", required_argument, 0, 0},           /* 26 (new: chr:from-to, through the .bai -- the reference's own region code is commented out, src/minimod.c:92-130) */
     {"host-replay", no_argument, 0, 0},            /* 25 (new: minimod's row order replayed by the host's serial restatement instead of on the device) */
     {0, 0, 0, 0}};
 
@@ -75,7 +76,8 @@ static struct option view_long_options[] = {
 typedef struct {
     int32_t K; int64_t B; int threads, debug_break, bedmethyl, insertions, haplotypes, allow_secondary, skip_supplementary;
     int progress_interval, device, view, canonical_order, gather, gpu_inflate, gpu_ingest, host_replay;
-    const char *codes, *threshes, *out_path, *devices;
+    const char *codes, *threshes, *out_path, *devices, *region;
+    int32_t region_tid; int64_t region_beg, region_end;   /* --region resolved against the BAM header: rows of [beg, end) on that contig are printed */
     FILE *out;
 } fopt_t;
 
@@ -140,6 +142,8 @@ static void print_help(FILE *fp, const fopt_t *o) {
                               "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
                               "                              --host-replay, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
                       o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
+    if (!o->view) fprintf(fp, "   --region STR               only the rows of chr:from-to (1-based, inclusive; chr alone: the whole contig): the reads that can reach it are\n"
+                              "                              found through reads.bam.bai and counted, rows outside are dropped [%s]\n", o->region ? o->region : "whole file");
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
 }
 
@@ -1061,12 +1065,22 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             sort_time += mmh_realtime() - tr;
         }
         double to = mmh_realtime();
+        mm_row_t *inside = NULL;
+        if (o.region && nrows > 0) {   /* (ordered first, over every key the run made: the order of what is left is the run's) */
+            inside = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
+            if (!inside) { MMH_ERROR("%s", "Out of memory"); exit(EXIT_FAILURE); }
+            int64_t k = 0;
+            for (int64_t i = 0; i < nrows; i++) if (rows[i].tid == o.region_tid && (int64_t)rows[i].pos >= o.region_beg && (int64_t)rows[i].pos < o.region_end) inside[k++] = rows[i];
+            fprintf(stderr, "[%s] --region %s: %ld of the %ld rows the region's reads made lie inside it\n", __func__, o.region, (long)k, (long)nrows);
+            rows = inside; nrows = k;
+        }
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
         print_freq_rows_any(o.out, pool, rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
         if (fmt_device_rows) fprintf(stderr, "[%s] %ld rows formatted on the device (k_fmt_len + scan + k_fmt_write: %.3f ms)\n", __func__, (long)fmt_device_rows, fmt_device_ms);
+        free(inside);
         free(ordered);
     }
     if (replay) fprintf(stderr, "[%s] Row order replay (the reference's hash table and sort, %s): %.3f sec (%.3f of them waiting for the calls of the second handle's launches)\n", __func__, dev_replay ? "on the device" : "on the host", replay_time, replay_fetch_seconds);
@@ -1484,6 +1498,7 @@ static int run_main(int argc, char **argv, int view) {
         } else if (c == 0 && strcmp(lname, "gpu-ingest") == 0) { o.gpu_ingest = 1;
         } else if (c == 0 && strcmp(lname, "no-gpu-ingest") == 0) { o.gpu_ingest = 0;
         } else if (c == 0 && strcmp(lname, "host-replay") == 0) { o.host_replay = 1;
+        } else if (c == 0 && strcmp(lname, "region") == 0) { o.region = optarg;
         } else if (c == 0 && strcmp(lname, "gather") == 0) {
             o.gather = atoi(optarg);
             if (o.gather < 1) { MMH_ERROR("--gather should be at least 1. You entered %d", o.gather); exit(EXIT_FAILURE); }
@@ -1544,6 +1559,7 @@ static int run_main(int argc, char **argv, int view) {
     mmh_ref_t *ref = mmh_load_ref_mt(ref_file, o.threads > 0 ? o.threads : 1);
     if (!ref) { MMH_ERROR("Could not to open file %s", ref_file); exit(EXIT_FAILURE); }
     fprintf(stderr, "[%s] Reference genome loaded in %.3f sec\n", __func__, mmh_realtime() - t1);
+    if (o.devices && strchr(o.devices, ',') && o.region) { MMH_ERROR("%s", "--region and --devices a,b,... do not go together"); exit(EXIT_FAILURE); }
     if (o.devices && strchr(o.devices, ',')) return run_devices(&o, &mods, ref, bam_file, realtime0);
     if (o.devices) {   /* one ordinal: the same as --device */
         char *end = NULL;
@@ -1555,6 +1571,52 @@ static int run_main(int argc, char **argv, int view) {
     wspec_t ws;
     memset(&ws, 0, sizeof ws);
     ws.fd = -1;
+    if (o.region) {
+        /* a region run is a run over the reads that can reach the region -- from the virtual offset the index's
+         * linear part gives for the 16 kb window of its first position (every read overlapping that window lies behind it) to the
+         * first read that starts behind its end -- with the dense counters over the region alone; what those reads call outside it is
+         * dropped when the rows are printed.  The counts are the whole file's for those positions (tests/test_cli_gpu.py). */
+        if (view) { MMH_ERROR("%s", "--region is a freq option"); exit(EXIT_FAILURE); }
+        mm_bam_hdr_t rh;
+        memset(&rh, 0, sizeof rh);
+        if (mm_bam_peek_header(bam_file, &rh) != 0) { MMH_ERROR("Could not read the header of %s (--region needs a regular, indexed BAM file)", bam_file); exit(EXIT_FAILURE); }
+        char name[1024];
+        int64_t from = 1, to = INT64_MAX;
+        const char *colon = strrchr(o.region, ':');
+        int ranged = 0;
+        if (colon && colon[1]) {   /* digits, commas, one '-' behind the last colon: a range; anything else: part of the name */
+            const char *q = colon + 1;
+            int ok = 1, dash = 0;
+            for (const char *z = q; *z; z++) { if (*z == '-') dash++; else if (!((*z >= '0' && *z <= '9') || *z == ',')) ok = 0; }
+            if (ok && dash <= 1 && q[0] != '-') {
+                ranged = 1;
+                int64_t v[2] = {0, 0}; int k = 0, any[2] = {0, 0};
+                for (const char *z = q; *z; z++) { if (*z == '-') k = 1; else if (*z != ',') { v[k] = v[k] * 10 + (*z - '0'); any[k] = 1; } }
+                from = any[0] ? v[0] : 1;
+                to = any[1] ? v[1] : INT64_MAX;
+            }
+        }
+        const size_t nl = ranged ? (size_t)(colon - o.region) : strlen(o.region);
+        if (nl == 0 || nl >= sizeof name) { MMH_ERROR("--region takes chr:from-to. You entered %s", o.region); exit(EXIT_FAILURE); }
+        memcpy(name, o.region, nl); name[nl] = 0;
+        int32_t tid = -1;
+        for (int32_t t = 0; t < rh.n_targets; t++) if (strcmp(rh.target_name[t], name) == 0) { tid = t; break; }
+        if (tid < 0) { MMH_ERROR("--region: no contig %s in the header of %s", name, bam_file); exit(EXIT_FAILURE); }
+        if (from < 1) from = 1;
+        if (to > (int64_t)rh.target_len[tid]) to = (int64_t)rh.target_len[tid];
+        if (to < from) { MMH_ERROR("--region: an empty range (%s)", o.region); exit(EXIT_FAILURE); }
+        o.region_tid = tid; o.region_beg = from - 1; o.region_end = to;
+        char bai_path[4096];
+        snprintf(bai_path, sizeof bai_path, "%s.bai", bam_file);
+        mm_bai_t *bai = mm_bai_load(bai_path);
+        if (!bai) { MMH_ERROR("Could not read the index %s (--region needs it: samtools index reads.bam)", bai_path); exit(EXIT_FAILURE); }
+        ws.sharded = 1; ws.tied = 1; ws.first = 0; ws.last = 0;
+        ws.n_iv = 1; ws.iv[0].tid = tid; ws.iv[0].begin = o.region_beg; ws.iv[0].end = o.region_end; ws.iv[0].halo = 0;
+        ws.lo_tid = tid; ws.lo_pos = 0; ws.hi_tid = tid; ws.hi_pos = o.region_end;
+        ws.voffset = mm_bai_start(bai, tid, o.region_beg);
+        mm_bai_free(bai);
+        mm_bam_hdr_free(&rh);
+    }
     const int rc = run_body(&o, &mods, ref, bam_file, realtime0, &ws);   /* (its first HIP call waits for the runtime's start if that is still under way) */
     if (warming) pthread_join(warm_thread, NULL);
     return rc;

@@ -1,6 +1,9 @@
 /* summary_main.c -- `minimod summary reads.bam`: per read, the set of (canonical base | modification codes | status flag)
  * of its MM groups that list at least one call (reference src/summary_main.c:46-60,156-420 driver, summary_single
- * src/mod.c:1426-1555, print_summary_output src/mod.c:1373-1400).  Host only: there is nothing here for a GPU.
+ * src/mod.c:1426-1555, print_summary_output src/mod.c:1373-1400).  Two ways to the same bytes: this file's host walk (the default: a
+ * census of a few hundred characters a read needs no GPU, and `minimod summary` must run on a box without one), and with --gpu the
+ * census kernel of include/minimod_summary.h (k_sum_reads: a thread per read, the read's table replayed as khash fills it) -- SURVEY
+ * section 8(f) row 4 on the device, checked against the reference's goldens in the GPU suite.
  *
  * The reference keeps a read's keys in a khash string map and prints them in the table's slot order.  To print the same
  * bytes this file keeps a table with the same observable behaviour -- X31 string hash, power-of-two slots, probe
@@ -12,6 +15,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include "minimod_summary.h"
 #include "mmhost.h"
 
 /* ------------------------------------------------------------------ slot-order string set */
@@ -151,6 +155,8 @@ static struct option long_options[] = {
     {"output", required_argument, 0, 'o'},
     {"allow-secondary", no_argument, 0, 0},
     {"skip-supplementary", no_argument, 0, 0},
+    {"gpu", no_argument, 0, 0},
+    {"device", required_argument, 0, 0},
     {0, 0, 0, 0}};
 
 static void print_help(FILE *fp, int threads, int32_t K, int64_t B, int prog, const char *out, int sec, int sup) {
@@ -168,6 +174,8 @@ static void print_help(FILE *fp, int threads, int32_t K, int64_t B, int prog, co
     fprintf(fp, "   --skip-supplementary       skip supplementary alignments [%s]\n", sup ? "yes" : "no");
     fprintf(fp, "\nadvanced options:\n");
     fprintf(fp, "   --debug-break INT          break after processing the specified no. of batches\n");
+    fprintf(fp, "   --gpu                      the census on the GPU (a thread per read; the same bytes)\n");
+    fprintf(fp, "   --device INT               GPU to use with --gpu [0]\n");
 }
 
 int mmh_summary_main(int argc, char **argv) {
@@ -176,7 +184,7 @@ int mmh_summary_main(int argc, char **argv) {
     int longindex = 0, c;
     FILE *fp_help = stderr, *out = stdout;
     int32_t K = 512; int64_t B = 20 * 1000 * 1000;
-    int threads = 8, debug_break = -1, prog = 0, sec = 0, sup = 0;
+    int threads = 8, debug_break = -1, prog = 0, sec = 0, sup = 0, gpu = 0, device = 0;
     const char *out_path = NULL;
     while ((c = getopt_long(argc, argv, optstring, long_options, &longindex)) >= 0) {
         const char *lname = c == 0 ? long_options[longindex].name : "";
@@ -207,6 +215,8 @@ int mmh_summary_main(int argc, char **argv) {
         } else if (c == 0 && strcmp(lname, "debug-break") == 0) { debug_break = atoi(optarg);
         } else if (c == 0 && strcmp(lname, "allow-secondary") == 0) { sec = 1;
         } else if (c == 0 && strcmp(lname, "skip-supplementary") == 0) { sup = 1;
+        } else if (c == 0 && strcmp(lname, "gpu") == 0) { gpu = 1;
+        } else if (c == 0 && strcmp(lname, "device") == 0) { device = atoi(optarg);
         } else {
             print_help(fp_help, threads, K, B, prog, out_path, sec, sup);
             exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
@@ -222,6 +232,12 @@ int mmh_summary_main(int argc, char **argv) {
     mmh_loader_t *ld = mmh_loader_open(bam_file, threads, K, B, sec, sup);
     if (!ld) { MMH_ERROR("NULL returned: could not open or parse %s.", bam_file); exit(EXIT_FAILURE); }
 
+    mm_summary_t *census = NULL;
+    if (gpu) {
+        char cerr[256];
+        census = mm_summary_create(device, cerr, sizeof cerr);
+        if (!census) { MMH_ERROR("--gpu: %s", cerr); exit(EXIT_FAILURE); }   /* (asked for by name: no quiet fallback) */
+    }
     fprintf(out, "read_id\t modifications\n");     /* print_summary_header, src/mod.c:1370 */
     int more = 1, counter = 0, set = 0;
     mm_batch_t batch;
@@ -230,6 +246,27 @@ int mmh_summary_main(int argc, char **argv) {
         if (n < 0) { MMH_ERROR("%s", "Truncated or corrupt BAM file"); exit(EXIT_FAILURE); }
         fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bases) loaded\n", __func__, mmh_realtime() - realtime0,
                 mmh_cputime() / (mmh_realtime() - realtime0), n, ld->last_processed_bytes / (1000.0 * 1000.0));
+        if (census && n > 0) {
+            const char *text = NULL; const uint64_t *off = NULL; const uint32_t *len = NULL;
+            int32_t bad = -1;
+            const int32_t e = mm_summary_batch(census, &batch, &text, &off, &len, &bad);
+            if (e) {
+                switch (e) {   /* the reference's messages, src/mod.c:1467-1530 */
+                    case MM_E_MMBASE: die("Assertion failed. Invalid base in the MM tag");
+                    case MM_E_MMSTRAND: die("Assertion failed. Invalid strand in the MM tag");
+                    case MM_E_MMCODE: die("Invalid base modification code. Modification codes should be either numeric or alphabetic.");
+                    case MM_E_MMEMPTY: die("Assertion failed. Invalid modification codes. Modification codes cannot be empty.");
+                    case MM_E_MMMIXED: die("Assertion failed. Invalid modification codes. Modification codes should be either numeric or alphabetic, not both.");
+                    case MM_E_SKIPLEN: die("Assertion failed. Skip count longer than 9 characters");
+                    default: MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE);
+                }
+            }
+            for (int32_t i = 0; i < n; i++) {
+                fputs(mmh_loader_qname(ld, set, i), out); fputc('\t', out);
+                if (len[i]) fwrite(text + off[i], 1, len[i], out);
+                fputc('\n', out);
+            }
+        } else
         for (int32_t i = 0; i < n; i++) {
             const mm_read_t *rd = &batch.reads[i];
             slotset_t keys;
@@ -253,6 +290,7 @@ int mmh_summary_main(int argc, char **argv) {
     fprintf(stderr, "[%s] total entries: %ld", __func__, (long)ld->total_reads);
     fprintf(stderr, "\n[%s] total skipped entries: %ld", __func__, (long)(ld->total_reads - ld->processed_reads));
     fprintf(stderr, "\n[%s] total processed entries: %ld\n", __func__, (long)ld->processed_reads);
+    if (census) { fprintf(stderr, "[%s] census on the device (k_sum_reads)\n", __func__); mm_summary_destroy(census); }
     mmh_loader_close(ld);
     return 0;
 }

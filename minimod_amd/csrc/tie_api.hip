@@ -582,3 +582,4 @@ int32_t mm_tie_last_stats(uint64_t out[8]) { memcpy(out, g_stats, sizeof g_stats
 }  // extern "C"
 
 #include "fmt_api.hip.h"
+#include "summary_api.hip.h"

@@ -301,3 +301,21 @@ def test_cli_gpu_ingest_on_synthetic_bam(tmp_path):
     open(cut, "wb").write(raw[:len(raw) * 2 // 3])
     r = subprocess.run([BIN, "freq", "--gpu-ingest", "-b", fa, cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 1 and b"Truncated or corrupt BAM file" in r.stderr
+
+
+# ---- `minimod summary --gpu`: the census kernel (include/minimod_summary.h)
+def test_cli_summary_census_on_the_device_matches_reference_goldens():
+    """the reference's five summary goldens (test/test.sh:252-256,494-503; plain diff there: the order of a read's keys is the slot order of
+    its khash) through k_sum_reads -- a thread per read walks the MM groups and fills the read's table as khash would -- for two batchings,
+    and the same bytes as the host walk on a file with every kind of group (ChEBI codes, multi-letter codes, groups without calls)"""
+    from tests.test_host_cpu import SUMMARY_CASES
+    for exp, bam, extra in SUMMARY_CASES:
+        for more in ([], ["-K", "7", "-t", "3"]):
+            r = subprocess.run([BIN, "summary", "--gpu"] + extra + more + [os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            assert b"census on the device" in r.stderr
+            assert r.stdout.decode() == open(os.path.join(GOLDEN, "expected", exp)).read(), (exp, more)
+    for bam in sorted(f for f in os.listdir(os.path.join(GOLDEN, "data")) if f.endswith(".bam")):
+        a = subprocess.run([BIN, "summary", os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        b = subprocess.run([BIN, "summary", "--gpu", os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert a.returncode == b.returncode and a.stdout == b.stdout, bam

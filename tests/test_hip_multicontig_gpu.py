@@ -291,3 +291,45 @@ def test_cli_devices_needs_the_index(genome, tmp_path):
     synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
     r = subprocess.run([BIN, "freq", "--devices", "0,0", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 1 and b"Could not read the index" in r.stderr
+
+
+@pytest.mark.parametrize("cfg", [(["-c", "m[CG]", "-m", "0.8"], True), (["-b", "-c", "m[CG]"], True), (["-c", "m[CG],h[CG]", "-m", "0.8,0.7"], False), (["-c", "m[CG]", "--haplotypes", "--insertions"], False)],
+                         ids=["m", "bedmethyl", "m_h", "hap_ins"])
+def test_cli_region_equals_the_full_run_restricted_to_the_region(cfg, genome, tmp_path):
+    """`minimod freq --region chr:from-to` (the reference's own region code is commented out, src/minimod.c:92-130):
+    the reads that can reach the region come through the .bai's linear index, the dense counters cover the region alone, rows outside
+    are dropped -- what is printed is the FULL run's rows of those positions (counts included: every read over the region is in), in
+    the full run's order where rows cannot tie; with the host threads and with the device-side reader."""
+    from minimod_amd import synth
+    flags, exact = cfg
+    gen = dict(haplotypes=True, long_insertions=True) if "--haplotypes" in flags else {}
+    bs = _batches(genome, **gen)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    base = [BIN, "freq", "-K", "200", "-t", "4"] + flags
+    full = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert full.returncode == 0, full.stderr.decode()[-2000:]
+    lines = full.stdout.decode().splitlines(True)
+    header = [l for l in lines if l.startswith("contig\t")]
+    body = [l for l in lines if not l.startswith("contig\t")]
+    for region, name, lo, hi in (("chr2:300,001-500000", "chr2", 300000, 500000), ("chr10", "chr10", 0, LENS[2]), ("chrX:1-70000", "chrX", 0, 70000),
+                                 ("chr1:1040000-", "chr1", 1039999, LENS[0]), ("chr2:777777-777777", "chr2", 777776, 777777)):
+        want = [l for l in body if l.split("\t")[0] == name and lo <= int(l.split("\t")[1]) < hi]
+        for extra in ([], ["--gpu-ingest"]):
+            r = subprocess.run(base + extra + ["--region", region, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            got = r.stdout.decode().splitlines(True)
+            assert got[:len(header)] == header
+            got = got[len(header):]
+            if exact:
+                assert got == want, (region, extra)
+            else:
+                assert sorted(got) == sorted(want), (region, extra)
+            assert len(want) > 0 or region.endswith("777777")
+            assert b"--region" in r.stderr and (b"[gpu-ingest]" in r.stderr) == bool(extra)
+    bad = subprocess.run(base + ["--region", "chrNone:1-5", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert bad.returncode == 1 and b"no contig chrNone" in bad.stderr
+    os.remove(bam + ".bai")
+    noidx = subprocess.run(base + ["--region", "chr2", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert noidx.returncode == 1 and b"index" in noidx.stderr

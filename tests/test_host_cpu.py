@@ -78,6 +78,17 @@ def test_tie_abi_symbols_exported():
         assert hasattr(H, name), name
 
 
+def test_summary_abi_symbols_exported():
+    import ctypes, re
+    from minimod_amd import build
+    hdr = open(os.path.join(ROOT, "include", "minimod_summary.h")).read()
+    declared = {d for d in set(re.findall(r"\b(mm_summary_[a-z_]+)\s*\(", hdr)) if not d.endswith("_t")}
+    assert declared == {"mm_summary_create", "mm_summary_batch", "mm_summary_destroy"}
+    L = ctypes.CDLL(build.lib_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
