@@ -44,13 +44,15 @@ def library_source_hash():
 
 
 def built_library_hash(path=None):
-    """the hash the library at `path` was built from (None: it does not say, or cannot be loaded)"""
-    import ctypes
+    """the hash the library at `path` was built from (None: it does not say).  Read from the file's bytes -- the marker string
+    'MMSRCHASH=<hex>' the BGZF unit carries -- not through dlopen: glibc caches a loaded library by path name, so a later CDLL of the
+    relinked file would hand back the old mapping."""
+    import re
     try:
-        L = ctypes.CDLL(path or lib_path())
-        L.mm_build_source_hash.restype = ctypes.c_char_p
-        return L.mm_build_source_hash().decode()
-    except (OSError, AttributeError):
+        with open(path or lib_path(), "rb") as f:
+            m = re.search(rb"MMSRCHASH=([0-9a-f]{16})", f.read())
+        return m.group(1).decode() if m else None
+    except OSError:
         return None
 
 

@@ -1818,7 +1818,9 @@ int32_t mm_freq_slab_add_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_t l
     if (hipIpcOpenMemHandle(&theirs, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -MM_E_HIP; }
     void* d = nullptr;
     int r = hipMalloc(&d, bytes) == hipSuccess ? 0 : -MM_E_NOMEM;
-    if (!r && hipMemcpy(d, theirs, bytes, hipMemcpyDeviceToDevice) != hipSuccess) r = -MM_E_HIP;
+    // the copy on the handle's own (non-blocking) stream and waited for: the kernel that adds the slab runs on that stream, and the mapping
+    // is closed -- and the sender told it may free the buffer -- only once the bytes are here (a D2D hipMemcpy on the null stream promises neither)
+    if (!r && (hipMemcpyAsync(d, theirs, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)) r = -MM_E_HIP;
     (void)hipIpcCloseMemHandle(theirs);
     if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
     if (d) (void)hipFree(d);

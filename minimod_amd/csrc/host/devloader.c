@@ -176,6 +176,8 @@ mmh_devloader_t *mmh_devloader_open(const char *bam_path, mm_pool_t *pool, const
         const char *e1 = getenv("MM_INGEST_MAX_BLOCKS"), *e2 = getenv("MM_INGEST_TARGET_BASES");
         if (e1 && atoi(e1) > 0) { io.max_blocks = atoi(e1); if (!io.max_cbytes) io.max_cbytes = (uint64_t)io.max_blocks * 66000 + 65536; }
         if (e2 && atoll(e2) > 0) dl->target_bases = (uint64_t)atoll(e2);
+        const char *e3 = getenv("MM_INGEST_HEAD_ROOM");   /* (a head room shorter than a record: the reader gives up on its first group, the CLI goes on with the host reader) */
+        if (e3 && atoll(e3) > 0) io.head_room = (uint64_t)atoll(e3);
     }
     const double t_create = dl_now();
     dl->ing = mm_ingest_create(&io, err, err_len);

@@ -546,6 +546,29 @@ static void tl_mark(double realtime0, const char *what) {
     if (on) fprintf(stderr, "[timeline] %.3f %s\n", mmh_realtime() - realtime0, what);
 }
 
+/* The device-side reader's batches are not the reference's -K / -B batches, and the reference names a failing read by its index in its
+ * batch (src/mod.c: "read %d"; load_db's limits, src/minimod.c:249): on the error path -- the run is about to exit -- the host reader walks
+ * the file with the run's -K / -B up to the failing read (number `ordinal` of the accepted reads, from 0) and says where it falls. */
+static int32_t batch_index_in_file(const fopt_t *o, const char *bam_file, const wspec_t *ws, uint64_t ordinal, int32_t fallback) {
+    mmh_loader_t *ld = ws->sharded
+        ? mmh_loader_open_share(bam_file, o->threads, o->K, o->B, o->allow_secondary, o->skip_supplementary, ws->voffset, ws->lo_tid, ws->lo_pos, ws->hi_tid, ws->hi_pos, ws->first, ws->last)
+        : mmh_loader_open(bam_file, o->threads, o->K, o->B, o->allow_secondary, o->skip_supplementary);
+    if (!ld) return fallback;
+    uint64_t seen = 0;
+    int more = 1, set = 0;
+    int32_t at = fallback;
+    mm_batch_t b;
+    while (more) {
+        const int32_t n = mmh_loader_next(ld, set, &b, &more);
+        if (n < 0) break;
+        if (ordinal < seen + (uint64_t)n) { at = (int32_t)(ordinal - seen); break; }
+        seen += (uint64_t)n;
+        set = (set + 1) % MMH_POOL_SETS;
+    }
+    mmh_loader_close(ld);
+    return at;
+}
+
 static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
     const fopt_t o = *op;
     const mmh_mods_t mods = *modsp;
@@ -573,6 +596,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     mmh_loader_t *ld = NULL;
     mmh_devloader_t *dl = NULL;   /* --gpu-ingest: the decoded BAM stays on the device (devloader.c) */
     mm_pool_t *pool = NULL;       /* the workers that format the rows (the host loader's, or one of this function's own) */
+    mm_pool_t *own_pool = NULL;   /* ... the latter, to be destroyed here */
+    uint64_t dev_reads_before = 0;   /* device reader: accepted reads of the batches in front of the one at hand (a failing read's place in the file) */
     dl_job_t dlj;
     memset(&dlj, 0, sizeof dlj);
     const mm_bam_hdr_t *hdr = NULL;
@@ -586,11 +611,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     uint64_t hdr_bytes = 0;
     /* the device loader takes the runs whose rows cannot tie (the headline run, -c m[CG]): the tie-order replay and the wildcard
      * code table work from host batches */
-    const int use_dev = o.gpu_ingest && !view && (!replay || dev_replay) && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
+    int use_dev = o.gpu_ingest && !view && (!replay || dev_replay) && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
     if (use_dev) {
         hdr = &hdr0;
         pool = mm_pool_create(o.threads);
         if (!pool) { MMH_ERROR("%s", "Could not start the worker threads"); exit(EXIT_FAILURE); }
+        own_pool = pool;
         mmh_devloader_opts_t *d = &dlj.o;
         d->device = o.device; d->n_targets = hdr0.n_targets; d->allow_secondary = o.allow_secondary; d->skip_supplementary = o.skip_supplementary;
         d->header_bytes = hdr_bytes;
@@ -731,6 +757,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
          * tickets are kept open (their arenas stay theirs until they have been waited for), a third arena is being filled. */
         int32_t tk[2] = {-1, -1}, tv[2] = {-1, -1};   /* (tv: the same batch's ticket of the replay's second handle) */
         int32_t tvn[2] = {0, 0};
+        uint64_t dev_reads_before_of[2] = {0, 0};   /* per open ticket: accepted reads of the device batches in front of it */
         int ar[2] = {-1, -1};
         void *stream = mmh_devloader_stream(dl);
         more = 1;
@@ -740,6 +767,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             int32_t n = mmh_devloader_next(dl, &db, &more);
             if (n < 0) {
                 const mmh_devloader_stats_t *st = mmh_devloader_stats(dl);
+                if (st->err > 1 && tk[0] < 0 && st->processed_reads == 0) {
+                    /* The device reader cannot take this file (a record longer than its head room, a group that does not fit an arena, a
+                     * header it cannot frame ...) and nothing has been counted yet: the host reader reads such a file without trouble, so
+                     * the run goes on with it -- in this process, same handle, same output (the automatic default for big
+                     * files must not turn inputs that used to work into failures). */
+                    MMH_WARNING("The device-side BAM reader gave up: %s; the host threads read the file", mm_ingest_strerror(st->err));
+                    mmh_devloader_close(dl); dl = NULL;
+                    use_dev = 0;
+                    ld = open_loader(&o, bam_file, ws);
+                    more = 1;
+                    break;
+                }
                 if (st->err > 1) MMH_ERROR("The device-side BAM reader gave up: %s (try --no-gpu-ingest)", mm_ingest_strerror(st->err));
                 else MMH_ERROR("%s", "Truncated or corrupt BAM file");
                 exit(EXIT_FAILURE);
@@ -755,11 +794,11 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 if (e) {
                     mm_read_t rec;
                     const int have = bad >= 0 && mm_freq_read_record(h, tk[0], bad, &rec) == 0;
-                    die_read_record(e, bad, have ? &rec : NULL, hdr);   /* (the read's index in the device's batch: -K does not cut those) */
+                    die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[0] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
                 }
                 if (dev_replay) replay_ticket_dev(hv, dtie, tv[0], &tvn[0], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
                 mmh_devloader_release(dl, ar[0]);
-                tk[0] = tk[1]; ar[0] = ar[1]; tv[0] = tv[1]; tvn[0] = tvn[1]; tk[1] = -1; ar[1] = -1; tv[1] = -1;
+                tk[0] = tk[1]; ar[0] = ar[1]; tv[0] = tv[1]; tvn[0] = tvn[1]; dev_reads_before_of[0] = dev_reads_before_of[1]; tk[1] = -1; ar[1] = -1; tv[1] = -1;
                 if (more) break;
             }
             if (n > 0) {
@@ -772,7 +811,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     t2 = mm_freq_submit_device_now(hv, &db.batch, stream, db.bases);
                     if (t2 < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror(t2)); exit(EXIT_FAILURE); }
                 }
-                if (tk[0] < 0) { tk[0] = t; ar[0] = db.arena; tv[0] = t2; tvn[0] = n; } else { tk[1] = t; ar[1] = db.arena; tv[1] = t2; tvn[1] = n; }
+                if (tk[0] < 0) { tk[0] = t; ar[0] = db.arena; tv[0] = t2; tvn[0] = n; dev_reads_before_of[0] = dev_reads_before; }
+                else { tk[1] = t; ar[1] = db.arena; tv[1] = t2; tvn[1] = n; dev_reads_before_of[1] = dev_reads_before; }
+                dev_reads_before += (uint64_t)n;
             }
             if (o.progress_interval <= 0 || mmh_realtime() - prog_t > o.progress_interval) {
                 fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bytes) processed\t%d Entries (%.1fM bytes) skipped\n", __func__,
@@ -796,7 +837,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             if (e) {
                 mm_read_t rec;
                 const int have = bad >= 0 && mm_freq_read_record(h, tk[k], bad, &rec) == 0;
-                die_read_record(e, bad, have ? &rec : NULL, hdr);
+                die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[k] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
             }
             if (dev_replay) replay_ticket_dev(hv, dtie, tv[k], &tvn[k], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
             mmh_devloader_release(dl, ar[k]);
@@ -1035,7 +1076,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             mm_freq_destroy(h);
             if (hv) mm_freq_destroy(hv);
             mmh_tie_destroy(tie); mm_tie_destroy(dtie);
-            close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
+            close_loaders(ld, dl, own_pool); bz_stop(bz);
             mm_bam_hdr_free(&hdr0);
             return 0;
         }
@@ -1096,7 +1137,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (write_all(ws->fd, &tt, sizeof tt)) { MMH_ERROR("%s", "Could not send the totals to the parent process"); exit(EXIT_FAILURE); }
         close(ws->fd);
         mm_freq_destroy(h);
-        close_loaders(ld, dl, use_dev ? pool : NULL); bz_stop(bz);
+        close_loaders(ld, dl, own_pool); bz_stop(bz);
         mm_bam_hdr_free(&hdr0);
         return 0;
     }
@@ -1130,7 +1171,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (hv) mm_freq_destroy(hv);
     tl_mark(realtime0, "handles destroyed");
     mmh_tie_destroy(tie); mm_tie_destroy(dtie);
-    close_loaders(ld, dl, use_dev ? pool : NULL);
+    close_loaders(ld, dl, own_pool);
     tl_mark(realtime0, "loader closed");
     bz_stop(bz);
     mm_bam_hdr_free(&hdr0);

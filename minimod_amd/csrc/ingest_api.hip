@@ -143,7 +143,12 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
         // MM_INGEST_E_ARENA: the caller closes the batch and runs the group again into an empty arena
         const uint64_t D = h->o.arena_bytes;
         a.cap_reads = D / 512 + 4096;
-        a.cap_cigar = D / 4 + (1 << 20); a.cap_seq = D / 2 + (1 << 20); a.cap_mm = std::min<uint64_t>(D / 4 + (1 << 20), 0xFFFFF000ull); a.cap_ml = D / 8 + (1 << 20);
+        // (no pool smaller than what ONE group can decode to, head room included: whatever a group's bytes are made of -- all MM text, all
+        // ML -- it fits an empty arena, so the "run the group again into an empty arena" answer to MM_INGEST_E_ARENA always ends)
+        const uint64_t one = max_ob + h->o.head_room + (1 << 20);
+        a.cap_cigar = std::max<uint64_t>(D / 4 + (1 << 20), one); a.cap_seq = std::max<uint64_t>(D / 2 + (1 << 20), one);
+        a.cap_mm = std::min<uint64_t>(std::max<uint64_t>(D / 4 + (1 << 20), one), 0xFFFFF000ull); a.cap_ml = std::max<uint64_t>(D / 8 + (1 << 20), one);
+        a.cap_reads = std::max<uint64_t>(a.cap_reads, one / 36 + 4096);   // (a record is at least 36 bytes of stream)
         ICHK(hipMalloc((void**)&a.reads, sizeof(mm_read_t) * a.cap_reads));
         ICHK(hipMalloc((void**)&a.cigar, a.cap_cigar)); ICHK(hipMalloc((void**)&a.seq, a.cap_seq));
         ICHK(hipMalloc((void**)&a.mm, a.cap_mm)); ICHK(hipMalloc((void**)&a.ml, a.cap_ml));
@@ -214,8 +219,10 @@ int32_t mm_ingest_flatten(mm_ingest_t* h, int32_t slot, int32_t arena, int32_t n
     if (!sp || arena < 0 || (size_t)arena >= h->arenas.size() || first_skip >= 0xFFFFFFFFull) return -MM_INGEST_E_ARG;
     GSlot& s = *sp;
     if (!s.inflating) return -MM_INGEST_E_ORDER;
-    if (s.seq == h->flat_seq) h->flat_seq++;                              // its first time
-    else if (s.seq + 1 != h->flat_seq) return -MM_INGEST_E_ORDER;         // or again, as long as no later group has been flattened
+    if (s.flattening) return -MM_INGEST_E_ORDER;                          // its chain is queued already: mm_ingest_result first
+    const bool first_time = s.seq == h->flat_seq;                         // (counted once the launches below have been queued)
+    if (!first_time && s.seq + 1 != h->flat_seq) return -MM_INGEST_E_ORDER;   // again is fine as long as no later group has been flattened
+    if (first_skip > s.obytes + (uint64_t)h->H) return -MM_INGEST_E_ARG;  // (k_frame_chain adds it to the head room in 32 bits)
     RCHK(hipSetDevice(h->device));
     const Arena& a = h->arenas[(size_t)arena];
     const size_t nb1 = (size_t)h->o.max_blocks + 1;
@@ -250,6 +257,7 @@ int32_t mm_ingest_flatten(mm_ingest_t* h, int32_t slot, int32_t arena, int32_t n
     if (s.n_blocks) RCHK(hipMemcpyAsync(s.h_status, s.d_status, sizeof(int32_t) * (size_t)s.n_blocks, hipMemcpyDeviceToHost, st));
     RCHK(hipEventRecord(s.ev_done, st));
     s.flattening = true;
+    if (first_time) h->flat_seq++;
     return 0;
 }
 

@@ -273,6 +273,28 @@ def test_cli_tied_runs_replay_on_the_device_and_take_the_device_reader(exp, bam,
         assert r.stdout.decode() == want, (exp, extra, env)
 
 
+def test_cli_goes_on_with_the_host_reader_when_the_device_reader_cannot_take_the_file(tmp_path):
+    """--gpu-ingest switches itself on for big files, so a file the device reader cannot take (here: records that straddle
+    its groups and are longer than its head room, forced through the environment; htslib's own files end their blocks on record boundaries,
+    the synthetic writer does not) must not fail the run -- nothing has been counted when it gives up on its first group, the host reader
+    takes over in the same process: a warning, the same bytes and totals as --no-gpu-ingest, tied runs (device replay) included"""
+    from minimod_amd import synth
+    ref = synth.reference(13, 4 << 20)
+    bs = [synth.batch(ref, i * 350, 350, seed=3, n_reads_total=700) for i in range(2)]
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    for flags in (["-b", "-c", "m[CG]", "-m", "0.8"], ["-c", "m[CG],h[CG]", "-m", "0.8,0.7"]):
+        cmd = [BIN, "freq", "-t", "4"] + flags
+        r = subprocess.run(cmd + ["--gpu-ingest", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MM_INGEST_HEAD_ROOM="256", MM_INGEST_MAX_BLOCKS="8"))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"the host threads read the file" in r.stderr and b"gave up" in r.stderr, r.stderr.decode()[-2000:]
+        r0 = subprocess.run(cmd + ["--no-gpu-ingest", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r0.returncode == 0 and len(r0.stdout) > 10000 and r.stdout == r0.stdout
+        pick = lambda err: [l.split("] ", 1)[1] for l in err.decode().splitlines() if "] total " in l]
+        assert pick(r.stderr) == pick(r0.stderr) and len(pick(r.stderr)) == 7
+
+
 def test_cli_gpu_ingest_on_synthetic_bam(tmp_path):
     """the synthetic ONT-shape file of test_cli_on_synthetic_bam_matches_oracle (filter fodder, records that straddle BGZF blocks and
     groups): the same bytes with the device loader, with small groups forced through the environment, and a hard-clipped read

@@ -200,3 +200,8 @@ def test_cli_names_a_failing_read_of_a_gathered_group(tmp_path):
     r = subprocess.run([BIN, "freq", "-K", "4", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 1
     assert b"Hard clipping found in read 1 of the batch (contig chrT, pos 2)" in r.stderr, r.stderr.decode()[-1500:]
+    # the device-side reader's batches are not -K batches: the message still names the read by its place in the reference's batch
+    # (round 5: the host reader walks the file up to it on the error path), for two batchings, tied runs (device replay) included
+    for extra, want in ((["-K", "4"], b"read 1 of the batch"), (["-K", "7"], b"read 2 of the batch"), (["-K", "4", "-c", "m,h"], b"read 1 of the batch")):
+        r = subprocess.run([BIN, "freq", "--gpu-ingest"] + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and b"Hard clipping found in " + want + b" (contig chrT, pos 2)" in r.stderr, r.stderr.decode()[-1500:]
