@@ -919,6 +919,10 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, wl, host_batches, plan, refs)
         if config_fracs:
             result["config_fracs"] = config_fracs
+            # (the driver's record keeps `roofline` whole and drops keys it does not know: the other workloads' fractions ride there too)
+            result["roofline"]["other_workloads"] = {k: ({"frac": round(v["frac"], 4), "traffic_x": (round(v["traffic"] / (v["achieved"] * 1e9 * v["kernel_ms_per_batch"] * 1e-3 * v["steps"]), 2)
+                                                                                                        if v.get("traffic") and v.get("kernel_ms_per_batch") else None)}
+                                                         if v.get("frac") is not None else {"frac": None}) for k, v in config_fracs.items()}
         if e2e:
             result["end_to_end"] = e2e
             result["cpu_baseline_e2e"] = cpu_e2e
