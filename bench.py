@@ -656,7 +656,7 @@ def main():
                 d = json.loads(r.stdout.decode().strip().splitlines()[-1])
                 rf = d["roofline"]
                 config_fracs[name] = {"frac": rf["frac"], "achieved": rf["achieved"], "traffic": rf.get("traffic"), "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                                      "kernel_ms_per_batch": rf.get("kernel_ms_per_batch"), "steps": st, "workload": d["config"]["workload"], "wall_s": time.time() - t_c}
+                                      "kernel_ms_per_batch": rf.get("kernel_ms_per_batch"), "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "steps": st, "workload": d["config"]["workload"], "wall_s": time.time() - t_c}
             except Exception as e:   # (a leg that fails leaves its reason, never a number)
                 config_fracs[name] = {"frac": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     # ---- the end-to-end leg runs in child processes, before this process has touched the GPU
@@ -920,8 +920,8 @@ def main():
         if config_fracs:
             result["config_fracs"] = config_fracs
             # (the driver's record keeps `roofline` whole and drops keys it does not know: the other workloads' fractions ride there too)
-            result["roofline"]["other_workloads"] = {k: ({"frac": round(v["frac"], 4), "traffic_x": (round(v["traffic"] / (v["achieved"] * 1e9 * v["kernel_ms_per_batch"] * 1e-3 * v["steps"]), 2)
-                                                                                                        if v.get("traffic") and v.get("kernel_ms_per_batch") else None)}
+            result["roofline"]["other_workloads"] = {k: ({"frac": round(v["frac"], 4), "traffic_x": (round(v["traffic"] / v["algorithmic_bytes_per_launch"], 2)
+                                                                                                        if v.get("traffic") and v.get("algorithmic_bytes_per_launch") else None)}
                                                          if v.get("frac") is not None else {"frac": None}) for k, v in config_fracs.items()}
         if e2e:
             result["end_to_end"] = e2e
