@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -12,6 +13,21 @@
 #include "minimod_bgzf.h"
 
 using namespace mmbgzf;
+
+// Workgroups of k_bgzf_inflate a CU is to hold (MM_INFLATE_WGS = 4 .. 7; a workgroup is four wavefronts of 5.6 KB of LDS each): the kernel is
+// bound by how many wavefronts' chains of dependent steps a SIMD interleaves, not by issue slots or memory, so more of
+// them decode more -- up to where nothing else fits beside them: the record framing and k_stream_reads (22.6 KB of LDS, 72 registers) run
+// beside the inflate in a `minimod freq --gpu-ingest`.  The launch asks for dynamic LDS it never touches to hold a CU at that many.
+static int inflate_wgs_per_cu() {
+    static int w = 0;
+    if (!w) { const char* e = std::getenv("MM_INFLATE_WGS"); w = e ? std::atoi(e) : 6; if (w < 1) w = 1; if (w > 7) w = 7; }
+    return w;
+}
+static unsigned inflate_lds_pad() {
+    const int w = inflate_wgs_per_cu();
+    const size_t fixed = sizeof(WaveLds) * kWaves, want = w >= 7 ? fixed : ((size_t)163840 / (size_t)w) / 1024 * 1024;
+    return want > fixed ? (unsigned)(want - fixed) : 0u;
+}
 static_assert(sizeof(mm_bgzf_block_t) == sizeof(Block), "the ABI's block record is the kernels'");
 
 namespace {
@@ -117,8 +133,8 @@ int32_t mm_bgzf_submit(mm_bgzf_t* h, int32_t slot, int32_t n_blocks, size_t cbyt
     SCHK(hipMemcpyAsync(s.d_c, s.h_c, cbytes, hipMemcpyHostToDevice, s.stream));
     SCHK(hipMemcpyAsync(s.d_blocks, s.h_blocks, sizeof(Block) * (size_t)n_blocks, hipMemcpyHostToDevice, s.stream));
     SCHK(hipEventRecord(s.ev[1], s.stream));
-    const int wgs = std::max(1, std::min(h->n_cu * 4, (n_blocks + kWaves - 1) / kWaves));   // (four workgroups of 32 KB of LDS fit a CU)
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(wgs), dim3(64 * kWaves), 0, s.stream, s.d_c, s.d_blocks, n_blocks, s.d_out, s.d_status);
+    const int wgs = std::max(1, std::min(h->n_cu * inflate_wgs_per_cu(), (n_blocks + kWaves - 1) / kWaves));
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(wgs), dim3(64 * kWaves), inflate_lds_pad(), s.stream, s.d_c, s.d_blocks, n_blocks, s.d_out, s.d_status);
     SCHK(hipEventRecord(s.ev[2], s.stream));
     hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(h->n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, s.stream, s.d_out, s.d_blocks, n_blocks, s.d_status);
     SCHK(hipEventRecord(s.ev[3], s.stream));
@@ -171,7 +187,7 @@ int32_t mm_bgzf_inflate_device(int32_t device, void* stream, const uint8_t* d_c,
     }
     const int n_cu = n_cu_of[device];
     hipStream_t st = (hipStream_t)stream;
-    if (n_blocks) hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::max(1, std::min(n_cu * 4, (n_blocks + kWaves - 1) / kWaves))), dim3(64 * kWaves), 0, st, d_c,
+    if (n_blocks) hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::max(1, std::min(n_cu * inflate_wgs_per_cu(), (n_blocks + kWaves - 1) / kWaves))), dim3(64 * kWaves), inflate_lds_pad(), st, d_c,
                                      reinterpret_cast<const Block*>(d_blocks), n_blocks, d_out, d_status);
     if (between_event && hipEventRecord((hipEvent_t)between_event, st) != hipSuccess) return -4;
     if (n_blocks) hipLaunchKernelGGL(k_bgzf_crc, dim3(std::max(1, std::min(n_cu * 8, (n_blocks + 3) / 4))), dim3(256), 0, st, d_out, reinterpret_cast<const Block*>(d_blocks), n_blocks, d_status);

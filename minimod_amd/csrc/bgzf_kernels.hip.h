@@ -41,12 +41,46 @@ enum { S_OK = 0, S_BAD_BLOCK_TYPE = 1, S_BAD_STORED = 2, S_BAD_CODE_LENGTHS = 3,
 // table entry: bits 0-3 code length (0: not a code of this level: the canonical path decides), 4-7 kind, 8-12 extra bits, 16-31 value
 enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_DIST = 4 };
 __host__ __device__ constexpr uint32_t ent(uint32_t len, uint32_t kind, uint32_t extra, uint32_t val) { return len | (kind << 4) | (extra << 8) | (val << 16); }
+// Round 5: the tables in LDS hold COMPACT entries, 16 bits -- code length 0-3, kind 4-5 (0 literal, 1 length, 2 end of block, 3 distance),
+// the literal's byte or the length / distance SYMBOL from bit 6 -- and a symbol's base value and extra-bit count are computed where the
+// entry is read (RFC 1951 3.2.5's tables are arithmetic: length symbol s >= 8 has (s - 4) >> 2 extra bits and base 3 + ((4 + (s & 3)) << extra),
+// distance symbol d >= 4 has (d - 2) >> 1 and 1 + ((2 + (d & 1)) << extra)).  A wavefront's tables are 2.5 KB instead of 5: its LDS 5.6 KB
+// instead of 8.1, and what bounds the kernel is how many wavefronts' chains a SIMD has to interleave (a block lasts ~8 ms whatever shares its
+// SIMD): five or six workgroups a CU instead of four.
 
 __constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
 __constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 __constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#ifdef MM_INFLATE_U32   // (A/B: round 4's 32-bit entries)
+typedef uint32_t tab_t;
+constexpr int kSymShift = 16;
+__host__ __device__ inline uint32_t cent(uint32_t len, uint32_t kind2, uint32_t val) {
+    return kind2 == 0u ? ent(len, K_LIT, 0, val) : (kind2 == 2u ? ent(len, K_EOB, 0, 0) : (kind2 == 1u ? ent(len, K_LEN, c_len_extra[val], c_len_base[val]) : ent(len, K_DIST, c_dist_extra[val], c_dist_base[val])));
+}
+__device__ __forceinline__ uint32_t expand_ll(uint32_t c) { return c; }
+__device__ __forceinline__ uint32_t expand_d(uint32_t c) { return c; }
+#else
+typedef uint16_t tab_t;
+constexpr int kSymShift = 6;
+__host__ __device__ constexpr uint32_t cent(uint32_t len, uint32_t kind2, uint32_t val) { return len | (kind2 << 4) | (val << 6); }
+__device__ __forceinline__ uint32_t expand_ll(uint32_t c) {   // compact literal / length entry -> the 32-bit form the decoder works with
+    const uint32_t len = c & 15u, k = (c >> 4) & 3u, v = c >> 6;
+    const uint32_t xl = v < 8u ? 0u : (v >= 28u ? 0u : (v - 4u) >> 2);
+    const uint32_t base = v < 8u ? 3u + v : (v >= 28u ? 258u : 3u + ((4u + (v & 3u)) << xl));
+    const uint32_t lit = len | ((uint32_t)K_LIT << 4) | (v << 16);
+    const uint32_t mat = len | ((uint32_t)K_LEN << 4) | (xl << 8) | (base << 16);
+    const uint32_t eob = len | ((uint32_t)K_EOB << 4);
+    return k == 0u ? lit : (k == 1u ? mat : eob);
+}
+__device__ __forceinline__ uint32_t expand_d(uint32_t c) {
+    const uint32_t len = c & 15u, v = c >> 6;
+    const uint32_t xd = v < 4u ? 0u : (v - 2u) >> 1;
+    const uint32_t base = v < 4u ? 1u + v : 1u + ((2u + (v & 1u)) << xd);
+    return ((c >> 4) & 3u) == 3u ? (len | ((uint32_t)K_DIST << 4) | (xd << 8) | (base << 16)) : 0u;
+}
+#endif
 
 struct Block {            // one BGZF block of a launch
     uint32_t c_off;       // its deflate payload in the launch's compressed bytes
@@ -65,8 +99,8 @@ struct CodeLdsD {         // the same for the distance code (30 symbols)
     uint16_t sorted[32];
 };
 struct WaveLds {
-    uint32_t ll[1 << kLL];   // (its first 128 words are the code-length code's table while a block's code lengths are read)
-    uint32_t dt[1 << kD];
+    tab_t ll[1 << kLL];   // compact entries (its first 128 are the code-length code's table while a block's code lengths are read)
+    tab_t dt[1 << kD];
     CodeLds cl_ll;
     CodeLdsD cl_d;
     uint8_t lens[320];    // litlen lengths, then distance lengths
@@ -133,7 +167,7 @@ struct Bits {
 // ---- one Huffman code from its lengths lens[0..n) (in LDS): table `tab` of `root` bits, canonical description `cd`.
 // Returns false for a code zlib refuses too (over-subscribed, or incomplete with more than one code).
 template <typename CD>
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_dist, int root, uint32_t* tab, CD& cd) {
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_dist, int root, tab_t* tab, CD& cd) {
     const int l = lane();
     // codes per length, the first code of every length, each symbol's place among the symbols of its length
     uint32_t cnt[16];
@@ -172,7 +206,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_d
         if (l < 16) cd.cnt[l] = (uint16_t)mine;
     }
     const uint32_t root_size = 1u << root;
-    for (uint32_t i = (uint32_t)l; i < root_size; i += 64u) tab[i] = 0u;
+    for (uint32_t i = (uint32_t)l; i < root_size; i += 64u) tab[i] = (tab_t)0;
     lds_sync();
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -185,12 +219,12 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, bool is_d
         cd.sorted[ok + my_rank[r]] = (uint16_t)s;
         if (ln <= (uint32_t)root) {
             uint32_t e;
-            if (is_dist) e = s < 30 ? ent(ln, K_DIST, c_dist_extra[s], c_dist_base[s]) : 0u;
-            else if (s < 256) e = ent(ln, K_LIT, 0, (uint32_t)s);
-            else if (s == 256) e = ent(ln, K_EOB, 0, 0);
-            else e = s <= 285 ? ent(ln, K_LEN, c_len_extra[s - 257], c_len_base[s - 257]) : 0u;
+            if (is_dist) e = s < 30 ? cent(ln, 3u, (uint32_t)s) : 0u;
+            else if (s < 256) e = cent(ln, 0u, (uint32_t)s);
+            else if (s == 256) e = cent(ln, 2u, 0u);
+            else e = s <= 285 ? cent(ln, 1u, (uint32_t)(s - 257)) : 0u;
             const uint32_t c = rev_bits(fk + my_rank[r], (int)ln);
-            for (uint32_t i = c; i < root_size; i += 1u << ln) tab[i] = e;
+            for (uint32_t i = c; i < root_size; i += 1u << ln) tab[i] = (tab_t)e;
         }
     }
     lds_sync();
@@ -264,14 +298,14 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
 #pragma unroll
             for (int k = 1; k < 8; k++) { left = (left << 1) - (int)cnt[k]; code = (code + cnt[k - 1]) << 1; first[k] = code; }
             if (left != 0 && r.st == S_OK) r.st = S_BAD_CODE_LENGTHS;   // the code-length code must be complete
-            S.ll[l] = 0u; S.ll[64 + l] = 0u;
+            S.ll[l] = (tab_t)0; S.ll[64 + l] = (tab_t)0;
             lds_sync();
             if (l < 19 && cl_len) {
                 uint32_t fk = 0;
 #pragma unroll
                 for (int k = 1; k < 8; k++) if (cl_len == (uint32_t)k) fk = first[k];
                 const uint32_t c = rev_bits(fk + rank, (int)cl_len);
-                for (uint32_t i = c; i < 128u; i += 1u << cl_len) S.ll[i] = ent(cl_len, 0, 0, (uint32_t)l);
+                for (uint32_t i = c; i < 128u; i += 1u << cl_len) S.ll[i] = (tab_t)(kSymShift == 16 ? ent(cl_len, 0, 0, (uint32_t)l) : cent(cl_len, 0u, (uint32_t)l));
             }
             lds_sync();
         }
@@ -285,11 +319,11 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
             if (++guard > 400u) { r.st = S_BAD_CODE_LENGTHS; break; }
             if (b.bitpos > 8ull * (uint64_t)b.c_len + 64ull) { r.st = S_OVERRUN_IN; break; }   // (a cut-off stream reads as zeros behind its end: never further than this)
             const uint32_t bits = b.peek32();
-            const uint32_t e = uni(S.ll[bits & 127u]);
+            const uint32_t e = uni((uint32_t)S.ll[bits & 127u]);
             const uint32_t el = e & 15u;
             if (!el) { r.st = S_BAD_CODE_LENGTHS; break; }
             b.bitpos += el;
-            const uint32_t s = e >> 16;
+            const uint32_t s = e >> kSymShift;
             if (s < 16u) { if (l == 0) S.lens[n] = (uint8_t)s; prev = s; n++; continue; }
             uint32_t rep, val = 0;
             if (s == 16u) { if (n == 0) { r.st = S_BAD_CODE_LENGTHS; break; } val = prev; rep = 3u + b.take(2); }
@@ -416,7 +450,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 const uint32_t sb = sh + (uint32_t)l, kq = sb >> 5, rq = sb & 31u;
                 const uint32_t a0 = kq == 0u ? w0 : (kq == 1u ? w1 : w2), a1 = kq == 0u ? w1 : (kq == 1u ? w2 : w3), a2 = kq == 0u ? w2 : (kq == 1u ? w3 : w4);
                 const uint64_t bits64 = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, rq) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, rq) << 32);
-                const uint32_t e1 = S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)];
+                const uint32_t e1 = expand_ll((uint32_t)S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)]);
                 const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
                 uint32_t t_type = 2u, t_bits = 0u, t_val = 0u, t_dist = 0u, t_out = 0u;   // 0 literal (val = byte), 1 match (val = length), 2 the plain path's
                 if (l1 != 0u && k1 == (uint32_t)K_LIT) { t_type = 0u; t_bits = l1; t_val = e1 >> 16; t_out = 1u; }
@@ -425,7 +459,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
                     const uint32_t used = l1 + xl;
                     const uint32_t dbits = (uint32_t)(bits64 >> used);
-                    const uint32_t d = S.dt[dbits & ((1u << kD) - 1u)];
+                    const uint32_t d = expand_d((uint32_t)S.dt[dbits & ((1u << kD) - 1u)]);
                     const uint32_t dl = d & 15u;
                     if (dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST) {
                         const uint32_t xd = (d >> 8) & 31u;
@@ -540,7 +574,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     // one token of the plain path at base + pos: the end of the block, a code longer than the first-level tables
                     b.bitpos = base + (uint64_t)pos;
                     uint32_t bits = b.peek32();
-                    uint32_t e = uni(S.ll[bits & ((1u << kLL) - 1u)]);
+                    uint32_t e = expand_ll(uni((uint32_t)S.ll[bits & ((1u << kLL) - 1u)]));
                     if ((e & 15u) == 0u) { e = decode_long(b, S.cl_ll, false); if ((e & 15u) == 0u) return S_BAD_SYMBOL; }
                     const uint32_t kind = (e >> 4) & 15u;
                     if (kind == K_LIT) {
@@ -556,7 +590,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                         const uint32_t len = (e >> 16) + (bits & ((1u << xl) - 1u));
                         b.bitpos += (e & 15u) + xl;
                         bits = b.peek32();
-                        uint32_t d = uni(S.dt[bits & ((1u << kD) - 1u)]);
+                        uint32_t d = expand_d(uni((uint32_t)S.dt[bits & ((1u << kD) - 1u)]));
                         if ((d & 15u) == 0u) { d = decode_long(b, S.cl_d, true); if ((d & 15u) == 0u) return S_BAD_DISTANCE; }
                         bits >>= d & 15u;
                         const uint32_t xd = (d >> 8) & 31u;
@@ -583,9 +617,11 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
 }
 
 // a wavefront takes every n-th block of the launch
-__global__ __launch_bounds__(64 * kWaves) void k_bgzf_inflate(const uint8_t* __restrict__ cdata, const Block* __restrict__ blocks, int n_blocks,
-                                                              uint8_t* __restrict__ out, int32_t* __restrict__ status) {
+__global__ __launch_bounds__(64 * kWaves, 6) void k_bgzf_inflate(const uint8_t* __restrict__ cdata, const Block* __restrict__ blocks, int n_blocks,
+                                                                 uint8_t* __restrict__ out, int32_t* __restrict__ status) {
     __shared__ WaveLds lds[kWaves];
+    extern __shared__ uint8_t occupancy_pad[];   // (dynamic LDS nobody touches: the launch asks for as much as keeps the workgroups per CU at what the host wants, inflate_wgs_per_cu)
+    (void)occupancy_pad;
     WaveLds& S = lds[threadIdx.x >> 6];
     const int n_waves = (int)gridDim.x * kWaves;
     const int first = (int)uni((uint32_t)((int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6)));   // (uniform to the compiler as well)

@@ -71,9 +71,29 @@ constexpr uint32_t kSegBlocks = MM_STREAM_SEG_BLOCKS;   // directory segment: 32
                          // 10 -- C2 36.6 against 35.1 us per batch, C3 30.5 against 29.2; 256: an ONT read's 1 000 ops are four
                          // dependent trips instead of two, C2 39.3)
 #endif
+#ifndef MM_NO_CK16
+#define MM_CK16 1
+#endif
+#ifdef MM_CK16
+// Round 5: a segment is 1024 ops in the LDS 512 took -- its checkpoints are 16-bit, RELATIVE to the segment's first op.  An ONT read's
+// thousand ops are ONE table: no second pass over the CIGAR when the tokens reach op 512, no round cut in two at that edge (365 vector
+// instructions a read fewer with 1024-op segments of 32-bit checkpoints, which cost the seventh wavefront its LDS: DESIGN section 5).
+// The pass over a segment still holds 512 ops at a time in registers (two halves, one behind the other).  A read with a segment whose
+// ops consume 65 535 positions or more of the read or of the reference (a 64 kb deletion, an intron) is WIDE: its tables are round 3's,
+// 512 ops with 32-bit checkpoints in the same bytes (kWideOps; seg_pass_wide).
+constexpr uint32_t kSegOps = 1024;
+constexpr int kSegVec = 2;                   // 16-byte words per lane of HALF a segment
+constexpr uint32_t kSegCk = kSegOps / 4;
+typedef uint16_t ck_t;
+constexpr uint32_t kCkInf = 0xFFFFu;
+constexpr uint32_t kWideOps = 512, kWideCk = kWideOps / 4;
+#else
 constexpr uint32_t kSegOps = MM_SEG_OPS;    // CIGAR segment: ops
 constexpr int kSegVec = (int)(kSegOps / 256u);   // ... as 16-byte words per lane
 constexpr uint32_t kSegCk = kSegOps / 4;    // ... and its checkpoints, one per four ops
+typedef uint32_t ck_t;
+constexpr uint32_t kCkInf = 0xFFFFFFFFu;
+#endif
 constexpr uint32_t kStreamGroups = 8;       // MM groups per read (more: tile pipeline)
 constexpr uint32_t kStreamMemo = 4;         // group ordinals whose last header is remembered
 constexpr uint32_t kStreamInf = 0xFFFFFFFFu; // the bound behind a table's last entry
@@ -91,8 +111,15 @@ struct StreamLdsT {
     // block's 16 bytes of sequence from memory a second time (the whole read, once more, long after the L2 had let go of it)
     alignas(16) uint32_t dm[kSegBlocks];
     uint32_t cw[kSegBlocks / 4 + 1];
+#ifdef MM_CK16
+    union {
+        struct { uint16_t cq[kSegCk + 2]; uint16_t cr[kSegCk]; };       // query / reference positions consumed in front of every fourth op of the segment, relative to its first op; then the bound
+        struct { uint32_t cq32[kWideCk + 1]; uint32_t cr32[kWideCk]; }; // a WIDE read's: 512 ops, absolute
+    };
+#else
     uint32_t cq[kSegCk + 1];                // query positions consumed in front of every fourth op of the segment (stored order), then 0xFFFFFFFF
     uint32_t cr[kSegCk];                    // ... reference positions
+#endif
     uint32_t gap_p[kDotLds ? 65 : 1];                     // '.' groups: first element (gap bases, then the token) of each token of the batch; [n] = all
     uint32_t gap_r[kDotLds ? 64 : 1];                     //             first rank of the gap in front of each token
     char hdr[16];
@@ -204,6 +231,17 @@ __device__ __forceinline__ uint32_t search_le_padded(const uint32_t* arr, uint32
     return lo;
 }
 
+template <uint32_t N>
+__device__ __forceinline__ uint32_t search_le_padded(const uint16_t* arr, uint32_t key) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t m = N; m > 1u; m -= m >> 1) {
+        const uint32_t at = lo + (m >> 1);
+        lo = (uint32_t)arr[at] <= key ? at : lo;
+    }
+    return lo;
+}
+
 // kDot: '.' groups (implicit calls) are this kernel's too; without it (the leaner instantiation) reads that have one go to the
 // tile pipeline and a flag tells the host to launch the other instantiation from then on (a file's reads carry one flag or the other)
 // kView: `minimod view` -- a call that passes the context test becomes a record (view_append) instead of a counter update
@@ -270,6 +308,12 @@ struct KF {
     // CIGAR segment: stored ops [c_o0, c_o0 + 1024) as c_n checkpoints (0: none); Q_lo / Q_hi (R_lo / R_hi) query (reference)
     // positions consumed in front of its first op / through its last op
     uint32_t c_o0, c_n, Q_lo, Q_hi, R_lo, R_hi;
+#ifdef MM_CK16
+    bool wide;          // the read's CIGAR tables are 512 ops of 32-bit checkpoints (a segment of 1024 ops spans 65 535 positions or more)
+    __device__ __forceinline__ uint32_t seg_ops() const { return wide ? kWideOps : kSegOps; }
+#else
+    __device__ __forceinline__ uint32_t seg_ops() const { return kSegOps; }
+#endif
     uint32_t rank_ok;   // 1 + the largest rank that has been found in the read (0: none yet): what an unrequested group's last rank is checked against
 #ifdef MM_STREAM_TIMING
     unsigned long long ftacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0 = 0;   // 0 record + CIGAR pass, 1 headers, 2 parse, 3 directory,
@@ -283,7 +327,7 @@ struct KF {
     // (the reference indexes ins[] with the BAM position there and everything else with the original one, mod.c:1234, :1314):
     // a reverse read's implicit calls look a second op up, anywhere in the CIGAR.  With the whole CIGAR in the table (up to kSegOps
     // ops) that is one more search; a longer reverse read stays with the tile pipeline, which keeps every op's sums in memory.
-    __device__ __forceinline__ bool dot_ins_far() const { return p.insertions && rev && ncig > kSegOps; }
+    __device__ __forceinline__ bool dot_ins_far() const { return p.insertions && rev && ncig > seg_ops(); }
     __device__ __forceinline__ int gcode_at(int m) const { return (int)(int16_t)(((m < 2 ? gc01 : gc23) >> (16 * (m & 1))) & 0xFFFFu); }
     __device__ __forceinline__ uint32_t cinfo_at(int m) const { return m == 0 ? ci0 : (m == 1 ? ci1 : (m == 2 ? ci2 : ci3)); }
 
@@ -492,6 +536,85 @@ struct KF {
             lenor |= len;
         }
     }
+#ifdef MM_CK16
+    // Segment o0 (1024 ops) of the CIGAR: its first half from the words the lanes hold, its second half loaded here; its totals (tq / tr)
+    // and, with `build`, its checkpoint table -- 16-bit entries relative to the segment's first op, whichever end (qa, ra) counts from
+    // (from_end: through the segment's last op -- a reverse read's tokens walk the CIGAR from its end): Q_lo / R_lo carry the rest.
+    __device__ __forceinline__ void seg_pass(uint4 (&cv)[kSegVec], uint32_t o0, uint32_t qa, uint32_t ra, bool from_end, bool build,
+                                             uint32_t& okops, uint32_t& lenor, uint32_t& tq_out, uint32_t& tr_out) {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t tq = 0, tr = 0;
+        if (build) wave_sync();
+        for (uint32_t hf = 0; hf < 2u; hf++) {
+            const uint32_t oh = o0 + 512u * hf;
+            if (oh >= ncig) break;
+            if (hf) load_seg(cv, oh);
+            if (!build) {
+                uint32_t a = 0, b = 0;
+#pragma unroll
+                for (int u = 0; u < kSegVec; u++) {
+                    uint32_t au, bu;
+                    word_sums(cv[u], oh + 256u * (uint32_t)u + 4u * lane, au, bu, okops, lenor);
+                    a += au; b += bu;
+                }
+                tq = uniu(tq + lane_valu(wave_incl_scan(a), 63)); tr = uniu(tr + lane_valu(wave_incl_scan(b), 63));
+            } else {
+#pragma unroll
+                for (int u = 0; u < kSegVec; u++) {
+                    if (oh + 256u * (uint32_t)u < ncig) {
+                        const uint32_t i = oh + 256u * (uint32_t)u + 4u * lane;
+                        uint32_t a, b;
+                        word_sums(cv[u], i, a, b, okops, lenor);
+                        const uint32_t iq = wave_incl_scan(a), ir = wave_incl_scan(b);
+                        // (a span of 65 535 or more wraps here: such a read never gets as far as a round, run() hands it on)
+                        if (i < ncig) { S.cq[128u * hf + 64u * (uint32_t)u + lane] = (ck_t)(tq + iq - a); S.cr[128u * hf + 64u * (uint32_t)u + lane] = (ck_t)(tr + ir - b); }
+                        tq = uniu(tq + lane_valu(iq, 63)); tr = uniu(tr + lane_valu(ir, 63));
+                    }
+                }
+            }
+        }
+        if (build) {
+            const uint32_t nck = (min(kSegOps, ncig - o0) + 3u) >> 2;
+            for (uint32_t c = nck + lane; c < kSegCk + 2u; c += 64u) S.cq[c] = (ck_t)kCkInf;   // (the bound, up to the table's end: search_le_padded)
+            const uint32_t qb = from_end ? qa - tq : qa, rb = from_end ? ra - tr : ra;
+            c_o0 = o0; c_n = nck; Q_lo = qb; Q_hi = qb + tq; R_lo = rb; R_hi = rb + tr;
+            wave_sync();
+        }
+        tq_out = tq; tr_out = tr;
+    }
+    // a WIDE read's segment: 512 ops from the words the lanes hold, 32-bit checkpoints, absolute (round 3's table)
+    __device__ __forceinline__ void seg_pass_wide(const uint4 (&cv)[kSegVec], uint32_t o0, uint32_t qa, uint32_t ra, bool from_end) {
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t tq = 0, tr = 0, okops = 0xFFFFFFFFu, lenor = 0;
+        const uint32_t q0 = from_end ? 0u : qa, r0 = from_end ? 0u : ra;
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < kSegVec; u++) {
+            if (o0 + 256u * (uint32_t)u < ncig) {
+                const uint32_t i = o0 + 256u * (uint32_t)u + 4u * lane;
+                uint32_t a, b;
+                word_sums(cv[u], i, a, b, okops, lenor);
+                const uint32_t iq = wave_incl_scan(a), ir = wave_incl_scan(b);
+                if (i < ncig) { S.cq32[64u * (uint32_t)u + lane] = q0 + tq + iq - a; S.cr32[64u * (uint32_t)u + lane] = r0 + tr + ir - b; }
+                tq = uniu(tq + lane_valu(iq, 63)); tr = uniu(tr + lane_valu(ir, 63));
+            }
+        }
+        const uint32_t nck = (min(kWideOps, ncig - o0) + 3u) >> 2;
+        uint32_t qb = q0, rb = r0;
+        if (from_end) {
+            qb = qa - tq; rb = ra - tr;
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < kSegVec; u++) {
+                const uint32_t c = 64u * (uint32_t)u + lane;
+                if (c < nck) { S.cq32[c] += qb; S.cr32[c] += rb; }
+            }
+        }
+        for (uint32_t c = nck + lane; c <= kWideCk; c += 64u) S.cq32[c] = kStreamInf;
+        c_o0 = o0; c_n = nck; Q_lo = qb; Q_hi = qb + tq; R_lo = rb; R_hi = rb + tr;
+        wave_sync();
+    }
+#else
     // Segment o0 of the CIGAR from the words the lanes hold: its totals (tq / tr) and, with `build`, its checkpoint table.
     // from_end = false: (qa, ra) are the positions consumed in front of op o0; true: through the segment's last op (a reverse
     // read's tokens walk the CIGAR from its end): the table is then written relative to the segment's start and moved.
@@ -540,6 +663,7 @@ struct KF {
         }
         tq_out = tq; tr_out = tr;
     }
+#endif
     // the segment that holds query position qf (< q_total): the neighbour in the direction the tokens walk, segment by segment;
     // with no table yet, from the end of the CIGAR the walk starts at
     __device__ __forceinline__ void ensure_cig(uint32_t qf) {
@@ -548,17 +672,20 @@ struct KF {
             bool from_end;
             if (c_n == 0u) {
                 from_end = rev != 0;
-                o0 = rev ? ((ncig - 1u) / kSegOps) * kSegOps : 0u;
+                o0 = rev ? ((ncig - 1u) / seg_ops()) * seg_ops() : 0u;
                 qa = rev ? q_total : 0u; ra = rev ? r_total : 0u;
             } else if (qf >= Q_hi) {
-                o0 = c_o0 + kSegOps; from_end = false; qa = Q_hi; ra = R_hi;
+                o0 = c_o0 + seg_ops(); from_end = false; qa = Q_hi; ra = R_hi;
             } else {
-                o0 = c_o0 - kSegOps; from_end = true; qa = Q_lo; ra = R_lo;
+                o0 = c_o0 - seg_ops(); from_end = true; qa = Q_lo; ra = R_lo;
             }
             if (o0 >= ncig) { err = MM_E_QOVER; break; }   // (cannot happen: the totals are this table's own sums)
             uint4 cv[kSegVec];
             uint32_t okops = 0xFFFFFFFFu, lenor = 0, tq, tr;
             load_seg(cv, o0);
+#ifdef MM_CK16
+            if (wide) { seg_pass_wide(cv, o0, qa, ra, from_end); continue; }
+#endif
             seg_pass(cv, o0, qa, ra, from_end, true, okops, lenor, tq, tr);
         }
     }
@@ -706,19 +833,33 @@ struct KF {
             if (__ballot(fin)) {
 #endif
                 // query position -> checkpoint (largest c with cq[c] <= qi) -> op: the checkpoint's four ops are walked
+#ifdef MM_CK16
+                uint32_t qk, ck, a0, b0;
+                if (!wide) {
+                    qk = qi - Q_lo;   // (the table's positions count from the segment's first op)
+                    ck = fin ? search_le_padded<kSegCk>(S.cq, qk) : 0u;
+                    a0 = S.cq[ck]; b0 = R_lo + S.cr[ck];
+                } else {
+                    qk = qi;
+                    ck = fin ? search_le_padded<kWideCk>(S.cq32, qi) : 0u;
+                    a0 = S.cq32[ck]; b0 = S.cr32[ck];
+                }
+#else
+                const uint32_t qk = qi;
                 const uint32_t ck = fin ? search_le_padded<kSegCk>(S.cq, qi) : 0u;
                 const uint32_t a0 = S.cq[ck], b0 = S.cr[ck];
+#endif
                 const uint4 ov = fin ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck) : make_uint4(0, 0, 0, 0);
                 const uint32_t o0 = ov.x & 15u, o1 = ov.y & 15u, o2 = ov.z & 15u, o3 = ov.w & 15u;
                 const uint32_t l0 = ov.x >> 4, l1 = ov.y >> 4, l2 = ov.z >> 4;
                 const uint32_t a1 = a0 + (l0 & op_mask(0x193u, o0)), a2 = a1 + (l1 & op_mask(0x193u, o1)), a3 = a2 + (l2 & op_mask(0x193u, o2));
                 const uint32_t b1 = b0 + (l0 & op_mask(0x18Du, o0)), b2 = b1 + (l1 & op_mask(0x18Du, o1)), b3 = b2 + (l2 & op_mask(0x18Du, o2));
                 // the op that holds qi: the first whose end lies behind it (ops that consume no query position are passed over)
-                const uint32_t kq = (qi >= a1 ? 1u : 0u) + (qi >= a2 ? 1u : 0u) + (qi >= a3 ? 1u : 0u);
+                const uint32_t kq = (qk >= a1 ? 1u : 0u) + (qk >= a2 ? 1u : 0u) + (qk >= a3 ? 1u : 0u);
                 const uint32_t op = kq == 0u ? o0 : (kq == 1u ? o1 : (kq == 2u ? o2 : o3));
                 const uint32_t a_s = kq == 0u ? a0 : (kq == 1u ? a1 : (kq == 2u ? a2 : a3));
                 const uint32_t b_s = kq == 0u ? b0 : (kq == 1u ? b1 : (kq == 2u ? b2 : b3));
-                const uint32_t e = qi - a_s;
+                const uint32_t e = qk - a_s;
                 bool call = fin && ((0x181u >> op) & 1u);
                 int32_t ref_pos = pos + (int32_t)(b_s + e);
                 uint32_t ins_off = 0;
@@ -737,14 +878,28 @@ struct KF {
                     if (__ballot(odd)) {
                         const uint32_t q2 = L - 1u - q, qi2 = q2 - q_shift;
                         const bool in2 = odd && qi2 < q_total;
+#ifdef MM_CK16
+                        uint32_t qk2, ck2, a20, b20;
+                        if (!wide) {
+                            qk2 = qi2 - Q_lo;
+                            ck2 = in2 ? search_le_padded<kSegCk>(S.cq, qk2) : 0u;
+                            a20 = S.cq[ck2]; b20 = R_lo + S.cr[ck2];
+                        } else {
+                            qk2 = qi2;
+                            ck2 = in2 ? search_le_padded<kWideCk>(S.cq32, qi2) : 0u;
+                            a20 = S.cq32[ck2]; b20 = S.cr32[ck2];
+                        }
+#else
+                        const uint32_t qk2 = qi2;
                         const uint32_t ck2 = in2 ? search_le_padded<kSegCk>(S.cq, qi2) : 0u;
                         const uint32_t a20 = S.cq[ck2], b20 = S.cr[ck2];
+#endif
                         const uint4 ov2 = in2 ? *reinterpret_cast<const uint4*>(cg + c_o0 + 4u * ck2) : make_uint4(0, 0, 0, 0);
                         const uint32_t p0 = ov2.x & 15u, p1 = ov2.y & 15u, p2 = ov2.z & 15u, p3 = ov2.w & 15u;
                         const uint32_t m0 = ov2.x >> 4, m1 = ov2.y >> 4, m2 = ov2.z >> 4;
                         const uint32_t a21 = a20 + (m0 & op_mask(0x193u, p0)), a22 = a21 + (m1 & op_mask(0x193u, p1)), a23 = a22 + (m2 & op_mask(0x193u, p2));
                         const uint32_t b21 = b20 + (m0 & op_mask(0x18Du, p0)), b22 = b21 + (m1 & op_mask(0x18Du, p1)), b23 = b22 + (m2 & op_mask(0x18Du, p2));
-                        const uint32_t k2 = (qi2 >= a21 ? 1u : 0u) + (qi2 >= a22 ? 1u : 0u) + (qi2 >= a23 ? 1u : 0u);
+                        const uint32_t k2 = (qk2 >= a21 ? 1u : 0u) + (qk2 >= a22 ? 1u : 0u) + (qk2 >= a23 ? 1u : 0u);
                         const uint32_t op2 = k2 == 0u ? p0 : (k2 == 1u ? p1 : (k2 == 2u ? p2 : p3));
                         const uint32_t bs2 = k2 == 0u ? b20 : (k2 == 1u ? b21 : (k2 == 2u ? b22 : b23));
                         if (odd) {
@@ -855,7 +1010,7 @@ struct KF {
         qhead = 0; qn = 0; kdone = 0; Rcarry = 0; ntok_parsed = 0;
         // a read of several segments starts the group at the table's first segment again (a short read's tables hold all of it)
         if (nblk > kSegBlocks) d_n = 0;
-        if (ncig > kSegOps && wanted) c_n = 0;
+        if (ncig > seg_ops() && wanted) c_n = 0;
         if (staged_at != cpos) fetch_chunk(cpos);
         int st = 0;
         // One loop, one call of round_core: the ranks of a round come from the ring (a batch of up to 64 tokens), or -- in a
@@ -954,6 +1109,7 @@ struct KF {
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                if (off0 + 256u * (uint32_t)u >= len) continue;   // (wave-uniform: a 350-character list is two of the trip's four quarters, not four)
                 const uint32_t o = off0 + 256u * (uint32_t)u + 4u * lane;
                 const uint32_t wa = va[u], wb = vb[u], wp = vp[u];
                 const uint32_t vm = o >= len ? 0u : (len - o >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * (len - o))) - 1u)));   // bytes inside the list
@@ -1013,6 +1169,9 @@ struct KF {
             uint32_t run_q = 0, run_r = 0;
             bool over = false;
             const uint32_t want_o0 = rev ? ((ncig - 1u) / kSegOps) * kSegOps : 0u;
+#ifdef MM_CK16
+            wide = false;
+#endif
 #ifdef MM_ABL_NOVALIDATE
             for (uint32_t i0 = 0; i0 < 0u; i0 += kSegOps) {
 #else
@@ -1025,11 +1184,17 @@ struct KF {
                 // looked at after every segment)
                 run_q += tq; run_r += tr;
                 over = over || run_q >= (1u << 28) || run_r >= (1u << 28);
+#ifdef MM_CK16
+                wide = wide || tq >= kCkInf || tr >= kCkInf;   // a segment's checkpoints do not fit 16 bits: the read's tables are the wide ones
+#endif
             }
             const bool badop = __ballot(okops == 0u || lenor >= kStreamMaxLen) != 0ull;
             if (badop || over || run_q > L || pos < 0 || (int64_t)pos + (int64_t)run_r > ctg_len) { st = 1; c_n = 0; }
             q_total = run_q; r_total = run_r;
             q_shift = (rev && run_q < L) ? L - run_q : 0u;
+#ifdef MM_CK16
+            if (wide) c_n = 0;   // (the table the pass has just made wrapped: ensure_cig makes the wide one when the first call asks)
+#endif
         }
         KFT_LAP(0);
         uint32_t ngrp = 0;
