@@ -745,6 +745,9 @@ def main():
         raise SystemExit("--config %s: %d side-list records per pass over the batches: too many steps for a list of %d"
                          % (args.config, side_per_pass, side_cap))
 
+    from minimod_amd import engine as _E
+    dev_structs = [_E.batch_struct(db, device=True) for db in dev_batches]   # (the C structs of the resident windows, made once: a C caller has them anyway)
+
     def run_steps(n, first_step=0, use_stream=stream):
         """n steps = n -K windows submitted in order; returns bases, device time per LAUNCH (a launch carries one window, or
         up to --coalesce consecutive ones: submits of one group return the same ticket), algorithmic bytes."""
@@ -755,7 +758,7 @@ def main():
             kms.append(eng.kernel_ms(g[0]))
         for s in range(n):
             bi = (first_step + s) % n_batches
-            t = eng.submit_device(dev_batches[bi], use_stream)
+            t = eng.submit_device(dev_structs[bi], use_stream)
             if groups and groups[-1][0] == t:
                 groups[-1][1] += 1
             else:
@@ -1057,11 +1060,14 @@ def bench_view(args, eng, host_batches, dev_batches, batch_bases, stream, rank, 
         alg_bytes.append(algorithmic_bytes(hb["reads"], st["lookups"], 0) + 16 * n)
     eng.stats_enable(False)
 
+    from minimod_amd import engine as _E
+    dev_structs = [_E.batch_struct(db, device=True) for db in dev_batches]
+
     def run_steps(n, first_step=0):
         tickets, bases, kms, abytes, rows = [], 0, [], 0, 0
         for s in range(n):
             bi = (first_step + s) % n_batches
-            tk = eng.submit_device(dev_batches[bi], stream)
+            tk = eng.submit_device(dev_structs[bi], stream)
             if not tickets or tickets[-1] != tk:   # (consecutive windows may share a launch and its ticket: --coalesce)
                 tickets.append(tk)
             bases += batch_bases[bi]

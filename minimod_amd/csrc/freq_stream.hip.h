@@ -1031,6 +1031,9 @@ struct KF {
                     qhead = uniu((qhead + n) & (kStreamRing - 1u)); qn = uniu(qn - n); kdone = uniu(kdone + n);
                     n = 0;
                 }
+#ifdef MM_ABL_NOPARSE   // (diagnostic: no list is ever parsed -- and so no round made; what is left is the record, the CIGAR pass, the headers, the twin comparison)
+                closed = true;
+#endif
                 while (qn < 64u && !closed && !bad_text) parse_chunk(wanted);
                 if (bad_text) { st = 2; break; }
                 e_done = 0; E = 0;
@@ -1091,6 +1094,9 @@ struct KF {
     // Are the skip lists [a, a + len) and [b, b + len) of the MM string the same text, and is that text nothing but
     // ",digits,digits,...,digits"?  Then its tokens are its commas (returned; 0: not the same, or not that plain).
     __device__ __forceinline__ uint32_t twin_lists(uint32_t a, uint32_t b, uint32_t len) const {
+#ifdef MM_ABL_NOTWIN   // (diagnostic: the lists are "the same" unseen)
+        return len / 3u + 1u;
+#endif
         const uint32_t lane = (uint32_t)lane_id();
         uint32_t bad = 0, commas = 0;
         // 1024 characters a trip: the twelve loads of a trip are requested together (a list of a 15 kb read is one trip)
