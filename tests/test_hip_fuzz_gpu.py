@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CAMPAIGNS = ["fuzz_mixed", "fuzz_options", "fuzz_long", "fuzz_contigs", "fuzz_shards", "fuzz_errors"]
+CAMPAIGNS = ["fuzz_mixed", "fuzz_options", "fuzz_long", "fuzz_contigs", "fuzz_shards", "fuzz_errors", "fuzz_tie"]   # (fuzz_tie, round 5: the device-side
+# replay of the reference's row order against the host's serial restatement, the same calls to both)
 FIRST = int(os.environ.get("MM_FUZZ_FIRST", "31000"))
 COUNT = int(os.environ.get("MM_FUZZ_SEEDS", "50"))
 
@@ -21,7 +22,7 @@ def campaigns():
     # (the error campaign gets four times the seeds: a corrupted record of the kind that shows a deviation -- a reverse read whose
     # leading clip overshoots the sequence -- comes once in sixty batches; it is the quickest of the six)
     procs = {c: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", c + ".py"), str(FIRST if c != "fuzz_errors" else 400),
-                                  str(COUNT if c != "fuzz_errors" else 4 * COUNT)], stdout=subprocess.PIPE,
+                                  str(COUNT if c not in ("fuzz_errors", "fuzz_tie") else (4 * COUNT if c == "fuzz_errors" else max(4, COUNT // 4)))], stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, cwd=ROOT) for c in CAMPAIGNS}
     out = {}
     for c, p in procs.items():
