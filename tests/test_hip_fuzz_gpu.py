@@ -43,7 +43,8 @@ def test_random_campaign_agrees_with_the_oracle(name, campaigns):
     last = txt.strip().splitlines()[-1]
     m = re.search(r"seeds (\d+)\.\.(\d+) done in \d+ s, (\d+) problems", last)
     assert m, txt[-3000:]
-    assert int(m.group(2)) - int(m.group(1)) + 1 == (COUNT if name != "fuzz_errors" else 4 * COUNT) and int(m.group(3)) == 0, txt[-3000:]
+    want = 4 * COUNT if name == "fuzz_errors" else (max(4, COUNT // 4) if name == "fuzz_tie" else COUNT)
+    assert int(m.group(2)) - int(m.group(1)) + 1 == want and int(m.group(3)) == 0, txt[-3000:]
     if name == "fuzz_errors":   # the malformed-input deviations DESIGN.md section 7 used to list are closed
         k = re.search(r"(\d+) known deviations", last)
         assert k and int(k.group(1)) == 0, last

@@ -106,4 +106,4 @@ if __name__ == "__main__":
         elif out != "same":
             bad += 1
             print("seed", seed, c, "ins", ins, "hap", hap, "batches", nb, "rows", nrows, out, flush=True)
-    print("seeds %d..%d done in %.0f s: %d problems, %d runs where both replays gave up" % (first, first + count - 1, time.time() - t0, bad, gave))
+    print("seeds %d..%d done in %.0f s, %d problems (%d runs where both replays gave up)" % (first, first + count - 1, time.time() - t0, bad, gave))
