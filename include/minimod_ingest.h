@@ -41,7 +41,7 @@ typedef struct mm_ingest_opts {
     int32_t group_slots;          /* 0 = 4 */
     int32_t max_blocks;           /* BGZF blocks per group; 0 = 2048 */
     int32_t arenas;               /* 0 = 3 */
-    int32_t rsvd;
+    int32_t names;                /* not 0: the read names are kept too (mm_ingest_arena_names; view prints them, src/mod.c:560-626) */
     uint64_t max_cbytes;          /* staging bytes per group; 0 = 48 MiB */
     uint64_t arena_bytes;         /* decoded bytes a batch may be made of (sizes the pools); 0 = 1 GiB */
     uint64_t head_room;           /* longest record tail that can be carried; 0 = 32 MiB */
@@ -69,9 +69,10 @@ typedef struct mm_ingest_result {
     uint64_t batch_reads, batch_bases;
     uint64_t cigar_bytes, seq_bytes, mm_bytes, ml_bytes;
     uint32_t max_n_cigar, max_l_qseq;
+    uint64_t qname_bytes;         /* opts.names: bytes of the batch's names, NULs included */
 } mm_ingest_result_t;
 
-enum { MM_INGEST_OK = 0, MM_INGEST_E_RECORD = 1, MM_INGEST_E_ARENA = 2, MM_INGEST_E_TAIL = 3, MM_INGEST_E_RECORDS = 4, MM_INGEST_E_HEADER = 5,
+enum { MM_INGEST_OK = 0, MM_INGEST_E_RECORD = 1, MM_INGEST_E_ARENA = 2, MM_INGEST_E_TAIL = 3, MM_INGEST_E_RECORDS = 4, MM_INGEST_E_HEADER = 5, MM_INGEST_E_CODES = 6,
        MM_INGEST_E_ARG = 16, MM_INGEST_E_HIP = 17, MM_INGEST_E_ORDER = 18 };
 
 mm_ingest_t *mm_ingest_create(const mm_ingest_opts_t *opts, char *err, size_t err_len);
@@ -98,6 +99,15 @@ int32_t mm_ingest_group_info(mm_ingest_t *h, int32_t slot, uint32_t *dst, uint32
 int32_t mm_ingest_patch_block(mm_ingest_t *h, int32_t slot, int32_t block, const uint8_t *decoded, size_t n);
 /* the arena's batch as it stands after the group `res` describes: device pointers, for mm_freq_submit_device(.., mm_ingest_stream(h)) */
 int32_t mm_ingest_arena_batch(mm_ingest_t *h, int32_t arena, const mm_ingest_result_t *res, mm_batch_t *out);
+/* opts.names: the batch's read names in DEVICE memory -- read i's name (NUL-terminated, bam1_t's qname) at names + name_off[i]; the
+ * batch's names take result.qname_bytes bytes.  (What print_view_output's first column is printed from, src/mod.c:560-626.) */
+int32_t mm_ingest_arena_names(mm_ingest_t *h, int32_t arena, const uint8_t **names_dev, const uint64_t **name_off_dev);
+/* A wildcard run (-c '*') counts whatever code a read's MM tag names (src/mod.c's req_all): the codes of a batch in DEVICE memory, in
+ * the order a walk over its reads and their MM text meets them first -- a group of digits is one code (a ChEBI number), a group of letters one
+ * code per letter: the string from that letter on, which is what the reference looks up (mod.c:1146-1160).  Writes up to max_codes
+ * strings of MM_CODE_LEN bytes (NUL-padded) and returns how many; -MM_INGEST_E_CODES when a code is longer than 8 characters or the
+ * batch holds more than 1024 different ones (the caller then reads the MM text itself).  Runs on the chain stream and waits for it. */
+int32_t mm_ingest_batch_codes(mm_ingest_t *h, const mm_batch_t *batch_dev, char *codes, int32_t max_codes);
 /* n bytes of device memory to the host, behind everything queued on the chain stream so far (tests; callers that want a batch's
  * read records on the host) */
 int32_t mm_ingest_copy_to_host(mm_ingest_t *h, void *dst_host, const void *src_dev, size_t n);

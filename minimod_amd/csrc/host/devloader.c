@@ -171,7 +171,7 @@ mmh_devloader_t *mmh_devloader_open(const char *bam_path, mm_pool_t *pool, const
     memset(&io, 0, sizeof io);
     io.device = o->device; io.n_targets = o->n_targets; io.allow_secondary = o->allow_secondary; io.skip_supplementary = o->skip_supplementary;
     io.ranged = o->ranged; io.first = o->first; io.last = o->last; io.lo_tid = o->lo_tid; io.hi_tid = o->hi_tid; io.lo_pos = o->lo_pos; io.hi_pos = o->hi_pos;
-    io.group_slots = o->group_slots; io.max_blocks = o->max_blocks; io.arenas = o->arenas; io.max_cbytes = o->max_cbytes; io.arena_bytes = o->arena_bytes; io.head_room = o->head_room;
+    io.group_slots = o->group_slots; io.max_blocks = o->max_blocks; io.arenas = o->arenas; io.max_cbytes = o->max_cbytes; io.arena_bytes = o->arena_bytes; io.head_room = o->head_room; io.names = o->names;
     {   /* tests: small groups and batches through the environment */
         const char *e1 = getenv("MM_INGEST_MAX_BLOCKS"), *e2 = getenv("MM_INGEST_TARGET_BASES");
         if (e1 && atoi(e1) > 0) { io.max_blocks = atoi(e1); if (!io.max_cbytes) io.max_cbytes = (uint64_t)io.max_blocks * 66000 + 65536; }
@@ -302,6 +302,7 @@ int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more) 
         if (n > 0) {
             if (mm_ingest_arena_batch(dl->ing, dl->cur_arena, &dl->cur, &out->batch) != 0) { dl->failed = 1; return -1; }
             out->arena = dl->cur_arena; out->bases = dl->cur.batch_bases;
+            if (mm_ingest_arena_names(dl->ing, dl->cur_arena, &out->names, &out->name_off) == 0) out->names_bytes = dl->cur.qname_bytes;
             dl->arena_busy[dl->cur_arena] = 1;
             dl->st.processed_bases += dl->cur.batch_bases;
         }
@@ -315,6 +316,7 @@ int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more) 
 
 void mmh_devloader_release(mmh_devloader_t *dl, int arena) { if (dl && arena >= 0 && arena < DL_MAX_ARENAS) dl->arena_busy[arena] = 0; }
 int mmh_devloader_fetch(mmh_devloader_t *dl, void *dst_host, const void *src_dev, size_t n) { return dl ? mm_ingest_copy_to_host(dl->ing, dst_host, src_dev, n) : -1; }
+int mmh_devloader_codes(mmh_devloader_t *dl, const mm_batch_t *batch, char *codes, int max_codes) { return dl ? mm_ingest_batch_codes(dl->ing, batch, codes, max_codes) : -1; }
 void *mmh_devloader_stream(mmh_devloader_t *dl) { return dl ? mm_ingest_stream(dl->ing) : NULL; }
 const mmh_devloader_stats_t *mmh_devloader_stats(mmh_devloader_t *dl) {
     dl->st.groups = dl->groups; dl->st.slow_blocks = dl->slow_blocks; dl->st.patched_blocks = dl->patched_blocks;

@@ -71,6 +71,8 @@ static struct option view_long_options[] = {
     {"gpu-inflate", no_argument, 0, 0},
     {"no-gpu-inflate", no_argument, 0, 0},
     {"gather", required_argument, 0, 0},
+    {"gpu-ingest", no_argument, 0, 0},
+    {"no-gpu-ingest", no_argument, 0, 0},
     {0, 0, 0, 0}};
 
 typedef struct {
@@ -138,10 +140,10 @@ static void print_help(FILE *fp, const fopt_t *o) {
             o->gpu_inflate < 0 ? "for a BAM file of 4 GiB or more per GPU" : (o->gpu_inflate ? "yes" : "no"));
     if (!o->view) fprintf(fp, "   --host-replay              replay minimod's row order (rows that tie on contig and start) with the host's serial restatement of its\n"
                               "                              hash table and sort instead of the device's parallel one (the checker; reads with the host threads) [%s]\n", o->host_replay ? "yes" : "no");
-    if (!o->view) fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
-                              "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
-                              "                              --host-replay, -c '*', --debug-break and pipes read with the host threads) [%s]\n",
-                      o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
+    fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
+                "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
+                "                              --host-replay or --debug-break, and pipes, read with the host threads) [%s]\n",
+            o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
     if (!o->view) fprintf(fp, "   --region STR               only the rows of chr:from-to (1-based, inclusive; chr alone: the whole contig): the reads that can reach it are\n"
                               "                              found through reads.bam.bai and counted, rows outside are dropped [%s]\n", o->region ? o->region : "whole file");
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
@@ -329,7 +331,8 @@ static int read_all(int fd, void *buf, size_t n) {
  * read names of every batch that went into it, one behind the other (a row names its read by its index in the launch) */
 typedef struct { mm_read_t *reads; size_t n, cap; char *names; size_t names_len, names_cap; uint64_t *name_off; size_t off_cap;
                  uint8_t *mm; size_t mm_len, mm_cap; } journal_t;   /* (mm: the replay's journal keeps the MM text instead of the names) */
-typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; journal_t j; } group_t;
+typedef struct { int32_t ticket, n; int32_t n_reads[MMH_MAX_GATHER]; journal_t j;
+                 int64_t dev_before; /* >= 0: a batch of the device-side reader -- accepted reads of the file in front of it */ } group_t;
 static void journal_reset(journal_t *j) { j->n = 0; j->names_len = 0; j->mm_len = 0; }
 static void journal_free(journal_t *j) { free(j->reads); free(j->names); free(j->name_off); free(j->mm); memset(j, 0, sizeof *j); }
 /* the replay's journal: read records with their MM text (tieorder.c looks at a read's group headers), offsets moved behind the text so far */
@@ -387,6 +390,39 @@ static int journal_add(journal_t *j, const mm_batch_t *b, const mmh_loader_t *ld
     return 0;
 }
 
+/* the same for a batch of the device-side reader: its read records and names come over from GPU memory (the names were kept for this:
+ * mmh_devloader_opts_t.names) */
+static int journal_from_device(journal_t *j, mmh_devloader_t *dl, const mmh_devbatch_t *db) {
+    const size_t n = (size_t)db->batch.n_reads;
+    journal_reset(j);
+    if (n > j->cap) {
+        size_t nc = j->cap ? j->cap : 8192;
+        while (nc < n) nc *= 2;
+        mm_read_t *r = (mm_read_t *)realloc(j->reads, nc * sizeof(mm_read_t));
+        uint64_t *o = (uint64_t *)realloc(j->name_off, nc * sizeof(uint64_t));
+        if (r) j->reads = r;
+        if (o) j->name_off = o;
+        if (!r || !o) return -1;
+        j->cap = nc;
+    }
+    if (db->names_bytes > j->names_cap) {
+        size_t nc = j->names_cap ? j->names_cap : ((size_t)1 << 20);
+        while (nc < db->names_bytes) nc *= 2;
+        char *g = (char *)realloc(j->names, nc);
+        if (!g) return -1;
+        j->names = g; j->names_cap = nc;
+    }
+    if (!db->names || !db->name_off) return -1;
+    if (mmh_devloader_fetch(dl, j->reads, db->batch.reads, n * sizeof(mm_read_t)) != 0 || mmh_devloader_fetch(dl, j->name_off, db->name_off, n * sizeof(uint64_t)) != 0 ||
+        mmh_devloader_fetch(dl, j->names, db->names, (size_t)db->names_bytes) != 0) return -1;
+    j->n = n; j->names_len = (size_t)db->names_bytes;
+    return 0;
+}
+
+/* (a read that fails in a batch of the device-side reader is named by where the host reader's -K / -B batches would have it: below) */
+static struct { const void *o; const char *bam; const void *ws; } err_ctx;
+static int32_t batch_index_in_file_ctx(uint64_t ordinal, int32_t fallback);
+
 /* wait for a group's launch; a failing read is named by its index in its own -K batch, like the reference does */
 static void retire_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr, double *wait_time) {
     if (g->ticket < 0) return;
@@ -415,7 +451,8 @@ static void retire_view_group(mm_freq_t *h, group_t *g, const mm_bam_hdr_t *hdr,
     *wait_time += mmh_realtime() - tw;
     if (n < 0) {
         int32_t in_batch = bad;
-        for (int m = 0; m < g->n && in_batch >= g->n_reads[m]; m++) in_batch -= g->n_reads[m];
+        if (g->dev_before >= 0) in_batch = batch_index_in_file_ctx((uint64_t)g->dev_before + (uint64_t)(bad > 0 ? bad : 0), bad);
+        else for (int m = 0; m < g->n && in_batch >= g->n_reads[m]; m++) in_batch -= g->n_reads[m];
         die_read_record((int)-n, in_batch, (bad >= 0 && (size_t)bad < g->j.n) ? &g->j.reads[bad] : NULL, hdr);
     }
     double to = mmh_realtime();
@@ -569,6 +606,32 @@ static int32_t batch_index_in_file(const fopt_t *o, const char *bam_file, const 
     return at;
 }
 
+static int32_t batch_index_in_file_ctx(uint64_t ordinal, int32_t fallback) {
+    if (!err_ctx.o) return fallback;
+    return batch_index_in_file((const fopt_t *)err_ctx.o, err_ctx.bam, (const wspec_t *)err_ctx.ws, ordinal, fallback);
+}
+
+/* the codes of a device batch into the handles' tables, in the order the host's walk (intern_batch_codes) meets them */
+static void intern_device_codes(mmh_devloader_t *dl, const mmh_devbatch_t *db, mm_freq_t *h, mm_freq_t *hv) {
+    char codes[2 * MM_MAX_CODES][MM_CODE_LEN];
+    const int k = mmh_devloader_codes(dl, &db->batch, &codes[0][0], 2 * MM_MAX_CODES);
+    if (k >= 0) {
+        for (int i = 0; i < k; i++) { (void)mm_freq_intern_code(h, codes[i]); if (hv) (void)mm_freq_intern_code(hv, codes[i]); }
+        return;
+    }
+    /* codes the census does not take (longer than 8 characters ...): the batch's records and MM text come over and are walked here */
+    mm_batch_t b = db->batch;
+    mm_read_t *rd = (mm_read_t *)malloc((size_t)(b.n_reads > 0 ? b.n_reads : 1) * sizeof(mm_read_t));
+    uint8_t *mm = (uint8_t *)malloc((size_t)b.n_mm_bytes + 1);
+    if (!rd || !mm || mmh_devloader_fetch(dl, rd, db->batch.reads, (size_t)b.n_reads * sizeof(mm_read_t)) != 0 || mmh_devloader_fetch(dl, mm, db->batch.mm, (size_t)b.n_mm_bytes) != 0) {
+        MMH_ERROR("%s", "Could not read the batch's modification codes"); exit(EXIT_FAILURE);
+    }
+    b.reads = rd; b.mm = mm;
+    intern_batch_codes(h, &b);
+    if (hv) intern_batch_codes(hv, &b);
+    free(rd); free(mm);
+}
+
 static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, const char *bam_file, double realtime0, const wspec_t *ws) {
     const fopt_t o = *op;
     const mmh_mods_t mods = *modsp;
@@ -609,9 +672,10 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     struct stat bst;   /* (a pipe's bytes can be read once: no header read-ahead there -- and no device inflate, which wants the file mapped) */
     const int regular = stat(bam_file, &bst) == 0 && S_ISREG(bst.st_mode);
     uint64_t hdr_bytes = 0;
-    /* the device loader takes the runs whose rows cannot tie (the headline run, -c m[CG]): the tie-order replay and the wildcard
-     * code table work from host batches */
-    int use_dev = o.gpu_ingest && !view && (!replay || dev_replay) && !wildcard && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
+    /* the device loader takes every run of a regular file but the ones that replay the tie order on the host (--host-replay): view gets
+     * the read names with its batches, a wildcard run the batch's codes from a census kernel (mm_ingest_batch_codes) */
+    err_ctx.o = &o; err_ctx.bam = bam_file; err_ctx.ws = ws;
+    int use_dev = o.gpu_ingest && (!replay || dev_replay) && regular && o.debug_break < 0 && mm_bam_peek_header2(bam_file, &hdr0, &hdr_bytes) == 0;
     if (use_dev) {
         hdr = &hdr0;
         pool = mm_pool_create(o.threads);
@@ -620,6 +684,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         mmh_devloader_opts_t *d = &dlj.o;
         d->device = o.device; d->n_targets = hdr0.n_targets; d->allow_secondary = o.allow_secondary; d->skip_supplementary = o.skip_supplementary;
         d->header_bytes = hdr_bytes;
+        if (view) {   /* rows are printed a batch at a time: batches of one group of 512 blocks (~15 Mbases) keep the printing beside the kernels */
+            d->names = 1; d->max_blocks = 512; d->target_bases = (uint64_t)16 * 1000 * 1000;
+        }
         if (ws->sharded) {
             d->ranged = 1; d->first = ws->first; d->last = ws->last; d->lo_tid = ws->lo_tid; d->lo_pos = ws->lo_pos; d->hi_tid = ws->hi_tid; d->hi_pos = ws->hi_pos;
             if (ws->voffset == UINT64_MAX) d->range_done_before_start = 1; else d->voffset = ws->voffset;
@@ -748,6 +815,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     group_t *cur = (group_t *)calloc(1, sizeof(group_t)), *prev = (group_t *)calloc(1, sizeof(group_t));
     group_t *vcur = (group_t *)calloc(1, sizeof(group_t)), *vprev = (group_t *)calloc(1, sizeof(group_t));   /* the replay handle's groups */
     cur->ticket = prev->ticket = vcur->ticket = vprev->ticket = -1;
+    cur->dev_before = prev->dev_before = vcur->dev_before = vprev->dev_before = -1;
     int32_t copied[MMH_POOL_SETS];
     for (int i = 0; i < MMH_POOL_SETS; i++) copied[i] = -1;
     double prog_t = mmh_realtime();
@@ -759,6 +827,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         int32_t tvn[2] = {0, 0};
         uint64_t dev_reads_before_of[2] = {0, 0};   /* per open ticket: accepted reads of the device batches in front of it */
         int ar[2] = {-1, -1};
+        group_t *vg[2] = {cur, prev};               /* view: the open tickets' journals (read records and names, for the printing) */
         void *stream = mmh_devloader_stream(dl);
         more = 1;
         while (more) {
@@ -787,21 +856,31 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             fprintf(stderr, "[%s::%.3f*%.2f] %d Entries (%.1fM bases) loaded\n", __func__, mmh_realtime() - realtime0,
                     mmh_cputime() / (mmh_realtime() - realtime0), n, db.processed_bytes / (1000.0 * 1000.0));
             for (int k = 0; k < 2 && tk[0] >= 0; k++) {   /* the older ticket; both when nothing follows */
-                double tw = mmh_realtime();
-                int32_t bad = -1;
-                int e = mm_freq_wait(h, tk[0], &bad);
-                process_wait_time += mmh_realtime() - tw;
-                if (e) {
-                    mm_read_t rec;
-                    const int have = bad >= 0 && mm_freq_read_record(h, tk[0], bad, &rec) == 0;
-                    die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[0] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
+                if (view) { vg[0]->ticket = tk[0]; retire_view_group(h, vg[0], hdr, &o, pool, &process_wait_time, &output_time); }
+                else {
+                    double tw = mmh_realtime();
+                    int32_t bad = -1;
+                    int e = mm_freq_wait(h, tk[0], &bad);
+                    process_wait_time += mmh_realtime() - tw;
+                    if (e) {
+                        mm_read_t rec;
+                        const int have = bad >= 0 && mm_freq_read_record(h, tk[0], bad, &rec) == 0;
+                        die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[0] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
+                    }
                 }
                 if (dev_replay) replay_ticket_dev(hv, dtie, tv[0], &tvn[0], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
                 mmh_devloader_release(dl, ar[0]);
+                { group_t *t = vg[0]; vg[0] = vg[1]; vg[1] = t; }
                 tk[0] = tk[1]; ar[0] = ar[1]; tv[0] = tv[1]; tvn[0] = tvn[1]; dev_reads_before_of[0] = dev_reads_before_of[1]; tk[1] = -1; ar[1] = -1; tv[1] = -1;
                 if (more) break;
             }
             if (n > 0) {
+                if (wildcard) intern_device_codes(dl, &db, h, replay ? hv : NULL);
+                if (view) {
+                    group_t *gj = tk[0] < 0 ? vg[0] : vg[1];
+                    if (journal_from_device(&gj->j, dl, &db) != 0) { MMH_ERROR("%s", "Could not fetch the batch's read names"); exit(EXIT_FAILURE); }
+                    gj->n = 1; gj->n_reads[0] = n; gj->dev_before = (int64_t)dev_reads_before;
+                }
                 const double t_sub = mmh_realtime();
                 int32_t t = mm_freq_submit_device_now(h, &db.batch, stream, db.bases);
                 submit_time += mmh_realtime() - t_sub;
@@ -830,14 +909,17 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         }
         for (int k = 0; k < 2; k++) {
             if (tk[k] < 0) continue;
-            double tw = mmh_realtime();
-            int32_t bad = -1;
-            int e = mm_freq_wait(h, tk[k], &bad);
-            process_wait_time += mmh_realtime() - tw;
-            if (e) {
-                mm_read_t rec;
-                const int have = bad >= 0 && mm_freq_read_record(h, tk[k], bad, &rec) == 0;
-                die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[k] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
+            if (view) { vg[k]->ticket = tk[k]; retire_view_group(h, vg[k], hdr, &o, pool, &process_wait_time, &output_time); }
+            else {
+                double tw = mmh_realtime();
+                int32_t bad = -1;
+                int e = mm_freq_wait(h, tk[k], &bad);
+                process_wait_time += mmh_realtime() - tw;
+                if (e) {
+                    mm_read_t rec;
+                    const int have = bad >= 0 && mm_freq_read_record(h, tk[k], bad, &rec) == 0;
+                    die_read_record(e, batch_index_in_file(&o, bam_file, ws, dev_reads_before_of[k] + (uint64_t)(bad > 0 ? bad : 0), bad), have ? &rec : NULL, hdr);
+                }
             }
             if (dev_replay) replay_ticket_dev(hv, dtie, tv[k], &tvn[k], 1, hdr, klass_of_code, &dtie_codes, &replay_time);
             mmh_devloader_release(dl, ar[k]);
@@ -1584,7 +1666,7 @@ static int run_main(int argc, char **argv, int view) {
         struct stat sb;
         int n_dev = 1;
         if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
-        o.gpu_ingest = !view && stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)512 << 20);   /* (tools/ingest_threshold.sh: the device reader's own start -- 192 MiB of pinned staging, 3 GiB of pools, their release at exit -- is 0.1 - 0.3 s by box; the host threads win below ~0.5 GiB, lose from ~1 GiB, between them it depends on the box) */
+        o.gpu_ingest = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)512 << 20);   /* (tools/ingest_threshold.sh: the device reader's own start -- 192 MiB of pinned staging, 3 GiB of pools, their release at exit -- is 0.1 - 0.3 s by box; the host threads win below ~0.5 GiB, lose from ~1 GiB, between them it depends on the box) */
     }
     /* the HIP runtime's start (~0.2 s) beside the reference's load -- unless this process is going to fork workers (--devices a,b,...:
      * the parent must not have touched HIP) */

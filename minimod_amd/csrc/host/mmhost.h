@@ -93,12 +93,16 @@ typedef struct mmh_devloader_opts {
     /* sizes, 0 = the library's defaults (tests make them small) */
     int group_slots, max_blocks, arenas;
     uint64_t max_cbytes, arena_bytes, head_room;
+    int names;                      /* not 0: the batches carry their read names (view) */
 } mmh_devloader_opts_t;
 typedef struct mmh_devbatch {
     mm_batch_t batch;               /* DEVICE pointers: for mm_freq_submit_device_now on mmh_devloader_stream() */
     int arena;                      /* give it back with mmh_devloader_release once the batch's ticket has been waited for */
     uint64_t bases;
     uint64_t total_reads, total_bytes, processed_bytes;   /* of the records this batch was made from (db_t counters, src/minimod.h:147-150) */
+    const uint8_t *names;           /* opts.names: DEVICE pointers -- read i's name at names + name_off[i], names_bytes in all */
+    const uint64_t *name_off;
+    uint64_t names_bytes;
 } mmh_devbatch_t;
 typedef struct mmh_devloader_stats {
     uint64_t total_reads, total_bytes, processed_reads, processed_bytes, processed_bases;   /* core_t counters, src/minimod.h:190-194 */
@@ -113,6 +117,9 @@ int32_t mmh_devloader_next(mmh_devloader_t *dl, mmh_devbatch_t *out, int *more);
 void mmh_devloader_release(mmh_devloader_t *dl, int arena);
 void *mmh_devloader_stream(mmh_devloader_t *dl);
 int mmh_devloader_fetch(mmh_devloader_t *dl, void *dst_host, const void *src_dev, size_t n);   /* device bytes of a batch to the host (0 ok) */
+/* the codes a batch's MM tags name, in the order a walk over the batch meets them (mm_ingest_batch_codes: -c '*' interns them before the
+ * batch is submitted); codes: max_codes strings of MM_CODE_LEN bytes.  The number written, or < 0 (the caller walks the MM text itself) */
+int mmh_devloader_codes(mmh_devloader_t *dl, const mm_batch_t *batch, char *codes, int max_codes);
 const mmh_devloader_stats_t *mmh_devloader_stats(mmh_devloader_t *dl);
 void mmh_devloader_close(mmh_devloader_t *dl);
 

@@ -33,6 +33,7 @@ struct GSlot {
 struct Arena {
     mm_read_t* reads = nullptr; uint8_t *cigar = nullptr, *seq = nullptr, *mm = nullptr, *ml = nullptr;
     uint64_t cap_reads = 0, cap_cigar = 0, cap_seq = 0, cap_mm = 0, cap_ml = 0;
+    uint8_t* names = nullptr; uint64_t* name_off = nullptr; uint64_t cap_names = 0;   // opts.names only
 };
 }  // namespace
 
@@ -48,6 +49,8 @@ struct mm_ingest {
     uint8_t* d_tail[2] = {nullptr, nullptr};
     uint64_t next_seq = 0;         // groups numbered by mm_ingest_inflate
     uint64_t flat_seq = 0;         // the next group to be flattened for the first time
+    CodeTab* d_codes = nullptr;    // mm_ingest_batch_codes (made at its first call)
+    CodeTab* h_codes = nullptr;    // pinned
 };
 
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::snprintf(err ? err : dummy, err ? err_len : sizeof dummy, "%s: %s", #x, hipGetErrorString(e_)); mm_ingest_destroy(h); return nullptr; } } while (0)
@@ -63,6 +66,7 @@ const char* mm_ingest_strerror(int32_t code) {
         case MM_INGEST_E_TAIL: return "a BAM record longer than the device reader's head room";
         case MM_INGEST_E_RECORDS: return "more records in a group of blocks than the device reader's tables hold";
         case MM_INGEST_E_HEADER: return "the BAM header does not end inside the first group of blocks";
+        case MM_INGEST_E_CODES: return "modification codes the device-side census does not take (longer than 8 characters, or more than 1024 of them)";
         case MM_INGEST_E_ARG: return "bad argument";
         case MM_INGEST_E_HIP: return "HIP runtime error";
         case MM_INGEST_E_ORDER: return "groups out of order";
@@ -152,6 +156,11 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
         ICHK(hipMalloc((void**)&a.reads, sizeof(mm_read_t) * a.cap_reads));
         ICHK(hipMalloc((void**)&a.cigar, a.cap_cigar)); ICHK(hipMalloc((void**)&a.seq, a.cap_seq));
         ICHK(hipMalloc((void**)&a.mm, a.cap_mm)); ICHK(hipMalloc((void**)&a.ml, a.cap_ml));
+        if (h->o.names) {   // a name is at most 255 of its record's bytes; an eighth of the stream holds the names of any BAM a sequencer's pipeline writes,
+            a.cap_names = std::max<uint64_t>(D / 8 + (1 << 20), one);   // and never less than what one group can hold (the answer to "full" is an empty arena)
+            ICHK(hipMalloc((void**)&a.names, a.cap_names));
+            ICHK(hipMalloc((void**)&a.name_off, sizeof(uint64_t) * a.cap_reads));
+        }
     }
     ICHK(hipDeviceSynchronize());
     if (tl) std::fprintf(stderr, "[timeline] mm_ingest_create: runtime + streams %.3f s, group slots %.3f s, arenas %.3f s\n", t1 - t0, t2 - t1, now() - t2);
@@ -172,7 +181,9 @@ void mm_ingest_destroy(mm_ingest_t* h) {
         for (void* p : ds) if (p) (void)hipFree(p);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
-    for (Arena& a : h->arenas) { void* ds[] = {a.reads, a.cigar, a.seq, a.mm, a.ml}; for (void* p : ds) if (p) (void)hipFree(p); }
+    for (Arena& a : h->arenas) { void* ds[] = {a.reads, a.cigar, a.seq, a.mm, a.ml, a.names, a.name_off}; for (void* p : ds) if (p) (void)hipFree(p); }
+    if (h->d_codes) (void)hipFree(h->d_codes);
+    if (h->h_codes) (void)hipHostFree(h->h_codes);
     void* ds[] = {h->d_carry, h->d_cursor, h->d_tail[0], h->d_tail[1]};
     for (void* p : ds) if (p) (void)hipFree(p);
     if (h->chain) (void)hipStreamDestroy(h->chain);
@@ -242,6 +253,7 @@ int32_t mm_ingest_flatten(mm_ingest_t* h, int32_t slot, int32_t arena, int32_t n
     P.reads = a.reads; P.cigar = a.cigar; P.seq = a.seq; P.mm = a.mm; P.ml = a.ml;
     P.cap_reads = a.cap_reads; P.cap_cigar = a.cap_cigar; P.cap_seq = a.cap_seq; P.cap_mm = a.cap_mm; P.cap_ml = a.cap_ml;
     P.new_arena = new_arena ? 1 : 0;
+    P.names = a.names; P.name_off = a.name_off; P.cap_names = a.cap_names;
     hipStream_t st = h->chain;
     RCHK(hipStreamWaitEvent(st, s.ev[3], 0));
     RCHK(hipEventRecord(s.ev_f0, st));
@@ -279,6 +291,7 @@ int32_t mm_ingest_result(mm_ingest_t* h, int32_t slot, mm_ingest_result_t* out) 
     out->batch_reads = R.cursor.n_reads; out->batch_bases = R.cursor.bases;
     out->cigar_bytes = R.cursor.cigar_bytes; out->seq_bytes = R.cursor.seq_bytes; out->mm_bytes = R.cursor.mm_bytes; out->ml_bytes = R.cursor.ml_bytes;
     out->max_n_cigar = R.cursor.max_n_cigar; out->max_l_qseq = R.cursor.max_l_qseq;
+    out->qname_bytes = R.cursor.qname_bytes;
     if (R.n_bad_blocks == 0 && R.carry.err != IE_ARENA) s.inflating = false;   // the slot is the caller's again
     return 0;
 }
@@ -311,6 +324,46 @@ int32_t mm_ingest_arena_batch(mm_ingest_t* h, int32_t arena, const mm_ingest_res
     out->n_cigar_words = (r->cigar_bytes + 64) / 4; out->n_seq_bytes = r->seq_bytes + 64; out->n_mm_bytes = r->mm_bytes + 64; out->n_ml_bytes = r->ml_bytes + 64;
     out->max_n_cigar = r->max_n_cigar; out->max_l_qseq = r->max_l_qseq;
     return 0;
+}
+
+int32_t mm_ingest_arena_names(mm_ingest_t* h, int32_t arena, const uint8_t** names, const uint64_t** name_off) {
+    if (!h || arena < 0 || (size_t)arena >= h->arenas.size() || !names || !name_off) return -MM_INGEST_E_ARG;
+    const Arena& a = h->arenas[(size_t)arena];
+    if (!a.names) return -MM_INGEST_E_ARG;   // the handle was made without opts.names
+    *names = a.names; *name_off = a.name_off;
+    return 0;
+}
+
+int32_t mm_ingest_batch_codes(mm_ingest_t* h, const mm_batch_t* b, char* codes, int32_t max_codes) {
+    if (!h || !b || b->n_reads < 0 || (!codes && max_codes > 0) || max_codes < 0) return -MM_INGEST_E_ARG;
+    RCHK(hipSetDevice(h->device));
+    if (!h->d_codes) {
+        RCHK(hipMalloc((void**)&h->d_codes, sizeof(CodeTab)));
+        RCHK(hipHostMalloc((void**)&h->h_codes, sizeof(CodeTab), hipHostMallocDefault));
+    }
+    RCHK(hipMemsetAsync(h->d_codes, 0, sizeof(CodeTab), h->chain));
+    RCHK(hipMemsetAsync(h->d_codes->stamp, 0xFF, sizeof(h->d_codes->stamp), h->chain));
+    if (b->n_reads > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)b->n_reads + 3) / 4, (int64_t)h->n_cu * 16);
+        hipLaunchKernelGGL(k_batch_codes, dim3(grid), dim3(256), 0, h->chain, b->reads, b->mm, (uint32_t)b->n_reads, h->d_codes);
+        RCHK(hipGetLastError());
+    }
+    RCHK(hipMemcpyAsync(h->h_codes, h->d_codes, sizeof(CodeTab), hipMemcpyDeviceToHost, h->chain));
+    RCHK(hipStreamSynchronize(h->chain));
+    const CodeTab& T = *h->h_codes;
+    if (T.flags) return -MM_INGEST_E_CODES;
+    std::vector<std::pair<unsigned long long, unsigned long long>> found;   // (stamp, key)
+    for (uint32_t s = 0; s < kCodeSlots; s++) if (T.key[s]) found.emplace_back(T.stamp[s], T.key[s]);
+    std::sort(found.begin(), found.end());
+    int32_t n = 0;
+    for (const auto& f : found) {
+        if (n >= max_codes) break;
+        char* dst = codes + (size_t)n * MM_CODE_LEN;
+        std::memset(dst, 0, MM_CODE_LEN);
+        std::memcpy(dst, &f.second, 8);
+        n++;
+    }
+    return n;
 }
 
 int32_t mm_ingest_copy_to_host(mm_ingest_t* h, void* dst, const void* src, size_t n) {

@@ -102,6 +102,8 @@ struct Params {
     mm_read_t* reads; uint8_t *cigar, *seq, *mm, *ml;
     uint64_t cap_reads, cap_cigar, cap_seq, cap_mm, cap_ml;   // reads / bytes
     int32_t new_arena;       // the group starts a batch (cursor_in is not looked at)
+    // the read names too (view prints them: src/mod.c print_view_output's first column) -- names == nullptr: not kept
+    uint8_t* names; uint64_t* name_off; uint64_t cap_names;
 };
 
 __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
@@ -440,9 +442,12 @@ __global__ __launch_bounds__(kScanThreads, 4) void k_rec_scan(Params P) {
         proc_bytes += t_x >> 24;
         uint64_t t_b;
         (void)wg_scan(acc ? (uint64_t)d.l_qseq : 0ull, sh, &t_b);
+        uint64_t t_q = 0, r_q = 0;
+        if (P.names) r_q = wg_scan(acc ? (uint64_t)(d.n_cigar_lname >> 16) : 0ull, sh, &t_q);   // l_read_name counts the NUL
         // room for the tile?  (+ 64 bytes of zero slack behind every pool)
         if (cu.n_reads + t_n > P.cap_reads || cu.cigar_bytes + t_c + 64 > P.cap_cigar || cu.seq_bytes + t_s + 64 > P.cap_seq ||
-            cu.mm_bytes + t_m + 64 > P.cap_mm || cu.ml_bytes + t_l + 64 > P.cap_ml || cu.mm_bytes + t_m >= 0xFFFFF000ull || cu.n_reads + t_n >= (1ull << 24)) { full = true; break; }
+            cu.mm_bytes + t_m + 64 > P.cap_mm || cu.ml_bytes + t_l + 64 > P.cap_ml || cu.mm_bytes + t_m >= 0xFFFFF000ull || cu.n_reads + t_n >= (1ull << 24) ||
+            (P.names && cu.qname_bytes + t_q > P.cap_names)) { full = true; break; }
         if (i < n_use) P.info[i] = d.l_data | (counted ? 1u << 30 : 0u) | (acc ? 1u << 31 : 0u);
         if (acc) {
             mm_read_t rd;
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void k_rec_scan(Params P) {
             rd.l_qseq = d.l_qseq; rd.n_cigar = n_cigar; rd.mm_len = d.mm_len; rd.ml_len = d.ml_len;
             rd.flag = (uint16_t)(d.flags >> 16); rd.hp = (uint8_t)(d.flags >> 8); rd.rsvd = 0; rd.rsvd2 = 0;
             P.reads[cu.n_reads + r_n] = rd;
+            if (P.names) P.name_off[cu.n_reads + r_n] = cu.qname_bytes + r_q;
             P.acc_rec[n_acc + (uint32_t)r_n] = i;
         }
         // the largest CIGAR / read of the batch
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(kScanThreads, 4) void k_rec_scan(Params P) {
         __syncthreads();
         for (int k = 0; k < kScanWaves; k++) { mx_c = max(mx_c, (uint32_t)(sh[k] >> 32)); mx_l = max(mx_l, (uint32_t)sh[k]); }
         __syncthreads();
-        cu.n_reads += t_n; cu.cigar_bytes += t_c; cu.seq_bytes += t_s; cu.mm_bytes += t_m; cu.ml_bytes += t_l; cu.bases += t_b;
+        cu.n_reads += t_n; cu.cigar_bytes += t_c; cu.seq_bytes += t_s; cu.mm_bytes += t_m; cu.ml_bytes += t_l; cu.bases += t_b; cu.qname_bytes += t_q;
         n_acc += (uint32_t)t_n;
     }
     cu.max_n_cigar = mx_c; cu.max_l_qseq = mx_l;
@@ -536,6 +542,85 @@ __global__ __launch_bounds__(256) void k_rec_copy(Params P) {
         copy_item16(P.seq + o_s, sq, sb, (sb + 15u) & ~15u, (l_qseq & 1u) != 0u);   // the unused low nibble must be zero for the base counts
         copy_item16(P.mm + o_m, P.out + mm_src, mm_len, (mm_len + 1u + 15u) & ~15u, false);
         copy_item4(P.ml + o_l, P.out + ml_src, ml_len, (ml_len + 3u) & ~3u);
+        if (P.names) {
+            uint8_t* nd = P.names + P.name_off[r0 + j];
+            const uint8_t* ns = P.out + ro + 36u;
+            for (uint32_t c = (uint32_t)lane(); c < l_name; c += 64u) nd[c] = ns[c];
+        }
+    }
+}
+
+// ---- the codes a batch's MM tags carry, for a wildcard run (-c '*': the reference counts whatever code a read names, src/mod.c's
+// req_all path; the host interns a code the first time it meets one, csrc/host/freq_main.c intern_batch_codes).  A wavefront per read
+// finds the groups of its MM text (the text's start and every byte behind a ';'), takes the code behind the base and the strand --
+// digits: one ChEBI code; letters: the string from each letter on -- and leaves, per distinct code of up to 8 characters, the SMALLEST (read, text
+// offset) it was seen at: sorted by that, the codes come out in the order the host's walk over the batch meets them.
+constexpr uint32_t kCodeSlots = 1024;
+struct CodeTab { unsigned long long key[kCodeSlots]; unsigned long long stamp[kCodeSlots]; uint32_t flags; uint32_t pad; };   // flags: 1 a code longer than 8 characters, 2 table full
+__device__ __forceinline__ void code_put(CodeTab* T, uint64_t key, uint64_t stamp) {
+    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54) & (kCodeSlots - 1u);
+    for (uint32_t probes = 0; probes < kCodeSlots; probes++, s = (s + 1u) & (kCodeSlots - 1u)) {
+        unsigned long long k = __atomic_load_n(&T->key[s], __ATOMIC_RELAXED);
+        if (k == 0ull) { k = atomicCAS(&T->key[s], 0ull, (unsigned long long)key); if (k == 0ull) k = key; }
+        if (k == key) {
+            if (__atomic_load_n(&T->stamp[s], __ATOMIC_RELAXED) > stamp) atomicMin(&T->stamp[s], (unsigned long long)stamp);
+            return;
+        }
+    }
+    atomicOr(&T->flags, 2u);
+}
+__global__ __launch_bounds__(256) void k_batch_codes(const mm_read_t* __restrict__ reads, const uint8_t* __restrict__ mm, uint32_t n_reads, CodeTab* T) {
+    const uint32_t wave = uni(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;
+    const int l = lane();
+    for (uint32_t r = wave; r < n_reads; r += n_waves) {
+        const uint32_t off = uni(reads[r].mm_off), n = uni(reads[r].mm_len);
+        const uint8_t* t = mm + off;                      // (16-byte aligned, zeros behind the text up to the next multiple of 16 and 64 more behind the pool)
+        for (uint32_t base = 0; base < n + 1u; base += 1024u) {
+            // group starts in [base, base + 1024): position 0, and p + 1 for every ';' at p
+            const uint32_t at = base + 16u * (uint32_t)l;
+            uint32_t semis = 0;                           // bit k: a group starts at at + k
+            if (at < n + 16u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(t + (at >= 16u ? at - 16u : 0u));
+                const uint4 w = at < n ? *reinterpret_cast<const uint4*>(t + at) : make_uint4(0, 0, 0, 0);
+                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+                if (at == 0u) semis |= 1u; else if ((v.w >> 24) == (uint32_t)';') semis |= 1u;
+#pragma unroll
+                for (int k = 0; k < 15; k++) if (((ws[k >> 2] >> (8 * (k & 3))) & 255u) == (uint32_t)';') semis |= 2u << k;
+            }
+            uint64_t m = __ballot(semis != 0u);
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+                uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)semis, src);
+                const uint32_t a0 = base + 16u * (uint32_t)src;
+                while (bits) {
+                    const uint32_t p = a0 + (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (p >= n) continue;
+                    const uint32_t s = p + 2u;
+                    if (s >= n) continue;
+                    // the code: [s, e), e = the first of , ; ? . or the text's end -- lanes look at a byte each (codes of 16 and more are not interned)
+                    const uint32_t c = s + (uint32_t)l < n ? (uint32_t)t[s + (uint32_t)l] : (uint32_t)';';
+                    const uint64_t stop = __ballot(c == ',' || c == ';' || c == '?' || c == '.') | (1ull << 63);
+                    const uint32_t len = (uint32_t)__builtin_ctzll(stop);
+                    if (len == 0u || len >= 16u) continue;
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    const uint64_t stamp = ((uint64_t)r << 32) | s;
+                    // digits: the whole string is one code; letters: the string from every letter on is one (mod.c:1146-1160 looks a letter's code
+                    // up as the C string that starts at it) -- lane m holds the code that starts at character m
+                    const bool digits = c0 >= '0' && c0 <= '9';
+                    uint64_t key = 0;
+                    for (uint32_t k = 0; k < len; k++) {
+                        const uint64_t ck = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c, (int)k);
+                        if (k >= (uint32_t)l && k - (uint32_t)l < 8u) key |= ck << (8u * (k - (uint32_t)l));
+                    }
+                    if ((uint32_t)l < (digits ? 1u : len)) {
+                        if (len - (uint32_t)l > 8u) atomicOr(&T->flags, 1u);
+                        else code_put(T, key, stamp + (uint32_t)l);
+                    }
+                }
+            }
+        }
     }
 }
 

@@ -167,12 +167,13 @@ class mmh_devloader_opts_t(ctypes.Structure):
                 ("lo_tid", ctypes.c_int32), ("hi_tid", ctypes.c_int32), ("lo_pos", ctypes.c_int64), ("hi_pos", ctypes.c_int64),
                 ("target_bases", ctypes.c_uint64),
                 ("group_slots", ctypes.c_int), ("max_blocks", ctypes.c_int), ("arenas", ctypes.c_int),
-                ("max_cbytes", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64), ("head_room", ctypes.c_uint64)]
+                ("max_cbytes", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64), ("head_room", ctypes.c_uint64), ("names", ctypes.c_int)]
 
 
 class mmh_devbatch_t(ctypes.Structure):
     _fields_ = [("batch", mm_batch_t), ("arena", ctypes.c_int), ("bases", ctypes.c_uint64),
-                ("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_bytes", ctypes.c_uint64)]
+                ("total_reads", ctypes.c_uint64), ("total_bytes", ctypes.c_uint64), ("processed_bytes", ctypes.c_uint64),
+                ("names", ctypes.c_void_p), ("name_off", ctypes.c_void_p), ("names_bytes", ctypes.c_uint64)]
 
 
 class mmh_devloader_stats_t(ctypes.Structure):
@@ -197,11 +198,12 @@ def peek_header(path):
     return names, lens, int(hb.value)
 
 
-def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementary=False, target_bases=0, device=0, sizes=None, share=None, voffset=0):
+def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementary=False, target_bases=0, device=0, sizes=None, share=None, voffset=0, names=False, codes=False):
     """Yield (numpy batch dict, per-batch totals) made by the DEVICE loader (devloader.c on include/minimod_ingest.h), copied back to
     the host for comparison with load_batches().  sizes: dict of the small test geometries (group_slots, max_blocks, arenas,
-    max_cbytes, arena_bytes, head_room).  share: (lo_tid, lo_pos, hi_tid, hi_pos, first, last).  The last item yielded is the
-    stats structure."""
+    max_cbytes, arena_bytes, head_room).  share: (lo_tid, lo_pos, hi_tid, hi_pos, first, last).  names: the batch dict also holds "names"
+    (the reads' names, a list of bytes); codes: ... and "codes" (mm_ingest_batch_codes' answer: a list of bytes, or the negative code).
+    The last item yielded is the stats structure."""
     L = _lib()
     L.mm_pool_create.restype = ctypes.c_void_p
     L.mm_pool_create.argtypes = [ctypes.c_int]
@@ -219,6 +221,9 @@ def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementa
     o = mmh_devloader_opts_t()
     o.device = device; o.n_targets = len(names); o.allow_secondary = int(allow_secondary); o.skip_supplementary = int(skip_supplementary)
     o.header_bytes = hb; o.voffset = voffset; o.target_bases = target_bases
+    o.names = int(bool(names))
+    L.mmh_devloader_codes.restype = ctypes.c_int
+    L.mmh_devloader_codes.argtypes = [ctypes.c_void_p, ctypes.POINTER(mm_batch_t), ctypes.c_char_p, ctypes.c_int]
     if share:
         o.ranged = 1
         o.lo_tid, o.lo_pos, o.hi_tid, o.hi_pos, o.first, o.last = share
@@ -248,6 +253,14 @@ def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementa
                 d = {"reads": fetch(b.reads, b.n_reads, READ_DTYPE), "cigar": fetch(b.cigar, b.n_cigar_words, "<u4"),
                      "seq": fetch(b.seq, b.n_seq_bytes, np.uint8), "mm": fetch(b.mm, b.n_mm_bytes, np.uint8),
                      "ml": fetch(b.ml, b.n_ml_bytes, np.uint8), "max_n_cigar": b.max_n_cigar, "max_l_qseq": b.max_l_qseq}
+                if names:
+                    off = fetch(db.name_off, b.n_reads, "<u8")
+                    txt = fetch(db.names, db.names_bytes, np.uint8).tobytes()
+                    d["names"] = [txt[int(a):txt.index(b"\0", int(a))] for a in off]
+                if codes:
+                    buf = ctypes.create_string_buffer(16 * 256)
+                    k = L.mmh_devloader_codes(dl, ctypes.byref(b), buf, 256)
+                    d["codes"] = k if k < 0 else [buf.raw[16 * i:16 * i + 16].split(b"\0")[0] for i in range(k)]
                 L.mmh_devloader_release(dl, db.arena)
             else:
                 d = None

@@ -341,3 +341,60 @@ def test_cli_summary_census_on_the_device_matches_reference_goldens():
         a = subprocess.run([BIN, "summary", os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         b = subprocess.run([BIN, "summary", "--gpu", os.path.join(GOLDEN, "data", bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert a.returncode == b.returncode and a.stdout == b.stdout, bam
+
+
+# ---- round 5: view and -c '*' take the device-side reader too ("device ingestion everywhere")
+@pytest.mark.parametrize("exp,bam,ctg,kw,exact", VIEW_CASES, ids=["ingest-view-" + c[0] for c in VIEW_CASES])
+def test_cli_view_with_the_device_reader_matches_reference_golden(exp, bam, ctg, kw, exact, fastas):
+    """`minimod view --gpu-ingest`: the read names come with the device batches (mm_ingest_arena_names), a wildcard run's codes from the
+    census kernel (mm_ingest_batch_codes) -- the reference's goldens, and the bytes of the host threads' run, also with groups of 8 blocks
+    (several batches, records carried from group to group)"""
+    tail = [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    want = open(os.path.join(GOLDEN, "expected", exp)).read()
+    r0 = subprocess.run([BIN, "view", "--no-gpu-ingest"] + _args(kw) + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r0.returncode == 0 and b"[gpu-ingest]" not in r0.stderr
+    for env in ({}, {"MM_INGEST_MAX_BLOCKS": "8", "MM_INGEST_TARGET_BASES": "200000"}):
+        r = subprocess.run([BIN, "view", "--gpu-ingest"] + _args(kw) + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"[gpu-ingest]" in r.stderr
+        got = r.stdout.decode()
+        assert got == r0.stdout.decode(), (exp, env)
+        assert got == want if exact else sorted(got.splitlines()) == sorted(want.splitlines())
+        pick = lambda err: [l.split("] ", 1)[1] for l in err.decode().splitlines() if "] total " in l]
+        assert pick(r.stderr) == pick(r0.stderr)
+
+
+@pytest.mark.parametrize("bam,ctg,c", [("example-ont.bam", "chr22", "*"), ("eb.bam", "chr1", "*"), ("dRNA.bam", "chr22", "*[*]"), ("example-hifi.bam", "chr22", "*[CG]")])
+def test_cli_wildcard_freq_with_the_device_reader(bam, ctg, c, fastas):
+    """`minimod freq -c '*' --gpu-ingest`: the code table is filled from the census of every device batch in the order the host's walk
+    fills it (code indices, and with them the replayed tie order, are the same): the bytes of the host threads' run, of the host's serial
+    replay, and -- with groups of 8 blocks -- of several batches whose codes arrive one batch after the other"""
+    tail = [fastas[ctg], os.path.join(GOLDEN, "data", bam)]
+    base = [BIN, "freq", "-c", c]
+    r0 = subprocess.run(base + ["--no-gpu-ingest", "--host-replay"] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r0.returncode == 0 and len(r0.stdout) > 1000, r0.stderr.decode()[-2000:]
+    for extra, env in ((["--gpu-ingest"], {}), (["--gpu-ingest"], {"MM_INGEST_MAX_BLOCKS": "8", "MM_INGEST_TARGET_BASES": "200000"}), (["--gpu-ingest", "--insertions"], {})):
+        r = subprocess.run(base + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"[gpu-ingest]" in r.stderr and b"on the device" in r.stderr
+        if "--insertions" in extra:
+            r1 = subprocess.run(base + ["--no-gpu-ingest", "--host-replay", "--insertions"] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert r1.returncode == 0 and r.stdout == r1.stdout
+        else:
+            assert r.stdout == r0.stdout, (bam, c, env)
+
+
+def test_cli_view_names_a_failing_read_with_the_device_reader(tmp_path):
+    """view's error message with the device-side reader: the failing read by its index in the reference's -K batch, as with the host reader"""
+    from minimod_amd import synth
+    from oracle import pybam
+    from tests.cases import KAT_REF, KAT_SEQ
+    recs = [pybam.make_record(0, 2, 0, KAT_SEQ, "20M", "C+m?,0,0;", [255, 3]) for _ in range(11)]
+    recs[9] = pybam.make_record(0, 2, 0, KAT_SEQ, "3H20M", "C+m?,0,0;", [255, 3])
+    bam, fa = str(tmp_path / "h.bam"), str(tmp_path / "h.fa")
+    synth.write_bam(bam, [("chrT", len(KAT_REF))], [pybam.flatten(recs)], filter_fodder=False)
+    synth.write_fasta(fa, "chrT", np.frombuffer(KAT_REF.encode(), dtype=np.uint8))
+    for extra, want in ((["-K", "4"], b"read 1 of the batch"), (["-K", "7"], b"read 2 of the batch")):
+        for ing in ("--gpu-ingest", "--no-gpu-ingest"):
+            r = subprocess.run([BIN, "view", ing] + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert r.returncode == 1 and b"Hard clipping found in " + want + b" (contig chrT, pos 2)" in r.stderr, (ing, extra, r.stderr.decode()[-1500:])

@@ -122,3 +122,82 @@ def test_totals_are_the_host_loaders():
         L.mmh_loader_close(ld)
         _, _, st = device_batches(path, **flt)
         assert (st["total_reads"], st["total_bytes"], st["processed_reads"], st["processed_bytes"], st["processed_bases"]) == want
+
+
+# ---- round 5: what view and -c '*' need of a device batch -- the read names (mm_ingest_arena_names) and the codes its MM tags name
+# (mm_ingest_batch_codes), so that those runs take the device-side reader too
+def _python_records(path, **flt):
+    """the accepted records, by the independent Python reader (oracle/pybam.py)"""
+    from oracle import pybam
+    bam = pybam.BamFile(path)
+    recs = [r for r in bam if pybam.accept(r, flt.get("allow_secondary", False), flt.get("skip_supplementary", False))]
+    bam.close()
+    return recs
+
+
+def _walk_codes(mm_texts):
+    """csrc/host/freq_main.c intern_batch_codes restated: the codes in the order a walk over the reads' MM text meets them first -- a
+    group of digits is one code, a group of letters one per letter: the string from that letter on (mod.c:1146-1160)"""
+    seen = []
+    for s in mm_texts:
+        n, p = len(s), 0
+        while p < n:
+            a = e = p + 2
+            while e < n and s[e:e + 1] not in (b",", b";", b"?", b"."):
+                e += 1
+            if e > a and e - a < 16:
+                code = s[a:e]
+                for c in ([code] if code[:1].isdigit() else [code[m:] for m in range(len(code))]):
+                    if c not in seen:
+                        seen.append(c)
+            while p < n and s[p:p + 1] != b";":
+                p += 1
+            p += 1
+    return seen
+
+
+@pytest.mark.parametrize("path", BAMS, ids=[os.path.basename(p) for p in BAMS])
+@pytest.mark.parametrize("sizes", [None, SMALL], ids=["default", "small"])
+def test_device_batches_carry_names_and_codes(path, sizes):
+    from minimod_amd import hostlib
+    recs = _python_records(path)
+    items = list(hostlib.load_batches_device(path, threads=2, sizes=sizes, target_bases=1 << 62, names=True, codes=True))
+    got = [b for b, _ in items[:-1] if b is not None]
+    assert items[-1][1]["err"] == 0
+    names = [n for b in got for n in b["names"]]
+    assert names == [r.qname.rstrip(b"\0") for r in recs]
+    at = 0
+    for b in got:   # per batch: the codes of ITS reads, in the order of ITS text
+        mine = recs[at:at + len(b["reads"])]
+        at += len(b["reads"])
+        assert b["codes"] == _walk_codes([bytes(r.mm()) for r in mine]), os.path.basename(path)
+    same_batch(concat(got), host_batch(path))   # (and the names' pool changes nothing else)
+
+
+def test_code_census_on_made_up_tags():
+    """groups of several letters (a code per suffix), ChEBI numbers, flags, codes behind skipped groups, codes first seen late in a long text,
+    a code of nine characters (the census hands the batch back: -MM_INGEST_E_CODES), in one synthetic BAM"""
+    import tempfile
+    from minimod_amd import hostlib, synth
+    from oracle import pybam
+    rng = np.random.default_rng(11)
+    def rec(i, mm, n_ml):
+        seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 400))
+        return pybam.make_record(0, 10 + i, 0, seq, "400M", mm, [int(x) for x in rng.integers(0, 256, n_ml)], qname=("read%d" % i).encode())
+    long_list = ",".join(["0"] * 700)
+    texts = ["C+m?,1,2;", "C+hm,0,0;A+a.,3;", "C+21839,1;C+m,2;", "N+xyz?,0;", "C+m," + long_list + ";G+76792?,1;T+gq,0;", "C+h.;", "C-m,1;C+c?;A-17596,0;",
+             "C+m?,1;" * 30 + "T+e,0;", "A+b"]
+    recs = [rec(i, t, 3) for i, t in enumerate(texts * 40)]
+    with tempfile.TemporaryDirectory() as d:
+        bam = os.path.join(d, "c.bam")
+        synth.write_bam(bam, [("chrS", 1 << 16)], [pybam.flatten(recs)], filter_fodder=False)
+        items = list(hostlib.load_batches_device(bam, threads=2, names=True, codes=True))
+        got = [b for b, _ in items[:-1] if b is not None]
+        assert len(got) == 1 and got[0]["codes"] == _walk_codes([t.encode() for t in texts])
+        assert got[0]["names"] == [r.qname.rstrip(b"\0") for r in _python_records(bam)] and len(got[0]["names"]) == len(recs)
+        # a code longer than 8 characters: the caller is told to walk the text itself
+        recs2 = recs[:5] + [rec(99, "C+123456789,0;", 1)]
+        bam2 = os.path.join(d, "c2.bam")
+        synth.write_bam(bam2, [("chrS", 1 << 16)], [pybam.flatten(recs2)], filter_fodder=False)
+        items = list(hostlib.load_batches_device(bam2, threads=2, codes=True))
+        assert items[0][0]["codes"] == -6
