@@ -105,6 +105,8 @@ struct WaveLds {
     CodeLdsD cl_d;
     uint8_t lens[320];    // litlen lengths, then distance lengths
     uint8_t ring[2048];   // the block's latest output (kRing)
+    uint32_t win[128 + 4];   // round 5: the 512 compressed bytes around the reader's position (what Bits::va / vb hold), for the lanes' unaligned reads; the ring's over-read pad in front of it
+
 };
 
 typedef uint32_t u32_unal __attribute__((aligned(1)));
@@ -113,6 +115,17 @@ __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside each row of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 (no LDS trip)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
 
 // ---- the bit reader: wave-uniform state, the bytes in two registers
 struct Bits {
@@ -359,6 +372,13 @@ __device__ __forceinline__ void ring_flush(uint8_t* out, const uint8_t* ring, ui
     }
 }
 
+// four bytes at any address of the block's flushed output, from L2 (sc1: a line of the vector cache may be older than the flush's stores)
+__device__ __forceinline__ uint32_t load_far(const uint8_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // ---- one block
 __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, uint8_t* out, uint32_t isize, WaveLds& S) {
     const int l = lane();
@@ -434,6 +454,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
             //      or, further back, from global memory -- as long as no match reads what this step writes (distance >= bytes in front of
             //      it in the step + its length).  A match that does (a run: distance < length), or a long one, ends the step and is
             //      copied the old way, all lanes on one match; the same tables serve the rest of the window.
+#ifdef MM_INFLATE_V1
             bool eob = false;
             for (;;) {
                 b.settle(); o = uni(o); f = uni(f); fenced = uni(fenced); guard = uni(guard);
@@ -607,6 +628,161 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 }
                 if (eob) break;
             }
+#else
+            // ---- the block's symbols, a WINDOW of 64 bit offsets at a time: round 5's loop (MM_INFLATE_V1 builds round 4's, above).
+            // The kernel is bound by the NUMBER of instructions a wavefront issues (a SIMD issues one every four cycles whatever their kind:
+            // ~600 a window in round 4's loop, measured), so this loop is written to be short:
+            //   1. the compressed bytes around the reader's position stand in LDS as well (S.win, refilled with the registers' window every 256
+            //      bytes): a lane's 64 bits at ITS bit offset are one unaligned ds_read_b64 and a shift (round 4: ten lane reads, five scalar
+            //      and nine vector selects, two alignbits);
+            //   2. every lane decodes the TOKEN that would start at its offset (two table lookups for 64 candidates), without branches;
+            //   3. the chain of real tokens is WALKED by the scalar unit -- position -> readlane(next position), five scalar instructions a
+            //      token in a hand-written loop, no LDS trip (round 4 doubled pointers: four dependent rounds of three ds_bpermute);
+            //   4. where a token's bytes go is a prefix sum over the chain's lanes (DPP, no LDS);
+            //   5. phase A: every token whose source lies in front of the window's output -- literals, matches of up to 16 bytes that reach back
+            //      past everything the window writes -- writes at once: whole dwords in a loop, the last one to three bytes (a literal is that case)
+            //      behind it; a source further back than the ring holds is ONE unaligned dword load from global memory;
+            //   6. phase B: the others (a match that reads what the window writes, a long one, one that straddles the ring's end) in chain order,
+            //      all lanes on one match.  Round 4 ended a "step" at the first such match and ran the step's bookkeeping again for what was left.
+            // One exit for errors (`st`): early returns from the nest made the compiler build a state machine of scalar moves around it.
+            bool eob = false;
+            uint32_t win_at = 0xFFFFFFFFu;                 // the window position S.win holds
+            while (!eob && st == S_OK) {
+                b.settle(); o = uni(o); f = uni(f); fenced = uni(fenced); win_at = uni(win_at);
+                // a stream that ends in the middle of a symbol reads as zeros from there on: the reader stays within a window's bits of the payload's end
+                if (b.bitpos > 8ull * (uint64_t)c_len + 64ull) { st = S_OVERRUN_IN; break; }
+                if (o - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                (void)b.peek32();                                  // places the window: the position's byte lies in its first 256
+                if (b.wpos != win_at) { S.win[l] = b.va; S.win[64 + l] = b.vb; win_at = b.wpos; lds_sync(); }
+                const uint64_t base = b.bitpos;
+                const uint32_t rel = (uint32_t)(base - 8ull * (uint64_t)b.wpos) + (uint32_t)l;   // this lane's bit offset in the window (< 2048 + 64)
+                uint64_t raw;
+                __builtin_memcpy(&raw, reinterpret_cast<const uint8_t*>(S.win) + (rel >> 3), 8);
+                const uint64_t bits64 = raw >> (rel & 7u);         // 57 bits and more: a token is at most 10 + 5 + 8 + 13
+                const uint32_t e1 = expand_ll((uint32_t)S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)]);
+                const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
+                const uint32_t xl = (e1 >> 8) & 31u;
+                const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
+                const uint32_t used = l1 + xl;
+                const uint32_t dbits = (uint32_t)(bits64 >> used);
+                const uint32_t d = expand_d((uint32_t)S.dt[dbits & ((1u << kD) - 1u)]);
+                const uint32_t dl = d & 15u, xd = (d >> 8) & 31u;
+                const bool is_lit = l1 != 0u && k1 == (uint32_t)K_LIT;
+                const bool is_mat = l1 != 0u && k1 == (uint32_t)K_LEN && dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST;
+                const uint32_t t_dist = (d >> 16) + ((dbits >> dl) & ((1u << xd) - 1u));
+                const uint32_t t_val = is_lit ? e1 >> 16 : mlen;      // a literal's byte / a match's length
+                const uint32_t t_out = is_lit ? 1u : (is_mat ? mlen : 0u);
+                // the chain from the reader's position: lane p holds where the token at offset p ends (bit 7: no token there)
+                const uint32_t nx = is_lit ? (uint32_t)l + l1 : (is_mat ? (uint32_t)l + used + dl + xd : 0x80u);
+                uint32_t pos, last, nxt;
+                uint64_t chain;
+                asm volatile(
+                    "s_mov_b32 %[pos], 0\n\t"
+                    "s_mov_b64 %[chain], 0\n"
+                    "1:\n\t"
+                    "v_readlane_b32 %[nxt], %[nx], %[pos]\n\t"
+                    "s_bitset1_b64 %[chain], %[pos]\n\t"
+                    "s_mov_b32 %[last], %[pos]\n\t"
+                    "s_mov_b32 %[pos], %[nxt]\n\t"
+                    "s_cmp_lt_u32 %[nxt], 64\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    : [pos] "=&s"(pos), [chain] "=&s"(chain), [last] "=&s"(last), [nxt] "=&s"(nxt)
+                    : [nx] "v"(nx)
+                    : "scc");
+                if (nxt & 0x80u) { chain &= ~(1ull << last); pos = last; }     // the walk ended ON an offset that holds no token: the plain path's
+                if (chain) {
+                    const bool on_chain = (((l < 32 ? (uint32_t)chain : (uint32_t)(chain >> 32)) >> (l & 31)) & 1u) != 0u;
+                    const uint32_t my_out = on_chain ? t_out : 0u;
+                    const uint32_t incl = wave_incl_scan(my_out);
+                    const uint32_t off = incl - my_out;                // bytes the chain produces in front of this token
+                    // a window's parallel writes stay within 256 + 16 bytes of its start (the ring's near sources stay whole): what would go
+                    // further begins the next window
+                    const uint64_t cutm = __ballot(on_chain && off != 0u && off + t_out > 256u);
+                    const uint32_t first = cutm ? (uint32_t)__builtin_ctzll(cutm) : 64u;
+                    const bool mine = on_chain && (uint32_t)l < first;
+                    const uint32_t n_total = cutm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(first & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (cutm) pos = first;
+                    const bool is_m = mine && is_mat;
+                    const uint32_t at = o + off;
+                    if (o + n_total > isize) { st = S_OVERRUN_OUT; break; }
+                    if (__ballot(is_m && t_dist > at)) { st = S_BAD_DISTANCE; break; }
+                    const uint32_t src = at - t_dist;
+                    // phase B's: reads what the window writes / long / source or destination across the ring's end (phase A moves whole dwords)
+                    const bool far = t_dist > kNear;
+                    const bool defer = is_m && (t_dist < off + mlen || mlen > 16u || ((at & (kRing - 1u)) + mlen > kRing) || (!far && (src & (kRing - 1u)) + mlen > kRing));
+                    // a far source: flushed bytes, in global memory -- behind a fence if they were flushed since the last one
+                    if (__ballot(is_m && !defer && far && src + mlen > fenced)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
+                    lds_sync();   // (the bytes in front of the window are other lanes' stores)
+                    const uint32_t my_n = (mine && !defer) ? t_out : 0u;
+                    const bool use_far = far && is_mat;
+                    uint8_t* const rdst = S.ring + (at & (kRing - 1u));
+                    const uint8_t* const rsrc = S.ring + (src & (kRing - 1u));
+                    // phase A: whole dwords ...
+                    for (uint32_t i = 0; __ballot(i + 4u <= my_n); i += 4u) {
+                        if (i + 4u <= my_n) {
+                            uint32_t v;
+                            if (use_far) v = load_far(out + src + i); else v = *reinterpret_cast<const u32_unal*>(rsrc + i);
+                            *reinterpret_cast<u32_unal*>(rdst + i) = v;
+                        }
+                    }
+                    // ... then the last one to three bytes (a literal: its byte)
+                    {
+                        const uint32_t r = my_n & 3u, i = my_n & ~3u;
+                        if (r) {
+                            uint32_t v = t_val;
+                            if (is_mat) { if (use_far) v = load_far(out + src + i); else v = *reinterpret_cast<const u32_unal*>(rsrc + i); }
+                            if (r & 2u) *reinterpret_cast<u16_unal*>(rdst + i) = (uint16_t)v;
+                            if (r & 1u) rdst[i + (r & 2u)] = (uint8_t)(v >> (8u * (r & 2u)));
+                        }
+                    }
+                    // phase B: in chain order, all lanes on one match
+                    uint64_t dm = __ballot(defer);
+                    while (dm) {
+                        const int kk = (int)__builtin_ctzll(dm);
+                        dm &= dm - 1ull;
+                        const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, kk), bd = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, kk);
+                        const uint32_t a = o + (uint32_t)__builtin_amdgcn_readlane((int)off, kk);
+                        if (a - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                        copy_match(a, bl, bd);
+                    }
+                    o += n_total;
+                    b.bitpos = base + (uint64_t)pos;
+                    if (pos >= 64u || cutm) continue;            // the window is used up (or cut short)
+                }
+                // one token of the plain path at base + pos: the end of the block, a code longer than the first-level tables
+                b.bitpos = base + (uint64_t)pos;
+                uint32_t bits = b.peek32();
+                uint32_t e = expand_ll(uni((uint32_t)S.ll[bits & ((1u << kLL) - 1u)]));
+                if ((e & 15u) == 0u) { e = decode_long(b, S.cl_ll, false); if ((e & 15u) == 0u) { st = S_BAD_SYMBOL; break; } }
+                const uint32_t kind = (e >> 4) & 15u;
+                if (kind == K_LIT) {
+                    b.bitpos += e & 15u;
+                    if (o >= isize) { st = S_OVERRUN_OUT; break; }
+                    if (l == 0) S.ring[o & (kRing - 1u)] = (uint8_t)(e >> 16);
+                    o++;
+                } else if (kind == K_EOB) { b.bitpos += e & 15u; eob = true; }
+                else {
+                    // a match: length (extra bits behind the code), distance code, its extra bits
+                    bits >>= e & 15u;
+                    const uint32_t xl2 = (e >> 8) & 31u;
+                    const uint32_t len = (e >> 16) + (bits & ((1u << xl2) - 1u));
+                    b.bitpos += (e & 15u) + xl2;
+                    bits = b.peek32();
+                    uint32_t d2 = expand_d(uni((uint32_t)S.dt[bits & ((1u << kD) - 1u)]));
+                    if ((d2 & 15u) == 0u) { d2 = decode_long(b, S.cl_d, true); if ((d2 & 15u) == 0u) { st = S_BAD_DISTANCE; break; } }
+                    bits >>= d2 & 15u;
+                    const uint32_t xd2 = (d2 >> 8) & 31u;
+                    const uint32_t dist = (d2 >> 16) + (bits & ((1u << xd2) - 1u));
+                    b.bitpos += (d2 & 15u) + xd2;
+                    if (dist > o) { st = S_BAD_DISTANCE; break; }
+                    if (o + len > isize) { st = S_OVERRUN_OUT; break; }
+                    if (o - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+                    copy_match(o, len, dist);
+                    o = uni(o + len);
+                }
+            }
+            if (st != S_OK) return st;
+#endif
             if (b.overrun()) return S_OVERRUN_IN;
         }
         if (final_block) break;
