@@ -82,6 +82,28 @@ __device__ __forceinline__ uint32_t expand_d(uint32_t c) {
 }
 #endif
 
+// Round 5's loop looks a length / distance symbol's base and extra-bit count up in a table of the workgroup's (64 words: 0-28 the length
+// symbols, 32-61 the distance symbols, in the 32-bit entries' form without the code length) instead of computing them: the kernel is
+// bound by the instructions it issues, and the arithmetic above is twenty-five of them a window
+__device__ __forceinline__ void fill_xtab(uint32_t* xtab) {
+    const uint32_t t = threadIdx.x;
+    if (t < 64u) {
+        uint32_t e = 0;
+        if (t < 29u) e = ent(0, K_LEN, c_len_extra[t], c_len_base[t]);
+        else if (t >= 32u && t < 62u) e = ent(0, K_DIST, c_dist_extra[t - 32u], c_dist_base[t - 32u]);
+        xtab[t] = e;
+    }
+}
+__device__ __forceinline__ uint32_t expand_ll_t(uint32_t c, const uint32_t* xtab) {
+    const uint32_t len = c & 15u, k = (c >> 4) & 3u, v = c >> 6;
+    const uint32_t x = xtab[k == 1u ? v : 0u];
+    return len | (k == 0u ? v << 16 : (k == 1u ? x : (uint32_t)K_EOB << 4));
+}
+__device__ __forceinline__ uint32_t expand_d_t(uint32_t c, const uint32_t* xtab) {
+    const uint32_t x = xtab[32u + ((c >> 6) & 31u)];
+    return ((c >> 4) & 3u) == 3u ? ((c & 15u) | x) : 0u;
+}
+
 struct Block {            // one BGZF block of a launch
     uint32_t c_off;       // its deflate payload in the launch's compressed bytes
     uint32_t c_len;
@@ -117,14 +139,24 @@ __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_REL
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 // inclusive prefix sum over the 64 lanes: DPP row shifts inside each row of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 (no LDS trip)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-    return (uint32_t)x;
+    // (v_add_u32 with the DPP modifier on its first source: one instruction a step -- the builtin makes a v_mov_dpp and an add of it; a lane
+    // whose source does not exist adds 0, bound_ctrl:0; a VGPR written by the VALU can be read through DPP two wait states later)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
 }
 
 // ---- the bit reader: wave-uniform state, the bytes in two registers
@@ -380,7 +412,7 @@ __device__ __forceinline__ uint32_t load_far(const uint8_t* p) {
 }
 
 // ---- one block
-__device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, uint8_t* out, uint32_t isize, WaveLds& S) {
+__device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, uint8_t* out, uint32_t isize, WaveLds& S, const uint32_t* xtab) {
     const int l = lane();
     Bits b;
     b.start(in, c_len);
@@ -659,13 +691,21 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 uint64_t raw;
                 __builtin_memcpy(&raw, reinterpret_cast<const uint8_t*>(S.win) + (rel >> 3), 8);
                 const uint64_t bits64 = raw >> (rel & 7u);         // 57 bits and more: a token is at most 10 + 5 + 8 + 13
-                const uint32_t e1 = expand_ll((uint32_t)S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)]);
+#ifdef MM_INFLATE_U32
+                const uint32_t e1 = (uint32_t)S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)];
+#else
+                const uint32_t e1 = expand_ll_t((uint32_t)S.ll[(uint32_t)bits64 & ((1u << kLL) - 1u)], xtab);
+#endif
                 const uint32_t l1 = e1 & 15u, k1 = (e1 >> 4) & 15u;
                 const uint32_t xl = (e1 >> 8) & 31u;
                 const uint32_t mlen = (e1 >> 16) + ((uint32_t)(bits64 >> l1) & ((1u << xl) - 1u));
                 const uint32_t used = l1 + xl;
                 const uint32_t dbits = (uint32_t)(bits64 >> used);
-                const uint32_t d = expand_d((uint32_t)S.dt[dbits & ((1u << kD) - 1u)]);
+#ifdef MM_INFLATE_U32
+                const uint32_t d = (uint32_t)S.dt[dbits & ((1u << kD) - 1u)];
+#else
+                const uint32_t d = expand_d_t((uint32_t)S.dt[dbits & ((1u << kD) - 1u)], xtab);
+#endif
                 const uint32_t dl = d & 15u, xd = (d >> 8) & 31u;
                 const bool is_lit = l1 != 0u && k1 == (uint32_t)K_LIT;
                 const bool is_mat = l1 != 0u && k1 == (uint32_t)K_LEN && dl != 0u && ((d >> 4) & 15u) == (uint32_t)K_DIST;
@@ -708,29 +748,38 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     if (__ballot(is_m && t_dist > at)) { st = S_BAD_DISTANCE; break; }
                     const uint32_t src = at - t_dist;
                     // phase B's: reads what the window writes / long / source or destination across the ring's end (phase A moves whole dwords)
-                    const bool far = t_dist > kNear;
-                    const bool defer = is_m && (t_dist < off + mlen || mlen > 16u || ((at & (kRing - 1u)) + mlen > kRing) || (!far && (src & (kRing - 1u)) + mlen > kRing));
-                    // a far source: flushed bytes, in global memory -- behind a fence if they were flushed since the last one
-                    if (__ballot(is_m && !defer && far && src + mlen > fenced)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
+                    const bool far = t_dist > kNear;                   // a source further back than the ring holds: flushed bytes, in global memory
+                    const bool defer = is_m && (t_dist < off + mlen || mlen > 16u || (far && mlen > 4u) || ((at & (kRing - 1u)) + mlen > kRing) || (!far && (src & (kRing - 1u)) + mlen > kRing));
+                    const bool use_far = is_m && !defer && far;
+                    uint32_t fv = 0;
+                    if (__ballot(use_far)) {
+                        // (behind a fence if the bytes were flushed since the last one; ONE unaligned dword: nine matches in ten are of three or four bytes)
+                        if (__ballot(use_far && src + mlen > fenced)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); fenced = f; }
+#ifndef MM_ABL_NOFAR
+                        if (use_far) fv = load_far(out + src);
+#endif
+                    }
                     lds_sync();   // (the bytes in front of the window are other lanes' stores)
+#ifdef MM_ABL_NOA   // (diagnostic builds: wrong bytes, right amount of everything else)
+                    const uint32_t my_n = 0u;
+#else
                     const uint32_t my_n = (mine && !defer) ? t_out : 0u;
-                    const bool use_far = far && is_mat;
+#endif
                     uint8_t* const rdst = S.ring + (at & (kRing - 1u));
                     const uint8_t* const rsrc = S.ring + (src & (kRing - 1u));
                     // phase A: whole dwords ...
                     for (uint32_t i = 0; __ballot(i + 4u <= my_n); i += 4u) {
                         if (i + 4u <= my_n) {
-                            uint32_t v;
-                            if (use_far) v = load_far(out + src + i); else v = *reinterpret_cast<const u32_unal*>(rsrc + i);
-                            *reinterpret_cast<u32_unal*>(rdst + i) = v;
+                            const uint32_t rv = *reinterpret_cast<const u32_unal*>(rsrc + i);
+                            *reinterpret_cast<u32_unal*>(rdst + i) = use_far ? fv : rv;
                         }
                     }
                     // ... then the last one to three bytes (a literal: its byte)
                     {
                         const uint32_t r = my_n & 3u, i = my_n & ~3u;
                         if (r) {
-                            uint32_t v = t_val;
-                            if (is_mat) { if (use_far) v = load_far(out + src + i); else v = *reinterpret_cast<const u32_unal*>(rsrc + i); }
+                            const uint32_t rv = *reinterpret_cast<const u32_unal*>(rsrc + i);
+                            const uint32_t v = is_lit ? t_val : (use_far ? fv : rv);
                             if (r & 2u) *reinterpret_cast<u16_unal*>(rdst + i) = (uint16_t)v;
                             if (r & 1u) rdst[i + (r & 2u)] = (uint8_t)(v >> (8u * (r & 2u)));
                         }
@@ -743,7 +792,9 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                         const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, kk), bd = (uint32_t)__builtin_amdgcn_readlane((int)t_dist, kk);
                         const uint32_t a = o + (uint32_t)__builtin_amdgcn_readlane((int)off, kk);
                         if (a - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
+#ifndef MM_ABL_NOB
                         copy_match(a, bl, bd);
+#endif
                     }
                     o += n_total;
                     b.bitpos = base + (uint64_t)pos;
@@ -796,6 +847,9 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
 __global__ __launch_bounds__(64 * kWaves, 6) void k_bgzf_inflate(const uint8_t* __restrict__ cdata, const Block* __restrict__ blocks, int n_blocks,
                                                                  uint8_t* __restrict__ out, int32_t* __restrict__ status) {
     __shared__ WaveLds lds[kWaves];
+    __shared__ uint32_t xtab[64];
+    fill_xtab(xtab);
+    __syncthreads();
     extern __shared__ uint8_t occupancy_pad[];   // (dynamic LDS nobody touches: the launch asks for as much as keeps the workgroups per CU at what the host wants, inflate_wgs_per_cu)
     (void)occupancy_pad;
     WaveLds& S = lds[threadIdx.x >> 6];
@@ -804,7 +858,7 @@ __global__ __launch_bounds__(64 * kWaves, 6) void k_bgzf_inflate(const uint8_t* 
     for (int i = first; i < n_blocks; i += n_waves) {
         const uint32_t c_off = uni(blocks[i].c_off), c_len = uni(blocks[i].c_len), o_off = uni(blocks[i].o_off), isize = uni(blocks[i].isize);
         int st = S_OK;
-        if (isize) st = inflate_block(cdata + c_off, c_len, out + o_off, isize, S);
+        if (isize) st = inflate_block(cdata + c_off, c_len, out + o_off, isize, S, xtab);
         if (lane() == 0) status[i] = st;
     }
 }
