@@ -714,22 +714,43 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 const uint32_t t_out = is_lit ? 1u : (is_mat ? mlen : 0u);
                 // the chain from the reader's position: lane p holds where the token at offset p ends (bit 7: no token there)
                 const uint32_t nx = is_lit ? (uint32_t)l + l1 : (is_mat ? (uint32_t)l + used + dl + xd : 0x80u);
-                uint32_t pos, last, nxt;
+                // The window is worked off in SEGMENTS: the chain of tokens from `pos` on, then -- where the chain ends on an offset that holds no
+                // token -- that one symbol by the plain path (a long code, the end of the block), and on with the chain behind it.
+                uint32_t pos = 0;
+                bool next_window = false;
+                while (!next_window) {
+                pos = uni(pos); o = uni(o); f = uni(f); fenced = uni(fenced);
+                uint32_t nxt, tmp;
                 uint64_t chain;
+                // the walk: A -> B = readlane(nx, A) -> A = readlane(nx, B) ...; five instructions a token (a lane select that a lane read wrote
+                // wants four wait states).  Out: `chain` = the offsets visited that hold tokens, pos = the first offset not worked off
+                // (>= 64: the window is used up; below: no token there)
                 asm volatile(
-                    "s_mov_b32 %[pos], 0\n\t"
                     "s_mov_b64 %[chain], 0\n"
                     "1:\n\t"
                     "v_readlane_b32 %[nxt], %[nx], %[pos]\n\t"
                     "s_bitset1_b64 %[chain], %[pos]\n\t"
-                    "s_mov_b32 %[last], %[pos]\n\t"
-                    "s_mov_b32 %[pos], %[nxt]\n\t"
                     "s_cmp_lt_u32 %[nxt], 64\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_nop 0\n\t"
+                    "v_readlane_b32 %[pos], %[nx], %[nxt]\n\t"
+                    "s_bitset1_b64 %[chain], %[nxt]\n\t"
+                    "s_nop 0\n\t"
+                    "s_cmp_lt_u32 %[pos], 64\n\t"
                     "s_cbranch_scc1 1b\n\t"
-                    : [pos] "=&s"(pos), [chain] "=&s"(chain), [last] "=&s"(last), [nxt] "=&s"(nxt)
+                    "s_mov_b32 %[tmp], %[pos]\n\t"
+                    "s_mov_b32 %[pos], %[nxt]\n\t"
+                    "s_mov_b32 %[nxt], %[tmp]\n"
+                    "2:\n\t"                                    // pos = the last offset visited, nxt = what it holds
+                    "s_bitcmp1_b32 %[nxt], 7\n\t"
+                    "s_cbranch_scc0 3f\n\t"
+                    "s_bitset0_b64 %[chain], %[pos]\n\t"       // no token there: not of the chain, and where the plain path starts
+                    "s_mov_b32 %[nxt], %[pos]\n"
+                    "3:\n\t"
+                    "s_mov_b32 %[pos], %[nxt]"
+                    : [pos] "+s"(pos), [chain] "=&s"(chain), [nxt] "=&s"(nxt), [tmp] "=&s"(tmp)
                     : [nx] "v"(nx)
                     : "scc");
-                if (nxt & 0x80u) { chain &= ~(1ull << last); pos = last; }     // the walk ended ON an offset that holds no token: the plain path's
                 if (chain) {
                     const bool on_chain = (((l < 32 ? (uint32_t)chain : (uint32_t)(chain >> 32)) >> (l & 31)) & 1u) != 0u;
                     const uint32_t my_out = on_chain ? t_out : 0u;
@@ -797,8 +818,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
 #endif
                     }
                     o += n_total;
-                    b.bitpos = base + (uint64_t)pos;
-                    if (pos >= 64u || cutm) continue;            // the window is used up (or cut short)
+                    if (pos >= 64u || cutm) { next_window = true; break; }   // the window is used up (or cut short: the next one begins at the cut)
                 }
                 // one token of the plain path at base + pos: the end of the block, a code longer than the first-level tables
                 b.bitpos = base + (uint64_t)pos;
@@ -811,7 +831,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     if (o >= isize) { st = S_OVERRUN_OUT; break; }
                     if (l == 0) S.ring[o & (kRing - 1u)] = (uint8_t)(e >> 16);
                     o++;
-                } else if (kind == K_EOB) { b.bitpos += e & 15u; eob = true; }
+                } else if (kind == K_EOB) { b.bitpos += e & 15u; eob = true; break; }
                 else {
                     // a match: length (extra bits behind the code), distance code, its extra bits
                     bits >>= e & 15u;
@@ -831,6 +851,12 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     copy_match(o, len, dist);
                     o = uni(o + len);
                 }
+                b.settle();
+                pos = (uint32_t)(b.bitpos - base);
+                if (pos >= 64u) { next_window = true; break; }
+                }   // (segments)
+                if (st != S_OK) break;
+                if (!eob) b.bitpos = base + (uint64_t)pos;
             }
             if (st != S_OK) return st;
 #endif
