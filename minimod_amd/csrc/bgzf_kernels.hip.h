@@ -758,20 +758,27 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                     const uint32_t off = incl - my_out;                // bytes the chain produces in front of this token
                     // a window's parallel writes stay within 256 + 16 bytes of its start (the ring's near sources stay whole): what would go
                     // further begins the next window
-                    const uint64_t cutm = __ballot(on_chain && off != 0u && off + t_out > 256u);
-                    const uint32_t first = cutm ? (uint32_t)__builtin_ctzll(cutm) : 64u;
-                    const bool mine = on_chain && (uint32_t)l < first;
-                    const uint32_t n_total = cutm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(first & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (cutm) pos = first;
-                    const bool is_m = mine && is_mat;
+                    uint32_t n_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint64_t cutm = 0;
+                    bool mine = on_chain;
+                    if (n_total > 256u) {                                 // (a window in twelve: it holds a long match)
+                        cutm = __ballot(on_chain & (off != 0u) & (off + t_out > 256u));
+                        if (cutm) {
+                            const uint32_t first = (uint32_t)__builtin_ctzll(cutm);
+                            mine = on_chain & ((uint32_t)l < first);
+                            n_total = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)first);
+                            pos = first;
+                        }
+                    }
+                    const bool is_m = mine & is_mat;
                     const uint32_t at = o + off;
                     if (o + n_total > isize) { st = S_OVERRUN_OUT; break; }
                     if (__ballot(is_m && t_dist > at)) { st = S_BAD_DISTANCE; break; }
                     const uint32_t src = at - t_dist;
                     // phase B's: reads what the window writes / long / source or destination across the ring's end (phase A moves whole dwords)
                     const bool far = t_dist > kNear;                   // a source further back than the ring holds: flushed bytes, in global memory
-                    const bool defer = is_m && (t_dist < off + mlen || mlen > 16u || (far && mlen > 4u) || ((at & (kRing - 1u)) + mlen > kRing) || (!far && (src & (kRing - 1u)) + mlen > kRing));
-                    const bool use_far = is_m && !defer && far;
+                    const bool defer = is_m & ((t_dist < off + mlen) | (mlen > 16u) | (far & (mlen > 4u)) | ((at & (kRing - 1u)) + mlen > kRing) | (!far & ((src & (kRing - 1u)) + mlen > kRing)));   // (| and &: no branches)
+                    const bool use_far = is_m & !defer & far;
                     uint32_t fv = 0;
                     if (__ballot(use_far)) {
                         // (behind a fence if the bytes were flushed since the last one; ONE unaligned dword: nine matches in ten are of three or four bytes)
@@ -795,15 +802,13 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                             *reinterpret_cast<u32_unal*>(rdst + i) = use_far ? fv : rv;
                         }
                     }
-                    // ... then the last one to three bytes (a literal: its byte)
+                    // ... then the last one to three bytes (a literal: its byte).  Every lane reads (its address is a ring address whatever it holds)
                     {
                         const uint32_t r = my_n & 3u, i = my_n & ~3u;
-                        if (r) {
-                            const uint32_t rv = *reinterpret_cast<const u32_unal*>(rsrc + i);
-                            const uint32_t v = is_lit ? t_val : (use_far ? fv : rv);
-                            if (r & 2u) *reinterpret_cast<u16_unal*>(rdst + i) = (uint16_t)v;
-                            if (r & 1u) rdst[i + (r & 2u)] = (uint8_t)(v >> (8u * (r & 2u)));
-                        }
+                        const uint32_t rv = *reinterpret_cast<const u32_unal*>(rsrc + i);
+                        const uint32_t v = is_lit ? t_val : (use_far ? fv : rv);
+                        if (r & 2u) *reinterpret_cast<u16_unal*>(rdst + i) = (uint16_t)v;
+                        if (r & 1u) rdst[i + (r & 2u)] = (uint8_t)(v >> (8u * (r & 2u)));
                     }
                     // phase B: in chain order, all lanes on one match
                     uint64_t dm = __ballot(defer);
