@@ -96,7 +96,7 @@ __device__ __forceinline__ void fill_xtab(uint32_t* xtab) {
 }
 __device__ __forceinline__ uint32_t expand_ll_t(uint32_t c, const uint32_t* xtab) {
     const uint32_t len = c & 15u, k = (c >> 4) & 3u, v = c >> 6;
-    const uint32_t x = xtab[k == 1u ? v : 0u];
+    const uint32_t x = xtab[v & 31u];                       // (read whatever the entry is: no branch around it)
     return len | (k == 0u ? v << 16 : (k == 1u ? x : (uint32_t)K_EOB << 4));
 }
 __device__ __forceinline__ uint32_t expand_d_t(uint32_t c, const uint32_t* xtab) {
@@ -120,13 +120,16 @@ struct CodeLdsD {         // the same for the distance code (30 symbols)
     uint16_t cnt[16];
     uint16_t sorted[32];
 };
+#ifndef MM_RING
+#define MM_RING 2048   // bytes of a block's latest output kept in LDS (a power of two; build-time experiments: 4096)
+#endif
 struct WaveLds {
     tab_t ll[1 << kLL];   // compact entries (its first 128 are the code-length code's table while a block's code lengths are read)
     tab_t dt[1 << kD];
     CodeLds cl_ll;
     CodeLdsD cl_d;
     uint8_t lens[320];    // litlen lengths, then distance lengths
-    uint8_t ring[2048];   // the block's latest output (kRing)
+    uint8_t ring[MM_RING];   // the block's latest output (kRing)
     uint32_t win[128 + 4];   // round 5: the 512 compressed bytes around the reader's position (what Bits::va / vb hold), for the lanes' unaligned reads; the ring's over-read pad in front of it
 
 };
@@ -394,7 +397,7 @@ __device__ __noinline__ TablesRet read_tables(const uint8_t* in_, uint32_t c_len
 // source lies that near (nearly all of them) is an LDS copy; every kFlush bytes the ring's older half goes to global memory in
 // whole dwords.  Only a match that reaches further back reads global memory -- bytes flushed long before -- after a release
 // fence if they were flushed since the last one.
-constexpr uint32_t kRing = 2048, kFlush = 1024, kNear = kRing - 320;   // a match is at most 258 bytes: positions >= o - kNear are in the ring
+constexpr uint32_t kRing = MM_RING, kFlush = 1024, kNear = kRing - 320;   // a match is at most 258 bytes: positions >= o - kNear are in the ring
 __device__ __forceinline__ void ring_flush(uint8_t* out, const uint8_t* ring, uint32_t from, uint32_t upto) {   // from: a multiple of 4
     for (uint32_t i = from + 4u * (uint32_t)lane(); i < upto; i += 256u) {
         uint32_t w;
