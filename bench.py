@@ -470,9 +470,9 @@ def run_e2e_big(args):
         cli = os.path.join(ROOT, "minimod_amd", "bin", "minimod")
         cpu_cli = O.build_cpu_cli()
 
-        def run(cmd, out_path):
+        def run(cmd, out_path, env=None):
             t = time.perf_counter()
-            r = subprocess.run(cmd + ["-o", out_path, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            r = subprocess.run(cmd + ["-o", out_path, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             wall = time.perf_counter() - t
             if r.returncode != 0:
                 raise SystemExit("end-to-end run failed: %s\n%s" % (" ".join(cmd), r.stderr.decode(errors="replace")[-2000:]))
@@ -530,6 +530,18 @@ def run_e2e_big(args):
                     f.write(verr)
             res.setdefault("variants", {})[name.strip()] = {"flags": fl.strip(), "wall_s": vw, "wall_s_first_run": vruns[0][0], "value": bases / vw / 1e6, "stages_s": _stage_timers(verr),
                                                             "byte_identical_to_cpu": md5(ov) == md5(oc)}
+        # MM_E2E_ENV_VARIANTS="eager:MM_INGEST_EAGER_SLOTS=1": the same files and flags with other environment variables, three alternating
+        # pairs of runs (default, variant) on this box -- an A/B that box-to-box differences do not drown
+        for spec in [x for x in os.environ.get("MM_E2E_ENV_VARIANTS", "").split(";") if x.strip()]:
+            name, _, ev = spec.partition(":")
+            venv = dict(os.environ, **dict(kv.split("=", 1) for kv in ev.split()))
+            ov = os.path.join(tmp, "gpu_env.bed")
+            pairs = []
+            for _ in range(3):
+                wa, ea = run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, ov)
+                wb, eb = run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, ov, env=venv)
+                pairs.append({"default": {"wall_s": wa, "stages_s": _stage_timers(ea)}, name.strip(): {"wall_s": wb, "stages_s": _stage_timers(eb)}})
+            res.setdefault("env_variants", {})[name.strip()] = {"env": ev.strip(), "pairs": pairs, "byte_identical_to_cpu": md5(ov) == md5(oc)}
         if args.e2e_devices:
             # one BAM, N worker processes (csrc/host/freq_main.c run_devices: shares cut at 64 kb-aligned positions, every worker reads its share
             # through the index, counts on its GPU, hands its halo slab to the right-hand neighbour, formats its own section)

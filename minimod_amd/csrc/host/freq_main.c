@@ -606,6 +606,8 @@ static int32_t batch_index_in_file(const fopt_t *o, const char *bam_file, const 
     return at;
 }
 
+static void *free_ref_main(void *p) { mmh_free_ref((mmh_ref_t *)p); return NULL; }
+
 static int32_t batch_index_in_file_ctx(uint64_t ordinal, int32_t fallback) {
     if (!err_ctx.o) return fallback;
     return batch_index_in_file((const fopt_t *)err_ctx.o, err_ctx.bam, (const wspec_t *)err_ctx.ws, ordinal, fallback);
@@ -769,7 +771,14 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         if (!hv || (!tie && !dtie)) { MMH_ERROR("Assertion failed. %s", hv ? "out of memory" : err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     }
     free(ctg);
-    mmh_free_ref(ref);   /* the reference now lives in HBM */
+    {   /* the reference now lives in HBM: its host copy (hundreds of MB to unmap: 40 ms for a 400-Mb genome) is let go beside the first batches */
+        pthread_t ft;
+        pthread_attr_t fa;
+        pthread_attr_init(&fa);
+        pthread_attr_setdetachstate(&fa, PTHREAD_CREATE_DETACHED);
+        if (getenv("MM_FULL_TEARDOWN") || pthread_create(&ft, &fa, free_ref_main, ref) != 0) mmh_free_ref(ref);
+        pthread_attr_destroy(&fa);
+    }
     fprintf(stderr, "[%s] Reference contexts loaded in %.3f sec\n", __func__, mmh_realtime() - t2);
     if (use_dev) {
         if (bz_running == 2) pthread_join(bz_thread, NULL);
