@@ -270,6 +270,14 @@ def test_cli_view_devices_equal_a_single_run(genome, tmp_path):
         many = subprocess.run(base + ["--devices", devs, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert many.returncode == 0, many.stderr.decode()[-3000:]
         assert len(one.stdout) > 100000 and many.stdout == one.stdout
+    # round 5: view's workers read their shares with the device-side reader too (the read names come with the batches); small groups:
+    # several batches a worker, records carried from group to group
+    for devs, env in (("0,0", {}), ("0,0,0", {"MM_INGEST_MAX_BLOCKS": "8", "MM_INGEST_TARGET_BASES": "200000"})):
+        many = subprocess.run(base + ["--gpu-ingest", "--devices", devs, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+        assert many.returncode == 0, many.stderr.decode()[-3000:]
+        assert b"[gpu-ingest]" in many.stderr and many.stdout == one.stdout
+    single = subprocess.run(base + ["--gpu-ingest", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert single.returncode == 0 and b"[gpu-ingest]" in single.stderr and single.stdout == one.stdout
 
 
 def test_cli_devices_rejects_a_malformed_list(genome, tmp_path):
