@@ -124,6 +124,7 @@ struct mm_freq {
     // context classes and their site index (freq_kernels.hip.h, DevClass)
     int n_classes = 0;
     std::vector<int32_t> cls_of_mod;
+    std::vector<int> first_mod;               // per class: the first entry with its context string
     std::vector<DevClass> classes;
     std::vector<int64_t> adj;                 // [(tid * n_classes + class) * 2 + strand]
     std::vector<int> plane_cls, plane_slot;   // per code plane
@@ -132,6 +133,7 @@ struct mm_freq {
     unsigned int* d_slab_flag = nullptr;
     void* d_ipc_slab = nullptr;   // the slab another process reads through an IPC handle (mm_freq_slab_export_ipc): kept until the next one or the end
     DevMod* d_mods = nullptr;
+    DevMod* d_ctx_mods = nullptr;             // [n_classes]: the first entry of every context class (what the reference words' bits are built from)
     DevCode* d_codes = nullptr;
     std::vector<DevCode> codes;
     bool codes_dirty = false;
@@ -785,6 +787,7 @@ void mm_freq_destroy(mm_freq_t* h) {
                   h->d_stab, h->d_scount, h->d_scur, h->d_base_k, h->d_base_v, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (void* p : h->d_site_arrays) if (p) (void)hipFree(p);
+    if (h->d_ctx_mods) (void)hipFree(h->d_ctx_mods);
     if (h->d_classes) (void)hipFree(h->d_classes);
     if (h->d_cls_of_mod) (void)hipFree(h->d_cls_of_mod);
     if (h->d_adj) (void)hipFree(h->d_adj);
@@ -801,7 +804,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         return nullptr;
     };
     if (!opts || opts->abi_version != MM_ABI_VERSION) return fail(nullptr, "ABI version mismatch");
-    if (opts->n_mods < 1 || opts->n_mods > MM_MAX_MODS) return fail(nullptr, "n_mods out of range (1..13)");
+    if (opts->n_mods < 1 || opts->n_mods > MM_MAX_MODS) return fail(nullptr, "n_mods out of range (1..32)");
     if (n_contigs < 0 || (n_contigs > 0 && !contigs)) return fail(nullptr, "bad contig table");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device (the HIP path has no CPU fallback)");
@@ -824,7 +827,21 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         for (size_t j = 0; j < MM_CODE_LEN && c[j]; j++) if (!std::strchr("ACGT", c[j])) return false;
         return true;
     };
-    h->ref_kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 && plain_context() ? 0 : 1);
+    // context classes (ABI 6): entries with one context string share a class -- its two bits of the reference word, its site index, its
+    // counters side by side per site.  The word's width goes by the classes, so thirty-two entries over a handful of contexts fit
+    {
+        h->cls_of_mod.assign(opts->n_mods, 0);
+        h->first_mod.clear();
+        for (int i = 0; i < opts->n_mods; i++) {
+            int c = -1;
+            for (size_t k = 0; k < h->first_mod.size(); k++) if (std::strcmp(opts->mods[h->first_mod[k]].context, opts->mods[i].context) == 0) c = (int)k;
+            if (c < 0) { c = (int)h->first_mod.size(); h->first_mod.push_back(i); }
+            h->cls_of_mod[i] = c;
+        }
+        h->n_classes = (int)h->first_mod.size();
+        if (h->n_classes > MM_MAX_CONTEXTS) return fail(h, "more than 13 different contexts among the requested modifications (entries with the same context share its bits: their number is not limited by this)");
+    }
+    h->ref_kind = h->n_classes > 5 ? 2 : (opts->n_mods == 1 && plain_context() ? 0 : 1);
 #ifdef MM_KIND
     if (h->ref_kind != MM_KIND) return fail(h, "the handle's reference-word kind is another copy's (freq_dispatch.cpp picks the copy by the same rule)");
 #endif
@@ -940,6 +957,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_side, sizeof(SideRec) * (size_t)h->side_cap)) return fail(h, "side list alloc failed");
     if (dev_alloc(h, (void**)&h->d_side_count, sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemcpy(h->d_mods, mods.data(), sizeof(DevMod) * mods.size(), hipMemcpyHostToDevice);
+    {
+        std::vector<DevMod> cm((size_t)h->n_classes);
+        for (int c = 0; c < h->n_classes; c++) cm[(size_t)c] = mods[(size_t)h->first_mod[(size_t)c]];
+        if (dev_alloc(h, (void**)&h->d_ctx_mods, sizeof(DevMod) * cm.size())) return fail(h, "alloc failed");
+        (void)hipMemcpy(h->d_ctx_mods, cm.data(), sizeof(DevMod) * cm.size(), hipMemcpyHostToDevice);
+    }
     (void)hipMemset(h->d_side_count, 0, sizeof(unsigned long long));
     if (dev_alloc(h, (void**)&h->d_stats, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemset(h->d_stats, 0, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long));
@@ -1020,10 +1043,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 int64_t len = h->ctg_len[t];
                 if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "reference upload failed"); }
                 int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
+                // (bits 5 + 2c / 6 + 2c: class c's context, described by the class's first entry)
                 if (h->ref_kind == 2) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                                         (uint32_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                                                         (uint32_t*)h->d_refw + h->ref_base[t], h->d_ctx_mods, h->n_classes);
                 else if (h->ref_kind == 1) hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                                              (uint16_t*)h->d_refw + h->ref_base[t], h->d_mods, opts->n_mods);
+                                                              (uint16_t*)h->d_refw + h->ref_base[t], h->d_ctx_mods, h->n_classes);
                 else if (std::strlen(opts->mods[0].context) <= 4)
                     hipLaunchKernelGGL(k_build_refnibs<4>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
@@ -1038,15 +1062,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     // ---- context classes: mods with one context string share a class (their counters lie side by side per site); every position
     // is a site of a DENSE class: the context `*`, and any class under --insertions, where no context is looked at (mod.c:1167-1172)
     {
-        h->cls_of_mod.assign(opts->n_mods, 0);
-        std::vector<int> first_mod;   // per class: the mod whose reference-word bits mark its sites
-        for (int i = 0; i < opts->n_mods; i++) {
-            int c = -1;
-            for (size_t k = 0; k < first_mod.size(); k++) if (std::strcmp(opts->mods[first_mod[k]].context, opts->mods[i].context) == 0) c = (int)k;
-            if (c < 0) { c = (int)first_mod.size(); first_mod.push_back(i); }
-            h->cls_of_mod[i] = c;
-        }
-        h->n_classes = (int)first_mod.size();
+        const std::vector<int>& first_mod = h->first_mod;   // (the classes were made in front of the reference words: their bits are per class)
         h->classes.assign(h->n_classes, DevClass{});
         // code planes -> (class, slot): plane i belongs to mod i, or, with -c '*', every plane to the one `*` mod
         h->plane_cls.assign(h->n_code_planes, 0); h->plane_slot.assign(h->n_code_planes, 0);
@@ -1088,7 +1104,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 bool ok = true;
                 if (n_blocks > 0) {
                     const int blocks = (int)std::min<int64_t>((n_blocks + 255) / 256, (int64_t)h->n_cu * 16);
-                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, first_mod[c], (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
+                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, c, (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
                     for (int sd = 0; sd < 2 && ok; sd++) {
                         (void)hipMemsetAsync(tsum + n_tiles, 0, 4, h->stream);
                         hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum);

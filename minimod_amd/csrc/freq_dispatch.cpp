@@ -68,7 +68,15 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         bool plain = true;   // (freq_api.hip: four bits a position need a context made of A C G T, or `*`)
         const char* c = opts->mods[0].context;
         if (std::strcmp(c, "*") != 0) for (size_t j = 0; j < MM_CODE_LEN && c[j]; j++) if (!std::strchr("ACGT", c[j])) plain = false;
-        kind = opts->n_mods > 5 ? 2 : (opts->n_mods == 1 && plain ? 0 : 1);
+        // (the word's width goes by the DIFFERENT contexts: entries with one context string share its bits)
+        int n_ctx = 0;
+        const int nm = opts->n_mods < 0 ? 0 : (opts->n_mods > MM_MAX_MODS ? MM_MAX_MODS : opts->n_mods);
+        for (int i = 0; i < nm; i++) {
+            bool seen = false;
+            for (int j = 0; j < i; j++) if (std::strcmp(opts->mods[j].context, opts->mods[i].context) == 0) seen = true;
+            if (!seen) n_ctx++;
+        }
+        kind = n_ctx > 5 ? 2 : (opts->n_mods == 1 && plain ? 0 : 1);
     }
     mm_freq_t* impl = kind == 2 ? mm_freq_create_k2(opts, n_contigs, contigs, n_intervals, intervals, err, err_len)
                     : kind == 1 ? mm_freq_create_k1(opts, n_contigs, contigs, n_intervals, intervals, err, err_len)

@@ -364,6 +364,7 @@ __device__ __forceinline__ int nt16_code(int c) {
         case 'N': return 15; default: return 16;
     }
 }
+// (mods: one entry per context CLASS -- the class's first requested entry; bit 5 + 2c / 6 + 2c: inside a forward / reverse match of class c's context)
 __device__ __forceinline__ uint32_t ref_word_bits(const uint8_t* __restrict__ raw, int64_t len, int64_t p, const DevMod* __restrict__ mods, int n_mods) {
     uint32_t w = (uint32_t)nt16_code(norm_ref_char(raw[p]));
     for (int i = 0; i < n_mods; i++) {
@@ -881,7 +882,7 @@ struct K1 {
                 int req = dc.req;
                 const DevMod& dm = p.mods[req];
                 if (!p.insertions) {
-                    bool in_ctx = (w[u] >> (5 + 2 * req + c.rev)) & 1u;
+                    bool in_ctx = (w[u] >> (5 + 2 * p.cls_of_mod[req] + c.rev)) & 1u;   // (the bits are the context class's: entries with one context share them)
                     bool matches = dm.ctx_is_star || c.mb_is_N || refcode == code[u];
                     if (!(in_ctx && matches)) continue;
                 }
@@ -1287,8 +1288,8 @@ __global__ __launch_bounds__(256, 3) void k_freq_reads(const DevParams p) {
 }
 
 // ---------------------------------------------------------------------------------- site index (K0, second half)
-// which positions of the reference-word space are sites of a context class: bit (5 + 2 * mod) / (6 + 2 * mod) of the reference
-// words of the class's first mod (bits 2 / 3 of the four-bit words), 32 positions a word, and how many a block holds
+// which positions of the reference-word space are sites of a context class: bit (5 + 2 * class) / (6 + 2 * class) of the reference
+// words (bits 2 / 3 of the four-bit words), 32 positions a word, and how many a block holds
 template <typename RefWord>
 __global__ __launch_bounds__(256) void k_site_bits(const void* __restrict__ refw, int64_t n_blocks, int mod, int stride, uint2* __restrict__ fwd,
                                                    uint2* __restrict__ rev, uint32_t* __restrict__ cnt_fwd, uint32_t* __restrict__ cnt_rev) {

@@ -1252,7 +1252,7 @@ struct KF {
                         gflags = (unwanted ? 64u : 0u) | (g.flag == '.' ? 4u : 0u) | ((uint32_t)g.n << 12);
                         c01 = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
                         c23 = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
-                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | req << 19 |
+                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | context class << 19 |
                         // (slot of the code's counters among its context class's + 1, 0: no dense counters) << 23
                         const int cix = lane == 0u ? a0 : (lane == 1u ? a1 : (lane == 2u ? a2 : a3));
                         int kcls = -1;
@@ -1261,7 +1261,7 @@ struct KF {
                             const int req = dc.req, plane = dc.plane;
                             const DevMod& dm = p.mods[req];
                             kcls = p.cls_of_mod[req];
-                            ci_w = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)req << 19) |
+                            ci_w = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)p.cls_of_mod[req] << 19) |
                                    ((uint32_t)(plane >= 0 ? dc.slot + 1 : 0) << 23);
                         }
                         // the requested codes of a group share one context class here (one site word answers for all of them)

@@ -10,8 +10,8 @@ import numpy as np
 
 from .build import build_hip, lib_path
 
-MM_ABI_VERSION = 5
-MM_MAX_MODS = 13
+MM_ABI_VERSION = 6
+MM_MAX_MODS = 32
 MM_CODE_LEN = 16
 
 READ_DTYPE = np.dtype([

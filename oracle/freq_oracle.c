@@ -57,7 +57,7 @@ enum {
     ORC_E_READPOS = 10, ORC_E_MLIDX = 11, ORC_E_NOCONTIG = 12, ORC_E_REFPOS = 13, ORC_E_QOVER = 14
 };
 
-#define MAX_MODS 16
+#define MAX_MODS 64   /* (array sizes of this restatement: the reference counts its entries in a byte, src/minimod.h:114) */
 #define MAX_CODES 256
 #define CODE_LEN 32
 

@@ -398,3 +398,33 @@ def test_cli_view_names_a_failing_read_with_the_device_reader(tmp_path):
         for ing in ("--gpu-ingest", "--no-gpu-ingest"):
             r = subprocess.run([BIN, "view", ing] + extra + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
             assert r.returncode == 1 and b"Hard clipping found in " + want + b" (contig chrT, pos 2)" in r.stderr, (ing, extra, r.stderr.decode()[-1500:])
+
+
+def test_cli_takes_more_than_thirteen_entries(fastas, chr22):
+    """ABI 6: 32 -c entries over at most 13 different contexts (the reference has no limit, src/minimod.h:114; rounds 1 - 4 stopped at 13).
+    Eighteen entries over three contexts on the reference's ONT example: the rows of the oracle, and the reference's tie order from the
+    device-side replay byte for byte what the host's serial restatement prints; a 33rd entry and a 14th context are refused with a message"""
+    from oracle import oracle as O
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    codes = ["m", "h", "a", "21839", "76792", "b", "c", "d", "e", "f", "g", "i", "j", "k", "l", "n", "o", "p"]
+    ctxs = ["CG", "A", "*"]
+    c = ",".join("%s[%s]" % (x, ctxs[i % 3]) for i, x in enumerate(codes))
+    m = ",".join(["0.8", "0.7", "0.5"][i % 3] for i in range(len(codes)))
+    base = [BIN, "freq", "-c", c, "-m", m]
+    tail = [fastas["chr22"], bam]
+    r = subprocess.run(base + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"on the device" in r.stderr
+    rh = subprocess.run(base + ["--host-replay"] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert rh.returncode == 0 and rh.stdout == r.stdout
+    rows, names, wcodes = O.freq(bam, chr22, c=c, m=m)
+    want = O.format_rows(rows, names, wcodes)
+    assert len(want) > 50000 and sorted(r.stdout.decode().splitlines()) == sorted(want.splitlines())
+    rb = subprocess.run(base + ["-b", "--gpu-ingest"] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)   # (bedmethyl: the m rows only)
+    assert rb.returncode == 0 and sorted(rb.stdout.decode().splitlines()) == sorted(O.format_rows(rows, names, wcodes, bedmethyl=True).splitlines())
+    too_many = ",".join("%d[CG]" % (1000 + i) for i in range(33))
+    r33 = subprocess.run([BIN, "freq", "-c", too_many] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r33.returncode == 1 and b"At most 32 modification codes" in r33.stderr
+    ctx14 = ["CG", "A", "C", "CT", "CC", "T", "G", "AC", "GC", "TA", "CA", "GG", "TT", "AG"]
+    r14 = subprocess.run([BIN, "freq", "-c", ",".join("%d[%s]" % (1000 + i, x) for i, x in enumerate(ctx14))] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r14.returncode == 1 and b"different contexts" in r14.stderr

@@ -625,3 +625,42 @@ def test_twin_groups_with_too_few_ml_bytes():
         with pytest.raises(minimod_amd.MinimodHipError) as he:
             hip_rows(recs, ref, "m,h", stream_mode=mode)
         assert (he.value.code, he.value.read) == (11, 3), mode
+
+
+# ---- ABI 6: up to 32 -c entries; entries with one context string share its bits of the reference word (13 DIFFERENT contexts at most)
+def _entries(codes, contexts):
+    return ",".join("%s[%s]" % (c, contexts[i % len(contexts)]) for i, c in enumerate(codes))
+
+
+MANY_CODES = ["m", "h", "x", "a", "21839", "76792", "b", "c", "d", "e", "f", "g", "i", "j", "k", "l", "n", "o", "p", "q", "r", "s", "t", "u", "v", "w", "y", "z", "17802", "19228", "27301", "1"]
+
+
+@pytest.mark.parametrize("n_entries,contexts", [(14, ["CG", "A", "*"]), (20, ["CG", "A", "*", "C", "CA"]), (32, ["CG", "A", "*", "C", "CA", "CT", "T", "G"]),
+                                                (16, ["CG"]), (32, ["*"]), (13, ["CG", "A", "*", "C", "CT", "CC", "T", "G", "AC", "GC", "TA", "CA", "GG"])],
+                         ids=["14x3", "20x5", "32x8", "16x1", "32xstar", "13x13"])
+def test_more_than_thirteen_entries(n_entries, contexts):
+    """The reference takes any number of -c entries (src/minimod.h:114); rounds 1 - 4 took 13 -- two context bits an entry in a 32-bit reference
+    word.  Since ABI 6 the bits belong to the context STRING: 32 entries, 13 different contexts.  Mixed reads (groups on every base, one or
+    two codes a group, all three flags) and regular ones, through the stream kernel, the tile pipeline and the fused kernel, against the oracle --
+    with three, five (16-bit words), eight (32-bit words) and thirteen contexts"""
+    rng = np.random.default_rng(4100 + n_entries)
+    ref = make_ref(rng, 200000)
+    recs = [_random_read(rng, ref, 16 if rng.random() < 0.5 else 0) for _ in range(40)] + [_mixed_read(rng, ref) for _ in range(80)]
+    c = _entries(MANY_CODES[:n_entries], contexts)
+    both_ways(recs, ref, c)
+    # a permutation of the entries: the same rows (code indices follow the entries, the context bits follow the contexts)
+    perm = list(rng.permutation(n_entries))
+    c2 = ",".join(c.split(",")[i] for i in perm)
+    assert sorted(oracle_rows(recs, ref, c2)) == sorted(hip_rows(recs, ref, c2)[0])
+
+
+def test_more_than_thirteen_contexts_are_refused():
+    from minimod_amd.engine import MinimodHipError
+    rng = np.random.default_rng(5)
+    ref = make_ref(rng, 100000)
+    ctx = ["CG", "A", "C", "CT", "CC", "T", "G", "AC", "GC", "TA", "CA", "GG", "TT", "AG"]
+    with pytest.raises(MinimodHipError) as e:
+        hip_rows([_random_read(rng, ref, 0)], ref, _entries(MANY_CODES[:14], ctx))
+    assert "different contexts" in str(e.value)
+    with pytest.raises(Exception):
+        hip_rows([_random_read(rng, ref, 0)], ref, _entries(MANY_CODES + ["2"], ["CG"]))   # 33 entries
