@@ -192,11 +192,16 @@ struct Bits {
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)(wi & 63u)), y = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)(wi & 63u));
         return wi < 64u ? x : y;
     }
-    // the next 32 bits (the stream's later bits in the higher positions)
-    __device__ __forceinline__ uint32_t peek32() {
+    // the window follows the position: its byte lies in the window's first 256
+    __device__ __forceinline__ void place() {
         const uint32_t byte = (uint32_t)(bitpos >> 3);
         if (byte - wpos >= 512u) { wpos = byte & ~255u; va = load_win(wpos); vb = load_win(wpos + 256u); }   // (behind a stored block)
         else if (byte - wpos >= 256u) { va = vb; wpos += 256u; vb = load_win(wpos + 256u); }
+    }
+    // the next 32 bits (the stream's later bits in the higher positions)
+    __device__ __forceinline__ uint32_t peek32() {
+        place();
+        const uint32_t byte = (uint32_t)(bitpos >> 3);
         const uint32_t rel = byte - wpos, wi = rel >> 2;
         const uint64_t w = (uint64_t)dword_at(wi) | ((uint64_t)dword_at(wi + 1u) << 32);
         return (uint32_t)(w >> ((rel & 3u) * 8u + (uint32_t)(bitpos & 7u)));
@@ -687,7 +692,7 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 // a stream that ends in the middle of a symbol reads as zeros from there on: the reader stays within a window's bits of the payload's end
                 if (b.bitpos > 8ull * (uint64_t)c_len + 64ull) { st = S_OVERRUN_IN; break; }
                 if (o - f >= kFlush + 256u) { lds_sync(); ring_flush(out, S.ring, f, f + kFlush); f += kFlush; }
-                (void)b.peek32();                                  // places the window: the position's byte lies in its first 256
+                b.place();                                         // the window: the position's byte lies in its first 256
                 if (b.wpos != win_at) { S.win[l] = b.va; S.win[64 + l] = b.vb; win_at = b.wpos; lds_sync(); }
                 const uint64_t base = b.bitpos;
                 const uint32_t rel = (uint32_t)(base - 8ull * (uint64_t)b.wpos) + (uint32_t)l;   // this lane's bit offset in the window (< 2048 + 64)
@@ -938,7 +943,18 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ ou
         const uint32_t a = min((uint32_t)l * per, bk.isize), e = min(a + per, bk.isize);
         const uint8_t* p = out + bk.o_off;
         uint32_t c = l == 0 ? 0xFFFFFFFFu : 0u;
-        for (uint32_t j = a; j < e; j++) c = tab[(c ^ p[j]) & 255u] ^ (c >> 8);
+        // (a dword a load: a lane walks its own kilobyte, and with a byte a load a launch of 6 144 blocks kept 50 MB of half-read lines in
+        // flight -- 57 GB/s against 215 in launches of 2 048)
+        uint32_t j = a;
+        for (; j + 4u <= e; j += 4u) {
+            uint32_t w;
+            __builtin_memcpy(&w, p + j, 4);
+            c = tab[(c ^ w) & 255u] ^ (c >> 8);
+            c = tab[(c ^ (w >> 8)) & 255u] ^ (c >> 8);
+            c = tab[(c ^ (w >> 16)) & 255u] ^ (c >> 8);
+            c = tab[(c ^ (w >> 24)) & 255u] ^ (c >> 8);
+        }
+        for (; j < e; j++) c = tab[(c ^ p[j]) & 255u] ^ (c >> 8);
         // the register of slice l has bk.isize - e bytes behind it
         uint32_t v = gf_mul(gf_x8n(bk.isize - e, x2n), c);
         if (bk.isize - e == 0u) v = c;
