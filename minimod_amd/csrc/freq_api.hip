@@ -183,6 +183,12 @@ namespace {
         }                                                                                              \
     } while (0)
 
+// a slot's own stream (launches of host batches, and of device batches whose caller names none): made at its first use
+static hipStream_t slot_stream(mm_freq* h, Slot& s) {
+    if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return h->stream; }
+    return s.stream;
+}
+
 int dev_alloc(mm_freq* h, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
@@ -847,6 +853,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
 #endif
     const double tl_a0 = tl_now();
     double tl_a1 = tl_a0;
+    double tl_last = tl_a0;
+    auto tl_step = [&](const char* what) { if (tl_on) { const double t = tl_now(); std::fprintf(stderr, "[timeline] mm_freq_create:   %-44s %.3f s\n", what, t - tl_last); tl_last = t; } };
     {
         int nb = 0;
         hipError_t e = hipSuccess;
@@ -875,6 +883,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->stream_blocks_per_cu_dot = nfd > 0 ? std::min(nfd, 8) : 4;
         h->stream_blocks_per_cu_dot_ins = h->stream_blocks_per_cu_dot;   // (one of the two is this handle's: `plain` says which)
         tl_a1 = tl_now();
+        tl_step("occupancy queries");
 #ifdef MM_STREAM_GRID_BLOCKS   // experiment: fewer resident workgroups per CU
         h->stream_blocks_per_cu = std::min(h->stream_blocks_per_cu, MM_STREAM_GRID_BLOCKS);
         h->stream_blocks_per_cu_dot = std::min(h->stream_blocks_per_cu_dot, MM_STREAM_GRID_BLOCKS);
@@ -883,7 +892,8 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
     for (auto& s : h->slots) {
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return fail(h, "stream create failed");
+        // (s.stream: made when a launch first asks for it -- slot_stream(); a caller that brings its own stream, like the device-side reader's
+        // chain stream, never does, and a stream is 8 - 10 ms of the process's start)
         if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming) != hipSuccess) return fail(h, "event create failed");
         if (dev_alloc(h, (void**)&s.d_ctl, 2 * kCtlSetWords * sizeof(unsigned int))) return fail(h, "alloc failed");
@@ -901,6 +911,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 return fail(h, "pinned alloc failed");
         }
     }
+    tl_step("streams, events, control words of the slots");
     // ---- mods / codes
     std::vector<DevMod> mods(opts->n_mods);
     h->wildcard = -1;
@@ -952,6 +963,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         if (side_table_clear(h) != 0) return fail(h, "side list init failed");
         h->side_possible = !opts->view && (opts->insertions || opts->haplotypes || h->wildcard >= 0 || n_intervals > 0);
     }
+    tl_step("side lists (alloc + clear)");
     if (dev_alloc(h, (void**)&h->d_mods, sizeof(DevMod) * mods.size())) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_codes, sizeof(DevCode) * MM_MAX_CODES)) return fail(h, "alloc failed");
     if (dev_alloc(h, (void**)&h->d_side, sizeof(SideRec) * (size_t)h->side_cap)) return fail(h, "side list alloc failed");
@@ -967,6 +979,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     if (dev_alloc(h, (void**)&h->d_stats, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long))) return fail(h, "alloc failed");
     (void)hipMemset(h->d_stats, 0, (16 + 4 * (size_t)kStatSlots) * sizeof(unsigned long long));
     h->codes_dirty = !h->codes.empty();
+    tl_step("mods, codes, stats");
     // ---- contigs: reference words for every contig that has a sequence; counter segments
     h->n_contigs = n_contigs;
     h->names.resize(n_contigs);
@@ -1030,6 +1043,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         (void)hipMemcpy(h->d_seg_len, h->seg_len.data(), tb, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_cnt_base, h->cnt_base.data(), tb, hipMemcpyHostToDevice);
     }
+    tl_step("reference words' buffer + contig tables");
     const double tl_b = tl_now();
     // K0 per contig through a staging buffer
     {
@@ -1221,7 +1235,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     if (gather && h->pending_slot >= 0 && !h->pending_host && !h->codes_dirty) {   // (a code interned since the group began: the table is uploaded before a launch's FIRST window, so the group ends here)
         // does this submit continue the gathered group?  (windows of one resident read set, one after the other)
         const mm_batch_t& g = h->pending_batch;
-        hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->slots[h->pending_slot].stream;
+        hipStream_t st = hip_stream ? (hipStream_t)hip_stream : slot_stream(h, h->slots[h->pending_slot]);
         if (b->cigar == g.cigar && b->seq == g.seq && b->mm == g.mm && b->ml == g.ml && b->reads == g.reads + g.n_reads &&
             b->n_cigar_words == g.n_cigar_words && b->n_seq_bytes == g.n_seq_bytes && b->n_mm_bytes == g.n_mm_bytes &&
             b->n_ml_bytes == g.n_ml_bytes && st == h->pending_stream && (int64_t)g.n_reads + b->n_reads < (1 << 24)) {
@@ -1237,7 +1251,7 @@ int32_t mm_freq_submit_device(mm_freq_t* h, const mm_batch_t* b, void* hip_strea
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s.stream;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : slot_stream(h, s);
     // all slots of the handle share the code table; make sure it is current (sync only when it changed)
     int r = upload_codes(h, st);
     if (r) return r;
@@ -1262,7 +1276,7 @@ int32_t mm_freq_submit_device_now(mm_freq_t* h, const mm_batch_t* b, void* hip_s
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s.stream;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : slot_stream(h, s);
     int r = upload_codes(h, st);
     if (r) return r;
     r = launch_k1(h, s, b, st, bases);
@@ -1308,7 +1322,7 @@ static int32_t submit_host_gathered(mm_freq* h, const mm_batch_t* hb) {
         const int si = acquire_slot(h);
         if (h->sticky_err) return -h->sticky_err;
         Slot& s = h->slots[si];
-        int r = upload_codes(h, s.stream);
+        int r = upload_codes(h, slot_stream(h, s));
         if (r) return r;
         // staging for as many batches like this one as may be gathered, within the budget
         const size_t budget = (size_t)(h->opts.gather_mb > 0 ? h->opts.gather_mb : 1024) << 20;
@@ -1319,13 +1333,13 @@ static int32_t submit_host_gathered(mm_freq* h, const mm_batch_t* hb) {
             (r = grow(h, &s.d_ml, &s.cap_ml, f * (hb->n_ml_bytes + 16))))
             return r;
         s.fill_reads = s.fill_cigar = s.fill_seq = s.fill_mm = s.fill_ml = 0;
-        h->pending_slot = si; h->pending_members = 0; h->pending_stream = s.stream; h->pending_host = true; h->pending_bases = 0;
+        h->pending_slot = si; h->pending_members = 0; h->pending_stream = slot_stream(h, s); h->pending_host = true; h->pending_bases = 0;
         std::memset(&h->pending_batch, 0, sizeof h->pending_batch);
         s.busy = true; s.timed = false; s.members = 1;
     }
     const int si = h->pending_slot;
     Slot& s = h->slots[si];
-    hipStream_t st = s.stream;
+    hipStream_t st = slot_stream(h, s);
     { int r = copy_host_batch(h, s, hb, st, s.fill_reads, s.fill_cigar, s.fill_seq, s.fill_mm, s.fill_ml); if (r) return r; }
     if (s.fill_reads) {   // (the group's first batch lies at offset 0)
         hipLaunchKernelGGL(k_rebase_reads, dim3((unsigned)((hb->n_reads + 255) / 256)), dim3(256), 0, st, (mm_read_t*)s.d_reads + s.fill_reads, hb->n_reads,
@@ -1362,7 +1376,7 @@ int32_t mm_freq_submit(mm_freq_t* h, const mm_batch_t* hb) {
     int si = acquire_slot(h);
     if (h->sticky_err) return -h->sticky_err;
     Slot& s = h->slots[si];
-    hipStream_t st = s.stream;
+    hipStream_t st = slot_stream(h, s);
     int r = upload_codes(h, st);
     if (r) return r;
     size_t nr = sizeof(mm_read_t) * (size_t)hb->n_reads;
