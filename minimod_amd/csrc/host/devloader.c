@@ -82,6 +82,7 @@ static void stage_group(mmh_devloader_t *dl, int slot, ginfo_t *g) {
     uint8_t *st = mm_ingest_staging(dl->ing, slot);
     mm_bgzf_block_t *rec = mm_ingest_blocks(dl->ing, slot);
     memset(g, 0, sizeof *g);
+    if (!st || !rec) { g->err = 2; g->last = 1; return; }   /* (the slot's buffers could not be made) */
     const uint64_t left = dl->file_size - dl->file_pos;
     /* the window: what max_blocks blocks of the last group's size take (+ 2 % and a block), so that little is read twice */
     size_t want = cap;

@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ingest_kernels.hip.h"
@@ -29,6 +32,7 @@ struct GSlot {
     int n_blocks = 0; size_t cbytes = 0, obytes = 0;
     uint64_t seq = 0;                // the group's number
     bool inflating = false, flattening = false, timed = false;
+    std::atomic<int> ready{0};       // 0: its buffers are still being made (the slots behind the first: on a thread of their own), 1: made, -1: could not be
 };
 struct Arena {
     mm_read_t* reads = nullptr; uint8_t *cigar = nullptr, *seq = nullptr, *mm = nullptr, *ml = nullptr;
@@ -49,9 +53,60 @@ struct mm_ingest {
     uint8_t* d_tail[2] = {nullptr, nullptr};
     uint64_t next_seq = 0;         // groups numbered by mm_ingest_inflate
     uint64_t flat_seq = 0;         // the next group to be flattened for the first time
+    int prio_least = 0;
+    std::thread slot_maker;        // makes the slots behind the first while the caller's reader stages its first group
     CodeTab* d_codes = nullptr;    // mm_ingest_batch_codes (made at its first call)
     CodeTab* h_codes = nullptr;    // pinned
 };
+
+static hipError_t slot_alloc(mm_ingest* h, GSlot& s) {
+#define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+    const size_t nb1 = (size_t)h->o.max_blocks + 1;
+    SCHK(hipSetDevice(h->device));
+    // the lowest priority: the inflate's workgroups run for milliseconds; the chain's and the freq path's kernels get the CUs they leave first
+    // (a stream with a CU mask that keeps the inflate off a few CUs -- hipExtStreamCreateWithCUMask -- hung the first launch on this
+    // pool's boxes: not used.  Instead the inflate's workgroups are sized so that four of them leave room on every CU, below.)
+    SCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, h->prio_least));
+    for (auto& e : s.ev) SCHK(hipEventCreate(&e));
+    SCHK(hipEventCreate(&s.ev_f0)); SCHK(hipEventCreate(&s.ev_done));
+    SCHK(hipHostMalloc((void**)&s.h_c, h->o.max_cbytes + 64, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&s.h_result, sizeof(Result), hipHostMallocDefault));
+    SCHK(hipMalloc((void**)&s.d_c, h->o.max_cbytes + 4096));   // (readable bytes behind the payloads: the inflate's window runs ahead)
+    SCHK(hipMemset(s.d_c, 0, h->o.max_cbytes + 4096));
+    SCHK(hipMalloc((void**)&s.d_out, (size_t)h->H + h->max_obytes + 256));
+    SCHK(hipMemset(s.d_out + (size_t)h->H + h->max_obytes, 0, 256));
+    SCHK(hipMalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)h->o.max_blocks));
+    SCHK(hipMalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)h->o.max_blocks));
+    SCHK(hipMalloc((void**)&s.d_tab, 6 * nb1 * sizeof(uint32_t)));
+    SCHK(hipMalloc((void**)&s.d_rec_off, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(hipMalloc((void**)&s.d_acc, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(hipMalloc((void**)&s.d_info, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(hipMalloc((void**)&s.d_desc, sizeof(Desc) * (size_t)h->max_records));
+    SCHK(hipMalloc((void**)&s.d_result, sizeof(Result)));
+    return hipSuccess;
+#undef SCHK
+}
+
+// A process that leaves through exit() while a handle's slot maker is still inside the HIP runtime would tear the runtime down under it:
+// the makers of the live handles are waited for first (an atexit handler registered behind the runtime's own runs in front of it).
+static std::mutex g_live_mu;
+static std::vector<mm_ingest*> g_live;
+static void join_slot_makers() {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (mm_ingest* h : g_live) if (h->slot_maker.joinable()) h->slot_maker.join();
+}
+static void live_add(mm_ingest* h) {
+    static bool registered = false;
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!registered) { std::atexit(join_slot_makers); registered = true; }
+    g_live.push_back(h);
+}
+static void live_remove(mm_ingest* h) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), h), g_live.end());
+}
 
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::snprintf(err ? err : dummy, err ? err_len : sizeof dummy, "%s: %s", #x, hipGetErrorString(e_)); mm_ingest_destroy(h); return nullptr; } } while (0)
 #define RCHK(x) do { if ((x) != hipSuccess) return -MM_INGEST_E_HIP; } while (0)
@@ -112,32 +167,12 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     ICHK(hipMemset(h->d_cursor, 0, 2 * sizeof(Cursor)));
     for (int k = 0; k < 2; k++) ICHK(hipMalloc((void**)&h->d_tail[k], h->H));
     const double t1 = now();
-    h->slots.resize((size_t)h->o.group_slots);
-    const size_t nb1 = (size_t)h->o.max_blocks + 1;
-    for (GSlot& s : h->slots) {
-        // the lowest priority: the inflate's workgroups run for milliseconds; the chain's and the freq path's kernels get the CUs they leave first
-        // (a stream with a CU mask that keeps the inflate off a few CUs -- hipExtStreamCreateWithCUMask -- hung the first launch on this
-        // pool's boxes: not used.  Instead the inflate's workgroups are sized so that four of them leave room on every CU, below.)
-        ICHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_least));
-        for (auto& e : s.ev) ICHK(hipEventCreate(&e));
-        ICHK(hipEventCreate(&s.ev_f0)); ICHK(hipEventCreate(&s.ev_done));
-        ICHK(hipHostMalloc((void**)&s.h_c, h->o.max_cbytes + 64, hipHostMallocDefault));
-        ICHK(hipHostMalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
-        ICHK(hipHostMalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
-        ICHK(hipHostMalloc((void**)&s.h_result, sizeof(Result), hipHostMallocDefault));
-        ICHK(hipMalloc((void**)&s.d_c, h->o.max_cbytes + 4096));   // (readable bytes behind the payloads: the inflate's window runs ahead)
-        ICHK(hipMemset(s.d_c, 0, h->o.max_cbytes + 4096));
-        ICHK(hipMalloc((void**)&s.d_out, (size_t)h->H + h->max_obytes + 256));
-        ICHK(hipMemset(s.d_out + (size_t)h->H + h->max_obytes, 0, 256));
-        ICHK(hipMalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)h->o.max_blocks));
-        ICHK(hipMalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)h->o.max_blocks));
-        ICHK(hipMalloc((void**)&s.d_tab, 6 * nb1 * sizeof(uint32_t)));
-        ICHK(hipMalloc((void**)&s.d_rec_off, sizeof(uint32_t) * (size_t)h->max_records));
-        ICHK(hipMalloc((void**)&s.d_acc, sizeof(uint32_t) * (size_t)h->max_records));
-        ICHK(hipMalloc((void**)&s.d_info, sizeof(uint32_t) * (size_t)h->max_records));
-        ICHK(hipMalloc((void**)&s.d_desc, sizeof(Desc) * (size_t)h->max_records));
-        ICHK(hipMalloc((void**)&s.d_result, sizeof(Result)));
-    }
+    h->slots = std::vector<GSlot>((size_t)h->o.group_slots);
+    h->prio_least = prio_least;
+    // the FIRST slot here; the others (48 MiB of pinned staging and ~230 MB of device memory each: 25 - 40 ms) on a thread of their own, beside the
+    // arenas below, the caller's handle set-up and the reader's first group -- mm_ingest_staging waits for a slot that is not made yet
+    ICHK(slot_alloc(h, h->slots[0]));
+    h->slots[0].ready.store(1);
     const double t2 = now();
     h->arenas.resize((size_t)h->o.arenas);
     for (Arena& a : h->arenas) {
@@ -162,6 +197,10 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
             ICHK(hipMalloc((void**)&a.name_off, sizeof(uint64_t) * a.cap_reads));
         }
     }
+    live_add(h);
+    if (h->slots.size() > 1) h->slot_maker = std::thread([h]() {
+        for (size_t i = 1; i < h->slots.size(); i++) h->slots[i].ready.store(slot_alloc(h, h->slots[i]) == hipSuccess ? 1 : -1);
+    });
     ICHK(hipDeviceSynchronize());
     if (tl) std::fprintf(stderr, "[timeline] mm_ingest_create: runtime + streams %.3f s, group slots %.3f s, arenas %.3f s\n", t1 - t0, t2 - t1, now() - t2);
     return h;
@@ -169,6 +208,8 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
 
 void mm_ingest_destroy(mm_ingest_t* h) {
     if (!h) return;
+    live_remove(h);
+    if (h->slot_maker.joinable()) h->slot_maker.join();
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (GSlot& s : h->slots) {
@@ -194,7 +235,12 @@ int32_t mm_ingest_group_slots(const mm_ingest_t* h) { return h ? h->o.group_slot
 int32_t mm_ingest_max_blocks(const mm_ingest_t* h) { return h ? h->o.max_blocks : 0; }
 uint64_t mm_ingest_max_cbytes(const mm_ingest_t* h) { return h ? h->o.max_cbytes : 0; }
 uint64_t mm_ingest_arena_bytes(const mm_ingest_t* h) { return h ? h->o.arena_bytes : 0; }
-static GSlot* slot_of(mm_ingest_t* h, int32_t slot) { return (h && slot >= 0 && (size_t)slot < h->slots.size()) ? &h->slots[(size_t)slot] : nullptr; }
+static GSlot* slot_of(mm_ingest_t* h, int32_t slot) {
+    if (!h || slot < 0 || (size_t)slot >= h->slots.size()) return nullptr;
+    GSlot* s = &h->slots[(size_t)slot];
+    while (s->ready.load() == 0) std::this_thread::yield();   // (a slot behind the first is still being made: tens of milliseconds at most)
+    return s->ready.load() > 0 ? s : nullptr;
+}
 uint8_t* mm_ingest_staging(mm_ingest_t* h, int32_t slot) { GSlot* s = slot_of(h, slot); return s ? s->h_c : nullptr; }
 mm_bgzf_block_t* mm_ingest_blocks(mm_ingest_t* h, int32_t slot) { GSlot* s = slot_of(h, slot); return s ? s->h_blocks : nullptr; }
 void* mm_ingest_stream(mm_ingest_t* h) { return h ? (void*)h->chain : nullptr; }
