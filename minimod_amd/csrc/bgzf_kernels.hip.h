@@ -90,14 +90,15 @@ __device__ __forceinline__ void fill_xtab(uint32_t* xtab) {
     if (t < 64u) {
         uint32_t e = 0;
         if (t < 29u) e = ent(0, K_LEN, c_len_extra[t], c_len_base[t]);
+        else if (t == 31u) e = ent(0, K_EOB, 0, 0);            // (expand_ll_t: kind 2 looks here)
         else if (t >= 32u && t < 62u) e = ent(0, K_DIST, c_dist_extra[t - 32u], c_dist_base[t - 32u]);
         xtab[t] = e;
     }
 }
 __device__ __forceinline__ uint32_t expand_ll_t(uint32_t c, const uint32_t* xtab) {
     const uint32_t len = c & 15u, k = (c >> 4) & 3u, v = c >> 6;
-    const uint32_t x = xtab[v & 31u];                       // (read whatever the entry is: no branch around it)
-    return len | (k == 0u ? v << 16 : (k == 1u ? x : (uint32_t)K_EOB << 4));
+    const uint32_t x = xtab[(v | (31u & (0u - (k >> 1)))) & 31u];   // (a length symbol's entry; the end of the block's is entry 31; read whatever the entry is)
+    return len | (k == 0u ? v << 16 : x);
 }
 __device__ __forceinline__ uint32_t expand_d_t(uint32_t c, const uint32_t* xtab) {
     const uint32_t x = xtab[32u + ((c >> 6) & 31u)];
@@ -721,7 +722,8 @@ __device__ __forceinline__ int inflate_block(const uint8_t* in, uint32_t c_len, 
                 const uint32_t t_val = is_lit ? e1 >> 16 : mlen;      // a literal's byte / a match's length
                 const uint32_t t_out = is_lit ? 1u : (is_mat ? mlen : 0u);
                 // the chain from the reader's position: lane p holds where the token at offset p ends (bit 7: no token there)
-                const uint32_t nx = is_lit ? (uint32_t)l + l1 : (is_mat ? (uint32_t)l + used + dl + xd : 0x80u);
+                const uint32_t tb = is_lit ? l1 : used + dl + xd;
+                const uint32_t nx = (is_lit | is_mat) ? (uint32_t)l + tb : 0x80u;
                 // The window is worked off in SEGMENTS: the chain of tokens from `pos` on, then -- where the chain ends on an offset that holds no
                 // token -- that one symbol by the plain path (a long code, the end of the block), and on with the chain behind it.
                 uint32_t pos = 0;
