@@ -143,7 +143,7 @@ static void print_help(FILE *fp, const fopt_t *o) {
     fprintf(fp, "   --gpu-ingest               keep the decoded BAM in GPU memory: BGZF inflate, record framing and the read filters all run on the\n"
                 "   --no-gpu-ingest            device and the host only moves compressed bytes (-K / -B then do not cut the batches; runs that\n"
                 "                              --host-replay or --debug-break, and pipes, read with the host threads) [%s]\n",
-            o->gpu_ingest < 0 ? "for a BAM file of 512 MiB or more per GPU" : (o->gpu_ingest ? "yes" : "no"));
+            o->gpu_ingest < 0 ? (o->view ? "for a BAM file of 2 GiB or more per GPU" : "for a BAM file of 512 MiB or more per GPU") : (o->gpu_ingest ? "yes" : "no"));
     if (!o->view) fprintf(fp, "   --region STR               only the rows of chr:from-to (1-based, inclusive; chr alone: the whole contig): the reads that can reach it are\n"
                               "                              found through reads.bam.bai and counted, rows outside are dropped [%s]\n", o->region ? o->region : "whole file");
     fprintf(fp, "   --devices LIST             GPUs to share the genome between, e.g. 0,1,2,3 (one worker process each; needs reads.bam.bai)\n");
@@ -1675,7 +1675,9 @@ static int run_main(int argc, char **argv, int view) {
         struct stat sb;
         int n_dev = 1;
         if (o.devices) for (const char *q = o.devices; *q; q++) if (*q == ',') n_dev++;
-        o.gpu_ingest = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= ((int64_t)512 << 20);   /* (tools/ingest_threshold.sh: the device reader's own start -- 192 MiB of pinned staging, 3 GiB of pools, their release at exit -- is 0.1 - 0.3 s by box; the host threads win below ~0.5 GiB, lose from ~1 GiB, between them it depends on the box) */
+        /* (view: from 2 GiB -- tools/view_batch_sweep.sh: on a 656-MB file the device reader's own start, pinned staging and pools, costs what its faster
+         * decode wins, 0.38 - 0.66 s against the host threads' steady 0.40 s) */
+        o.gpu_ingest = stat(bam_file, &sb) == 0 && (int64_t)sb.st_size / n_dev >= (view ? ((int64_t)2 << 30) : ((int64_t)512 << 20));   /* (tools/ingest_threshold.sh: the device reader's own start -- 192 MiB of pinned staging, 3 GiB of pools, their release at exit -- is 0.1 - 0.3 s by box; the host threads win below ~0.5 GiB, lose from ~1 GiB, between them it depends on the box) */
     }
     /* the HIP runtime's start (~0.2 s) beside the reference's load -- unless this process is going to fork workers (--devices a,b,...:
      * the parent must not have touched HIP) */
