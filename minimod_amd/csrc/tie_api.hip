@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,10 @@ int radix_sort(u64* k0, uint32_t* v0, u64* k1, uint32_t* v1, uint64_t n, uint32_
 int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n, int put_after_last, uint32_t* d_slot, uint32_t* d_final, hipStream_t st) {
     if (n == 0) return 0;
     if (n >= 0xFFFFFFF0ull) return -MM_E_TOOMANY;
+    const bool tl = std::getenv("MM_TIMELINE") != nullptr;   // (where the call's milliseconds go: a synchronisation at every mark, so only then)
+    auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    double t_last = now();
+    auto mark = [&](const char* what) { if (tl) { (void)hipStreamSynchronize(st); const double t = now(); std::fprintf(stderr, "[timeline] tie order: %-40s %.2f ms\n", what, 1e3 * (t - t_last)); t_last = t; } };
     Bufs B;
     volatile uint32_t* hflag = nullptr;   // [0] changed, [1] moved, [2] fail, [4..5] a 64-bit word, [6] a count
     if (hipHostMalloc((void**)&hflag, 64, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
@@ -91,6 +97,7 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
     u64* word = B.get<u64>(half);
     u64* tw = B.get<u64>(Cfin);
     if (!tab[0] || !tab[1] || !cur || !stp || !land || !pred || !word || !tw) return -MM_E_NOMEM;
+    mark("T3 buffers");
     int tcur = 0;
     uint64_t C = 4, done = 0;
     LAUNCH(k_fill32, blocks(C), 256, st, tab[0], (u64)C, kNone);
@@ -125,7 +132,28 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
         tcur ^= 1; C *= 2;
         return 0;
     };
-    for (;;) {
+    // the small tables (4 ... 8 192 buckets) in ONE workgroup (k_small_epochs: the same steps without a launch a round and a synchronisation a
+    // fixpoint test); MM_TIE_SMALL=0: everything through the loop below, as rounds 5's first version did (the tests run both)
+    bool finished = false;
+    {
+        const char* e = std::getenv("MM_TIE_SMALL");
+        const uint64_t Cstop = e ? (uint64_t)std::strtoull(e, nullptr, 10) : 8192ull;
+        if (Cstop >= 8) {
+            SmallState* d_state = B.get<SmallState>(1);
+            unsigned long long* d_counts = B.get<unsigned long long>(4);
+            if (!d_state || !d_counts) return -MM_E_NOMEM;
+            LAUNCH(k_small_epochs, 1, 1024, st, d_hash, (u64)n, put_after_last, (uint32_t)std::min<uint64_t>(Cstop, Cfin), tab[0], tab[1], cur, stp, land, pred, word, tw, d_state, d_counts);
+            SmallState hs;
+            unsigned long long hcnt[4] = {0, 0, 0, 0};
+            if (hipMemcpyAsync(&hs, d_state, sizeof hs, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hcnt, d_counts, 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
+            if (hs.fail) return -MM_E_TOOMANY;
+            C = hs.C; done = hs.done; tcur = (int)hs.tcur; finished = hs.finished != 0;
+            g_stats[1] += hcnt[0]; g_stats[2] += hcnt[1]; g_stats[3] += hcnt[2];
+        }
+    }
+    mark("T3 small tables (one workgroup)");
+    while (!finished) {
         const uint64_t U = upper_of(C), hi = std::min<uint64_t>(n, U);
         if (hi > done) {
             const uint32_t lo32 = (uint32_t)done, hi32 = (uint32_t)hi, mask = (uint32_t)(C - 1);
@@ -145,6 +173,7 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
         }
         { const int r = grow(); if (r) return r; }
     }
+    mark("T3 big tables (host loop)");
     // the keys in slot order
     u64* f = B.get<u64>(std::max<uint64_t>(C, n));
     u64* tiles = B.get<u64>(std::max<uint64_t>(C, n) / kScanTile + 4);
@@ -156,6 +185,7 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
     LAUNCH(k_slot_gather, blocks(C), 256, st, (const uint32_t*)tab[tcur], (u64)C, (const u64*)f, d_sortkey, key, id);
     if (d_slot && hipMemcpyAsync(d_slot, id, 4 * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return -MM_E_HIP;
 
+    mark("slot order");
     // ---- T4: ks_introsort's partitions, level by level
     if (n == 2) {   // (src/ksort.h: two elements are compared and that is all)
         long long hk[2]; uint32_t hi2[2];
@@ -218,8 +248,10 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
             n_small = hc[1];
         }
         g_stats[5] = n_small;
+        mark("T4 partition levels");
         if (n_small) LAUNCH(k_qs_small, blocks(n_small, 64), 64, st, (const Seg*)small, n_small, key, id);
     }
+    mark("T4 small segments (a thread each)");
     // the insertion sort over everything that ends ks_introsort: a stable sort of what the partitions left
     u64* bk[2] = {B.get<u64>(n), B.get<u64>(n)};
     uint32_t* bv1 = B.get<uint32_t>(n);
@@ -231,6 +263,7 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
     const int w = radix_sort(bk[0], id, bk[1], bv1, n, hist, d_or, (volatile uint64_t*)&hflag[4], st);
     if (w < 0) return -MM_E_HIP;
     if (hipMemcpyAsync(d_final, w ? bv1 : id, 4 * n, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
+    mark("final stable sort");
     return 0;
 }
 

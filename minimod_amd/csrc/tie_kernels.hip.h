@@ -189,6 +189,135 @@ __global__ __launch_bounds__(256) void k_grow_commit(const uint32_t* __restrict_
     const uint32_t r = told[s];
     if (r != kNone) tnew[land[s]] = r;
 }
+// ---- T3 for the SMALL tables, in one workgroup (round 5's end).  The host's loop around k_place_* / k_grow_* pays a launch per round and a
+// stream synchronisation per fixpoint test, and a table of a few thousand buckets gives a launch nothing to do: of the 1 311 launches a
+// 3-million-key run needed, some 700 were for the eleven growths from 4 to 8 192 buckets.  This kernel runs the same steps -- the very bodies
+// above, a thread striding over the keys / buckets -- for every epoch up to `Cstop` buckets, with a workgroup barrier where the host had a
+// kernel boundary: stores and atomics drained in front of the barrier (release), the vector L1 invalidated behind it (acquire), which is what a
+// kernel boundary gives the next launch's loads.  It leaves the table as the host's loop would find it at that point and says where it stopped.
+struct SmallState { uint32_t C, tcur, finished, fail; unsigned long long done; };
+__device__ __forceinline__ void wg_phase() { __threadfence(); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restrict__ hash, u64 n, int put_after_last, uint32_t Cstop, uint32_t* tab0, uint32_t* tab1,
+                                                       uint32_t* cur, uint32_t* stp, uint32_t* land, uint32_t* pred, u64* word, u64* tw, SmallState* out, unsigned long long* counts) {
+    __shared__ uint32_t sh_flag[2];   // changed / moved (or failed)
+    const uint32_t T = 1024u, t = threadIdx.x;
+    uint32_t C = 4u, tcur = 0u, finished = 0u, fail = 0u;
+    u64 done = 0;
+    unsigned long long n_growths = 0, n_passes = 0, n_rounds = 0;
+    for (uint32_t s = t; s < C; s += T) tab0[s] = kNone;
+    wg_phase();
+    for (;;) {
+        uint32_t* tab = tcur ? tab1 : tab0;
+        const uint32_t U = (uint32_t)((double)C * 0.77 + 0.5);
+        const u64 hi64 = n < (u64)U ? n : (u64)U;
+        if (hi64 > done) {
+            // an epoch's keys at their home slots, then rounds until nothing moves (k_place_init / k_place_round)
+            const uint32_t lo = (uint32_t)done, hi = (uint32_t)hi64, mask = C - 1u;
+            for (uint32_t r = lo + t; r < hi; r += T) { cur[r] = hash[r] & mask; stp[r] = 0u; }
+            for (;;) {
+                if (t == 0) sh_flag[0] = 0u;
+                wg_phase();
+                for (uint32_t r = lo + t; r < hi; r += T) {
+                    uint32_t i = cur[r];
+                    if (tab[i] == r) continue;
+                    uint32_t st = stp[r];
+                    for (;;) {
+                        const uint32_t w = atomicMin(&tab[i], r);
+                        if (w >= r) break;
+                        st++; i = (i + st) & mask;
+                    }
+                    cur[r] = i; stp[r] = st;
+                    sh_flag[0] = 1u;
+                }
+                n_rounds++;
+                wg_phase();
+                if (!sh_flag[0]) break;
+            }
+            done = hi64;
+        }
+        bool grow = false;
+        if (done == n) { grow = put_after_last && n >= (u64)U; finished = grow ? 2u : 1u; }   // (2: finished behind the growth below)
+        else if (C >= Cstop) break;                                                            // the host's loop goes on from here: its next step is this growth
+        else grow = true;
+        if (!grow) break;
+        // ---- the growth C -> 2 C (k_grow_home, then passes of succ / prio / rounds / check until the landings hold, then commit)
+        {
+            const uint32_t mask2 = 2u * C - 1u;
+            uint32_t* tnew = tcur ? tab0 : tab1;
+            n_growths++;
+            for (uint32_t s = t; s < C; s += T) { const uint32_t r = tab[s]; land[s] = r == kNone ? kNone : (hash[r] & mask2); }
+            for (;;) {
+                n_passes++;
+                for (uint32_t s = t; s < C; s += T) pred[s] = kNone;
+                wg_phase();
+                for (uint32_t s = t; s < C; s += T) {
+                    if (tab[s] == kNone) continue;
+                    const uint32_t l = land[s];
+                    if (l < C && l != s && tab[l] != kNone) pred[l] = s;
+                }
+                for (uint32_t s = t; s < 2u * C; s += T) tw[s] = kNone64;
+                if (t == 0) sh_flag[1] = 0u;
+                wg_phase();
+                for (uint32_t s = t; s < C; s += T) {
+                    const uint32_t r = tab[s];
+                    if (r == kNone) continue;
+                    uint32_t best = s, dist = 0, d = 1, p = pred[s];
+                    while (p != kNone && p != s) {
+                        if (p < best) { best = p; dist = d; }
+                        p = pred[p]; d++;
+                        if (d > kChainLimit) { sh_flag[1] = 1u; break; }
+                    }
+                    word[s] = ((u64)best << 32) | (u64)dist;
+                    cur[s] = hash[r] & mask2; stp[s] = 0u;
+                }
+                for (;;) {
+                    if (t == 0) sh_flag[0] = 0u;
+                    wg_phase();
+                    for (uint32_t s = t; s < C; s += T) {
+                        if (tab[s] == kNone) continue;
+                        const u64 me = word[s];
+                        uint32_t i = cur[s];
+                        if (tw[i] == me) continue;
+                        uint32_t st = stp[s];
+                        for (;;) {
+                            const u64 w = atomicMin(&tw[i], me);
+                            if (w >= me) break;
+                            st++; i = (i + st) & mask2;
+                        }
+                        cur[s] = i; stp[s] = st;
+                        sh_flag[0] = 1u;
+                    }
+                    n_rounds++;
+                    wg_phase();
+                    if (!sh_flag[0]) break;
+                }
+                if (sh_flag[1]) { fail = 1u; break; }
+                if (t == 0) sh_flag[1] = 0u;
+                wg_phase();
+                for (uint32_t s = t; s < C; s += T) {
+                    if (tab[s] == kNone) continue;
+                    if (land[s] != cur[s]) { land[s] = cur[s]; sh_flag[1] = 1u; }
+                }
+                wg_phase();
+                const bool moved = sh_flag[1] != 0u;
+                wg_phase();   // (everybody has read the flag before the next pass clears it)
+                if (!moved) break;
+            }
+            if (fail) break;
+            for (uint32_t s = t; s < 2u * C; s += T) tnew[s] = kNone;
+            wg_phase();
+            for (uint32_t s = t; s < C; s += T) { const uint32_t r = tab[s]; if (r != kNone) tnew[land[s]] = r; }
+            wg_phase();
+            tcur ^= 1u; C *= 2u;
+        }
+        if (finished) { finished = 1u; break; }
+    }
+    if (t == 0) {
+        out->C = C; out->tcur = tcur; out->finished = finished ? 1u : 0u; out->fail = fail; out->done = done;
+        counts[0] = n_growths; counts[1] = n_passes; counts[2] = n_rounds;
+    }
+}
+
 // the table's keys in slot order: flags -> (scan) -> gather
 __global__ __launch_bounds__(256) void k_slot_flags(const uint32_t* __restrict__ tab, u64 C, u64* __restrict__ f) {
     const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
@@ -274,7 +403,10 @@ __global__ __launch_bounds__(256) void k_qs_swap(const uint32_t* __restrict__ se
 }
 // per segment: where the pivot goes, the children (those of more than 16 elements: src/ksort.h pushes / continues with nothing smaller),
 // handed to the next level or, from 2048 elements down, to the list of segments a thread finishes
-constexpr uint32_t kSmallSeg = 2048;
+#ifndef MM_TIE_SMALL_SEG
+#define MM_TIE_SMALL_SEG 64   /* (2 048 until the end of round 5: 3 000 threads then finished a thousand keys each, 37 of a 3-million-key call's 57 ms; 512: 5 ms, 256: 1.8, 64: 0.3, for four more levels of 0.12 ms) */
+#endif
+constexpr uint32_t kSmallSeg = MM_TIE_SMALL_SEG;
 __global__ __launch_bounds__(256) void k_qs_finish(const Seg* __restrict__ segs, uint32_t n_seg, const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ rpos, const uint32_t* __restrict__ nswap,
                                                    long long* __restrict__ key, uint32_t* __restrict__ id, Seg* __restrict__ next, uint32_t* __restrict__ n_next, Seg* __restrict__ small, uint32_t* __restrict__ n_small,
                                                    uint32_t* __restrict__ pivot_at, uint32_t* __restrict__ child) {
