@@ -14,6 +14,8 @@ struct SumKey { uint32_t off, len; uint8_t base, flag, pad[2]; uint32_t hash; };
 __device__ inline bool sum_valid_base(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'U' || c == 'N' || c == 'a' || c == 'c' || c == 'g' || c == 't' || c == 'u' || c == 'n'; }
 
 // per read: how many groups its MM text can hold at most (its ';' + 1): sizes of its scratch and of its text
+// a read's table of census keys: key numbers and khash's two flag arrays (kh_resize works in place with both)
+struct SumTab { uint32_t* id; uint8_t* old; uint8_t* nw; uint32_t nb, size, upper; };
 __global__ __launch_bounds__(256) void k_sum_bound(const mm_read_t* __restrict__ reads, const uint8_t* __restrict__ mm, uint32_t n, u64* __restrict__ groups) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(64) void k_sum_reads(const mm_read_t* __restrict__ 
     const u64 g0 = r ? gincl[r - 1] : 0ull;           // groups of the reads in front: this read's keys start there
     SumKey* K = keys + g0;
     const u64 tb = 4ull * g0 + 8ull * r;              // its table: up to 4 g + 8 buckets
-    ReadTab tab;
+    SumTab tab;
     tab.id = tab_id + tb; tab.old = tab_old + tb; tab.nw = tab_new + tb; tab.nb = 0; tab.size = 0; tab.upper = 0;
     const u64 t0 = rd.mm_off + 6ull * g0;             // its text: at most mm_len + 6 per group
     char* out = text + t0;

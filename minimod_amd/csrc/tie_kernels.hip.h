@@ -606,7 +606,7 @@ struct TieLaunch {
     u64 serial0;
     u64* sk_a; u64* sk_b;                       // n_rows each: the calls' sort words
     u64* keys; uint32_t* khash;                 // n_rows * per
-    uint32_t* tab_id; uint8_t* tab_old; uint8_t* tab_new;   // 4 * per * n_rows + 8 * n_reads each
+    u64* tab;   // 4 * per * n_rows + 8 * n_reads words: the reads' own tables (ReadTab)
     u64* gkey; u64* gstamp; u64 gmask;
     u64* last_put; uint32_t* fail;
 };
@@ -665,43 +665,52 @@ __device__ inline void shell_sort(u64* a, uint32_t n) {
     }
 }
 
-struct ReadTab { uint32_t* id; uint8_t* old; uint8_t* nw; uint32_t nb, size, upper; };
-__device__ inline void rtab_grow(ReadTab& t, const uint32_t* kh) {   // kh_resize to the next power of two, in place, with its kick-outs
-    uint32_t nb2 = t.nb ? t.nb * 2u : 4u;
+// A read's own table (update_freq_map's khash, src/mod.c:883-929), ONE 64-bit word a bucket: the key's X31 hash (32) | its number among the read's
+// keys << 32 (20 bits) | two flag bits -- `fo`: the bucket holds a key; the other: it holds a key the running resize has placed.  (The first form kept
+// three arrays -- key numbers, "old" and "new" flag bytes -- and looked the hash and the 64-bit key up through the number at every probe: four
+// dependent loads from global memory a probe in a kernel that is one serial walk a thread, bounded by its longest read: 19 ms a launch.)
+struct ReadTab { u64* ent; uint32_t nb, size, upper; u64 fo; };
+constexpr u64 kRtData = (1ull << 52) - 1ull, kRtA = 1ull << 63, kRtB = 1ull << 62;
+__device__ inline void rtab_grow(ReadTab& t) {   // kh_resize to the next power of two, in place, with its kick-outs
+    const uint32_t nb2 = t.nb ? t.nb * 2u : 4u;
     const uint32_t mask = nb2 - 1u;
-    for (uint32_t i = 0; i < nb2; i++) t.nw[i] = 0;
+    const u64 fo = t.fo, fn = fo ^ (kRtA | kRtB);       // (occupied before / placed by this resize: the roles swap at its end)
+    for (uint32_t i = t.nb; i < nb2; i++) t.ent[i] = 0ull;
     for (uint32_t j = 0; j < t.nb; j++) {
-        if (!t.old[j]) continue;
-        uint32_t key = t.id[j];
-        t.old[j] = 0;
+        const u64 e = t.ent[j];
+        if (!(e & fo)) continue;
+        u64 key = e & kRtData;
+        t.ent[j] = 0ull;
         for (;;) {
-            uint32_t i = kh[key] & mask, step = 0;
-            while (t.nw[i]) i = (i + (++step)) & mask;
-            t.nw[i] = 1;
-            if (i < t.nb && t.old[i]) { const uint32_t tmp = t.id[i]; t.id[i] = key; key = tmp; t.old[i] = 0; }
-            else { t.id[i] = key; break; }
+            uint32_t i = (uint32_t)key & mask, step = 0;
+            u64 x;
+            while ((x = t.ent[i]) & fn) i = (i + (++step)) & mask;
+            t.ent[i] = fn | key;
+            if (i < t.nb && (x & fo)) key = x & kRtData;       // (the bucket's old key is kicked out and placed next)
+            else break;
         }
     }
-    uint8_t* x = t.old; t.old = t.nw; t.nw = x;
+    t.fo = fn;
     t.nb = nb2; t.upper = (uint32_t)(nb2 * 0.77 + 0.5);
 }
 // update_freq_map: kh_get, and kh_put only for a key that is not there (the put looks at the growth bound first)
-__device__ inline bool rtab_put(ReadTab& t, uint32_t k, const u64* keys, const uint32_t* kh) {
-    const uint32_t h = kh[k];
+__device__ inline bool rtab_put(ReadTab& t, uint32_t k, uint32_t h, const u64* keys) {
+    const u64 mine = ((u64)k << 32) | (u64)h;
     if (t.nb) {
         const uint32_t mask = t.nb - 1u;
         uint32_t i = h & mask, step = 0;
-        while (t.old[i]) {
-            if (kh[t.id[i]] == h && keys[t.id[i]] == keys[k]) return false;
+        u64 e;
+        while ((e = t.ent[i]) & t.fo) {
+            if ((uint32_t)e == h && keys[(uint32_t)((e & kRtData) >> 32)] == keys[k]) return false;
             i = (i + (++step)) & mask;
         }
-        if (t.size < t.upper) { t.old[i] = 1; t.id[i] = k; t.size++; return true; }
+        if (t.size < t.upper) { t.ent[i] = t.fo | mine; t.size++; return true; }
     }
-    rtab_grow(t, kh);
+    rtab_grow(t);
     const uint32_t mask = t.nb - 1u;
     uint32_t i = h & mask, step = 0;
-    while (t.old[i]) i = (i + (++step)) & mask;
-    t.old[i] = 1; t.id[i] = k; t.size++;
+    while (t.ent[i] & t.fo) i = (i + (++step)) & mask;
+    t.ent[i] = t.fo | mine; t.size++;
     return true;
 }
 
@@ -764,7 +773,7 @@ __global__ __launch_bounds__(64) void k_tie_reads(TieTables T, TieLaunch L) {
     uint32_t* kh = L.khash + (u64)a * per;
     const u64 tb = 4ull * per * a + 8ull * r;
     ReadTab tab;
-    tab.id = L.tab_id + tb; tab.old = L.tab_old + tb; tab.nw = L.tab_new + tb; tab.nb = 0; tab.size = 0; tab.upper = 0;
+    tab.ent = L.tab + tb; tab.nb = 0; tab.size = 0; tab.upper = 0; tab.fo = kRtA;
     const uint32_t strand = (rd.flag & 0x10) ? 1u : 0u;
     const uint32_t hc = T.ctg_hash[rd.tid];
     const u64 gbase = T.ctg_base[rd.tid];
@@ -782,15 +791,16 @@ __global__ __launch_bounds__(64) void k_tie_reads(TieTables T, TieLaunch L) {
             const int hp = T.haplotypes ? (v == 0u ? (int)rd.hp : -1) : -1;
             keys[nk] = tie_key(gbase + (u64)(uint32_t)w.pos, strand, w.code, ins, (uint32_t)(hp + 1));
             kh[nk] = x31_dec(h0, (long long)hp);
-            if (rtab_put(tab, nk, keys, kh)) nk++;
+            if (rtab_put(tab, nk, kh[nk], keys)) nk++;
         }
     }
     // 4. the table's slot order is the order merge_freq_maps offers the keys to the core table (src/mod.c:743-774): stamps, smallest kept per key
     uint32_t w2 = 0;
     const u64 sbase = (L.serial0 + (u64)r) << 24;
     for (uint32_t s = 0; s < tab.nb; s++) {
-        if (!tab.old[s]) continue;
-        const u64 key = keys[tab.id[s]], stamp = sbase | (u64)w2;
+        const u64 e = tab.ent[s];
+        if (!(e & tab.fo)) continue;
+        const u64 key = keys[(uint32_t)((e & kRtData) >> 32)], stamp = sbase | (u64)w2;
         w2++;
         u64 i = mix64(key) & L.gmask;
         for (;;) {
@@ -816,11 +826,16 @@ __global__ __launch_bounds__(256) void k_stamp_rehash(const u64* __restrict__ ok
         i = (i + 1ull) & nmask;
     }
 }
+// (a thread strides over the table and a workgroup adds ONE number: the first form added a wavefront's count at a time -- a million atomics
+// on one address for a table of 2^26 slots, 5.9 ms a launch of the replay's second handle)
 __global__ __launch_bounds__(256) void k_stamp_count(const u64* __restrict__ gk, u64 cap, u64* __restrict__ count) {
-    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
-    const bool have = j < cap && gk[j] != kNone64;
-    const u64 b = __ballot(have);
-    if (lane() == 0 && b) atomicAdd(count, (u64)__popcll(b));
+    __shared__ uint32_t part[4];
+    uint32_t mine = 0;
+    for (u64 j = (u64)blockIdx.x * 256u + threadIdx.x; j < cap; j += (u64)gridDim.x * 256u) mine += gk[j] != kNone64 ? 1u : 0u;
+    for (int d = 32; d; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+    if (lane() == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(count, (u64)t); }
 }
 // X31 of make_key's string for a key (src/mod.c:428-439)
 __device__ inline uint32_t key_x31(const TieTables& T, int32_t tid, int32_t pos, uint32_t strand, uint32_t code, uint32_t ins, int hp) {
