@@ -283,6 +283,8 @@ struct mm_tie {
     uint32_t *d_beg = nullptr, *d_end = nullptr; size_t cap_reads = 0;
     u64 *d_ska = nullptr, *d_skb = nullptr, *d_keys = nullptr; uint32_t* d_khash = nullptr; size_t cap_rows = 0;
     u64* d_tab = nullptr; size_t cap_tab = 0;
+    uint32_t* d_rt = nullptr; size_t cap_rt = 0;
+    uint32_t* d_rc = nullptr; size_t cap_rc = 0;
     // the stamps
     u64 *d_gkey = nullptr, *d_gstamp = nullptr; uint64_t gcap = 0, distinct = 0;
     u64* d_words = nullptr;   // [0] last put, [1] count scratch
@@ -460,20 +462,23 @@ int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view
         return -MM_E_NOMEM;
     t->cap_rows = std::min(std::min(c1, c2), std::min(c3, c4) / per);
     const size_t tabn = 4 * per * (size_t)n_rows + 8 * (size_t)nr;
-    if (grow_buf(t, &t->d_tab, &t->cap_tab, tabn)) return -MM_E_NOMEM;
+    if (grow_buf(t, &t->d_tab, &t->cap_tab, tabn) || grow_buf(t, &t->d_rt, &t->cap_rt, (size_t)nr) || grow_buf(t, &t->d_rc, &t->cap_rc, (size_t)nr)) return -MM_E_NOMEM;
     { const int r = ensure_stamps(t, (uint64_t)n_rows * per); if (r) return r; }
     hipStream_t st = t->st;
     if (hipMemsetAsync(t->d_beg, 0, 4 * (size_t)nr, st) != hipSuccess || hipMemsetAsync(t->d_end, 0, 4 * (size_t)nr, st) != hipSuccess ||
-        hipMemsetAsync(t->d_fail, 0, 4, st) != hipSuccess || hipMemsetAsync(t->d_words + 1, 0, 8, st) != hipSuccess) return -MM_E_HIP;
+        hipMemsetAsync(t->d_fail, 0, 4, st) != hipSuccess || hipMemsetAsync(t->d_words + 1, 0, 8, st) != hipSuccess || hipMemsetAsync(t->d_rt, 0, 4 * (size_t)nr, st) != hipSuccess || hipMemsetAsync(t->d_rc, 0, 4 * (size_t)nr, st) != hipSuccess) return -MM_E_HIP;
     LAUNCH(k_tie_bounds, blocks((uint64_t)n_rows), 256, st, (const mm_view_row_t*)dev_view_rows, (uint32_t)n_rows, nr, t->d_beg, t->d_end, t->d_fail);
     TieLaunch L;
     L.reads = b->reads; L.mm = b->mm; L.rows = (const mm_view_row_t*)dev_view_rows; L.n_reads = nr; L.n_rows = (uint32_t)n_rows;
     L.beg = t->d_beg; L.end = t->d_end; L.serial0 = t->serial;
     L.sk_a = t->d_ska; L.sk_b = t->d_skb; L.keys = t->d_keys; L.khash = t->d_khash;
-    L.tab = t->d_tab;
+    L.tab = t->d_tab; L.rt = t->d_rt; L.rc = t->d_rc;
     L.gkey = t->d_gkey; L.gstamp = t->d_gstamp; L.gmask = t->gcap - 1;
     L.last_put = t->d_words; L.fail = t->d_fail;
     LAUNCH(k_tie_reads, blocks(nr, 64), 64, st, tables_of(t), L);
+    LAUNCH(k_tie_keys, blocks((uint64_t)n_rows), 256, st, tables_of(t), L);
+    LAUNCH(k_tie_puts, blocks(nr, 64), 64, st, tables_of(t), L);
+    LAUNCH(k_tie_stamps, blocks(nr, 4), 256, st, tables_of(t), L);
     LAUNCH(k_stamp_count, (unsigned)std::min<uint64_t>(blocks(t->gcap), 2048), 256, st, (const u64*)t->d_gkey, (u64)t->gcap, t->d_words + 1);
     uint64_t cnt = 0; uint32_t hfail = 0;
     if (hipMemcpyAsync(&cnt, t->d_words + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&hfail, t->d_fail, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -568,7 +573,7 @@ void mm_tie_destroy(mm_tie_t* t) {
     (void)hipSetDevice(t->o.device);
     if (t->st) (void)hipStreamSynchronize(t->st);
     void* ps[] = {t->d_klass, t->d_ctg_hash, t->d_ctg_base, t->d_ctg_rank, t->d_mid, t->d_codes, t->d_beg, t->d_end, t->d_ska, t->d_skb, t->d_keys, t->d_khash,
-                  t->d_tab, t->d_gkey, t->d_gstamp, t->d_words, t->d_fail};
+                  t->d_tab, t->d_rt, t->d_rc, t->d_gkey, t->d_gstamp, t->d_words, t->d_fail};
     for (void* p : ps) if (p) (void)hipFree(p);
     if (t->h_words) (void)hipHostFree((void*)t->h_words);
     if (t->st) (void)hipStreamDestroy(t->st);

@@ -607,6 +607,8 @@ struct TieLaunch {
     u64* sk_a; u64* sk_b;                       // n_rows each: the calls' sort words
     u64* keys; uint32_t* khash;                 // n_rows * per
     u64* tab;   // 4 * per * n_rows + 8 * n_reads words: the reads' own tables (ReadTab)
+    uint32_t* rc;   // n_reads (zeroed): what k_tie_reads leaves k_tie_keys / k_tie_puts -- the read's calls that reach the table | their order stands in sk_b << 31
+    uint32_t* rt;   // n_reads (zeroed): what k_tie_reads leaves k_tie_stamps -- a read's table size | which flag bit marks its buckets << 31
     u64* gkey; u64* gstamp; u64 gmask;
     u64* last_put; uint32_t* fail;
 };
@@ -767,51 +769,93 @@ __global__ __launch_bounds__(64) void k_tie_reads(TieTables T, TieLaunch L) {
         }
         ord = sb;
     } else shell_sort(sa, cnt);
-    // 3. keys and their X31 hashes in that order, through the read's own table
+    // 3. (k_tie_keys, k_tie_puts) keys and their X31 hashes in that order, through the read's own table
+    if (T.haplotypes && rd.hp > 61) { atomicOr(L.fail, (uint32_t)TIE_F_HP); return; }
+    L.rc[r] = cnt | (ord == sb ? 0x80000000u : 0u);
+}
+// 3a. the keys and their X31 hashes, in the order step 2 left the calls in: a THREAD A CALL (round 5's end: nothing here depends on the call in
+// front -- as part of the read's thread it was a random load and a hundred and fifty instructions a key in the longest read's chain)
+__global__ __launch_bounds__(256) void k_tie_keys(TieTables T, TieLaunch L) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= L.n_rows) return;
+    const uint32_t r = L.rows[g].read & 0x1FFFFFu;
+    if (r >= L.n_reads) return;
+    const uint32_t c = L.rc[r], cnt = c & 0x7FFFFFFFu, a = L.beg[r], j = g - a;
+    if (j >= cnt) return;
+    const u64* ord = ((c >> 31) ? L.sk_b : L.sk_a) + a;
+    const mm_read_t rd = L.reads[r];
+    const mm_view_row_t w = L.rows[a + (uint32_t)(ord[j] & 0x3FFFFu)];
     const uint32_t per = T.haplotypes ? 2u : 1u;
-    u64* keys = L.keys + (u64)a * per;
-    uint32_t* kh = L.khash + (u64)a * per;
-    const u64 tb = 4ull * per * a + 8ull * r;
-    ReadTab tab;
-    tab.ent = L.tab + tb; tab.nb = 0; tab.size = 0; tab.upper = 0; tab.fo = kRtA;
     const uint32_t strand = (rd.flag & 0x10) ? 1u : 0u;
     const uint32_t hc = T.ctg_hash[rd.tid];
     const u64 gbase = T.ctg_base[rd.tid];
-    if (T.haplotypes && rd.hp > 61) { atomicOr(L.fail, (uint32_t)TIE_F_HP); return; }
-    uint32_t nk = 0;
-    for (uint32_t j = 0; j < cnt; j++) {
-        const mm_view_row_t w = L.rows[a + (uint32_t)(ord[j] & 0x3FFFFu)];
-        const uint32_t ins = T.insertions ? w.ins_offset : 0u;
-        const uint2 md = T.mid[strand * 64u + w.code];
-        uint32_t h0 = x31_dec(hc, (long long)w.pos);
-        h0 = h0 * md.x + md.y;
-        h0 = x31_dec(h0, (long long)ins);
-        h0 = x31_c(h0, (uint32_t)'\t');
-        for (uint32_t v = 0; v < per; v++) {   // the key with the haplotype, then the aggregate (src/mod.c:883-929)
-            const int hp = T.haplotypes ? (v == 0u ? (int)rd.hp : -1) : -1;
-            keys[nk] = tie_key(gbase + (u64)(uint32_t)w.pos, strand, w.code, ins, (uint32_t)(hp + 1));
-            kh[nk] = x31_dec(h0, (long long)hp);
-            if (rtab_put(tab, nk, kh[nk], keys)) nk++;
-        }
+    const uint32_t ins = T.insertions ? w.ins_offset : 0u;
+    const uint2 md = T.mid[strand * 64u + w.code];
+    uint32_t h0 = x31_dec(hc, (long long)w.pos);
+    h0 = h0 * md.x + md.y;
+    h0 = x31_dec(h0, (long long)ins);
+    h0 = x31_c(h0, (uint32_t)'\t');
+    for (uint32_t v = 0; v < per; v++) {   // the key with the haplotype, then the aggregate (src/mod.c:883-929)
+        const int hp = T.haplotypes ? (v == 0u ? (int)rd.hp : -1) : -1;
+        const u64 at = ((u64)a + j) * per + v;
+        L.keys[at] = tie_key(gbase + (u64)(uint32_t)w.pos, strand, w.code, ins, (uint32_t)(hp + 1));
+        L.khash[at] = x31_dec(h0, (long long)hp);
     }
-    // 4. the table's slot order is the order merge_freq_maps offers the keys to the core table (src/mod.c:743-774): stamps, smallest kept per key
-    uint32_t w2 = 0;
+}
+// 3b. update_freq_map's puts, one after the other: a thread a read -- the chain that is left
+__global__ __launch_bounds__(64) void k_tie_puts(TieTables T, TieLaunch L) {
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= L.n_reads) return;
+    const uint32_t cnt = L.rc[r] & 0x7FFFFFFFu;
+    if (cnt == 0u) return;
+    const uint32_t a = L.beg[r];
+    const uint32_t per = T.haplotypes ? 2u : 1u;
+    const u64* keys = L.keys + (u64)a * per;
+    const uint32_t* kh = L.khash + (u64)a * per;
+    ReadTab tab;
+    tab.ent = L.tab + (4ull * per * a + 8ull * r); tab.nb = 0; tab.size = 0; tab.upper = 0; tab.fo = kRtA;
+    const uint32_t n = cnt * per;
+    for (uint32_t k = 0; k < n; k++) (void)rtab_put(tab, k, kh[k], keys);
+    L.rt[r] = tab.nb | (tab.fo == kRtB ? 0x80000000u : 0u);
+}
+// 4. the table's slot order is the order merge_freq_maps offers the keys to the core table (src/mod.c:743-774): stamps, smallest kept per key.
+// A WAVEFRONT a read (round 5's end: this walk over up to four buckets a key, with two atomics a key on the global table, was the longest read's
+// last eight milliseconds as one thread's chain; the buckets are independent once the table stands): a lane a bucket, a bucket's rank among the
+// occupied ones from a ballot.
+__global__ __launch_bounds__(256) void k_tie_stamps(TieTables T, TieLaunch L) {
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= L.n_reads) return;
+    const uint32_t w = L.rt[r], nb = w & 0x7FFFFFFFu;
+    if (nb == 0u) return;
+    const u64 fo = (w >> 31) ? kRtB : kRtA;
+    const uint32_t a = L.beg[r];
+    const uint32_t per = T.haplotypes ? 2u : 1u;
+    const u64* keys = L.keys + (u64)a * per;
+    const u64* ent = L.tab + (4ull * per * a + 8ull * r);
     const u64 sbase = (L.serial0 + (u64)r) << 24;
-    for (uint32_t s = 0; s < tab.nb; s++) {
-        const u64 e = tab.ent[s];
-        if (!(e & tab.fo)) continue;
-        const u64 key = keys[(uint32_t)((e & kRtData) >> 32)], stamp = sbase | (u64)w2;
-        w2++;
-        u64 i = mix64(key) & L.gmask;
-        for (;;) {
-            u64 k = L.gkey[i];
-            if (k == kNone64) { k = atomicCAS(&L.gkey[i], kNone64, key); if (k == kNone64) k = key; }
-            if (k == key) { atomicMin(&L.gstamp[i], stamp); break; }
-            i = (i + 1ull) & L.gmask;
+    const uint32_t l = (uint32_t)lane();
+    uint32_t w2 = 0;
+    for (uint32_t s0 = 0; s0 < nb; s0 += 64u) {
+        const uint32_t sl = s0 + l;
+        const u64 e = sl < nb ? ent[sl] : 0ull;
+        const bool occ = (e & fo) != 0ull;
+        const u64 m = __ballot(occ);
+        if (occ) {
+            const u64 key = keys[(uint32_t)((e & kRtData) >> 32)], stamp = sbase | (u64)(w2 + (uint32_t)__popcll(m & ((1ull << l) - 1ull)));
+            u64 i = mix64(key) & L.gmask;
+            for (;;) {
+                u64 k = L.gkey[i];
+                if (k == kNone64) { k = atomicCAS(&L.gkey[i], kNone64, key); if (k == kNone64) k = key; }
+                if (k == key) { atomicMin(&L.gstamp[i], stamp); break; }
+                i = (i + 1ull) & L.gmask;
+            }
         }
+        w2 += (uint32_t)__popcll(m);
     }
-    if (w2 >= (1u << 24)) atomicOr(L.fail, (uint32_t)TIE_F_SLOTS);
-    if (w2) atomicMax(L.last_put, sbase | (u64)(w2 - 1u));
+    if (l == 0u) {
+        if (w2 >= (1u << 24)) atomicOr(L.fail, (uint32_t)TIE_F_SLOTS);
+        if (w2) atomicMax(L.last_put, sbase | (u64)(w2 - 1u));
+    }
 }
 // the stamp table into one of twice the size
 __global__ __launch_bounds__(256) void k_stamp_rehash(const u64* __restrict__ ok, const u64* __restrict__ os, u64 ocap, u64* __restrict__ nk, u64* __restrict__ ns, u64 nmask) {
