@@ -354,9 +354,10 @@ def run_end_to_end(args, wl, host_batches, contig, ref):
         bases1 = int(sum(hb["n_bases"] for hb in host_batches[:n1]))
         common = ["-b"] + wl["cli"] + ["-K", str(args.batch), "-B", "200M"]
 
-        def run(cmd, out_path):
+        def run(cmd, out_path, env=None):
+            time.sleep(1.0)   # (the kernel -- or the CLI's exit helper -- is still clearing the last GPU process away for 0.1 - 0.3 s after it is reaped; a run started into that pays for it in its own start-up)
             t = time.perf_counter()
-            r = subprocess.run(cmd + ["-o", out_path, fa] + [cmd_bam[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            r = subprocess.run(cmd + ["-o", out_path, fa] + [cmd_bam[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             wall = time.perf_counter() - t
             if r.returncode != 0:
                 raise SystemExit("end-to-end run failed: %s\n%s" % (" ".join(cmd), r.stderr.decode(errors="replace")[-2000:]))
@@ -375,12 +376,17 @@ def run_end_to_end(args, wl, host_batches, contig, ref):
         for _ in range(2):      # the first run also pages the file in and brings the HIP runtime up cold
             w, err_gpu = run(gpu_cmd, out_gpu)
             walls.append(w)
+        # the same run with the process's teardown INSIDE the caller's wait (MM_SYNC_EXIT=1: csrc/host/main.c leaves it to a helper that shares
+        # the address space otherwise -- queue save areas, pinned staging, the driver's mappings: nothing of the job, 0.1 - 0.2 s of the kernel's work)
+        w_sync, _ = run(gpu_cmd, out_gpu, env=dict(os.environ, MM_SYNC_EXIT="1"))
         cpu_cmd = [cpu_cli] + common + ["-t", str(threads)]
         w_cpu, err_cpu = run(cpu_cmd, out_cpu)
         cmd_bam = [bam1]
         w_cpu1, err_cpu1 = run([cpu_cli] + common + ["-t", "1"], out_cpu1)
         (md_g, sz_g), (md_c, sz_c) = digest(out_gpu), digest(out_cpu)
-        e2e = {"value": bases / min(walls) / 1e6, "unit": "Mbases/s", "wall_s": min(walls), "wall_s_first_run": walls[0], "bases": bases,
+        e2e = {"value": bases / min(walls) / 1e6, "unit": "Mbases/s", "wall_s": min(walls), "wall_s_first_run": walls[0], "wall_s_sync_exit": w_sync,
+               "exit": "the process is reaped when its output is closed; its address space (GPU queues' save areas, pinned buffers) is taken apart by a helper behind it "
+                       "(csrc/host/main.c); wall_s_sync_exit = the same run with that inside the caller's wait (MM_SYNC_EXIT=1)", "bases": bases,
                "reads": reads, "threads": threads, "cmd": "minimod freq " + " ".join(common + ["-t", str(threads)]) + " ref.fa reads.bam",
                "what": "whole child process: start, HIP initialisation, FASTA load + context kernel, BGZF/BAM decode of a %d MB file with "
                        "filter fodder, batches through host memory, finalize, %d MB of bedmethyl written" % (os.path.getsize(bam) >> 20, sz_g >> 20),
@@ -471,12 +477,18 @@ def run_e2e_big(args):
         cpu_cli = O.build_cpu_cli()
 
         def run(cmd, out_path, env=None):
-            t = time.perf_counter()
+            time.sleep(float(os.environ.get("MM_E2E_PAUSE", "1.5")))   # (the kernel goes on clearing a HIP process away after it is reaped: a run started right behind another waits for that in its own start-up, 0.2 - 0.3 s)
+            t, e0 = time.perf_counter(), time.time()
             r = subprocess.run(cmd + ["-o", out_path, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-            wall = time.perf_counter() - t
+            wall, e1 = time.perf_counter() - t, time.time()
             if r.returncode != 0:
                 raise SystemExit("end-to-end run failed: %s\n%s" % (" ".join(cmd), r.stderr.decode(errors="replace")[-2000:]))
-            return wall, r.stderr.decode(errors="replace")
+            err = r.stderr.decode(errors="replace")
+            if os.environ.get("MM_TIMELINE"):   # what lies outside the CLI's own clock: spawn -> its first mark, its last mark -> reaped
+                marks = [float(x) for x in re.findall(r"\(epoch ([0-9.]+),", err)]
+                if marks:
+                    err += "[outside] %.3f s from the spawn to the first mark, %.3f s from the last mark to the reaped child\n" % (marks[0] - e0, e1 - marks[-1])
+            return wall, err
 
         def md5(path):
             h = hashlib.md5()
@@ -491,6 +503,7 @@ def run_e2e_big(args):
         gpu_flags = os.environ.get("MM_E2E_CLI_FLAGS", "").split()   # e.g. --gpu-inflate (the GPU CLI's runs only)
         runs = [run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, og) for _ in range(2)]
         wall, err = min(runs, key=lambda x: x[0])
+        w_sync, _ = run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, og, env=dict(os.environ, MM_SYNC_EXIT="1"))   # (teardown inside the caller's wait: main.c)
         if os.environ.get("MM_E2E_STDERR"):   # the CLI's own log of the timed run (its lines carry the time since start)
             with open(os.environ["MM_E2E_STDERR"], "w") as f:
                 f.write(err)
@@ -502,7 +515,8 @@ def run_e2e_big(args):
         res = {"metric": "minimod freq end to end, steady state", "unit": "Mbases/s", "bases": bases, "reads": n_reads, "reference_bases": region,
                "bam_bytes": os.path.getsize(bam), "threads": threads, "cores": cores, "input_build_s": t_build,
                "gpu_cli": {"value": bases / wall / 1e6, "value_without_startup": bases / max(wall - startup, 1e-9) / 1e6, "wall_s": wall,
-                           "wall_s_first_run": runs[0][0], "startup_s": startup, "stages_s": st,
+                           "wall_s_first_run": runs[0][0], "wall_s_sync_exit": w_sync, "startup_s": startup, "stages_s": st,
+                           "exit": "reaped when the output is closed; the address space is taken apart by a helper behind the process (csrc/host/main.c); wall_s_sync_exit: MM_SYNC_EXIT=1, the teardown inside the caller's wait",
                            "launches": {"launches": int(m.group(1)), "batches": int(m.group(2)), "with_k_stream_reads": int(m.group(3))} if m else None,
                            "cmd": "minimod freq " + " ".join(gpu_flags + common) + " ref.fa reads.bam",
                            "what": "whole child process (start, HIP initialisation, FASTA load + context kernels, BGZF/BAM decode, batches through "
@@ -540,7 +554,10 @@ def run_e2e_big(args):
             for _ in range(3):
                 wa, ea = run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, ov)
                 wb, eb = run([cli, "freq"] + gpu_flags + (["--canonical-order"] if tied else []) + common, ov, env=venv)
-                pairs.append({"default": {"wall_s": wa, "stages_s": _stage_timers(ea)}, name.strip(): {"wall_s": wb, "stages_s": _stage_timers(eb)}})
+                def outside(e):   # (MM_TIMELINE=1: spawn -> first mark, last mark -> reaped, and the CLI's own clock)
+                    m1, m2 = re.search(r"\[outside\] ([0-9.]+) s from the spawn to the first mark, ([0-9.]+) s", e), re.search(r"Real time: ([0-9.]+) sec", e)
+                    return {"before_main_s": float(m1.group(1)), "after_last_word_s": float(m1.group(2)), "real_time_s": float(m2.group(1)) if m2 else None} if m1 else None
+                pairs.append({"default": {"wall_s": wa, "stages_s": _stage_timers(ea), "outside": outside(ea)}, name.strip(): {"wall_s": wb, "stages_s": _stage_timers(eb), "outside": outside(eb)}})
             res.setdefault("env_variants", {})[name.strip()] = {"env": ev.strip(), "pairs": pairs, "byte_identical_to_cpu": md5(ov) == md5(oc)}
         if args.e2e_devices:
             # one BAM, N worker processes (csrc/host/freq_main.c run_devices: shares cut at 64 kb-aligned positions, every worker reads its share

@@ -166,7 +166,9 @@ int32_t mm_hip_warm(int32_t device) {
         hipStream_t st = nullptr;
         int* d = nullptr;
         int v = 0;
-        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&d, 64) == hipSuccess &&
+        // (on the null stream, whose queue the handles' synchronous copies need anyway: a stream of its own here was one more hardware queue --
+        // 8 - 12 ms to make, 173 MB of host memory for its waves' saved state, tools/exit_probe_streams.hip)
+        ok = (!std::getenv("MM_WARM_OWN_STREAM") || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) && hipMalloc((void**)&d, 64) == hipSuccess &&
              hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st) == hipSuccess;
         if (ok) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st, d); ok = hipStreamSynchronize(st) == hipSuccess; }
         if (d) (void)hipFree(d);

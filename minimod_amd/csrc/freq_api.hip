@@ -197,8 +197,12 @@ int dev_alloc(mm_freq* h, void** p, size_t bytes) {
     return 0;
 }
 
+static double g_grow_seconds = 0;   // (MM_TIMELINE: what the allocations inside a launch took)
 int grow(mm_freq* h, void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
+    static const bool tl = std::getenv("MM_TIMELINE") != nullptr;
+    struct Timer { bool on; timespec a; Timer(bool o) : on(o) { if (on) clock_gettime(CLOCK_MONOTONIC, &a); }
+                   ~Timer() { if (on) { timespec b; clock_gettime(CLOCK_MONOTONIC, &b); g_grow_seconds += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); } } } timer(tl);
     size_t ncap = std::max(need + need / 4, (size_t)4096);
     if (*p) { (void)hipFree(*p); h->device_bytes -= (int64_t)*cap; }
     *p = nullptr; *cap = 0;
@@ -406,7 +410,18 @@ __global__ void k_rebase_reads(mm_read_t* reads, int32_t n, uint64_t cigar_words
 }
 
 // bases_hint: the bases of the launch's reads when the caller knows them (host batches), else 0
+static int launch_k1_body(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t bases_hint);
 int launch_k1(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t bases_hint = 0) {
+    static const bool tl = std::getenv("MM_TIMELINE") != nullptr;
+    static int calls = 0;
+    if (!tl || calls >= 6) return launch_k1_body(h, s, b, st, bases_hint);
+    auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double t0 = now(), g0 = g_grow_seconds;
+    const int r = launch_k1_body(h, s, b, st, bases_hint);
+    std::fprintf(stderr, "[timeline] launch %d of the handle (%d reads): %.4f s on the host, %.4f of them in device allocations\n", ++calls, b->n_reads, now() - t0, g_grow_seconds - g0);
+    return r;
+}
+static int launch_k1_body(mm_freq* h, Slot& s, const mm_batch_t* b, hipStream_t st, uint64_t bases_hint) {
     DevParams p = base_params(h);
     p.reads = b->reads; p.cigar = b->cigar; p.seq = b->seq; p.mm = b->mm; p.ml = b->ml; p.order = b->order;
     p.n_reads = b->n_reads;
@@ -854,7 +869,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     const double tl_a0 = tl_now();
     double tl_a1 = tl_a0;
     double tl_last = tl_a0;
-    auto tl_step = [&](const char* what) { if (tl_on) { const double t = tl_now(); std::fprintf(stderr, "[timeline] mm_freq_create:   %-44s %.3f s\n", what, t - tl_last); tl_last = t; } };
+    auto big_maps = []() {   // (MM_TIMELINE: the mappings of 64 MB or more that are resident, counted from /proc/self/smaps)
+        int n = 0; double mb = 0; char line[512]; unsigned long kb;
+        if (FILE* f = std::fopen("/proc/self/smaps", "r")) { while (std::fgets(line, sizeof line, f)) if (std::sscanf(line, "Rss: %lu kB", &kb) == 1 && kb >= 65536) { n++; mb += (double)kb / 1024.0; } std::fclose(f); }
+        std::fprintf(stderr, "[timeline]          %d big mappings, %.0f MB resident in them\n", n, mb);
+    };
+    auto tl_step = [&](const char* what) { if (tl_on) { const double t = tl_now(); std::fprintf(stderr, "[timeline] mm_freq_create:   %-44s %.3f s\n", what, t - tl_last); if (std::atoi(std::getenv("MM_TIMELINE")) >= 2) big_maps(); tl_last = tl_now(); } };
     {
         int nb = 0;
         hipError_t e = hipSuccess;

@@ -32,6 +32,6 @@ int main(int argc, char *argv[]) {
     fprintf(stderr, "\n[%s] Real time: %.3f sec; CPU time: %.3f sec; Peak RAM: %.3f GB\n\n", __func__, mmh_realtime() - realtime0,
             mmh_cputime(), mmh_peakrss() / 1024.0 / 1024.0 / 1024.0);
     /* (freq_main.c, run_body's end) the output is complete and flushed: no exit handlers, the process's death frees what is left */
-    if (!getenv("MM_FULL_TEARDOWN")) { fflush(NULL); _exit(ret); }
+    if (!getenv("MM_FULL_TEARDOWN")) { fflush(NULL); mmh_leave_teardown_behind();   /* (exitpath.c: a process that held the GPU is reaped at once, its address space is taken apart behind it) */ _exit(ret); }
     return ret;
 }

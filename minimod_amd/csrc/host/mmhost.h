@@ -162,6 +162,8 @@ int mmh_tie_import2(mmh_tie_t *t, const void *keys, const uint32_t *hash, int64_
 void mmh_tie_keys_from_rows(const mm_row_t *rows, const uint32_t *seq, int64_t n, void *keys16);
 void mmh_tie_destroy(mmh_tie_t *t);
 
+extern int mmh_gpu_in_use;   /* set once the HIP runtime is up in this process (exitpath.c) */
+void mmh_leave_teardown_behind(void);   /* just before _exit(): the address space outlives the process in a helper that holds nothing else (exitpath.c) */
 int mmh_freq_main(int argc, char **argv);
 int mmh_view_main(int argc, char **argv);
 int mmh_summary_main(int argc, char **argv);   /* host only */

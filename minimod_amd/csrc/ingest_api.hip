@@ -54,7 +54,7 @@ struct mm_ingest {
     uint64_t next_seq = 0;         // groups numbered by mm_ingest_inflate
     uint64_t flat_seq = 0;         // the next group to be flattened for the first time
     int prio_least = 0;
-    std::thread slot_maker;        // makes the slots behind the first while the caller's reader stages its first group
+    std::vector<std::thread> slot_makers;   // make the slots behind the first while the caller's reader stages its first group (a thread a slot: the pinning, the queue and the allocations of one slot are mostly the kernel's work and run beside another's)
     CodeTab* d_codes = nullptr;    // mm_ingest_batch_codes (made at its first call)
     CodeTab* h_codes = nullptr;    // pinned
 };
@@ -66,7 +66,8 @@ static hipError_t slot_alloc(mm_ingest* h, GSlot& s) {
     // the lowest priority: the inflate's workgroups run for milliseconds; the chain's and the freq path's kernels get the CUs they leave first
     // (a stream with a CU mask that keeps the inflate off a few CUs -- hipExtStreamCreateWithCUMask -- hung the first launch on this
     // pool's boxes: not used.  Instead the inflate's workgroups are sized so that four of them leave room on every CU, below.)
-    SCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, h->prio_least));
+    if (std::getenv("MM_INGEST_PLAIN_STREAMS")) SCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    else SCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, h->prio_least));
     for (auto& e : s.ev) SCHK(hipEventCreate(&e));
     SCHK(hipEventCreate(&s.ev_f0)); SCHK(hipEventCreate(&s.ev_done));
     SCHK(hipHostMalloc((void**)&s.h_c, h->o.max_cbytes + 64, hipHostMallocDefault));
@@ -95,7 +96,7 @@ static std::mutex g_live_mu;
 static std::vector<mm_ingest*> g_live;
 static void join_slot_makers() {
     std::lock_guard<std::mutex> lk(g_live_mu);
-    for (mm_ingest* h : g_live) if (h->slot_maker.joinable()) h->slot_maker.join();
+    for (mm_ingest* h : g_live) for (std::thread& t : h->slot_makers) if (t.joinable()) t.join();
 }
 static void live_add(mm_ingest* h) {
     static bool registered = false;
@@ -153,7 +154,14 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     h->max_records = (uint32_t)((h->o.head_room + max_ob) / 48);
     const bool tl = std::getenv("MM_TIMELINE") != nullptr;
     auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    auto big_maps = [&](const char* where) {   // (MM_TIMELINE=2: the resident mappings of 64 MB or more)
+        if (!tl || std::atoi(std::getenv("MM_TIMELINE")) < 2) return;
+        int n = 0; double mb = 0; char line[512]; unsigned long kb;
+        if (FILE* f = std::fopen("/proc/self/smaps", "r")) { while (std::fgets(line, sizeof line, f)) if (std::sscanf(line, "Rss: %lu kB", &kb) == 1 && kb >= 65536) { n++; mb += (double)kb / 1024.0; } std::fclose(f); }
+        std::fprintf(stderr, "[timeline]          mm_ingest_create, %s: %d big mappings, %.0f MB resident in them\n", where, n, mb);
+    };
     const double t0 = now();
+    big_maps("start");
     ICHK(hipSetDevice(h->device));
     hipDeviceProp_t prop;
     ICHK(hipGetDeviceProperties(&prop, h->device));
@@ -167,6 +175,7 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     ICHK(hipMemset(h->d_cursor, 0, 2 * sizeof(Cursor)));
     for (int k = 0; k < 2; k++) ICHK(hipMalloc((void**)&h->d_tail[k], h->H));
     const double t1 = now();
+    big_maps("runtime + streams");
     h->slots = std::vector<GSlot>((size_t)h->o.group_slots);
     h->prio_least = prio_least;
     // the FIRST slot here; the others (48 MiB of pinned staging and ~230 MB of device memory each: 25 - 40 ms) on a thread of their own, beside the
@@ -174,6 +183,7 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     ICHK(slot_alloc(h, h->slots[0]));
     h->slots[0].ready.store(1);
     const double t2 = now();
+    big_maps("first slot");
     h->arenas.resize((size_t)h->o.arenas);
     for (Arena& a : h->arenas) {
         // a batch is made of about arena_bytes of decoded stream, and a BAM's records are mostly sequence (a nibble a base) and
@@ -197,10 +207,13 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
             ICHK(hipMalloc((void**)&a.name_off, sizeof(uint64_t) * a.cap_reads));
         }
     }
+    big_maps("arenas");
     live_add(h);
-    if (h->slots.size() > 1) h->slot_maker = std::thread([h]() {
-        for (size_t i = 1; i < h->slots.size(); i++) h->slots[i].ready.store(slot_alloc(h, h->slots[i]) == hipSuccess ? 1 : -1);
-    });
+    if (std::getenv("MM_INGEST_SERIAL_SLOTS")) {
+        if (h->slots.size() > 1) h->slot_makers.emplace_back([h]() { for (size_t i = 1; i < h->slots.size(); i++) h->slots[i].ready.store(slot_alloc(h, h->slots[i]) == hipSuccess ? 1 : -1); });
+    } else {
+        for (size_t i = 1; i < h->slots.size(); i++) h->slot_makers.emplace_back([h, i]() { h->slots[i].ready.store(slot_alloc(h, h->slots[i]) == hipSuccess ? 1 : -1); });
+    }
     ICHK(hipDeviceSynchronize());
     if (tl) std::fprintf(stderr, "[timeline] mm_ingest_create: runtime + streams %.3f s, group slots %.3f s, arenas %.3f s\n", t1 - t0, t2 - t1, now() - t2);
     return h;
@@ -209,7 +222,7 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
 void mm_ingest_destroy(mm_ingest_t* h) {
     if (!h) return;
     live_remove(h);
-    if (h->slot_maker.joinable()) h->slot_maker.join();
+    for (std::thread& t : h->slot_makers) if (t.joinable()) t.join();
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (GSlot& s : h->slots) {
