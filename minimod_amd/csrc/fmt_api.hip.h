@@ -77,7 +77,9 @@ mm_fmt_t* mm_fmt_create(const mm_fmt_opts_t* o, const char* const* contig_names,
         const size_t l = strnlen(codes[c], MM_CODE_LEN - 1);
         memcpy(&cs[(size_t)c * MM_CODE_LEN], codes[c], l); cl[(size_t)c] = (uint32_t)l;
     }
-    bool ok = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) == hipSuccess;
+    // (the NULL stream: a stream of its own is one more hardware queue -- 8 - 12 ms to make at the one moment of a run when nothing else is under way,
+    // 173 MB of host memory for its waves' saved state; MM_FMT_OWN_STREAM=1 makes one all the same)
+    bool ok = !std::getenv("MM_FMT_OWN_STREAM") || hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->d_names, names.size()) == hipSuccess && hipMalloc((void**)&f->d_name_off, 4 * off.size()) == hipSuccess && hipMalloc((void**)&f->d_name_len, 4 * len.size()) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->d_codes, cs.size()) == hipSuccess && hipMalloc((void**)&f->d_code_len, 4 * cl.size()) == hipSuccess;
     ok = ok && hipMemcpy(f->d_names, names.data(), names.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(f->d_name_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice) == hipSuccess &&
@@ -144,7 +146,7 @@ float mm_fmt_last_kernel_ms(const mm_fmt_t* f) { return f ? f->last_ms : -1.f; }
 void mm_fmt_destroy(mm_fmt_t* f) {
     if (!f) return;
     (void)hipSetDevice(f->o.device);
-    if (f->st) (void)hipStreamSynchronize(f->st);
+    (void)hipStreamSynchronize(f->st);
     void* ps[] = {f->d_names, f->d_name_off, f->d_name_len, f->d_codes, f->d_code_len, f->d_rows, f->d_len, f->d_tiles, f->d_text};
     for (void* p : ps) if (p) (void)hipFree(p);
     free(f->h_text[0]); free(f->h_text[1]);

@@ -275,14 +275,21 @@ static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows,
             fo.abi_version = MM_TIE_ABI_VERSION; fo.device = device; fo.bedmethyl = bedmethyl; fo.insertions = insertions; fo.haplotypes = haplotypes;
             fo.n_contigs = hdr->n_targets; fo.n_codes = n_codes;
             char ferr[256];
+            const double tc = mmh_realtime();
             f = mm_fmt_create(&fo, (const char *const *)hdr->target_name, codes, ferr, sizeof ferr);
             f_key = key;
+            if (getenv("MM_TIMELINE")) fprintf(stderr, "[timeline] output: mm_fmt_create %.3f s\n", mmh_realtime() - tc);
             if (!f) MMH_WARNING("the device-side row formatter could not be set up (%s): the host threads format", ferr);
         }
         if (f) {
             if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
             /* a piece's text is written by a thread of its own while the device makes the next piece's (the handle's two buffers take turns) */
-            const int64_t piece = (int64_t)1 << 20;
+            /* (pieces of 128 k rows, ~9 MB of text: the copy out of the device, the write of the piece before and the kernels of the piece behind
+             * overlap from the second piece on -- with pieces of a million rows an output of 770 k rows was one piece and nothing overlapped) */
+            const char *pe = getenv("MM_FMT_PIECE");
+            const int64_t piece = pe && atoll(pe) > 0 ? atoll(pe) : (int64_t)1 << 17;
+            const int tl = getenv("MM_TIMELINE") != NULL;
+            double t_fmt = 0, t_join = 0;
             int ok = 1, writing = 0;
             pthread_t wt;
             fmt_wjob_t job;
@@ -290,15 +297,20 @@ static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows,
             for (int64_t i = 0; i < n && ok; i += piece) {
                 const int64_t m = n - i < piece ? n - i : piece;
                 const char *text = NULL;
+                const double tf = mmh_realtime();
                 const int64_t nb = mm_fmt_rows(f, rows + i, m, &text);
+                t_fmt += mmh_realtime() - tf;
                 if (nb < 0) { ok = 0; if (i == 0) break; MMH_ERROR("the device-side row formatter failed: %s", mm_strerror((int32_t)nb)); exit(EXIT_FAILURE); }
+                const double tj = mmh_realtime();
                 if (writing) { pthread_join(wt, NULL); writing = 0; if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
+                t_join += mmh_realtime() - tj;
                 job.fp = fp; job.p = text; job.n = (size_t)nb; job.err = 0;
                 if (i + piece < n && pthread_create(&wt, NULL, fmt_write_main, &job) == 0) writing = 1;
                 else { (void)fmt_write_main(&job); if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
                 fmt_device_ms += mm_fmt_last_kernel_ms(f); fmt_device_rows += m;
             }
             if (writing) { pthread_join(wt, NULL); if (job.err) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); } }
+            if (tl) fprintf(stderr, "[timeline] output: %ld rows in pieces of %ld: mm_fmt_rows %.3f s, waiting for the writer %.3f s\n", (long)n, (long)piece, t_fmt, t_join);
             if (ok) return;
             MMH_WARNING("%s", "the device-side row formatter failed on its first piece: the host threads format");
         }
