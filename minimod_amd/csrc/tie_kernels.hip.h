@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void k_grow_commit(const uint32_t* __restrict_
 // kernel boundary gives the next launch's loads.  It leaves the table as the host's loop would find it at that point and says where it stopped.
 struct SmallState { uint32_t C, tcur, finished, fail; unsigned long long done; };
 __device__ __forceinline__ void wg_phase() { __threadfence(); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// a workgroup's flag, read by everybody BEFORE anybody may go on and clear it for the next round: without the second barrier thread 0 -- one wavefront ahead of
+// the others -- cleared the flag while a slower wavefront had not read it yet; that wavefront left the loop alone, and the barriers behind paired up wrongly
+// (seen only with other processes' kernels on the device: tests/test_hip_fuzz_gpu.py's seven campaigns at once, one run in four)
+__device__ __forceinline__ bool wg_flag(const uint32_t* f) { const bool v = *(const volatile uint32_t*)f != 0u; __syncthreads(); return v; }
 __global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restrict__ hash, u64 n, int put_after_last, uint32_t Cstop, uint32_t* tab0, uint32_t* tab1,
                                                        uint32_t* cur, uint32_t* stp, uint32_t* land, uint32_t* pred, u64* word, u64* tw, SmallState* out, unsigned long long* counts) {
     __shared__ uint32_t sh_flag[2];   // changed / moved (or failed)
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restric
                 }
                 n_rounds++;
                 wg_phase();
-                if (!sh_flag[0]) break;
+                if (!wg_flag(&sh_flag[0])) break;
             }
             done = hi64;
         }
@@ -289,9 +293,9 @@ __global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restric
                     }
                     n_rounds++;
                     wg_phase();
-                    if (!sh_flag[0]) break;
+                    if (!wg_flag(&sh_flag[0])) break;
                 }
-                if (sh_flag[1]) { fail = 1u; break; }
+                if (wg_flag(&sh_flag[1])) { fail = 1u; break; }
                 if (t == 0) sh_flag[1] = 0u;
                 wg_phase();
                 for (uint32_t s = t; s < C; s += T) {
@@ -299,8 +303,7 @@ __global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restric
                     if (land[s] != cur[s]) { land[s] = cur[s]; sh_flag[1] = 1u; }
                 }
                 wg_phase();
-                const bool moved = sh_flag[1] != 0u;
-                wg_phase();   // (everybody has read the flag before the next pass clears it)
+                const bool moved = wg_flag(&sh_flag[1]);
                 if (!moved) break;
             }
             if (fail) break;

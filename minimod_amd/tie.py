@@ -87,6 +87,7 @@ class TieReplay(object):
         rows = np.ascontiguousarray(rows)
         perm = np.zeros(max(1, len(rows)), np.uint32)
         r = self.L.mm_tie_order_rows(self.h, rows.ctypes.data, len(rows), perm.ctypes.data)
+        self.last_rc = int(r)
         return perm[:len(rows)] if r == 0 else None
 
     def sequence(self):

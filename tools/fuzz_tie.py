@@ -77,7 +77,7 @@ def run(seed):
         host = np.ascontiguousarray(rows.copy())
         hrc = L.mmh_tie_order_rows_mt(ht, pool, host.ctypes.data, len(host))
         if perm is None or hrc != 0:
-            out = "gave up: device %s (bits 0x%x), host rc %d" % (perm is None, dt.failed(), hrc)
+            out = "gave up: device %s (bits 0x%x, rc %d), host rc %d" % (perm is None, dt.failed(), getattr(dt, "last_rc", 0), hrc)
             if (perm is None) != (hrc != 0) and not (dt.failed() & 4):   # (a haplotype tag above 61 is the device's own limit)
                 out = "ONE SIDE " + out
         else:
