@@ -200,7 +200,11 @@ __device__ __forceinline__ void wg_phase() { __threadfence(); __syncthreads(); _
 // a workgroup's flag, read by everybody BEFORE anybody may go on and clear it for the next round: without the second barrier thread 0 -- one wavefront ahead of
 // the others -- cleared the flag while a slower wavefront had not read it yet; that wavefront left the loop alone, and the barriers behind paired up wrongly
 // (seen only with other processes' kernels on the device: tests/test_hip_fuzz_gpu.py's seven campaigns at once, one run in four)
+#ifdef MM_TIE_RACY_FLAGS   // (diagnostic build: the race as it was, to show that tests/test_hip_tie_gpu.py::test_small_tables_with_a_busy_device finds it)
+__device__ __forceinline__ bool wg_flag(const uint32_t* f) { return *(const volatile uint32_t*)f != 0u; }
+#else
 __device__ __forceinline__ bool wg_flag(const uint32_t* f) { const bool v = *(const volatile uint32_t*)f != 0u; __syncthreads(); return v; }
+#endif
 __global__ __launch_bounds__(1024) void k_small_epochs(const uint32_t* __restrict__ hash, u64 n, int put_after_last, uint32_t Cstop, uint32_t* tab0, uint32_t* tab1,
                                                        uint32_t* cur, uint32_t* stp, uint32_t* land, uint32_t* pred, u64* word, u64* tw, SmallState* out, unsigned long long* counts) {
     __shared__ uint32_t sh_flag[2];   // changed / moved (or failed)

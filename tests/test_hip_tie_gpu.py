@@ -79,6 +79,33 @@ def test_random_sizes_and_tie_shapes(seed):
         assert (hs == ds).all() and (hf == df).all(), (n, pal, shape)
 
 
+def test_small_tables_with_a_busy_device():
+    """k_small_epochs is ONE workgroup whose wavefronts agree through flags in LDS: with other processes' kernels on the device its wavefronts drift apart,
+    and a flag read without a barrier behind the read gave wrong orders there (found by the seven fuzz campaigns running at once, one run in four; a build
+    with -DMM_TIE_RACY_FLAGS has the race back).  Four child processes keep the device busy -- orderings of 300 000 keys, whose kernels fill it -- while this
+    one checks 400 small ones against the host's serial replay."""
+    import subprocess
+    import sys
+    busy = ("import sys, numpy as np\nsys.path.insert(0, %r)\nfrom tests.test_hip_tie_gpu import _both\nrng = np.random.default_rng(int(sys.argv[1]))\nfirst = True\n"
+            "while True:\n    n = 300000; _both(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32), rng.integers(0, n // 3, n).astype(np.int64), 0)\n"
+            "    if first: print('ready', flush=True); first = False\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    kids = [subprocess.Popen([sys.executable, "-c", busy, str(k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(4)]
+    try:
+        for k in kids:
+            assert k.stdout.readline().strip() == b"ready"
+        rng = np.random.default_rng(77)
+        for i in range(400):
+            n = int(rng.integers(50, 6300))
+            h = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+            sk = rng.integers(0, max(2, n // 3), n).astype(np.int64)
+            hs, hf, ds, df, _ = _both(h, sk, i & 1)
+            assert (hs == ds).all() and (hf == df).all(), (i, n)
+    finally:
+        for k in kids:
+            k.kill()
+            k.wait()
+
+
 def test_hashes_of_real_key_strings():
     """X31 of 'chr1\\t<pos>\\t<strand>\\tm|h\\t0\\t-1' over neighbouring positions: the hashes differ in their low digits' weights only, the
     probe paths are long and crowded -- what a two-code run hands the table."""
