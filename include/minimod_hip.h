@@ -261,6 +261,12 @@ const char *mm_freq_code_name(const mm_freq_t *h, int32_t code);
  * order.  *rows is owned by the handle and valid until the next finalize/destroy.  Returns the row count or
  * -MM_E_*.  Counters are left intact (more batches may follow). */
 int64_t mm_freq_finalize(mm_freq_t *h, const mm_row_t **rows);
+/* The same rows, left WHERE THEY ARE MADE when every one of them comes from the dense counters (no haplotype planes, nothing on the
+ * side lists -- a plain freq run): *device_rows is then the handle's array in GPU memory (in output order, valid until the next
+ * finalize / destroy) and *rows is NULL -- a caller that formats on the device (mm_fmt_rows_device, include/minimod_tie.h) never
+ * brings the rows to the host (print_freq_output's walk over the map, src/mod.c:644-728, becomes two kernels and no copy).
+ * Otherwise *device_rows is NULL and *rows is what mm_freq_finalize returns.  Returns the row count or -MM_E_*. */
+int64_t mm_freq_finalize_device(mm_freq_t *h, const mm_row_t **rows, const mm_row_t **device_rows);
 
 /* Multi-GPU halo exchange: device pointer and element count (uint64 each) of the
  * counter slab covering [begin, begin+len) of an interval, plane-major: for plane, for strand: len words.

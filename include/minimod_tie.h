@@ -90,6 +90,8 @@ typedef struct mm_fmt_opts {
 typedef struct mm_fmt mm_fmt_t;
 mm_fmt_t *mm_fmt_create(const mm_fmt_opts_t *opts, const char *const *contig_names, const char *const *codes, char *err, size_t err_len);
 int64_t mm_fmt_rows(mm_fmt_t *f, const mm_row_t *rows, int64_t n, const char **text);   /* bytes of text, or -MM_E_* */
+/* ... of rows that are in GPU memory already (mm_freq_finalize_device's, include/minimod_hip.h; any part of them): read where they lie */
+int64_t mm_fmt_rows_device(mm_fmt_t *f, const mm_row_t *device_rows, int64_t n, const char **text);
 float mm_fmt_last_kernel_ms(const mm_fmt_t *f);   /* device time of the last call's kernels (length, scan, write) */
 void mm_fmt_destroy(mm_fmt_t *f);
 

@@ -46,7 +46,7 @@ struct mm_fmt {
     mm_fmt_opts_t o;
     hipStream_t st = nullptr;
     char* d_names = nullptr; uint32_t *d_name_off = nullptr, *d_name_len = nullptr; char* d_codes = nullptr; uint32_t* d_code_len = nullptr;
-    mm_row_t* d_rows = nullptr; u64* d_len = nullptr; u64* d_tiles = nullptr; size_t cap_rows = 0;
+    mm_row_t* d_rows = nullptr; u64* d_len = nullptr; u64* d_tiles = nullptr; size_t cap_rows = 0, cap_own_rows = 0;
     char* d_text = nullptr; size_t cap_text = 0;
     char* h_text[2] = {nullptr, nullptr}; size_t cap_htext[2] = {0, 0}; int turn = 0;   // two host buffers taken in turn (plain memory: pinning 100 MB costs more than the copy)
     float last_ms = 0.f;
@@ -89,26 +89,36 @@ mm_fmt_t* mm_fmt_create(const mm_fmt_opts_t* o, const char* const* contig_names,
     return f;
 }
 
-int64_t mm_fmt_rows(mm_fmt_t* f, const mm_row_t* rows, int64_t n, const char** text) {
+static int64_t fmt_rows_impl(mm_fmt_t* f, const mm_row_t* rows, bool on_device, int64_t n, const char** text);
+int64_t mm_fmt_rows(mm_fmt_t* f, const mm_row_t* rows, int64_t n, const char** text) { return fmt_rows_impl(f, rows, false, n, text); }
+int64_t mm_fmt_rows_device(mm_fmt_t* f, const mm_row_t* device_rows, int64_t n, const char** text) { return fmt_rows_impl(f, device_rows, true, n, text); }
+static int64_t fmt_rows_impl(mm_fmt_t* f, const mm_row_t* rows, bool on_device, int64_t n, const char** text) {
     if (!f || n < 0 || (n > 0 && !rows) || !text) return -MM_E_ARG;
     *text = "";
     if (n == 0) return 0;
     if (hipSetDevice(f->o.device) != hipSuccess) return -MM_E_HIP;
     hipStream_t st = f->st;
     if ((size_t)n > f->cap_rows) {
-        if (f->d_rows) { (void)hipFree(f->d_rows); (void)hipFree(f->d_len); (void)hipFree(f->d_tiles); f->d_rows = nullptr; f->d_len = nullptr; f->d_tiles = nullptr; f->cap_rows = 0; }
+        if (f->d_len) { (void)hipFree(f->d_len); (void)hipFree(f->d_tiles); f->d_len = nullptr; f->d_tiles = nullptr; f->cap_rows = 0; }
         const size_t cap = (size_t)n + (size_t)n / 8 + 1024;
-        if (hipMalloc((void**)&f->d_rows, sizeof(mm_row_t) * cap) != hipSuccess || hipMalloc((void**)&f->d_len, 8 * cap) != hipSuccess || hipMalloc((void**)&f->d_tiles, 8 * (cap / kScanTile + 4)) != hipSuccess) return -MM_E_NOMEM;
+        if (hipMalloc((void**)&f->d_len, 8 * cap) != hipSuccess || hipMalloc((void**)&f->d_tiles, 8 * (cap / kScanTile + 4)) != hipSuccess) return -MM_E_NOMEM;
         f->cap_rows = cap;
     }
+    if (!on_device && (size_t)n > f->cap_own_rows) {   // (rows that are on the device already are read where they lie)
+        if (f->d_rows) { (void)hipFree(f->d_rows); f->d_rows = nullptr; f->cap_own_rows = 0; }
+        const size_t cap = (size_t)n + (size_t)n / 8 + 1024;
+        if (hipMalloc((void**)&f->d_rows, sizeof(mm_row_t) * cap) != hipSuccess) return -MM_E_NOMEM;
+        f->cap_own_rows = cap;
+    }
+    const mm_row_t* const src = on_device ? rows : (const mm_row_t*)f->d_rows;
     FmtTables T;
     T.names = f->d_names; T.name_off = f->d_name_off; T.name_len = f->d_name_len; T.codes = f->d_codes; T.code_len = f->d_code_len;
     T.n_contigs = f->o.n_contigs; T.n_codes = f->o.n_codes; T.bedmethyl = f->o.bedmethyl; T.insertions = f->o.insertions; T.haplotypes = f->o.haplotypes;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    if (hipMemcpyAsync(f->d_rows, rows, sizeof(mm_row_t) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return -MM_E_HIP;
+    if (!on_device && hipMemcpyAsync(f->d_rows, rows, sizeof(mm_row_t) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return -MM_E_HIP;
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(k_fmt_len, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, (const mm_row_t*)f->d_rows, (u64)n, f->d_len);
+    hipLaunchKernelGGL(k_fmt_len, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, src, (u64)n, f->d_len);
     const unsigned nt = blocks((uint64_t)n, kScanTile);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nt), dim3(256), 0, st, (const u64*)f->d_len, (u64)n, f->d_tiles);
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, f->d_tiles, (uint32_t)nt);
@@ -132,7 +142,7 @@ int64_t mm_fmt_rows(mm_fmt_t* f, const mm_row_t* rows, int64_t n, const char** t
         if (!f->h_text[tn]) return -MM_E_NOMEM;
         f->cap_htext[tn] = cap;
     }
-    hipLaunchKernelGGL(k_fmt_write, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, (const mm_row_t*)f->d_rows, (u64)n, (const u64*)f->d_len, f->d_text);
+    hipLaunchKernelGGL(k_fmt_write, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, src, (u64)n, (const u64*)f->d_len, f->d_text);
     (void)hipEventRecord(e1, st);
     if (hipMemcpyAsync(f->h_text[tn], f->d_text, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
     (void)hipEventElapsedTime(&f->last_ms, e0, e1);

@@ -1506,7 +1506,23 @@ void mm_freq_reset_counters(mm_freq_t* h) {
     h->sticky_err = 0; h->sticky_read = -1; h->sticky_ticket = -1;
 }
 
-int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
+}  // extern "C"
+namespace mmhip {   // (mmhip is the kind's own namespace, freq_kinds.h)
+__global__ __launch_bounds__(256) void k_rows_overflow(const mm_row_t* __restrict__ rows, unsigned long long n, unsigned int* __restrict__ flag) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i < n && rows[i].n_mod > rows[i].n_called) *flag = 1u;
+}
+}  // namespace mmhip
+extern "C" {
+static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_row_t** out_dev);
+int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) { return finalize_impl(h, out_rows, nullptr); }
+int64_t mm_freq_finalize_device(mm_freq_t* h, const mm_row_t** out_rows, const mm_row_t** out_dev) {
+    if (!out_rows || !out_dev) return -MM_E_ARG;
+    *out_rows = nullptr; *out_dev = nullptr;
+    return finalize_impl(h, out_rows, out_dev);
+}
+// out_dev non-null: the dense rows stay on the device unless side rows have to be merged into them on the host
+static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_row_t** out_dev) {
     if (!h || h->opts.view) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     { int r = drain(h); if (r) return r; }
@@ -1523,7 +1539,15 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
     auto overflowed = [&]() { for (const mm_row_t& r : rows) if (r.n_mod > r.n_called) return true; return false; };
     // ---- the dense counters: the device walks the positions and writes finished rows in output order (k_site_count /
     // k_site_emit: contig by name, position, strand, code plane, haplotype plane); the host copies them
-    size_t n_dense = 0;
+    size_t n_dense = 0, dense_total = 0;
+    bool dense_on_host = true;
+    auto dense_to_host = [&]() -> int {   // the dense rows were left on the device and are wanted here after all
+        if (dense_on_host) return 0;
+        dense_on_host = true;
+        rows.resize(dense_total);
+        if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * dense_total, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -MM_E_HIP;
+        return 0;
+    };
     if (h->n_counter_words > 0) {
         std::vector<int> order;
         for (int t = 0; t < h->n_contigs; t++) if (h->seg_len[t] > 0) order.push_back(t);
@@ -1568,30 +1592,47 @@ int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** out_rows) {
                         if (dev_alloc(h, (void**)&h->d_rows, sizeof(mm_row_t) * cap)) { result = -MM_E_NOMEM; break; }
                         h->cap_rows = cap;
                     }
-                    rows.resize((size_t)total);
                     if (hipMemcpyAsync(h->d_tile_offsets, to.data(), sizeof(unsigned long long) * (size_t)tiles, hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
                     hipLaunchKernelGGL(k_site_emit, dim3((unsigned)tiles), dim3(256), 0, h->stream, kp, d_segs, (int)segs.size(), h->d_tile_offsets, h->d_rows);
                     if (hipGetLastError() != hipSuccess) { result = -MM_E_HIP; break; }
-                    if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                        hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    dense_total = (size_t)total;
+                    if (out_dev) { dense_on_host = false; if (hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; } }   // (brought over below if side rows turn up)
+                    else {
+                        rows.resize((size_t)total);
+                        if (hipMemcpyAsync(rows.data(), h->d_rows, sizeof(mm_row_t) * (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                            hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
+                    }
                 }
             } while (0);
             (void)hipFree(d_segs); h->device_bytes -= (int64_t)std::max<size_t>(sizeof(SiteSeg) * segs.size(), 16);
             if (result < 0) return result;
         }
     }
-    n_dense = rows.size();
     // every row a dense one (no haplotype planes, nothing on the side table or list): done
     if (!h->opts.haplotypes && !h->opts.finalize_by_runs) {
         unsigned long long ns0 = 0;
         HIPCHK(hipMemcpy(&ns0, h->d_side_count, sizeof(ns0), hipMemcpyDeviceToHost));
         { int rc = side_compact(h); if (rc) return rc; }
         if (ns0 == 0 && h->n_base == 0) {
+            if (!dense_on_host) {   // the caller takes them from the device: the overflow check (below, on the host) as a kernel
+                unsigned int* d_flag = nullptr; unsigned int hflag = 0;
+                if (hipMalloc((void**)&d_flag, 4) != hipSuccess) return -MM_E_NOMEM;
+                bool ok = hipMemsetAsync(d_flag, 0, 4, h->stream) == hipSuccess;
+                if (ok) { hipLaunchKernelGGL(k_rows_overflow, dim3((unsigned)((dense_total + 255) / 256)), dim3(256), 0, h->stream, (const mm_row_t*)h->d_rows, (unsigned long long)dense_total, d_flag);
+                          ok = hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess; }
+                (void)hipFree(d_flag);
+                if (!ok) return -MM_E_HIP;
+                if (hflag) return -MM_E_OVERFLOW;
+                *out_dev = (const mm_row_t*)h->d_rows;
+                return (int64_t)dense_total;
+            }
             if (overflowed()) return -MM_E_OVERFLOW;
             if (out_rows) *out_rows = rows.data();
             return (int64_t)rows.size();
         }
     }
+    { int rc = dense_to_host(); if (rc) return rc; }
+    n_dense = rows.size();
     // ---- side table (K3): unique keys with their counts, compacted and ordered on the device
     size_t n_side_sorted = 0;   // rows.size() up to which the side rows are known to be in output order
     {

@@ -24,6 +24,7 @@
     int32_t mm_freq_n_codes_k##K(const mm_freq_t*); \
     const char* mm_freq_code_name_k##K(const mm_freq_t*, int32_t); \
     int64_t mm_freq_finalize_k##K(mm_freq_t*, const mm_row_t**); \
+    int64_t mm_freq_finalize_device_k##K(mm_freq_t*, const mm_row_t**, const mm_row_t**); \
     int64_t mm_freq_slab_words_k##K(const mm_freq_t*, int64_t); \
     int32_t mm_freq_slab_export_k##K(mm_freq_t*, int32_t, int64_t, int64_t, void*, void*); \
     int32_t mm_freq_slab_add_k##K(mm_freq_t*, int32_t, int64_t, int64_t, const void*, void*); \
@@ -119,6 +120,8 @@ int32_t mm_freq_n_codes(const mm_freq_t* h) { MM_FWD(h, 0, C11); }
 const char* mm_freq_code_name(const mm_freq_t* h, int32_t code) { MM_FWD(h, nullptr, C12); }
 #define C13(K) mm_freq_finalize_k##K(h->impl, rows)
 int64_t mm_freq_finalize(mm_freq_t* h, const mm_row_t** rows) { MM_FWD(h, -MM_E_ARG, C13); }
+#define C13D(K) mm_freq_finalize_device_k##K(h->impl, rows, device_rows)
+int64_t mm_freq_finalize_device(mm_freq_t* h, const mm_row_t** rows, const mm_row_t** device_rows) { MM_FWD(h, -MM_E_ARG, C13D); }
 #define C14(K) mm_freq_slab_words_k##K(h->impl, len)
 int64_t mm_freq_slab_words(const mm_freq_t* h, int64_t len) { MM_FWD(h, 0, C14); }
 #define C15(K) mm_freq_slab_export_k##K(h->impl, tid, begin, len, dst, st)

@@ -30,6 +30,7 @@
 #define mm_freq_n_codes MM_K(mm_freq_n_codes)
 #define mm_freq_code_name MM_K(mm_freq_code_name)
 #define mm_freq_finalize MM_K(mm_freq_finalize)
+#define mm_freq_finalize_device MM_K(mm_freq_finalize_device)
 #define mm_freq_slab_words MM_K(mm_freq_slab_words)
 #define mm_freq_slab_export MM_K(mm_freq_slab_export)
 #define mm_freq_slab_add MM_K(mm_freq_slab_add)

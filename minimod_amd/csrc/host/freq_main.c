@@ -261,10 +261,11 @@ static int code_names(mm_freq_t *h, const char **codes) {
 static double fmt_device_ms; static int64_t fmt_device_rows;
 typedef struct { FILE *fp; const char *p; size_t n; int err; } fmt_wjob_t;
 static void *fmt_write_main(void *arg) { fmt_wjob_t *j = (fmt_wjob_t *)arg; if (j->n && fwrite(j->p, 1, j->n, j->fp) != j->n) j->err = 1; return NULL; }
-static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, int64_t n, const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes,
+/* (drows: the same rows in GPU memory, when they never came to the host -- then the device formats, whatever their number) */
+static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows, const mm_row_t *drows, int64_t n, const mm_bam_hdr_t *hdr, const char *const *codes, int n_codes,
                                 int bedmethyl, int insertions, int haplotypes, int device) {
     const char *e = getenv("MINIMOD_FMT");
-    const int use = e ? strcmp(e, "device") == 0 : n >= 65536;
+    const int use = drows ? 1 : (e ? strcmp(e, "device") == 0 : n >= 65536);
     if (use && n > 0) {
         static mm_fmt_t *f; static int f_key = -1;
         const int key = (bedmethyl ? 1 : 0) | (insertions ? 2 : 0) | (haplotypes ? 4 : 0) | (n_codes << 3);
@@ -298,7 +299,7 @@ static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows,
                 const int64_t m = n - i < piece ? n - i : piece;
                 const char *text = NULL;
                 const double tf = mmh_realtime();
-                const int64_t nb = mm_fmt_rows(f, rows + i, m, &text);
+                const int64_t nb = drows ? mm_fmt_rows_device(f, drows + i, m, &text) : mm_fmt_rows(f, rows + i, m, &text);
                 t_fmt += mmh_realtime() - tf;
                 if (nb < 0) { ok = 0; if (i == 0) break; MMH_ERROR("the device-side row formatter failed: %s", mm_strerror((int32_t)nb)); exit(EXIT_FAILURE); }
                 const double tj = mmh_realtime();
@@ -315,6 +316,7 @@ static void print_freq_rows_any(FILE *fp, mm_pool_t *pool, const mm_row_t *rows,
             MMH_WARNING("%s", "the device-side row formatter failed on its first piece: the host threads format");
         }
     }
+    if (!rows && n > 0) { MMH_ERROR("%s", "the device-side row formatter could not be used and the rows are not in host memory"); exit(EXIT_FAILURE); }
     mmh_print_freq_rows(fp, pool, rows, n, hdr, codes, n_codes, bedmethyl, insertions, haplotypes);
 }
 
@@ -1117,9 +1119,18 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     tl_mark(realtime0, "last batch handed over");
     if (!view) {
         double ts = mmh_realtime();
-        const mm_row_t *rows = NULL;
-        int64_t nrows = mm_freq_finalize(h, &rows);
+        const mm_row_t *rows = NULL, *drows = NULL;
+        /* a plain run (one process, the fixed order or no ties, no --region) whose rows the device formats: they stay in GPU memory between the
+         * kernel that makes them and the kernels that make their text (mm_freq_finalize_device: NULL in *drows when side rows had to be merged in) */
+        const char *fe = getenv("MINIMOD_FMT");
+        const int rows_stay = !replay && !o.region && ws->fd < 0 && !(fe && strcmp(fe, "device") != 0) && !getenv("MM_ROWS_TO_HOST");
+        int64_t nrows = rows_stay ? mm_freq_finalize_device(h, &rows, &drows) : mm_freq_finalize(h, &rows);
         if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
+        if (drows && nrows < 65536 && !fe) {   /* (few rows: the worker pool formats them, and wants them here) */
+            drows = NULL;
+            nrows = mm_freq_finalize(h, &rows);
+            if (nrows < 0) { MMH_ERROR("GPU path failed: %s", mm_strerror((int32_t)nrows)); exit(EXIT_FAILURE); }
+        }
         sort_time = mmh_realtime() - ts;
         if (ws->fd >= 0) {
             /* A worker of --devices.  Its rows behind its share's end -- what its reads called past the halo, and every row
@@ -1190,7 +1201,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     while (j < n_mine && mine[j].tid == mine[i].tid) j++;
                     if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     const int64_t at = (int64_t)ftello(pf);
-                    print_freq_rows_any(pf, pool, mine + i, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
+                    print_freq_rows_any(pf, pool, mine + i, NULL, j - i, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
                     if (mmh_emit_flush() != 0 || fflush(pf) != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
                     sec[n_sec].tid = mine[i].tid; sec[n_sec].pad = 0; sec[n_sec].off = at; sec[n_sec].len = (int64_t)ftello(pf) - at;
                     n_sec++;
@@ -1247,7 +1258,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         }
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
-        print_freq_rows_any(o.out, pool, rows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
+        print_freq_rows_any(o.out, pool, rows, drows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
         if (fmt_device_rows) fprintf(stderr, "[%s] %ld rows formatted on the device (k_fmt_len + scan + k_fmt_write: %.3f ms)\n", __func__, (long)fmt_device_rows, fmt_device_ms);

@@ -61,7 +61,7 @@ class mm_interval_t(ctypes.Structure):
 
 
 EXPORTS = ["mm_freq_plan_batch", "mm_freq_ticket_batches", "mm_abi_version", "mm_strerror", "mm_freq_create", "mm_freq_submit", "mm_freq_submit_device", "mm_freq_submit_device_now",
-           "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_freq_ticket_batch", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize",
+           "mm_freq_wait", "mm_freq_host_done", "mm_freq_read_record", "mm_freq_ticket_batch", "mm_view_fetch", "mm_view_fetch_device", "mm_freq_intern_code", "mm_freq_n_codes", "mm_freq_code_name", "mm_freq_finalize", "mm_freq_finalize_device",
            "mm_freq_slab_words", "mm_freq_slab_export", "mm_freq_slab_add", "mm_freq_slab_clear", "mm_freq_slab_export_host", "mm_freq_slab_add_host", "mm_freq_slab_export_ipc", "mm_freq_slab_add_ipc",
            "mm_freq_last_kernel_ms", "mm_freq_stats_enable", "mm_freq_stats_get", "mm_freq_device_bytes", "mm_freq_launch_counts", "mm_freq_reset_counters", "mm_freq_destroy"]
 
@@ -141,6 +141,8 @@ def load_library(build=True):
     L.mm_freq_code_name.argtypes = [vp, i32]
     L.mm_freq_finalize.restype = i64
     L.mm_freq_finalize.argtypes = [vp, ctypes.POINTER(vp)]
+    L.mm_freq_finalize_device.restype = i64
+    L.mm_freq_finalize_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mm_freq_slab_words.restype = i64
     L.mm_freq_slab_words.argtypes = [vp, i64]
     for f in ("mm_freq_slab_export", "mm_freq_slab_add"):
@@ -387,6 +389,19 @@ class FreqEngine(object):
             return np.zeros(0, dtype=ROW_DTYPE)
         buf = (ctypes.c_char * (n * ROW_DTYPE.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+
+    def finalize_device(self):
+        """mm_freq_finalize_device: (rows in host memory or None, device pointer or None, n) -- exactly one of the first two when n > 0"""
+        p, d = ctypes.c_void_p(), ctypes.c_void_p()
+        n = self.L.mm_freq_finalize_device(self.h, ctypes.byref(p), ctypes.byref(d))
+        if n < 0:
+            raise MinimodHipError(-n, "mm_freq_finalize_device: " + self.L.mm_strerror(int(n)).decode())
+        if d.value:
+            return None, d.value, int(n)
+        if n == 0 or not p.value:
+            return np.zeros(0, dtype=ROW_DTYPE), None, int(n)
+        buf = (ctypes.c_char * (n * ROW_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=ROW_DTYPE).copy(), None, int(n)
 
     def code_names(self):
         return [self.L.mm_freq_code_name(self.h, i).decode() for i in range(self.L.mm_freq_n_codes(self.h))]

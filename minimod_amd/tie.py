@@ -50,6 +50,8 @@ def _lib():
         L.mm_fmt_create.argtypes = [ctypes.POINTER(mm_fmt_opts_t), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         L.mm_fmt_rows.restype = ctypes.c_int64
         L.mm_fmt_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+        L.mm_fmt_rows_device.restype = ctypes.c_int64
+        L.mm_fmt_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
         L.mm_fmt_last_kernel_ms.restype = ctypes.c_float
         L.mm_fmt_last_kernel_ms.argtypes = [ctypes.c_void_p]
         L.mm_fmt_destroy.argtypes = [ctypes.c_void_p]
@@ -141,6 +143,14 @@ class RowFormatter(object):
         if n < 0:
             raise RuntimeError("mm_fmt_rows: %d" % n)
         return ctypes.string_at(p.value, n) if n else b""
+
+    def format_device(self, device_ptr, n):
+        """rows that are in GPU memory already (mm_freq_finalize_device's): mm_fmt_rows_device"""
+        p = ctypes.c_void_p()
+        k = self.L.mm_fmt_rows_device(self.h, ctypes.c_void_p(device_ptr), int(n), ctypes.byref(p))
+        if k < 0:
+            raise RuntimeError("mm_fmt_rows_device: %d" % k)
+        return ctypes.string_at(p.value, k) if k else b""
 
     def kernel_ms(self):
         return float(self.L.mm_fmt_last_kernel_ms(self.h))

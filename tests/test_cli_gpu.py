@@ -85,6 +85,9 @@ def test_cli_device_formatter_matches_reference_golden(exp, bam, ctg, kw, exact,
         assert sorted(r.stdout.decode().splitlines()) == sorted(want.splitlines())
     else:
         assert r.stdout.decode() == want
+    # (a run without ties leaves its rows in GPU memory for the formatter, mm_freq_finalize_device; MM_ROWS_TO_HOST=1: through the host as before)
+    r2 = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MINIMOD_FMT="device", MM_ROWS_TO_HOST="1"))
+    assert r2.returncode == 0 and r2.stdout == r.stdout, r2.stderr.decode()[-2000:]
 
 
 def test_cli_tie_order_does_not_depend_on_batching(fastas):

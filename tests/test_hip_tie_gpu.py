@@ -291,4 +291,50 @@ def test_device_formatter_writes_the_reference_text(fmt):
     got = f.format(rows)
     assert got == _py_rows_text(rows, names, codes, bed, ins, hp)
     assert f.format(rows[:1]) == _py_rows_text(rows[:1], names, codes, bed, ins, hp) and f.format(rows[:0]) == b""
+    # the same rows read where they lie in GPU memory (mm_fmt_rows_device), whole and a part from the middle, between two host-side calls
+    hip = ctypes.CDLL("libamdhip64.so")
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(rows.nbytes)) == 0
+    assert hip.hipMemcpy(d, ctypes.c_void_p(rows.ctypes.data), ctypes.c_size_t(rows.nbytes), 1) == 0
+    assert f.format_device(d.value, n) == got
+    assert f.format_device(d.value + 5000 * rows.itemsize, 7000) == _py_rows_text(rows[5000:12000], names, codes, bed, ins, hp)
+    assert f.format(rows[:300]) == _py_rows_text(rows[:300], names, codes, bed, ins, hp)
     f.close()
+    assert hip.hipFree(d) == 0
+
+
+@pytest.mark.parametrize("c,ins,hap,stays", [("m[CG]", False, False, True), ("m,h", False, False, True), ("m[*],a[*]", False, False, True), ("m[CG]", True, False, False), ("m", False, True, False)],
+                         ids=["one-code", "two-codes", "star-contexts", "insertions", "haplotypes"])
+def test_rows_left_on_the_device_are_the_rows_finalize_returns(c, ins, hap, stays):
+    """mm_freq_finalize_device: a run whose rows all come from the dense counters leaves them in GPU memory (the CLI formats them there); with side rows
+    (--insertions) or haplotype planes they are merged on the host as before.  Either way: the rows of mm_freq_finalize, and their text."""
+    from minimod_amd import engine as E, tie as T
+    from oracle import pybam, oracle as O
+    from tests import test_hip_stream_gpu as S
+    from tests.hiprun import make_engine
+    rng = np.random.default_rng(4242)
+    ref = S.make_ref(rng, 120000)
+    recs = [S._mixed_read(rng, ref) for _ in range(90)]
+    if hap:
+        for r in recs:
+            r.aux += b"HPC" + bytes([int(rng.integers(1, 3))])
+    mods = O.parse_mod_codes(c)
+    th = O.parse_mod_threshes(None, len(mods))
+    eng = make_engine(mods, th, ["chrT"], [len(ref)], {"chrT": ref.encode()}, insertions=ins, haplotypes=hap)
+    eng.process(pybam.flatten(recs))
+    want = eng.finalize()
+    assert len(want) > 500
+    host, dptr, n = eng.finalize_device()
+    assert n == len(want) and (dptr is not None) == stays and (host is None) == stays
+    if stays:
+        hip = ctypes.CDLL("libamdhip64.so")
+        got = np.zeros(n, E.ROW_DTYPE)
+        assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(dptr), ctypes.c_size_t(n * E.ROW_DTYPE.itemsize), 2) == 0
+        assert got.tobytes() == want.tobytes()
+        f = T.RowFormatter(["chrT"], eng.code_names(), bedmethyl=False, insertions=ins, haplotypes=hap)
+        assert f.format_device(dptr, n) == f.format(want)
+        f.close()
+    else:
+        assert host.tobytes() == want.tobytes()
+    assert eng.finalize().tobytes() == want.tobytes()   # (and the plain call afterwards still brings them over)
+    eng.close()
