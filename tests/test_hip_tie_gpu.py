@@ -291,16 +291,7 @@ def test_device_formatter_writes_the_reference_text(fmt):
     got = f.format(rows)
     assert got == _py_rows_text(rows, names, codes, bed, ins, hp)
     assert f.format(rows[:1]) == _py_rows_text(rows[:1], names, codes, bed, ins, hp) and f.format(rows[:0]) == b""
-    # the same rows read where they lie in GPU memory (mm_fmt_rows_device), whole and a part from the middle, between two host-side calls
-    hip = ctypes.CDLL("libamdhip64.so")
-    d = ctypes.c_void_p()
-    assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(rows.nbytes)) == 0
-    assert hip.hipMemcpy(d, ctypes.c_void_p(rows.ctypes.data), ctypes.c_size_t(rows.nbytes), 1) == 0
-    assert f.format_device(d.value, n) == got
-    assert f.format_device(d.value + 5000 * rows.itemsize, 7000) == _py_rows_text(rows[5000:12000], names, codes, bed, ins, hp)
-    assert f.format(rows[:300]) == _py_rows_text(rows[:300], names, codes, bed, ins, hp)
     f.close()
-    assert hip.hipFree(d) == 0
 
 
 @pytest.mark.parametrize("c,ins,hap,stays", [("m[CG]", False, False, True), ("m,h", False, False, True), ("m[*],a[*]", False, False, True), ("m[CG]", True, False, False), ("m", False, True, False)],
@@ -327,12 +318,11 @@ def test_rows_left_on_the_device_are_the_rows_finalize_returns(c, ins, hap, stay
     host, dptr, n = eng.finalize_device()
     assert n == len(want) and (dptr is not None) == stays and (host is None) == stays
     if stays:
-        hip = ctypes.CDLL("libamdhip64.so")
-        got = np.zeros(n, E.ROW_DTYPE)
-        assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(dptr), ctypes.c_size_t(n * E.ROW_DTYPE.itemsize), 2) == 0
-        assert got.tobytes() == want.tobytes()
+        # (read where they lie, mm_fmt_rows_device: the whole array, a part from its middle, a host-side call in between)
         f = T.RowFormatter(["chrT"], eng.code_names(), bedmethyl=False, insertions=ins, haplotypes=hap)
         assert f.format_device(dptr, n) == f.format(want)
+        assert f.format_device(dptr + 100 * E.ROW_DTYPE.itemsize, 300) == f.format(want[100:400])
+        assert f.format(want[:50]) == f.format_device(dptr, 50)
         f.close()
     else:
         assert host.tobytes() == want.tobytes()
