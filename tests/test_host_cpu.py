@@ -752,3 +752,48 @@ def test_stream_kernel_fits_its_waves():
             assert f["vgpr_count"] <= (72 if lean else 80), (name, f)
             assert f["group_segment_fixed_size"] * (7 if lean else 6) <= 160 * 1024, (name, f)
     assert seen == 36
+
+
+def test_a_process_leaves_its_teardown_behind_without_holding_its_pipes():
+    """csrc/host/exitpath.c: the helper that shares a dying process's address space must not hold the process's stdout / stderr (a caller that reads them to
+    their end would wait for the helper), must see the process go and must go itself; a process that never touched the GPU makes no helper at all."""
+    import subprocess
+    import sys
+    import time
+    from minimod_amd import build as B
+    child = ("import ctypes, os, sys\n"
+             "L = ctypes.CDLL(%r)\n"
+             "big = bytearray(200 << 20)\n"
+             "for i in range(0, len(big), 4096): big[i] = 1\n"
+             "ctypes.c_int.in_dll(L, 'mmh_gpu_in_use').value = int(sys.argv[1])\n"
+             "sys.stdout.write('the last word'); sys.stdout.flush(); sys.stderr.write('and its echo'); sys.stderr.flush()\n"
+             "L.mmh_leave_teardown_behind()\n"
+             "os._exit(7)\n") % os.path.join(B.LIBDIR, "libminimod_host.so")
+
+    def helpers_of(pid_text):
+        n = 0
+        for p in os.listdir("/proc"):
+            if p.isdigit():
+                try:
+                    with open("/proc/%s/cmdline" % p, "rb") as f:
+                        cmd = f.read()
+                    with open("/proc/%s/stat" % p) as f:
+                        state = f.read().rsplit(") ", 1)[1][0]
+                except OSError:
+                    continue
+                if pid_text.encode() in cmd and state != "Z":
+                    n += 1
+        return n
+    for in_use in (1, 0):
+        tag = "exitpath-test-%d-%d" % (os.getpid(), in_use)
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-c", child, str(in_use), tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert r.returncode == 7 and r.stdout == b"the last word" and r.stderr == b"and its echo"
+        assert time.time() - t0 < 30
+        deadline = time.time() + 20
+        while helpers_of(tag) and time.time() < deadline:   # (the helper shares the child's command line; it leaves when it has seen the pipe close)
+            time.sleep(0.05)
+        assert helpers_of(tag) == 0
+    # MM_SYNC_EXIT=1: no helper
+    r = subprocess.run([sys.executable, "-c", child, "1", "exitpath-test-sync"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=dict(os.environ, MM_SYNC_EXIT="1"))
+    assert r.returncode == 7 and r.stdout == b"the last word"
