@@ -53,6 +53,14 @@ const char *mm_build_source_hash(void);
  * reference, say -- makes it on a thread of its own.  NOT in a process that is going to fork workers.  0 or -4 */
 int32_t mm_hip_warm(int32_t device);
 
+/* The library's device and pinned memory (csrc/devmem.h): blocks a handle gives up are KEPT and handed out again, never returned to the driver while the
+ * process lives -- an address the driver takes back and hands out again was seen through its old translation by one XCD's workgroups when a dozen processes
+ * shared the GPU (round 6).  No reference counterpart (CPU code).  mm_devmem_stats: [0] device bytes held by handles, [1] device bytes kept for reuse,
+ * [2] / [3] the same for pinned memory, [4] requests served from kept blocks, [5] requests that went to the driver, [6] blocks given back (out of memory,
+ * or mm_devmem_trim).  mm_devmem_trim: gives every kept block back -- for a long-lived process at a moment when none of its kernels is queued; the bytes. */
+void mm_devmem_stats(int64_t out[7]);
+int64_t mm_devmem_trim(void);
+
 /* The same two kernels on blocks that already lie in DEVICE memory, the decoded bytes left there (include/minimod_ingest.h builds on
  * it): d_c = the payloads (at least 1024 readable bytes behind the last one), d_blocks = n_blocks records, d_out / d_status = where the
  * decoded bytes and the status words go, stream = a hipStream_t, between_event = a hipEvent_t recorded between the inflate and the

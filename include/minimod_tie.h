@@ -59,7 +59,8 @@ int32_t mm_tie_order_rows2(mm_tie_t *t, const mm_row_t *rows, int64_t n, uint32_
  * new key's.  mm_tie_sequence_size: how many there are; mm_tie_sequence returns that count (cap must hold it). */
 int64_t mm_tie_sequence_size(const mm_tie_t *t);
 int64_t mm_tie_sequence(mm_tie_t *t, mm_row_t *keys, uint32_t *hash, int64_t cap, int32_t *put_after_last);
-uint32_t mm_tie_failed(const mm_tie_t *t);   /* 0, or why the replay gave up (bit set, csrc/tie_kernels.hip.h TIE_F_*) */
+uint32_t mm_tie_failed(const mm_tie_t *t);   /* 0, or why the replay gave up (bit set, csrc/tie_kernels.hip.h TIE_F_*; 64 = a launch was not taken: out of memory, a HIP
+                                                * failure -- STICKY: from then on mm_tie_order_rows* and mm_tie_sequence refuse, and the caller hands the run to the host's replay) */
 int64_t mm_tie_device_bytes(const mm_tie_t *t);
 void mm_tie_destroy(mm_tie_t *t);
 
@@ -90,7 +91,9 @@ typedef struct mm_fmt_opts {
 typedef struct mm_fmt mm_fmt_t;
 mm_fmt_t *mm_fmt_create(const mm_fmt_opts_t *opts, const char *const *contig_names, const char *const *codes, char *err, size_t err_len);
 int64_t mm_fmt_rows(mm_fmt_t *f, const mm_row_t *rows, int64_t n, const char **text);   /* bytes of text, or -MM_E_* */
-/* ... of rows that are in GPU memory already (mm_freq_finalize_device's, include/minimod_hip.h; any part of them): read where they lie */
+/* ... of rows that are in GPU memory already (mm_freq_finalize_device's, include/minimod_hip.h; any part of them): read where they lie.  The rows must be
+ * COMPLETE when this is called -- the stream that produced them synchronised (mm_freq_finalize_device returns that way): the formatter runs on the NULL
+ * stream, which does not order itself behind the handles' non-blocking streams. */
 int64_t mm_fmt_rows_device(mm_fmt_t *f, const mm_row_t *device_rows, int64_t n, const char **text);
 float mm_fmt_last_kernel_ms(const mm_fmt_t *f);   /* device time of the last call's kernels (length, scan, write) */
 void mm_fmt_destroy(mm_fmt_t *f);

@@ -40,7 +40,7 @@ def library_source_hash():
     """sha256 over EVERY source of the device library (csrc/*.hip*, include/*.h): what the built library carries
     (mm_build_source_hash) and what build() / smoke() compare it with -- a shipped .so made from other sources is rebuilt, not reused."""
     import glob
-    return _hash_files(sorted(glob.glob(os.path.join(CSRC, "*.hip*")) + glob.glob(os.path.join(CSRC, "fmt_core.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))))
+    return _hash_files(sorted(glob.glob(os.path.join(CSRC, "*.hip*")) + glob.glob(os.path.join(CSRC, "fmt_core.h")) + glob.glob(os.path.join(CSRC, "devmem.*")) + glob.glob(os.path.join(INCLUDE, "*.h"))))
 
 
 def built_library_hash(path=None):
@@ -90,8 +90,10 @@ def build_hip(force=False, verbose=False):
     # scratch -- with these two flags the hot instantiation has 0 bytes of scratch instead of 68 and 18 % fewer v_readlane; C2 35.1 ->
     # 33.9 us per batch, C3 -2.3 %, C5 -2.2 %, tools/ab.sh)
     freq_flags = ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]
+    devmem = os.path.join(CSRC, "devmem.h")   # (the block-keeping allocator every unit allocates through)
+    freq_srcs, bgzf_srcs, ingest_srcs, tie_srcs = freq_srcs + [devmem], bgzf_srcs + [devmem], ingest_srcs + [devmem], tie_srcs + [devmem]
     units = [("freq_api_k%d" % k, freq_srcs, ["-DMM_KIND=%d" % k] + freq_flags) for k in (0, 1, 2)] + \
-            [("freq_dispatch", dispatch_srcs, []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, []), ("tie_api", tie_srcs + [os.path.join(CSRC, "fmt_api.hip.h"), os.path.join(CSRC, "fmt_core.h"), os.path.join(CSRC, "summary_api.hip.h"), os.path.join(INCLUDE, "minimod_summary.h")], [])]
+            [("freq_dispatch", dispatch_srcs, []), ("devmem", [os.path.join(CSRC, "devmem.cpp"), devmem], []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, []), ("tie_api", tie_srcs + [os.path.join(CSRC, "fmt_api.hip.h"), os.path.join(CSRC, "fmt_core.h"), os.path.join(CSRC, "summary_api.hip.h"), os.path.join(INCLUDE, "minimod_summary.h")], [])]
     todo = []
     for name, srcs, extra in units:
         obj = os.path.join(objdir, name + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))

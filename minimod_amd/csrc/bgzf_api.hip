@@ -1,6 +1,7 @@
 // bgzf_api.hip -- host side of the device BGZF inflate (include/minimod_bgzf.h): slots of pinned staging + device buffers, one
 // stream per slot so that one slot's copies run beside another's kernels.
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -78,14 +79,14 @@ mm_bgzf_t* mm_bgzf_create(int32_t device, int32_t slots, int32_t max_blocks, siz
     for (BSlot& s : h->slots) {
         BCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_least));
         for (auto& e : s.ev) BCHK(hipEventCreate(&e));
-        BCHK(hipHostMalloc((void**)&s.h_c, max_cbytes + 64, hipHostMallocDefault));
-        BCHK(hipHostMalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)max_blocks, hipHostMallocDefault));
-        BCHK(hipHostMalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)max_blocks, hipHostMallocDefault));
-        BCHK(hipMalloc((void**)&s.d_c, max_cbytes + kPad));
+        BCHK(mmdev::hmalloc((void**)&s.h_c, max_cbytes + 64, hipHostMallocDefault));
+        BCHK(mmdev::hmalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)max_blocks, hipHostMallocDefault));
+        BCHK(mmdev::hmalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)max_blocks, hipHostMallocDefault));
+        BCHK(mmdev::dmalloc((void**)&s.d_c, max_cbytes + kPad));
         BCHK(hipMemset(s.d_c, 0, max_cbytes + kPad));
-        BCHK(hipMalloc((void**)&s.d_out, max_obytes + 64));
-        BCHK(hipMalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)max_blocks));
-        BCHK(hipMalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)max_blocks));
+        BCHK(mmdev::dmalloc((void**)&s.d_out, max_obytes + 64));
+        BCHK(mmdev::dmalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)max_blocks));
+        BCHK(mmdev::dmalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)max_blocks));
     }
     return h;
 }
@@ -96,11 +97,11 @@ void mm_bgzf_destroy(mm_bgzf_t* h) {
     for (BSlot& s : h->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
-        if (s.h_c) (void)hipHostFree(s.h_c);
-        if (s.h_blocks) (void)hipHostFree(s.h_blocks);
-        if (s.h_status) (void)hipHostFree(s.h_status);
+        if (s.h_c) (void)mmdev::hfree(s.h_c);
+        if (s.h_blocks) (void)mmdev::hfree(s.h_blocks);
+        if (s.h_status) (void)mmdev::hfree(s.h_status);
         void* ds[] = {s.d_c, s.d_out, s.d_blocks, s.d_status};
-        for (void* p : ds) if (p) (void)hipFree(p);
+        for (void* p : ds) if (p) (void)mmdev::dfree(p);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete h;
@@ -108,10 +109,10 @@ void mm_bgzf_destroy(mm_bgzf_t* h) {
 
 void* mm_bgzf_host_alloc(size_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (mmdev::hmalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
-void mm_bgzf_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void mm_bgzf_host_free(void* p) { if (p) (void)mmdev::hfree(p); }
 
 uint8_t* mm_bgzf_staging(mm_bgzf_t* h, int32_t slot) { return (h && slot >= 0 && (size_t)slot < h->slots.size()) ? h->slots[(size_t)slot].h_c : nullptr; }
 mm_bgzf_block_t* mm_bgzf_blocks(mm_bgzf_t* h, int32_t slot) { return (h && slot >= 0 && (size_t)slot < h->slots.size()) ? h->slots[(size_t)slot].h_blocks : nullptr; }
@@ -161,17 +162,17 @@ int32_t mm_hip_warm(int32_t device) {
     static int done[64];
     std::lock_guard<std::mutex> g(mu);
     if (device >= 0 && device < 64 && done[device]) return done[device] > 0 ? 0 : -4;
-    bool ok = hipSetDevice(device) == hipSuccess && hipFree(nullptr) == hipSuccess;
+    bool ok = hipSetDevice(device) == hipSuccess && mmdev::dfree(nullptr) == hipSuccess;
     if (ok) {
         hipStream_t st = nullptr;
         int* d = nullptr;
         int v = 0;
         // (on the null stream, whose queue the handles' synchronous copies need anyway: a stream of its own here was one more hardware queue --
         // 8 - 12 ms to make, 173 MB of host memory for its waves' saved state, tools/exit_probe_streams.hip)
-        ok = (!std::getenv("MM_WARM_OWN_STREAM") || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) && hipMalloc((void**)&d, 64) == hipSuccess &&
+        ok = (!std::getenv("MM_WARM_OWN_STREAM") || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) && mmdev::dmalloc((void**)&d, 64) == hipSuccess &&
              hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st) == hipSuccess;
         if (ok) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st, d); ok = hipStreamSynchronize(st) == hipSuccess; }
-        if (d) (void)hipFree(d);
+        if (d) (void)mmdev::dfree(d);
         if (st) (void)hipStreamDestroy(st);
     }
     if (device >= 0 && device < 64) done[device] = ok ? 1 : -1;

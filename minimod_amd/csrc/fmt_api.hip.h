@@ -80,8 +80,8 @@ mm_fmt_t* mm_fmt_create(const mm_fmt_opts_t* o, const char* const* contig_names,
     // (the NULL stream: a stream of its own is one more hardware queue -- 8 - 12 ms to make at the one moment of a run when nothing else is under way,
     // 173 MB of host memory for its waves' saved state; MM_FMT_OWN_STREAM=1 makes one all the same)
     bool ok = !std::getenv("MM_FMT_OWN_STREAM") || hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc((void**)&f->d_names, names.size()) == hipSuccess && hipMalloc((void**)&f->d_name_off, 4 * off.size()) == hipSuccess && hipMalloc((void**)&f->d_name_len, 4 * len.size()) == hipSuccess;
-    ok = ok && hipMalloc((void**)&f->d_codes, cs.size()) == hipSuccess && hipMalloc((void**)&f->d_code_len, 4 * cl.size()) == hipSuccess;
+    ok = ok && mmdev::dmalloc((void**)&f->d_names, names.size()) == hipSuccess && mmdev::dmalloc((void**)&f->d_name_off, 4 * off.size()) == hipSuccess && mmdev::dmalloc((void**)&f->d_name_len, 4 * len.size()) == hipSuccess;
+    ok = ok && mmdev::dmalloc((void**)&f->d_codes, cs.size()) == hipSuccess && mmdev::dmalloc((void**)&f->d_code_len, 4 * cl.size()) == hipSuccess;
     ok = ok && hipMemcpy(f->d_names, names.data(), names.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(f->d_name_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(f->d_name_len, len.data(), 4 * len.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(f->d_codes, cs.data(), cs.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(f->d_code_len, cl.data(), 4 * cl.size(), hipMemcpyHostToDevice) == hipSuccess;
@@ -99,23 +99,28 @@ static int64_t fmt_rows_impl(mm_fmt_t* f, const mm_row_t* rows, bool on_device, 
     if (hipSetDevice(f->o.device) != hipSuccess) return -MM_E_HIP;
     hipStream_t st = f->st;
     if ((size_t)n > f->cap_rows) {
-        if (f->d_len) { (void)hipFree(f->d_len); (void)hipFree(f->d_tiles); f->d_len = nullptr; f->d_tiles = nullptr; f->cap_rows = 0; }
+        if (f->d_len) { (void)mmdev::dfree(f->d_len); (void)mmdev::dfree(f->d_tiles); f->d_len = nullptr; f->d_tiles = nullptr; f->cap_rows = 0; }
         const size_t cap = (size_t)n + (size_t)n / 8 + 1024;
-        if (hipMalloc((void**)&f->d_len, 8 * cap) != hipSuccess || hipMalloc((void**)&f->d_tiles, 8 * (cap / kScanTile + 4)) != hipSuccess) return -MM_E_NOMEM;
+        if (mmdev::dmalloc((void**)&f->d_len, 8 * cap) != hipSuccess || mmdev::dmalloc((void**)&f->d_tiles, 8 * (cap / kScanTile + 4)) != hipSuccess) return -MM_E_NOMEM;
         f->cap_rows = cap;
     }
     if (!on_device && (size_t)n > f->cap_own_rows) {   // (rows that are on the device already are read where they lie)
-        if (f->d_rows) { (void)hipFree(f->d_rows); f->d_rows = nullptr; f->cap_own_rows = 0; }
+        if (f->d_rows) { (void)mmdev::dfree(f->d_rows); f->d_rows = nullptr; f->cap_own_rows = 0; }
         const size_t cap = (size_t)n + (size_t)n / 8 + 1024;
-        if (hipMalloc((void**)&f->d_rows, sizeof(mm_row_t) * cap) != hipSuccess) return -MM_E_NOMEM;
+        if (mmdev::dmalloc((void**)&f->d_rows, sizeof(mm_row_t) * cap) != hipSuccess) return -MM_E_NOMEM;
         f->cap_own_rows = cap;
     }
     const mm_row_t* const src = on_device ? rows : (const mm_row_t*)f->d_rows;
     FmtTables T;
     T.names = f->d_names; T.name_off = f->d_name_off; T.name_len = f->d_name_len; T.codes = f->d_codes; T.code_len = f->d_code_len;
     T.n_contigs = f->o.n_contigs; T.n_codes = f->o.n_codes; T.bedmethyl = f->o.bedmethyl; T.insertions = f->o.insertions; T.haplotypes = f->o.haplotypes;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    struct Events {   // (made per call, gone on every way out)
+        hipEvent_t a = nullptr, b = nullptr;
+        Events() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
+    (void)hipGetLastError();
     if (!on_device && hipMemcpyAsync(f->d_rows, rows, sizeof(mm_row_t) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) return -MM_E_HIP;
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(k_fmt_len, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, src, (u64)n, f->d_len);
@@ -124,30 +129,31 @@ static int64_t fmt_rows_impl(mm_fmt_t* f, const mm_row_t* rows, bool on_device, 
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, f->d_tiles, (uint32_t)nt);
     hipLaunchKernelGGL(k_scan_apply, dim3(nt), dim3(256), 0, st, f->d_len, (u64)n, (const u64*)f->d_tiles);
     uint64_t total = 0;
+    if (hipGetLastError() != hipSuccess) return -MM_E_HIP;   // (a launch that did not start must not leave `total` to whatever d_len held)
     if (hipMemcpyAsync(&total, f->d_len + (n - 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
     if (total + 64 > f->cap_text) {
-        if (f->d_text) (void)hipFree(f->d_text);
+        if (f->d_text) (void)mmdev::dfree(f->d_text);
         f->d_text = nullptr; f->cap_text = 0;
         const size_t cap = (size_t)total + (size_t)total / 8 + 4096;
-        if (hipMalloc((void**)&f->d_text, cap) != hipSuccess) return -MM_E_NOMEM;
+        if (mmdev::dmalloc((void**)&f->d_text, cap) != hipSuccess) return -MM_E_NOMEM;
         f->cap_text = cap;
     }
     const int tn = f->turn;
     f->turn ^= 1;
     if (total + 64 > f->cap_htext[tn]) {
-        if (f->pinned[tn]) (void)hipHostFree(f->h_text[tn]); else free(f->h_text[tn]);
+        if (f->pinned[tn]) (void)mmdev::hfree(f->h_text[tn]); else free(f->h_text[tn]);
         f->h_text[tn] = nullptr; f->cap_htext[tn] = 0;
         const size_t cap = (size_t)total + (size_t)total / 8 + 4096;
-        f->pinned[tn] = cap <= ((size_t)64 << 20) && !std::getenv("MM_FMT_PLAIN_TEXT") && hipHostMalloc((void**)&f->h_text[tn], cap, hipHostMallocDefault) == hipSuccess;
+        f->pinned[tn] = cap <= ((size_t)64 << 20) && !std::getenv("MM_FMT_PLAIN_TEXT") && mmdev::hmalloc((void**)&f->h_text[tn], cap, hipHostMallocDefault) == hipSuccess;
         if (!f->pinned[tn]) f->h_text[tn] = (char*)malloc(cap);
         if (!f->h_text[tn]) return -MM_E_NOMEM;
         f->cap_htext[tn] = cap;
     }
     hipLaunchKernelGGL(k_fmt_write, dim3(blocks((uint64_t)n)), dim3(256), 0, st, T, src, (u64)n, (const u64*)f->d_len, f->d_text);
+    if (hipGetLastError() != hipSuccess) return -MM_E_HIP;
     (void)hipEventRecord(e1, st);
     if (hipMemcpyAsync(f->h_text[tn], f->d_text, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
     (void)hipEventElapsedTime(&f->last_ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *text = f->h_text[tn];
     return (int64_t)total;
 }
@@ -159,8 +165,8 @@ void mm_fmt_destroy(mm_fmt_t* f) {
     (void)hipSetDevice(f->o.device);
     (void)hipStreamSynchronize(f->st);
     void* ps[] = {f->d_names, f->d_name_off, f->d_name_len, f->d_codes, f->d_code_len, f->d_rows, f->d_len, f->d_tiles, f->d_text};
-    for (void* p : ps) if (p) (void)hipFree(p);
-    for (int i = 0; i < 2; i++) { if (f->pinned[i]) (void)hipHostFree(f->h_text[i]); else free(f->h_text[i]); }
+    for (void* p : ps) if (p) (void)mmdev::dfree(p);
+    for (int i = 0; i < 2; i++) { if (f->pinned[i]) (void)mmdev::hfree(f->h_text[i]); else free(f->h_text[i]); }
     if (f->st) (void)hipStreamDestroy(f->st);
     delete f;
 }

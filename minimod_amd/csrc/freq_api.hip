@@ -9,6 +9,7 @@
 // There is no CPU fallback: every entry point needs a HIP device and fails with MM_E_HIP otherwise.
 #include "freq_kinds.h"   // (first: this copy's names)
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -191,7 +192,7 @@ static hipStream_t slot_stream(mm_freq* h, Slot& s) {
 
 int dev_alloc(mm_freq* h, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = mmdev::dmalloc(p, bytes);
     if (e != hipSuccess) return -MM_E_NOMEM;
     h->device_bytes += (int64_t)bytes;
     return 0;
@@ -204,7 +205,7 @@ int grow(mm_freq* h, void** p, size_t* cap, size_t need) {
     struct Timer { bool on; timespec a; Timer(bool o) : on(o) { if (on) clock_gettime(CLOCK_MONOTONIC, &a); }
                    ~Timer() { if (on) { timespec b; clock_gettime(CLOCK_MONOTONIC, &b); g_grow_seconds += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); } } } timer(tl);
     size_t ncap = std::max(need + need / 4, (size_t)4096);
-    if (*p) { (void)hipFree(*p); h->device_bytes -= (int64_t)*cap; }
+    if (*p) { (void)mmdev::dfree(*p); h->device_bytes -= (int64_t)*cap; }
     *p = nullptr; *cap = 0;
     int r = dev_alloc(h, p, ncap);
     if (r) return r;
@@ -221,7 +222,7 @@ int side_table_clear(mm_freq* h) {
 
 int ensure_sort_buffers(mm_freq* h, size_t n) {
     if (n > h->cap_sort) {
-        for (int i = 0; i < 2; i++) { if (h->d_sort_k[i]) (void)hipFree(h->d_sort_k[i]); if (h->d_sort_v[i]) (void)hipFree(h->d_sort_v[i]); h->d_sort_k[i] = h->d_sort_v[i] = nullptr; }
+        for (int i = 0; i < 2; i++) { if (h->d_sort_k[i]) (void)mmdev::dfree(h->d_sort_k[i]); if (h->d_sort_v[i]) (void)mmdev::dfree(h->d_sort_v[i]); h->d_sort_k[i] = h->d_sort_v[i] = nullptr; }
         h->cap_sort = 0;
         size_t cap = n + n / 8 + 1024;
         for (int i = 0; i < 2; i++)
@@ -230,7 +231,7 @@ int ensure_sort_buffers(mm_freq* h, size_t n) {
     }
     const size_t nblk = (n + kSortTile - 1) / kSortTile;
     if (256 * nblk + 256 > h->cap_sort_hist) {
-        if (h->d_sort_hist) (void)hipFree(h->d_sort_hist);
+        if (h->d_sort_hist) (void)mmdev::dfree(h->d_sort_hist);
         h->d_sort_hist = nullptr; h->cap_sort_hist = 0;
         if (dev_alloc(h, (void**)&h->d_sort_hist, 4 * (256 * nblk + 1024))) return -MM_E_NOMEM;
         h->cap_sort_hist = 256 * nblk + 1024;
@@ -253,7 +254,7 @@ int side_compact(mm_freq* h) {
     if (n_new == 0) return 0;
     { int r = ensure_sort_buffers(h, n); if (r) return r; }
     unsigned long long* d_off = nullptr;
-    if (hipMalloc((void**)&d_off, 8 * off.size()) != hipSuccess) return -MM_E_NOMEM;
+    if (mmdev::dmalloc((void**)&d_off, 8 * off.size()) != hipSuccess) return -MM_E_NOMEM;
     int result = 0;
     do {
         if (hipMemcpyAsync(d_off, off.data(), 8 * off.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
@@ -280,7 +281,7 @@ int side_compact(mm_freq* h) {
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&n_unique, h->d_sort_hist + ntile, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
         if ((size_t)n_unique > h->cap_base) {
-            if (h->d_base_k) { (void)hipFree(h->d_base_k); (void)hipFree(h->d_base_v); h->device_bytes -= (int64_t)(16 * h->cap_base); }
+            if (h->d_base_k) { (void)mmdev::dfree(h->d_base_k); (void)mmdev::dfree(h->d_base_v); h->device_bytes -= (int64_t)(16 * h->cap_base); }
             h->d_base_k = h->d_base_v = nullptr; h->cap_base = 0;
             const size_t cap = (size_t)n_unique + (size_t)n_unique / 4 + 1024;
             if (dev_alloc(h, (void**)&h->d_base_k, 8 * cap) || dev_alloc(h, (void**)&h->d_base_v, 8 * cap)) { result = -MM_E_NOMEM; break; }
@@ -291,7 +292,7 @@ int side_compact(mm_freq* h) {
             hipStreamSynchronize(h->stream) != hipSuccess) { result = -MM_E_HIP; break; }
         h->n_base = n_unique;
     } while (0);
-    (void)hipFree(d_off);
+    (void)mmdev::dfree(d_off);
     return result;
 }
 
@@ -721,7 +722,6 @@ int drain(mm_freq* h) {
 
 // status of a slot whose kernels are complete: 0, or the first failing read's code (its batch index in *bad_read)
 int slot_status(mm_freq* h, Slot& s, int32_t* bad_read) {
-    (void)h;
     if (s.h_ctl[129] == 0xFFFFFFFFu) return 0;
     unsigned int sum = 0xFFFFFFFFu;
     if (hipMemcpy(&sum, s.d_err_word, sizeof sum, hipMemcpyDeviceToHost) != hipSuccess) return MM_E_HIP;
@@ -784,7 +784,7 @@ const char* mm_strerror(int32_t code) {
 void mm_freq_destroy(mm_freq_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->d_ipc_slab) (void)hipFree(h->d_ipc_slab);
+    if (h->d_ipc_slab) (void)mmdev::dfree(h->d_ipc_slab);
     (void)flush_pending(h);
     (void)hipDeviceSynchronize();
     for (auto& s : h->slots) {
@@ -798,23 +798,81 @@ void mm_freq_destroy(mm_freq_t* h) {
                       s.d_plan, s.d_plan_stream, s.d_plan_state,
                       s.d_vkeys, s.d_vvals, s.d_vseq, s.d_vtile, s.d_vcount, s.d_ka, s.d_va, s.d_vrows, s.d_vout, s.d_vreadcount, s.d_voff, s.d_vcursor,
                       s.d_vkept, s.d_vnewoff};
-        for (void* p : ps) if (p) (void)hipFree(p);
-        if (s.h_ctl) (void)hipHostFree(s.h_ctl);
-        if (s.h_vcount) (void)hipHostFree(s.h_vcount);
-        if (s.h_vrows) (void)hipHostFree(s.h_vrows);
+        for (void* p : ps) if (p) (void)mmdev::dfree(p);
+        if (s.h_ctl) (void)mmdev::hfree(s.h_ctl);
+        if (s.h_vcount) (void)mmdev::hfree(s.h_vcount);
+        if (s.h_vrows) (void)mmdev::hfree(s.h_vrows);
     }
     void* ps[] = {h->d_refw, h->d_ref_base, h->d_ctg_len, h->d_seg_begin, h->d_seg_len, h->d_cnt_base, h->d_counters,
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
                   h->d_stab, h->d_scount, h->d_scur, h->d_base_k, h->d_base_v, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
-    for (void* p : ps) if (p) (void)hipFree(p);
-    for (void* p : h->d_site_arrays) if (p) (void)hipFree(p);
-    if (h->d_ctx_mods) (void)hipFree(h->d_ctx_mods);
-    if (h->d_classes) (void)hipFree(h->d_classes);
-    if (h->d_cls_of_mod) (void)hipFree(h->d_cls_of_mod);
-    if (h->d_adj) (void)hipFree(h->d_adj);
-    if (h->d_slab_flag) (void)hipFree(h->d_slab_flag);
+    for (void* p : ps) if (p) (void)mmdev::dfree(p);
+    for (void* p : h->d_site_arrays) if (p) (void)mmdev::dfree(p);
+    if (h->d_ctx_mods) (void)mmdev::dfree(h->d_ctx_mods);
+    if (h->d_classes) (void)mmdev::dfree(h->d_classes);
+    if (h->d_cls_of_mod) (void)mmdev::dfree(h->d_cls_of_mod);
+    if (h->d_adj) (void)mmdev::dfree(h->d_adj);
+    if (h->d_slab_flag) (void)mmdev::dfree(h->d_slab_flag);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// the site index failed its check (k_site_check): what the device's pieces hold, set against what the host computes from the same counts, and what the
+// workgroups of every XCD see of them -- the lines that named round 5's defect (profiles/r6_site_index_root_cause.txt)
+// what every XCD sees of the index: res[0..7] blocks that break the chain by plain loads, res[8..15] by agent-scope loads, per XCC_ID of the observer; res[16 + x] tiles observed by XCC x
+static __global__ __launch_bounds__(256) void k_site_views(const uint2* __restrict__ site, int stride, const uint32_t* __restrict__ cnt, int64_t n_blocks, uint32_t* __restrict__ res) {
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    if (threadIdx.x == 0) atomicAdd(&res[16 + xcc], 1u);
+    for (int64_t b = (int64_t)blockIdx.x * kScanTile + threadIdx.x; b + 1 < n_blocks && b < (int64_t)(blockIdx.x + 1) * kScanTile; b += 256) {
+        const uint2 w = site[b * stride]; const uint32_t nx = site[(b + 1) * stride].y, c = cnt[b];
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(site);
+        const uint32_t ax = __hip_atomic_load(&q[(b * stride) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ay = __hip_atomic_load(&q[(b * stride) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t an = __hip_atomic_load(&q[((b + 1) * stride) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ac = __hip_atomic_load(&cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w.y + (uint32_t)__popc(w.x) != nx || c != (uint32_t)__popc(w.x)) atomicAdd(&res[xcc], 1u);
+        if (ay + (uint32_t)__popc(ax) != an || ac != (uint32_t)__popc(ax)) atomicAdd(&res[8 + xcc], 1u);
+    }
+}
+static void site_index_diag(int sd, uint32_t bad, const uint2* site, int stride, const uint32_t* cnt, int64_t n_blocks, const uint32_t* tsum, int64_t n_tiles, uint32_t total) {
+    const std::vector<uint32_t> prev;
+    {
+        uint32_t* d_res = nullptr; uint32_t hr[24] = {0};
+        if (mmdev::dmalloc((void**)&d_res, sizeof hr) == hipSuccess && hipMemset(d_res, 0, sizeof hr) == hipSuccess) {
+            hipLaunchKernelGGL(k_site_views, dim3((unsigned)n_tiles), dim3(256), 0, 0, site, stride, cnt, n_blocks, d_res);
+            (void)hipMemcpy(hr, d_res, sizeof hr, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[site-diag]   seen again by a kernel, per XCD of the observer (tiles / bad blocks by plain loads / by agent-scope loads):");
+            for (int x = 0; x < 8; x++) std::fprintf(stderr, " %u/%u/%u", hr[16 + x], hr[x], hr[8 + x]);
+            std::fprintf(stderr, "\n");
+            (void)mmdev::dfree(d_res);
+        }
+        std::fprintf(stderr, "[site-diag]   addresses: site words %p + %zu; counts %p + %zu; tile sums %p\n", (const void*)site, sizeof(uint2) * (size_t)n_blocks * (size_t)stride, (const void*)cnt, 4 * (size_t)n_blocks, (const void*)tsum);
+    }
+    std::vector<uint32_t> c((size_t)n_blocks), ts((size_t)n_tiles + 1);
+    std::vector<uint2> sw((size_t)n_blocks * (size_t)stride);
+    (void)hipMemcpy(c.data(), cnt, 4 * c.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ts.data(), tsum, 4 * ts.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(sw.data(), site, sizeof(uint2) * sw.size(), hipMemcpyDeviceToHost);
+    std::vector<uint32_t> S((size_t)n_tiles + 1, 0), O((size_t)n_tiles + 1, 0);
+    for (int64_t b = 0; b < n_blocks; b++) S[(size_t)(b / kScanTile)] += c[(size_t)b];
+    for (int64_t t = 0; t < n_tiles; t++) O[(size_t)t + 1] = O[(size_t)t] + S[(size_t)t];
+    int64_t ts_bad = 0, ts_is_sum = 0, first_bad = 0, first_is_zero = 0, first_is_sum = 0, first_is_prev = 0, intile_bad = 0, cnt_bad = 0;
+    for (int64_t t = 0; t <= n_tiles; t++) { ts_bad += ts[(size_t)t] != O[(size_t)t]; ts_is_sum += ts[(size_t)t] == S[(size_t)t]; }
+    for (int64_t t = 0; t < n_tiles; t++) {
+        const uint32_t got = sw[(size_t)(t * kScanTile) * (size_t)stride].y;
+        if (got != O[(size_t)t]) { first_bad++; first_is_zero += got == 0u; first_is_sum += got == S[(size_t)t]; first_is_prev += !prev.empty() && got == prev[(size_t)t]; }
+    }
+    for (int64_t b = 0; b < n_blocks; b++) {
+        cnt_bad += c[(size_t)b] != (uint32_t)__builtin_popcount(sw[(size_t)b * (size_t)stride].x);
+        if (b + 1 < n_blocks && (b + 1) % kScanTile) intile_bad += sw[(size_t)(b + 1) * (size_t)stride].y - sw[(size_t)b * (size_t)stride].y != c[(size_t)b];
+    }
+    std::fprintf(stderr, "[site-diag] strand %d: check counted %u bad blocks of %lld (%lld tiles); total seen %u, expected %u\n", sd, bad, (long long)n_blocks, (long long)n_tiles, total, O[(size_t)n_tiles]);
+    std::fprintf(stderr, "[site-diag]   tile offsets in memory now: %lld of %lld differ from the expected offsets (%lld equal the unscanned sums)\n", (long long)ts_bad, (long long)n_tiles + 1, (long long)ts_is_sum);
+    std::fprintf(stderr, "[site-diag]   tiles whose first rank is not the expected offset: %lld (of these: %lld zero, %lld the tile's own sum, %lld the other strand's offset)\n", (long long)first_bad, (long long)first_is_zero, (long long)first_is_sum, (long long)first_is_prev);
+    std::fprintf(stderr, "[site-diag]   ranks wrong inside a tile: %lld; counts that are not their bits' popcount: %lld\n", (long long)intile_bad, (long long)cnt_bad);
+    int shown = 0;
+    for (int64_t t = 0; t < n_tiles && shown < 6; t++) {
+        const uint32_t got = sw[(size_t)(t * kScanTile) * (size_t)stride].y;
+        if (got != O[(size_t)t] || ts[(size_t)t] != O[(size_t)t]) { shown++; std::fprintf(stderr, "[site-diag]   tile %lld: first rank %u, offset in memory %u, expected %u, tile sum %u, other strand's offset %u\n", (long long)t, got, ts[(size_t)t], O[(size_t)t], S[(size_t)t], prev.empty() ? 0u : prev[(size_t)t]); }
+    }
 }
 
 mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const mm_contig_t* contigs,
@@ -924,10 +982,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             if (dev_alloc(h, (void**)&s.d_tq, 2 * kQueueWords * sizeof(unsigned int))) return fail(h, "alloc failed");
             if (hipMemset(s.d_tq, 0, 2 * kQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(h, "control word init failed");
         }
-        if (hipHostMalloc((void**)&s.h_ctl, 512 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        if (mmdev::hmalloc((void**)&s.h_ctl, 512 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(h, "pinned alloc failed");
+        std::memset(s.h_ctl, 0, 512 * sizeof(unsigned int));   // (every slot's word 132 is looked at, used or not: a kept block is not a zeroed one)
         if (opts->view) {
             if (dev_alloc(h, (void**)&s.d_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2))) return fail(h, "alloc failed");
-            if (hipHostMalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipHostMallocDefault) != hipSuccess)
+            if (mmdev::hmalloc((void**)&s.h_vcount, sizeof(unsigned int) * (kViewRegions * kViewCountStride + 2), hipHostMallocDefault) != hipSuccess)
                 return fail(h, "pinned alloc failed");
         }
     }
@@ -1071,11 +1130,11 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         for (int t = 0; t < n_contigs; t++) if (h->ref_base[t] >= 0) maxlen = std::max(maxlen, h->ctg_len[t]);
         uint8_t* d_raw = nullptr;
         if (maxlen > 0) {
-            if (hipMalloc((void**)&d_raw, (size_t)maxlen + 64) != hipSuccess) return fail(h, "staging alloc failed");   // (k_build_refnibs loads whole 16-byte pieces)
+            if (mmdev::dmalloc((void**)&d_raw, (size_t)maxlen + 64) != hipSuccess) return fail(h, "staging alloc failed");   // (k_build_refnibs loads whole 16-byte pieces)
             for (int t = 0; t < n_contigs; t++) {
                 if (h->ref_base[t] < 0 || h->ctg_len[t] == 0) continue;
                 int64_t len = h->ctg_len[t];
-                if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "reference upload failed"); }
+                if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)mmdev::dfree(d_raw); return fail(h, "reference upload failed"); }
                 int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
                 // (bits 5 + 2c / 6 + 2c: class c's context, described by the class's first entry)
                 if (h->ref_kind == 2) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
@@ -1087,9 +1146,9 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
                 else hipLaunchKernelGGL(k_build_refnibs<15>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
                                         (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);
-                if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipFree(d_raw); return fail(h, "context kernel failed"); }
+                if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)mmdev::dfree(d_raw); return fail(h, "context kernel failed"); }
             }
-            (void)hipFree(d_raw);
+            (void)mmdev::dfree(d_raw);
         }
     }
     const double tl_c = tl_now();
@@ -1126,27 +1185,43 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 // the class's site index over the whole reference-word space: bits, then ranks (an exclusive scan in tiles)
                 uint2* site[2] = {nullptr, nullptr};
                 uint32_t* cnt[2] = {nullptr, nullptr};
-                uint32_t* tsum = nullptr;
+                uint32_t* tsum[2] = {nullptr, nullptr};   // (one a strand: no address of the sequence changes its meaning between two kernels)
+                uint32_t* d_bad = nullptr;
                 const int64_t n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
                 for (int sd = 0; sd < 2; sd++) {
                     if (dev_alloc(h, (void**)&site[sd], sizeof(uint2) * (size_t)k.stride * (size_t)std::max<int64_t>(n_blocks, 1))) return fail(h, "site index alloc failed");
                     h->d_site_arrays.push_back(site[sd]);
-                    if (hipMalloc((void**)&cnt[sd], 4 * (size_t)std::max<int64_t>(n_blocks, 1)) != hipSuccess) return fail(h, "site index alloc failed");
+                    if (mmdev::dmalloc((void**)&cnt[sd], 4 * (size_t)std::max<int64_t>(n_blocks, 1)) != hipSuccess || mmdev::dmalloc((void**)&tsum[sd], 4 * (size_t)(n_tiles + 1)) != hipSuccess)
+                        return fail(h, "site index alloc failed");
                 }
-                if (hipMalloc((void**)&tsum, 4 * (size_t)(n_tiles + 1)) != hipSuccess) return fail(h, "site index alloc failed");
+                if (mmdev::dmalloc((void**)&d_bad, 8) != hipSuccess) return fail(h, "site index alloc failed");
                 uint32_t total[2] = {0, 0};
                 bool ok = true;
-                if (n_blocks > 0) {
+                // Both strands' kernels are queued behind each other and waited for once.  Behind them the guard (k_site_check): every block's rank plus its own
+                // sites is the next block's rank, the last block ends at the strand's total.  An index that fails it is built once more and then REFUSED --
+                // nothing counts into a wrong index (round 5's defect: one XCD read the counts through a freed buffer's translation, csrc/devmem.h).
+                const int site_fault = std::getenv("MM_SITE_FAULT") ? std::atoi(std::getenv("MM_SITE_FAULT")) : 0;
+                for (int attempt = 0; n_blocks > 0 && ok && attempt < 2; attempt++) {
                     const int blocks = (int)std::min<int64_t>((n_blocks + 255) / 256, (int64_t)h->n_cu * 16);
+                    uint32_t bad[2] = {0, 0};
+                    (void)hipMemsetAsync(d_bad, 0, 8, h->stream);
                     MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, c, (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
-                    for (int sd = 0; sd < 2 && ok; sd++) {
-                        (void)hipMemsetAsync(tsum + n_tiles, 0, 4, h->stream);
-                        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum);
-                        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, tsum, (unsigned long long)n_tiles + 1ull);
-                        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum, site[sd], (int)k.stride);
-                        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total[sd], tsum + n_tiles, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-                             hipStreamSynchronize(h->stream) == hipSuccess;
+                    for (int sd = 0; sd < 2; sd++) {
+                        (void)hipMemsetAsync(tsum[sd] + n_tiles, 0, 4, h->stream);
+                        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum[sd]);
+                        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, h->stream, tsum[sd], (unsigned long long)n_tiles + 1ull);
+                        if (sd == 1 && attempt < site_fault) (void)hipMemsetAsync(cnt[1] + n_blocks / 2, 0x01, 4, h->stream);   // (the tests' way to trip the guard: MM_SITE_FAULT=1 once, =2 twice)
+                        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum[sd], site[sd], (int)k.stride);
+                        hipLaunchKernelGGL(k_site_check, dim3(blocks), dim3(256), 0, h->stream, site[sd], (int)k.stride, cnt[sd], n_blocks, tsum[sd] + n_tiles, d_bad + sd);
                     }
+                    ok = hipGetLastError() == hipSuccess;
+                    for (int sd = 0; sd < 2 && ok; sd++)
+                        ok = hipMemcpyAsync(&total[sd], tsum[sd] + n_tiles, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipMemcpyAsync(&bad[sd], d_bad + sd, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+                    ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+                    if (!ok || !(bad[0] | bad[1])) break;
+                    for (int sd = 0; sd < 2; sd++) if (bad[sd]) site_index_diag(sd, bad[sd], site[sd], (int)k.stride, cnt[sd], n_blocks, tsum[sd], n_tiles, total[sd]);
+                    std::fprintf(stderr, "[minimod_hip] the site index of context class %d failed its check (%u + %u blocks): %s\n", c, bad[0], bad[1], attempt == 0 ? "building it once more" : "refused");
+                    if (attempt == 1) ok = false;
                 }
                 // the contigs' segments in the class's site numbering: ranks at every segment's two ends
                 std::vector<int64_t> gq;
@@ -1155,7 +1230,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                 std::vector<uint32_t> rk[2];
                 if (ok && !gq.empty()) {
                     int64_t* d_g = nullptr; uint32_t* d_o = nullptr;
-                    ok = hipMalloc((void**)&d_g, 8 * gq.size()) == hipSuccess && hipMalloc((void**)&d_o, 4 * gq.size()) == hipSuccess &&
+                    ok = mmdev::dmalloc((void**)&d_g, 8 * gq.size()) == hipSuccess && mmdev::dmalloc((void**)&d_o, 4 * gq.size()) == hipSuccess &&
                          hipMemcpy(d_g, gq.data(), 8 * gq.size(), hipMemcpyHostToDevice) == hipSuccess;
                     for (int sd = 0; sd < 2 && ok; sd++) {
                         rk[sd].resize(gq.size());
@@ -1163,12 +1238,12 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(rk[sd].data(), d_o, 4 * gq.size(), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
                              hipStreamSynchronize(h->stream) == hipSuccess;
                     }
-                    if (d_g) (void)hipFree(d_g);
-                    if (d_o) (void)hipFree(d_o);
+                    if (d_g) (void)mmdev::dfree(d_g);
+                    if (d_o) (void)mmdev::dfree(d_o);
                 }
-                for (int sd = 0; sd < 2; sd++) if (cnt[sd]) (void)hipFree(cnt[sd]);
-                if (tsum) (void)hipFree(tsum);
-                if (!ok) return fail(h, "site index kernels failed");
+                for (int sd = 0; sd < 2; sd++) { (void)mmdev::dfree(cnt[sd]); (void)mmdev::dfree(tsum[sd]); }
+                (void)mmdev::dfree(d_bad);
+                if (!ok) return fail(h, "site index kernels failed, or the index failed its check twice");
                 int64_t ns[2] = {0, 0};
                 for (size_t i = 0; i < gt.size(); i++)
                     for (int sd = 0; sd < 2; sd++) {
@@ -1317,7 +1392,6 @@ static uint64_t batch_bases(const mm_batch_t* b) {
 }
 
 static int copy_host_batch(mm_freq* h, Slot& s, const mm_batch_t* hb, hipStream_t st, size_t at_reads, size_t at_cigar, size_t at_seq, size_t at_mm, size_t at_ml) {
-    (void)h;
     if (hb->n_reads) HIPCHK(hipMemcpyAsync((char*)s.d_reads + sizeof(mm_read_t) * at_reads, hb->reads, sizeof(mm_read_t) * (size_t)hb->n_reads, hipMemcpyHostToDevice, st));
     if (hb->n_cigar_words) HIPCHK(hipMemcpyAsync((char*)s.d_cigar + 4 * at_cigar, hb->cigar, 4 * hb->n_cigar_words, hipMemcpyHostToDevice, st));
     if (hb->n_seq_bytes) HIPCHK(hipMemcpyAsync((char*)s.d_seq + at_seq, hb->seq, hb->n_seq_bytes, hipMemcpyHostToDevice, st));
@@ -1563,8 +1637,8 @@ static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_r
         if (tiles >= (int64_t)0x7FFFFFFF) return -MM_E_ARG;
         if (tiles > 0) {
             if ((size_t)tiles > h->cap_tiles) {
-                if (h->d_tile_counts) (void)hipFree(h->d_tile_counts);
-                if (h->d_tile_offsets) (void)hipFree(h->d_tile_offsets);
+                if (h->d_tile_counts) (void)mmdev::dfree(h->d_tile_counts);
+                if (h->d_tile_offsets) (void)mmdev::dfree(h->d_tile_offsets);
                 h->d_tile_counts = nullptr; h->d_tile_offsets = nullptr; h->cap_tiles = 0;
                 if (dev_alloc(h, (void**)&h->d_tile_counts, sizeof(uint32_t) * (size_t)tiles) ||
                     dev_alloc(h, (void**)&h->d_tile_offsets, sizeof(unsigned long long) * (size_t)tiles)) return -MM_E_NOMEM;
@@ -1586,7 +1660,7 @@ static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_r
                 for (size_t i = 0; i < (size_t)tiles; i++) { to[i] = total; total += tc[i]; }
                 if (total > 0) {
                     if ((size_t)total > h->cap_rows) {
-                        if (h->d_rows) (void)hipFree(h->d_rows);
+                        if (h->d_rows) (void)mmdev::dfree(h->d_rows);
                         h->d_rows = nullptr; h->cap_rows = 0;
                         size_t cap = (size_t)total + (size_t)total / 8 + 1024;
                         if (dev_alloc(h, (void**)&h->d_rows, sizeof(mm_row_t) * cap)) { result = -MM_E_NOMEM; break; }
@@ -1604,7 +1678,7 @@ static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_r
                     }
                 }
             } while (0);
-            (void)hipFree(d_segs); h->device_bytes -= (int64_t)std::max<size_t>(sizeof(SiteSeg) * segs.size(), 16);
+            (void)mmdev::dfree(d_segs); h->device_bytes -= (int64_t)std::max<size_t>(sizeof(SiteSeg) * segs.size(), 16);
             if (result < 0) return result;
         }
     }
@@ -1616,11 +1690,11 @@ static int64_t finalize_impl(mm_freq_t* h, const mm_row_t** out_rows, const mm_r
         if (ns0 == 0 && h->n_base == 0) {
             if (!dense_on_host) {   // the caller takes them from the device: the overflow check (below, on the host) as a kernel
                 unsigned int* d_flag = nullptr; unsigned int hflag = 0;
-                if (hipMalloc((void**)&d_flag, 4) != hipSuccess) return -MM_E_NOMEM;
+                if (mmdev::dmalloc((void**)&d_flag, 4) != hipSuccess) return -MM_E_NOMEM;
                 bool ok = hipMemsetAsync(d_flag, 0, 4, h->stream) == hipSuccess;
                 if (ok) { hipLaunchKernelGGL(k_rows_overflow, dim3((unsigned)((dense_total + 255) / 256)), dim3(256), 0, h->stream, (const mm_row_t*)h->d_rows, (unsigned long long)dense_total, d_flag);
                           ok = hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess; }
-                (void)hipFree(d_flag);
+                (void)mmdev::dfree(d_flag);
                 if (!ok) return -MM_E_HIP;
                 if (hflag) return -MM_E_OVERFLOW;
                 *out_dev = (const mm_row_t*)h->d_rows;
@@ -1753,10 +1827,10 @@ static int64_t view_finish(mm_freq_t* h, int32_t ticket, int32_t* bad_read, bool
     auto copy_out = [&](size_t nsel) -> int {
         if (!to_host || s.view_on_host || nsel == 0) return 0;
         if (nsel > s.cap_hrows) {
-            if (s.h_vrows) (void)hipHostFree(s.h_vrows);
+            if (s.h_vrows) (void)mmdev::hfree(s.h_vrows);
             s.h_vrows = nullptr; s.cap_hrows = 0;
             size_t cap = nsel + nsel / 4 + 4096;
-            if (hipHostMalloc((void**)&s.h_vrows, sizeof(ViewRow) * cap, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
+            if (mmdev::hmalloc((void**)&s.h_vrows, sizeof(ViewRow) * cap, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
             s.cap_hrows = cap;
         }
         HIPCHK(hipMemcpyAsync(s.h_vrows, s.view_dev_rows, sizeof(ViewRow) * nsel, hipMemcpyDeviceToHost, st));
@@ -1860,10 +1934,10 @@ int32_t mm_freq_slab_export_host(mm_freq_t* h, int32_t tid, int64_t begin, int64
     if (bytes == 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     void* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
+    if (mmdev::dmalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
     int r = slab_op(h, 0, tid, begin, len, d, nullptr);
     if (!r && hipMemcpy(dst_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) r = -MM_E_HIP;
-    (void)hipFree(d);
+    (void)mmdev::dfree(d);
     return r;
 }
 int32_t mm_freq_slab_add_host(mm_freq_t* h, int32_t tid, int64_t begin, int64_t len, const void* src_host) {
@@ -1872,10 +1946,10 @@ int32_t mm_freq_slab_add_host(mm_freq_t* h, int32_t tid, int64_t begin, int64_t 
     if (bytes == 0) return 0;
     HIPCHK(hipSetDevice(h->device));
     void* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
+    if (mmdev::dmalloc(&d, bytes) != hipSuccess) return -MM_E_NOMEM;
     int r = hipMemcpy(d, src_host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -MM_E_HIP;
     if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
-    (void)hipFree(d);
+    (void)mmdev::dfree(d);
     return r;
 }
 
@@ -1888,8 +1962,8 @@ int32_t mm_freq_slab_export_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_
     const size_t bytes = 8 * (size_t)mm_freq_slab_words(h, len);
     if (bytes == 0) return -MM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (h->d_ipc_slab) { (void)hipFree(h->d_ipc_slab); h->d_ipc_slab = nullptr; }
-    if (hipMalloc(&h->d_ipc_slab, bytes) != hipSuccess) return -MM_E_NOMEM;
+    if (h->d_ipc_slab) { (void)mmdev::dfree(h->d_ipc_slab); h->d_ipc_slab = nullptr; }
+    if (mmdev::dmalloc(&h->d_ipc_slab, bytes) != hipSuccess) return -MM_E_NOMEM;
     int r = slab_op(h, 0, tid, begin, len, h->d_ipc_slab, nullptr);
     if (r) return r;
     HIPCHK(hipDeviceSynchronize());   // the neighbour reads it from another process: complete, and written back
@@ -1908,13 +1982,13 @@ int32_t mm_freq_slab_add_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_t l
     void* theirs = nullptr;
     if (hipIpcOpenMemHandle(&theirs, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -MM_E_HIP; }
     void* d = nullptr;
-    int r = hipMalloc(&d, bytes) == hipSuccess ? 0 : -MM_E_NOMEM;
+    int r = mmdev::dmalloc(&d, bytes) == hipSuccess ? 0 : -MM_E_NOMEM;
     // the copy on the handle's own (non-blocking) stream and waited for: the kernel that adds the slab runs on that stream, and the mapping
     // is closed -- and the sender told it may free the buffer -- only once the bytes are here (a D2D hipMemcpy on the null stream promises neither)
     if (!r && (hipMemcpyAsync(d, theirs, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)) r = -MM_E_HIP;
     (void)hipIpcCloseMemHandle(theirs);
     if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
-    if (d) (void)hipFree(d);
+    if (d) (void)mmdev::dfree(d);
     return r;
 }
 

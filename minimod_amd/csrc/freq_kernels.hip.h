@@ -1329,7 +1329,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     __shared__ uint32_t wsum[4];
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t run = tile_offsets[blockIdx.x];
+    // (a vector load at agent scope, not the s_load a wave-uniform address would be: the standalone probe found nothing wrong with the scalar cache --
+    // tools/scache_probe.hip, 0 stale words in 288 processes -- but the words were written by the kernel in front, and the load is one of 2 048 a workgroup)
+    uint32_t run = __hip_atomic_load(&tile_offsets[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int j0 = 0; j0 < kScanTile; j0 += 256) {
         const int64_t i = base + j0 + threadIdx.x;
         const uint32_t c = i < n ? cnt[i] : 0u;
@@ -1342,6 +1344,18 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
         run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
+}
+// the guard behind the index (nothing counts into an index that does not hold): every block's rank plus its own sites is the next block's rank, the first
+// rank is 0, the last block ends at the strand's total, and a block's count is its bits' -- bad[0] counts the blocks that break one of these
+__global__ __launch_bounds__(256) void k_site_check(const uint2* __restrict__ site, int stride, const uint32_t* __restrict__ cnt, int64_t n_blocks, const uint32_t* __restrict__ total,
+                                                    uint32_t* __restrict__ bad) {
+    uint32_t wrong = 0;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 w = site[b * stride];
+        const uint32_t next = b + 1 < n_blocks ? site[(b + 1) * stride].y : __hip_atomic_load(total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wrong += (w.y + (uint32_t)__popc(w.x) != next) || (b == 0 && w.y != 0u) || (cnt && cnt[b] != (uint32_t)__popc(w.x));
+    }
+    if (wrong) atomicAdd(bad, wrong);
 }
 // rank of a few positions (segment boundaries): out[i] = sites of the strand in front of g[i]
 __global__ void k_rank_at(const uint2* __restrict__ site, int stride, const int64_t* __restrict__ g, int n, int64_t n_blocks, uint32_t total, uint32_t* __restrict__ out) {

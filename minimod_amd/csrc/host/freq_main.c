@@ -7,6 +7,7 @@
 #include <errno.h>
 #include <getopt.h>
 #include <pthread.h>
+#include <spawn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
@@ -515,6 +516,34 @@ static void tie_codes(mm_tie_t *dtie, mm_freq_t *hv, const uint8_t *const *klass
     (void)mm_tie_set_codes(dtie, n_codes, codes, klass_of_code);
     *have = n_codes;
 }
+/* Where the device-side replay of the row order gives up (a haplotype tag above 61, a read with 2^18 calls, a launch it could not take: mm_tie_failed), the
+ * run is handed to the host's replay, which has none of those limits (tieorder.c restates src/khash.h and src/ksort.h serially): the SAME command line with
+ * --host-replay, as a child process -- nothing has been printed yet, a freq run prints when its rows are ordered -- and this process leaves with the child's
+ * exit code.  The canonical order is printed only when it is asked for (--canonical-order): a run never prints other bytes than the reference's by itself. */
+static int g_run_argc = 0;
+static char **g_run_argv = NULL;   /* run_main's arguments: "freq", options, reference, BAM */
+static int g_is_worker = 0;        /* a --devices worker: the parent starts the run again, the worker only says that it gave up */
+static int g_dev_replay_gave_up = 0;
+extern char **environ;
+static void rerun_with_host_replay(const char *why, unsigned bits) {
+    MMH_WARNING("the device-side replay of minimod's row order gave up (%s, reason bits 0x%x): the run starts again with --host-replay", why, bits);
+    fflush(stderr);
+    char **av = (char **)calloc((size_t)g_run_argc + 4, sizeof(char *));
+    if (!av || g_run_argc < 1) { MMH_ERROR("%s", "Could not start the run again"); _exit(EXIT_FAILURE); }
+    int n = 0;
+    av[n++] = (char *)"minimod"; av[n++] = g_run_argv[0]; av[n++] = (char *)"--host-replay";
+    for (int i = 1; i < g_run_argc; i++) av[n++] = g_run_argv[i];
+    av[n] = NULL;
+    pid_t pid = 0;
+    if (posix_spawn(&pid, "/proc/self/exe", NULL, NULL, av, environ) != 0) { MMH_ERROR("%s", "Could not start the run again (posix_spawn)"); _exit(EXIT_FAILURE); }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
+    _exit(WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE);   /* (_exit: what this process buffered for its own output is not written behind the child's) */
+}
+static void dev_replay_failed(const char *why, unsigned bits) {
+    if (g_is_worker) { if (!g_dev_replay_gave_up) MMH_WARNING("the device-side replay gave up in a worker (%s, reason bits 0x%x)", why, bits); g_dev_replay_gave_up = 1; return; }
+    rerun_with_host_replay(why, bits);
+}
 static void replay_ticket_dev(mm_freq_t *hv, mm_tie_t *dtie, int32_t ticket, const int32_t *n_reads, int n_batches, const mm_bam_hdr_t *hdr,
                               const uint8_t *const *klass_of_code, int *have_codes, double *seconds) {
     if (ticket < 0) return;
@@ -531,9 +560,12 @@ static void replay_ticket_dev(mm_freq_t *hv, mm_tie_t *dtie, int32_t ticket, con
         die_read_record((int)-n, in_batch, have ? &rec : NULL, hdr);
     }
     mm_batch_t db;
-    if (mm_freq_ticket_batch(hv, ticket, &db) == 0) {
+    if (g_dev_replay_gave_up) { *seconds += mmh_realtime() - t0; return; }
+    if (mm_freq_ticket_batch(hv, ticket, &db) != 0) dev_replay_failed("a launch's batch is gone", mm_tie_failed(dtie));
+    else {
         tie_codes(dtie, hv, klass_of_code, have_codes);
-        (void)mm_tie_add_launch(dtie, &db, rows, n, NULL);
+        const int32_t rc = mm_tie_add_launch(dtie, &db, rows, n, NULL);   /* (a launch it does not take marks the replay failed: its keys' stamps would be missing) */
+        if (rc != 0) dev_replay_failed(mm_strerror(-rc), mm_tie_failed(dtie));
     }
     *seconds += mmh_realtime() - t0;
 }
@@ -726,7 +758,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         }
         dlj.path = bam_file; dlj.pool = pool;
         /* its pinned staging and device buffers are made on a thread of their own while this one sets up the freq handle */
-        if (pthread_create(&bz_thread, NULL, dl_open_main, &dlj) == 0) bz_running = 2;
+        if (!getenv("MM_SERIAL_OPEN") && pthread_create(&bz_thread, NULL, dl_open_main, &dlj) == 0) bz_running = 2;
         else dl_open_main(&dlj);
     } else if (o.gpu_inflate && regular && mm_bam_peek_header(bam_file, &hdr0) == 0 && pthread_create(&bz_thread, NULL, bz_create_main, &bzj) == 0) {
         bz_running = 1;
@@ -776,8 +808,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
     if (!h) { MMH_ERROR("Assertion failed. %s", err); fprintf(stderr, "Exiting.\n"); exit(EXIT_FAILURE); }
     tl_mark(realtime0, "mm_freq_create done");
     if (replay && o.K >= (1 << 21)) {   /* (the rows the replay works from number a batch's reads with 21 bits) */
-        MMH_WARNING("%s", "-K of 2097152 or more: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype (the order of minimod's hash table is replayed for smaller batches)");
-        replay = 0;
+        MMH_ERROR("%s", "-K of 2097152 or more: the order minimod's hash table leaves rows that tie on (contig, start) in is replayed for smaller batches only. Use a smaller -K, or --canonical-order to print such rows by strand, code, ins_offset, haplotype");
+        exit(EXIT_FAILURE);
     }
     mm_freq_t *hv = NULL;      /* the second handle of a replay run: the same batches in view mode (rows with group ordinals) */
     mmh_tie_t *tie = NULL;
@@ -836,7 +868,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
      * hash table and its unstable sort leave them in (tieorder.c): that order is replayed from the calls of every read,
      * which a second handle in view mode delivers for the same batches.  A run whose rows cannot tie (-c m[CG]) needs
      * none of this. */
-    if (ws->fd < 0) {
+    const int header_late = !view && dev_replay;   /* (a run whose device replay gives up starts again as a child process: it must not have printed) */
+    if (ws->fd < 0 && !header_late) {
         if (view) mmh_print_view_header(o.out, o.insertions, o.haplotypes);
         else mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
     }
@@ -1175,12 +1208,12 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 int pal = 0;
                 void *dk = NULL; uint32_t *dh = NULL;
                 if (dev_replay) {   /* the sequence from the device: every key this worker's reads entered, in the order they did, as keys the parent's table takes */
-                    const int64_t nk = mm_tie_sequence_size(dtie);
+                    const int64_t nk = g_dev_replay_gave_up ? -1 : mm_tie_sequence_size(dtie);
                     mm_row_t *kr = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)(nk > 0 ? nk : 1));
                     dk = malloc(16 * (size_t)(nk > 0 ? nk : 1)); dh = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nk > 0 ? nk : 1));
                     int32_t pl = 0;
                     if (nk >= 0 && kr && dk && dh && mm_tie_sequence(dtie, kr, dh, nk, &pl) == nk) { mmh_tie_keys_from_rows(kr, NULL, nk, dk); tk = dk; th = dh; ntk = nk; pal = pl; }
-                    else MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
+                    else MMH_WARNING("the device-side replay gave up in a worker (reason bits 0x%x): the parent starts the run again with --host-replay", mm_tie_failed(dtie));
                     free(kr);
                 } else if (replay) ntk = mmh_tie_export2(tie, &tk, &th, &pal);
                 tt.n_rows = n_mine; tt.n_tie_keys = ntk; tt.tie_put_after = pal;
@@ -1227,8 +1260,8 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
             ordered = (mm_row_t *)malloc(sizeof(mm_row_t) * (size_t)nrows);
             int ord_rc = -1;
             if (ordered && dev_replay) {
-                ord_rc = mm_tie_order_rows2(dtie, rows, nrows, NULL, ordered);
-                if (ord_rc != 0) MMH_WARNING("the device-side replay gave up (reason bits 0x%x)", mm_tie_failed(dtie));
+                ord_rc = g_dev_replay_gave_up ? -1 : mm_tie_order_rows2(dtie, rows, nrows, NULL, ordered);
+                if (ord_rc != 0) rerun_with_host_replay("the final ordering", mm_tie_failed(dtie));   /* (does not return) */
                 else {
                     uint64_t ts[8];
                     (void)mm_tie_last_stats(ts);
@@ -1239,9 +1272,9 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                 memcpy(ordered, rows, sizeof(mm_row_t) * (size_t)nrows);
                 ord_rc = mmh_tie_order_rows_mt(tie, pool, ordered, nrows);
             }
-            if (!ordered || ord_rc != 0) {
-                MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
-                free(ordered); ordered = NULL;
+            if (!ordered || ord_rc != 0) {   /* (the host's replay has no limit but memory) */
+                MMH_ERROR("%s", "The order of minimod's hash table could not be replayed for this input (out of memory?). --canonical-order prints rows that tie on (contig, start) by strand, code, ins_offset, haplotype instead");
+                exit(EXIT_FAILURE);
             } else rows = ordered;
             replay_time += mmh_realtime() - tr;
             sort_time += mmh_realtime() - tr;
@@ -1258,6 +1291,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
         }
         const char *codes[MM_MAX_CODES];
         int n_codes = code_names(h, codes);
+        if (header_late) mmh_print_freq_header(o.out, o.bedmethyl, o.insertions, o.haplotypes);
         print_freq_rows_any(o.out, pool, rows, drows, nrows, hdr, codes, n_codes, o.bedmethyl, o.insertions, o.haplotypes, o.device);
         if (mmh_emit_flush() != 0) { MMH_ERROR("%s", "Could not write the output"); exit(EXIT_FAILURE); }
         output_time += mmh_realtime() - to;
@@ -1473,6 +1507,7 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
             wo.device = dev[r];
             wo.threads = o->threads / nd > 0 ? o->threads / nd : 1;
             ws[r].fd = pp[1];
+            g_is_worker = 1;
             if (o->view) {   /* a view worker prints its share's rows into its part file, no header */
                 wo.out = fopen(ws[r].part_path, "wb");
                 if (!wo.out) { MMH_ERROR("Cannot open file %s for writing", ws[r].part_path); _exit(EXIT_FAILURE); }
@@ -1573,8 +1608,11 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
             if (tot[r].n_tie_keys < 0) ok = 0;
             else if (tot[r].n_tie_keys > 0 && mmh_tie_import2(tie, wtk[r], wth[r], tot[r].n_tie_keys, (int)tot[r].tie_put_after) != 0) ok = 0;
         }
-        if (!ok || mmh_tie_order_rows(tie, out_rows, n_out) != 0)
-            MMH_WARNING("%s", "The order of minimod's hash table could not be replayed for this input: rows that tie on (contig, start) are printed by strand, code, ins_offset, haplotype");
+        if (!ok && !o->host_replay && !getenv("MINIMOD_HOST_REPLAY")) rerun_with_host_replay("a worker of --devices", 0u);   /* (does not return; nothing is printed yet) */
+        if (!ok || mmh_tie_order_rows(tie, out_rows, n_out) != 0) {
+            MMH_ERROR("%s", "The order of minimod's hash table could not be replayed for this input (out of memory?). --canonical-order prints rows that tie on (contig, start) by strand, code, ins_offset, haplotype instead");
+            exit(EXIT_FAILURE);
+        }
         mmh_tie_destroy(tie);
         sort_time = mmh_realtime() - ts;
         double to = mmh_realtime();
@@ -1628,6 +1666,7 @@ static int run_devices(const fopt_t *o, const mmh_mods_t *mods, mmh_ref_t *ref, 
 
 static int run_main(int argc, char **argv, int view) {
     double realtime0 = mmh_realtime();
+    g_run_argc = argc; g_run_argv = argv;   /* (getopt_long permutes argv in place: still the same command line) */
     const char *optstring = view ? "c:t:B:K:v:p:o:hV" : "m:c:t:B:K:v:p:o:hVb";   /* src/view_main.c:168, src/freq_main.c:185 */
     const struct option *lopts = view ? view_long_options : long_options;
     int longindex = 0, c;

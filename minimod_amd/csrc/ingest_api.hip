@@ -1,6 +1,7 @@
 // ingest_api.hip -- host side of the device-side BAM ingestion (include/minimod_ingest.h): group slots (pinned staging, device
 // buffers, a stream each for the copies and the inflate), arenas (a batch's pools), one chain stream for framing + flattening.
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -70,22 +71,22 @@ static hipError_t slot_alloc(mm_ingest* h, GSlot& s) {
     else SCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, h->prio_least));
     for (auto& e : s.ev) SCHK(hipEventCreate(&e));
     SCHK(hipEventCreate(&s.ev_f0)); SCHK(hipEventCreate(&s.ev_done));
-    SCHK(hipHostMalloc((void**)&s.h_c, h->o.max_cbytes + 64, hipHostMallocDefault));
-    SCHK(hipHostMalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
-    SCHK(hipHostMalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
-    SCHK(hipHostMalloc((void**)&s.h_result, sizeof(Result), hipHostMallocDefault));
-    SCHK(hipMalloc((void**)&s.d_c, h->o.max_cbytes + 4096));   // (readable bytes behind the payloads: the inflate's window runs ahead)
+    SCHK(mmdev::hmalloc((void**)&s.h_c, h->o.max_cbytes + 64, hipHostMallocDefault));
+    SCHK(mmdev::hmalloc((void**)&s.h_blocks, sizeof(mm_bgzf_block_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
+    SCHK(mmdev::hmalloc((void**)&s.h_status, sizeof(int32_t) * (size_t)h->o.max_blocks, hipHostMallocDefault));
+    SCHK(mmdev::hmalloc((void**)&s.h_result, sizeof(Result), hipHostMallocDefault));
+    SCHK(mmdev::dmalloc((void**)&s.d_c, h->o.max_cbytes + 4096));   // (readable bytes behind the payloads: the inflate's window runs ahead)
     SCHK(hipMemset(s.d_c, 0, h->o.max_cbytes + 4096));
-    SCHK(hipMalloc((void**)&s.d_out, (size_t)h->H + h->max_obytes + 256));
+    SCHK(mmdev::dmalloc((void**)&s.d_out, (size_t)h->H + h->max_obytes + 256));
     SCHK(hipMemset(s.d_out + (size_t)h->H + h->max_obytes, 0, 256));
-    SCHK(hipMalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)h->o.max_blocks));
-    SCHK(hipMalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)h->o.max_blocks));
-    SCHK(hipMalloc((void**)&s.d_tab, 6 * nb1 * sizeof(uint32_t)));
-    SCHK(hipMalloc((void**)&s.d_rec_off, sizeof(uint32_t) * (size_t)h->max_records));
-    SCHK(hipMalloc((void**)&s.d_acc, sizeof(uint32_t) * (size_t)h->max_records));
-    SCHK(hipMalloc((void**)&s.d_info, sizeof(uint32_t) * (size_t)h->max_records));
-    SCHK(hipMalloc((void**)&s.d_desc, sizeof(Desc) * (size_t)h->max_records));
-    SCHK(hipMalloc((void**)&s.d_result, sizeof(Result)));
+    SCHK(mmdev::dmalloc((void**)&s.d_blocks, sizeof(Block) * (size_t)h->o.max_blocks));
+    SCHK(mmdev::dmalloc((void**)&s.d_status, sizeof(int32_t) * (size_t)h->o.max_blocks));
+    SCHK(mmdev::dmalloc((void**)&s.d_tab, 6 * nb1 * sizeof(uint32_t)));
+    SCHK(mmdev::dmalloc((void**)&s.d_rec_off, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(mmdev::dmalloc((void**)&s.d_acc, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(mmdev::dmalloc((void**)&s.d_info, sizeof(uint32_t) * (size_t)h->max_records));
+    SCHK(mmdev::dmalloc((void**)&s.d_desc, sizeof(Desc) * (size_t)h->max_records));
+    SCHK(mmdev::dmalloc((void**)&s.d_result, sizeof(Result)));
     return hipSuccess;
 #undef SCHK
 }
@@ -169,11 +170,11 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     ICHK(hipStreamCreateWithFlags(&h->chain, hipStreamNonBlocking));
-    ICHK(hipMalloc((void**)&h->d_carry, 2 * sizeof(Carry)));
+    ICHK(mmdev::dmalloc((void**)&h->d_carry, 2 * sizeof(Carry)));
     ICHK(hipMemset(h->d_carry, 0, 2 * sizeof(Carry)));
-    ICHK(hipMalloc((void**)&h->d_cursor, 2 * sizeof(Cursor)));
+    ICHK(mmdev::dmalloc((void**)&h->d_cursor, 2 * sizeof(Cursor)));
     ICHK(hipMemset(h->d_cursor, 0, 2 * sizeof(Cursor)));
-    for (int k = 0; k < 2; k++) ICHK(hipMalloc((void**)&h->d_tail[k], h->H));
+    for (int k = 0; k < 2; k++) ICHK(mmdev::dmalloc((void**)&h->d_tail[k], h->H));
     const double t1 = now();
     big_maps("runtime + streams");
     h->slots = std::vector<GSlot>((size_t)h->o.group_slots);
@@ -198,13 +199,13 @@ mm_ingest_t* mm_ingest_create(const mm_ingest_opts_t* opts, char* err, size_t er
         a.cap_cigar = std::max<uint64_t>(D / 4 + (1 << 20), one); a.cap_seq = std::max<uint64_t>(D / 2 + (1 << 20), one);
         a.cap_mm = std::min<uint64_t>(std::max<uint64_t>(D / 4 + (1 << 20), one), 0xFFFFF000ull); a.cap_ml = std::max<uint64_t>(D / 8 + (1 << 20), one);
         a.cap_reads = std::max<uint64_t>(a.cap_reads, one / 36 + 4096);   // (a record is at least 36 bytes of stream)
-        ICHK(hipMalloc((void**)&a.reads, sizeof(mm_read_t) * a.cap_reads));
-        ICHK(hipMalloc((void**)&a.cigar, a.cap_cigar)); ICHK(hipMalloc((void**)&a.seq, a.cap_seq));
-        ICHK(hipMalloc((void**)&a.mm, a.cap_mm)); ICHK(hipMalloc((void**)&a.ml, a.cap_ml));
+        ICHK(mmdev::dmalloc((void**)&a.reads, sizeof(mm_read_t) * a.cap_reads));
+        ICHK(mmdev::dmalloc((void**)&a.cigar, a.cap_cigar)); ICHK(mmdev::dmalloc((void**)&a.seq, a.cap_seq));
+        ICHK(mmdev::dmalloc((void**)&a.mm, a.cap_mm)); ICHK(mmdev::dmalloc((void**)&a.ml, a.cap_ml));
         if (h->o.names) {   // a name is at most 255 of its record's bytes; an eighth of the stream holds the names of any BAM a sequencer's pipeline writes,
             a.cap_names = std::max<uint64_t>(D / 8 + (1 << 20), one);   // and never less than what one group can hold (the answer to "full" is an empty arena)
-            ICHK(hipMalloc((void**)&a.names, a.cap_names));
-            ICHK(hipMalloc((void**)&a.name_off, sizeof(uint64_t) * a.cap_reads));
+            ICHK(mmdev::dmalloc((void**)&a.names, a.cap_names));
+            ICHK(mmdev::dmalloc((void**)&a.name_off, sizeof(uint64_t) * a.cap_reads));
         }
     }
     big_maps("arenas");
@@ -230,16 +231,16 @@ void mm_ingest_destroy(mm_ingest_t* h) {
         if (s.ev_f0) (void)hipEventDestroy(s.ev_f0);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         void* hs[] = {s.h_c, s.h_blocks, s.h_status, s.h_result};
-        for (void* p : hs) if (p) (void)hipHostFree(p);
+        for (void* p : hs) if (p) (void)mmdev::hfree(p);
         void* ds[] = {s.d_c, s.d_out, s.d_blocks, s.d_status, s.d_tab, s.d_rec_off, s.d_acc, s.d_info, s.d_desc, s.d_result};
-        for (void* p : ds) if (p) (void)hipFree(p);
+        for (void* p : ds) if (p) (void)mmdev::dfree(p);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
-    for (Arena& a : h->arenas) { void* ds[] = {a.reads, a.cigar, a.seq, a.mm, a.ml, a.names, a.name_off}; for (void* p : ds) if (p) (void)hipFree(p); }
-    if (h->d_codes) (void)hipFree(h->d_codes);
-    if (h->h_codes) (void)hipHostFree(h->h_codes);
+    for (Arena& a : h->arenas) { void* ds[] = {a.reads, a.cigar, a.seq, a.mm, a.ml, a.names, a.name_off}; for (void* p : ds) if (p) (void)mmdev::dfree(p); }
+    if (h->d_codes) (void)mmdev::dfree(h->d_codes);
+    if (h->h_codes) (void)mmdev::hfree(h->h_codes);
     void* ds[] = {h->d_carry, h->d_cursor, h->d_tail[0], h->d_tail[1]};
-    for (void* p : ds) if (p) (void)hipFree(p);
+    for (void* p : ds) if (p) (void)mmdev::dfree(p);
     if (h->chain) (void)hipStreamDestroy(h->chain);
     delete h;
 }
@@ -397,8 +398,8 @@ int32_t mm_ingest_batch_codes(mm_ingest_t* h, const mm_batch_t* b, char* codes, 
     if (!h || !b || b->n_reads < 0 || (!codes && max_codes > 0) || max_codes < 0) return -MM_INGEST_E_ARG;
     RCHK(hipSetDevice(h->device));
     if (!h->d_codes) {
-        RCHK(hipMalloc((void**)&h->d_codes, sizeof(CodeTab)));
-        RCHK(hipHostMalloc((void**)&h->h_codes, sizeof(CodeTab), hipHostMallocDefault));
+        RCHK(mmdev::dmalloc((void**)&h->d_codes, sizeof(CodeTab)));
+        RCHK(mmdev::hmalloc((void**)&h->h_codes, sizeof(CodeTab), hipHostMallocDefault));
     }
     RCHK(hipMemsetAsync(h->d_codes, 0, sizeof(CodeTab), h->chain));
     RCHK(hipMemsetAsync(h->d_codes->stamp, 0xFF, sizeof(h->d_codes->stamp), h->chain));

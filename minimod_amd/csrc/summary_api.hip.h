@@ -167,19 +167,19 @@ int32_t mm_summary_batch(mm_summary_t* s, const mm_batch_t* b, const char** text
     hipStream_t st = s->st;
     auto regrow = [&](void** p, size_t* cap, size_t need, size_t elem) -> int {
         if (*p && need <= *cap) return 0;
-        if (*p) (void)hipFree(*p);
+        if (*p) (void)mmdev::dfree(*p);
         *p = nullptr;
         const size_t nc = need + need / 4 + 1024;
-        if (hipMalloc(p, nc * elem) != hipSuccess) return MM_E_NOMEM;
+        if (mmdev::dmalloc(p, nc * elem) != hipSuccess) return MM_E_NOMEM;
         *cap = nc;
         return 0;
     };
     if (n > s->cap_reads) {
         void* ps[] = {s->d_reads, s->d_groups, s->d_tiles, s->d_toff, s->d_tlen, s->d_status};
-        for (void* p : ps) if (p) (void)hipFree(p);
+        for (void* p : ps) if (p) (void)mmdev::dfree(p);
         const size_t nc = (size_t)n + n / 4 + 1024;
-        if (hipMalloc((void**)&s->d_reads, sizeof(mm_read_t) * nc) != hipSuccess || hipMalloc((void**)&s->d_groups, 8 * nc) != hipSuccess || hipMalloc((void**)&s->d_tiles, 8 * (nc / kScanTile + 4)) != hipSuccess ||
-            hipMalloc((void**)&s->d_toff, 8 * nc) != hipSuccess || hipMalloc((void**)&s->d_tlen, 4 * nc) != hipSuccess || hipMalloc((void**)&s->d_status, 4 * nc) != hipSuccess) return MM_E_NOMEM;
+        if (mmdev::dmalloc((void**)&s->d_reads, sizeof(mm_read_t) * nc) != hipSuccess || mmdev::dmalloc((void**)&s->d_groups, 8 * nc) != hipSuccess || mmdev::dmalloc((void**)&s->d_tiles, 8 * (nc / kScanTile + 4)) != hipSuccess ||
+            mmdev::dmalloc((void**)&s->d_toff, 8 * nc) != hipSuccess || mmdev::dmalloc((void**)&s->d_tlen, 4 * nc) != hipSuccess || mmdev::dmalloc((void**)&s->d_status, 4 * nc) != hipSuccess) return MM_E_NOMEM;
         s->cap_reads = nc;
     }
     { size_t c = s->cap_mm; if (regrow((void**)&s->d_mm, &c, (size_t)b->n_mm_bytes + 64, 1)) return MM_E_NOMEM; s->cap_mm = c; }
@@ -192,10 +192,10 @@ int32_t mm_summary_batch(mm_summary_t* s, const mm_batch_t* b, const char** text
     const size_t tab_need = 4 * (size_t)total_groups + 8 * (size_t)n + 64;
     if (total_groups > s->cap_groups || !s->d_keys || tab_need > s->cap_tab) {
         void* ps[] = {s->d_keys, s->d_tab, s->d_old, s->d_new};
-        for (void* p : ps) if (p) (void)hipFree(p);
+        for (void* p : ps) if (p) (void)mmdev::dfree(p);
         s->d_keys = nullptr; s->d_tab = nullptr; s->d_old = nullptr; s->d_new = nullptr; s->cap_groups = 0; s->cap_tab = 0;
         const size_t nc = (size_t)total_groups + (size_t)total_groups / 4 + 1024, tn = tab_need + tab_need / 4;
-        if (hipMalloc((void**)&s->d_keys, sizeof(SumKey) * nc) != hipSuccess || hipMalloc((void**)&s->d_tab, 4 * tn) != hipSuccess || hipMalloc((void**)&s->d_old, tn) != hipSuccess || hipMalloc((void**)&s->d_new, tn) != hipSuccess) return MM_E_NOMEM;
+        if (mmdev::dmalloc((void**)&s->d_keys, sizeof(SumKey) * nc) != hipSuccess || mmdev::dmalloc((void**)&s->d_tab, 4 * tn) != hipSuccess || mmdev::dmalloc((void**)&s->d_old, tn) != hipSuccess || mmdev::dmalloc((void**)&s->d_new, tn) != hipSuccess) return MM_E_NOMEM;
         s->cap_groups = nc; s->cap_tab = tn;
     }
     const size_t text_cap = (size_t)b->n_mm_bytes + 6 * (size_t)total_groups + 64;
@@ -216,7 +216,7 @@ void mm_summary_destroy(mm_summary_t* s) {
     (void)hipSetDevice(s->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
     void* ps[] = {s->d_reads, s->d_mm, s->d_groups, s->d_tiles, s->d_toff, s->d_tlen, s->d_status, s->d_keys, s->d_tab, s->d_old, s->d_new, s->d_text};
-    for (void* p : ps) if (p) (void)hipFree(p);
+    for (void* p : ps) if (p) (void)mmdev::dfree(p);
     if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
 }

@@ -2,6 +2,7 @@
 // The fixpoint loops (placement rounds, growth passes, sort levels) are driven from the host: a round is a kernel over all keys of the
 // step, a flag in pinned host memory says whether anything moved.
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -25,11 +26,11 @@ struct Bufs {   // device allocations of one call, freed together
     int64_t bytes = 0;
     template <class T> T* get(size_t n) {
         void* q = nullptr;
-        if (hipMalloc(&q, sizeof(T) * (n ? n : 1)) != hipSuccess) return nullptr;
+        if (mmdev::dmalloc(&q, sizeof(T) * (n ? n : 1)) != hipSuccess) return nullptr;
         p.push_back(q); bytes += (int64_t)(sizeof(T) * (n ? n : 1));
         return (T*)q;
     }
-    ~Bufs() { for (void* q : p) (void)hipFree(q); }
+    ~Bufs() { for (void* q : p) (void)mmdev::dfree(q); }
 };
 
 inline unsigned blocks(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per ? (n + per - 1) / per : 1); }
@@ -77,8 +78,8 @@ int core_and_sort(const uint32_t* d_hash, const long long* d_sortkey, uint64_t n
     auto mark = [&](const char* what) { if (tl) { (void)hipStreamSynchronize(st); const double t = now(); std::fprintf(stderr, "[timeline] tie order: %-40s %.2f ms\n", what, 1e3 * (t - t_last)); t_last = t; } };
     Bufs B;
     volatile uint32_t* hflag = nullptr;   // [0] changed, [1] moved, [2] fail, [4..5] a 64-bit word, [6] a count
-    if (hipHostMalloc((void**)&hflag, 64, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
-    struct HF { volatile uint32_t* p; ~HF() { (void)hipHostFree((void*)p); } } hf{hflag};
+    if (mmdev::hmalloc((void**)&hflag, 64, hipHostMallocDefault) != hipSuccess) return -MM_E_NOMEM;
+    struct HF { volatile uint32_t* p; ~HF() { (void)mmdev::hfree((void*)p); } } hf{hflag};
     for (int i = 0; i < 16; i++) hflag[i] = 0;
     uint32_t* f_changed = (uint32_t*)&hflag[0];
     uint32_t* f_moved = (uint32_t*)&hflag[1];
@@ -297,9 +298,9 @@ namespace {
 template <class T> int grow_buf(mm_tie* t, T** p, size_t* cap, size_t need, size_t elems_per = 1) {
     (void)elems_per;
     if (need <= *cap && *p) return 0;
-    if (*p) { (void)hipFree(*p); t->device_bytes -= (int64_t)(sizeof(T) * *cap); *p = nullptr; *cap = 0; }
+    if (*p) { (void)mmdev::dfree(*p); t->device_bytes -= (int64_t)(sizeof(T) * *cap); *p = nullptr; *cap = 0; }
     const size_t nc = need + need / 4 + 1024;
-    if (hipMalloc((void**)p, sizeof(T) * nc) != hipSuccess) { *p = nullptr; return -MM_E_NOMEM; }
+    if (mmdev::dmalloc((void**)p, sizeof(T) * nc) != hipSuccess) { *p = nullptr; return -MM_E_NOMEM; }
     *cap = nc; t->device_bytes += (int64_t)(sizeof(T) * nc);
     return 0;
 }
@@ -318,13 +319,13 @@ int ensure_stamps(mm_tie* t, uint64_t incoming) {
     uint64_t nc = t->gcap ? t->gcap : (1ull << 16);
     while (nc < need) nc *= 2;
     u64 *nk = nullptr, *ns = nullptr;
-    if (hipMalloc((void**)&nk, 8 * nc) != hipSuccess) return -MM_E_NOMEM;
-    if (hipMalloc((void**)&ns, 8 * nc) != hipSuccess) { (void)hipFree(nk); return -MM_E_NOMEM; }
+    if (mmdev::dmalloc((void**)&nk, 8 * nc) != hipSuccess) return -MM_E_NOMEM;
+    if (mmdev::dmalloc((void**)&ns, 8 * nc) != hipSuccess) { (void)mmdev::dfree(nk); return -MM_E_NOMEM; }
     LAUNCH(k_fill64, blocks(nc), 256, t->st, nk, (u64)nc, kNone64);
     LAUNCH(k_fill64, blocks(nc), 256, t->st, ns, (u64)nc, kNone64);
     if (t->gcap) LAUNCH(k_stamp_rehash, blocks(t->gcap), 256, t->st, (const u64*)t->d_gkey, (const u64*)t->d_gstamp, (u64)t->gcap, nk, ns, (u64)(nc - 1));
-    if (hipStreamSynchronize(t->st) != hipSuccess) { (void)hipFree(nk); (void)hipFree(ns); return -MM_E_HIP; }
-    if (t->d_gkey) { (void)hipFree(t->d_gkey); (void)hipFree(t->d_gstamp); t->device_bytes -= (int64_t)(16 * t->gcap); }
+    if (hipStreamSynchronize(t->st) != hipSuccess) { (void)mmdev::dfree(nk); (void)mmdev::dfree(ns); return -MM_E_HIP; }
+    if (t->d_gkey) { (void)mmdev::dfree(t->d_gkey); (void)mmdev::dfree(t->d_gstamp); t->device_bytes -= (int64_t)(16 * t->gcap); }
     t->d_gkey = nk; t->d_gstamp = ns; t->gcap = nc; t->device_bytes += (int64_t)(16 * nc);
     return 0;
 }
@@ -403,11 +404,11 @@ mm_tie_t* mm_tie_create(const mm_tie_opts_t* opts, const char* const* contig_nam
     }
     bool ok = hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking) == hipSuccess;
     const size_t ncs = (size_t)std::max(nc, 1);
-    ok = ok && hipMalloc((void**)&t->d_ctg_hash, 4 * ncs) == hipSuccess && hipMalloc((void**)&t->d_ctg_base, 8 * ncs) == hipSuccess && hipMalloc((void**)&t->d_ctg_rank, 4 * ncs) == hipSuccess;
-    ok = ok && hipMalloc((void**)&t->d_klass, 256 * MM_MAX_CODES) == hipSuccess && hipMalloc((void**)&t->d_mid, sizeof(uint2) * 2 * MM_MAX_CODES) == hipSuccess &&
-         hipMalloc((void**)&t->d_codes, MM_MAX_CODES * MM_CODE_LEN) == hipSuccess;
-    ok = ok && hipMalloc((void**)&t->d_words, 32) == hipSuccess && hipMalloc((void**)&t->d_fail, 16) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&t->h_words, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && mmdev::dmalloc((void**)&t->d_ctg_hash, 4 * ncs) == hipSuccess && mmdev::dmalloc((void**)&t->d_ctg_base, 8 * ncs) == hipSuccess && mmdev::dmalloc((void**)&t->d_ctg_rank, 4 * ncs) == hipSuccess;
+    ok = ok && mmdev::dmalloc((void**)&t->d_klass, 256 * MM_MAX_CODES) == hipSuccess && mmdev::dmalloc((void**)&t->d_mid, sizeof(uint2) * 2 * MM_MAX_CODES) == hipSuccess &&
+         mmdev::dmalloc((void**)&t->d_codes, MM_MAX_CODES * MM_CODE_LEN) == hipSuccess;
+    ok = ok && mmdev::dmalloc((void**)&t->d_words, 32) == hipSuccess && mmdev::dmalloc((void**)&t->d_fail, 16) == hipSuccess;
+    ok = ok && mmdev::hmalloc((void**)&t->h_words, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) {
         ok = hipMemcpy(t->d_ctg_hash, ch.data(), 4 * ncs, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(t->d_ctg_base, cb.data(), 8 * ncs, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(t->d_ctg_rank, rk.data(), 4 * ncs, hipMemcpyHostToDevice) == hipSuccess && hipMemset(t->d_words, 0, 32) == hipSuccess && hipMemset(t->d_fail, 0, 16) == hipSuccess &&
@@ -445,14 +446,13 @@ int32_t mm_tie_set_codes(mm_tie_t* t, int32_t n_codes, const char* const* codes,
     return 0;
 }
 
-int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view_rows, int64_t n_rows, void* hip_stream) {
-    if (!t || !b || n_rows < 0) return -MM_E_ARG;
-    (void)hip_stream;   // (the rows are complete when mm_view_fetch_device returns; the replay has a stream of its own)
+// (the launch's work: whatever it returns, mm_tie_add_launch has counted the launch's reads -- a launch that is NOT taken leaves the replay marked failed:
+// keys of an unstamped launch that come again later would get a later first-insertion stamp, and the order printed from that would be wrong without a word)
+static int32_t add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view_rows, int64_t n_rows, const uint64_t serial0) {
     const uint32_t nr = (uint32_t)b->n_reads;
-    if (b->n_reads <= 0) return 0;
-    if (b->n_reads >= (1 << 21) || n_rows >= 0xFFFFFFF0ll) { t->failed |= TIE_F_ROWS; t->serial += nr; return -MM_E_TOOMANY; }
+    if (b->n_reads >= (1 << 21) || n_rows >= 0xFFFFFFF0ll) { t->failed |= TIE_F_ROWS; return -MM_E_TOOMANY; }
     if (hipSetDevice(t->o.device) != hipSuccess) return -MM_E_HIP;
-    if (n_rows == 0) { t->serial += nr; return 0; }
+    if (n_rows == 0) return 0;
     const size_t per = t->o.haplotypes ? 2 : 1;
     size_t cap_beg = t->cap_reads, cap_end = t->cap_reads;
     if (grow_buf(t, &t->d_beg, &cap_beg, nr) || grow_buf(t, &t->d_end, &cap_end, nr)) return -MM_E_NOMEM;
@@ -470,7 +470,7 @@ int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view
     LAUNCH(k_tie_bounds, blocks((uint64_t)n_rows), 256, st, (const mm_view_row_t*)dev_view_rows, (uint32_t)n_rows, nr, t->d_beg, t->d_end, t->d_fail);
     TieLaunch L;
     L.reads = b->reads; L.mm = b->mm; L.rows = (const mm_view_row_t*)dev_view_rows; L.n_reads = nr; L.n_rows = (uint32_t)n_rows;
-    L.beg = t->d_beg; L.end = t->d_end; L.serial0 = t->serial;
+    L.beg = t->d_beg; L.end = t->d_end; L.serial0 = serial0;
     L.sk_a = t->d_ska; L.sk_b = t->d_skb; L.keys = t->d_keys; L.khash = t->d_khash;
     L.tab = t->d_tab; L.rt = t->d_rt; L.rc = t->d_rc;
     L.gkey = t->d_gkey; L.gstamp = t->d_gstamp; L.gmask = t->gcap - 1;
@@ -484,9 +484,19 @@ int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view
     if (hipMemcpyAsync(&cnt, t->d_words + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&hfail, t->d_fail, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) return -MM_E_HIP;
     t->distinct = cnt;
-    t->serial += nr;
     if (hfail) { t->failed |= hfail; return -MM_E_NOCODE; }
     return 0;
+}
+int32_t mm_tie_add_launch(mm_tie_t* t, const mm_batch_t* b, const void* dev_view_rows, int64_t n_rows, void* hip_stream) {
+    if (!t || !b || n_rows < 0) return -MM_E_ARG;
+    (void)hip_stream;   // (the rows are complete when mm_view_fetch_device returns; the replay has a stream of its own)
+    if (b->n_reads <= 0) return 0;
+    const uint64_t serial0 = t->serial;
+    t->serial += (uint64_t)b->n_reads;   // once, whatever becomes of the launch: later launches' reads keep their serials
+    const int32_t r = add_launch(t, b, dev_view_rows, n_rows, serial0);
+    if (r != 0 && !t->failed) t->failed |= TIE_F_INTERNAL;   // (sticky: mm_tie_order_rows / mm_tie_sequence refuse from here on)
+    if (r != 0) (void)hipGetLastError();
+    return r;
 }
 
 int32_t mm_tie_order_rows(mm_tie_t* t, const mm_row_t* rows, int64_t n, uint32_t* perm) { return mm_tie_order_rows2(t, rows, n, perm, nullptr); }
@@ -574,8 +584,8 @@ void mm_tie_destroy(mm_tie_t* t) {
     if (t->st) (void)hipStreamSynchronize(t->st);
     void* ps[] = {t->d_klass, t->d_ctg_hash, t->d_ctg_base, t->d_ctg_rank, t->d_mid, t->d_codes, t->d_beg, t->d_end, t->d_ska, t->d_skb, t->d_keys, t->d_khash,
                   t->d_tab, t->d_rt, t->d_rc, t->d_gkey, t->d_gstamp, t->d_words, t->d_fail};
-    for (void* p : ps) if (p) (void)hipFree(p);
-    if (t->h_words) (void)hipHostFree((void*)t->h_words);
+    for (void* p : ps) if (p) (void)mmdev::dfree(p);
+    if (t->h_words) (void)mmdev::hfree((void*)t->h_words);
     if (t->st) (void)hipStreamDestroy(t->st);
     delete t;
 }

@@ -619,7 +619,7 @@ struct TieLaunch {
     u64* gkey; u64* gstamp; u64 gmask;
     u64* last_put; uint32_t* fail;
 };
-enum { TIE_F_CODE = 1, TIE_F_ROWS = 2, TIE_F_HP = 4, TIE_F_CONTIG = 8, TIE_F_SLOTS = 16, TIE_F_MISSING = 32 };
+enum { TIE_F_CODE = 1, TIE_F_ROWS = 2, TIE_F_HP = 4, TIE_F_CONTIG = 8, TIE_F_SLOTS = 16, TIE_F_MISSING = 32, TIE_F_INTERNAL = 64 /* a launch was not taken: out of memory, a HIP failure */ };
 
 // rows arrive ordered by read: [beg, end) of every read that has any (the arrays start zeroed)
 __global__ __launch_bounds__(256) void k_tie_bounds(const mm_view_row_t* __restrict__ rows, uint32_t n, uint32_t n_reads, uint32_t* __restrict__ beg, uint32_t* __restrict__ end, uint32_t* __restrict__ fail) {

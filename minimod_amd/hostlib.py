@@ -217,9 +217,9 @@ def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementa
     L.mmh_devloader_stats.restype = ctypes.POINTER(mmh_devloader_stats_t)
     L.mmh_devloader_stats.argtypes = [ctypes.c_void_p]
     L.mmh_devloader_close.argtypes = [ctypes.c_void_p]
-    names, lens, hb = peek_header(path)
+    tnames, lens, hb = peek_header(path)   # (the contigs' names: `names` is the caller's switch for the READS' names)
     o = mmh_devloader_opts_t()
-    o.device = device; o.n_targets = len(names); o.allow_secondary = int(allow_secondary); o.skip_supplementary = int(skip_supplementary)
+    o.device = device; o.n_targets = len(tnames); o.allow_secondary = int(allow_secondary); o.skip_supplementary = int(skip_supplementary)
     o.header_bytes = hb; o.voffset = voffset; o.target_bases = target_bases
     o.names = int(bool(names))
     L.mmh_devloader_codes.restype = ctypes.c_int
@@ -253,6 +253,8 @@ def load_batches_device(path, threads=2, allow_secondary=False, skip_supplementa
                 d = {"reads": fetch(b.reads, b.n_reads, READ_DTYPE), "cigar": fetch(b.cigar, b.n_cigar_words, "<u4"),
                      "seq": fetch(b.seq, b.n_seq_bytes, np.uint8), "mm": fetch(b.mm, b.n_mm_bytes, np.uint8),
                      "ml": fetch(b.ml, b.n_ml_bytes, np.uint8), "max_n_cigar": b.max_n_cigar, "max_l_qseq": b.max_l_qseq}
+                if not names:   # (the default reader geometry -- what a plain freq run uses -- keeps no names)
+                    assert not db.names and db.names_bytes == 0, "a reader opened without names handed names out"
                 if names:
                     off = fetch(db.name_off, b.n_reads, "<u8")
                     txt = fetch(db.names, db.names_bytes, np.uint8).tobytes()

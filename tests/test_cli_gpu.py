@@ -431,3 +431,61 @@ def test_cli_takes_more_than_thirteen_entries(fastas, chr22):
     ctx14 = ["CG", "A", "C", "CT", "CC", "T", "G", "AC", "GC", "TA", "CA", "GG", "TT", "AG"]
     r14 = subprocess.run([BIN, "freq", "-c", ",".join("%d[%s]" % (1000 + i, x) for i, x in enumerate(ctx14))] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r14.returncode == 1 and b"different contexts" in r14.stderr
+
+
+# ---- many processes on one GPU (round 6: csrc/devmem.h, profiles/r6_site_index_root_cause.txt)
+def test_twelve_clis_at_once(tmp_path):
+    """Twelve CLIs at once on one GPU, each on an input of its own, ten runs each: every run exits 0 with the bytes of a quiet run on the same
+    input.  (Rounds 4 and 5 printed a wrong strand's rows once in a hundred such runs: the site index's block counts were read through the
+    translation of the buffer mm_freq_create had just freed.  tools/cli_stress.py is the same loop for longer campaigns.)"""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    from minimod_amd import synth
+    from oracle import oracle as O
+    W, K = 12, 10
+    cmds, want = [], []
+    for w in range(W):
+        ref = synth.reference(13 + w, (2 << 20) - w * 50000)
+        bs = [synth.batch(ref, i * 200, 200, seed=3 + 11 * w, n_reads_total=600) for i in range(3)]
+        bam, fa = str(tmp_path / ("s%d.bam" % w)), str(tmp_path / ("s%d.fa" % w))
+        synth.write_bam(bam, [("chrS", len(ref))], bs)
+        synth.write_fasta(fa, "chrS", ref)
+        cmds.append([BIN, "freq", "-b", "-c", "m[CG]", "-m", "0.8", "-K", "512", "-B", "100M", "-t", "4", fa, bam])
+        quiet = subprocess.run(cmds[-1], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert quiet.returncode == 0, quiet.stderr.decode()[-2000:]
+        if w == 0:   # (one of the inputs against the oracle: the quiet runs are the reference's bytes)
+            orc = O.Oracle([("m", "CG")], [0.8], ["chrS"])
+            orc.add_contig("chrS", ref)
+            for b in bs:
+                orc.process(b, threads=4)
+            assert quiet.stdout.decode() == O.format_rows(orc.rows(), ["chrS"], orc.code_names(), bedmethyl=True)
+        want.append(hashlib.md5(quiet.stdout).hexdigest())
+
+    def worker(w):
+        bad = []
+        for k in range(K):
+            r = subprocess.run(cmds[w], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0 or hashlib.md5(r.stdout).hexdigest() != want[w] or b"failed its check" in r.stderr:
+                bad.append((w, k, r.returncode, r.stderr.decode(errors="replace")[-800:]))
+        return bad
+    with ThreadPoolExecutor(max_workers=W) as ex:
+        bad = [b for bl in ex.map(worker, range(W)) for b in bl]
+    assert not bad, "%d of %d runs went wrong: %r" % (len(bad), W * K, bad[:2])
+
+
+def test_a_site_index_that_fails_its_check_is_rebuilt_once_and_then_refused(tmp_path):
+    """The guard behind the site index (k_site_check, mm_freq_create): an index whose ranks do not add up is never counted into.  MM_SITE_FAULT=1
+    damages the first build (the run repairs it and prints the right bytes), =2 both (the run refuses)."""
+    from minimod_amd import synth
+    ref = synth.reference(5, 1 << 20)
+    bs = [synth.batch(ref, 0, 200, seed=9, n_reads_total=200)]
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, [("chrS", len(ref))], bs)
+    synth.write_fasta(fa, "chrS", ref)
+    cmd = [BIN, "freq", "-b", "-c", "m[CG]", "-m", "0.8", fa, bam]
+    good = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert good.returncode == 0 and len(good.stdout) > 10000 and b"failed its check" not in good.stderr
+    once = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MM_SITE_FAULT="1"))
+    assert once.returncode == 0 and once.stdout == good.stdout and b"failed its check" in once.stderr and b"building it once more" in once.stderr
+    twice = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MM_SITE_FAULT="2"))
+    assert twice.returncode != 0 and twice.stdout == b"" and b"refused" in twice.stderr

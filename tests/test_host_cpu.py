@@ -28,6 +28,20 @@ def test_abi_exports_every_declared_symbol():
     assert [n for n in engine.READ_DTYPE.names] == [n for n in pybam.READ_DTYPE.names]
 
 
+def test_allocator_symbols_exported():
+    """mm_devmem_stats / mm_devmem_trim (include/minimod_bgzf.h; csrc/devmem.h): exported, and no unit of the device library goes to the
+    driver's malloc / free by itself -- an address the driver takes back and hands out again is what broke the site index (round 6)."""
+    import ctypes, glob
+    from minimod_amd import build
+    L = ctypes.CDLL(build.lib_path())
+    hdr = open(os.path.join(ROOT, "include", "minimod_bgzf.h")).read()
+    for name in ("mm_devmem_stats", "mm_devmem_trim"):
+        assert name in hdr and hasattr(L, name), name
+    for f in glob.glob(os.path.join(ROOT, "minimod_amd", "csrc", "*.hip*")):
+        src = open(f).read()
+        assert not re.search(r"\bhip(Malloc|Free|HostMalloc|HostFree)\(", src), "%s allocates behind the library's allocator" % os.path.basename(f)
+
+
 def test_bgzf_abi_symbols_exported():
     """Every function include/minimod_bgzf.h declares is exported by the device library (no calls: there is no GPU here)."""
     import ctypes, re
@@ -766,6 +780,11 @@ def test_a_process_leaves_its_teardown_behind_without_holding_its_pipes():
              "big = bytearray(200 << 20)\n"
              "for i in range(0, len(big), 4096): big[i] = 1\n"
              "ctypes.c_int.in_dll(L, 'mmh_gpu_in_use').value = int(sys.argv[1])\n"
+             "if len(sys.argv) > 3 and sys.argv[3] == 'high':\n"   # the pipe's descriptors above 4096 (the helper kept its own write end there)
+             "    import resource\n"
+             "    resource.setrlimit(resource.RLIMIT_NOFILE, (8192, resource.getrlimit(resource.RLIMIT_NOFILE)[1]))\n"
+             "    null = os.open('/dev/null', os.O_RDONLY)\n"
+             "    for i in range(4300): os.dup(null)\n"
              "sys.stdout.write('the last word'); sys.stdout.flush(); sys.stderr.write('and its echo'); sys.stderr.flush()\n"
              "L.mmh_leave_teardown_behind()\n"
              "os._exit(7)\n") % os.path.join(B.LIBDIR, "libminimod_host.so")
@@ -784,16 +803,21 @@ def test_a_process_leaves_its_teardown_behind_without_holding_its_pipes():
                 if pid_text.encode() in cmd and state != "Z":
                     n += 1
         return n
-    for in_use in (1, 0):
-        tag = "exitpath-test-%d-%d" % (os.getpid(), in_use)
+    on = dict(os.environ, MM_ASYNC_EXIT="1")   # (round 6: the helper is opt-in)
+    on.pop("MM_SYNC_EXIT", None)
+    for in_use, where in ((1, "low"), (1, "high"), (0, "low")):
+        tag = "exitpath-test-%d-%d-%s" % (os.getpid(), in_use, where)
         t0 = time.time()
-        r = subprocess.run([sys.executable, "-c", child, str(in_use), tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        r = subprocess.run([sys.executable, "-c", child, str(in_use), tag, where], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=on)
         assert r.returncode == 7 and r.stdout == b"the last word" and r.stderr == b"and its echo"
         assert time.time() - t0 < 30
         deadline = time.time() + 20
         while helpers_of(tag) and time.time() < deadline:   # (the helper shares the child's command line; it leaves when it has seen the pipe close)
             time.sleep(0.05)
         assert helpers_of(tag) == 0
-    # MM_SYNC_EXIT=1: no helper
-    r = subprocess.run([sys.executable, "-c", child, "1", "exitpath-test-sync"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=dict(os.environ, MM_SYNC_EXIT="1"))
-    assert r.returncode == 7 and r.stdout == b"the last word"
+    # the default, and MM_SYNC_EXIT=1 on top of MM_ASYNC_EXIT=1: no helper
+    off = {k: v for k, v in os.environ.items() if k not in ("MM_ASYNC_EXIT", "MM_SYNC_EXIT")}
+    for env in (off, dict(on, MM_SYNC_EXIT="1")):
+        r = subprocess.run([sys.executable, "-c", child, "1", "exitpath-test-sync-%d" % os.getpid()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+        assert r.returncode == 7 and r.stdout == b"the last word"
+        assert helpers_of("exitpath-test-sync-%d" % os.getpid()) == 0
