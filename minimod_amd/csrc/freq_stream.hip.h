@@ -1167,6 +1167,9 @@ struct KF {
         const int64_t seg_begin = scalar_load(p.seg_begin + tid_c), seg_len = scalar_load(p.seg_len + tid_c);
         int st = (tid_ok && ref_base >= 0 && L > 0u && ncig > 0u) ? 0 : 1;
         d_n = 0; c_n = 0; rank_ok = 0; v_seq = 0; v_sorted = 0;
+#ifdef MM_ABL_NORUN   // (diagnostic, with tools/valu.sh: the hand-out and the record alone)
+        return (int)(lane_valu(cv[0].x, 0) == 0xDEADBEEFu && nx_w0 == 0x12345u) + (int)(ctg_len + seg_begin + seg_len == -77) + st * 0;
+#endif
         if (st == 0) {
             // the whole CIGAR once (get_aln walks it before anything else, mod.c:776-881): totals, the checks reduced to what a
             // clean record passes outright (anything else is the tile pipeline's to judge op by op) -- and, on the way, the

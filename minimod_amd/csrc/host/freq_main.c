@@ -1116,6 +1116,7 @@ static int run_body(const fopt_t *op, const mmh_mods_t *modsp, mmh_ref_t *ref, c
                     if (!buf || read_all(ws->slab_in, buf, sizeof(uint64_t) * (size_t)nw) != 0) { MMH_ERROR("%s", "A worker of --devices lost its left neighbour"); exit(EXIT_FAILURE); }
                     int e = mm_freq_slab_add_host(h, (int32_t)hd[0], hd[1], hd[2], buf);
                     if (e) { MMH_ERROR("GPU path failed: %s", mm_strerror(e)); exit(EXIT_FAILURE); }
+                    fprintf(stderr, "[%s] halo slab of %ld positions taken from the left neighbour through host memory\n", __func__, (long)hd[2]);
                     free(buf);
                 }
             }

@@ -489,3 +489,71 @@ def test_a_site_index_that_fails_its_check_is_rebuilt_once_and_then_refused(tmp_
     assert once.returncode == 0 and once.stdout == good.stdout and b"failed its check" in once.stderr and b"building it once more" in once.stderr
     twice = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, MM_SITE_FAULT="2"))
     assert twice.returncode != 0 and twice.stdout == b"" and b"refused" in twice.stderr
+
+
+# ---- where the device-side replay of the row order gives up, the run goes to the host's replay: the reference's bytes (src/mod.c:59-93,655-663)
+def _tied_inputs(tmp_path, records, ref):
+    from minimod_amd import synth
+    from oracle import pybam
+    bam, fa = str(tmp_path / "t.bam"), str(tmp_path / "t.fa")
+    synth.write_bam(bam, [("chrT", len(ref))], [pybam.flatten(records)], filter_fodder=False)
+    synth.write_fasta(fa, "chrT", np.frombuffer(ref, dtype=np.uint8))
+    return bam, fa
+
+
+def _fallback_equals_host_replay(cmd, fa, bam):
+    host = subprocess.run(cmd + ["--host-replay", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert host.returncode == 0 and b"on the host" in host.stderr, host.stderr.decode()[-2000:]
+    dflt = subprocess.run(cmd + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert dflt.returncode == 0, dflt.stderr.decode()[-2000:]
+    assert b"the run starts again with --host-replay" in dflt.stderr, dflt.stderr.decode()[-2000:]
+    assert len(host.stdout) > 1000 and dflt.stdout == host.stdout
+    canon = subprocess.run(cmd + ["--canonical-order", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert canon.returncode == 0 and sorted(canon.stdout.splitlines()) == sorted(host.stdout.splitlines())
+    return host.stdout, canon.stdout
+
+
+def test_cli_haplotype_tag_above_61_goes_to_the_host_replay(tmp_path):
+    """HP:C:62 -- a haplotype the device replay's 6-bit field does not hold: the run is handed to --host-replay (tieorder.c), not printed in the
+    canonical order with a warning."""
+    from oracle import pybam
+    rng = np.random.default_rng(7)
+    ref = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=6000).tobytes())
+    recs = []
+    for i in range(60):
+        pos = int(rng.integers(0, 3000))
+        seq = ref[pos:pos + 2000].decode()
+        cs = [j for j, ch in enumerate(seq) if ch == "C"]
+        skips = [cs[0]] and [0] * min(len(cs), 150)
+        mm = "C+m?" + "".join(",%d" % k for k in skips) + ";C+h?" + "".join(",%d" % k for k in skips) + ";"
+        ml = [int(x) for x in rng.integers(0, 256, size=2 * len(skips))]
+        recs.append(pybam.make_record(0, pos, 0, seq, "2000M", mm, ml, hp=[1, 2, 62, 63][i % 4], qname=b"r%d" % i))
+    recs.sort(key=lambda r: r.pos)
+    bam, fa = _tied_inputs(tmp_path, recs, ref)
+    host, canon = _fallback_equals_host_replay([BIN, "freq", "--haplotypes", "-c", "m[*],h[*]", "-m", "0.5,0.5", "-K", "16"], fa, bam)
+    assert host != canon   # (the two orders differ on this input: the test means something)
+
+
+def test_cli_read_with_300k_calls_goes_to_the_host_replay(tmp_path):
+    """A read with more than 2^18 calls (the device replay numbers a read's calls with 18 bits): handed to --host-replay."""
+    from oracle import pybam
+    n = 270000   # (two groups: of a multi-code group "C+mh" only the suffix "h" is a code the reference looks up, src/mod.c:1151)
+    ref = b"C" * (n + 64) + b"ACGT" * 16
+    mm = "C+m?" + ",0" * n + ";C+h?,5,7;"
+    rng = np.random.default_rng(11)
+    ml = [int(x) for x in rng.integers(0, 256, size=n + 2)]
+    recs = [pybam.make_record(0, 0, 0, "C" * n, "%dM" % n, mm, ml, qname=b"long"),
+            pybam.make_record(0, 10, 16, "G" * 50 + "ACGT", "54M", "C+mh?,0;", [200, 10], qname=b"short")]
+    bam, fa = _tied_inputs(tmp_path, recs, ref)
+    _fallback_equals_host_replay([BIN, "freq", "-c", "m[*],h[*]", "-m", "0.5,0.5"], fa, bam)
+
+
+def test_cli_refuses_what_neither_replay_takes_unless_the_canonical_order_is_asked_for(fastas):
+    """-K 2097152 and more with rows that can tie: neither replay numbers such a batch's reads -- the run refuses (exit 1) instead of printing another
+    order than the reference's; --canonical-order prints."""
+    bam = os.path.join(GOLDEN, "data", "example-ont.bam")
+    base = [BIN, "freq", "-c", "m[CG],h[CG]", "-K", "2097152"]
+    r = subprocess.run(base + [fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and r.stdout == b"" and b"--canonical-order" in r.stderr
+    c = subprocess.run(base + ["--canonical-order", fastas["chr22"], bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert c.returncode == 0 and len(c.stdout) > 1000

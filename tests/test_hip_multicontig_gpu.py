@@ -341,3 +341,25 @@ def test_cli_region_equals_the_full_run_restricted_to_the_region(cfg, genome, tm
     os.remove(bam + ".bai")
     noidx = subprocess.run(base + ["--region", "chr2", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert noidx.returncode == 1 and b"index" in noidx.stderr
+
+
+def test_cli_eight_workers_on_one_gpu_equal_a_single_run(genome, tmp_path):
+    """`--devices 0,0,0,0,0,0,0,0`: the eight workers of a node, all on the one GPU there is -- eight processes at once on a device (the condition
+    round 5's wrong site index needed), seven halo slabs through HIP IPC handles, eight device readers on one host.  The same bytes as one run, with
+    rows that tie in the reference's order as well."""
+    from minimod_amd import synth
+    bs = _batches(genome)
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    synth.write_bam(bam, list(zip(NAMES, LENS)), bs, index=True)
+    synth.write_fasta_multi(fa, [(n, g) for n, g in zip(NAMES, genome) if g is not None])
+    for order in (["--canonical-order"], []):
+        base = [BIN, "freq"] + order + ["-b", "-c", "m[CG],h[CG]", "-m", "0.8,0.7", "-K", "200", "-t", "8"]
+        one = subprocess.run(base + [fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert one.returncode == 0, one.stderr.decode()[-2000:]
+        for attempt in range(3):
+            many = subprocess.run(base + ["--devices", "0,0,0,0,0,0,0,0", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert many.returncode == 0, many.stderr.decode()[-3000:]
+            assert len(one.stdout) > 100000 and many.stdout == one.stdout
+            assert b"devices: 8" in many.stderr and b"failed its check" not in many.stderr
+            # every cut that falls inside a contig hands its slab over through a HIP IPC handle
+            assert many.stderr.count(b"through a HIP IPC handle") >= 3 and b"through host memory" not in many.stderr   # (a share without calls near its cut sends no slab), many.stderr.decode()[-1500:]
