@@ -63,7 +63,10 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_hip(force=False, verbose=False):
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}   # what the last build_hip() did (build() prints it: a record of whether anything was compiled)
+
+
+def build_hip(force=False, verbose=False, always=()):
     """hipcc cross-compiles for gfx950 without a GPU present.  Two translation units, compiled to objects of their own (the
     freq path takes 80 s, the BGZF inflate 6 s) and linked into the one library."""
     out = lib_path()
@@ -95,6 +98,7 @@ def build_hip(force=False, verbose=False):
     units = [("freq_api_k%d" % k, freq_srcs, ["-DMM_KIND=%d" % k] + freq_flags) for k in (0, 1, 2)] + \
             [("freq_dispatch", dispatch_srcs, []), ("devmem", [os.path.join(CSRC, "devmem.cpp"), devmem], []), ("bgzf_api", bgzf_srcs, ['-DMM_SOURCE_HASH="%s"' % full]), ("ingest_api", ingest_srcs, []), ("tie_api", tie_srcs + [os.path.join(CSRC, "fmt_api.hip.h"), os.path.join(CSRC, "fmt_core.h"), os.path.join(CSRC, "summary_api.hip.h"), os.path.join(INCLUDE, "minimod_summary.h")], [])]
     todo = []
+    LAST_BUILD["compiled"], LAST_BUILD["reused"], LAST_BUILD["linked"] = [], [], False
     for name, srcs, extra in units:
         obj = os.path.join(objdir, name + (".%s.o" % "_".join(defs).replace("-D", "").replace("=", "") if defs else ".o"))
         # an object is reused only when it was made from these very bytes and flags (their hash is kept beside it): time stamps say
@@ -102,9 +106,12 @@ def build_hip(force=False, verbose=False):
         want = _hash_files(srcs) + "+" + "+".join(extra + defs)
         side = obj + ".srchash"
         have = open(side).read().strip() if os.path.exists(side) and os.path.exists(obj) else None
-        if force or have != want:
+        if force or have != want or name in always:
             cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-I", INCLUDE, "-o", obj, srcs[0]] + extra + defs
             todo.append((cmd, side, want))
+            LAST_BUILD["compiled"].append(name)
+        else:
+            LAST_BUILD["reused"].append(name)
         objs.append(obj)
     # the three copies of the freq path take half a minute each: side by side
     procs = []
@@ -123,6 +130,7 @@ def build_hip(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        LAST_BUILD["linked"] = True
     return out
 
 
@@ -136,6 +144,6 @@ def build_host(force=False, verbose=False):
     return hostdir
 
 
-def build_all(force=False, verbose=False):
-    build_hip(force, verbose)
+def build_all(force=False, verbose=False, always=()):
+    build_hip(force, verbose, always)
     build_host(force, verbose)

@@ -664,3 +664,24 @@ def test_more_than_thirteen_contexts_are_refused():
     assert "different contexts" in str(e.value)
     with pytest.raises(Exception):
         hip_rows([_random_read(rng, ref, 0)], ref, _entries(MANY_CODES + ["2"], ["CG"]))   # 33 entries
+
+
+def test_haplotype_tags_beyond_the_dense_planes_are_counted():
+    """--haplotypes with tags the handle keeps no dense plane for (the default is 8 planes; a tag is a byte: `HP:C`, src/mod.c:181-202): 9 - 16, 62, 200
+    and 255 count through the side lists -- the same rows as the oracle, `*` aggregates included, in every stream mode and with --insertions."""
+    import minimod_amd
+    from minimod_amd import synth
+    ref = synth.reference(31, 2 << 20)
+    b = synth.batch(ref, 0, 600, seed=123, n_reads_total=600, haplotypes=True, long_insertions=True, max_len=20000.0)
+    tags = np.array(list(range(0, 17)) + [62, 200, 255], dtype=b["reads"]["hp"].dtype)
+    b["reads"]["hp"] = tags[np.arange(len(b["reads"])) % len(tags)]
+    for kw in (dict(haplotypes=True), dict(haplotypes=True, insertions=True)):
+        orc = O.Oracle([("m", "CG")], [0.8], ["chrS"], **kw); orc.add_contig("chrS", ref); orc.process(b, threads=8)
+        want = orc.rows()
+        key = lambda r, io: sorted(zip(r["pos"].tolist(), r["strand"].tolist(), r["code"].tolist(), r[io].tolist(), r["hp"].tolist(), r["n_called"].tolist(), r["n_mod"].tolist()))
+        assert len(want) > 5000 and {9, 16, 62, 200, 255} <= set(want["hp"].tolist())
+        for mode in (0, 1):
+            eng = minimod_amd.FreqEngine([("m", "CG", 0.8)], [("chrS", len(ref), ref)], stream_mode=mode, side_capacity=8 << 20, **kw)
+            eng.process(b)
+            got = eng.finalize(); eng.close()
+            assert key(got, "ins_offset") == key(want, "ins_off"), (kw, mode)
