@@ -37,6 +37,9 @@ def test_allocator_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "minimod_bgzf.h")).read()
     for name in ("mm_devmem_stats", "mm_devmem_trim"):
         assert name in hdr and hasattr(L, name), name
+    out = (ctypes.c_int64 * 7)(*([-1] * 7))
+    L.mm_devmem_stats(out)   # (bookkeeping only: no HIP call, so it answers without a GPU -- nothing held, nothing kept)
+    assert list(out) == [0] * 7
     for f in glob.glob(os.path.join(ROOT, "minimod_amd", "csrc", "*.hip*")):
         src = open(f).read()
         assert not re.search(r"\bhip(Malloc|Free|HostMalloc|HostFree)\(", src), "%s allocates behind the library's allocator" % os.path.basename(f)
