@@ -43,7 +43,7 @@ hipError_t take(Pool& pool, bool pinned, void** p, size_t bytes, unsigned int fl
     *p = nullptr;
     int device = 0;
     (void)hipGetDevice(&device);
-    const Key k{pinned ? -1 : device, flags, g_off ? (bytes ? bytes : 16) : size_class(bytes)};
+    const Key k{device, flags, g_off ? (bytes ? bytes : 16) : size_class(bytes)};   // (pinned blocks by device too: they were made with that device current)
     std::lock_guard<std::mutex> lk(pool.mu);
     auto it = pool.kept.find(k);
     if (it != pool.kept.end() && !it->second.empty()) {
@@ -67,8 +67,15 @@ hipError_t take(Pool& pool, bool pinned, void** p, size_t bytes, unsigned int fl
 }
 hipError_t put(Pool& pool, bool pinned, void* p) {
     if (!p) return hipSuccess;
-    // hipFree's and hipHostFree's meaning: nothing that is queued or running uses the block once this returns
+    int owner = -1;
+    { std::lock_guard<std::mutex> lk(pool.mu); auto it = pool.held.find(p); if (it != pool.held.end()) owner = it->second.device; }
+    // hipFree's and hipHostFree's meaning: nothing that is queued or running uses the block once this returns -- on the device the block
+    // was made for (a process with handles on two GPUs frees one's memory while the other is current)
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (owner >= 0 && owner != cur) (void)hipSetDevice(owner);
     const hipError_t se = hipDeviceSynchronize();
+    if (owner >= 0 && owner != cur) (void)hipSetDevice(cur);
     std::lock_guard<std::mutex> lk(pool.mu);
     auto it = pool.held.find(p);
     if (it == pool.held.end()) return pinned ? hipHostFree(p) : hipFree(p);   // (not one of ours)
