@@ -37,7 +37,8 @@ extern "C" {
 
 #define MM_ABI_VERSION 6
 #define MM_MAX_MODS 32    /* requested -c entries (ABI 6; 13 before: the reference has no limit of its own, src/minimod.h:114 counts them in a byte) */
-#define MM_MAX_CONTEXTS 13 /* DIFFERENT context strings among them: entries with one context share its two bits of the reference word (5 base bits + 2 x 13 in 32) */
+#define MM_MAX_CONTEXTS 13 /* DIFFERENT context strings a PASS of the reference words holds: entries with one context share its two bits (5 base bits + 2 x 13 in 32).  Not a limit
+                            * of the run since round 6: more contexts are built in further passes (mm_freq_create) and tested through their site words */
 #define MM_MAX_CODES 64   /* code strings known to the device (wildcard -c '*' interns what reads carry) */
 #define MM_CODE_LEN 16    /* bytes per code / context string incl. NUL */
 #define MM_MAX_HP_PLANES 8

@@ -918,7 +918,9 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             h->cls_of_mod[i] = c;
         }
         h->n_classes = (int)h->first_mod.size();
-        if (h->n_classes > MM_MAX_CONTEXTS) return fail(h, "more than 13 different contexts among the requested modifications (entries with the same context share its bits: their number is not limited by this)");
+        // (round 6: more than MM_MAX_CONTEXTS = 13 different contexts -- what a 32-bit reference word holds -- are built in passes of 13: the site index of a
+        // class comes from the pass that carries its bits, and the kernels that test a position's context in the reference word take classes 13 and up from
+        // the site word instead.  The reference has no limit of its own, src/mod.c:204-326)
     }
     h->ref_kind = h->n_classes > 5 ? 2 : (opts->n_mods == 1 && plain_context() ? 0 : 1);
 #ifdef MM_KIND
@@ -1124,33 +1126,38 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
     }
     tl_step("reference words' buffer + contig tables");
     const double tl_b = tl_now();
-    // K0 per contig through a staging buffer
-    {
+    // K0 per contig through a staging buffer.  A PASS carries the context bits of up to MM_MAX_CONTEXTS classes (pass q: classes 13 q ... 13 q + 12 in
+    // bits 5 ... 30); runs with more classes come back for the later passes while the site indices are built, and once more for pass 0, whose bits stay
+    auto build_ref_words = [&](int pass) -> bool {
         int64_t maxlen = 0;
         for (int t = 0; t < n_contigs; t++) if (h->ref_base[t] >= 0) maxlen = std::max(maxlen, h->ctg_len[t]);
         uint8_t* d_raw = nullptr;
-        if (maxlen > 0) {
-            if (mmdev::dmalloc((void**)&d_raw, (size_t)maxlen + 64) != hipSuccess) return fail(h, "staging alloc failed");   // (k_build_refnibs loads whole 16-byte pieces)
-            for (int t = 0; t < n_contigs; t++) {
-                if (h->ref_base[t] < 0 || h->ctg_len[t] == 0) continue;
-                int64_t len = h->ctg_len[t];
-                if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { (void)mmdev::dfree(d_raw); return fail(h, "reference upload failed"); }
-                int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
-                // (bits 5 + 2c / 6 + 2c: class c's context, described by the class's first entry)
-                if (h->ref_kind == 2) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                                         (uint32_t*)h->d_refw + h->ref_base[t], h->d_ctx_mods, h->n_classes);
-                else if (h->ref_kind == 1) hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
-                                                              (uint16_t*)h->d_refw + h->ref_base[t], h->d_ctx_mods, h->n_classes);
-                else if (std::strlen(opts->mods[0].context) <= 4)
-                    hipLaunchKernelGGL(k_build_refnibs<4>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
-                                       (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
-                else hipLaunchKernelGGL(k_build_refnibs<15>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
-                                        (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);
-                if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)mmdev::dfree(d_raw); return fail(h, "context kernel failed"); }
-            }
-            (void)mmdev::dfree(d_raw);
+        if (maxlen <= 0) return true;
+        if (mmdev::dmalloc((void**)&d_raw, (size_t)maxlen + 64) != hipSuccess) return false;   // (k_build_refnibs loads whole 16-byte pieces)
+        const DevMod* pass_mods = h->d_ctx_mods + (size_t)pass * MM_MAX_CONTEXTS;
+        const int pass_n = std::min(MM_MAX_CONTEXTS, h->n_classes - pass * MM_MAX_CONTEXTS);
+        bool ok = true;
+        for (int t = 0; t < n_contigs && ok; t++) {
+            if (h->ref_base[t] < 0 || h->ctg_len[t] == 0) continue;
+            int64_t len = h->ctg_len[t];
+            if (hipMemcpy(d_raw, contigs[t].seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { ok = false; break; }
+            int blocks = (int)std::min<int64_t>((len + 255) / 256, (int64_t)h->n_cu * 16);
+            // (bits 5 + 2c / 6 + 2c: class c's context, described by the class's first entry)
+            if (h->ref_kind == 2) hipLaunchKernelGGL(k_build_refwords<uint32_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                                     (uint32_t*)h->d_refw + h->ref_base[t], pass_mods, pass_n);
+            else if (h->ref_kind == 1) hipLaunchKernelGGL(k_build_refwords<uint16_t>, dim3(blocks), dim3(256), 0, h->stream, d_raw, len,
+                                                          (uint16_t*)h->d_refw + h->ref_base[t], pass_mods, pass_n);
+            else if (std::strlen(opts->mods[0].context) <= 4)
+                hipLaunchKernelGGL(k_build_refnibs<4>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
+                                   (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);   // (ref_base: a multiple of 64)
+            else hipLaunchKernelGGL(k_build_refnibs<15>, dim3((unsigned)std::min<int64_t>((len / 16 + 256) / 256, (int64_t)h->n_cu * 16)), dim3(256), 0, h->stream, d_raw, len,
+                                    (uint8_t*)h->d_refw + h->ref_base[t] / 2, h->d_mods);
+            ok = hipStreamSynchronize(h->stream) == hipSuccess;
         }
-    }
+        (void)mmdev::dfree(d_raw);
+        return ok;
+    };
+    if (!build_ref_words(0)) return fail(h, "reference upload or context kernel failed");
     const double tl_c = tl_now();
     // ---- context classes: mods with one context string share a class (their counters lie side by side per site); every position
     // is a site of a DENSE class: the context `*`, and any class under --insertions, where no context is looked at (mod.c:1167-1172)
@@ -1170,6 +1177,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
         h->adj.assign((size_t)std::max(n_contigs, 1) * h->n_classes * 2, 0);
         int64_t words = 0;
         for (int c = 0; c < h->n_classes; c++) {
+            if (c > 0 && c % MM_MAX_CONTEXTS == 0 && !build_ref_words(c / MM_MAX_CONTEXTS)) return fail(h, "reference upload or context kernel failed");   // the next thirteen classes' bits
             DevClass& k = h->classes[c];
             k.np = std::max(np[c], 1);
             k.dense = (opts->insertions || std::strcmp(opts->mods[first_mod[c]].context, "*") == 0) ? 1 : 0;
@@ -1205,7 +1213,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
                     const int blocks = (int)std::min<int64_t>((n_blocks + 255) / 256, (int64_t)h->n_cu * 16);
                     uint32_t bad[2] = {0, 0};
                     (void)hipMemsetAsync(d_bad, 0, 8, h->stream);
-                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, c, (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
+                    MM_REF_DISPATCH(h, hipLaunchKernelGGL(k_site_bits<RW>, dim3(blocks), dim3(256), 0, h->stream, h->d_refw, n_blocks, c % MM_MAX_CONTEXTS, (int)k.stride, site[0], site[1], cnt[0], cnt[1]));
                     for (int sd = 0; sd < 2; sd++) {
                         (void)hipMemsetAsync(tsum[sd] + n_tiles, 0, 4, h->stream);
                         hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, cnt[sd], n_blocks, tsum[sd]);
@@ -1255,6 +1263,7 @@ mm_freq_t* mm_freq_create(const mm_freq_opts_t* opts, int32_t n_contigs, const m
             }
             words += (int64_t)h->n_hp * 2 * k.nsites * k.np;
         }
+        if (h->n_classes > MM_MAX_CONTEXTS && !build_ref_words(0)) return fail(h, "reference upload or context kernel failed");   // (the words keep the first thirteen classes' bits)
         h->n_counter_words = opts->view ? 0 : words;   // view keeps no counters
         const size_t nadj = h->adj.size();
         if (dev_alloc(h, (void**)&h->d_classes, sizeof(DevClass) * (size_t)h->n_classes) || dev_alloc(h, (void**)&h->d_cls_of_mod, 4 * (size_t)opts->n_mods) ||

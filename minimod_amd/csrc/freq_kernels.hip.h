@@ -68,6 +68,7 @@ struct DevClass {
     int32_t pad;
 };
 __device__ __forceinline__ uint32_t site_rank(uint2 w, uint32_t bit) { return w.y + (uint32_t)__popc(w.x & ((1u << bit) - 1u)); }
+constexpr int kPassContexts = 13;   // == MM_MAX_CONTEXTS: context classes whose two bits a reference word holds (bits 5 ... 30)
 
 struct DevMod {
     uint8_t klass[256];
@@ -154,6 +155,16 @@ struct DevParams {
     unsigned int* ctl_next;
     unsigned int* queue_next;      // likewise: the 64 tile-queue + 64 scan-queue + 64 stream-queue counters (kQueueStride words apart) of the next launch
 };
+// Is position g of the reference-word space inside a match of context class `cls` on the read's strand?  The reference word's own bit for the thirteen
+// classes of the words' pass (kPassContexts), the class's site word for the classes behind them (round 6: a run may name more than thirteen different
+// contexts); every position of a dense class -- the context `*` -- is one.  (k_stream_reads asks the site word for every class.)
+__device__ __forceinline__ bool class_context_bit(const DevParams& p, uint32_t w, int cls, int rev, int64_t g) {
+    if (cls < kPassContexts) return (w >> (5 + 2 * cls + (rev ? 1 : 0))) & 1u;
+    const DevClass k = p.classes[cls];
+    if (k.dense) return true;
+    const uint2* site = rev ? k.site[1] : k.site[0];
+    return (site[(g >> 5) * k.stride].x >> ((uint32_t)g & 31u)) & 1u;
+}
 constexpr int kCtlWords = 80;    // words of a control set that are reset: [0..8) scalars, [8..72) tile counts
 constexpr int kCtlSetWords = 128;
 constexpr int kQueueStride = 32; // the 64 tile-queue counters lie 128 bytes apart (atomics on one line serialise)
@@ -882,7 +893,7 @@ struct K1 {
                 int req = dc.req;
                 const DevMod& dm = p.mods[req];
                 if (!p.insertions) {
-                    bool in_ctx = (w[u] >> (5 + 2 * p.cls_of_mod[req] + c.rev)) & 1u;   // (the bits are the context class's: entries with one context share them)
+                    const bool in_ctx = class_context_bit(p, w[u], p.cls_of_mod[req], c.rev, c.ref_base + ref_pos[u]);   // (the bits are the context class's: entries with one context share them; classes 13 and up: the site word)
                     bool matches = dm.ctx_is_star || c.mb_is_N || refcode == code[u];
                     if (!(in_ctx && matches)) continue;
                 }

@@ -759,7 +759,7 @@ struct KF {
     __device__ __forceinline__ void flush_pending() {
         if (pend != kNoPend) {
             // (the first code's slot is wave-uniform: the lane keeps one word, not an address and an increment)
-            const uint32_t slot = ((ci0 >> 23) & 127u) - 1u;
+            const uint32_t slot = ((ci0 >> 24) & 127u) - 1u;
             // (one code a class -- the usual run -- needs no 64-bit multiply for the counter's place: that instruction issues at a quarter of the rate)
             const uint64_t at = gnp == 1u ? (uint64_t)(pend >> 1) + slot : (uint64_t)(pend >> 1) * gnp + slot;
             atomicAdd(gcb + at, (pend & 1u) ? 0x100000001ull : 1ull);
@@ -979,7 +979,7 @@ struct KF {
                             else if (mv <= t_lo) is_mod = 0;
                             else continue;
                         }
-                        const int slot = (int)((cinfo >> 23) & 127u) - 1;
+                        const int slot = (int)((cinfo >> 24) & 127u) - 1;
                         const bool dense = gcb != nullptr && slot >= 0 && (uint32_t)ref_pos - seg_lo32 < seg_len32 && (!kIns || (ins_off == 0u && hpi >= 0));
                         if (dense) {
 #ifndef MM_ABL_NOATOMIC
@@ -1255,8 +1255,8 @@ struct KF {
                         gflags = (unwanted ? 64u : 0u) | (g.flag == '.' ? 4u : 0u) | ((uint32_t)g.n << 12);
                         c01 = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
                         c23 = (uint32_t)(uint16_t)a2 | ((uint32_t)(uint16_t)a3 << 16);
-                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | context class << 19 |
-                        // (slot of the code's counters among its context class's + 1, 0: no dense counters) << 23
+                        // what a call needs of its code's table entries: t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | context class << 19 (five bits) |
+                        // (slot of the code's counters among its context class's + 1, 0: no dense counters) << 24
                         const int cix = lane == 0u ? a0 : (lane == 1u ? a1 : (lane == 2u ? a2 : a3));
                         int kcls = -1;
                         if ((int)lane < g.n && lane < 4u && cix >= 0) {
@@ -1265,7 +1265,7 @@ struct KF {
                             const DevMod& dm = p.mods[req];
                             kcls = p.cls_of_mod[req];
                             ci_w = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)p.cls_of_mod[req] << 19) |
-                                   ((uint32_t)(plane >= 0 ? dc.slot + 1 : 0) << 23);
+                                   ((uint32_t)(plane >= 0 ? dc.slot + 1 : 0) << 24);
                         }
                         // the requested codes of a group share one context class here (one site word answers for all of them)
                         const uint64_t wl = __ballot(kcls >= 0);
@@ -1346,7 +1346,7 @@ struct KF {
                     gc01 = c01; gc23 = c23;
                     ci0 = uniu(S.g_ci[gi][0]); ci1 = uniu(S.g_ci[gi][1]); ci2 = uniu(S.g_ci[gi][2]); ci3 = uniu(S.g_ci[gi][3]);
                     // the counters of the group's context class for this read: its strand and haplotype plane, its contig's sites
-                    const int kc = (int)((gflags >> 16) & 15u);
+                    const int kc = (int)((gflags >> 16) & 31u);
                     const DevClass kd = scalar_load(p.classes + kc);
                     const int64_t adjv = scalar_load(p.adj + ((int64_t)tid * p.n_classes + kc) * 2 + rev);
                     gnp = (uint32_t)kd.np;
@@ -1382,7 +1382,7 @@ struct KF {
                     const uint32_t f2 = uniu(S.g_flags[gi + 1u]);
                     const uint32_t lstartB = uniu(S.g_lstart[gi + 1u]), endB = uniu(S.g_end[gi + 1u]);
                     if (!(f2 & (64u | 4u)) && ((f2 >> 12) & 7u) == 1u && endA > lstart && endA - lstart == endB - lstartB) {
-                        if (((f2 >> 16) & 15u) == ((gflags >> 16) & 15u)) tw = twin_lists(lstart, lstartB, endA - lstart);   // (one context class for both codes)
+                        if (((f2 >> 16) & 31u) == ((gflags >> 16) & 31u)) tw = twin_lists(lstart, lstartB, endA - lstart);   // (one context class for both codes)
                         if (tw) {
                             ncg = 2;
                             gc01 = (c01 & 0xFFFFu) | (uniu(S.g_c01[gi + 1u]) << 16);

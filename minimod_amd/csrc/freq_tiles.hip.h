@@ -1004,7 +1004,7 @@ struct KC {
     int32_t tid, pos, rev, hp, hpi, cls, direct, mb_is_N, ncg;
     int32_t gc0, gc1, gc2, gc3;
     // what a call needs of its code's table entries, fetched once per tile (wave-uniform; read per call they were
-    // three dependent global loads in every round): t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | context class << 19 | (plane + 1) << 23
+    // three dependent global loads in every round): t_hi | (t_lo + 1) << 9 | ctx_is_star << 18 | context class << 19 (five bits) | (plane + 1) << 24
     uint32_t ci0, ci1, ci2, ci3;
     uint32_t v_ridx, v_gord, v_region;   // view mode: read index, group ordinal, append region
     // LDS slices (wave-uniform): directory blocks [ds_lo, ds_lo+ds_cnt) answer ranks in [ds_rr_lo, ds_rr_hi);
@@ -1269,10 +1269,10 @@ struct KC {
                 int ci = gcode_at(m);
                 if (ci < 0) continue;
                 const uint32_t cinfo = cinfo_at(m);
-                const int cls_c = (int)((cinfo >> 19) & 15u), dc_plane = (int)((cinfo >> 23) & 127u) - 1;
+                const int cls_c = (int)((cinfo >> 19) & 31u), dc_plane = (int)((cinfo >> 24) & 127u) - 1;
                 const int t_hi = (int)(cinfo & 511u), t_lo = (int)((cinfo >> 9) & 511u) - 1;
                 if (!opt_insertions()) {
-                    bool in_ctx = (w[u] >> (5 + 2 * cls_c + rev)) & 1u;   // (the context class's bits)
+                    const bool in_ctx = class_context_bit(p, w[u], cls_c, rev, ref_base + ref_pos[u]);   // (the context class's bits; classes 13 and up: the site word)
                     bool matches = ((cinfo >> 18) & 1u) || mb_is_N || refcode == code[u];
                     if (!(in_ctx && matches)) continue;
                 }
@@ -1402,7 +1402,7 @@ struct KC {
                 const int req = dc.req, plane = dc.plane;
                 const DevMod& dm = p.mods[req];
                 info = (uint32_t)dm.t_hi | ((uint32_t)(dm.t_lo + 1) << 9) | (dm.ctx_is_star ? (1u << 18) : 0u) | ((uint32_t)P.d.cls_of_mod[req] << 19) |
-                       ((uint32_t)(plane + 1) << 23);
+                       ((uint32_t)(plane + 1) << 24);
             }
             ci0 = lane_valu(info, 0); ci1 = lane_valu(info, 1); ci2 = lane_valu(info, 2); ci3 = lane_valu(info, 3);
         }
