@@ -131,6 +131,7 @@ struct mm_freq {
     std::vector<int> plane_cls, plane_slot;   // per code plane
     DevClass* d_classes = nullptr; int32_t* d_cls_of_mod = nullptr; int64_t* d_adj = nullptr;
     std::vector<void*> d_site_arrays;
+    std::vector<void*> ipc_open;              // peers' slab buffers this handle has mapped (mm_freq_slab_add_ipc): closed when the handle goes
     unsigned int* d_slab_flag = nullptr;
     void* d_ipc_slab = nullptr;   // the slab another process reads through an IPC handle (mm_freq_slab_export_ipc): kept until the next one or the end
     DevMod* d_mods = nullptr;
@@ -807,6 +808,7 @@ void mm_freq_destroy(mm_freq_t* h) {
                   h->d_mods, h->d_codes, h->d_side, h->d_side_count, h->d_stats, h->d_tile_counts, h->d_tile_offsets, h->d_rows,
                   h->d_stab, h->d_scount, h->d_scur, h->d_base_k, h->d_base_v, h->d_sort_k[0], h->d_sort_k[1], h->d_sort_v[0], h->d_sort_v[1], h->d_sort_hist};
     for (void* p : ps) if (p) (void)mmdev::dfree(p);
+    for (void* p : h->ipc_open) if (p) (void)hipIpcCloseMemHandle(p);
     for (void* p : h->d_site_arrays) if (p) (void)mmdev::dfree(p);
     if (h->d_ctx_mods) (void)mmdev::dfree(h->d_ctx_mods);
     if (h->d_classes) (void)mmdev::dfree(h->d_classes);
@@ -1995,7 +1997,9 @@ int32_t mm_freq_slab_add_ipc(mm_freq_t* h, int32_t tid, int64_t begin, int64_t l
     // the copy on the handle's own (non-blocking) stream and waited for: the kernel that adds the slab runs on that stream, and the mapping
     // is closed -- and the sender told it may free the buffer -- only once the bytes are here (a D2D hipMemcpy on the null stream promises neither)
     if (!r && (hipMemcpyAsync(d, theirs, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)) r = -MM_E_HIP;
-    (void)hipIpcCloseMemHandle(theirs);
+    // (the peer's mapping stays open until the handle goes: closing it here would unmap an address range in the middle of the run, which a later
+    // allocation could be handed again -- what csrc/devmem.h is there to keep from happening; a worker of --devices ends a moment later anyway)
+    h->ipc_open.push_back(theirs);
     if (!r) r = slab_op(h, 1, tid, begin, len, d, nullptr);
     if (d) (void)mmdev::dfree(d);
     return r;

@@ -796,7 +796,8 @@ struct KF {
         if (n1 > 0u) {
             // rank -> four blocks: largest g with cw[g] <= rho (cw[0] = S_lo <= rho_0) -> the block among them by its members' counts
             const bool act = lane < n1;
-            const uint32_t g4 = act ? search_le_padded<kSegBlocks / 4>(S.cw, rho) : 0u;
+            const uint32_t dn4 = (d_n + 3u) >> 2;   // (entries of `cw` in use, the running total behind them: a read of 2 kb needs four steps, not seven)
+            const uint32_t g4 = !act ? 0u : (dn4 < 16u ? search_le_padded<16>(S.cw, rho) : (dn4 < 64u ? search_le_padded<64>(S.cw, rho) : search_le_padded<kSegBlocks / 4>(S.cw, rho)));
             const uint4 mb = *reinterpret_cast<const uint4*>(S.dm + 4u * g4);
             const uint32_t rg = rho - S.cw[g4];
             const uint32_t e1 = __popc(mb.x), e2 = e1 + __popc(mb.y), e3 = e2 + __popc(mb.z);
@@ -837,7 +838,9 @@ struct KF {
                 uint32_t qk, ck, a0, b0;
                 if (!wide) {
                     qk = qi - Q_lo;   // (the table's positions count from the segment's first op)
-                    ck = fin ? search_le_padded<kSegCk>(S.cq, qk) : 0u;
+                    // (as many steps as the table in use needs: a HiFi read's 40 ops are ten checkpoints -- four dependent LDS reads, not eight; the entries
+                    // behind the ones in use hold the bound up to the table's end, so any power of two that covers c_n will do)
+                    ck = !fin ? 0u : (c_n <= 16u ? search_le_padded<16>(S.cq, qk) : (c_n <= 64u ? search_le_padded<64>(S.cq, qk) : search_le_padded<kSegCk>(S.cq, qk)));
                     a0 = S.cq[ck]; b0 = R_lo + S.cr[ck];
                 } else {
                     qk = qi;
